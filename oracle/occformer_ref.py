@@ -1,0 +1,647 @@
+"""ORACLE (test infrastructure, never shipped, never measured as the product).
+
+A CPU fp32 restatement, in plain functional PyTorch, of the reference's OccFormer
+forward hot path.  Every function takes a flat state dict
+``sd`` that uses the REFERENCE's own parameter names plus a
+key prefix, so the product modules' ``state_dict()`` feeds it directly.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg
+may import this module.
+
+Pinning: the reference has no tests/golden vectors for this path, so
+this restatement is pinned against the reference's OWN Python, imported unmodified
+through ``tests/refshim`` and run on CPU in the build container
+(``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``; ``tests/test_oracle_vs_reference.py``
+re-checks live whenever /root/reference is present).  The third-party mmcv/mmdet
+semantics underneath the reference are themselves restated in the shim
+ -- that link is "parity unpinned" and is declared as such in
+DESIGN.md.
+
+Reference citations use P/ = projects/mmdet3d_plugin/, M/ = mmdetection3d/mmdet3d/.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ============================================================================ LSS / row 1-7
+def mlp_input_from_cameras(rots, trans, intrins, post_rots, post_trans, bda):
+    """P/occformer/image2bev/ViewTransformerLSSBEVDepth.py:591-646 (get_mlp_input)."""
+    B, N = rots.shape[:2]
+    bda_n = bda.view(B, 1, *bda.shape[-2:]).expand(B, N, *bda.shape[-2:])
+    cols = [intrins[..., 0, 0], intrins[..., 1, 1], intrins[..., 0, 2], intrins[..., 1, 2]]
+    if intrins.shape[-1] == 4:  # KITTI 3x4 projection padded to 4x4
+        cols += [intrins[..., 0, 3], intrins[..., 1, 3], intrins[..., 2, 3]]
+    cols += [post_rots[..., 0, 0], post_rots[..., 0, 1], post_trans[..., 0],
+             post_rots[..., 1, 0], post_rots[..., 1, 1], post_trans[..., 1],
+             bda_n[..., 0, 0], bda_n[..., 0, 1], bda_n[..., 1, 0], bda_n[..., 1, 1],
+             bda_n[..., 2, 2]]
+    feats = torch.stack(cols, -1)
+    if intrins.shape[-1] == 4 and bda.shape[-1] == 4:
+        feats = torch.cat((feats, bda_n[..., :3, 3]), -1)
+    sensor2ego = torch.cat((rots, trans.unsqueeze(-1)), -1).reshape(B, N, 12)
+    return torch.cat((feats, sensor2ego), -1)
+
+
+def make_frustum(input_size, downsample, dbound):
+    """ViewTransformerLSSBEVDepth.py:104-115 (create_frustum): [D, fH, fW, 3] = (u, v, d)."""
+    H, W = input_size
+    fH, fW = H // downsample, W // downsample
+    d = torch.arange(*dbound, dtype=torch.float32)
+    u = torch.linspace(0, W - 1, fW, dtype=torch.float32)
+    v = torch.linspace(0, H - 1, fH, dtype=torch.float32)
+    D = d.numel()
+    return torch.stack((u.view(1, 1, fW).expand(D, fH, fW),
+                        v.view(1, fH, 1).expand(D, fH, fW),
+                        d.view(D, 1, 1).expand(D, fH, fW)), -1)
+
+
+def grid_constants(xbound, ybound, zbound):
+    """ViewTransformerLSSBEVDepth.py:21-25 (gen_dx_bx): dx, bx (cell centres), nx (float)."""
+    rows = (xbound, ybound, zbound)
+    dx = torch.tensor([r[2] for r in rows], dtype=torch.float32)
+    bx = torch.tensor([r[0] + r[2] / 2.0 for r in rows], dtype=torch.float32)
+    nx = torch.tensor([(r[1] - r[0]) / r[2] for r in rows], dtype=torch.float32)
+    return dx, bx, nx
+
+
+def lss_geometry(frustum, rots, trans, intrins, post_rots, post_trans, bda):
+    """ViewTransformerLSSBEVDepth.py:117-150 (get_geometry), same operation order.
+    Returns ego-frame xyz [B, N, D, fH, fW, 3]."""
+    B, N = trans.shape[:2]
+    p = frustum - post_trans.view(B, N, 1, 1, 1, 3)
+    p = torch.inverse(post_rots).view(B, N, 1, 1, 1, 3, 3).matmul(p.unsqueeze(-1))
+    p = torch.cat((p[..., :2, :] * p[..., 2:3, :], p[..., 2:3, :]), -2)
+    if intrins.shape[-1] == 4:
+        p = p - intrins[:, :, :3, 3].view(B, N, 1, 1, 1, 3, 1)
+        intrins = intrins[:, :, :3, :3]
+    cam2ego = rots.matmul(torch.inverse(intrins))
+    p = cam2ego.view(B, N, 1, 1, 1, 3, 3).matmul(p).squeeze(-1)
+    p = p + trans.view(B, N, 1, 1, 1, 3)
+    if bda.shape[-1] == 4:
+        ph = torch.cat((p, torch.ones_like(p[..., :1])), -1)
+        p = bda.view(B, 1, 1, 1, 1, 4, 4).matmul(ph.unsqueeze(-1)).squeeze(-1)[..., :3]
+    else:
+        p = bda.view(B, 1, 1, 1, 1, 3, 3).matmul(p.unsqueeze(-1)).squeeze(-1)
+    return p
+
+
+def lss_voxel_coords(geom, dx, bx, nx):
+    """P/occformer/image2bev/ViewTransformerLSSVoxel.py:83-94.  Quantise with
+    TRUNCATION toward zero (``.long()``), so raw index in (-1, 0) maps to 0 and is kept.
+    Returns (coords int64 [Nprime, 4] = (x, y, z, b), kept bool [Nprime])."""
+    B = geom.shape[0]
+    nprime = geom[..., 0].numel()
+    idx = ((geom - (bx - dx / 2.0)) / dx).long().view(nprime, 3)
+    b = torch.arange(B).repeat_interleave(nprime // B).view(nprime, 1)
+    coords = torch.cat((idx, b), 1)
+    kept = ((coords[:, 0] >= 0) & (coords[:, 0] < nx[0]) & (coords[:, 1] >= 0) &
+            (coords[:, 1] < nx[1]) & (coords[:, 2] >= 0) & (coords[:, 2] < nx[2]))
+    return coords, kept
+
+
+def bev_pool_intervals(coords, B, Z, X, Y):
+    """M/ops/bev_pool/bev_pool.py:83-97 + :37-45.  rank = x*(Y*Z*B) + y*(Z*B) + z*B + b,
+    sort (we use a STABLE sort so the oracle is deterministic; the reference's argsort
+    leaves intra-voxel order undefined), then run starts/lengths.
+    Returns (order, geom int32 [n,4] sorted, starts int32 [m], lengths int32 [m])."""
+    ranks = (coords[:, 0] * (Y * Z * B) + coords[:, 1] * (Z * B) + coords[:, 2] * B + coords[:, 3])
+    order = torch.sort(ranks, stable=True)[1]
+    ranks = ranks[order]
+    geom = coords[order].int()
+    first = torch.ones(ranks.numel(), dtype=torch.bool)
+    first[1:] = ranks[1:] != ranks[:-1]
+    starts = torch.where(first)[0].int()
+    lengths = torch.empty_like(starts)
+    lengths[:-1] = starts[1:] - starts[:-1]
+    if starts.numel():
+        lengths[-1] = ranks.numel() - starts[-1]
+    return order, geom, starts, lengths
+
+
+def bev_pool_forward(x, geom, starts, lengths, B, Z, X, Y):
+    """M/ops/bev_pool/src/bev_pool_cuda.cu:20-42: out[b, z, x, y, :] = direct sum of the
+    interval's rows (sequential fp32 adds in row order).  Output [B, Z, X, Y, C]."""
+    n, C = x.shape
+    out = torch.zeros(B, Z, X, Y, C, dtype=x.dtype)
+    if starts.numel() == 0:
+        return out
+    seg = torch.repeat_interleave(torch.arange(starts.numel()), lengths.long())
+    pooled = torch.zeros(starts.numel(), C, dtype=x.dtype).index_add_(0, seg, x)
+    g = geom[starts.long()].long()
+    out[g[:, 3], g[:, 2], g[:, 0], g[:, 1]] = pooled
+    return out
+
+
+def bev_pool_backward(out_grad, geom, starts, lengths):
+    """bev_pool_cuda.cu:61-84: x_grad[row] = out_grad[voxel(row)] (broadcast)."""
+    seg = torch.repeat_interleave(torch.arange(starts.numel()), lengths.long())
+    g = geom[starts.long()].long()
+    return out_grad[g[:, 3], g[:, 2], g[:, 0], g[:, 1]][seg]
+
+
+def lift_splat(depth_prob, img_feat, geom, dx, bx, nx):
+    """ViewTransformerLSSVoxel.py:112-118 + :77-100 (lift, voxel_pooling, bev_pool, permutes).
+    depth_prob [B*N, D, fH, fW], img_feat [B*N, C, fH, fW], geom [B, N, D, fH, fW, 3]
+    -> voxel features [B, C, X, Y, Z]."""
+    B, N = geom.shape[:2]
+    BN, D, fH, fW = depth_prob.shape
+    C = img_feat.shape[1]
+    vol = depth_prob.unsqueeze(1) * img_feat.unsqueeze(2)            # [BN, C, D, fH, fW]
+    vol = vol.view(B, N, C, D, fH, fW).permute(0, 1, 3, 4, 5, 2).reshape(-1, C)
+    coords, kept = lss_voxel_coords(geom, dx, bx, nx)
+    X, Y, Z = (int(v) for v in nx)
+    order, g, starts, lengths = bev_pool_intervals(coords[kept], B, Z, X, Y)
+    out = bev_pool_forward(vol[kept][order], g, starts, lengths, B, Z, X, Y)   # [B,Z,X,Y,C]
+    return out.permute(0, 4, 2, 3, 1).contiguous()                    # [B,C,X,Y,Z]
+
+
+# ---------------------------------------------------------------------------- DepthNet (row 2)
+def _bn(sd, p, x, eps=1e-5):
+    return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"],
+                        sd[p + "bias"], False, 0.0, eps)
+
+
+def _conv2d(sd, p, x, **kw):
+    return F.conv2d(x, sd[p + "weight"], sd.get(p + "bias"), **kw)
+
+
+def _linear(sd, p, x):
+    return F.linear(x, sd[p + "weight"], sd.get(p + "bias"))
+
+
+def deform_conv2d(x, offset, weight, stride=1, padding=1, dilation=1, groups=1, deform_groups=1):
+    """mmcv-full 1.4.0 ``deform_conv2d`` (DCNv1; third-party, not under /root/reference;
+    call site ViewTransformerLSSBEVDepth.py:479-487).  Published algorithm: for output
+    pixel (ho, wo) and tap (ky, kx) sample the input bilinearly (zeros outside) at
+    (ho*s - pad + ky*dil + dy, wo*s - pad + kx*dil + dx); offset channel layout
+    [deform_group][tap][(dy, dx)]; then a grouped matmul with ``weight``; no bias."""
+    B, C, H, W = x.shape
+    Co, Cg, k, _ = weight.shape
+    Ho = (H + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+    base_y = (torch.arange(Ho, dtype=x.dtype) * stride - padding).view(1, Ho, 1)
+    base_x = (torch.arange(Wo, dtype=x.dtype) * stride - padding).view(1, 1, Wo)
+    off = offset.view(B, deform_groups, k * k, 2, Ho, Wo)
+    cpg = C // deform_groups
+    taps = []
+    for t in range(k * k):
+        ky, kx = divmod(t, k)
+        parts = []
+        for g in range(deform_groups):
+            py = base_y + ky * dilation + off[:, g, t, 0]
+            px = base_x + kx * dilation + off[:, g, t, 1]
+            y0, x0 = torch.floor(py), torch.floor(px)
+            wy1, wx1 = py - y0, px - x0
+            acc = 0
+            for (yy, wy) in ((y0, 1 - wy1), (y0 + 1, wy1)):
+                for (xx, wx) in ((x0, 1 - wx1), (x0 + 1, wx1)):
+                    ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+                    yi = yy.clamp(0, H - 1).long()
+                    xi = xx.clamp(0, W - 1).long()
+                    flat = (yi * W + xi).view(B, 1, Ho * Wo).expand(B, cpg, Ho * Wo)
+                    v = x[:, g * cpg:(g + 1) * cpg].reshape(B, cpg, H * W).gather(2, flat)
+                    acc = acc + v.view(B, cpg, Ho, Wo) * (wy * wx * ok).unsqueeze(1)
+            parts.append(acc)
+        taps.append(torch.cat(parts, 1))
+    col = torch.stack(taps, 2).view(B, groups, C // groups, k * k, Ho, Wo)
+    w = weight.view(groups, Co // groups, Cg, k * k)
+    return torch.einsum("bgckhw,gock->bgohw", col, w).reshape(B, Co, Ho, Wo)
+
+
+def _basic_block(sd, p, x):
+    """mmdet 2.14.0 ResNet BasicBlock (third-party): conv-bn-relu-conv-bn, +id, relu."""
+    y = F.relu(_bn(sd, p + "bn1.", _conv2d(sd, p + "conv1.", x, padding=1)))
+    y = _bn(sd, p + "bn2.", _conv2d(sd, p + "conv2.", y, padding=1))
+    return F.relu(y + x)
+
+
+def _aspp2d_bn(sd, p, x):
+    """ViewTransformerLSSBEVDepth.py:337-407 (ASPP inside DepthNet; BN, eval => dropout off)."""
+    outs = []
+    for i, dil in enumerate((1, 6, 12, 18), 1):
+        q = f"{p}aspp{i}."
+        y = _conv2d(sd, q + "atrous_conv.", x, padding=0 if i == 1 else dil, dilation=dil)
+        outs.append(F.relu(_bn(sd, q + "bn.", y)))
+    g = x.mean((2, 3), keepdim=True)
+    g = F.relu(_bn(sd, p + "global_avg_pool.2.", _conv2d(sd, p + "global_avg_pool.1.", g)))
+    outs.append(g.expand(-1, -1, *x.shape[2:]))
+    y = _conv2d(sd, p + "conv1.", torch.cat(outs, 1))
+    return F.relu(_bn(sd, p + "bn1.", y))
+
+
+def _se(sd, p, x, x_se):
+    """ViewTransformerLSSBEVDepth.py:432-446 (SELayer)."""
+    g = _conv2d(sd, p + "conv_expand.", F.relu(_conv2d(sd, p + "conv_reduce.", x_se)))
+    return x * torch.sigmoid(g)
+
+
+def _cam_mlp(sd, p, x):
+    return _linear(sd, p + "fc2.", F.relu(_linear(sd, p + "fc1.", x)))
+
+
+def depthnet(sd, p, x, mlp_input, dcn_groups=4):
+    """ViewTransformerLSSBEVDepth.py:450-504 (DepthNet.forward), eval-mode BN.
+    x [B*N, Cin, fH, fW] -> [B*N, D + C, fH, fW] (depth logits first, then context)."""
+    m = F.batch_norm(mlp_input.reshape(-1, mlp_input.shape[-1]), sd[p + "bn.running_mean"],
+                     sd[p + "bn.running_var"], sd[p + "bn.weight"], sd[p + "bn.bias"],
+                     False, 0.0, 1e-5)
+    x = F.relu(_bn(sd, p + "reduce_conv.1.", _conv2d(sd, p + "reduce_conv.0.", x, padding=1)))
+    ctx = _se(sd, p + "context_se.", x, _cam_mlp(sd, p + "context_mlp.", m)[..., None, None])
+    ctx = _conv2d(sd, p + "context_conv.", ctx)
+    d = _se(sd, p + "depth_se.", x, _cam_mlp(sd, p + "depth_mlp.", m)[..., None, None])
+    for i in range(3):
+        d = _basic_block(sd, f"{p}depth_conv.{i}.", d)
+    d = _aspp2d_bn(sd, p + "depth_conv.3.", d)
+    off = _conv2d(sd, p + "depth_conv.4.conv_offset.", d, padding=1)
+    d = deform_conv2d(d, off, sd[p + "depth_conv.4.weight"], 1, 1, 1, dcn_groups, 1)
+    d = _conv2d(sd, p + "depth_conv.5.", d)
+    return torch.cat((d, ctx), 1)
+
+
+def view_transformer(sd, p, img_feats, cams, D, C):
+    """ViewTransformerLSSVoxel.py:102-121 (forward).  ``cams`` = (rots, trans, intrins,
+    post_rots, post_trans, bda).  Uses the state dict's ``frustum/dx/bx/nx``.
+    Returns (voxel [B,C,X,Y,Z], depth_prob [B*N, D, fH, fW])."""
+    B, N, Cin, fH, fW = img_feats.shape
+    mlp_in = mlp_input_from_cameras(*cams)
+    y = depthnet(sd, p + "depth_net.", img_feats.reshape(B * N, Cin, fH, fW), mlp_in)
+    depth_prob = y[:, :D].softmax(1)
+    feat = y[:, D:D + C]
+    geom = lss_geometry(sd[p + "frustum"], *cams)
+    vox = lift_splat(depth_prob, feat, geom, sd[p + "dx"], sd[p + "bx"], sd[p + "nx"])
+    return vox, depth_prob
+
+
+# ============================================================================ encoder rows 8-11
+def rel_pos_index(ws=7):
+    """P/occformer/backbones/modules/window_attention.py:55-60: index[i, j] =
+    (2*ws-1)*(ri - rj + ws-1) + (ci - cj + ws-1)."""
+    t = torch.arange(ws * ws)
+    r, c = t // ws, t % ws
+    return (2 * ws - 1) * (r[:, None] - r[None, :] + ws - 1) + (c[:, None] - c[None, :] + ws - 1)
+
+
+def shift_window_mask(Hp, Wp, ws, shift):
+    """window_attention.py:187-208: region ids 0..8 on the padded, rolled map; pairs in
+    different regions get -100.  Returns [nW, ws*ws, ws*ws]."""
+    ids = torch.zeros(Hp, Wp)
+    cnt = 0
+    for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            ids[hs, wsl] = cnt
+            cnt += 1
+    win = ids.view(Hp // ws, ws, Wp // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+    diff = win[:, None, :] - win[:, :, None]
+    return torch.where(diff != 0, torch.full_like(diff, -100.0), torch.zeros_like(diff))
+
+
+def window_msa(sd, p, xw, heads, mask=None, ws=7):
+    """window_attention.py:69-107 (WindowMSA.forward).  xw [nWB, ws*ws, C]."""
+    nWB, T, C = xw.shape
+    hd = C // heads
+    qkv = _linear(sd, p + "qkv.", xw).view(nWB, T, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
+    attn = q @ k.transpose(-2, -1)
+    idx = sd.get(p + "relative_position_index", rel_pos_index(ws)).view(-1)
+    bias = sd[p + "relative_position_bias_table"][idx].view(T, T, heads).permute(2, 0, 1)
+    attn = attn + bias.unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        attn = attn.view(nWB // nW, nW, heads, T, T) + mask[None, :, None]
+        attn = attn.view(nWB, heads, T, T)
+    attn = attn.softmax(-1)
+    out = (attn @ v).transpose(1, 2).reshape(nWB, T, C)
+    return _linear(sd, p + "proj.", out)
+
+
+def shift_window_msa(sd, p, x, H, W, heads, shift, ws=7):
+    """window_attention.py:168-242 (ShiftWindowMSA.forward).  x [Bp, H*W, C] (already LN'd)."""
+    Bp, L, C = x.shape
+    x = x.view(Bp, H, W, C)
+    pr, pb = (ws - W % ws) % ws, (ws - H % ws) % ws
+    x = F.pad(x, (0, 0, 0, pr, 0, pb))
+    Hp, Wp = H + pb, W + pr
+    mask = None
+    if shift > 0:
+        x = torch.roll(x, (-shift, -shift), (1, 2))
+        mask = shift_window_mask(Hp, Wp, ws, shift)
+    xw = x.view(Bp, Hp // ws, ws, Wp // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+    yw = window_msa(sd, p + "w_msa.", xw, heads, mask, ws)
+    y = yw.view(Bp, Hp // ws, Wp // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(Bp, Hp, Wp, C)
+    if shift > 0:
+        y = torch.roll(y, (shift, shift), (1, 2))
+    return y[:, :H, :W].reshape(Bp, H * W, C)
+
+
+def swin_block(sd, p, x, heads, shift, ws=7):
+    """window_attention.py:346-372 (SwinBlock.forward), eval mode (DropPath = identity).
+    x [Bp, C, H, W] -> same."""
+    Bp, C, H, W = x.shape
+    t = x.permute(0, 2, 3, 1).reshape(Bp, H * W, C)
+    y = F.layer_norm(t, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5)
+    t = t + shift_window_msa(sd, p + "attn.", y, H, W, heads, ws // 2 if shift else 0, ws)
+    y = F.layer_norm(t, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)
+    y = _linear(sd, p + "ffn.layers.1.", F.gelu(_linear(sd, p + "ffn.layers.0.0.", y)))
+    t = t + y
+    return t.view(Bp, H, W, C).permute(0, 3, 1, 2).contiguous()
+
+
+def _gn(sd, p, x, groups):
+    return F.group_norm(x, groups, sd[p + "weight"], sd[p + "bias"], 1e-5)
+
+
+def bottleneck_aspp(sd, p, x, groups=32):
+    """P/occformer/backbones/modules/aspp.py:134-172 (BottleNeckASPP) with ASPP :107-122,
+    eval mode.  x [B, C, X, Y]."""
+    C = x.shape[1]
+    ch = C // 4
+    g_in = groups
+    g_aspp = ch // 2 if ch <= groups else groups
+    y = F.relu(_gn(sd, p + "input_conv.1.", _conv2d(sd, p + "input_conv.0.", x), g_in))
+    a = p + "aspp."
+    outs = []
+    for i, dil in enumerate((1, 6, 12, 18), 1):
+        q = f"{a}aspp{i}."
+        z = _conv2d(sd, q + "atrous_conv.", y, padding=0 if i == 1 else dil, dilation=dil)
+        outs.append(F.relu(_gn(sd, q + "bn.", z, g_aspp)))
+    g = y.mean((2, 3), keepdim=True)
+    g = F.relu(_gn(sd, a + "global_avg_pool.2.", _conv2d(sd, a + "global_avg_pool.1.", g), g_aspp))
+    outs.append(g.expand(-1, -1, *y.shape[2:]))
+    z = F.relu(_gn(sd, a + "bn1.", _conv2d(sd, a + "conv1.", torch.cat(outs, 1)), g_aspp))
+    y = y + z
+    y = F.relu(_gn(sd, p + "output_conv.1.", _conv2d(sd, p + "output_conv.0.", y), groups))
+    return x + y
+
+
+def dualpath_block(sd, p, x, stride, shift, groups=32):
+    """P/occformer/backbones/dualpath_block.py:65-82.  x [B, Cin, X, Y, Z]."""
+    ident = x
+    y = F.conv3d(x, sd[p + "input_conv.0.weight"], None, stride=stride, padding=1)
+    y = F.relu(_gn(sd, p + "input_conv.1.", y, groups))
+    B, C, X, Y, Z = y.shape
+    heads = C // 32
+    bev = y.mean(-1)
+    slices = y.permute(0, 4, 1, 2, 3).reshape(B * Z, C, X, Y)
+    out = swin_block(sd, p + "bev_encoder.", torch.cat((bev, slices), 0), heads, shift)
+    bev, slices = out[:B], out[B:]
+    y = slices.view(B, Z, C, X, Y).permute(0, 2, 3, 4, 1)
+    bev = bottleneck_aspp(sd, p + "aspp.", bev, groups)
+    coeff = torch.sigmoid(F.conv3d(y, sd[p + "combine_coeff.weight"], sd.get(p + "combine_coeff.bias")))
+    y = y + coeff * bev.unsqueeze(-1)
+    if stride > 1:
+        ident = F.conv3d(ident, sd[p + "downsample.0.weight"], None, stride=stride)
+        ident = _gn(sd, p + "downsample.1.", ident, groups)
+    return y + ident
+
+
+def occupancy_encoder(sd, p, x, block_numbers=(2, 2, 2, 2), block_strides=(1, 2, 2, 2),
+                      out_indices=(0, 1, 2, 3), groups=32):
+    """P/occformer/backbones/occnet.py:49-75: layer_index counts blocks globally; odd => shifted."""
+    outs, li = [], 0
+    for s, (nb, st) in enumerate(zip(block_numbers, block_strides)):
+        for b in range(nb):
+            x = dualpath_block(sd, f"{p}layers.{s}.{b}.", x, st if b == 0 else 1, li % 2 == 1, groups)
+            li += 1
+        if s in out_indices:
+            outs.append(x)
+    return outs
+
+
+# ============================================================================ pixel decoder rows 12-14
+def sine_pos_enc_3d(shape, num_feats, temperature=10000, scale=2 * math.pi, eps=1e-6):
+    """P/occformer/mask2former/positional_encodings/positional_encoding.py:58-108 with an
+    all-valid mask, normalize=True, offset=0.  shape=(X, Y, Z) -> [3*num_feats, X, Y, Z]."""
+    X, Y, Z = shape
+    emb = []
+    for n, ax in ((X, 0), (Y, 1), (Z, 2)):
+        e = torch.arange(1, n + 1, dtype=torch.float32)
+        e = e / (e[-1] + eps) * scale
+        emb.append(e)
+    dim_t = torch.arange(num_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_feats)
+    parts = []
+    for e, ax in zip(emb, (0, 1, 2)):
+        pos = e[:, None] / dim_t                                   # [n, F]
+        pos = torch.stack((pos[:, 0::2].sin(), pos[:, 1::2].cos()), 2).flatten(1)
+        view = [1, 1, 1, num_feats]
+        view[ax] = -1
+        parts.append(pos.view(*view).expand(X, Y, Z, num_feats))
+    return torch.cat(parts, 3).permute(3, 0, 1, 2).contiguous()
+
+
+def reference_points_3d(shape):
+    """P/utils/point_generator.py:111-137 + multiscale_deformattn_3d.py:167-172: normalised
+    cell centres in (z, y, x) order, [X*Y*Z, 3]; the stride cancels."""
+    X, Y, Z = shape
+    x = (torch.arange(X, dtype=torch.float32) + 0.5) / X
+    y = (torch.arange(Y, dtype=torch.float32) + 0.5) / Y
+    z = (torch.arange(Z, dtype=torch.float32) + 0.5) / Z
+    xx, yy, zz = torch.meshgrid(x, y, z, indexing="ij")
+    return torch.stack((zz, yy, xx), -1).reshape(-1, 3)
+
+
+def msda3d_core(value, shapes, loc, attw):
+    """P/occformer/necks/multi_scale_deform_attn_3d.py:17-80.  value [B, Nv, H, Dh];
+    shapes list of (X, Y, Z); loc [B, Nq, H, L, P, 3] in [0,1] with last dim (z, y, x);
+    attw [B, Nq, H, L, P].  Trilinear, zeros padding, align_corners=False."""
+    B, Nv, H, Dh = value.shape
+    Nq, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
+    out = 0
+    start = 0
+    for l, (X, Y, Z) in enumerate(shapes):
+        n = X * Y * Z
+        v = value[:, start:start + n].permute(0, 2, 3, 1).reshape(B * H, Dh, X, Y, Z)
+        start += n
+        grid = (2 * loc[:, :, :, l] - 1).transpose(1, 2).reshape(B * H, 1, Nq, P, 3)
+        s = F.grid_sample(v, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+        s = s.view(B, H, Dh, Nq, P)
+        w = attw[:, :, :, l].permute(0, 2, 1, 3).unsqueeze(2)       # [B,H,1,Nq,P]
+        out = out + (s * w).sum(-1)
+    return out.permute(0, 3, 1, 2).reshape(B, Nq, H * Dh)
+
+
+def msda3d_layer(sd, p, q, pos, ref, shapes, heads=8, points=4):
+    """multi_scale_deform_attn_3d.py:185-286 (batch-first here).  q/pos [B, Nq, E];
+    ref [B, Nq, L, 3]."""
+    B, Nq, E = q.shape
+    L = len(shapes)
+    qp = q + pos
+    value = _linear(sd, p + "value_proj.", q).view(B, Nq, heads, E // heads)
+    off = _linear(sd, p + "sampling_offsets.", qp).view(B, Nq, heads, L, points, 3)
+    w = _linear(sd, p + "attention_weights.", qp).view(B, Nq, heads, L * points).softmax(-1)
+    w = w.view(B, Nq, heads, L, points)
+    norm = torch.tensor([[s[2], s[1], s[0]] for s in shapes], dtype=torch.float32)
+    loc = ref[:, :, None, :, None, :] + off / norm[None, None, None, :, None, :]
+    out = msda3d_core(value, shapes, loc, w)
+    return _linear(sd, p + "output_proj.", out) + q
+
+
+def pixel_decoder(sd, p, feats, num_layers=6, heads=8, points=4, groups=32, num_enc_levels=3):
+    """P/occformer/necks/multiscale_deformattn_3d.py:145-249.  feats: list of 4
+    [B, C_i, X_i, Y_i, Z_i] fine->coarse.  Returns [mask_feature, lvl1, lvl2, lvl3]."""
+    B = feats[0].shape[0]
+    nlv = len(feats)
+    E = sd[p + "level_encoding.weight"].shape[1]
+    toks, poss, refs, shapes = [], [], [], []
+    for i in range(num_enc_levels):
+        f = feats[nlv - 1 - i]
+        q = f"{p}input_convs.{i}."
+        y = _gn(sd, q + "gn.", F.conv3d(f, sd[q + "conv.weight"], sd[q + "conv.bias"]), groups)
+        shp = tuple(f.shape[-3:])
+        pe = sine_pos_enc_3d(shp, E // 3) + sd[p + "level_encoding.weight"][i].view(-1, 1, 1, 1)
+        toks.append(y.flatten(2).transpose(1, 2))
+        poss.append(pe.flatten(1).t().unsqueeze(0).expand(B, -1, -1))
+        refs.append(reference_points_3d(shp))
+        shapes.append(shp)
+    x = torch.cat(toks, 1)
+    pos = torch.cat(poss, 1)
+    ref = torch.cat(refs, 0)[None, :, None, :].expand(B, -1, num_enc_levels, -1)
+    for l in range(num_layers):
+        q = f"{p}encoder.layers.{l}."
+        x = msda3d_layer(sd, q + "attentions.0.", x, pos, ref, shapes, heads, points)
+        x = F.layer_norm(x, (E,), sd[q + "norms.0.weight"], sd[q + "norms.0.bias"], 1e-5)
+        y = _linear(sd, q + "ffns.0.layers.1.", F.relu(_linear(sd, q + "ffns.0.layers.0.0.", x)))
+        x = F.layer_norm(x + y, (E,), sd[q + "norms.1.weight"], sd[q + "norms.1.bias"], 1e-5)
+    outs, start = [], 0
+    for shp in shapes:
+        n = shp[0] * shp[1] * shp[2]
+        outs.append(x[:, start:start + n].transpose(1, 2).reshape(B, E, *shp))
+        start += n
+    for j, i in enumerate(range(nlv - num_enc_levels - 1, -1, -1)):
+        q = f"{p}lateral_convs.{j}."
+        cur = _gn(sd, q + "gn.", F.conv3d(feats[i], sd[q + "conv.weight"], sd.get(q + "conv.bias")), groups)
+        y = cur + F.interpolate(outs[-1], size=cur.shape[-3:], mode="trilinear", align_corners=False)
+        q = f"{p}output_convs.{j}."
+        y = F.conv3d(y, sd[q + "conv.weight"], sd.get(q + "conv.bias"), padding=1)
+        outs.append(F.relu(_gn(sd, q + "gn.", y, groups)))
+    outs[-1] = F.conv3d(outs[-1], sd[p + "mask_feature.weight"], sd[p + "mask_feature.bias"])
+    return outs[::-1]
+
+
+# ============================================================================ head rows 15-17
+def _mha(sd, p, q, k, v, heads, mask=None):
+    """torch.nn.MultiheadAttention forward (batch-first tensors [B, L, E] here); bool mask
+    [B, heads, Q, L] True = blocked."""
+    E = q.shape[-1]
+    w, b = sd[p + "in_proj_weight"], sd[p + "in_proj_bias"]
+    hd = E // heads
+    qh = F.linear(q, w[:E], b[:E]).view(*q.shape[:2], heads, hd).transpose(1, 2)
+    kh = F.linear(k, w[E:2 * E], b[E:2 * E]).view(*k.shape[:2], heads, hd).transpose(1, 2)
+    vh = F.linear(v, w[2 * E:], b[2 * E:]).view(*v.shape[:2], heads, hd).transpose(1, 2)
+    att = (qh * hd ** -0.5) @ kh.transpose(-2, -1)
+    if mask is not None:
+        att = att.masked_fill(mask, float("-inf"))
+    att = att.softmax(-1)
+    out = (att @ vh).transpose(1, 2).reshape(*q.shape[:2], E)
+    return F.linear(out, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
+
+
+def head_predict(sd, p, dec, mask_feat, target_shape, heads, pooling=True):
+    """P/occformer/mask2former/mask2former_nusc_occ.py:426-471 (forward_head).
+    dec [B, Q, E]; mask_feat [B, E, X, Y, Z].  Returns cls [B,Q,K+1], mask_pred
+    [B,Q,X,Y,Z], pooled logits [B,Q,L] and bool attn mask [B, Q, L] (True = blocked;
+    identical for every head)."""
+    E = dec.shape[-1]
+    d = F.layer_norm(dec, (E,), sd[p + "transformer_decoder.post_norm.weight"],
+                     sd[p + "transformer_decoder.post_norm.bias"], 1e-5)
+    cls = _linear(sd, p + "cls_embed.", d)
+    m = _linear(sd, p + "mask_embed.4.", F.relu(_linear(sd, p + "mask_embed.2.", F.relu(
+        _linear(sd, p + "mask_embed.0.", d)))))
+    mask_pred = torch.einsum("bqc,bcxyz->bqxyz", m, mask_feat)
+    if pooling:
+        pooled = F.adaptive_max_pool3d(mask_pred, target_shape)
+    else:
+        pooled = F.interpolate(mask_pred, target_shape, mode="trilinear", align_corners=True)
+    pooled = pooled.flatten(2)
+    return cls, mask_pred, pooled, pooled.sigmoid() < 0.5
+
+
+def mask2former_head(sd, p, feats, heads=6, num_layers=9, num_levels=3, pooling=True,
+                     return_intermediates=False):
+    """mask2former_nusc_occ.py:589-689 (forward).  feats = pixel decoder output
+    [mask_feature, lvl1, lvl2, lvl3]; memories are consumed coarse->fine."""
+    mask_feat = feats[0]
+    mem = feats[:0:-1]
+    B, E = mask_feat.shape[:2]
+    keys, kpos = [], []
+    for i in range(num_levels):
+        t = mem[i].flatten(2).transpose(1, 2) + sd[p + "level_embed.weight"][i].view(1, 1, -1)
+        pe = sine_pos_enc_3d(tuple(mem[i].shape[-3:]), E // 3).flatten(1).t()
+        keys.append(t)
+        kpos.append(pe.unsqueeze(0).expand(B, -1, -1))
+    q = sd[p + "query_feat.weight"].unsqueeze(0).expand(B, -1, -1)
+    qpos = sd[p + "query_embed.weight"].unsqueeze(0).expand(B, -1, -1)
+    cls_list, mask_list, inter = [], [], []
+    cls, mp, pooled, blocked = head_predict(sd, p, q, mask_feat, mem[0].shape[-3:], heads, pooling)
+    cls_list.append(cls)
+    mask_list.append(mp)
+    for i in range(num_layers):
+        lv = i % num_levels
+        blocked = blocked & ~blocked.all(-1, keepdim=True)         # :652-653 all-masked-row fix
+        lp = f"{p}transformer_decoder.layers.{i}."
+        a = _mha(sd, lp + "attentions.0.attn.", q + qpos, keys[lv] + kpos[lv], keys[lv], heads,
+                 blocked.unsqueeze(1))
+        q = F.layer_norm(q + a, (E,), sd[lp + "norms.0.weight"], sd[lp + "norms.0.bias"], 1e-5)
+        a = _mha(sd, lp + "attentions.1.attn.", q + qpos, q + qpos, q, heads)
+        q = F.layer_norm(q + a, (E,), sd[lp + "norms.1.weight"], sd[lp + "norms.1.bias"], 1e-5)
+        y = _linear(sd, lp + "ffns.0.layers.1.", F.relu(_linear(sd, lp + "ffns.0.layers.0.0.", q)))
+        q = F.layer_norm(q + y, (E,), sd[lp + "norms.2.weight"], sd[lp + "norms.2.bias"], 1e-5)
+        inter.append((pooled, blocked))
+        cls, mp, pooled, blocked = head_predict(
+            sd, p, q, mask_feat, mem[(i + 1) % num_levels].shape[-3:], heads, pooling)
+        cls_list.append(cls)
+        mask_list.append(mp)
+    if return_intermediates:
+        return cls_list, mask_list, inter
+    return cls_list, mask_list
+
+
+def format_results(cls, mask_pred):
+    """mask2former_nusc_occ.py:691-696."""
+    return torch.einsum("bqc,bqxyz->bcxyz", cls.softmax(-1)[..., :-1], mask_pred.sigmoid())
+
+
+def lidarseg_points(cls, mask_pred, points, pc_range, padding_mode="border"):
+    """mask2former_nusc_occ.py:505-542 (eval branch).  points: list of [P_i, >=3] ego xyz."""
+    lo = torch.tensor(pc_range[:3], dtype=torch.float32)
+    ext = torch.tensor(pc_range[3:], dtype=torch.float32) - lo
+    vox = format_results(cls, mask_pred)
+    outs = []
+    for b, pts in enumerate(points):
+        g = ((pts[:, :3].float() - lo) / ext * 2 - 1)[:, [2, 1, 0]].view(1, 1, 1, -1, 3)
+        s = F.grid_sample(vox[b:b + 1], g, mode="bilinear", padding_mode=padding_mode,
+                          align_corners=True)
+        outs.append(s.view(vox.shape[1], -1).t())
+    return torch.cat(outs, 0).softmax(1)
+
+
+def head_simple_test(sd, p, feats, occ_size, points=None, pc_range=None, **kw):
+    """mask2former_nusc_occ.py:698-745."""
+    cls_list, mask_list = mask2former_head(sd, p, feats, **kw)
+    cls, mp = cls_list[-1], mask_list[-1]
+    up = F.interpolate(mp, size=tuple(occ_size), mode="trilinear", align_corners=True)
+    res = {"output_voxels": format_results(cls, up), "output_points": None}
+    if points is not None:
+        res["output_points"] = lidarseg_points(cls, mp, points, pc_range)
+    return res
+
+
+# ============================================================================ whole path
+def occformer_forward(sd, img_feats, cams, cfg, points=None):
+    """occupancyformer.py:59-91 + :201-237 minus the 2-D image backbone: view transformer ->
+    encoder -> pixel decoder -> head.simple_test.  ``cfg`` keys: D, C, occ_size, pc_range,
+    groups."""
+    g = cfg.get("groups", 32)
+    vox, depth = view_transformer(sd, "img_view_transformer.", img_feats, cams, cfg["D"], cfg["C"])
+    enc = occupancy_encoder(sd, "img_bev_encoder_backbone.", vox, groups=g,
+                            block_numbers=cfg.get("block_numbers", (2, 2, 2, 2)),
+                            block_strides=cfg.get("block_strides", (1, 2, 2, 2)))
+    dec = pixel_decoder(sd, "img_bev_encoder_neck.", enc, groups=g,
+                        num_layers=cfg.get("pd_layers", 6))
+    res = head_simple_test(sd, "pts_bbox_head.", dec, cfg["occ_size"], points, cfg["pc_range"],
+                           heads=cfg.get("heads", 6), num_layers=cfg.get("dec_layers", 9))
+    res["voxel_feat"] = vox
+    res["depth"] = depth
+    return res
