@@ -1,0 +1,124 @@
+/* occformer_hip.h -- C ABI of liboccformer_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the OccFormer forward hot path.  Every entry point takes plain
+ * device pointers + sizes + a hipStream_t (as void*), launches asynchronously on that
+ * stream and returns 0 on success, a positive hipError_t, or a negative OCCF_E* code for
+ * bad arguments.  No torch types cross this boundary.
+ *
+ * Citations are into the reference tree (zhangyp15/OccFormer):
+ *   M/ = mmdetection3d/mmdet3d/      P/ = projects/mmdet3d_plugin/
+ */
+#ifndef OCCFORMER_HIP_H
+#define OCCFORMER_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ view transform ---- */
+
+/* Replaces bev_pool_ext.bev_pool_forward  (M/ops/bev_pool/src/bev_pool.cpp:22-57,
+ * kernel bev_pool_cuda.cu:20-42).  x[n,c] f32 sorted by voxel rank, geom[n,4] i32 =
+ * (x,y,z,b), interval starts/lengths [m] i32.  out[b,d,h,w,c] is zero-filled by the
+ * callee (as the reference does) and out[b, z, x, y, :] = in-order fp32 sum of the
+ * interval's rows -- bit-identical to the reference kernel.  Unlike the reference it
+ * honours `stream` (the reference launches on the default stream, bev_pool_cuda.cu:88). */
+int occf_bev_pool_fwd(const float* x, const int32_t* geom, const int32_t* interval_starts,
+                      const int32_t* interval_lengths, float* out, int b, int d, int h, int w,
+                      int n, int c, int n_intervals, void* stream);
+
+/* Replaces bev_pool_ext.bev_pool_backward (bev_pool.cpp:60-87, bev_pool_cuda.cu:61-84):
+ * x_grad[row,:] = out_grad[voxel(row),:]. */
+int occf_bev_pool_bwd(const float* out_grad, const int32_t* geom, const int32_t* interval_starts,
+                      const int32_t* interval_lengths, float* x_grad, int b, int d, int h, int w,
+                      int n, int c, int n_intervals, void* stream);
+
+/* Replaces get_geometry + the quantise/range-mask half of voxel_pooling
+ * (P/occformer/image2bev/ViewTransformerLSSBEVDepth.py:117-150,
+ *  P/occformer/image2bev/ViewTransformerLSSVoxel.py:83-94).
+ * frustum[DHW,3]; cam[B*N,27] = inv(post_rots)[9] post_trans[3] (rots@inv(K))[9] trans[3]
+ * K[:3,3][3]; bda[B,12] (3x4, row-major); grid[9] = lo[3] dx[3] nx[3];
+ * vox[B*N*DHW] <- channels-last voxel row ((b*X+x)*Y+y)*Z+z, or -1 when outside. */
+int occf_lss_voxel_index(const float* frustum, const float* cam, const float* bda,
+                         const float* grid, int32_t* vox, int B, int N, int DHW, int X, int Y,
+                         int Z, int bda4, void* stream);
+
+/* Fused lift + splat: subsumes the volume materialisation, the two boolean-mask gathers,
+ * bev_pool and the permutes of ViewTransformerLSSVoxel.py:112-118,77-100.
+ * depth[BN,D,HW] (softmaxed), feat[BN,HW,C] channels-last, CSR over all n_vox voxels
+ * (offsets[n_vox+1], sorted_pts = original point indices, ascending inside a voxel).
+ * out[n_vox, C] = channels-last [B,X,Y,Z,C]; every row written exactly once. */
+int occf_lift_splat_fwd(const float* depth, const float* feat, const int32_t* offsets,
+                        const int32_t* sorted_pts, float* out, long n_vox, int BN, int D, int HW,
+                        int C, void* stream);
+
+/* Backward of the fused op (QuickCumsumCuda.backward + the lift's autograd,
+ * M/ops/bev_pool/bev_pool.py:63-80).  vox[n_pts] as produced by occf_lss_voxel_index. */
+int occf_lift_splat_bwd(const float* out_grad, const float* depth, const float* feat,
+                        const int32_t* vox, float* d_depth, float* d_feat, long n_pts, int BN,
+                        int D, int HW, int C, void* stream);
+
+/* ------------------------------------------------------------------ dual-path encoder -- */
+
+/* Windowed MSA core of the shared SwinBlock: replaces F.pad + torch.roll + window_partition +
+ * WindowMSA's (q@k^T + rel-pos bias + shift mask -> softmax -> @v) + window_reverse + un-roll +
+ * crop  (P/occformer/backbones/modules/window_attention.py:69-107,168-242).
+ * qkv[n_tok, 3C] = fused qkv projection of the layer-normed tokens, token order
+ * ((b*X + x)*Y + y)*S + s (S slices per batch: Z height slices + the BEV mean slice);
+ * qkv_bias[3C] (value of padded tokens); bias_table[(2*7-1)^2, heads];
+ * out[n_tok, C] = attention output before `proj`.  head_dim is 32 (dualpath_block.py:31-32),
+ * window 7, shift in {0, 3}. */
+int occf_window_attn_fwd(const float* qkv, const float* qkv_bias, const float* bias_table,
+                         float* out, int B, int X, int Y, int S, int C, int heads, int shift,
+                         void* stream);
+
+/* ------------------------------------------------------------------ pixel decoder ------ */
+
+/* Sampling core of MultiScaleDeformableAttention3D: replaces the location arithmetic, the
+ * softmax over levels*points and multi_scale_deformable_attn_pytorch
+ * (P/occformer/necks/multi_scale_deform_attn_3d.py:246-273, 17-80).
+ * value[B, Nq, heads*head_dim] (projected), sampling_offsets[B, Nq, heads, L, P, 3] raw linear
+ * output (last dim ordered z, y, x), attn_logits[B, Nq, heads, L*P] raw, out[B, Nq, heads*head_dim]
+ * (before output_proj).  level_shapes is a HOST array [L][3] = (X, Y, Z) per level, coarse->fine
+ * as the decoder concatenates them; the queries are the level cells themselves (Nq = sum XYZ). */
+int occf_msda3d_fwd(const float* value, const float* sampling_offsets, const float* attn_logits,
+                    float* out, const int32_t* level_shapes, int num_levels, int B, int Nq,
+                    int heads, int head_dim, int num_points, void* stream);
+
+/* ------------------------------------------------------------------ occupancy decoder -- */
+
+/* Preserve-pooling: F.adaptive_max_pool3d(mask_pred, (ox,oy,oz)) -> sigmoid < 0.5
+ * (P/occformer/mask2former/mask2former_nusc_occ.py:457-466).  mask_pred[BQ, X, Y, Z];
+ * pooled[BQ, L] logits, blocked[BQ, L] bytes (1 = masked out), row_open[BQ] (1 when any key of
+ * the row is open; zeroed by the callee). */
+int occf_mask_pool_fwd(const float* mask_pred, float* pooled, uint8_t* blocked, int32_t* row_open,
+                       long BQ, int X, int Y, int Z, int ox, int oy, int oz, void* stream);
+
+/* Masked multi-head cross-attention core (scaled dot product + boolean mask + softmax + @V) of
+ * the decoder layers, incl. the all-masked-row fix (mask2former_nusc_occ.py:652-667; mmcv
+ * MultiheadAttention -> torch.nn.MultiheadAttention).  q[B, Q, E], k/v[B, L, E] already
+ * projected; blocked may be NULL (plain attention); out[B, Q, E] before out_proj; head_dim 32.
+ * workspace: occf_masked_xattn_workspace(...) floats of scratch. */
+int occf_masked_xattn_fwd(const float* q, const float* k, const float* v, const uint8_t* blocked,
+                          const int32_t* row_open, float* out, float* workspace,
+                          long workspace_floats, int B, int Q, int L, int E, int heads,
+                          void* stream);
+long occf_masked_xattn_workspace(int B, int Q, int L, int heads);
+
+/* simple_test's tail fused: F.interpolate(mask_pred, occ_size, trilinear, align_corners=True) ->
+ * sigmoid -> einsum('bqc,bqxyz->bcxyz') with softmax(cls)[..., :-1]
+ * (mask2former_nusc_occ.py:725-733, 691-696).  cls[B, Q, K+1]; out[B, K, X2, Y2, Z2]. */
+int occf_upsample_classify_fwd(const float* mask_pred, const float* cls, float* out, int B, int Q,
+                               int K, int X, int Y, int Z, int X2, int Y2, int Z2, void* stream);
+
+/* forward_lidarseg (eval branch, mask2former_nusc_occ.py:505-542): class volume at mask
+ * resolution sampled at points (bilinear=trilinear, align_corners=True, border padding) and
+ * soft-maxed.  pts[P, 4] = (batch, gx, gy, gz) in [-1, 1] along (X, Y, Z); out[P, K]. */
+int occf_lidarseg_sample_fwd(const float* mask_pred, const float* cls, const float* pts, float* out,
+                             int P, int B, int Q, int K, int X, int Y, int Z, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCCFORMER_HIP_H */

@@ -1,0 +1,346 @@
+// Mask2Former-style occupancy decoder kernels:
+//   * preserve-pooling  (adaptive 3-D max-pool of the mask logits -> attention mask)
+//   * masked cross-attention  (100 queries x up to ~10^5 voxel keys, split over key chunks)
+//   * fused trilinear upsample + sigmoid + class-weighted reduction (final occupancy volume)
+//   * lidarseg point sampling of the class volume
+//
+// Reference: projects/mmdet3d_plugin/occformer/mask2former/mask2former_nusc_occ.py
+//   forward_head :426-471, forward :589-689 (all-masked-row fix :652-653),
+//   simple_test :698-745, format_results :691-696, forward_lidarseg :505-542.
+#include "occf_common.h"
+#include "../../include/occformer_hip.h"
+
+// ---------------------------------------------------------------------------------------
+// Preserve-pooling: F.adaptive_max_pool3d(mask_pred, (ox,oy,oz)) then `.sigmoid() < 0.5`
+// (== pooled logit < 0).  mask_pred [BQ, X, Y, Z] (z fastest).  Writes the pooled logits
+// [BQ, L] (L = ox*oy*oz), the blocked bytes [BQ, L] (1 = key may NOT be attended) and ORs
+// row_open[bq] = 1 when at least one key of the row is open (feeds the all-masked fix).
+__global__ void __launch_bounds__(256) mask_pool_kernel(
+    const float* __restrict__ mask_pred, float* __restrict__ pooled, uint8_t* __restrict__ blocked,
+    int* __restrict__ row_open, long BQ, int X, int Y, int Z, int ox, int oy, int oz) {
+  const long L = (long)ox * oy * oz;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= BQ * L) return;
+  const long bq = gid / L;
+  const int cell = (int)(gid % L);
+  const int cz = cell % oz, cy = (cell / oz) % oy, cx = cell / (oz * oy);
+  // adaptive pooling window: [floor(i*in/out), ceil((i+1)*in/out))
+  const int x0 = (int)(((long)cx * X) / ox), x1 = (int)((((long)cx + 1) * X + ox - 1) / ox);
+  const int y0 = (int)(((long)cy * Y) / oy), y1 = (int)((((long)cy + 1) * Y + oy - 1) / oy);
+  const int z0 = (int)(((long)cz * Z) / oz), z1 = (int)((((long)cz + 1) * Z + oz - 1) / oz);
+  const float* src = mask_pred + bq * (long)X * Y * Z;
+  float m = -INFINITY;
+  for (int x = x0; x < x1; ++x)
+    for (int y = y0; y < y1; ++y) {
+      const float* row = src + ((long)x * Y + y) * Z;
+      for (int z = z0; z < z1; ++z) {
+        const float v = row[z];
+        m = (v > m || v != v) ? v : m;     // NaN propagates like torch's max-pool
+      }
+    }
+  pooled[gid] = m;
+  // sigmoid(m) < 0.5, evaluated as the reference does (fp32 sigmoid, then compare)
+  const float sg = 1.0f / (1.0f + expf(-m));
+  const bool blk = sg < 0.5f;
+  blocked[gid] = blk ? 1 : 0;
+  if (!blk) atomicOr((unsigned*)&row_open[bq], 1u);
+}
+
+extern "C" int occf_mask_pool_fwd(const float* mask_pred, float* pooled, uint8_t* blocked,
+                                  int32_t* row_open, long BQ, int X, int Y, int Z, int ox, int oy,
+                                  int oz, void* stream) {
+  if (BQ <= 0 || X <= 0 || Y <= 0 || Z <= 0 || ox <= 0 || oy <= 0 || oz <= 0) return OCCF_EINVAL;
+  if (ox > X || oy > Y || oz > Z) return OCCF_ESHAPE;
+  hipStream_t st = (hipStream_t)stream;
+#ifndef OCCF_EMU
+  hipError_t e = hipMemsetAsync(row_open, 0, sizeof(int32_t) * BQ, st);
+  if (e != hipSuccess) return (int)e;
+#else
+  memset(row_open, 0, sizeof(int32_t) * BQ);
+#endif
+  const long total = BQ * ox * oy * oz;
+  hipLaunchKernelGGL(mask_pool_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, mask_pred, pooled,
+                     blocked, (int*)row_open, BQ, X, Y, Z, ox, oy, oz);
+  OCCF_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------
+// Masked cross-attention, head_dim = 32.  q [B, Q, E] (already projected, includes the
+// query positional embedding), k/v [B, L, E] (projected; k includes the key positional
+// encoding), blocked [B, Q, L] bytes shared by all heads, row_open [B*Q].
+// Phase 1: workgroup = (key chunk, head, batch); thread = one query row (q in registers,
+// running max / sum / 32-wide output in registers); the chunk's K and V head slices are
+// staged through LDS and consumed as broadcasts.  Phase 2 merges the chunks (log-sum-exp).
+#define XA_HD 32
+#define XA_TILE 64       // keys per LDS tile
+#define XA_QPB 128       // query rows per workgroup (threads)
+
+__global__ void __launch_bounds__(XA_QPB) masked_xattn_partial_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const uint8_t* __restrict__ blocked, const int* __restrict__ row_open, float* __restrict__ part_o,
+    float* __restrict__ part_ml, int B, int Q, int L, int E, int heads, int chunk, int n_chunks,
+    float scale) {
+  __shared__ __attribute__((aligned(16))) float lds_k[XA_TILE * XA_HD];
+  __shared__ __attribute__((aligned(16))) float lds_v[XA_TILE * XA_HD];
+  const int ck = blockIdx.x % n_chunks;
+  const int qb = blockIdx.x / n_chunks;      // query block
+  const int h = blockIdx.y;
+  const int b = blockIdx.z;
+  const int qi = qb * XA_QPB + threadIdx.x;
+  const bool valid = qi < Q;
+  float qr[XA_HD], o[XA_HD];
+  float m = -INFINITY, l = 0.f;
+  bool use_mask = false;
+  if (valid) {
+    const float* qp = q + ((long)b * Q + qi) * E + h * XA_HD;
+#pragma unroll
+    for (int d = 0; d < XA_HD; ++d) qr[d] = qp[d] * scale;
+    use_mask = blocked != nullptr && row_open[b * Q + qi] != 0;
+  }
+#pragma unroll
+  for (int d = 0; d < XA_HD; ++d) o[d] = 0.f;
+  const int k0 = ck * chunk;
+  const int k1 = (k0 + chunk < L) ? k0 + chunk : L;
+  const uint8_t* brow = valid && use_mask ? blocked + ((long)b * Q + qi) * L : nullptr;
+  for (int t0 = k0; t0 < k1; t0 += XA_TILE) {
+    const int nt = (k1 - t0 < XA_TILE) ? k1 - t0 : XA_TILE;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nt * (XA_HD / 4); idx += XA_QPB) {
+      const int r = idx >> 3, c4 = (idx & 7) * 4;
+      const long src = ((long)b * L + t0 + r) * E + h * XA_HD + c4;
+      *(float4*)(&lds_k[r * XA_HD + c4]) = *(const float4*)(k + src);
+      *(float4*)(&lds_v[r * XA_HD + c4]) = *(const float4*)(v + src);
+    }
+    __syncthreads();
+    if (!valid) continue;
+    for (int r = 0; r < nt; ++r) {
+      if (brow != nullptr && brow[t0 + r]) continue;
+      const float* kr = &lds_k[r * XA_HD];
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < XA_HD; ++d) s = fmaf(qr[d], kr[d], s);
+      if (s > m) {
+        const float c = expf(m - s);       // m = -inf on first hit -> c = 0
+        l *= c;
+#pragma unroll
+        for (int d = 0; d < XA_HD; ++d) o[d] *= c;
+        m = s;
+      }
+      const float p = expf(s - m);
+      l += p;
+      const float* vr = &lds_v[r * XA_HD];
+#pragma unroll
+      for (int d = 0; d < XA_HD; ++d) o[d] = fmaf(p, vr[d], o[d]);
+    }
+  }
+  if (!valid) return;
+  const long slot = (((long)b * heads + h) * Q + qi) * n_chunks + ck;
+  part_ml[slot * 2 + 0] = m;
+  part_ml[slot * 2 + 1] = l;
+  float* po = part_o + slot * XA_HD;
+#pragma unroll
+  for (int d = 0; d < XA_HD; d += 4) *(float4*)(po + d) = make_float4(o[d], o[d + 1], o[d + 2], o[d + 3]);
+}
+
+__global__ void __launch_bounds__(256) masked_xattn_merge_kernel(
+    const float* __restrict__ part_o, const float* __restrict__ part_ml, float* __restrict__ out, int B,
+    int Q, int E, int heads, int n_chunks) {
+  // thread = (b, h, q, d)
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * heads * Q * XA_HD;
+  if (gid >= total) return;
+  const int d = (int)(gid % XA_HD);
+  long r = gid / XA_HD;
+  const int qi = (int)(r % Q);
+  r /= Q;
+  const int h = (int)(r % heads);
+  const int b = (int)(r / heads);
+  const long base = (((long)b * heads + h) * Q + qi) * n_chunks;
+  float M = -INFINITY;
+  for (int c = 0; c < n_chunks; ++c) M = fmaxf(M, part_ml[(base + c) * 2]);
+  float l = 0.f, o = 0.f;
+  for (int c = 0; c < n_chunks; ++c) {
+    const float mc = part_ml[(base + c) * 2];
+    if (mc == -INFINITY) continue;
+    const float w = expf(mc - M);
+    l = fmaf(part_ml[(base + c) * 2 + 1], w, l);
+    o = fmaf(part_o[(base + c) * XA_HD + d], w, o);
+  }
+  out[((long)b * Q + qi) * E + h * XA_HD + d] = o / l;
+}
+
+extern "C" int occf_masked_xattn_fwd(const float* q, const float* k, const float* v,
+                                     const uint8_t* blocked, const int32_t* row_open, float* out,
+                                     float* workspace, long workspace_floats, int B, int Q, int L,
+                                     int E, int heads, void* stream) {
+  if (B <= 0 || Q <= 0 || L <= 0 || heads <= 0 || E != heads * XA_HD) return OCCF_ESHAPE;
+  // chunking: enough workgroups to fill 256 CUs, chunks a multiple of the LDS tile
+  int chunk = 1024;
+  while (chunk > XA_TILE && (long)occf_cdiv(L, chunk) * heads * B < 512) chunk >>= 1;
+  const int n_chunks = occf_cdiv(L, chunk);
+  const int qblocks = occf_cdiv(Q, XA_QPB);
+  const long need = (long)B * heads * Q * n_chunks * (XA_HD + 2);
+  if (workspace == nullptr || workspace_floats < need) return OCCF_EINVAL;
+  float* part_o = workspace;
+  float* part_ml = workspace + (long)B * heads * Q * n_chunks * XA_HD;
+  const float scale = (float)(1.0 / sqrt((double)XA_HD));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(masked_xattn_partial_kernel, dim3(n_chunks * qblocks, heads, B), dim3(XA_QPB), 0, st,
+                     q, k, v, blocked, (const int*)row_open, part_o, part_ml, B, Q, L, E, heads, chunk,
+                     n_chunks, scale);
+  const long total = (long)B * heads * Q * XA_HD;
+  hipLaunchKernelGGL(masked_xattn_merge_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, part_o,
+                     part_ml, out, B, Q, E, heads, n_chunks);
+  OCCF_LAUNCH_CHECK();
+}
+
+extern "C" long occf_masked_xattn_workspace(int B, int Q, int L, int heads) {
+  int chunk = 1024;
+  while (chunk > XA_TILE && (long)occf_cdiv(L, chunk) * heads * B < 512) chunk >>= 1;
+  return (long)B * heads * Q * occf_cdiv(L, chunk) * (XA_HD + 2);
+}
+
+// ---------------------------------------------------------------------------------------
+// Final occupancy volume: trilinear upsample (align_corners=True) of the last mask logits
+// to occ_size, sigmoid, and the class-weighted sum over queries with softmax(cls)[..., :-1]
+// -- one pass; the reference's [B,100,256,256,32] fp32 intermediate (839 MB) never exists.
+// mask_pred [B, Q, X, Y, Z]; cls [B, Q, K+1]; out [B, K, X2, Y2, Z2].
+#define UC_MAXQ 128
+#define UC_MAXK 24
+
+__global__ void __launch_bounds__(256) upsample_classify_kernel(
+    const float* __restrict__ mask_pred, const float* __restrict__ cls, float* __restrict__ out, int B,
+    int Q, int K, int X, int Y, int Z, int X2, int Y2, int Z2) {
+  __shared__ float prob[UC_MAXQ * UC_MAXK];
+  const int b = blockIdx.y;
+  // softmax over K+1 logits per query, keep the first K
+  for (int qi = threadIdx.x; qi < Q; qi += blockDim.x) {
+    const float* c = cls + ((long)b * Q + qi) * (K + 1);
+    float mx = c[0];
+    for (int i = 1; i <= K; ++i) mx = fmaxf(mx, c[i]);
+    float sum = 0.f;
+    for (int i = 0; i <= K; ++i) sum += expf(c[i] - mx);
+    for (int i = 0; i < K; ++i) prob[qi * UC_MAXK + i] = expf(c[i] - mx) / sum;
+  }
+  __syncthreads();
+  const long V2 = (long)X2 * Y2 * Z2;
+  const long vid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vid >= V2) return;
+  const int z2 = (int)(vid % Z2), y2 = (int)((vid / Z2) % Y2), x2 = (int)(vid / ((long)Z2 * Y2));
+  // align_corners=True source coordinate: dst * (in-1)/(out-1)
+  const float sx = X2 > 1 ? (float)(X - 1) / (float)(X2 - 1) : 0.f;
+  const float sy = Y2 > 1 ? (float)(Y - 1) / (float)(Y2 - 1) : 0.f;
+  const float sz = Z2 > 1 ? (float)(Z - 1) / (float)(Z2 - 1) : 0.f;
+  const float fx = sx * x2, fy = sy * y2, fz = sz * z2;
+  const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+  const int x1 = x0 + (x0 < X - 1), y1 = y0 + (y0 < Y - 1), z1 = z0 + (z0 < Z - 1);
+  const float tx = fx - x0, ty = fy - y0, tz = fz - z0;
+  float acc[UC_MAXK];
+#pragma unroll
+  for (int i = 0; i < UC_MAXK; ++i) acc[i] = 0.f;
+  const long V = (long)X * Y * Z;
+  const long o00 = ((long)x0 * Y + y0) * Z, o01 = ((long)x0 * Y + y1) * Z;
+  const long o10 = ((long)x1 * Y + y0) * Z, o11 = ((long)x1 * Y + y1) * Z;
+  for (int qi = 0; qi < Q; ++qi) {
+    const float* mp = mask_pred + ((long)b * Q + qi) * V;
+    // same nesting as upsample_trilinear3d: x outermost, z innermost
+    const float c00 = (1.f - tz) * mp[o00 + z0] + tz * mp[o00 + z1];
+    const float c01 = (1.f - tz) * mp[o01 + z0] + tz * mp[o01 + z1];
+    const float c10 = (1.f - tz) * mp[o10 + z0] + tz * mp[o10 + z1];
+    const float c11 = (1.f - tz) * mp[o11 + z0] + tz * mp[o11 + z1];
+    const float val = (1.f - tx) * ((1.f - ty) * c00 + ty * c01) + tx * ((1.f - ty) * c10 + ty * c11);
+    const float sg = 1.0f / (1.0f + expf(-val));
+    const float* pr = &prob[qi * UC_MAXK];
+#pragma unroll
+    for (int i = 0; i < UC_MAXK; ++i)
+      if (i < K) acc[i] = fmaf(pr[i], sg, acc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < UC_MAXK; ++i)
+    if (i < K) out[((long)b * K + i) * V2 + vid] = acc[i];
+}
+
+extern "C" int occf_upsample_classify_fwd(const float* mask_pred, const float* cls, float* out, int B,
+                                          int Q, int K, int X, int Y, int Z, int X2, int Y2, int Z2,
+                                          void* stream) {
+  if (B <= 0 || Q <= 0 || Q > UC_MAXQ || K <= 0 || K > UC_MAXK) return OCCF_ESHAPE;
+  const long V2 = (long)X2 * Y2 * Z2;
+  hipLaunchKernelGGL(upsample_classify_kernel, dim3(occf_cdiv(V2, 256), B), dim3(256), 0,
+                     (hipStream_t)stream, mask_pred, cls, out, B, Q, K, X, Y, Z, X2, Y2, Z2);
+  OCCF_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------
+// Lidarseg: per point, trilinear sample (align_corners=True, border padding) of the
+// low-resolution class volume  sum_q softmax(cls)[q, :K] * sigmoid(mask_pred[q, cell]),
+// then a softmax over the K classes.  One 64-lane wave per point, lanes over queries.
+// pts [P, 4] = (batch index, gx, gy, gz) with g in grid_sample's [-1, 1] convention,
+// gx along X (first spatial dim), gz along Z.
+__global__ void __launch_bounds__(256) lidarseg_sample_kernel(
+    const float* __restrict__ mask_pred, const float* __restrict__ cls, const float* __restrict__ pts,
+    float* __restrict__ out, int P, int Q, int K, int X, int Y, int Z) {
+  const int lane = threadIdx.x & 63;
+  const long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (p >= P) return;
+  const int b = (int)pts[p * 4 + 0];
+  float c3[3];
+  int i0[3], i1[3];
+  const int dims[3] = {X, Y, Z};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float f = (pts[p * 4 + 1 + a] + 1.f) * 0.5f * (float)(dims[a] - 1);
+    f = fminf(fmaxf(f, 0.f), (float)(dims[a] - 1));               // border padding
+    const float fl = floorf(f);
+    i0[a] = (int)fl;
+    i1[a] = i0[a] + 1 < dims[a] ? i0[a] + 1 : i0[a];               // weight of the clamped tap is 0
+    c3[a] = f - fl;
+  }
+  const long V = (long)X * Y * Z;
+  float acc[UC_MAXK];
+#pragma unroll
+  for (int i = 0; i < UC_MAXK; ++i) acc[i] = 0.f;
+  for (int qi = lane; qi < Q; qi += 64) {
+    const float* mp = mask_pred + ((long)b * Q + qi) * V;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int xx = (c >> 2) ? i1[0] : i0[0], yy = ((c >> 1) & 1) ? i1[1] : i0[1], zz = (c & 1) ? i1[2] : i0[2];
+      const float w = ((c >> 2) ? c3[0] : 1.f - c3[0]) * (((c >> 1) & 1) ? c3[1] : 1.f - c3[1]) *
+                      ((c & 1) ? c3[2] : 1.f - c3[2]);
+      const float m = mp[((long)xx * Y + yy) * Z + zz];
+      s = fmaf(w, 1.0f / (1.0f + expf(-m)), s);
+    }
+    const float* cl = cls + ((long)b * Q + qi) * (K + 1);
+    float mx = cl[0];
+    for (int i = 1; i <= K; ++i) mx = fmaxf(mx, cl[i]);
+    float sum = 0.f;
+    for (int i = 0; i <= K; ++i) sum += expf(cl[i] - mx);
+#pragma unroll
+    for (int i = 0; i < UC_MAXK; ++i)
+      if (i < K) acc[i] = fmaf(expf(cl[i] - mx) / sum, s, acc[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < UC_MAXK; ++i) {
+    if (i < K) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[i] += __shfl_xor(acc[i], o);
+    }
+  }
+  if (lane == 0) {
+    float mx = acc[0];
+    for (int i = 1; i < K; ++i) mx = fmaxf(mx, acc[i]);
+    float sum = 0.f;
+    for (int i = 0; i < K; ++i) sum += expf(acc[i] - mx);
+    for (int i = 0; i < K; ++i) out[p * K + i] = expf(acc[i] - mx) / sum;
+  }
+}
+
+extern "C" int occf_lidarseg_sample_fwd(const float* mask_pred, const float* cls, const float* pts,
+                                        float* out, int P, int B, int Q, int K, int X, int Y, int Z,
+                                        void* stream) {
+  if (P < 0 || B <= 0 || Q <= 0 || K <= 0 || K > UC_MAXK) return OCCF_ESHAPE;
+  if (P == 0) return 0;
+  hipLaunchKernelGGL(lidarseg_sample_kernel, dim3(occf_cdiv((long)P * 64, 256)), dim3(256), 0,
+                     (hipStream_t)stream, mask_pred, cls, pts, out, P, Q, K, X, Y, Z);
+  OCCF_LAUNCH_CHECK();
+}

@@ -1,0 +1,155 @@
+// 3-D multi-scale deformable attention sampling core of the pixel decoder.
+//
+// Reference: projects/mmdet3d_plugin/occformer/necks/multi_scale_deform_attn_3d.py
+//   multi_scale_deformable_attn_pytorch :17-80 (per level F.grid_sample, trilinear, zeros
+//   padding, align_corners=False, weighted sum over levels*points) and the location /
+//   softmax arithmetic of MultiScaleDeformableAttention3D.forward :246-273.
+//
+// The reference launches one grid_sample per level per layer and materialises a
+// [B*heads, Dh, Nq, L*P] stack; here one pass reads the raw sampling offsets and attention
+// logits, does the 12-way softmax in registers and gathers the 8 corners of every sample
+// straight from the projected value tensor [B, Nv, heads*Dh] (a (key, head) row is Dh
+// contiguous floats, read as 16-byte pieces by Dh/4 adjacent lanes).  Reference points are
+// the queries' own normalised cell centres (point_generator.py:111-137), recomputed from
+// the query index instead of being read from memory.
+//
+// Gather-bound: the value tensor (<= 70 MB at the 200-grid) is L2/Infinity-Cache resident.
+#include "occf_common.h"
+#include "../../include/occformer_hip.h"
+
+#define MSDA_MAX_LEVELS 4
+
+struct MsdaLevels {
+  int n;
+  int X[MSDA_MAX_LEVELS], Y[MSDA_MAX_LEVELS], Z[MSDA_MAX_LEVELS], start[MSDA_MAX_LEVELS];
+};
+
+template <int VEC, int LP_MAX>
+__global__ void __launch_bounds__(256) msda3d_fwd_kernel(
+    const float* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
+    float* __restrict__ out, MsdaLevels lv, int B, int Nq, int H, int Dh, int P) {
+  const int lanes = Dh / VEC;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * Nq * H * lanes;
+  if (gid >= total) return;
+  const int cv = (int)(gid % lanes) * VEC;
+  long r = gid / lanes;
+  const int h = (int)(r % H);
+  r /= H;
+  const int q = (int)(r % Nq);
+  const int b = (int)(r / Nq);
+  const int L = lv.n;
+  const int LP = L * P;
+
+  // normalised reference point of this query: its own cell centre, in its own level
+  int ql = 0;
+  while (ql + 1 < L && q >= lv.start[ql + 1]) ++ql;
+  const int local = q - lv.start[ql];
+  const int qz = local % lv.Z[ql];
+  const int qy = (local / lv.Z[ql]) % lv.Y[ql];
+  const int qx = local / (lv.Z[ql] * lv.Y[ql]);
+  const float rz = ((float)qz + 0.5f) / (float)lv.Z[ql];
+  const float ry = ((float)qy + 0.5f) / (float)lv.Y[ql];
+  const float rx = ((float)qx + 0.5f) / (float)lv.X[ql];
+
+  // softmax over the L*P logits of this (query, head)
+  const float* lg = logits + ((long)(b * Nq + q) * H + h) * LP;
+  float w[LP_MAX];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < LP_MAX; ++i) {
+    w[i] = i < LP ? lg[i] : -3.0e38f;
+    mx = fmaxf(mx, w[i]);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP_MAX; ++i) {
+    w[i] = i < LP ? expf(w[i] - mx) : 0.f;
+    sum += w[i];
+  }
+  const float inv = 1.0f / sum;
+
+  const float* of = offs + ((long)(b * Nq + q) * H + h) * LP * 3;
+  const int E = H * Dh;
+  float acc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+
+#pragma unroll
+  for (int i = 0; i < LP_MAX; ++i) {
+    if (i < LP) {
+    const int l = i / P;
+    const int Xl = lv.X[l], Yl = lv.Y[l], Zl = lv.Z[l];
+    // loc = ref + off / (Z, Y, X);  grid = 2 loc - 1;  pixel = ((grid + 1) * size - 1) / 2
+    const float lz = rz + of[i * 3 + 0] / (float)Zl;
+    const float ly = ry + of[i * 3 + 1] / (float)Yl;
+    const float lx = rx + of[i * 3 + 2] / (float)Xl;
+    const float pz = ((2.f * lz - 1.f + 1.f) * (float)Zl - 1.f) * 0.5f;
+    const float py = ((2.f * ly - 1.f + 1.f) * (float)Yl - 1.f) * 0.5f;
+    const float px = ((2.f * lx - 1.f + 1.f) * (float)Xl - 1.f) * 0.5f;
+    const float fz = floorf(pz), fy = floorf(py), fx = floorf(px);
+    const float tz = pz - fz, ty = py - fy, tx = px - fx;
+    const int iz = (int)fz, iy = (int)fy, ix = (int)fx;
+    const float wgt = w[i] * inv;
+    const float* vbase = value + ((long)b * (lv.start[L - 1] + lv.X[L - 1] * lv.Y[L - 1] * lv.Z[L - 1]) +
+                                  lv.start[l]) * E + h * Dh + cv;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int xx = ix + (c >> 2), yy = iy + ((c >> 1) & 1), zz = iz + (c & 1);
+      if (xx < 0 || xx >= Xl || yy < 0 || yy >= Yl || zz < 0 || zz >= Zl) continue;
+      const float cw = ((c >> 2) ? tx : 1.f - tx) * (((c >> 1) & 1) ? ty : 1.f - ty) *
+                       ((c & 1) ? tz : 1.f - tz) * wgt;
+      const float* vp = vbase + ((long)(xx * Yl + yy) * Zl + zz) * E;
+      if (VEC == 4) {
+        const float4 t = *(const float4*)vp;
+        acc[0] = fmaf(cw, t.x, acc[0]);
+        acc[1 % VEC] = fmaf(cw, t.y, acc[1 % VEC]);
+        acc[2 % VEC] = fmaf(cw, t.z, acc[2 % VEC]);
+        acc[3 % VEC] = fmaf(cw, t.w, acc[3 % VEC]);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = fmaf(cw, vp[v], acc[v]);
+      }
+    }
+    }
+  }
+  float* o = out + (long)(b * Nq + q) * E + h * Dh + cv;
+  if (VEC == 4) {
+    *(float4*)o = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) o[v] = acc[v];
+  }
+}
+
+extern "C" int occf_msda3d_fwd(const float* value, const float* sampling_offsets,
+                               const float* attn_logits, float* out, const int32_t* level_shapes,
+                               int num_levels, int B, int Nq, int heads, int head_dim,
+                               int num_points, void* stream) {
+  if (num_levels <= 0 || num_levels > MSDA_MAX_LEVELS || B <= 0 || heads <= 0 || head_dim <= 0 ||
+      num_points <= 0 || num_levels * num_points > 16)
+    return OCCF_ESHAPE;
+  MsdaLevels lv;
+  lv.n = num_levels;
+  int start = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    lv.X[l] = level_shapes[l * 3 + 0];
+    lv.Y[l] = level_shapes[l * 3 + 1];
+    lv.Z[l] = level_shapes[l * 3 + 2];
+    lv.start[l] = start;
+    start += lv.X[l] * lv.Y[l] * lv.Z[l];
+  }
+  for (int l = num_levels; l < MSDA_MAX_LEVELS; ++l) lv.X[l] = lv.Y[l] = lv.Z[l] = lv.start[l] = 0;
+  if (start != Nq) return OCCF_ESHAPE;   // queries ARE the keys (encoder self-attention)
+  hipStream_t st = (hipStream_t)stream;
+  if (head_dim % 4 == 0) {
+    const long total = (long)B * Nq * heads * (head_dim / 4);
+    hipLaunchKernelGGL((msda3d_fwd_kernel<4, 16>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,
+                       sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points);
+  } else {
+    const long total = (long)B * Nq * heads * head_dim;
+    hipLaunchKernelGGL((msda3d_fwd_kernel<1, 16>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,
+                       sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points);
+  }
+  OCCF_LAUNCH_CHECK();
+}

@@ -1,0 +1,52 @@
+// Common device-side definitions for the gfx950 (CDNA4) kernels of the OccFormer
+// forward hot path.  Wavefront = 64 lanes everywhere.
+#pragma once
+#include <stdint.h>
+
+#ifdef OCCF_EMU
+// test-only host build of the same kernel sources (tests/hipemu); never shipped
+#include "hipemu.h"
+typedef emu_f32x16 f32x16;
+typedef emu_f32x4 f32x4;
+typedef emu_bf16x8 bf16x8;
+#define occf_mfma_f32_32x32x2(a, b, c) emu_mfma_f32_32x32x2f32(a, b, c)
+#define occf_mfma_f32_16x16x4(a, b, c) emu_mfma_f32_16x16x4f32(a, b, c)
+#define occf_mfma_bf16_32x32x16(a, b, c) emu_mfma_f32_32x32x16_bf16(a, b, c)
+static inline float occf_fmul(float a, float b) {
+  volatile float r = a * b;
+  return r;
+}
+static inline float occf_fadd(float a, float b) {
+  volatile float r = a + b;
+  return r;
+}
+struct float4 {
+  float x, y, z, w;
+};
+struct float2 {
+  float x, y;
+};
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+#define OCCF_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define occf_mfma_f32_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
+#define occf_mfma_f32_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+#define occf_mfma_bf16_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+// un-contracted fp32 ops: the reference's arithmetic is mul-then-add, never fma
+__device__ __forceinline__ float occf_fmul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float occf_fadd(float a, float b) { return __fadd_rn(a, b); }
+#endif
+
+#define OCCF_WAVE 64
+
+// error codes of the C ABI (0 = ok, >0 = hipError_t, <0 = argument error)
+#define OCCF_EINVAL (-1)
+#define OCCF_ESHAPE (-2)
+
+static inline int occf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+#define OCCF_LAUNCH_CHECK() return (int)hipGetLastError()

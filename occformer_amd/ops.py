@@ -1,0 +1,177 @@
+"""Thin host-side marshalling from torch tensors to the C ABI of liboccformer_hip.so.
+
+Tensors are only used for device memory, streams and shapes; every computation happens in
+the hand-written gfx950 kernels behind ``include/occformer_hip.h``.  ``ops`` (the module
+level instance) is bound to the real library and refuses non-GPU tensors.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class OccfError(RuntimeError):
+    pass
+
+
+class HipOps:
+    """One method per C entry point.  ``strict=True`` (the product binding) requires
+    GPU-resident contiguous tensors; the test-suite builds a non-strict binding around
+    the host-emulation build of the same kernel sources to check index math on CPU."""
+
+    def __init__(self, lib, strict=True):
+        self.lib = lib
+        self.strict = strict
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        if self.strict:
+            return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return ctypes.c_void_p(0)
+
+    def _ptr(self, t, dtype=None):
+        if t is None:
+            return ctypes.c_void_p(0)
+        if self.strict and not t.is_cuda:
+            raise OccfError("occformer_amd ops need GPU tensors (no CPU path exists)")
+        if not t.is_contiguous():
+            raise OccfError("non-contiguous tensor passed to a HIP op")
+        if dtype is not None and t.dtype != dtype:
+            raise OccfError(f"expected {dtype}, got {t.dtype}")
+        return ctypes.c_void_p(t.data_ptr())
+
+    def _call(self, name, *args):
+        rc = getattr(self.lib, name)(*args)
+        if rc != 0:
+            raise OccfError(f"{name} failed with code {rc}")
+
+    f32 = torch.float32
+    i32 = torch.int32
+
+    # ------------------------------------------------------------------ view transform
+    def bev_pool_forward(self, x, geom, interval_lengths, interval_starts, b, d, h, w):
+        """Same signature/argument order as bev_pool_ext.bev_pool_forward
+        (mmdet3d/ops/bev_pool/src/bev_pool.cpp:22-28)."""
+        n, c = x.shape
+        out = torch.empty((b, d, h, w, c), dtype=x.dtype, device=x.device)
+        self._call("occf_bev_pool_fwd", self._ptr(x, self.f32), self._ptr(geom, self.i32),
+                   self._ptr(interval_starts, self.i32), self._ptr(interval_lengths, self.i32),
+                   self._ptr(out), int(b), int(d), int(h), int(w), n, c,
+                   interval_starts.numel(), self._stream())
+        return out
+
+    def bev_pool_backward(self, out_grad, geom, interval_lengths, interval_starts, b, d, h, w):
+        n = geom.shape[0]
+        c = out_grad.shape[4]
+        x_grad = torch.empty((n, c), dtype=out_grad.dtype, device=out_grad.device)
+        self._call("occf_bev_pool_bwd", self._ptr(out_grad, self.f32), self._ptr(geom, self.i32),
+                   self._ptr(interval_starts, self.i32), self._ptr(interval_lengths, self.i32),
+                   self._ptr(x_grad), int(b), int(d), int(h), int(w), n, c,
+                   interval_starts.numel(), self._stream())
+        return x_grad
+
+    def lss_voxel_index(self, frustum, cam, bda, grid, B, N, X, Y, Z, bda4):
+        DHW = frustum.numel() // 3
+        vox = torch.empty((B * N * DHW,), dtype=self.i32, device=frustum.device)
+        self._call("occf_lss_voxel_index", self._ptr(frustum, self.f32), self._ptr(cam, self.f32),
+                   self._ptr(bda, self.f32), self._ptr(grid, self.f32), self._ptr(vox), B, N, DHW,
+                   X, Y, Z, int(bda4), self._stream())
+        return vox
+
+    def lift_splat_forward(self, depth, feat_cl, offsets, sorted_pts, n_vox):
+        """depth [BN, D, HW] f32, feat_cl [BN, HW, C] f32 -> [n_vox, C]."""
+        BN, D, HW = depth.shape
+        C = feat_cl.shape[-1]
+        out = torch.empty((n_vox, C), dtype=depth.dtype, device=depth.device)
+        self._call("occf_lift_splat_fwd", self._ptr(depth, self.f32), self._ptr(feat_cl, self.f32),
+                   self._ptr(offsets, self.i32), self._ptr(sorted_pts, self.i32), self._ptr(out),
+                   n_vox, BN, D, HW, C, self._stream())
+        return out
+
+    def lift_splat_backward(self, out_grad, depth, feat_cl, vox):
+        BN, D, HW = depth.shape
+        C = feat_cl.shape[-1]
+        d_depth = torch.empty_like(depth)
+        d_feat = torch.empty_like(feat_cl)
+        self._call("occf_lift_splat_bwd", self._ptr(out_grad, self.f32), self._ptr(depth, self.f32),
+                   self._ptr(feat_cl, self.f32), self._ptr(vox, self.i32), self._ptr(d_depth),
+                   self._ptr(d_feat), vox.numel(), BN, D, HW, C, self._stream())
+        return d_depth, d_feat
+
+    # ------------------------------------------------------------------ encoder
+    def window_attention(self, qkv, qkv_bias, bias_table, B, X, Y, S, heads, shift):
+        """qkv [B*X*Y*S, 3C] -> attention output [B*X*Y*S, C] (before proj)."""
+        C = qkv.shape[1] // 3
+        out = torch.empty((qkv.shape[0], C), dtype=qkv.dtype, device=qkv.device)
+        self._call("occf_window_attn_fwd", self._ptr(qkv, self.f32), self._ptr(qkv_bias, self.f32),
+                   self._ptr(bias_table, self.f32), self._ptr(out), B, X, Y, S, C, heads, int(shift),
+                   self._stream())
+        return out
+
+    # ------------------------------------------------------------------ pixel decoder
+    def msda3d(self, value, offsets, logits, level_shapes, heads, points):
+        """value [B, Nq, E]; offsets [B, Nq, heads*L*P*3]; logits [B, Nq, heads*L*P]."""
+        B, Nq, E = value.shape
+        L = len(level_shapes)
+        arr = (ctypes.c_int32 * (3 * L))(*[int(v) for s in level_shapes for v in s])
+        out = torch.empty_like(value)
+        self._call("occf_msda3d_fwd", self._ptr(value, self.f32), self._ptr(offsets, self.f32),
+                   self._ptr(logits, self.f32), self._ptr(out),
+                   ctypes.cast(arr, ctypes.c_void_p), L, B, Nq, heads, E // heads, points, self._stream())
+        return out
+
+    # ------------------------------------------------------------------ occupancy decoder
+    def mask_pool(self, mask_pred, target):
+        """mask_pred [B, Q, X, Y, Z] -> pooled [B, Q, L], blocked u8 [B, Q, L], row_open i32 [B*Q]."""
+        B, Q, X, Y, Z = mask_pred.shape
+        ox, oy, oz = (int(t) for t in target)
+        L = ox * oy * oz
+        pooled = torch.empty((B, Q, L), dtype=mask_pred.dtype, device=mask_pred.device)
+        blocked = torch.empty((B, Q, L), dtype=torch.uint8, device=mask_pred.device)
+        row_open = torch.empty((B * Q,), dtype=self.i32, device=mask_pred.device)
+        self._call("occf_mask_pool_fwd", self._ptr(mask_pred, self.f32), self._ptr(pooled),
+                   self._ptr(blocked), self._ptr(row_open), B * Q, X, Y, Z, ox, oy, oz, self._stream())
+        return pooled, blocked, row_open
+
+    def masked_attention(self, q, k, v, heads, blocked=None, row_open=None):
+        """q [B, Q, E]; k, v [B, L, E] -> [B, Q, E] (all projected; before out_proj)."""
+        B, Q, E = q.shape
+        L = k.shape[1]
+        need = self.lib.occf_masked_xattn_workspace(B, Q, L, heads)
+        ws = torch.empty((need,), dtype=self.f32, device=q.device)
+        out = torch.empty_like(q)
+        self._call("occf_masked_xattn_fwd", self._ptr(q, self.f32), self._ptr(k, self.f32),
+                   self._ptr(v, self.f32), self._ptr(blocked, torch.uint8), self._ptr(row_open, self.i32),
+                   self._ptr(out), self._ptr(ws), need, B, Q, L, E, heads, self._stream())
+        return out
+
+    def upsample_classify(self, mask_pred, cls, occ_size):
+        B, Q, X, Y, Z = mask_pred.shape
+        K = cls.shape[-1] - 1
+        X2, Y2, Z2 = (int(t) for t in occ_size)
+        out = torch.empty((B, K, X2, Y2, Z2), dtype=mask_pred.dtype, device=mask_pred.device)
+        self._call("occf_upsample_classify_fwd", self._ptr(mask_pred, self.f32), self._ptr(cls, self.f32),
+                   self._ptr(out), B, Q, K, X, Y, Z, X2, Y2, Z2, self._stream())
+        return out
+
+    def lidarseg_sample(self, mask_pred, cls, pts):
+        """pts [P, 4] = (batch, gx, gy, gz) -> class probabilities [P, K]."""
+        B, Q, X, Y, Z = mask_pred.shape
+        K = cls.shape[-1] - 1
+        P = pts.shape[0]
+        out = torch.empty((P, K), dtype=mask_pred.dtype, device=mask_pred.device)
+        self._call("occf_lidarseg_sample_fwd", self._ptr(mask_pred, self.f32), self._ptr(cls, self.f32),
+                   self._ptr(pts, self.f32), self._ptr(out), P, B, Q, K, X, Y, Z, self._stream())
+        return out
+
+
+_ops = None
+
+
+def get_ops():
+    """The product binding (real gfx950 library, GPU tensors only)."""
+    global _ops
+    if _ops is None:
+        _ops = HipOps(_lib.get(), strict=True)
+    return _ops

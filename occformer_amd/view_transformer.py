@@ -1,0 +1,321 @@
+"""Image -> voxel view transform (LSS depth-splat voxel pooling), registry name
+``ViewTransformerLiftSplatShootVoxel``.
+
+Host-side mirror of projects/mmdet3d_plugin/occformer/image2bev/ViewTransformerLSSVoxel.py
+(+ the pieces of ViewTransformerLSSBEVDepth.py it inherits): same constructor keys, same
+``get_mlp_input`` / ``forward`` / ``get_depth_loss`` contract, same state-dict names
+(SURVEY.md Appendix D).  The lift, the geometry/quantisation and the voxel pooling run in
+the gfx950 kernels of csrc/lss.hip; the [B,N,D,fH,fW,C] volume is never materialised.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .ops import get_ops
+from .registry import NECKS
+
+
+# ------------------------------------------------------------------ host-side packing
+def pack_cameras(rots, trans, intrins, post_rots, post_trans, bda):
+    """Per-camera constants for occf_lss_voxel_index, computed with the same torch ops and
+    in the same order as get_geometry (ViewTransformerLSSBEVDepth.py:126-141).
+    Returns cam [B*N, 27] and bda12 [B, 12] (3x4 row-major)."""
+    B, N = trans.shape[:2]
+    ipr = torch.inverse(post_rots)
+    if intrins.shape[-1] == 4:
+        shift = intrins[:, :, :3, 3]
+        K = intrins[:, :, :3, :3]
+    else:
+        shift = torch.zeros_like(trans)
+        K = intrins
+    comb = rots.matmul(torch.inverse(K))
+    cam = torch.cat((ipr.reshape(B, N, 9), post_trans.reshape(B, N, 3), comb.reshape(B, N, 9),
+                     trans.reshape(B, N, 3), shift.reshape(B, N, 3)), -1).reshape(B * N, 27)
+    bda12 = torch.zeros(B, 3, 4, dtype=torch.float32, device=bda.device)
+    if bda.shape[-1] == 4:
+        bda12.copy_(bda[:, :3, :4])
+    else:
+        bda12[:, :, :3] = bda
+    return cam.float().contiguous(), bda12.reshape(B, 12).contiguous()
+
+
+def build_voxel_csr(vox, n_vox):
+    """Stable counting order of the kept points by voxel row: offsets [n_vox+1] i32 and the
+    point indices sorted by (voxel, original index).  Out-of-range points (vox = -1) sort
+    to the tail and are never referenced.  No host synchronisation."""
+    key = torch.where(vox < 0, torch.full_like(vox, n_vox), vox).long()
+    order = torch.sort(key, stable=True)[1]
+    counts = torch.bincount(key, minlength=n_vox + 1)[:n_vox]
+    offsets = torch.zeros(n_vox + 1, dtype=torch.int32, device=vox.device)
+    offsets[1:] = torch.cumsum(counts, 0).int()
+    return offsets, order.int()
+
+
+class _LiftSplat(torch.autograd.Function):
+    """Fused lift+splat with the hand-written backward (the reference's counterpart is
+    QuickCumsumCuda, mmdet3d/ops/bev_pool/bev_pool.py:37-80)."""
+
+    @staticmethod
+    def forward(ctx, depth, feat_cl, vox, offsets, sorted_pts, n_vox):
+        ctx.save_for_backward(depth, feat_cl, vox)
+        return get_ops().lift_splat_forward(depth, feat_cl, offsets, sorted_pts, n_vox)
+
+    @staticmethod
+    def backward(ctx, grad):
+        depth, feat_cl, vox = ctx.saved_tensors
+        d_depth, d_feat = get_ops().lift_splat_backward(grad.contiguous(), depth, feat_cl, vox)
+        return d_depth, d_feat, None, None, None, None
+
+
+# ------------------------------------------------------------------ DepthNet (dense 2-D part)
+class _BasicBlock(nn.Module):
+    """mmdet ResNet BasicBlock as used by DepthNet (ViewTransformerLSSBEVDepth.py:475-477)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.conv1 = nn.Conv2d(c, c, 3, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(c)
+        self.conv2 = nn.Conv2d(c, c, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(c)
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        return F.relu(self.bn2(self.conv2(y)) + x)
+
+
+class _AtrousBranch(nn.Module):
+    def __init__(self, cin, cout, k, dil):
+        super().__init__()
+        self.atrous_conv = nn.Conv2d(cin, cout, k, padding=0 if k == 1 else dil, dilation=dil, bias=False)
+        self.bn = nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.atrous_conv(x)))
+
+
+class _ImageASPP(nn.Module):
+    """ViewTransformerLSSBEVDepth.py:337-407."""
+
+    def __init__(self, cin, mid):
+        super().__init__()
+        self.aspp1 = _AtrousBranch(cin, mid, 1, 1)
+        self.aspp2 = _AtrousBranch(cin, mid, 3, 6)
+        self.aspp3 = _AtrousBranch(cin, mid, 3, 12)
+        self.aspp4 = _AtrousBranch(cin, mid, 3, 18)
+        self.global_avg_pool = nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)), nn.Conv2d(cin, mid, 1, bias=False),
+                                             nn.BatchNorm2d(mid), nn.ReLU())
+        self.conv1 = nn.Conv2d(mid * 5, mid, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(mid)
+        self.dropout = nn.Dropout(0.5)
+
+    def forward(self, x):
+        g = self.global_avg_pool(x).expand(-1, -1, *x.shape[2:])
+        y = torch.cat((self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), g), 1)
+        return self.dropout(F.relu(self.bn1(self.conv1(y))))
+
+
+class _CamMlp(nn.Module):
+    def __init__(self, cin, hidden, cout):
+        super().__init__()
+        self.fc1 = nn.Linear(cin, hidden)
+        self.fc2 = nn.Linear(hidden, cout)
+
+    def forward(self, x):
+        return self.fc2(F.relu(self.fc1(x)))
+
+
+class _SE(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv_reduce = nn.Conv2d(c, c, 1)
+        self.conv_expand = nn.Conv2d(c, c, 1)
+
+    def forward(self, x, x_se):
+        return x * torch.sigmoid(self.conv_expand(F.relu(self.conv_reduce(x_se))))
+
+
+class DeformConv2dPack(nn.Module):
+    """DCNv1 as configured in DepthNet (ViewTransformerLSSBEVDepth.py:479-487: 3x3, pad 1,
+    groups 4, deform_groups 1, no bias; mmcv zero-initialises conv_offset).  Bilinear
+    im2col (zeros outside) followed by a grouped contraction."""
+
+    def __init__(self, cin, cout, k=3, padding=1, groups=4, deform_groups=1):
+        super().__init__()
+        self.k, self.padding, self.groups, self.deform_groups = k, padding, groups, deform_groups
+        self.weight = nn.Parameter(torch.empty(cout, cin // groups, k, k))
+        nn.init.kaiming_uniform_(self.weight, nonlinearity="relu")
+        self.conv_offset = nn.Conv2d(cin, deform_groups * 2 * k * k, k, padding=padding)
+        nn.init.zeros_(self.conv_offset.weight)
+        nn.init.zeros_(self.conv_offset.bias)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        k, pad = self.k, self.padding
+        off = self.conv_offset(x).view(B, self.deform_groups, k * k, 2, H, W)
+        ys = torch.arange(H, device=x.device, dtype=x.dtype).view(1, H, 1) - pad
+        xs = torch.arange(W, device=x.device, dtype=x.dtype).view(1, 1, W) - pad
+        cpg = C // self.deform_groups
+        cols = []
+        for t in range(k * k):
+            ky, kx = divmod(t, k)
+            parts = []
+            for g in range(self.deform_groups):
+                py = ys + ky + off[:, g, t, 0]
+                px = xs + kx + off[:, g, t, 1]
+                # grid_sample's zero padding == DCN's "corner taps outside contribute 0"
+                grid = torch.stack(((px + 0.5) / W * 2 - 1, (py + 0.5) / H * 2 - 1), -1)
+                parts.append(F.grid_sample(x[:, g * cpg:(g + 1) * cpg], grid, mode="bilinear",
+                                           padding_mode="zeros", align_corners=False))
+            cols.append(torch.cat(parts, 1))
+        col = torch.stack(cols, 2).view(B, self.groups, C // self.groups, k * k, H * W)
+        w = self.weight.view(self.groups, -1, C // self.groups, k * k)
+        return torch.einsum("bgckp,gock->bgop", col, w).reshape(B, -1, H, W)
+
+
+class DepthNet(nn.Module):
+    """ViewTransformerLSSBEVDepth.py:450-504.  Dense 2-D convolutions run through
+    PyTorch-ROCm (MIOpen); SURVEY.md §8a row 2 keeps them outside the custom-kernel scope."""
+
+    def __init__(self, in_channels, mid_channels, context_channels, depth_channels, cam_channels=27):
+        super().__init__()
+        self.reduce_conv = nn.Sequential(nn.Conv2d(in_channels, mid_channels, 3, padding=1),
+                                         nn.BatchNorm2d(mid_channels), nn.ReLU(inplace=True))
+        self.context_conv = nn.Conv2d(mid_channels, context_channels, 1)
+        self.bn = nn.BatchNorm1d(cam_channels)
+        self.depth_mlp = _CamMlp(cam_channels, mid_channels, mid_channels)
+        self.depth_se = _SE(mid_channels)
+        self.context_mlp = _CamMlp(cam_channels, mid_channels, mid_channels)
+        self.context_se = _SE(mid_channels)
+        self.depth_conv = nn.Sequential(
+            _BasicBlock(mid_channels), _BasicBlock(mid_channels), _BasicBlock(mid_channels),
+            _ImageASPP(mid_channels, mid_channels),
+            DeformConv2dPack(mid_channels, mid_channels, 3, 1, groups=4),
+            nn.Conv2d(mid_channels, depth_channels, 1))
+
+    def forward(self, x, mlp_input):
+        m = self.bn(mlp_input.reshape(-1, mlp_input.shape[-1]))
+        x = self.reduce_conv(x)
+        ctx = self.context_conv(self.context_se(x, self.context_mlp(m)[..., None, None]))
+        depth = self.depth_conv(self.depth_se(x, self.depth_mlp(m)[..., None, None]))
+        return torch.cat((depth, ctx), 1)
+
+
+# ------------------------------------------------------------------ the registered module
+@NECKS.register_module()
+class ViewTransformerLiftSplatShootVoxel(nn.Module):
+    def __init__(self, loss_depth_weight, grid_config=None, data_config=None, numC_input=512,
+                 numC_Trans=64, downsample=16, cam_channels=27, point_cloud_range=None,
+                 loss_depth_type="bce", loss_depth_reg_weight=0.0, use_voxel_net=False,
+                 accelerate=False, use_bev_pool=True, vp_megvii=False, vp_stero=False,
+                 cache_geometry=False, **kwargs):
+        super().__init__()
+        if grid_config is None:
+            grid_config = dict(xbound=[-51.2, 51.2, 0.8], ybound=[-51.2, 51.2, 0.8],
+                               zbound=[-10.0, 10.0, 20.0], dbound=[1.0, 60.0, 1.0])
+        if vp_megvii or use_voxel_net:
+            raise NotImplementedError("only the bev_pool voxel path of the OccFormer configs is built")
+        self.grid_config = grid_config
+        self.data_config = data_config or dict(input_size=(256, 704))
+        self.downsample = downsample
+        self.loss_depth_weight = loss_depth_weight
+        self.loss_depth_type = loss_depth_type
+        self.cam_channels = cam_channels
+        self.point_cloud_range = point_cloud_range
+        self.cam_depth_range = grid_config["dbound"]
+        rows = [grid_config["xbound"], grid_config["ybound"], grid_config["zbound"]]
+        # float nn.Parameters, as in the reference: they are part of released checkpoints
+        self.dx = nn.Parameter(torch.tensor([r[2] for r in rows], dtype=torch.float32), requires_grad=False)
+        self.bx = nn.Parameter(torch.tensor([r[0] + r[2] / 2.0 for r in rows], dtype=torch.float32),
+                               requires_grad=False)
+        self.nx = nn.Parameter(torch.tensor([(r[1] - r[0]) / r[2] for r in rows], dtype=torch.float32),
+                               requires_grad=False)
+        self.grid_size = tuple(int(round((r[1] - r[0]) / r[2])) for r in rows)
+        H, W = self.data_config["input_size"]
+        fH, fW = H // downsample, W // downsample
+        d = torch.arange(*grid_config["dbound"], dtype=torch.float32)
+        self.D = d.numel()
+        u = torch.linspace(0, W - 1, fW, dtype=torch.float32).view(1, 1, fW).expand(self.D, fH, fW)
+        v = torch.linspace(0, H - 1, fH, dtype=torch.float32).view(1, fH, 1).expand(self.D, fH, fW)
+        self.frustum = nn.Parameter(torch.stack((u, v, d.view(-1, 1, 1).expand(self.D, fH, fW)), -1),
+                                    requires_grad=False)
+        self.numC_input = numC_input
+        self.numC_Trans = numC_Trans
+        self.depth_net = DepthNet(numC_input, numC_input, numC_Trans, self.D, cam_channels=cam_channels)
+        self.cache_geometry = cache_geometry
+        self._geom_cache = None
+
+    # -- ViewTransformerLSSBEVDepth.py:591-646
+    def get_mlp_input(self, rot, tran, intrin, post_rot, post_tran, bda=None):
+        B, N = rot.shape[:2]
+        if bda is None:
+            bda = torch.eye(3).to(rot).view(1, 3, 3).repeat(B, 1, 1)
+        bda_n = bda.view(B, 1, *bda.shape[-2:]).expand(B, N, *bda.shape[-2:])
+        cols = [intrin[..., 0, 0], intrin[..., 1, 1], intrin[..., 0, 2], intrin[..., 1, 2]]
+        if intrin.shape[-1] == 4:
+            cols += [intrin[..., 0, 3], intrin[..., 1, 3], intrin[..., 2, 3]]
+        cols += [post_rot[..., 0, 0], post_rot[..., 0, 1], post_tran[..., 0], post_rot[..., 1, 0],
+                 post_rot[..., 1, 1], post_tran[..., 1], bda_n[..., 0, 0], bda_n[..., 0, 1],
+                 bda_n[..., 1, 0], bda_n[..., 1, 1], bda_n[..., 2, 2]]
+        feats = torch.stack(cols, -1)
+        if intrin.shape[-1] == 4 and bda.shape[-1] == 4:
+            feats = torch.cat((feats, bda_n[..., :3, 3]), -1)
+        sensor2ego = torch.cat((rot, tran.reshape(B, N, 3, 1)), -1).reshape(B, N, -1)
+        return torch.cat((feats, sensor2ego), -1)
+
+    def get_depth_dist(self, x):
+        return x.softmax(dim=1)
+
+    def voxel_index(self, rots, trans, intrins, post_rots, post_trans, bda):
+        """(vox [B*N*D*fH*fW] i32, offsets, sorted_pts): frustum -> voxel rows + CSR."""
+        B, N = trans.shape[:2]
+        X, Y, Z = self.grid_size
+        key = None
+        if self.cache_geometry:
+            key = tuple(t.data_ptr() for t in (rots, trans, intrins, post_rots, post_trans, bda))
+            if self._geom_cache is not None and self._geom_cache[0] == key:
+                return self._geom_cache[1]
+        cam, bda12 = pack_cameras(rots, trans, intrins, post_rots, post_trans, bda)
+        grid = torch.cat((self.bx - self.dx / 2.0, self.dx, self.nx)).float()
+        vox = get_ops().lss_voxel_index(self.frustum.reshape(-1, 3), cam, bda12, grid, B, N, X, Y, Z,
+                                        bda.shape[-1] == 4)
+        offsets, pts = build_voxel_csr(vox, B * X * Y * Z)
+        res = (vox, offsets, pts)
+        if self.cache_geometry:
+            self._geom_cache = (key, res)
+        return res
+
+    def forward(self, input):
+        x, rots, trans, intrins, post_rots, post_trans, bda, mlp_input = input[:8]
+        B, N, C, H, W = x.shape
+        y = self.depth_net(x.view(B * N, C, H, W), mlp_input)
+        depth_prob = self.get_depth_dist(y[:, :self.D])
+        feat_cl = y[:, self.D:self.D + self.numC_Trans].permute(0, 2, 3, 1).reshape(B * N, H * W, -1)
+        vox, offsets, pts = self.voxel_index(rots, trans, intrins, post_rots, post_trans, bda)
+        X, Y, Z = self.grid_size
+        out = _LiftSplat.apply(depth_prob.reshape(B * N, self.D, H * W).contiguous(),
+                               feat_cl.contiguous(), vox, offsets, pts, B * X * Y * Z)
+        # logical [B, C, X, Y, Z] over channels-last memory (what the 3-D encoder consumes)
+        return out.view(B, X, Y, Z, self.numC_Trans).permute(0, 4, 1, 2, 3), depth_prob
+
+    # -- ViewTransformerLSSVoxel.py:27-75
+    def get_downsampled_gt_depth(self, gt_depths):
+        B, N, H, W = gt_depths.shape
+        ds = self.downsample
+        g = gt_depths.view(B * N, H // ds, ds, W // ds, ds).permute(0, 1, 3, 2, 4).reshape(-1, ds * ds)
+        g = torch.where(g == 0.0, torch.full_like(g, 1e5), g).min(-1).values
+        g = g.view(B * N, H // ds, W // ds)
+        db = self.grid_config["dbound"]
+        g = (g - (db[0] - db[2] / 2)) / db[2]
+        vals = g.clone()
+        g = torch.where((g < self.D + 1) & (g >= 0.0), g, torch.zeros_like(g))
+        onehot = F.one_hot(g.long(), num_classes=self.D + 1).view(-1, self.D + 1)[:, 1:]
+        return vals, onehot.float()
+
+    def get_depth_loss(self, depth_labels, depth_preds):
+        if self.loss_depth_type != "bce":
+            raise NotImplementedError(self.loss_depth_type)
+        _, labels = self.get_downsampled_gt_depth(depth_labels)
+        preds = depth_preds.float().permute(0, 2, 3, 1).reshape(-1, self.D)
+        fg = labels.max(1).values > 0.0
+        loss = F.binary_cross_entropy(preds[fg], labels[fg], reduction="none").sum() / max(1.0, fg.sum())
+        return self.loss_depth_weight * loss

@@ -1,0 +1,66 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: torch.from_numpy(z[k]) if z[k].ndim else z[k].item() for k in z.files}
+
+
+class Backend:
+    """Either the real gfx950 library on cuda:0 ('hip', -m gpu) or the TEST-ONLY host
+    emulation build of the same kernel sources ('emu', CPU)."""
+
+    def __init__(self, kind):
+        self.kind = kind
+        if kind == "hip":
+            from occformer_amd.ops import get_ops
+            self.ops = get_ops()
+            self.device = torch.device("cuda:0")
+        else:
+            from occformer_amd import _lib
+            from occformer_amd.ops import HipOps
+            from tests.hipemu import build as emu_build
+            self.ops = HipOps(_lib.bind(emu_build.build()), strict=False)
+            self.device = torch.device("cpu")
+
+    def to(self, *ts):
+        out = tuple(t.to(self.device) if torch.is_tensor(t) else t for t in ts)
+        return out if len(out) > 1 else out[0]
+
+
+_backends = {}
+
+
+def _get_backend(kind):
+    if kind not in _backends:
+        _backends[kind] = Backend(kind)
+    return _backends[kind]
+
+
+@pytest.fixture(params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def be(request):
+    if request.param == "hip" and not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return _get_backend(request.param)
+
+
+@pytest.fixture
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return _get_backend("hip")

@@ -1,0 +1,56 @@
+"""TEST-ONLY: compile the kernel sources of occformer_amd/csrc for the HOST with the
+fiber emulator (tests/hipemu/hipemu.h) into tests/hipemu/build/libocc_emu.so, so the
+CPU test-suite can exercise the kernels' index math against the oracle without a GPU.
+The product never loads this library."""
+import hashlib
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "occformer_amd", "csrc")
+OUT = os.path.join(HERE, "build")
+LIB = os.path.join(OUT, "libocc_emu.so")
+CXX = "/opt/rocm/lib/llvm/bin/clang++"
+FLAGS = ["-O2", "-std=c++17", "-fPIC", "-DOCCF_EMU", "-ffp-contract=off", "-x", "c++",
+         "-Wno-unused-value", "-Wno-unknown-attributes",
+         "-I", HERE, "-I", CSRC, "-I", os.path.join(ROOT, "include")]
+
+
+def available():
+    return os.path.exists(CXX)
+
+
+def build(force=False):
+    os.makedirs(OUT, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    for f in ("hipemu.h", "hipemu.cpp"):
+        h.update(open(os.path.join(HERE, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "occformer_hip.h"), "rb").read())
+    stamp = os.path.join(OUT, "digest.txt")
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == h.hexdigest():
+        return LIB
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.join(OUT, s.replace(".hip", ".o"))
+        objs.append(o)
+        procs.append((s, subprocess.Popen([CXX, *FLAGS, "-c", os.path.join(CSRC, s), "-o", o],
+                                          stderr=subprocess.PIPE, text=True)))
+    for s, p in procs:
+        _, err = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"emu compile failed for {s}:\n{err}")
+    o = os.path.join(OUT, "hipemu.o")
+    subprocess.check_call([CXX, "-O2", "-std=c++17", "-fPIC", "-c", os.path.join(HERE, "hipemu.cpp"), "-o", o])
+    subprocess.check_call([CXX, "-shared", "-o", LIB, *objs, o])
+    open(stamp, "w").write(h.hexdigest())
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True))

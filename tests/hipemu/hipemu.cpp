@@ -1,0 +1,84 @@
+// TEST-ONLY: fiber scheduler behind tests/hipemu/hipemu.h (see the header).
+#include "hipemu.h"
+
+namespace hipemu {
+Block* g_blk = nullptr;
+emu_uint3 g_bid;
+dim3 g_bdim, g_gdim;
+char* g_dyn_smem = nullptr;
+void (*g_entry)(void*) = nullptr;
+void* g_entry_arg = nullptr;
+
+static const size_t STACK = 96 * 1024;
+
+void fiber_main() {
+  g_entry(g_entry_arg);
+  Block& b = *g_blk;
+  Fiber& f = b.fibers[b.cur];
+  f.done = true;
+  // leaving threads no longer take part in rendezvous; release waiters if complete
+  Wave& w = b.waves[f.wave];
+  w.alive--;
+  if (w.alive > 0 && w.arrived >= w.alive) {
+    w.arrived = 0;
+    w.gen++;
+  }
+  b.alive--;
+  if (b.alive > 0 && b.arrived >= b.alive) {
+    b.arrived = 0;
+    b.gen++;
+  }
+  swapcontext(&f.ctx, &b.sched);
+}
+
+void run_block(void (*entry)(void*), void* arg, dim3 grid, dim3 block, emu_uint3 bid, size_t shmem) {
+  static std::vector<char*> stacks;
+  const int nt = (int)(block.x * block.y * block.z);
+  while ((int)stacks.size() < nt) stacks.push_back((char*)malloc(STACK));
+  std::vector<char> dyn(shmem + 64);
+  Block b;
+  b.fibers.resize(nt);
+  b.waves.resize((nt + WAVE - 1) / WAVE);
+  b.alive = nt;
+  g_blk = &b;
+  g_bid = bid;
+  g_bdim = block;
+  g_gdim = grid;
+  g_dyn_smem = (char*)(((uintptr_t)dyn.data() + 63) & ~(uintptr_t)63);
+  g_entry = entry;
+  g_entry_arg = arg;
+  for (int t = 0; t < nt; ++t) {
+    Fiber& f = b.fibers[t];
+    f.tid.x = t % block.x;
+    f.tid.y = (t / block.x) % block.y;
+    f.tid.z = t / (block.x * block.y);
+    f.lane = t % WAVE;
+    f.wave = t / WAVE;
+    b.waves[f.wave].alive++;
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = stacks[t];
+    f.ctx.uc_stack.ss_size = STACK;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, (void (*)())fiber_main, 0);
+  }
+  int remaining = nt;
+  long spins = 0;
+  while (remaining > 0) {
+    int progressed = 0;
+    for (int t = 0; t < nt; ++t) {
+      if (b.fibers[t].done) continue;
+      b.cur = t;
+      swapcontext(&b.sched, &b.fibers[t].ctx);
+      if (b.fibers[t].done) {
+        remaining--;
+        progressed++;
+      }
+    }
+    if (++spins > 50000000L) {
+      fprintf(stderr, "hipemu: deadlock suspected (block %u,%u,%u)\n", bid.x, bid.y, bid.z);
+      abort();
+    }
+  }
+  g_blk = nullptr;
+}
+}  // namespace hipemu

@@ -1,0 +1,126 @@
+"""Encoder / pixel-decoder / occupancy-decoder kernels
+against the oracle.  CPU: host emulation of the kernel sources; -m gpu: gfx950 library."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import occformer_ref as O
+from tests import paramgen
+
+TOL = dict(atol=2e-5, rtol=1e-4)     # fp32 kernels vs fp32 oracle; north_star bound is 1e-3
+
+
+@pytest.mark.parametrize("X,Y,S,heads,shift,B", [(14, 14, 3, 1, 0, 1), (10, 9, 2, 2, 3, 2),
+                                                 (7, 16, 1, 4, 3, 1), (5, 5, 2, 5, 0, 1)])
+def test_window_attention(be, X, Y, S, heads, shift, B):
+    C = heads * 32
+    sd = {"w.qkv.weight": paramgen.tensor("qkvw", (3 * C, C), 1, C ** -0.5),
+          "w.qkv.bias": paramgen.tensor("qkvb", (3 * C,), 1, 0.3),
+          "w.proj.weight": torch.eye(C), "w.proj.bias": torch.zeros(C),
+          "w.relative_position_bias_table": paramgen.tensor("tab", (169, heads), 1, 0.5)}
+    y = paramgen.tensor("tokens", (B * S, X * Y, C), 2)                  # (b s) (x y) c, "after LN"
+    ref = O.shift_window_msa(sd, "", y, X, Y, heads, shift) if False else None
+    sd2 = {k.replace("w.", "a.w_msa."): v for k, v in sd.items()}
+    ref = O.shift_window_msa(sd2, "a.", y, X, Y, heads, shift)           # [(b s), x*y, C]
+    yk = y.view(B, S, X, Y, C).permute(0, 2, 3, 1, 4).reshape(-1, C).contiguous()
+    qkv = F.linear(yk, sd["w.qkv.weight"], sd["w.qkv.bias"]).contiguous()
+    out = be.ops.window_attention(*be.to(qkv, sd["w.qkv.bias"], sd["w.relative_position_bias_table"]),
+                                  B, X, Y, S, heads, shift).cpu()
+    out = out.view(B, X, Y, S, C).permute(0, 3, 1, 2, 4).reshape(B * S, X * Y, C)
+    assert torch.allclose(out, ref, **TOL), float((out - ref).abs().max())
+
+
+def test_window_mask_and_index_tables():
+    """known-answer helpers the kernel re-derives arithmetically"""
+    from tests.conftest import golden
+    g = golden("tables")
+    assert torch.equal(O.rel_pos_index(7).int(), g["rel_pos_index"])
+    m = O.shift_window_mask(14, 14, 7, 3)
+    assert m.shape == (4, 49, 49) and float(m[0].abs().sum()) == 0.0 and float(m[3].min()) == -100.0
+
+
+@pytest.mark.parametrize("E,heads,shapes", [(96, 8, [(2, 2, 1), (4, 4, 2), (8, 8, 4)]),
+                                            (48, 4, [(3, 2, 2), (5, 4, 3)]),
+                                            (40, 8, [(2, 3, 1), (4, 4, 2), (6, 5, 3)])])
+def test_msda3d(be, E, heads, shapes):
+    B, P = 2, 4
+    L = len(shapes)
+    Nq = sum(x * y * z for x, y, z in shapes)
+    value = paramgen.tensor("value", (B, Nq, E), 1)
+    offs = paramgen.tensor("offs", (B, Nq, heads * L * P * 3), 1, 2.0)
+    logits = paramgen.tensor("logits", (B, Nq, heads * L * P), 1)
+    ref_pts = torch.cat([O.reference_points_3d(s) for s in shapes], 0)[None, :, None, :].expand(B, -1, L, -1)
+    norm = torch.tensor([[s[2], s[1], s[0]] for s in shapes], dtype=torch.float32)
+    loc = ref_pts[:, :, None, :, None, :] + offs.view(B, Nq, heads, L, P, 3) / norm[None, None, None, :, None, :]
+    w = logits.view(B, Nq, heads, L * P).softmax(-1).view(B, Nq, heads, L, P)
+    ref = O.msda3d_core(value.view(B, Nq, heads, E // heads), shapes, loc, w)
+    out = be.ops.msda3d(*be.to(value, offs, logits), shapes, heads, P).cpu()
+    assert torch.allclose(out, ref, **TOL), float((out - ref).abs().max())
+
+
+@pytest.mark.parametrize("shape,target", [((16, 16, 8), (4, 4, 2)), ((16, 16, 8), (8, 8, 4)),
+                                          ((10, 7, 5), (3, 2, 2)), ((6, 6, 2), (6, 6, 2))])
+def test_mask_pool(be, shape, target):
+    B, Q = 2, 5
+    mp = paramgen.tensor("mp", (B, Q, *shape), 3, 2.0)
+    mp[0, 1] = -mp[0, 1].abs() - 0.1                                     # a fully blocked row
+    pooled, blocked, row_open = be.ops.mask_pool(be.to(mp), target)
+    ref = F.adaptive_max_pool3d(mp, target).flatten(2)
+    assert torch.equal(pooled.cpu(), ref)
+    assert torch.equal(blocked.cpu().bool(), ref.sigmoid() < 0.5)
+    assert torch.equal(row_open.cpu().view(B, Q).bool(), ~(ref.sigmoid() < 0.5).all(-1))
+    assert not bool(row_open.cpu().view(B, Q)[0, 1])
+
+
+@pytest.mark.parametrize("Q,L,heads,masked", [(20, 70, 3, True), (100, 300, 2, True), (7, 1500, 1, True),
+                                              (20, 64, 2, False)])
+def test_masked_attention(be, Q, L, heads, masked):
+    B, E = 2, heads * 32
+    q = paramgen.tensor("q", (B, Q, E), 1)
+    k = paramgen.tensor("k", (B, L, E), 1)
+    v = paramgen.tensor("v", (B, L, E), 1)
+    blocked = paramgen.uniform("blk", (B, Q, L), 1) < 0.6
+    blocked[0, 0] = True                                                 # all-masked row -> unmasked
+    blocked[1, 2, : L - 1] = True                                        # single open key at the end
+    blocked[1, 3, 1:] = True                                             # single open key at the start
+    fixed = blocked & ~blocked.all(-1, keepdim=True)
+    qh = q.view(B, Q, heads, 32).transpose(1, 2) * 32 ** -0.5
+    kh = k.view(B, L, heads, 32).transpose(1, 2)
+    vh = v.view(B, L, heads, 32).transpose(1, 2)
+    att = qh @ kh.transpose(-2, -1)
+    if masked:
+        att = att.masked_fill(fixed.unsqueeze(1), float("-inf"))
+    ref = (att.softmax(-1) @ vh).transpose(1, 2).reshape(B, Q, E)
+    if masked:
+        row_open = (~blocked.all(-1)).int().view(-1)
+        out = be.ops.masked_attention(*be.to(q, k, v), heads, *be.to(blocked.to(torch.uint8).contiguous(), row_open))
+    else:
+        out = be.ops.masked_attention(*be.to(q, k, v), heads)
+    assert torch.allclose(out.cpu(), ref, **TOL), float((out.cpu() - ref).abs().max())
+
+
+@pytest.mark.parametrize("shape,occ", [((8, 8, 4), (16, 16, 8)), ((5, 6, 3), (9, 12, 5)), ((4, 4, 2), (4, 4, 2))])
+def test_upsample_classify(be, shape, occ):
+    B, Q, K = 2, 12, 17
+    mp = paramgen.tensor("mp", (B, Q, *shape), 5, 2.0)
+    cls = paramgen.tensor("cls", (B, Q, K + 1), 5)
+    ref = O.format_results(cls, F.interpolate(mp, size=occ, mode="trilinear", align_corners=True))
+    out = be.ops.upsample_classify(*be.to(mp, cls), occ).cpu()
+    assert torch.allclose(out, ref, **TOL), float((out - ref).abs().max())
+
+
+def test_lidarseg_sample(be):
+    B, Q, K = 2, 70, 17
+    shape = (8, 6, 4)
+    pc_range = [-8.0, -8.0, -2.0, 8.0, 8.0, 2.0]
+    mp = paramgen.tensor("mp", (B, Q, *shape), 6, 2.0)
+    cls = paramgen.tensor("cls", (B, Q, K + 1), 6)
+    lo, hi = torch.tensor(pc_range[:3]), torch.tensor(pc_range[3:])
+    pts = [paramgen.uniform(f"p{b}", (50 + b, 3), 6) * (hi - lo) * 1.2 + lo - 0.1 * (hi - lo) for b in range(B)]
+    ref = O.lidarseg_points(cls, mp, pts, pc_range)
+    rows = []
+    for b, p in enumerate(pts):
+        g = (p - lo) / (hi - lo) * 2 - 1
+        rows.append(torch.cat((torch.full((p.shape[0], 1), float(b)), g), 1))
+    out = be.ops.lidarseg_sample(*be.to(mp, cls, torch.cat(rows, 0).contiguous())).cpu()
+    assert torch.allclose(out, ref, **TOL), float((out - ref).abs().max())
