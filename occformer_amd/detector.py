@@ -1,0 +1,224 @@
+"""Detector glue, registry names ``OccupancyFormer`` (+ the 2-D image branch ``ResNet`` /
+``SECONDFPN`` so the unchanged nuScenes configs build).
+
+Host-side mirror of projects/mmdet3d_plugin/occformer/detectors/occupancyformer.py
+(:14-254) on top of BEVDet.__init__ (detectors/bevdepth.py:16-34) and
+MVXTwoStageDetector.__init__ (mmdet3d/models/detectors/mvx_two_stage.py:23-70): same
+constructor keys, sub-module attribute names, ``forward(return_loss=...)`` dispatch and
+``simple_test`` output dict.  The image branch is dense 2-D convolution and stays on
+PyTorch-ROCm/MIOpen (outside the hand-written kernel scope).
+"""
+import collections
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .registry import BACKBONES, DETECTORS, MODELS, NECKS
+
+
+# ------------------------------------------------------------------ 2-D image branch (non-hot-path)
+class _Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, planes, stride=1, downsample=None, style="pytorch"):
+        super().__init__()
+        s1, s2 = (1, stride) if style == "pytorch" else (stride, 1)
+        self.conv1 = nn.Conv2d(cin, planes, 1, stride=s1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=s2, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.downsample = downsample
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = F.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return F.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+
+@BACKBONES.register_module()
+class ResNet(nn.Module):
+    """mmdet 2.14 ResNet-50/101 (Bottleneck, no DCN) with mmdet/torchvision parameter names."""
+
+    arch = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+
+    def __init__(self, depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1, norm_cfg=None,
+                 norm_eval=False, style="pytorch", pretrained=None, with_cp=False, dcn=None,
+                 stage_with_dcn=None, init_cfg=None, **kwargs):
+        super().__init__()
+        if dcn is not None:
+            raise NotImplementedError("DCNv2 image backbones (R101-DCN config) are a next-round row (SURVEY §8f.1)")
+        self.out_indices = tuple(out_indices)
+        self.norm_eval = norm_eval
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        cin = 64
+        for i, n in enumerate(self.arch[depth][:num_stages]):
+            planes, stride = 64 * 2 ** i, 1 if i == 0 else 2
+            blocks = []
+            for j in range(n):
+                ds = None
+                if j == 0 and (stride != 1 or cin != planes * 4):
+                    ds = nn.Sequential(nn.Conv2d(cin, planes * 4, 1, stride=stride, bias=False),
+                                       nn.BatchNorm2d(planes * 4))
+                blocks.append(_Bottleneck(cin, planes, stride if j == 0 else 1, ds, style))
+                cin = planes * 4
+            setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
+        self.num_stages = num_stages
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)
+        outs = []
+        for i in range(self.num_stages):
+            x = getattr(self, f"layer{i + 1}")(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return tuple(outs)
+
+
+@NECKS.register_module()
+class SECONDFPN(nn.Module):
+    """mmdet3d/models/necks/second_fpn.py:11-91."""
+
+    def __init__(self, in_channels=(128, 128, 256), out_channels=(256, 256, 256), upsample_strides=(1, 2, 4),
+                 norm_cfg=None, upsample_cfg=None, conv_cfg=None, use_conv_for_no_stride=False, init_cfg=None):
+        super().__init__()
+        norm_cfg = norm_cfg or dict(type="BN", eps=1e-3, momentum=0.01)
+        blocks = []
+        for cin, cout, s in zip(in_channels, out_channels, upsample_strides):
+            if s > 1 or (s == 1 and not use_conv_for_no_stride):
+                s = int(s)
+                up = nn.ConvTranspose2d(cin, cout, s, stride=s, bias=False)
+            else:
+                k = int(np.round(1 / s))
+                up = nn.Conv2d(cin, cout, k, stride=k, bias=False)
+            blocks.append(nn.Sequential(up, nn.BatchNorm2d(cout, eps=norm_cfg.get("eps", 1e-3),
+                                                           momentum=norm_cfg.get("momentum", 0.01)),
+                                        nn.ReLU(inplace=True)))
+        self.deblocks = nn.ModuleList(blocks)
+
+    def forward(self, x):
+        ups = [blk(x[i]) for i, blk in enumerate(self.deblocks)]
+        return [torch.cat(ups, 1) if len(ups) > 1 else ups[0]]
+
+
+# ------------------------------------------------------------------ the detector
+@DETECTORS.register_module()
+class OccupancyFormer(nn.Module):
+    STAGES = ("img_encoder", "view_transformer", "bev_encoder", "bev_neck", "mask2former_head")
+
+    def __init__(self, img_backbone=None, img_neck=None, img_view_transformer=None,
+                 img_bev_encoder_backbone=None, img_bev_encoder_neck=None, pts_bbox_head=None,
+                 train_cfg=None, test_cfg=None, pretrained=None, init_cfg=None, **kwargs):
+        super().__init__()
+        self.img_backbone = MODELS.build(img_backbone) if img_backbone else None
+        self.img_neck = MODELS.build(img_neck) if img_neck else None
+        if pts_bbox_head:
+            head = dict(pts_bbox_head)
+            # mvx_two_stage.py:56-61: the head receives train_cfg.pts / test_cfg.pts
+            head["train_cfg"] = train_cfg["pts"] if train_cfg and "pts" in train_cfg else None
+            head["test_cfg"] = test_cfg["pts"] if test_cfg and "pts" in test_cfg else None
+            self.pts_bbox_head = MODELS.build(head)
+        self.img_view_transformer = MODELS.build(img_view_transformer)
+        self.img_bev_encoder_backbone = MODELS.build(img_bev_encoder_backbone)
+        self.img_bev_encoder_neck = MODELS.build(img_bev_encoder_neck)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.record_time = False
+        self.time_stats = collections.defaultdict(list)
+
+    @property
+    def with_img_neck(self):
+        return self.img_neck is not None
+
+    def _tick(self, name, t0):
+        if not self.record_time:
+            return t0
+        torch.cuda.synchronize()
+        t1 = time.time()
+        self.time_stats[name].append(t1 - t0)
+        return t1
+
+    def image_encoder(self, img):
+        if self.img_backbone is None:            # caller already supplies neck features [B,N,C,fH,fW]
+            return img
+        B, N, C, H, W = img.shape
+        x = self.img_backbone(img.view(B * N, C, H, W))
+        if self.with_img_neck:
+            x = self.img_neck(x)
+            if isinstance(x, (list, tuple)):
+                x = x[0]
+        return x.view(B, N, *x.shape[1:])
+
+    def bev_encoder(self, x):
+        t = self._tick("", 0.0) if self.record_time else 0.0
+        x = self.img_bev_encoder_backbone(x.float())
+        t = self._tick("bev_encoder", t)
+        x = self.img_bev_encoder_neck(x)
+        self._tick("bev_neck", t)
+        return x
+
+    def extract_img_feat(self, img, img_metas=None):
+        t = self._tick("", 0.0) if self.record_time else 0.0
+        x = self.image_encoder(img[0])
+        img_feats = x
+        t = self._tick("img_encoder", t)
+        rots, trans, intrins, post_rots, post_trans, bda = img[1:7]
+        mlp_input = self.img_view_transformer.get_mlp_input(rots, trans, intrins, post_rots, post_trans, bda)
+        x, depth = self.img_view_transformer([x, rots, trans, intrins, post_rots, post_trans, bda, mlp_input])
+        self._tick("view_transformer", t)
+        x = self.bev_encoder(x)
+        if not isinstance(x, list):
+            x = [x]
+        return x, depth, img_feats
+
+    def extract_feat(self, points, img, img_metas):
+        voxel_feats, depth, img_feats = self.extract_img_feat(img, img_metas)
+        return voxel_feats, img_feats, depth
+
+    def forward(self, return_loss=True, **kwargs):
+        """mmdet3d/models/detectors/base.py:46-61."""
+        if return_loss:
+            return self.forward_train(**kwargs)
+        return self.forward_test(**kwargs)
+
+    def forward_train(self, points=None, img_metas=None, img_inputs=None, gt_occ=None, points_occ=None,
+                      **kwargs):
+        raise NotImplementedError("training losses (Hungarian assignment, class-guided sampling) are the "
+                                  "next rows of the scope table; the forward path is complete")
+
+    def forward_test(self, img_metas=None, img_inputs=None, **kwargs):
+        return self.simple_test(img_metas, img_inputs, **kwargs)
+
+    def simple_test(self, img_metas, img=None, rescale=False, points_occ=None, gt_occ=None, points_uv=None):
+        voxel_feats, img_feats, depth = self.extract_feat(points=None, img=img, img_metas=img_metas)
+        t = self._tick("", 0.0) if self.record_time else 0.0
+        output = self.pts_bbox_head.simple_test(voxel_feats=voxel_feats, points=points_occ,
+                                                img_metas=img_metas, img_feats=img_feats,
+                                                points_uv=points_uv)
+        self._tick("mask2former_head", t)
+        if output["output_points"] is not None and points_occ is not None:
+            output["output_points"] = torch.argmax(output["output_points"][:, 1:], dim=1) + 1
+            target = torch.cat(points_occ, dim=0)
+            output["evaluation_semantic"] = self.simple_evaluation_semantic(output["output_points"], target)
+            output["target_points"] = target
+        vox = output["output_voxels"][0]
+        occ = tuple(int(v) for v in img_metas[0]["occ_size"])
+        if tuple(vox.shape[-3:]) != occ:
+            vox = F.interpolate(vox, size=occ, mode="trilinear", align_corners=True)
+        output["output_voxels"] = vox
+        output["target_voxels"] = gt_occ
+        return output
+
+    @staticmethod
+    def simple_evaluation_semantic(pred, gt, n=16):
+        """P/utils/metric_util.py:8-22 (fast_hist_crop over labels 1..16)."""
+        pred = pred.cpu().numpy().astype(np.int64)
+        gt = gt.cpu().numpy()[:, 3].astype(np.int64)
+        k = (gt >= 0) & (gt < n + 1)      # labels 0..16, row/col 0 cropped below
+        hist = np.bincount((n + 1) * gt[k] + pred[k], minlength=(n + 1) ** 2).reshape(n + 1, n + 1)
+        return hist[1:, 1:]

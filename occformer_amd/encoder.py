@@ -1,0 +1,232 @@
+"""Dual-path 3-D encoder, registry name ``OccupancyEncoder``.
+
+Host-side mirror of projects/mmdet3d_plugin/occformer/backbones/{occnet.py,
+dualpath_block.py, modules/window_attention.py, modules/aspp.py}: same constructor keys,
+same output list, same state-dict names.
+
+Layout: voxel tensors are logical [B, C, X, Y, Z] over channels-last memory
+[B, X, Y, Z, C].  A block builds ONE token buffer [B, X, Y, Z+1, C] (the Z height slices
+plus the BEV mean slice) and runs the shared SwinBlock on it in place of the reference's
+rearrange / cat / permute().contiguous() round trips; windows, padding and the cyclic shift
+are index arithmetic inside the window-attention kernel (csrc/window_attn.hip).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .ops import get_ops
+from .registry import BACKBONES
+
+
+def build_norm(cfg, channels):
+    """mmcv build_norm_layer for the norm types the OccFormer configs use."""
+    cfg = dict(cfg)
+    t = cfg.pop("type")
+    requires_grad = cfg.pop("requires_grad", True)
+    if t == "GN":
+        layer = nn.GroupNorm(cfg["num_groups"], channels, eps=cfg.get("eps", 1e-5))
+    elif t == "LN":
+        layer = nn.LayerNorm(channels, eps=cfg.get("eps", 1e-5))
+    elif t == "BN3d":
+        layer = nn.BatchNorm3d(channels, eps=cfg.get("eps", 1e-5))
+    elif t in ("BN", "BN2d"):
+        layer = nn.BatchNorm2d(channels, eps=cfg.get("eps", 1e-5))
+    else:
+        raise KeyError(f"norm type {t}")
+    for p in layer.parameters():
+        p.requires_grad = requires_grad
+    return layer
+
+
+# ------------------------------------------------------------------ SwinBlock on the token buffer
+class _WindowMSA(nn.Module):
+    def __init__(self, dims, heads, ws=7):
+        super().__init__()
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) ** 2, heads))
+        t = torch.arange(ws * ws)
+        r, c = t // ws, t % ws
+        idx = (2 * ws - 1) * (r[:, None] - r[None, :] + ws - 1) + (c[:, None] - c[None, :] + ws - 1)
+        self.register_buffer("relative_position_index", idx)    # kept for checkpoint compatibility
+        self.qkv = nn.Linear(dims, dims * 3)
+        self.proj = nn.Linear(dims, dims)
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+
+
+class _ShiftWindowMSA(nn.Module):
+    def __init__(self, dims, heads, ws, shift):
+        super().__init__()
+        self.w_msa = _WindowMSA(dims, heads, ws)
+        self.shift_size = shift
+
+
+class _FFN(nn.Module):
+    """mmcv FFN parameter layout: layers.0.0 = fc1, layers.1 = fc2."""
+
+    def __init__(self, dims, hidden, act="gelu"):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Sequential(nn.Linear(dims, hidden)), nn.Linear(hidden, dims))
+        self.act = act
+
+    def forward(self, x):
+        h = self.layers[0][0](x)
+        h = F.gelu(h) if self.act == "gelu" else F.relu(h)
+        return self.layers[1](h)
+
+
+class SwinBlock(nn.Module):
+    """window_attention.py:346-372 on tokens [B, X, Y, S, C]."""
+
+    def __init__(self, embed_dims, num_heads, feedforward_channels, window_size=7, shift=False,
+                 drop_path_rate=0.2):
+        super().__init__()
+        assert window_size == 7 and embed_dims == num_heads * 32
+        self.heads = num_heads
+        self.norm1 = nn.LayerNorm(embed_dims)
+        self.attn = _ShiftWindowMSA(embed_dims, num_heads, window_size, window_size // 2 if shift else 0)
+        self.norm2 = nn.LayerNorm(embed_dims)
+        self.ffn = _FFN(embed_dims, feedforward_channels)
+        self.drop_path_rate = drop_path_rate
+
+    def _drop_path(self, y, B, S):
+        """stochastic depth per (batch, slice) 'sample' of the reference's (b z) batch"""
+        if not self.training or self.drop_path_rate == 0.0:
+            return y
+        keep = 1.0 - self.drop_path_rate
+        mask = (keep + torch.rand(B, 1, 1, S, 1, device=y.device, dtype=y.dtype)).floor()
+        return (y.view(B, -1, 1, S, y.shape[-1]) / keep * mask.view(B, 1, 1, S, 1)).view_as(y)
+
+    def forward(self, tok):
+        B, X, Y, S, C = tok.shape
+        t = tok.reshape(-1, C)
+        m = self.attn.w_msa
+        qkv = m.qkv(self.norm1(t))
+        a = get_ops().window_attention(qkv, m.qkv.bias.detach().contiguous(),
+                                       m.relative_position_bias_table.detach().contiguous(), B, X, Y, S,
+                                       self.heads, self.attn.shift_size)
+        t = t + self._drop_path(m.proj(a), B, S)
+        t = t + self._drop_path(self.ffn(self.norm2(t)), B, S)
+        return t.view(B, X, Y, S, C)
+
+
+# ------------------------------------------------------------------ BEV ASPP (global path)
+class _AtrousGN(nn.Module):
+    def __init__(self, cin, cout, k, dil, groups):
+        super().__init__()
+        self.atrous_conv = nn.Conv2d(cin, cout, k, padding=0 if k == 1 else dil, dilation=dil, bias=False)
+        self.bn = nn.GroupNorm(groups, cout)      # named 'bn' in the reference, GroupNorm in practice
+        nn.init.kaiming_normal_(self.atrous_conv.weight)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.atrous_conv(x)))
+
+
+class _ASPP(nn.Module):
+    """aspp.py:49-122."""
+
+    def __init__(self, ch, groups, dilations, dropout):
+        super().__init__()
+        self.aspp1 = _AtrousGN(ch, ch, 1, dilations[0], groups)
+        self.aspp2 = _AtrousGN(ch, ch, 3, dilations[1], groups)
+        self.aspp3 = _AtrousGN(ch, ch, 3, dilations[2], groups)
+        self.aspp4 = _AtrousGN(ch, ch, 3, dilations[3], groups)
+        self.global_avg_pool = nn.Sequential(nn.AdaptiveAvgPool2d((1, 1)), nn.Conv2d(ch, ch, 1, bias=False),
+                                             nn.GroupNorm(groups, ch), nn.ReLU(inplace=True))
+        self.conv1 = nn.Conv2d(ch * 5, ch, 1, bias=False)
+        self.bn1 = nn.GroupNorm(groups, ch)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        g = self.global_avg_pool(x).expand(-1, -1, *x.shape[2:])   # bilinear from 1x1 == broadcast
+        y = torch.cat((self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), g), 1)
+        return x + self.dropout(F.relu(self.bn1(self.conv1(y))))
+
+
+class BottleNeckASPP(nn.Module):
+    """aspp.py:134-172."""
+
+    def __init__(self, inplanes, reduction=4, dilations=(1, 6, 12, 18), norm_cfg=None, dropout=0.1):
+        super().__init__()
+        norm_cfg = norm_cfg or dict(type="GN", num_groups=32, requires_grad=True)
+        assert norm_cfg["type"] == "GN"
+        ch = inplanes // reduction
+        groups = norm_cfg["num_groups"]
+        self.input_conv = nn.Sequential(nn.Conv2d(inplanes, ch, 1, bias=False), nn.GroupNorm(groups, ch),
+                                        nn.ReLU(inplace=True))
+        self.aspp = _ASPP(ch, ch // 2 if ch <= groups else groups, list(dilations), dropout)
+        self.output_conv = nn.Sequential(nn.Conv2d(ch, inplanes, 1, bias=False),
+                                         nn.GroupNorm(groups, inplanes), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return x + self.output_conv(self.aspp(self.input_conv(x)))
+
+
+# ------------------------------------------------------------------ the block and the encoder
+class DualpathTransformerBlock(nn.Module):
+    """dualpath_block.py:13-82."""
+
+    def __init__(self, in_channels, channels, stride=1, norm_cfg=None, coeff_bias=True, aspp_drop=0.1,
+                 layer_index=0, **kwargs):
+        super().__init__()
+        self.stride = stride
+        self.channels = channels
+        self.shift = layer_index % 2 == 1
+        if stride > 1:
+            self.downsample = nn.Sequential(nn.Conv3d(in_channels, channels, 1, stride=stride, bias=False),
+                                            build_norm(norm_cfg, channels))
+        else:
+            self.downsample = nn.Identity()
+        self.input_conv = nn.Sequential(nn.Conv3d(in_channels, channels, 3, padding=1, stride=stride, bias=False),
+                                        build_norm(norm_cfg, channels), nn.ReLU(inplace=True))
+        self.bev_encoder = SwinBlock(channels, channels // 32, channels, window_size=7, drop_path_rate=0.2,
+                                     shift=self.shift)
+        self.aspp = BottleNeckASPP(channels, norm_cfg=norm_cfg, dropout=aspp_drop)
+        self.combine_coeff = nn.Conv3d(channels, 1, 1, bias=coeff_bias)
+
+    def forward(self, x):
+        y = self.input_conv(x)                                           # [B, C, X, Y, Z]
+        B, C, X, Y, Z = y.shape
+        ycl = y.permute(0, 2, 3, 4, 1)                                   # [B, X, Y, Z, C]
+        tok = torch.cat((ycl, ycl.mean(3, keepdim=True)), 3).contiguous()   # slot Z = BEV mean
+        tok = self.bev_encoder(tok)
+        sl = tok[:, :, :, :Z]
+        bev = self.aspp(tok[:, :, :, Z].permute(0, 3, 1, 2))             # [B, C, X, Y]
+        w = self.combine_coeff.weight.view(1, C)
+        coeff = torch.sigmoid(F.linear(sl, w, self.combine_coeff.bias))  # [B, X, Y, Z, 1]
+        out = sl + coeff * bev.permute(0, 2, 3, 1).unsqueeze(3)
+        ident = self.downsample(x)
+        return out.permute(0, 4, 1, 2, 3) + ident
+
+
+@BACKBONES.register_module()
+class OccupancyEncoder(nn.Module):
+    """occnet.py:12-75."""
+
+    def __init__(self, in_channels, num_stage=4, block_numbers=(2, 2, 2, 2),
+                 block_inplanes=(64, 128, 256, 512), block_strides=(1, 2, 2, 2), out_indices=(0, 1, 2, 3),
+                 norm_cfg=None, with_cp=True, **kwargs):
+        super().__init__()
+        norm_cfg = norm_cfg or dict(type="BN3d", requires_grad=True)
+        self.out_indices = tuple(out_indices)
+        self.with_cp = with_cp
+        self.layers = nn.ModuleList()
+        index = 0
+        for i in range(num_stage):
+            blocks = []
+            for j in range(block_numbers[i]):
+                blocks.append(DualpathTransformerBlock(
+                    in_channels, block_inplanes[i], stride=block_strides[i] if j == 0 else 1,
+                    norm_cfg=norm_cfg, layer_index=index, **kwargs))
+                in_channels = block_inplanes[i]
+                index += 1
+            self.layers.append(nn.Sequential(*blocks))
+
+    def forward(self, x):
+        outs = []
+        for i, layer in enumerate(self.layers):
+            if self.with_cp and x.requires_grad:
+                x = torch.utils.checkpoint.checkpoint(layer, x, use_reentrant=False)
+            else:
+                x = layer(x)
+            if i in self.out_indices:
+                outs.append(x)
+        return outs

@@ -1,0 +1,212 @@
+"""Mask2Former-style occupancy decoder, registry names ``Mask2FormerNuscOccHead`` and
+``Mask2FormerOccHead``.
+
+Host-side mirror of projects/mmdet3d_plugin/occformer/mask2former/{mask2former_nusc_occ.py,
+mask2former_occ.py}: same constructor keys, ``forward`` / ``simple_test`` contract and
+state-dict names; the mmcv/mmdet bricks underneath
+(DetrTransformerDecoder(+Layer), MultiheadAttention -> nn.MultiheadAttention, FFN) are
+folded into plain modules.  Tokens are batch-first.  Kernels: csrc/mask_head.hip.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .encoder import _FFN
+from .ops import get_ops
+from .pixel_decoder import SinePositionalEncoding3D
+from .registry import HEADS
+
+
+class _MHAParams(nn.Module):
+    """Parameter holder with torch.nn.MultiheadAttention's names (in_proj_*, out_proj.*)."""
+
+    def __init__(self, E):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * E, E))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * E))
+        self.out_proj = nn.Linear(E, E)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _MHA(nn.Module):
+    """mmcv MultiheadAttention: positional terms are added to q and k, never to v; returns
+    identity + attention output (dropout 0 in every OccFormer config)."""
+
+    def __init__(self, E, heads):
+        super().__init__()
+        self.attn = _MHAParams(E)
+        self.heads = heads
+        self.E = E
+
+    def forward(self, query, key, value, query_pos, key_pos, blocked=None, row_open=None):
+        E = self.E
+        w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
+        q = F.linear(query + query_pos, w[:E], b[:E])
+        k = F.linear(key + key_pos if key_pos is not None else key, w[E:2 * E], b[E:2 * E])
+        v = F.linear(value, w[2 * E:], b[2 * E:])
+        o = get_ops().masked_attention(q.contiguous(), k.contiguous(), v.contiguous(), self.heads,
+                                       blocked, row_open)
+        return query + self.attn.out_proj(o)
+
+
+class _DecoderLayer(nn.Module):
+    """DetrTransformerDecoderLayer with operation_order
+    ('cross_attn','norm','self_attn','norm','ffn','norm')."""
+
+    def __init__(self, E, heads, ffn_channels):
+        super().__init__()
+        self.attentions = nn.ModuleList([_MHA(E, heads), _MHA(E, heads)])
+        self.ffns = nn.ModuleList([_FFN(E, ffn_channels, act="relu")])
+        self.norms = nn.ModuleList([nn.LayerNorm(E) for _ in range(3)])
+
+    def forward(self, q, qpos, key, key_pos, blocked, row_open):
+        q = self.norms[0](self.attentions[0](q, key, key, qpos, key_pos, blocked, row_open))
+        q = self.norms[1](self.attentions[1](q, q, q, qpos, qpos))
+        return self.norms[2](q + self.ffns[0](q))
+
+
+class _Decoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        tl = cfg["transformerlayers"]
+        assert tuple(tl["operation_order"]) == ("cross_attn", "norm", "self_attn", "norm", "ffn", "norm")
+        E = tl["attn_cfgs"]["embed_dims"]
+        heads = tl["attn_cfgs"]["num_heads"]
+        ffn = tl.get("feedforward_channels", tl.get("ffn_cfgs", {}).get("feedforward_channels", 2048))
+        self.layers = nn.ModuleList([_DecoderLayer(E, heads, ffn) for _ in range(cfg["num_layers"])])
+        self.post_norm = nn.LayerNorm(E)
+        self.embed_dims = E
+
+
+class _Mask2FormerOccBase(nn.Module):
+    def __init__(self, feat_channels, out_channels, num_occupancy_classes=20, num_queries=100,
+                 num_transformer_feat_level=3, enforce_decoder_input_project=False,
+                 transformer_decoder=None, positional_encoding=None, pooling_attn_mask=True,
+                 point_cloud_range=None, padding_mode="border", sample_weight_gamma=0.25,
+                 loss_cls=None, loss_mask=None, loss_dice=None, train_cfg=None, test_cfg=None,
+                 init_cfg=None, align_corners=True, **kwargs):
+        super().__init__()
+        self.num_occupancy_classes = self.num_classes = num_occupancy_classes
+        self.num_queries = num_queries
+        self.point_cloud_range = point_cloud_range
+        self.num_transformer_feat_level = num_transformer_feat_level
+        self.num_heads = transformer_decoder["transformerlayers"]["attn_cfgs"]["num_heads"]
+        self.num_transformer_decoder_layers = transformer_decoder["num_layers"]
+        self.transformer_decoder = _Decoder(transformer_decoder)
+        self.decoder_embed_dims = E = self.transformer_decoder.embed_dims
+        self.decoder_input_projs = nn.ModuleList()
+        for _ in range(num_transformer_feat_level):
+            if E != feat_channels or enforce_decoder_input_project:
+                self.decoder_input_projs.append(nn.Conv3d(feat_channels, E, kernel_size=1))
+            else:
+                self.decoder_input_projs.append(nn.Identity())
+        pe = dict(positional_encoding)
+        pe.pop("type", None)
+        self.decoder_positional_encoding = SinePositionalEncoding3D(**pe)
+        self.query_embed = nn.Embedding(num_queries, feat_channels)
+        self.query_feat = nn.Embedding(num_queries, feat_channels)
+        self.level_embed = nn.Embedding(num_transformer_feat_level, feat_channels)
+        self.cls_embed = nn.Linear(feat_channels, self.num_classes + 1)
+        self.mask_embed = nn.Sequential(nn.Linear(feat_channels, feat_channels), nn.ReLU(inplace=True),
+                                        nn.Linear(feat_channels, feat_channels), nn.ReLU(inplace=True),
+                                        nn.Linear(feat_channels, out_channels))
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.loss_cfgs = dict(cls=loss_cls, mask=loss_mask, dice=loss_dice)
+        self.class_weight = loss_cls["class_weight"] if loss_cls else None
+        self.pooling_attn_mask = pooling_attn_mask
+        self.align_corners = align_corners
+        self.padding_mode = padding_mode
+        self.sample_weight_gamma = sample_weight_gamma
+        if not pooling_attn_mask:
+            raise NotImplementedError("only preserve-pooling attention masks (every OccFormer config)")
+
+    def init_weights(self):
+        for p in self.transformer_decoder.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_normal_(p)
+
+    # -- mask2former_nusc_occ.py:426-471
+    def forward_head(self, decoder_out, mask_feat_tok, vol_shape, target_shape):
+        """decoder_out [B, Q, E]; mask_feat_tok [B, V, E] channels-last tokens.
+        Returns cls [B,Q,K+1], mask_pred [B,Q,X,Y,Z], (blocked u8 [B,Q,L], row_open)."""
+        d = self.transformer_decoder.post_norm(decoder_out)
+        cls_pred = self.cls_embed(d)
+        mask_embed = self.mask_embed(d)
+        B, Q = mask_embed.shape[:2]
+        mask_pred = torch.matmul(mask_embed, mask_feat_tok.transpose(1, 2)).view(B, Q, *vol_shape)
+        _, blocked, row_open = get_ops().mask_pool(mask_pred.detach(), target_shape)
+        return cls_pred, mask_pred, (blocked, row_open)
+
+    # -- mask2former_nusc_occ.py:589-689
+    def forward(self, voxel_feats, img_metas=None, **kwargs):
+        mask_features = voxel_feats[0]
+        memories = voxel_feats[:0:-1]
+        B, E = mask_features.shape[:2]
+        vol_shape = tuple(mask_features.shape[-3:])
+        mask_tok = mask_features.permute(0, 2, 3, 4, 1).reshape(B, -1, E)
+        keys, key_pos, shapes = [], [], []
+        for i in range(self.num_transformer_feat_level):
+            m = self.decoder_input_projs[i](memories[i])
+            shp = tuple(m.shape[-3:])
+            t = m.permute(0, 2, 3, 4, 1).reshape(B, -1, E) + self.level_embed.weight[i]
+            keys.append(t)
+            key_pos.append(self.decoder_positional_encoding.for_shape(shp, m.device).unsqueeze(0))
+            shapes.append(shp)
+        q = self.query_feat.weight.unsqueeze(0).expand(B, -1, -1)
+        qpos = self.query_embed.weight.unsqueeze(0).expand(B, -1, -1)
+        cls_list, mask_list = [], []
+        cls, mp, am = self.forward_head(q, mask_tok, vol_shape, shapes[0])
+        cls_list.append(cls)
+        mask_list.append(mp)
+        for i, layer in enumerate(self.transformer_decoder.layers):
+            lv = i % self.num_transformer_feat_level
+            q = layer(q, qpos, keys[lv], key_pos[lv], am[0], am[1])
+            cls, mp, am = self.forward_head(q, mask_tok, vol_shape,
+                                            shapes[(i + 1) % self.num_transformer_feat_level])
+            cls_list.append(cls)
+            mask_list.append(mp)
+        return cls_list, mask_list
+
+    # -- mask2former_nusc_occ.py:691-696 at mask resolution (used by callers that want it)
+    def format_results(self, mask_cls_results, mask_pred_results):
+        return get_ops().upsample_classify(mask_pred_results.contiguous(), mask_cls_results.contiguous(),
+                                           mask_pred_results.shape[-3:])
+
+    def _output_voxels(self, cls, mask_pred, occ_size):
+        return get_ops().upsample_classify(mask_pred.contiguous(), cls.contiguous(), tuple(occ_size))
+
+
+@HEADS.register_module()
+class Mask2FormerNuscOccHead(_Mask2FormerOccBase):
+    # -- mask2former_nusc_occ.py:505-542 (eval branch)
+    def forward_lidarseg(self, cls_preds, mask_preds, points, img_metas=None):
+        pc = torch.tensor(img_metas[0]["pc_range"], dtype=torch.float32, device=mask_preds.device)
+        lo, ext = pc[:3], pc[3:] - pc[:3]
+        rows = []
+        for b, p in enumerate(points):
+            g = (p[:, :3].float() - lo) / ext * 2 - 1
+            rows.append(torch.cat((torch.full((p.shape[0], 1), float(b), device=g.device), g), 1))
+        if self.padding_mode != "border" or not self.align_corners:
+            raise NotImplementedError("lidarseg sampling is built for border padding / align_corners=True")
+        return get_ops().lidarseg_sample(mask_preds.contiguous(), cls_preds.contiguous(),
+                                         torch.cat(rows, 0).contiguous())
+
+    # -- mask2former_nusc_occ.py:698-745
+    def simple_test(self, voxel_feats, img_metas, points=None, **kwargs):
+        all_cls, all_masks = self(voxel_feats, img_metas)
+        cls, mp = all_cls[-1], all_masks[-1]
+        res = {"output_voxels": [self._output_voxels(cls, mp, img_metas[0]["occ_size"])],
+               "output_points": None}
+        if points is not None:
+            res["output_points"] = self.forward_lidarseg(cls, mp, points, img_metas)
+        return res
+
+
+@HEADS.register_module()
+class Mask2FormerOccHead(_Mask2FormerOccBase):
+    # -- mask2former_occ.py:673-703
+    def simple_test(self, voxel_feats, img_metas, **kwargs):
+        all_cls, all_masks = self(voxel_feats, img_metas)
+        return {"output_voxels": [self._output_voxels(all_cls[-1], all_masks[-1], img_metas[0]["occ_size"])],
+                "output_points": None}
