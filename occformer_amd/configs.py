@@ -1,0 +1,82 @@
+"""Config dicts with the structure and values of the reference's
+projects/configs/occformer_nusc/occformer_nusc_r50_256x704.py (:17-205), generated for a
+chosen voxel grid.  ``grid='reference'`` is the shipped 128x128x16 LSS grid (256x256x32
+output); ``grid='200'`` is BASELINE.json's 200x200x16 synthetic grid
+(point_cloud_range [-50,-50,-5,50,50,3], occ_size [400,400,32]).
+The reference's own .py configs load through ``occformer_amd.registry.Config.fromfile``.
+"""
+
+
+def nusc_r50(grid="200", with_image_branch=False, num_queries=100):
+    if grid == "reference":
+        pc_range, occ_size = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], [256, 256, 32]
+    elif grid == "200":
+        pc_range, occ_size = [-50.0, -50.0, -5.0, 50.0, 50.0, 3.0], [400, 400, 32]
+    else:
+        raise KeyError(grid)
+    ds = [2, 2, 2]
+    vs = [(pc_range[3 + i] - pc_range[i]) / occ_size[i] for i in range(3)]
+    data_config = dict(cams=["CAM_FRONT_LEFT", "CAM_FRONT", "CAM_FRONT_RIGHT", "CAM_BACK_LEFT", "CAM_BACK",
+                             "CAM_BACK_RIGHT"], Ncams=6, input_size=(256, 704), src_size=(900, 1600))
+    grid_config = dict(xbound=[pc_range[0], pc_range[3], vs[0] * ds[0]],
+                       ybound=[pc_range[1], pc_range[4], vs[1] * ds[1]],
+                       zbound=[pc_range[2], pc_range[5], vs[2] * ds[2]], dbound=[2.0, 58.0, 0.5])
+    numC_Trans = 128
+    ch = [128, 256, 512, 1024]
+    E = 192
+    norm_cfg = dict(type="GN", num_groups=32, requires_grad=True)
+    num_class = 17
+    model = dict(
+        type="OccupancyFormer",
+        img_view_transformer=dict(type="ViewTransformerLiftSplatShootVoxel", loss_depth_weight=1.0,
+                                  grid_config=grid_config, data_config=data_config, numC_Trans=numC_Trans,
+                                  vp_megvii=False),
+        img_bev_encoder_backbone=dict(type="OccupancyEncoder", num_stage=4, in_channels=numC_Trans,
+                                      block_numbers=[2, 2, 2, 2], block_inplanes=ch,
+                                      block_strides=[1, 2, 2, 2], out_indices=(0, 1, 2, 3), with_cp=True,
+                                      norm_cfg=norm_cfg),
+        img_bev_encoder_neck=dict(
+            type="MSDeformAttnPixelDecoder3D", strides=[2, 4, 8, 16], in_channels=ch, feat_channels=E,
+            out_channels=E, norm_cfg=norm_cfg,
+            encoder=dict(type="DetrTransformerEncoder", num_layers=6,
+                         transformerlayers=dict(
+                             type="BaseTransformerLayer",
+                             attn_cfgs=dict(type="MultiScaleDeformableAttention3D", embed_dims=E, num_heads=8,
+                                            num_levels=3, num_points=4, im2col_step=64, dropout=0.0,
+                                            batch_first=False, norm_cfg=None, init_cfg=None),
+                             ffn_cfgs=dict(embed_dims=E), feedforward_channels=E * 4, ffn_dropout=0.0,
+                             operation_order=("self_attn", "norm", "ffn", "norm")),
+                         init_cfg=None),
+            positional_encoding=dict(type="SinePositionalEncoding3D", num_feats=E // 3, normalize=True)),
+        pts_bbox_head=dict(
+            type="Mask2FormerNuscOccHead", feat_channels=E, out_channels=E, num_queries=num_queries,
+            num_occupancy_classes=num_class, pooling_attn_mask=True, sample_weight_gamma=0.25,
+            positional_encoding=dict(type="SinePositionalEncoding3D", num_feats=E / 3, normalize=True),
+            transformer_decoder=dict(
+                type="DetrTransformerDecoder", return_intermediate=True, num_layers=9,
+                transformerlayers=dict(
+                    type="DetrTransformerDecoderLayer",
+                    attn_cfgs=dict(type="MultiheadAttention", embed_dims=E, num_heads=E // 32, attn_drop=0.0,
+                                   proj_drop=0.0, dropout_layer=None, batch_first=False),
+                    ffn_cfgs=dict(embed_dims=E, num_fcs=2, act_cfg=dict(type="ReLU", inplace=True),
+                                  ffn_drop=0.0, dropout_layer=None, add_identity=True),
+                    feedforward_channels=E * 8,
+                    operation_order=("cross_attn", "norm", "self_attn", "norm", "ffn", "norm")),
+                init_cfg=None),
+            loss_cls=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=2.0, reduction="mean",
+                          class_weight=[1.0] * num_class + [0.1]),
+            loss_mask=dict(type="CrossEntropyLoss", use_sigmoid=True, reduction="mean", loss_weight=5.0),
+            loss_dice=dict(type="DiceLoss", use_sigmoid=True, activate=True, reduction="mean",
+                           naive_dice=True, eps=1.0, loss_weight=5.0),
+            point_cloud_range=pc_range),
+    )
+    if with_image_branch:
+        model["img_backbone"] = dict(type="ResNet", depth=50, num_stages=4, out_indices=(0, 1, 2, 3),
+                                     frozen_stages=0, norm_cfg=dict(type="BN", requires_grad=True),
+                                     norm_eval=False, style="pytorch")
+        model["img_neck"] = dict(type="SECONDFPN", in_channels=[256, 512, 1024, 2048],
+                                 upsample_strides=[0.25, 0.5, 1, 2], out_channels=[128, 128, 128, 128])
+    meta = dict(pc_range=pc_range, occ_size=occ_size, D=112, C=numC_Trans, groups=32, heads=E // 32,
+                fH=16, fW=44, neck_channels=512, ncams=6, grid=tuple(o // d for o, d in zip(occ_size, ds)),
+                focal=557.0, input_size=(256, 704))
+    return model, meta
