@@ -1,0 +1,24 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, smoke, bench, rocprof kernel trace.  Everything is logged
+# under gpurun_out/ (merged back by gpurun).  Each step has its own timeout.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/${1:-run}
+mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+echo "== rocminfo" ; (rocminfo | grep -E "Marketing Name|gfx" | head -4) 2>&1
+echo "== pytest -m gpu"
+timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_gpu.log 2>&1 ; echo "pytest rc=$?" ; tail -15 $O/pytest_gpu.log
+echo "== smoke"
+timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1 ; echo "smoke rc=$?" ; tail -4 $O/smoke.log
+echo "== bench"
+timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --check > $O/bench.json 2> $O/bench.err ; echo "bench rc=$?" ; tail -3 $O/bench.err ; cat $O/bench.json
+echo "== rocprof kernel trace"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof.log 2>&1 ; echo "rocprof rc=$?" ; tail -2 $O/prof.log
+cd $R
+python scripts/summarize_prof.py $O/prof > $O/kernel_stats.txt 2>&1 ; head -40 $O/kernel_stats.txt
+# keep the merged-back artefacts small
+find $O/prof -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
+du -sh $O
