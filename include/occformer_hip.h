@@ -118,6 +118,58 @@ int occf_upsample_classify_fwd(const float* mask_pred, const float* cls, float* 
 int occf_lidarseg_sample_fwd(const float* mask_pred, const float* cls, const float* pts, float* out,
                              int P, int B, int Q, int K, int X, int Y, int Z, void* stream);
 
+/* ------------------------------------------------------------------ dense contractions - */
+
+/* out[M, N] = act(x[M, K] @ weight[N, K]^T + bias[N]) + residual[M, N]  on the fp32 matrix
+ * cores (v_mfma_f32_32x32x2_f32).  Replaces nn.Linear / mmcv FFN / the 1x1x1 convolutions on
+ * channels-last tokens (e.g. P/occformer/backbones/modules/window_attention.py:63-66,336-344;
+ * P/occformer/mask2former/mask2former_nusc_occ.py:448-455).  bias/residual may be NULL;
+ * act: 0 none, 1 ReLU, 2 exact GELU; ldx/ldo/ldr = row strides in floats; K % 4 == 0. */
+int occf_linear_fwd(const float* x, const float* weight, const float* bias, const float* residual,
+                    float* out, long M, int N, int K, long ldx, long ldo, long ldr, int act,
+                    void* stream);
+
+/* Implicit-GEMM convolution over a channels-last volume (nn.Conv3d / nn.Conv2d as Zi = kZ = 1):
+ * x[B, Xi, Yi, Zi, Cin] addressed by element strides (in_sb, in_sx, in_sy, in_sz; channel stride
+ * 1), weight_tapmajor[Cout, kX*kY*kZ*Cin] (k = ((dx*kY + dy)*kZ + dz)*Cin + cin), zero padding,
+ * out[B*Xo*Yo*Zo, Cout] channels-last; same epilogue as occf_linear_fwd.  Replaces the 3^3 / 1^3
+ * convolutions of P/occformer/backbones/dualpath_block.py:36-48 and
+ * P/occformer/necks/multiscale_deformattn_3d.py:70-116.  Cin % 4 == 0 (fast path Cin % 16 == 0). */
+int occf_conv3d_fwd(const float* x, const float* weight_tapmajor, const float* bias,
+                    const float* residual, float* out, int B, int Xi, int Yi, int Zi, int Cin, int Cout,
+                    int kX, int kY, int kZ, int stride, int dil, int pad_x, int pad_y, int pad_z,
+                    long in_sb, long in_sx, long in_sy, long in_sz, int act, void* stream);
+
+/* ------------------------------------------------------------------ norms / fusion ----- */
+
+/* GroupNorm over channels-last x[B, V, C] (nn.GroupNorm, eps inside the sqrt): stats[B, G, 2] =
+ * (mean, rstd); deterministic two-stage reduction.  workspace: occf_groupnorm_workspace floats. */
+long occf_groupnorm_workspace(int B, long V, int C, int G);
+int occf_groupnorm_stats(const float* x, float* stats, float* workspace, int B, long V, int C, int G,
+                         float eps, void* stream);
+/* y = (x - mean) * rstd * gamma + beta [ReLU] [+ residual];  x[B, P, Z, C] -> out[B, P, Zs, C].
+ * tokens = 1: Zs = Z + 1 and slot Z = mean_z(y): builds the dual-path token buffer (the Z height
+ * slices plus the BEV slice, dualpath_block.py:70-76) in the same pass. */
+int occf_groupnorm_apply(const float* x, const float* stats, const float* gamma, const float* beta,
+                         const float* residual, float* out, int B, long P, int Z, int C, int G, int relu,
+                         int tokens, void* stream);
+
+/* Row LayerNorm (nn.LayerNorm over the last dim), x[M, C] -> out[M, C], C <= 1024. */
+int occf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* out, long M, int C,
+                       float eps, void* stream);
+
+/* Dual-path fusion (dualpath_block.py:79-82): out = tok + sigmoid(<tok, w> + b) * bev + identity.
+ * tokens[BP, Z+1, C], bev[BP, C], identity/out[BP, Z, C]; coeff_bias: device scalar or NULL. */
+int occf_dualpath_combine(const float* tokens, const float* bev, const float* coeff_weight,
+                          const float* coeff_bias, const float* identity, float* out, long BP, int Z, int C,
+                          void* stream);
+
+/* FPN top-down step (P/occformer/necks/multiscale_deformattn_3d.py:233-243):
+ * out = lateral + trilinear_upsample(coarse -> lateral's size, align_corners=False); channels-last
+ * coarse[B, X, Y, Z, C], lateral/out[B, X2, Y2, Z2, C]. */
+int occf_upsample_add(const float* coarse, const float* lateral, float* out, int B, int X, int Y, int Z,
+                      int X2, int Y2, int Z2, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

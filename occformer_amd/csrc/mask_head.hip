@@ -15,35 +15,58 @@
 // (== pooled logit < 0).  mask_pred [BQ, X, Y, Z] (z fastest).  Writes the pooled logits
 // [BQ, L] (L = ox*oy*oz), the blocked bytes [BQ, L] (1 = key may NOT be attended) and ORs
 // row_open[bq] = 1 when at least one key of the row is open (feeds the all-masked fix).
+__device__ __forceinline__ float occf_nanmax(float m, float v) { return (v > m || v != v) ? v : m; }
+
+// Workgroup = (bq, output x-cell).  Phase 1: the x-window is a contiguous run of
+// (x1-x0)*Y*Z floats; every thread owns float4 columns (y, z..z+3) and folds the window's
+// x-planes into them (fully coalesced 16-byte reads).  Phase 2: the Y*Z column maxima sit in
+// LDS and one thread per output cell folds its (y, z) window.
 __global__ void __launch_bounds__(256) mask_pool_kernel(
     const float* __restrict__ mask_pred, float* __restrict__ pooled, uint8_t* __restrict__ blocked,
     int* __restrict__ row_open, long BQ, int X, int Y, int Z, int ox, int oy, int oz) {
-  const long L = (long)ox * oy * oz;
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= BQ * L) return;
-  const long bq = gid / L;
-  const int cell = (int)(gid % L);
-  const int cz = cell % oz, cy = (cell / oz) % oy, cx = cell / (oz * oy);
-  // adaptive pooling window: [floor(i*in/out), ceil((i+1)*in/out))
+  OCCF_DYN_SMEM(smem);
+  float* col = (float*)smem;                       // [Y*Z]
+  const long bq = blockIdx.x / ox;
+  const int cx = (int)(blockIdx.x % ox);
   const int x0 = (int)(((long)cx * X) / ox), x1 = (int)((((long)cx + 1) * X + ox - 1) / ox);
-  const int y0 = (int)(((long)cy * Y) / oy), y1 = (int)((((long)cy + 1) * Y + oy - 1) / oy);
-  const int z0 = (int)(((long)cz * Z) / oz), z1 = (int)((((long)cz + 1) * Z + oz - 1) / oz);
-  const float* src = mask_pred + bq * (long)X * Y * Z;
-  float m = -INFINITY;
-  for (int x = x0; x < x1; ++x)
-    for (int y = y0; y < y1; ++y) {
-      const float* row = src + ((long)x * Y + y) * Z;
-      for (int z = z0; z < z1; ++z) {
-        const float v = row[z];
-        m = (v > m || v != v) ? v : m;     // NaN propagates like torch's max-pool
+  const int YZ = Y * Z;
+  const float* src = mask_pred + bq * (long)X * YZ;
+  if ((YZ & 3) == 0) {
+    for (int e = threadIdx.x * 4; e < YZ; e += blockDim.x * 4) {
+      float4 m = *(const float4*)(src + (long)x0 * YZ + e);
+      for (int x = x0 + 1; x < x1; ++x) {
+        const float4 v = *(const float4*)(src + (long)x * YZ + e);
+        m.x = occf_nanmax(m.x, v.x); m.y = occf_nanmax(m.y, v.y);
+        m.z = occf_nanmax(m.z, v.z); m.w = occf_nanmax(m.w, v.w);
       }
+      *(float4*)(col + e) = m;
     }
-  pooled[gid] = m;
-  // sigmoid(m) < 0.5, evaluated as the reference does (fp32 sigmoid, then compare)
-  const float sg = 1.0f / (1.0f + expf(-m));
-  const bool blk = sg < 0.5f;
-  blocked[gid] = blk ? 1 : 0;
-  if (!blk) atomicOr((unsigned*)&row_open[bq], 1u);
+  } else {
+    for (int e = threadIdx.x; e < YZ; e += blockDim.x) {
+      float m = src[(long)x0 * YZ + e];
+      for (int x = x0 + 1; x < x1; ++x) m = occf_nanmax(m, src[(long)x * YZ + e]);
+      col[e] = m;
+    }
+  }
+  __syncthreads();
+  const long L = (long)ox * oy * oz;
+  bool any_open = false;
+  for (int c = threadIdx.x; c < oy * oz; c += blockDim.x) {
+    const int cz = c % oz, cy = c / oz;
+    const int y0 = (int)(((long)cy * Y) / oy), y1 = (int)((((long)cy + 1) * Y + oy - 1) / oy);
+    const int z0 = (int)(((long)cz * Z) / oz), z1 = (int)((((long)cz + 1) * Z + oz - 1) / oz);
+    float m = -INFINITY;
+    for (int y = y0; y < y1; ++y)
+      for (int z = z0; z < z1; ++z) m = occf_nanmax(m, col[y * Z + z]);
+    const long o = bq * L + ((long)cx * oy + cy) * oz + cz;
+    pooled[o] = m;
+    // sigmoid(m) < 0.5, evaluated as the reference does (fp32 sigmoid, then compare)
+    const float sg = 1.0f / (1.0f + expf(-m));
+    const bool blk = sg < 0.5f;
+    blocked[o] = blk ? 1 : 0;
+    any_open |= !blk;
+  }
+  if (any_open) atomicOr((unsigned*)&row_open[bq], 1u);
 }
 
 extern "C" int occf_mask_pool_fwd(const float* mask_pred, float* pooled, uint8_t* blocked,
@@ -58,9 +81,9 @@ extern "C" int occf_mask_pool_fwd(const float* mask_pred, float* pooled, uint8_t
 #else
   memset(row_open, 0, sizeof(int32_t) * BQ);
 #endif
-  const long total = BQ * ox * oy * oz;
-  hipLaunchKernelGGL(mask_pool_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, mask_pred, pooled,
-                     blocked, (int*)row_open, BQ, X, Y, Z, ox, oy, oz);
+  if (BQ * ox >= 2147483647L || (long)Y * Z * 4 > 160 * 1024) return OCCF_ESHAPE;
+  hipLaunchKernelGGL(mask_pool_kernel, dim3((unsigned)(BQ * ox)), dim3(256), (size_t)Y * Z * sizeof(float), st,
+                     mask_pred, pooled, blocked, (int*)row_open, BQ, X, Y, Z, ox, oy, oz);
   OCCF_LAUNCH_CHECK();
 }
 

@@ -11,9 +11,11 @@ rearrange / cat / permute().contiguous() round trips; windows, padding and the c
 are index arithmetic inside the window-attention kernel (csrc/window_attn.hip).
 """
 import torch
+import torch.utils.checkpoint
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused
 from .ops import get_ops
 from .registry import BACKBONES
 
@@ -87,24 +89,19 @@ class SwinBlock(nn.Module):
         self.ffn = _FFN(embed_dims, feedforward_channels)
         self.drop_path_rate = drop_path_rate
 
-    def _drop_path(self, y, B, S):
-        """stochastic depth per (batch, slice) 'sample' of the reference's (b z) batch"""
-        if not self.training or self.drop_path_rate == 0.0:
-            return y
-        keep = 1.0 - self.drop_path_rate
-        mask = (keep + torch.rand(B, 1, 1, S, 1, device=y.device, dtype=y.dtype)).floor()
-        return (y.view(B, -1, 1, S, y.shape[-1]) / keep * mask.view(B, 1, 1, S, 1)).view_as(y)
-
     def forward(self, tok):
+        """tok [B, X, Y, S, C] contiguous -> same shape.  LN / qkv / proj+residual / FFN(+GELU,
+        +residual) all run in the HIP kernels; DropPath is the identity in eval mode."""
+        fused.require_eval(self)
         B, X, Y, S, C = tok.shape
         t = tok.reshape(-1, C)
         m = self.attn.w_msa
-        qkv = m.qkv(self.norm1(t))
-        a = get_ops().window_attention(qkv, m.qkv.bias.detach().contiguous(),
-                                       m.relative_position_bias_table.detach().contiguous(), B, X, Y, S,
-                                       self.heads, self.attn.shift_size)
-        t = t + self._drop_path(m.proj(a), B, S)
-        t = t + self._drop_path(self.ffn(self.norm2(t)), B, S)
+        qkv = fused.linear(fused.layernorm(t, self.norm1), m.qkv)
+        a = get_ops().window_attention(qkv, m.qkv.bias.detach(), m.relative_position_bias_table.detach(),
+                                       B, X, Y, S, self.heads, self.attn.shift_size)
+        t = fused.linear(a, m.proj, residual=t)
+        h = fused.linear(fused.layernorm(t, self.norm2), self.ffn.layers[0][0], act=2)
+        t = fused.linear(h, self.ffn.layers[1], residual=t)
         return t.view(B, X, Y, S, C)
 
 
@@ -116,12 +113,12 @@ class _AtrousGN(nn.Module):
         self.bn = nn.GroupNorm(groups, cout)      # named 'bn' in the reference, GroupNorm in practice
         nn.init.kaiming_normal_(self.atrous_conv.weight)
 
-    def forward(self, x):
-        return F.relu(self.bn(self.atrous_conv(x)))
+    def forward(self, x_cl):
+        return fused.group_norm(fused.conv(x_cl, self.atrous_conv), self.bn, relu=True)
 
 
 class _ASPP(nn.Module):
-    """aspp.py:49-122."""
+    """aspp.py:49-122 on channels-last BEV maps [B, X, Y, 1, C]."""
 
     def __init__(self, ch, groups, dilations, dropout):
         super().__init__()
@@ -135,10 +132,16 @@ class _ASPP(nn.Module):
         self.bn1 = nn.GroupNorm(groups, ch)
         self.dropout = nn.Dropout(dropout)
 
-    def forward(self, x):
-        g = self.global_avg_pool(x).expand(-1, -1, *x.shape[2:])   # bilinear from 1x1 == broadcast
-        y = torch.cat((self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), g), 1)
-        return x + self.dropout(F.relu(self.bn1(self.conv1(y))))
+    def forward(self, x_cl):
+        B, X, Y, _, C = x_cl.shape
+        # image-level branch: mean over (X, Y) -> 1x1 conv -> GN -> ReLU -> broadcast
+        # (bilinear upsampling of a 1x1 map with align_corners=True is a broadcast)
+        g = x_cl.mean((1, 2), keepdim=True)
+        g = F.relu(self.global_avg_pool[2](self.global_avg_pool[1](g.reshape(B, C, 1, 1))))
+        g = g.view(B, 1, 1, 1, C).expand(B, X, Y, 1, C)
+        y = torch.cat((self.aspp1(x_cl), self.aspp2(x_cl), self.aspp3(x_cl), self.aspp4(x_cl), g), -1)
+        y = fused.group_norm(fused.conv(y, self.conv1), self.bn1, relu=True, residual=x_cl)
+        return y                                   # = x + dropout(relu(gn(conv1(cat))))  (eval)
 
 
 class BottleNeckASPP(nn.Module):
@@ -156,8 +159,13 @@ class BottleNeckASPP(nn.Module):
         self.output_conv = nn.Sequential(nn.Conv2d(ch, inplanes, 1, bias=False),
                                          nn.GroupNorm(groups, inplanes), nn.ReLU(inplace=True))
 
-    def forward(self, x):
-        return x + self.output_conv(self.aspp(self.input_conv(x)))
+    def forward(self, x_cl):
+        """x_cl [B, X, Y, 1, C] (any row stride) -> contiguous [B, X, Y, 1, C]."""
+        fused.require_eval(self)
+        y = fused.group_norm(fused.conv(x_cl, self.input_conv[0]), self.input_conv[1], relu=True)
+        y = self.aspp(y)
+        return fused.group_norm(fused.conv(y, self.output_conv[0]), self.output_conv[1], relu=True,
+                                residual=x_cl.contiguous())
 
 
 # ------------------------------------------------------------------ the block and the encoder
@@ -183,18 +191,25 @@ class DualpathTransformerBlock(nn.Module):
         self.combine_coeff = nn.Conv3d(channels, 1, 1, bias=coeff_bias)
 
     def forward(self, x):
-        y = self.input_conv(x)                                           # [B, C, X, Y, Z]
-        B, C, X, Y, Z = y.shape
-        ycl = y.permute(0, 2, 3, 4, 1)                                   # [B, X, Y, Z, C]
-        tok = torch.cat((ycl, ycl.mean(3, keepdim=True)), 3).contiguous()   # slot Z = BEV mean
+        """x logical [B, Cin, X, Y, Z] -> logical [B, C, X', Y', Z'] over channels-last memory."""
+        fused.require_eval(self)
+        if not isinstance(self.input_conv[1], nn.GroupNorm):
+            raise NotImplementedError("the HIP path implements the GroupNorm blocks of the OccFormer configs")
+        ops = get_ops()
+        x_cl = fused.channels_last_view(x.float())
+        raw = fused.conv(x_cl, self.input_conv[0])                                  # 3^3 implicit GEMM
+        tok = fused.group_norm(raw, self.input_conv[1], relu=True, tokens=True)     # [B,X,Y,Z+1,C]
+        Z = tok.shape[3] - 1
         tok = self.bev_encoder(tok)
-        sl = tok[:, :, :, :Z]
-        bev = self.aspp(tok[:, :, :, Z].permute(0, 3, 1, 2))             # [B, C, X, Y]
-        w = self.combine_coeff.weight.view(1, C)
-        coeff = torch.sigmoid(F.linear(sl, w, self.combine_coeff.bias))  # [B, X, Y, Z, 1]
-        out = sl + coeff * bev.permute(0, 2, 3, 1).unsqueeze(3)
-        ident = self.downsample(x)
-        return out.permute(0, 4, 1, 2, 3) + ident
+        bev = self.aspp(tok[:, :, :, Z:Z + 1])                                      # [B,X,Y,1,C]
+        if self.stride > 1:
+            ident = fused.group_norm(fused.conv(x_cl, self.downsample[0]), self.downsample[1])
+        else:
+            ident = x_cl
+        cw = self.combine_coeff
+        out = ops.dualpath_combine(tok, bev.reshape(*bev.shape[:3], -1), cw.weight.detach().reshape(-1),
+                                   None if cw.bias is None else cw.bias.detach(), ident)
+        return out.permute(0, 4, 1, 2, 3)
 
 
 @BACKBONES.register_module()

@@ -1,0 +1,67 @@
+"""Host-side helpers that bind nn.Module parameters (kept in the reference's layout and
+names for checkpoint compatibility) to the channels-last HIP kernels."""
+import torch
+
+from .ops import get_ops
+
+_TAP_CACHE = {}
+
+
+def tap_major(conv):
+    """Conv weight [Cout, Cin, kX, kY(, kZ)] -> [Cout, taps*Cin] (k = tap*Cin + cin), cached
+    until the parameter is modified (optimizer step / load_state_dict bump ``_version``)."""
+    w = conv.weight
+    key = id(conv)
+    ver = (w._version, w.data_ptr(), w.device)
+    hit = _TAP_CACHE.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    wd = w.detach()
+    if wd.dim() == 4:
+        wd = wd.unsqueeze(-1)
+    t = wd.permute(0, 2, 3, 4, 1).reshape(wd.shape[0], -1).contiguous()
+    _TAP_CACHE[key] = (ver, t)
+    return t
+
+
+def channels_last_view(x):
+    """logical [B, C, X, Y, Z] -> [B, X, Y, Z, C] with unit channel stride (copy only if needed)."""
+    v = x.permute(0, 2, 3, 4, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def linear(x, lin, act=0, residual=None):
+    return get_ops().linear(x, lin.weight.detach(), None if lin.bias is None else lin.bias.detach(), act,
+                            residual)
+
+
+def layernorm(x, ln):
+    return get_ops().layernorm(x, ln.weight.detach(), ln.bias.detach(), ln.eps)
+
+
+def conv(x_cl, conv, act=0):
+    """nn.Conv3d / nn.Conv2d module applied to a channels-last [B, X, Y, Z, C] tensor."""
+    ks = tuple(conv.kernel_size) + (1,) * (3 - len(conv.kernel_size))
+    pad = tuple(conv.padding) + (0,) * (3 - len(conv.padding))
+    stride = conv.stride[0]
+    dil = conv.dilation[0]
+    assert all(s == stride for s in conv.stride) and all(d == dil for d in conv.dilation) and conv.groups == 1
+    if ks == (1, 1, 1) and stride == 1 and x_cl.is_contiguous():
+        return get_ops().linear(x_cl, conv.weight.detach().reshape(conv.out_channels, -1),
+                                None if conv.bias is None else conv.bias.detach(), act)
+    return get_ops().conv3d(x_cl, tap_major(conv), ks, stride, dil, pad,
+                            None if conv.bias is None else conv.bias.detach(), act)
+
+
+def group_norm(x_cl, gn, relu=False, tokens=False, residual=None):
+    """nn.GroupNorm module on a contiguous channels-last tensor [B, ..., Z, C]."""
+    ops = get_ops()
+    stats = ops.groupnorm_stats(x_cl, gn.num_groups, gn.eps)
+    return ops.groupnorm_apply(x_cl, stats, gn.weight.detach(), gn.bias.detach(), gn.num_groups, relu, tokens,
+                               residual)
+
+
+def require_eval(module):
+    if module.training:
+        raise NotImplementedError(f"{type(module).__name__}: the HIP forward path is inference-only in this "
+                                  "round (backward kernels are the next scope row); call .eval()")

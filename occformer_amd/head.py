@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused
 from .encoder import _FFN
 from .ops import get_ops
 from .pixel_decoder import SinePositionalEncoding3D
@@ -41,13 +42,13 @@ class _MHA(nn.Module):
 
     def forward(self, query, key, value, query_pos, key_pos, blocked=None, row_open=None):
         E = self.E
-        w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
-        q = F.linear(query + query_pos, w[:E], b[:E])
-        k = F.linear(key + key_pos if key_pos is not None else key, w[E:2 * E], b[E:2 * E])
-        v = F.linear(value, w[2 * E:], b[2 * E:])
-        o = get_ops().masked_attention(q.contiguous(), k.contiguous(), v.contiguous(), self.heads,
-                                       blocked, row_open)
-        return query + self.attn.out_proj(o)
+        ops = get_ops()
+        w, b = self.attn.in_proj_weight.detach(), self.attn.in_proj_bias.detach()
+        q = ops.linear(query + query_pos, w[:E], b[:E])
+        k = ops.linear(key + key_pos if key_pos is not None else key, w[E:2 * E], b[E:2 * E])
+        v = ops.linear(value, w[2 * E:], b[2 * E:])
+        o = ops.masked_attention(q, k, v, self.heads, blocked, row_open)
+        return fused.linear(o, self.attn.out_proj, residual=query.contiguous())
 
 
 class _DecoderLayer(nn.Module):
@@ -61,9 +62,11 @@ class _DecoderLayer(nn.Module):
         self.norms = nn.ModuleList([nn.LayerNorm(E) for _ in range(3)])
 
     def forward(self, q, qpos, key, key_pos, blocked, row_open):
-        q = self.norms[0](self.attentions[0](q, key, key, qpos, key_pos, blocked, row_open))
-        q = self.norms[1](self.attentions[1](q, q, q, qpos, qpos))
-        return self.norms[2](q + self.ffns[0](q))
+        q = fused.layernorm(self.attentions[0](q, key, key, qpos, key_pos, blocked, row_open), self.norms[0])
+        q = fused.layernorm(self.attentions[1](q, q, q, qpos, qpos), self.norms[1])
+        ffn = self.ffns[0].layers
+        y = fused.linear(fused.linear(q, ffn[0][0], act=1), ffn[1], residual=q)
+        return fused.layernorm(y, self.norms[2])
 
 
 class _Decoder(nn.Module):
@@ -130,11 +133,18 @@ class _Mask2FormerOccBase(nn.Module):
     def forward_head(self, decoder_out, mask_feat_tok, vol_shape, target_shape):
         """decoder_out [B, Q, E]; mask_feat_tok [B, V, E] channels-last tokens.
         Returns cls [B,Q,K+1], mask_pred [B,Q,X,Y,Z], (blocked u8 [B,Q,L], row_open)."""
-        d = self.transformer_decoder.post_norm(decoder_out)
-        cls_pred = self.cls_embed(d)
-        mask_embed = self.mask_embed(d)
+        ops = get_ops()
+        d = fused.layernorm(decoder_out.contiguous(), self.transformer_decoder.post_norm)
+        cls_pred = fused.linear(d, self.cls_embed)
+        me = self.mask_embed
+        mask_embed = fused.linear(fused.linear(fused.linear(d, me[0], act=1), me[2], act=1), me[4])
         B, Q = mask_embed.shape[:2]
-        mask_pred = torch.matmul(mask_embed, mask_feat_tok.transpose(1, 2)).view(B, Q, *vol_shape)
+        # einsum('bqc,bcxyz->bqxyz'): per batch a [Q, E] x [V, E]^T GEMM whose "weight" is the
+        # channels-last mask feature itself
+        mask_pred = torch.empty((B, Q, mask_feat_tok.shape[1]), dtype=d.dtype, device=d.device)
+        for b in range(B):
+            ops.linear(mask_embed[b], mask_feat_tok[b], out=mask_pred[b])
+        mask_pred = mask_pred.view(B, Q, *vol_shape)
         _, blocked, row_open = get_ops().mask_pool(mask_pred.detach(), target_shape)
         return cls_pred, mask_pred, (blocked, row_open)
 
@@ -144,12 +154,12 @@ class _Mask2FormerOccBase(nn.Module):
         memories = voxel_feats[:0:-1]
         B, E = mask_features.shape[:2]
         vol_shape = tuple(mask_features.shape[-3:])
-        mask_tok = mask_features.permute(0, 2, 3, 4, 1).reshape(B, -1, E)
+        mask_tok = fused.channels_last_view(mask_features.float()).reshape(B, -1, E)
         keys, key_pos, shapes = [], [], []
         for i in range(self.num_transformer_feat_level):
             m = self.decoder_input_projs[i](memories[i])
             shp = tuple(m.shape[-3:])
-            t = m.permute(0, 2, 3, 4, 1).reshape(B, -1, E) + self.level_embed.weight[i]
+            t = fused.channels_last_view(m.float()).reshape(B, -1, E) + self.level_embed.weight[i]
             keys.append(t)
             key_pos.append(self.decoder_positional_encoding.for_shape(shp, m.device).unsqueeze(0))
             shapes.append(shp)

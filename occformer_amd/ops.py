@@ -23,6 +23,7 @@ class HipOps:
     def __init__(self, lib, strict=True):
         self.lib = lib
         self.strict = strict
+        self.last_flops = 0          # set by the MFMA-bound ops (for bench.py's roofline)
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -163,6 +164,97 @@ class HipOps:
         out = torch.empty((P, K), dtype=mask_pred.dtype, device=mask_pred.device)
         self._call("occf_lidarseg_sample_fwd", self._ptr(mask_pred, self.f32), self._ptr(cls, self.f32),
                    self._ptr(pts, self.f32), self._ptr(out), P, B, Q, K, X, Y, Z, self._stream())
+        return out
+
+    # ------------------------------------------------------------------ dense contractions
+    def linear(self, x, weight, bias=None, act=0, residual=None, out=None):
+        """x [..., K] (rows contiguous along K) @ weight[N, K]^T -> [..., N]."""
+        K = x.shape[-1]
+        N = weight.shape[0]
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        if out is None:
+            out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+        r2 = residual.reshape(-1, N) if residual is not None else None
+        self.last_flops = 2 * M * N * K
+        for t in (x2, out, r2):
+            if t is not None and (t.stride(1) != 1 or (self.strict and not t.is_cuda)):
+                raise OccfError("linear: rows must be channel-contiguous GPU tensors")
+        rp = ctypes.c_void_p(r2.data_ptr()) if r2 is not None else ctypes.c_void_p(0)
+        self._call("occf_linear_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(weight, self.f32), self._ptr(bias),
+                   rp, ctypes.c_void_p(out.data_ptr()), M, N, K, x2.stride(0), out.stride(0),
+                   r2.stride(0) if r2 is not None else 0, int(act), self._stream())
+        return out.view(*x.shape[:-1], N)
+
+    def conv3d(self, x_cl, weight_tap, ksize, stride=1, dil=1, pad=None, bias=None, act=0, residual=None):
+        """x_cl [B, Xi, Yi, Zi, Cin] (any strides with unit channel stride) -> [B, Xo, Yo, Zo, Cout]."""
+        B, Xi, Yi, Zi, Cin = x_cl.shape
+        assert x_cl.stride(4) == 1
+        kX, kY, kZ = ksize
+        if pad is None:
+            pad = tuple(dil * (k - 1) // 2 for k in ksize)
+        Cout = weight_tap.shape[0]
+        Xo = (Xi + 2 * pad[0] - dil * (kX - 1) - 1) // stride + 1
+        Yo = (Yi + 2 * pad[1] - dil * (kY - 1) - 1) // stride + 1
+        Zo = (Zi + 2 * pad[2] - dil * (kZ - 1) - 1) // stride + 1
+        out = torch.empty((B, Xo, Yo, Zo, Cout), dtype=x_cl.dtype, device=x_cl.device)
+        self.last_flops = 2 * B * Xo * Yo * Zo * Cout * kX * kY * kZ * Cin
+        if self.strict and not x_cl.is_cuda:
+            raise OccfError("occformer_amd ops need GPU tensors (no CPU path exists)")
+        self._call("occf_conv3d_fwd", ctypes.c_void_p(x_cl.data_ptr()), self._ptr(weight_tap, self.f32),
+                   self._ptr(bias), self._ptr(residual), self._ptr(out), B, Xi, Yi, Zi, Cin, Cout, kX, kY, kZ,
+                   int(stride), int(dil), pad[0], pad[1], pad[2], x_cl.stride(0), x_cl.stride(1),
+                   x_cl.stride(2), x_cl.stride(3), int(act), self._stream())
+        return out
+
+    # ------------------------------------------------------------------ norms / fusion
+    def groupnorm_stats(self, x_cl, groups, eps=1e-5):
+        """x_cl [B, ..., C] contiguous channels-last -> stats [B, G, 2]."""
+        B, C = x_cl.shape[0], x_cl.shape[-1]
+        V = x_cl.numel() // (B * C)
+        need = self.lib.occf_groupnorm_workspace(B, V, C, groups)
+        ws = torch.empty((need,), dtype=self.f32, device=x_cl.device)
+        stats = torch.empty((B, groups, 2), dtype=self.f32, device=x_cl.device)
+        self._call("occf_groupnorm_stats", self._ptr(x_cl, self.f32), self._ptr(stats), self._ptr(ws), B, V, C,
+                   groups, float(eps), self._stream())
+        return stats
+
+    def groupnorm_apply(self, x_cl, stats, gamma, beta, groups, relu=False, tokens=False, residual=None):
+        """x_cl [B, P..., Z, C]; tokens=True appends the z-mean slot -> [B, P..., Z+1, C]."""
+        B, C, Z = x_cl.shape[0], x_cl.shape[-1], x_cl.shape[-2]
+        P = x_cl.numel() // (B * C * Z)
+        shape = list(x_cl.shape)
+        if tokens:
+            shape[-2] = Z + 1
+        out = torch.empty(shape, dtype=x_cl.dtype, device=x_cl.device)
+        self._call("occf_groupnorm_apply", self._ptr(x_cl, self.f32), self._ptr(stats, self.f32),
+                   self._ptr(gamma, self.f32), self._ptr(beta, self.f32), self._ptr(residual), self._ptr(out),
+                   B, P, Z, C, groups, int(relu), int(tokens), self._stream())
+        return out
+
+    def layernorm(self, x, gamma, beta, eps=1e-5):
+        C = x.shape[-1]
+        out = torch.empty_like(x)
+        self._call("occf_layernorm_fwd", self._ptr(x, self.f32), self._ptr(gamma, self.f32),
+                   self._ptr(beta, self.f32), self._ptr(out), x.numel() // C, C, float(eps), self._stream())
+        return out
+
+    def dualpath_combine(self, tokens, bev, w, b, identity):
+        """tokens [B, X, Y, Z+1, C], bev [B, X, Y, C], identity [B, X, Y, Z, C] -> [B, X, Y, Z, C]."""
+        B, X, Y, Zs, C = tokens.shape
+        out = torch.empty((B, X, Y, Zs - 1, C), dtype=tokens.dtype, device=tokens.device)
+        self._call("occf_dualpath_combine", self._ptr(tokens, self.f32), self._ptr(bev, self.f32),
+                   self._ptr(w, self.f32), self._ptr(b), self._ptr(identity, self.f32), self._ptr(out),
+                   B * X * Y, Zs - 1, C, self._stream())
+        return out
+
+    def upsample_add(self, coarse, lateral):
+        """coarse [B, X, Y, Z, C] trilinearly resized (align_corners=False) onto lateral [B, X2, Y2, Z2, C]."""
+        B, X, Y, Z, C = coarse.shape
+        _, X2, Y2, Z2, _ = lateral.shape
+        out = torch.empty_like(lateral)
+        self._call("occf_upsample_add", self._ptr(coarse, self.f32), self._ptr(lateral, self.f32), self._ptr(out),
+                   B, X, Y, Z, X2, Y2, Z2, C, self._stream())
         return out
 
 

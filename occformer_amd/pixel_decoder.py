@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import fused
 from .encoder import _FFN
 from .ops import get_ops
 from .registry import ATTENTION, NECKS, POSITIONAL_ENCODING
@@ -93,14 +94,28 @@ class MultiScaleDeformableAttention3D(nn.Module):
         nn.init.xavier_uniform_(self.output_proj.weight)
         nn.init.zeros_(self.output_proj.bias)
 
+    def _offset_logit_weights(self):
+        """sampling_offsets and attention_weights share their input: one fused GEMM, N = H*L*P*4."""
+        a, b = self.sampling_offsets, self.attention_weights
+        key = (a.weight._version, b.weight._version, a.bias._version, b.bias._version, a.weight.data_ptr())
+        if getattr(self, "_fused_key", None) != key:
+            self._fused_w = torch.cat((a.weight.detach(), b.weight.detach()), 0).contiguous()
+            self._fused_b = torch.cat((a.bias.detach(), b.bias.detach()), 0).contiguous()
+            self._fused_key = key
+        return self._fused_w, self._fused_b
+
     def forward(self, query, query_pos, level_shapes):
         """query/query_pos [B, Nq, E]; queries are the cells of ``level_shapes`` in order."""
+        fused.require_eval(self)
+        ops = get_ops()
         qp = query + query_pos
-        value = self.value_proj(query)
-        out = get_ops().msda3d(value.contiguous(), self.sampling_offsets(qp).contiguous(),
-                               self.attention_weights(qp).contiguous(), level_shapes, self.num_heads,
-                               self.num_points)
-        return self.dropout(self.output_proj(out)) + query
+        value = fused.linear(query, self.value_proj)
+        w, b = self._offset_logit_weights()
+        ol = ops.linear(qp, w, b)
+        n_off = self.sampling_offsets.out_features
+        out = ops.msda3d(value, ol[..., :n_off].contiguous(), ol[..., n_off:].contiguous(), level_shapes,
+                         self.num_heads, self.num_points)
+        return fused.linear(out, self.output_proj, residual=query)       # dropout = identity (eval)
 
 
 class _EncoderLayer(nn.Module):
@@ -115,8 +130,10 @@ class _EncoderLayer(nn.Module):
         self.norms = nn.ModuleList([nn.LayerNorm(embed_dims), nn.LayerNorm(embed_dims)])
 
     def forward(self, x, pos, level_shapes):
-        x = self.norms[0](self.attentions[0](x, pos, level_shapes))
-        return self.norms[1](x + self.ffns[0](x))
+        x = fused.layernorm(self.attentions[0](x, pos, level_shapes), self.norms[0])
+        ffn = self.ffns[0].layers
+        y = fused.linear(fused.linear(x, ffn[0][0], act=1), ffn[1], residual=x)
+        return fused.layernorm(y, self.norms[1])
 
 
 class _Encoder(nn.Module):
@@ -140,9 +157,9 @@ class _ConvModule(nn.Module):
         self.gn = nn.GroupNorm(groups, cout)
         self.act = act
 
-    def forward(self, x):
-        x = self.gn(self.conv(x))
-        return F.relu(x) if self.act else x
+    def forward(self, x_cl):
+        """channels-last [B, X, Y, Z, Cin] -> contiguous [B, X, Y, Z, Cout]"""
+        return fused.group_norm(fused.conv(x_cl, self.conv), self.gn, relu=self.act)
 
 
 @NECKS.register_module()
@@ -192,15 +209,18 @@ class MSDeformAttnPixelDecoder3D(nn.Module):
             layer.attentions[0].init_weights()
 
     def forward(self, feats):
+        fused.require_eval(self)
+        ops = get_ops()
         B = feats[0].shape[0]
         n_in, n_enc = self.num_input_levels, self.num_encoder_levels
+        feats_cl = [fused.channels_last_view(f.float()) for f in feats]
         toks, poss, shapes = [], [], []
         for i in range(n_enc):
-            f = feats[n_in - 1 - i]
-            y = self.input_convs[i](f)
-            shp = tuple(f.shape[-3:])
+            f = feats_cl[n_in - 1 - i]
+            y = self.input_convs[i](f)                                   # [B, X, Y, Z, E]
+            shp = tuple(f.shape[1:4])
             pe = self.postional_encoding.for_shape(shp, f.device) + self.level_encoding.weight[i]
-            toks.append(y.flatten(2).transpose(1, 2))
+            toks.append(y.reshape(B, -1, y.shape[-1]))
             poss.append(pe.unsqueeze(0).expand(B, -1, -1))
             shapes.append(shp)
         x = torch.cat(toks, 1).contiguous()
@@ -210,12 +230,12 @@ class MSDeformAttnPixelDecoder3D(nn.Module):
         outs, start = [], 0
         for shp in shapes:
             n = shp[0] * shp[1] * shp[2]
-            # logical [B, E, X, Y, Z] over channels-last memory
-            outs.append(x[:, start:start + n].reshape(B, *shp, -1).permute(0, 4, 1, 2, 3))
+            outs.append(x[:, start:start + n].reshape(B, *shp, -1))      # channels-last [B, X, Y, Z, E]
             start += n
         for j, i in enumerate(range(n_in - n_enc - 1, -1, -1)):
-            cur = self.lateral_convs[j](feats[i])
-            y = cur + F.interpolate(outs[-1], size=cur.shape[-3:], mode="trilinear", align_corners=False)
+            cur = self.lateral_convs[j](feats_cl[i])
+            y = ops.upsample_add(outs[-1].contiguous(), cur)
             outs.append(self.output_convs[j](y))
-        outs[-1] = self.mask_feature(outs[-1])
-        return outs[::-1]
+        outs[-1] = fused.conv(outs[-1], self.mask_feature)
+        # logical [B, E, X, Y, Z] views over channels-last memory, fine -> coarse
+        return [o.permute(0, 4, 1, 2, 3) for o in outs[::-1]]

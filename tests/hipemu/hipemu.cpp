@@ -1,6 +1,29 @@
 // TEST-ONLY: fiber scheduler behind tests/hipemu/hipemu.h (see the header).
 #include "hipemu.h"
 
+asm(R"(
+.text
+.globl hipemu_swap
+.type hipemu_swap, @function
+hipemu_swap:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size hipemu_swap, .-hipemu_swap
+)");
+
 namespace hipemu {
 Block* g_blk = nullptr;
 emu_uint3 g_bid;
@@ -28,7 +51,8 @@ void fiber_main() {
     b.arrived = 0;
     b.gen++;
   }
-  swapcontext(&f.ctx, &b.sched);
+  hipemu_swap(&f.sp, b.sched_sp);
+  abort();   // a finished fiber is never resumed
 }
 
 void run_block(void (*entry)(void*), void* arg, dim3 grid, dim3 block, emu_uint3 bid, size_t shmem) {
@@ -55,11 +79,14 @@ void run_block(void (*entry)(void*), void* arg, dim3 grid, dim3 block, emu_uint3
     f.lane = t % WAVE;
     f.wave = t / WAVE;
     b.waves[f.wave].alive++;
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = stacks[t];
-    f.ctx.uc_stack.ss_size = STACK;
-    f.ctx.uc_link = nullptr;
-    makecontext(&f.ctx, (void (*)())fiber_main, 0);
+    // initial frame: 6 callee-saved slots, then the entry address `ret` jumps to, then a fake
+    // return address so that the entry sees a call-aligned stack (rsp % 16 == 8)
+    uintptr_t top = ((uintptr_t)stacks[t] + STACK) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;
+    *--sp = (void*)fiber_main;
+    for (int k = 0; k < 6; ++k) *--sp = nullptr;
+    f.sp = (void*)sp;
   }
   int remaining = nt;
   long spins = 0;
@@ -68,7 +95,7 @@ void run_block(void (*entry)(void*), void* arg, dim3 grid, dim3 block, emu_uint3
     for (int t = 0; t < nt; ++t) {
       if (b.fibers[t].done) continue;
       b.cur = t;
-      swapcontext(&b.sched, &b.fibers[t].ctx);
+      hipemu_swap(&b.sched_sp, b.fibers[t].sp);
       if (b.fibers[t].done) {
         remaining--;
         progressed++;

@@ -10,7 +10,6 @@
 // Model: every thread of a block is a ucontext fiber; blocks run sequentially.
 // __syncthreads and wave collectives are rendezvous points between fibers.
 #pragma once
-#include <ucontext.h>
 
 #include <cmath>
 #include <cstdint>
@@ -41,8 +40,12 @@ struct Wave {
   unsigned gen = 0;
   alignas(16) unsigned char slot[64][64];  // up to 64 B per lane of exchange payload
 };
+// minimal x86-64 context switch (callee-saved registers + stack pointer); ucontext's
+// swapcontext makes a sigprocmask syscall per switch, ~50x slower
+extern "C" void hipemu_swap(void** save_sp, void* load_sp);
+
 struct Fiber {
-  ucontext_t ctx;
+  void* sp = nullptr;
   char* stack = nullptr;
   bool done = false;
   emu_uint3 tid;
@@ -53,7 +56,7 @@ struct Block {
   std::vector<Wave> waves;
   int alive = 0, arrived = 0;
   unsigned gen = 0;
-  ucontext_t sched;
+  void* sched_sp = nullptr;
   int cur = -1;
 };
 extern Block* g_blk;
@@ -64,7 +67,7 @@ extern void (*g_entry)(void*);
 extern void* g_entry_arg;
 
 inline Fiber& cur() { return g_blk->fibers[g_blk->cur]; }
-inline void yield() { swapcontext(&cur().ctx, &g_blk->sched); }
+inline void yield() { hipemu_swap(&cur().sp, g_blk->sched_sp); }
 
 inline void block_sync() {
   Block& b = *g_blk;

@@ -1,0 +1,138 @@
+"""MFMA GEMM / implicit-GEMM conv, GroupNorm, LayerNorm and dual-path fusion kernels against
+plain PyTorch fp32 (the floating-point reference of the same op) and the oracle."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import paramgen
+
+TOL = dict(atol=3e-5, rtol=1e-4)
+
+
+def conv_weight_tapmajor(w):
+    """[Cout, Cin, kX, kY, kZ] -> [Cout, kX*kY*kZ*Cin]"""
+    return w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K,act,use_bias,use_res", [
+    (300, 96, 64, 0, True, False),          # 64x64 tile, ragged M and N
+    (130, 130, 32, 1, True, True),          # asymmetric-tail N > 128
+    (1, 18, 192, 0, True, False),           # single row (decoder-style)
+    (257, 64, 48, 2, False, True),
+])
+def test_linear(be, M, N, K, act, use_bias, use_res):
+    x = paramgen.tensor("x", (M, K), 1)
+    w = paramgen.tensor("w", (N, K), 2, K ** -0.5)           # asymmetric: catches transposes
+    b = paramgen.tensor("b", (N,), 3) if use_bias else None
+    r = paramgen.tensor("r", (M, N), 4) if use_res else None
+    ref = F.linear(x, w, b)
+    ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    if use_res:
+        ref = ref + r
+    out = be.ops.linear(be.to(x), be.to(w), be.to(b) if use_bias else None, act,
+                        be.to(r) if use_res else None).cpu()
+    assert torch.allclose(out, ref, **TOL), float((out - ref).abs().max())
+
+
+def test_linear_identity_asymmetric(be):
+    """A = I with an asymmetric W detects a row/col swap in the MFMA C layout."""
+    K = 64
+    x = torch.eye(K)
+    w = torch.arange(96 * K, dtype=torch.float32).view(96, K) / 100.0
+    out = be.ops.linear(be.to(x), be.to(w)).cpu()
+    assert torch.equal(out, w.t())
+
+
+def test_linear_strided_rows(be):
+    x = paramgen.tensor("xs", (70, 3, 32), 5)
+    w = paramgen.tensor("ws", (40, 32), 5)
+    xv = x[:, 1]                                             # row stride 96
+    out = be.ops.linear(be.to(x)[:, 1], be.to(w)).cpu()
+    assert torch.allclose(out, F.linear(xv, w), **TOL)
+
+
+@pytest.mark.parametrize("shape,cin,cout,k,stride,dil", [
+    ((1, 6, 5, 4), 16, 32, 3, 1, 1),
+    ((2, 8, 8, 4), 32, 48, 3, 2, 1),
+    ((1, 7, 6, 3), 16, 16, 1, 2, 1),
+    ((1, 9, 9, 1), 16, 32, 3, 1, 2),      # 2-D dilated (ASPP style): kZ = 1
+])
+def test_conv3d(be, shape, cin, cout, k, stride, dil):
+    B, X, Y, Z = shape
+    x = paramgen.tensor("cx", (B, cin, X, Y, Z), 1)
+    kz = 1 if Z == 1 else k
+    w = paramgen.tensor("cw", (cout, cin, k, k, kz), 2, (cin * k * k * kz) ** -0.5)
+    b = paramgen.tensor("cb", (cout,), 3)
+    pad = (dil * (k - 1) // 2, dil * (k - 1) // 2, dil * (kz - 1) // 2)
+    ref = F.conv3d(x, w, b, stride=stride, padding=pad, dilation=dil)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous()
+    out = be.ops.conv3d(be.to(x_cl), be.to(conv_weight_tapmajor(w)), (k, k, kz), stride, dil, pad,
+                        bias=be.to(b)).cpu()
+    out = out.permute(0, 4, 1, 2, 3)
+    assert out.shape == ref.shape
+    assert torch.allclose(out, ref, **TOL), float((out - ref).abs().max())
+
+
+def test_conv3d_strided_input_view(be):
+    """input read through strides: the Z height slices of a [B,X,Y,Z+1,C] token buffer"""
+    B, X, Y, Z, C = 1, 5, 4, 3, 16
+    tok = paramgen.tensor("tokv", (B, X, Y, Z + 1, C), 7)
+    w = paramgen.tensor("cw2", (32, C, 3, 3, 3), 7, 0.05)
+    view = tok[:, :, :, :Z]
+    ref = F.conv3d(view.permute(0, 4, 1, 2, 3), w, padding=1)
+    out = be.ops.conv3d(be.to(tok)[:, :, :, :Z], be.to(conv_weight_tapmajor(w)), (3, 3, 3)).cpu()
+    assert torch.allclose(out.permute(0, 4, 1, 2, 3), ref, **TOL)
+
+
+@pytest.mark.parametrize("C,G,shape", [(32, 8, (2, 5, 4, 3)), (192, 32, (1, 6, 6, 2)), (48, 8, (1, 40, 30, 2))])
+def test_groupnorm(be, C, G, shape):
+    B, X, Y, Z = shape
+    x = paramgen.tensor("gx", (B, C, X, Y, Z), 1, 2.0) + 0.5
+    gamma = 1 + 0.2 * paramgen.tensor("gg", (C,), 2)
+    beta = 0.1 * paramgen.tensor("gb", (C,), 3)
+    res = paramgen.tensor("gr", (B, C, X, Y, Z), 4)
+    ref = F.group_norm(x, G, gamma, beta, 1e-5)
+    x_cl = x.permute(0, 2, 3, 4, 1).contiguous()
+    stats = be.ops.groupnorm_stats(be.to(x_cl), G)
+    out = be.ops.groupnorm_apply(be.to(x_cl), stats, be.to(gamma), be.to(beta), G).cpu()
+    assert torch.allclose(out.permute(0, 4, 1, 2, 3), ref, **TOL)
+    # ReLU + token buffer (z-mean slot) + residual variants
+    tok = be.ops.groupnorm_apply(be.to(x_cl), stats, be.to(gamma), be.to(beta), G, relu=True, tokens=True).cpu()
+    r = F.relu(ref).permute(0, 2, 3, 4, 1)
+    assert torch.allclose(tok[..., :Z, :], r, **TOL) and torch.allclose(tok[..., Z, :], r.mean(3), **TOL)
+    outr = be.ops.groupnorm_apply(be.to(x_cl), stats, be.to(gamma), be.to(beta), G,
+                                  residual=be.to(res.permute(0, 2, 3, 4, 1).contiguous())).cpu()
+    assert torch.allclose(outr.permute(0, 4, 1, 2, 3), ref + res, **TOL)
+
+
+@pytest.mark.parametrize("C", [32, 192, 1024])
+def test_layernorm(be, C):
+    x = paramgen.tensor("lx", (37, C), 1, 3.0) + 1.0
+    g = 1 + 0.2 * paramgen.tensor("lg", (C,), 2)
+    b = 0.1 * paramgen.tensor("lb", (C,), 3)
+    out = be.ops.layernorm(*be.to(x, g, b)).cpu()
+    assert torch.allclose(out, F.layer_norm(x, (C,), g, b, 1e-5), **TOL)
+
+
+def test_dualpath_combine(be):
+    B, X, Y, Z, C = 2, 3, 4, 5, 64
+    tok = paramgen.tensor("ct", (B, X, Y, Z + 1, C), 1)
+    bev = paramgen.tensor("cb", (B, X, Y, C), 2)
+    w = paramgen.tensor("cw", (C,), 3, 0.3)
+    bias = torch.tensor([0.2])
+    ident = paramgen.tensor("ci", (B, X, Y, Z, C), 4)
+    sl = tok[..., :Z, :]
+    ref = sl + torch.sigmoid((sl * w).sum(-1, keepdim=True) + bias) * bev.unsqueeze(3) + ident
+    out = be.ops.dualpath_combine(*be.to(tok, bev, w, bias, ident)).cpu()
+    assert torch.allclose(out, ref, **TOL)
+
+
+@pytest.mark.parametrize("lo,hi", [((4, 4, 2), (8, 8, 4)), ((3, 5, 2), (7, 9, 5))])
+def test_upsample_add(be, lo, hi):
+    B, C = 2, 16
+    coarse = paramgen.tensor("uc", (B, C, *lo), 1)
+    lat = paramgen.tensor("ul", (B, C, *hi), 2)
+    ref = lat + F.interpolate(coarse, size=hi, mode="trilinear", align_corners=False)
+    out = be.ops.upsample_add(be.to(coarse.permute(0, 2, 3, 4, 1).contiguous()),
+                              be.to(lat.permute(0, 2, 3, 4, 1).contiguous())).cpu()
+    assert torch.allclose(out.permute(0, 4, 1, 2, 3), ref, **TOL)
