@@ -18,7 +18,17 @@ echo "== rocprof kernel trace"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof.log 2>&1 ; echo "rocprof rc=$?" ; tail -2 $O/prof.log
 cd $R
-python scripts/summarize_prof.py $O/prof > $O/kernel_stats.txt 2>&1 ; head -40 $O/kernel_stats.txt
+python scripts/summarize_prof.py $O/prof > $O/kernel_stats.txt 2>&1 ; head -${HEADN:-45} $O/kernel_stats.txt
+if [ "${PMC:-0}" = "1" ]; then
+  echo "== rocprof PMC passes (HBM traffic; separate runs, no tracing domains besides kernel-trace)"
+  cd /tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_$c.log 2>&1 ; echo "pmc $c rc=$?"
+  done
+  cd $R
+  python scripts/summarize_pmc.py $O > $O/pmc_summary.txt 2>&1 ; head -30 $O/pmc_summary.txt
+  find $O -name "*counter_collection.csv" -size +30M -delete 2>/dev/null
+fi
 # keep the merged-back artefacts small
 find $O/prof -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
 du -sh $O

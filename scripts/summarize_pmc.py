@@ -1,0 +1,26 @@
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB units).
+MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced stream,
+so the read side is also shown doubled ('fetch_x2')."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+agg = defaultdict(lambda: defaultdict(float))
+calls = defaultdict(int)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(os.path.join(root, f"pmc_{c}", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") != c:
+                continue
+            k = r["Kernel_Name"]
+            agg[k][c] += float(r["Counter_Value"])
+            if c == "FETCH_SIZE":
+                calls[k] += 1
+print(f"{'kernel':80s} {'calls':>6s} {'fetch_MB/call':>14s} {'fetch_x2':>10s} {'write_MB/call':>14s}")
+for k, v in sorted(agg.items(), key=lambda kv: -(kv[1]['FETCH_SIZE'] + kv[1]['WRITE_SIZE']))[:40]:
+    n = max(calls[k], 1)
+    fe, wr = v["FETCH_SIZE"] * 1024 / n / 1e6, v["WRITE_SIZE"] * 1024 / n / 1e6
+    print(f"{k[:80]:80s} {n:6d} {fe:14.2f} {2 * fe:10.2f} {wr:14.2f}")
