@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
 def synthetic_sample(meta, device, seed=0):
@@ -132,6 +133,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", default="200", choices=["200", "reference"])
+    ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16"],
+                    help="arithmetic of the dense contractions (default: the library default, bf16x3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also report max abs err vs the oracle output")
     args = ap.parse_args()
@@ -151,6 +154,9 @@ def main():
     from occformer_amd.ops import get_ops
     from occformer_amd.registry import build_model
 
+    if args.precision:
+        get_ops().precision = args.precision
+    prec = get_ops().precision
     torch.manual_seed(0)
     cfg, meta = configs.nusc_r50(args.grid)
     model = build_model(cfg).eval().to(device)
@@ -195,8 +201,10 @@ def main():
     kd = kernels[dom]
     if kd["flops_per_call"] > 0:         # MFMA-bound contraction: algorithmic FLOPs / launch time
         achieved = kd["flops_per_call"] / (kd["avg_ms"] * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": F32_MFMA_PEAK_TF,
-                "unit": "TFLOP/s", "frac": achieved / F32_MFMA_PEAK_TF, "traffic": None,
+        peak = F32_MFMA_PEAK_TF if prec == "f32" else BF16_MFMA_PEAK_TF
+        roof = {"bound": "mfma", "kernel": dom, "achieved": achieved, "peak": peak,
+                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                "mfma_products_per_algorithmic_product": {"f32": 1, "bf16x3": 3, "bf16": 1}[prec],
                 "avg_kernel_ms": kd["avg_ms"], "algorithmic_flops_per_launch": kd["flops_per_call"],
                 "launches_per_step": kd["calls"]}
     else:
@@ -209,7 +217,9 @@ def main():
                   "(LSS voxel pooling -> dual-path encoder -> pixel decoder -> occupancy decoder)",
         "value": world * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": {"f32": "f32", "bf16x3": "f32 (contractions as 3-term bf16 split on the bf16 matrix cores, fp32 "
+                  "accumulate)", "bf16": "bf16 products, fp32 accumulate"}[prec], "data": "synthetic",
         "config": {"workload": f"nusc_r50_256x704_6cam_grid{'200x200x16' if args.grid == '200' else '128x128x16'}"
                                "_forward_from_neck_features", "global_batch": world,
                    "parallelism": f"dp{world} (independent samples, no data-path collective)"},

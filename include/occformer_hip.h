@@ -170,6 +170,24 @@ int occf_dualpath_combine(const float* tokens, const float* bev, const float* co
 int occf_upsample_add(const float* coarse, const float* lateral, float* out, int B, int X, int Y, int Z,
                       int X2, int Y2, int Z2, int C, void* stream);
 
+/* ------------------------------------------------------------------ split-bf16 contractions */
+
+/* Same contracts as occf_linear_fwd / occf_conv3d_fwd, products on the bf16 matrix cores
+ * (v_mfma_f32_32x32x16_bf16) with fp32 accumulation.  terms = 3: every operand is split
+ * a = a_hi + a_lo (bf16) and a_hi*b_hi + a_hi*b_lo + a_lo*b_hi is accumulated -- fp32-class
+ * accuracy (~2^-17 rel. per product) at 16/3 of the fp32-MFMA rate; terms = 1: plain bf16 (w_lo may
+ * be NULL).  The weight is given pre-split (occf_split_bf16) as two bf16 arrays [N, K]; the
+ * activation is split while it is staged.  K % 32 == 0 (conv: Cin % 32 == 0). */
+int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
+                         const float* residual, float* out, long M, int N, int K, long ldx, long ldo,
+                         long ldr, int act, int terms, void* stream);
+int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
+                         const float* residual, float* out, int B, int Xi, int Yi, int Zi, int Cin, int Cout,
+                         int kX, int kY, int kZ, int stride, int dil, int pad_x, int pad_y, int pad_z,
+                         long in_sb, long in_sx, long in_sy, long in_sz, int act, int terms, void* stream);
+/* hi = bf16_rne(x), lo = bf16_rne(x - hi), n elements. */
+int occf_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,341 @@
+// Split-bf16 MFMA GEMM / implicit-GEMM convolution for gfx950: fp32 in, fp32 out, fp32
+// accumulate, products on the bf16 matrix cores.
+//
+// gfx950 has no TF32; its fp32 MFMA runs at the vector rate (157 TF).  To keep the reference's
+// fp32 numerics (the whole 3-D path is force_fp32) at matrix-core speed every operand
+// is split as a = a_hi + a_lo (both bf16, a_hi = RNE(a), a_lo = RNE(a - a_hi)) and
+//     a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi                        (TERMS = 3)
+// is accumulated in fp32 by v_mfma_f32_32x32x16_bf16; the dropped a_lo*b_lo term and the
+// rounding of the lo parts are ~2^-17 relative, i.e. fp32-class accuracy at 3 bf16 MFMAs per
+// product = 16/3 of the fp32-MFMA rate.  TERMS = 1 is plain bf16 (fast, ~2^-8).
+//
+// Same contract as gemm.hip (C = epilogue(A(m,:) . W[n,:]), DENSE or CONV3D loader), but the
+// weight comes pre-split as two bf16 arrays [N, K] (static in inference; occf_split_bf16) and
+// the activation is split on the fly while it is staged into LDS.
+//
+// Tiling: 256 threads = 4 waves (2x2), block tile 128 x BN (BN = 128 or 64), BK = 32.
+// LDS rows are 64 B (32 bf16) per operand row with the four 16-B k-slots XOR-swizzled by
+// (row>>2)&3: the ds_read_b128 fragment reads (lane -> row lane&31, k-slot (lane>>5)) and the
+// row-contiguous staging writes are both bank-conflict free.  MFMA operand: lane l supplies
+// 8 consecutive k for row/col l&31 (k-slot l>>5); C/D layout as in gemm.hip.
+#include "occf_common.h"
+#include "../../include/occformer_hip.h"
+
+#define GB_BK 32
+#define GB_BM 128
+
+struct ConvGeomB {
+  int Xo, Yo, Zo, Xi, Yi, Zi, kX, kY, kZ, stride, dil, pad_x, pad_y, pad_z, Cin;
+  long sb, sx, sy, sz;
+};
+struct GemmArgsB {
+  const float* A;
+  const uint16_t* Wh;
+  const uint16_t* Wl;
+  const float* bias;
+  const float* residual;
+  float* C;
+  int M, N, K;
+  long lda, ldc, ldr;
+  int act;
+  ConvGeomB g;
+};
+
+__device__ __forceinline__ uint32_t occf_bf16_rne(float x) {
+#ifdef OCCF_EMU
+  uint32_t u;
+  memcpy(&u, &x, 4);
+#else
+  const uint32_t u = __float_as_uint(x);
+#endif
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float occf_bf16_up(uint32_t h) {
+#ifdef OCCF_EMU
+  uint32_t u = h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+#else
+  return __uint_as_float(h << 16);
+#endif
+}
+// two fp32 -> packed (hi pair, lo pair)
+__device__ __forceinline__ void occf_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const uint32_t ha = occf_bf16_rne(a), hb = occf_bf16_rne(b);
+  const uint32_t la = occf_bf16_rne(a - occf_bf16_up(ha)), lb = occf_bf16_rne(b - occf_bf16_up(hb));
+  hi = ha | (hb << 16);
+  lo = la | (lb << 16);
+}
+__device__ __forceinline__ int occf_lds_slot(int row, int kslot) {   // byte offset inside an operand array
+  return row * 64 + ((kslot ^ ((row >> 2) & 3)) << 4);
+}
+__device__ __forceinline__ float occf_gelu_b(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+struct occf_u4 {
+  uint32_t x, y, z, w;
+};
+
+template <int BN, int TERMS, bool CONV>
+__global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
+  constexpr int TN = BN / 64;                      // 32-wide MFMA tiles per wave along N
+  constexpr int NB = BN * 4 / 256;                 // 16-B weight pieces per thread per array
+  __shared__ __attribute__((aligned(16))) unsigned char Ah[GB_BM * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Al[GB_BM * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Bh[BN * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char Bl[BN * 64];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n_tiles = (p.N + BN - 1) / BN;
+  const long m0 = (long)(blockIdx.x / n_tiles) * GB_BM;
+  const int n0 = (blockIdx.x % n_tiles) * BN;
+
+  // A staging: 4 float4 per thread; 8 consecutive lanes cover one 128-B row segment
+  long a_base[4];
+  int a_x[4], a_y[4], a_z[4], a_m[4], a_kq[4];
+  bool a_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + i * 256;
+    a_m[i] = idx >> 3;
+    a_kq[i] = idx & 7;
+    const long m = m0 + a_m[i];
+    a_ok[i] = m < p.M;
+    if (CONV) {
+      const long mm = a_ok[i] ? m : 0;
+      const int zo = (int)(mm % p.g.Zo);
+      const int yo = (int)((mm / p.g.Zo) % p.g.Yo);
+      const int xo = (int)((mm / ((long)p.g.Zo * p.g.Yo)) % p.g.Xo);
+      const long b = mm / ((long)p.g.Zo * p.g.Yo * p.g.Xo);
+      a_base[i] = b * p.g.sb;
+      a_x[i] = xo * p.g.stride - p.g.pad_x;
+      a_y[i] = yo * p.g.stride - p.g.pad_y;
+      a_z[i] = zo * p.g.stride - p.g.pad_z;
+    } else {
+      a_base[i] = (a_ok[i] ? m : 0) * p.lda;
+      a_x[i] = a_y[i] = a_z[i] = 0;
+    }
+  }
+  long b_base[NB];
+  int b_n[NB], b_slot[NB];
+  bool b_ok[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int idx = tid + i * 256;
+    b_n[i] = idx >> 2;
+    b_slot[i] = idx & 3;
+    const int n = n0 + b_n[i];
+    b_ok[i] = n < p.N;
+    b_base[i] = (long)(b_ok[i] ? n : 0) * p.K;
+  }
+
+  float4 ra[4];
+  occf_u4 rbh[NB], rbl[NB];
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * GB_BK;
+    if (CONV) {
+      const int tap = k0 / p.g.Cin;                 // Cin % 32 == 0: block-uniform tap
+      const int c0 = k0 - tap * p.g.Cin;
+      const int dz = tap % p.g.kZ, dy = (tap / p.g.kZ) % p.g.kY, dx = tap / (p.g.kZ * p.g.kY);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int xi = a_x[i] + dx * p.g.dil, yi = a_y[i] + dy * p.g.dil, zi = a_z[i] + dz * p.g.dil;
+        const bool ok = a_ok[i] && xi >= 0 && xi < p.g.Xi && yi >= 0 && yi < p.g.Yi && zi >= 0 && zi < p.g.Zi;
+        if (ok) {
+          ra[i] = *(const float4*)(p.A + a_base[i] + xi * p.g.sx + yi * p.g.sy + zi * p.g.sz + c0 + a_kq[i] * 4);
+        } else {
+          ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (a_ok[i]) {
+          ra[i] = *(const float4*)(p.A + a_base[i] + k0 + a_kq[i] * 4);
+        } else {
+          ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if (b_ok[i]) {
+        rbh[i] = *(const occf_u4*)(p.Wh + b_base[i] + k0 + b_slot[i] * 8);
+        if (TERMS == 3) rbl[i] = *(const occf_u4*)(p.Wl + b_base[i] + k0 + b_slot[i] * 8);
+      } else {
+        rbh[i] = occf_u4{0, 0, 0, 0};
+        if (TERMS == 3) rbl[i] = occf_u4{0, 0, 0, 0};
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t h0, l0, h1, l1;
+      occf_split2(ra[i].x, ra[i].y, h0, l0);
+      occf_split2(ra[i].z, ra[i].w, h1, l1);
+      const int off = occf_lds_slot(a_m[i], a_kq[i] >> 1) + (a_kq[i] & 1) * 8;
+      *(uint32_t*)(Ah + off) = h0;
+      *(uint32_t*)(Ah + off + 4) = h1;
+      if (TERMS == 3) {
+        *(uint32_t*)(Al + off) = l0;
+        *(uint32_t*)(Al + off + 4) = l1;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int off = occf_lds_slot(b_n[i], b_slot[i]);
+      *(occf_u4*)(Bh + off) = rbh[i];
+      if (TERMS == 3) *(occf_u4*)(Bl + off) = rbl[i];
+    }
+  };
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / GB_BK;
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  const int li = lane & 31, lk = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int kslot = s * 2 + lk;
+      bf16x8 ah[2], al[2], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int off = occf_lds_slot(wm * 64 + i * 32 + li, kslot);
+        ah[i] = *(const bf16x8*)(Ah + off);
+        if (TERMS == 3) al[i] = *(const bf16x8*)(Al + off);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int off = occf_lds_slot(wn * (BN / 2) + j * 32 + li, kslot);
+        bh[j] = *(const bf16x8*)(Bh + off);
+        if (TERMS == 3) bl[j] = *(const bf16x8*)(Bl + off);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (TERMS == 3) {
+            acc[i][j] = occf_mfma_bf16_32x32x16(al[i], bh[j], acc[i][j]);
+            acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bl[j], acc[i][j]);
+          }
+          acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bh[j], acc[i][j]);
+        }
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      store_tile();
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + li;
+      if (n >= p.N) continue;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] + bv;
+        if (p.act == 1) v = fmaxf(v, 0.f);
+        else if (p.act == 2) v = occf_gelu_b(v);
+        if (p.residual) v += p.residual[m * p.ldr + n];
+        p.C[m * p.ldc + n] = v;
+      }
+    }
+  }
+}
+
+template <bool CONV>
+static int launch_gemm_b(const GemmArgsB& a, int terms, hipStream_t st) {
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % GB_BK != 0) return OCCF_ESHAPE;
+  if (terms != 1 && terms != 3) return OCCF_EINVAL;
+  if (terms == 3 && a.Wl == nullptr) return OCCF_EINVAL;
+  const int mt = occf_cdiv(a.M, GB_BM);
+  const bool wide = (a.N % 128 == 0) || a.N > 512;
+  if (wide) {
+    const unsigned grid = (unsigned)((long)mt * occf_cdiv(a.N, 128));
+    if (terms == 3) hipLaunchKernelGGL((gemm_bf16_kernel<128, 3, CONV>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<128, 1, CONV>), dim3(grid), dim3(256), 0, st, a);
+  } else {
+    const unsigned grid = (unsigned)((long)mt * occf_cdiv(a.N, 64));
+    if (terms == 3) hipLaunchKernelGGL((gemm_bf16_kernel<64, 3, CONV>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<64, 1, CONV>), dim3(grid), dim3(256), 0, st, a);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
+                                    const float* bias, const float* residual, float* out, long M, int N,
+                                    int K, long ldx, long ldo, long ldr, int act, int terms, void* stream) {
+  if (M >= 2147483647L || ldx % 4 != 0) return OCCF_ESHAPE;
+  GemmArgsB a = {};
+  a.A = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.C = out;
+  a.M = (int)M; a.N = N; a.K = K; a.lda = ldx; a.ldc = ldo; a.ldr = ldr; a.act = act;
+  return launch_gemm_b<false>(a, terms, (hipStream_t)stream);
+}
+
+extern "C" int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
+                                    const float* bias, const float* residual, float* out, int B, int Xi,
+                                    int Yi, int Zi, int Cin, int Cout, int kX, int kY, int kZ, int stride,
+                                    int dil, int pad_x, int pad_y, int pad_z, long in_sb, long in_sx,
+                                    long in_sy, long in_sz, int act, int terms, void* stream) {
+  if (B <= 0 || Cin % GB_BK != 0 || stride <= 0 || dil <= 0) return OCCF_ESHAPE;
+  if (in_sb % 4 || in_sx % 4 || in_sy % 4 || in_sz % 4) return OCCF_ESHAPE;
+  GemmArgsB a = {};
+  ConvGeomB& g = a.g;
+  g.Xi = Xi; g.Yi = Yi; g.Zi = Zi; g.kX = kX; g.kY = kY; g.kZ = kZ;
+  g.stride = stride; g.dil = dil; g.pad_x = pad_x; g.pad_y = pad_y; g.pad_z = pad_z; g.Cin = Cin;
+  g.Xo = (Xi + 2 * pad_x - dil * (kX - 1) - 1) / stride + 1;
+  g.Yo = (Yi + 2 * pad_y - dil * (kY - 1) - 1) / stride + 1;
+  g.Zo = (Zi + 2 * pad_z - dil * (kZ - 1) - 1) / stride + 1;
+  g.sb = in_sb; g.sx = in_sx; g.sy = in_sy; g.sz = in_sz;
+  const long M = (long)B * g.Xo * g.Yo * g.Zo;
+  if (g.Xo <= 0 || g.Yo <= 0 || g.Zo <= 0 || M >= 2147483647L) return OCCF_ESHAPE;
+  a.A = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.C = out;
+  a.M = (int)M; a.N = Cout; a.K = kX * kY * kZ * Cin; a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.act = act;
+  return launch_gemm_b<true>(a, terms, (hipStream_t)stream);
+}
+
+// fp32 -> (hi, lo) bf16 split of a whole array (weights once per version; the mask features once
+// per forward for the ten mask_embed x mask_feature contractions).
+__global__ void __launch_bounds__(256) split_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ hi,
+                                                         uint16_t* __restrict__ lo, long n) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (i + 1 < n) {
+    uint32_t h, l;
+    occf_split2(x[i], x[i + 1], h, l);
+    *(uint32_t*)(hi + i) = h;
+    *(uint32_t*)(lo + i) = l;
+  } else if (i < n) {
+    uint32_t h, l;
+    occf_split2(x[i], 0.f, h, l);
+    hi[i] = (uint16_t)h;
+    lo[i] = (uint16_t)l;
+  }
+}
+
+extern "C" int occf_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, long n, void* stream) {
+  if (n <= 0) return OCCF_EINVAL;
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(occf_cdiv((n + 1) / 2, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     hi, lo, n);
+  OCCF_LAUNCH_CHECK();
+}

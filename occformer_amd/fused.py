@@ -4,24 +4,44 @@ import torch
 
 from .ops import get_ops
 
+import weakref
+
 _TAP_CACHE = {}
+_SPLIT_CACHE = {}
+
+
+def _versioned(cache, param, make):
+    """value derived from a Parameter, recomputed when the parameter changes (its ``_version``
+    bumps on optimizer steps / load_state_dict) or when ``id(param)`` gets reused."""
+    key = id(param)
+    hit = cache.get(key)
+    ver = (param._version, param.data_ptr())
+    if hit is not None and hit[0] == ver and hit[2]() is param:
+        return hit[1]
+    val = make()
+    cache[key] = (ver, val, weakref.ref(param))
+    return val
+
+
+def split_weight(param, as_2d=None):
+    """(hi, lo) bf16 split of a weight for the bf16 matrix-core path, or None in exact-fp32 mode."""
+    ops = get_ops()
+    if ops.precision == "f32":
+        return None
+    return _versioned(_SPLIT_CACHE, param,
+                      lambda: ops.split_bf16(param.detach() if as_2d is None else as_2d(param.detach())))
+
+
+def _tap_layout(w):
+    if w.dim() == 4:
+        w = w.unsqueeze(-1)
+    return w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1).contiguous()
 
 
 def tap_major(conv):
     """Conv weight [Cout, Cin, kX, kY(, kZ)] -> [Cout, taps*Cin] (k = tap*Cin + cin), cached
-    until the parameter is modified (optimizer step / load_state_dict bump ``_version``)."""
-    w = conv.weight
-    key = id(conv)
-    ver = (w._version, w.data_ptr(), w.device)
-    hit = _TAP_CACHE.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1]
-    wd = w.detach()
-    if wd.dim() == 4:
-        wd = wd.unsqueeze(-1)
-    t = wd.permute(0, 2, 3, 4, 1).reshape(wd.shape[0], -1).contiguous()
-    _TAP_CACHE[key] = (ver, t)
-    return t
+    until the parameter is modified."""
+    return _versioned(_TAP_CACHE, conv.weight, lambda: _tap_layout(conv.weight.detach()))
 
 
 def channels_last_view(x):
@@ -32,7 +52,7 @@ def channels_last_view(x):
 
 def linear(x, lin, act=0, residual=None):
     return get_ops().linear(x, lin.weight.detach(), None if lin.bias is None else lin.bias.detach(), act,
-                            residual)
+                            residual, w_split=split_weight(lin.weight))
 
 
 def layernorm(x, ln):
@@ -46,11 +66,12 @@ def conv(x_cl, conv, act=0):
     stride = conv.stride[0]
     dil = conv.dilation[0]
     assert all(s == stride for s in conv.stride) and all(d == dil for d in conv.dilation) and conv.groups == 1
+    bias = None if conv.bias is None else conv.bias.detach()
     if ks == (1, 1, 1) and stride == 1 and x_cl.is_contiguous():
-        return get_ops().linear(x_cl, conv.weight.detach().reshape(conv.out_channels, -1),
-                                None if conv.bias is None else conv.bias.detach(), act)
-    return get_ops().conv3d(x_cl, tap_major(conv), ks, stride, dil, pad,
-                            None if conv.bias is None else conv.bias.detach(), act)
+        return get_ops().linear(x_cl, conv.weight.detach().reshape(conv.out_channels, -1), bias, act,
+                                w_split=split_weight(conv.weight, lambda w: w.reshape(w.shape[0], -1)))
+    return get_ops().conv3d(x_cl, tap_major(conv), ks, stride, dil, pad, bias, act,
+                            w_split=split_weight(conv.weight, _tap_layout))
 
 
 def group_norm(x_cl, gn, relu=False, tokens=False, residual=None):

@@ -44,9 +44,12 @@ class _MHA(nn.Module):
         E = self.E
         ops = get_ops()
         w, b = self.attn.in_proj_weight.detach(), self.attn.in_proj_bias.detach()
-        q = ops.linear(query + query_pos, w[:E], b[:E])
-        k = ops.linear(key + key_pos if key_pos is not None else key, w[E:2 * E], b[E:2 * E])
-        v = ops.linear(value, w[2 * E:], b[2 * E:])
+        sp = fused.split_weight(self.attn.in_proj_weight)
+        part = (lambda lo, hi: None) if sp is None else (lambda lo, hi: (sp[0][lo:hi], sp[1][lo:hi]))
+        q = ops.linear(query + query_pos, w[:E], b[:E], w_split=part(0, E))
+        k = ops.linear(key + key_pos if key_pos is not None else key, w[E:2 * E], b[E:2 * E],
+                       w_split=part(E, 2 * E))
+        v = ops.linear(value, w[2 * E:], b[2 * E:], w_split=part(2 * E, 3 * E))
         o = ops.masked_attention(q, k, v, self.heads, blocked, row_open)
         return fused.linear(o, self.attn.out_proj, residual=query.contiguous())
 
@@ -130,7 +133,7 @@ class _Mask2FormerOccBase(nn.Module):
                 nn.init.xavier_normal_(p)
 
     # -- mask2former_nusc_occ.py:426-471
-    def forward_head(self, decoder_out, mask_feat_tok, vol_shape, target_shape):
+    def forward_head(self, decoder_out, mask_feat_tok, vol_shape, target_shape, mask_feat_split=None):
         """decoder_out [B, Q, E]; mask_feat_tok [B, V, E] channels-last tokens.
         Returns cls [B,Q,K+1], mask_pred [B,Q,X,Y,Z], (blocked u8 [B,Q,L], row_open)."""
         ops = get_ops()
@@ -143,7 +146,8 @@ class _Mask2FormerOccBase(nn.Module):
         # channels-last mask feature itself
         mask_pred = torch.empty((B, Q, mask_feat_tok.shape[1]), dtype=d.dtype, device=d.device)
         for b in range(B):
-            ops.linear(mask_embed[b], mask_feat_tok[b], out=mask_pred[b])
+            sp = None if mask_feat_split is None else (mask_feat_split[0][b], mask_feat_split[1][b])
+            ops.linear(mask_embed[b], mask_feat_tok[b], out=mask_pred[b], w_split=sp)
         mask_pred = mask_pred.view(B, Q, *vol_shape)
         _, blocked, row_open = get_ops().mask_pool(mask_pred.detach(), target_shape)
         return cls_pred, mask_pred, (blocked, row_open)
@@ -166,14 +170,16 @@ class _Mask2FormerOccBase(nn.Module):
         q = self.query_feat.weight.unsqueeze(0).expand(B, -1, -1)
         qpos = self.query_embed.weight.unsqueeze(0).expand(B, -1, -1)
         cls_list, mask_list = [], []
-        cls, mp, am = self.forward_head(q, mask_tok, vol_shape, shapes[0])
+        # the mask features are the "weight" of ten contractions: split them to bf16 (hi, lo) once
+        mf_split = None if get_ops().precision == "f32" else get_ops().split_bf16(mask_tok)
+        cls, mp, am = self.forward_head(q, mask_tok, vol_shape, shapes[0], mf_split)
         cls_list.append(cls)
         mask_list.append(mp)
         for i, layer in enumerate(self.transformer_decoder.layers):
             lv = i % self.num_transformer_feat_level
             q = layer(q, qpos, keys[lv], key_pos[lv], am[0], am[1])
             cls, mp, am = self.forward_head(q, mask_tok, vol_shape,
-                                            shapes[(i + 1) % self.num_transformer_feat_level])
+                                            shapes[(i + 1) % self.num_transformer_feat_level], mf_split)
             cls_list.append(cls)
             mask_list.append(mp)
         return cls_list, mask_list

@@ -5,6 +5,7 @@ the hand-written gfx950 kernels behind ``include/occformer_hip.h``.  ``ops`` (th
 level instance) is bound to the real library and refuses non-GPU tensors.
 """
 import ctypes
+import os
 
 import torch
 
@@ -24,6 +25,9 @@ class HipOps:
         self.lib = lib
         self.strict = strict
         self.last_flops = 0          # set by the MFMA-bound ops (for bench.py's roofline)
+        # arithmetic of the dense contractions: "f32" = exact fp32 MFMA; "bf16x3" = 3-term bf16
+        # split (fp32-class accuracy, matrix-core rate); "bf16" = plain bf16 products
+        self.precision = os.environ.get("OCCF_PRECISION", "bf16x3")
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -167,8 +171,23 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ dense contractions
-    def linear(self, x, weight, bias=None, act=0, residual=None, out=None):
-        """x [..., K] (rows contiguous along K) @ weight[N, K]^T -> [..., N]."""
+    def split_bf16(self, w):
+        """fp32 tensor -> (hi, lo) bf16 bit patterns (int16 tensors of the same shape)."""
+        w = w.contiguous()
+        hi = torch.empty(w.shape, dtype=torch.int16, device=w.device)
+        lo = torch.empty(w.shape, dtype=torch.int16, device=w.device)
+        self._call("occf_split_bf16", self._ptr(w, self.f32), self._ptr(hi), self._ptr(lo), w.numel(),
+                   self._stream())
+        return hi, lo
+
+    def _bf16_terms(self, K, rows, w_split):
+        if self.precision == "f32" or w_split is None or K % 32 != 0 or rows < 64:
+            return 0
+        return 3 if self.precision == "bf16x3" else 1
+
+    def linear(self, x, weight, bias=None, act=0, residual=None, out=None, w_split=None):
+        """x [..., K] (rows contiguous along K) @ weight[N, K]^T -> [..., N].  ``w_split`` = the
+        (hi, lo) bf16 split of ``weight`` enables the bf16 matrix-core path (see ``precision``)."""
         K = x.shape[-1]
         N = weight.shape[0]
         x2 = x.reshape(-1, K)
@@ -181,12 +200,20 @@ class HipOps:
             if t is not None and (t.stride(1) != 1 or (self.strict and not t.is_cuda)):
                 raise OccfError("linear: rows must be channel-contiguous GPU tensors")
         rp = ctypes.c_void_p(r2.data_ptr()) if r2 is not None else ctypes.c_void_p(0)
-        self._call("occf_linear_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(weight, self.f32), self._ptr(bias),
-                   rp, ctypes.c_void_p(out.data_ptr()), M, N, K, x2.stride(0), out.stride(0),
-                   r2.stride(0) if r2 is not None else 0, int(act), self._stream())
+        terms = self._bf16_terms(K, max(M, N), w_split)
+        if terms:
+            self._call("occf_linear_bf16_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(w_split[0]),
+                       self._ptr(w_split[1]), self._ptr(bias), rp, ctypes.c_void_p(out.data_ptr()), M, N, K,
+                       x2.stride(0), out.stride(0), r2.stride(0) if r2 is not None else 0, int(act), terms,
+                       self._stream())
+        else:
+            self._call("occf_linear_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(weight, self.f32),
+                       self._ptr(bias), rp, ctypes.c_void_p(out.data_ptr()), M, N, K, x2.stride(0),
+                       out.stride(0), r2.stride(0) if r2 is not None else 0, int(act), self._stream())
         return out.view(*x.shape[:-1], N)
 
-    def conv3d(self, x_cl, weight_tap, ksize, stride=1, dil=1, pad=None, bias=None, act=0, residual=None):
+    def conv3d(self, x_cl, weight_tap, ksize, stride=1, dil=1, pad=None, bias=None, act=0, residual=None,
+               w_split=None):
         """x_cl [B, Xi, Yi, Zi, Cin] (any strides with unit channel stride) -> [B, Xo, Yo, Zo, Cout]."""
         B, Xi, Yi, Zi, Cin = x_cl.shape
         assert x_cl.stride(4) == 1
@@ -201,10 +228,16 @@ class HipOps:
         self.last_flops = 2 * B * Xo * Yo * Zo * Cout * kX * kY * kZ * Cin
         if self.strict and not x_cl.is_cuda:
             raise OccfError("occformer_amd ops need GPU tensors (no CPU path exists)")
-        self._call("occf_conv3d_fwd", ctypes.c_void_p(x_cl.data_ptr()), self._ptr(weight_tap, self.f32),
-                   self._ptr(bias), self._ptr(residual), self._ptr(out), B, Xi, Yi, Zi, Cin, Cout, kX, kY, kZ,
-                   int(stride), int(dil), pad[0], pad[1], pad[2], x_cl.stride(0), x_cl.stride(1),
-                   x_cl.stride(2), x_cl.stride(3), int(act), self._stream())
+        geom = (B, Xi, Yi, Zi, Cin, Cout, kX, kY, kZ, int(stride), int(dil), pad[0], pad[1], pad[2],
+                x_cl.stride(0), x_cl.stride(1), x_cl.stride(2), x_cl.stride(3), int(act))
+        terms = self._bf16_terms(Cin, B * Xo * Yo * Zo, w_split)
+        if terms:
+            self._call("occf_conv3d_bf16_fwd", ctypes.c_void_p(x_cl.data_ptr()), self._ptr(w_split[0]),
+                       self._ptr(w_split[1]), self._ptr(bias), self._ptr(residual), self._ptr(out), *geom, terms,
+                       self._stream())
+        else:
+            self._call("occf_conv3d_fwd", ctypes.c_void_p(x_cl.data_ptr()), self._ptr(weight_tap, self.f32),
+                       self._ptr(bias), self._ptr(residual), self._ptr(out), *geom, self._stream())
         return out
 
     # ------------------------------------------------------------------ norms / fusion

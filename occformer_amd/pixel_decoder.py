@@ -97,10 +97,12 @@ class MultiScaleDeformableAttention3D(nn.Module):
     def _offset_logit_weights(self):
         """sampling_offsets and attention_weights share their input: one fused GEMM, N = H*L*P*4."""
         a, b = self.sampling_offsets, self.attention_weights
-        key = (a.weight._version, b.weight._version, a.bias._version, b.bias._version, a.weight.data_ptr())
+        key = (a.weight._version, b.weight._version, a.bias._version, b.bias._version, a.weight.data_ptr(),
+               get_ops().precision, id(get_ops()))
         if getattr(self, "_fused_key", None) != key:
             self._fused_w = torch.cat((a.weight.detach(), b.weight.detach()), 0).contiguous()
             self._fused_b = torch.cat((a.bias.detach(), b.bias.detach()), 0).contiguous()
+            self._fused_split = None if get_ops().precision == "f32" else get_ops().split_bf16(self._fused_w)
             self._fused_key = key
         return self._fused_w, self._fused_b
 
@@ -111,7 +113,7 @@ class MultiScaleDeformableAttention3D(nn.Module):
         qp = query + query_pos
         value = fused.linear(query, self.value_proj)
         w, b = self._offset_logit_weights()
-        ol = ops.linear(qp, w, b)
+        ol = ops.linear(qp, w, b, w_split=self._fused_split)
         n_off = self.sampling_offsets.out_features
         out = ops.msda3d(value, ol[..., :n_off].contiguous(), ol[..., n_off:].contiguous(), level_shapes,
                          self.num_heads, self.num_points)

@@ -14,6 +14,9 @@ echo "== smoke"
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1 ; echo "smoke rc=$?" ; tail -4 $O/smoke.log
 echo "== bench"
 timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --check > $O/bench.json 2> $O/bench.err ; echo "bench rc=$?" ; tail -3 $O/bench.err ; cat $O/bench.json
+for pr in ${EXTRA_PREC:-}; do
+  timeout 600 python bench.py --steps ${STEPS:-5} --warmup 2 --precision $pr --check > $O/bench_$pr.json 2> $O/bench_$pr.err ; echo "bench $pr rc=$?" ; cat $O/bench_$pr.json
+done
 echo "== rocprof kernel trace"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof.log 2>&1 ; echo "rocprof rc=$?" ; tail -2 $O/prof.log

@@ -136,3 +136,45 @@ def test_upsample_add(be, lo, hi):
     out = be.ops.upsample_add(be.to(coarse.permute(0, 2, 3, 4, 1).contiguous()),
                               be.to(lat.permute(0, 2, 3, 4, 1).contiguous())).cpu()
     assert torch.allclose(out.permute(0, 4, 1, 2, 3), ref, **TOL)
+
+
+# ---------------------------------------------------------------- split-bf16 matrix-core path
+@pytest.mark.parametrize("M,N,K,act", [(300, 96, 64, 0), (130, 256, 96, 2), (100, 1000, 192, 0), (257, 192, 32, 1)])
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
+def test_linear_bf16_modes(be, monkeypatch, M, N, K, act, prec, tol):
+    monkeypatch.setattr(be.ops, "precision", prec)
+    x = paramgen.tensor("x", (M, K), 1)
+    w = paramgen.tensor("w", (N, K), 2, K ** -0.5)
+    b = paramgen.tensor("b", (N,), 3)
+    r = paramgen.tensor("r", (M, N), 4)
+    ref = F.linear(x.double(), w.double(), b.double())
+    ref = F.relu(ref) if act == 1 else (F.gelu(ref) if act == 2 else ref)
+    ref = (ref + r.double()).float()
+    out = be.ops.linear(be.to(x), be.to(w), be.to(b), act, be.to(r), w_split=be.ops.split_bf16(be.to(w))).cpu()
+    err = float((out - ref).abs().max() / ref.abs().max())
+    assert err < tol, err
+
+
+def test_split_bf16_exactness(be):
+    w = paramgen.tensor("sw", (37, 65), 9, 3.0)
+    hi, lo = be.ops.split_bf16(be.to(w))
+    up = lambda t: (t.cpu().to(torch.int32) << 16).view(torch.float32)
+    rec = up(hi) + up(lo)
+    assert float(((rec - w).abs() / w.abs().clamp_min(1e-30)).max()) < 2.0 ** -15
+    assert torch.equal(up(hi), w.to(torch.bfloat16).float())          # hi is exactly RNE bf16
+
+
+@pytest.mark.parametrize("shape,cin,cout,k,stride", [((1, 6, 5, 4), 32, 64, 3, 1), ((2, 8, 8, 4), 64, 96, 3, 2),
+                                                     ((1, 7, 6, 3), 32, 32, 1, 2)])
+def test_conv3d_bf16x3(be, monkeypatch, shape, cin, cout, k, stride):
+    monkeypatch.setattr(be.ops, "precision", "bf16x3")
+    B, X, Y, Z = shape
+    x = paramgen.tensor("cx", (B, cin, X, Y, Z), 1)
+    w = paramgen.tensor("cw", (cout, cin, k, k, k), 2, (cin * k ** 3) ** -0.5)
+    pad = (k // 2,) * 3
+    ref = F.conv3d(x.double(), w.double(), stride=stride, padding=pad).float()
+    wt = conv_weight_tapmajor(w)
+    out = be.ops.conv3d(be.to(x.permute(0, 2, 3, 4, 1).contiguous()), be.to(wt), (k, k, k), stride, 1, pad,
+                        w_split=be.ops.split_bf16(be.to(wt))).cpu().permute(0, 4, 1, 2, 3)
+    err = float((out - ref).abs().max() / ref.abs().max())
+    assert err < 2e-5, err
