@@ -70,6 +70,7 @@ class KernelCensus:
     def __init__(self, ops):
         self.ops = ops
         self.records = {}
+        self.shapes = {}
         self._orig = {}
 
     def __enter__(self):
@@ -88,6 +89,9 @@ class KernelCensus:
                 tensors = [t for t in list(a) + list(kw.values()) + list(outs) if torch.is_tensor(t)]
                 nbytes = sum(t.numel() * t.element_size() for t in {t.data_ptr(): t for t in tensors}.values())
                 self.records.setdefault(_name, []).append((e0, e1, nbytes, self.ops.last_flops))
+                if _name in ("linear", "conv3d"):
+                    shp = (tuple(a[0].shape), tuple(a[1].shape))
+                    self.shapes.setdefault((_name, shp), []).append((e0, e1, self.ops.last_flops))
                 return out
 
             setattr(self.ops, name, wrapped)
@@ -106,6 +110,18 @@ class KernelCensus:
                              bytes_per_call=sum(r[2] for r in recs) / len(recs),
                              flops_per_call=sum(r[3] for r in recs) / len(recs))
         return out
+
+
+def shape_report(census, path):
+    rows = []
+    for (name, shp), recs in census.shapes.items():
+        ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+        fl = sum(r[2] for r in recs)
+        rows.append((ms, name, shp, len(recs), fl / (ms * 1e-3) / 1e12))
+    rows.sort(reverse=True)
+    with open(path, "w") as f:
+        for ms, name, shp, n, tf in rows:
+            f.write(f"{ms:8.3f} ms  {n:3d}x  {tf:7.1f} TF  {name} x{shp[0]} w{shp[1]}\n")
 
 
 def cpu_baseline(model, meta, img_inputs, points):
@@ -136,6 +152,7 @@ def main():
     ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the dense contractions (default: the library default, bf16x3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shape-report", default=None, help="write a per-shape GEMM/conv timing table here")
     ap.add_argument("--check", action="store_true", help="also report max abs err vs the oracle output")
     args = ap.parse_args()
 
@@ -191,6 +208,8 @@ def main():
         res_gpu = step_full()
     model.record_time = False
     kernels = census.summary()
+    if args.shape_report and rank == 0:
+        shape_report(census, args.shape_report)
     stages = {k: round(1e3 * sum(v) / len(v), 3) for k, v in model.time_stats.items() if k}
 
     if rank != 0:

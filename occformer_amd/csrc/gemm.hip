@@ -69,8 +69,9 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   // blockIdx.x walks N-tiles fastest: neighbouring workgroups share the same A rows (L2)
   const int n_tiles = (p.N + BN - 1) / BN;
-  const long m0 = (long)(blockIdx.x / n_tiles) * BM;
-  const int n0 = (blockIdx.x % n_tiles) * BN;
+  const unsigned wg = occf_xcd_remap(blockIdx.x, gridDim.x);
+  const long m0 = (long)(wg / n_tiles) * BM;
+  const int n0 = (wg % n_tiles) * BN;
 
   // ---- per-thread load bookkeeping (rows are fixed over the K loop)
   long a_base[NA];            // DENSE: element offset of the row; CONV: offset of (b, 0,0,0)

@@ -91,8 +91,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int n_tiles = (p.N + BN - 1) / BN;
-  const long m0 = (long)(blockIdx.x / n_tiles) * GB_BM;
-  const int n0 = (blockIdx.x % n_tiles) * BN;
+  const unsigned wg = occf_xcd_remap(blockIdx.x, gridDim.x);
+  const long m0 = (long)(wg / n_tiles) * GB_BM;
+  const int n0 = (wg % n_tiles) * BN;
 
   // A staging: 4 float4 per thread; 8 consecutive lanes cover one 128-B row segment
   long a_base[4];

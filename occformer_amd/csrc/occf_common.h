@@ -49,4 +49,13 @@ __device__ __forceinline__ float occf_fadd(float a, float b) { return __fadd_rn(
 
 static inline int occf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// XCD-aware workgroup remap (MI355X: 8 XCDs, workgroup b is observed to run on XCD b % 8, each
+// XCD has a private 4 MB L2).  Gives every XCD a CONTIGUOUS range of tiles so that neighbouring
+// tiles -- which share operand rows (GEMM) or halo voxels (implicit conv) -- hit the same L2.
+// Bijective for any grid size; a wrong placement guess only costs speed.
+__device__ __forceinline__ unsigned occf_xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 #define OCCF_LAUNCH_CHECK() return (int)hipGetLastError()

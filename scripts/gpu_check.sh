@@ -13,7 +13,7 @@ timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $O/pytest_gpu
 echo "== smoke"
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1 ; echo "smoke rc=$?" ; tail -4 $O/smoke.log
 echo "== bench"
-timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --check > $O/bench.json 2> $O/bench.err ; echo "bench rc=$?" ; tail -3 $O/bench.err ; cat $O/bench.json
+timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --check --shape-report $O/shapes.txt > $O/bench.json 2> $O/bench.err ; echo "bench rc=$?" ; tail -3 $O/bench.err ; cat $O/bench.json ; head -40 $O/shapes.txt
 for pr in ${EXTRA_PREC:-}; do
   timeout 600 python bench.py --steps ${STEPS:-5} --warmup 2 --precision $pr --check > $O/bench_$pr.json 2> $O/bench_$pr.err ; echo "bench $pr rc=$?" ; cat $O/bench_$pr.json
 done
