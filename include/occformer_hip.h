@@ -180,13 +180,28 @@ int occf_upsample_add(const float* coarse, const float* lateral, float* out, int
  * activation is split while it is staged.  K % 32 == 0 (conv: Cin % 32 == 0). */
 int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
                          const float* residual, float* out, long M, int N, int K, long ldx, long ldo,
-                         long ldr, int act, int terms, void* stream);
+                         long ldr, int act, int terms, float* workspace, long workspace_floats, void* stream);
 int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
                          const float* residual, float* out, int B, int Xi, int Yi, int Zi, int Cin, int Cout,
                          int kX, int kY, int kZ, int stride, int dil, int pad_x, int pad_y, int pad_z,
-                         long in_sb, long in_sx, long in_sy, long in_sz, int act, int terms, void* stream);
+                         long in_sb, long in_sx, long in_sy, long in_sz, int act, int terms, float* workspace,
+                         long workspace_floats, void* stream);
+/* Small-M problems (few output tiles, long K: the coarse encoder stages) are split along K over
+ * blockIdx.y into partial slabs and reduced in fixed order; workspace (may be NULL = never split)
+ * needs occf_gemm_bf16_workspace(M, N, K) floats (0 = this shape is not split). */
+long occf_gemm_bf16_workspace(long M, int N, int K);
 /* hi = bf16_rne(x), lo = bf16_rne(x - hi), n elements. */
 int occf_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, long n, void* stream);
+
+/* ------------------------------------------------------------------ DepthNet's DCN ------ */
+
+/* Deformable im2col of mmcv-full 1.4.0 `deform_conv2d` (DCNv1; third-party op behind
+ * `build_conv_layer(dict(type='DCN', ...))`, P/occformer/image2bev/ViewTransformerLSSBEVDepth.py:479-487).
+ * x[BN, H, W, C] channels-last, offset[BN, dg*2*K*K, Ho, Wo] (conv_offset's NCHW output, (dy, dx)
+ * pairs per tap), col[BN*Ho*Wo, groups, K*K, C/groups]; the grouped contraction is occf_linear_*
+ * per group on the contiguous K-slabs. */
+int occf_deform_im2col(const float* x, const float* offset, float* col, int BN, int H, int W, int C, int K,
+                       int stride, int pad, int dil, int groups, int deform_groups, void* stream);
 
 #ifdef __cplusplus
 }

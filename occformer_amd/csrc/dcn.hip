@@ -1,0 +1,71 @@
+// Deformable-convolution im2col (DCNv1) for DepthNet's depth branch.
+//
+// Reference: mmcv-full 1.4.0 `deform_conv2d` (third-party CUDA op, not under /root/reference;
+// call site projects/mmdet3d_plugin/occformer/image2bev/ViewTransformerLSSBEVDepth.py:479-487:
+// 3x3, padding 1, groups 4, deform_groups 1, im2col_step 128).  Published algorithm: for output
+// pixel (h, w) and tap (ky, kx) sample the input bilinearly (zero outside) at
+// (h*stride - pad + ky*dil + dy, w*stride - pad + kx*dil + dx) with (dy, dx) =
+// offset[2*(dg*K*K + tap) + {0, 1}], then contract with the grouped weight.
+//
+// Input x channels-last [BN, H, W, C]; offsets in the conv_offset layout [BN, dg*2*K*K, Ho, Wo];
+// output columns [BN*Ho*Wo][groups][K*K][C/groups] so that every conv group's K-slab is one
+// contiguous row segment for the MFMA GEMM that follows (occf_linear_*).
+// Thread = (output pixel, tap, channel quad); gathers are 16-B channel-contiguous.
+#include "occf_common.h"
+#include "../../include/occformer_hip.h"
+
+__global__ void __launch_bounds__(256) deform_im2col_kernel(
+    const float* __restrict__ x, const float* __restrict__ offset, float* __restrict__ col, int BN, int H,
+    int W, int C, int Ho, int Wo, int K, int stride, int pad, int dil, int groups, int dgroups) {
+  const int Q = C / 4, KK = K * K;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)BN * Ho * Wo * KK * Q;
+  if (gid >= total) return;
+  const int cq = (int)(gid % Q);
+  long r = gid / Q;
+  const int t = (int)(r % KK);
+  r /= KK;
+  const int wo = (int)(r % Wo);
+  r /= Wo;
+  const int ho = (int)(r % Ho);
+  const int bn = (int)(r / Ho);
+  const int c = cq * 4;
+  const int dg = c / (C / dgroups);
+  const int ky = t / K, kx = t % K;
+  const long obase = (((long)bn * dgroups + dg) * 2 * KK + 2 * t) * Ho * Wo + (long)ho * Wo + wo;
+  const float py = (float)(ho * stride - pad + ky * dil) + offset[obase];
+  const float px = (float)(wo * stride - pad + kx * dil) + offset[obase + (long)Ho * Wo];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (py > -1.f && px > -1.f && py < (float)H && px < (float)W) {
+    const float fy = floorf(py), fx = floorf(px);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const float ly = py - fy, lx = px - fx;
+    const float* xb = x + (long)bn * H * W * C + c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      const float wgt = ((k >> 1) ? ly : 1.f - ly) * ((k & 1) ? lx : 1.f - lx);
+      const float4 v = *(const float4*)(xb + ((long)yy * W + xx) * C);
+      acc[0] = fmaf(wgt, v.x, acc[0]); acc[1] = fmaf(wgt, v.y, acc[1]);
+      acc[2] = fmaf(wgt, v.z, acc[2]); acc[3] = fmaf(wgt, v.w, acc[3]);
+    }
+  }
+  const int cpg = C / groups;
+  const int g = c / cpg, cg = c - g * cpg;
+  const long pix = ((long)bn * Ho + ho) * Wo + wo;
+  *(float4*)(col + (pix * groups + g) * KK * cpg + (long)t * cpg + cg) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+extern "C" int occf_deform_im2col(const float* x, const float* offset, float* col, int BN, int H, int W, int C,
+                                  int K, int stride, int pad, int dil, int groups, int deform_groups,
+                                  void* stream) {
+  if (BN <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || groups <= 0 || deform_groups <= 0) return OCCF_EINVAL;
+  if (C % groups || C % deform_groups || (C / groups) % 4 || (C / deform_groups) % 4) return OCCF_ESHAPE;
+  const int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  const int Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  const long total = (long)BN * Ho * Wo * K * K * (C / 4);
+  hipLaunchKernelGGL(deform_im2col_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     offset, col, BN, H, W, C, Ho, Wo, K, stride, pad, dil, groups, deform_groups);
+  OCCF_LAUNCH_CHECK();
+}

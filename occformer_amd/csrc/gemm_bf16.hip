@@ -38,6 +38,8 @@ struct GemmArgsB {
   int M, N, K;
   long lda, ldc, ldr;
   int act;
+  int ksplit;          // > 1: blockIdx.y = K-slice, raw partial tiles go to `slab`
+  float* slab;         // [ksplit][M][N]
   ConvGeomB g;
 };
 
@@ -203,12 +205,15 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = p.K / GB_BK;
-  load_tile(0);
+  // K range of this workgroup (split-K: blockIdx.y selects a contiguous slice of k-tiles)
+  const int nk_all = p.K / GB_BK;
+  const int kt0 = p.ksplit > 1 ? (int)((long)blockIdx.y * nk_all / p.ksplit) : 0;
+  const int nk = p.ksplit > 1 ? (int)((long)(blockIdx.y + 1) * nk_all / p.ksplit) : nk_all;
+  load_tile(kt0);
   store_tile();
   __syncthreads();
   const int li = lane & 31, lk = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -250,6 +255,14 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * (BN / 2) + j * 32 + li;
       if (n >= p.N) continue;
+      if (p.ksplit > 1) {       // raw partial sums; bias / activation / residual in the reduce pass
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (m < p.M) p.slab[((long)blockIdx.y * p.M + m) * p.N + n] = acc[i][j][r];
+        }
+        continue;
+      }
       const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -265,40 +278,85 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
   }
 }
 
+// out[m, n] = epilogue(sum_s slab[s, m, n]) in fixed order (deterministic)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ slab,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ residual,
+                                                            float* __restrict__ out, long M, int N, int S,
+                                                            long ldc, long ldr, int act) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= M * N) return;
+  const long m = gid / N;
+  const int n = (int)(gid % N);
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += slab[(long)s * M * N + gid];
+  if (bias) v += bias[n];
+  if (act == 1) v = fmaxf(v, 0.f);
+  else if (act == 2) v = occf_gelu_b(v);
+  if (residual) v += residual[m * ldr + n];
+  out[m * ldc + n] = v;
+}
+
+static int occf_pick_ksplit(long M, int N, int K, bool wide, long workspace_floats) {
+  const long tiles = (long)occf_cdiv(M, GB_BM) * occf_cdiv(N, wide ? 128 : 64);
+  const int nk = K / GB_BK;
+  if (tiles >= 192 || nk < 32) return 1;
+  int S = (int)((512 + tiles - 1) / tiles);
+  if (S > nk / 8) S = nk / 8;
+  if (S > 16) S = 16;
+  while (S > 1 && (long)S * M * N > workspace_floats) --S;
+  return S < 2 ? 1 : S;
+}
+
 template <bool CONV>
-static int launch_gemm_b(const GemmArgsB& a, int terms, hipStream_t st) {
+static int launch_gemm_b(GemmArgsB a, int terms, float* workspace, long workspace_floats, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % GB_BK != 0) return OCCF_ESHAPE;
   if (terms != 1 && terms != 3) return OCCF_EINVAL;
   if (terms == 3 && a.Wl == nullptr) return OCCF_EINVAL;
   const int mt = occf_cdiv(a.M, GB_BM);
   const bool wide = (a.N % 128 == 0) || a.N > 512;
+  a.ksplit = workspace ? occf_pick_ksplit(a.M, a.N, a.K, wide, workspace_floats) : 1;
+  a.slab = workspace;
+  const dim3 grid((unsigned)((long)mt * occf_cdiv(a.N, wide ? 128 : 64)), a.ksplit);
   if (wide) {
-    const unsigned grid = (unsigned)((long)mt * occf_cdiv(a.N, 128));
-    if (terms == 3) hipLaunchKernelGGL((gemm_bf16_kernel<128, 3, CONV>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<128, 1, CONV>), dim3(grid), dim3(256), 0, st, a);
+    if (terms == 3) hipLaunchKernelGGL((gemm_bf16_kernel<128, 3, CONV>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<128, 1, CONV>), grid, dim3(256), 0, st, a);
   } else {
-    const unsigned grid = (unsigned)((long)mt * occf_cdiv(a.N, 64));
-    if (terms == 3) hipLaunchKernelGGL((gemm_bf16_kernel<64, 3, CONV>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<64, 1, CONV>), dim3(grid), dim3(256), 0, st, a);
+    if (terms == 3) hipLaunchKernelGGL((gemm_bf16_kernel<64, 3, CONV>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<64, 1, CONV>), grid, dim3(256), 0, st, a);
+  }
+  if (a.ksplit > 1) {
+    const long total = (long)a.M * a.N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, a.slab, a.bias,
+                       a.residual, a.C, (long)a.M, a.N, a.ksplit, a.ldc, a.ldr, a.act);
   }
   return (int)hipGetLastError();
 }
 
+// scratch (floats) that lets small-M problems use split-K; 0 when no split would be chosen
+extern "C" long occf_gemm_bf16_workspace(long M, int N, int K) {
+  const bool wide = (N % 128 == 0) || N > 512;
+  const int S = occf_pick_ksplit(M, N, K, wide, (long)1 << 60);
+  return S > 1 ? (long)S * M * N : 0;
+}
+
 extern "C" int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
                                     const float* bias, const float* residual, float* out, long M, int N,
-                                    int K, long ldx, long ldo, long ldr, int act, int terms, void* stream) {
+                                    int K, long ldx, long ldo, long ldr, int act, int terms, float* workspace,
+                                    long workspace_floats, void* stream) {
   if (M >= 2147483647L || ldx % 4 != 0) return OCCF_ESHAPE;
   GemmArgsB a = {};
   a.A = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.C = out;
   a.M = (int)M; a.N = N; a.K = K; a.lda = ldx; a.ldc = ldo; a.ldr = ldr; a.act = act;
-  return launch_gemm_b<false>(a, terms, (hipStream_t)stream);
+  return launch_gemm_b<false>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
 }
 
 extern "C" int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
                                     const float* bias, const float* residual, float* out, int B, int Xi,
                                     int Yi, int Zi, int Cin, int Cout, int kX, int kY, int kZ, int stride,
                                     int dil, int pad_x, int pad_y, int pad_z, long in_sb, long in_sx,
-                                    long in_sy, long in_sz, int act, int terms, void* stream) {
+                                    long in_sy, long in_sz, int act, int terms, float* workspace,
+                                    long workspace_floats, void* stream) {
   if (B <= 0 || Cin % GB_BK != 0 || stride <= 0 || dil <= 0) return OCCF_ESHAPE;
   if (in_sb % 4 || in_sx % 4 || in_sy % 4 || in_sz % 4) return OCCF_ESHAPE;
   GemmArgsB a = {};
@@ -313,7 +371,7 @@ extern "C" int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const 
   if (g.Xo <= 0 || g.Yo <= 0 || g.Zo <= 0 || M >= 2147483647L) return OCCF_ESHAPE;
   a.A = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.C = out;
   a.M = (int)M; a.N = Cout; a.K = kX * kY * kZ * Cin; a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.act = act;
-  return launch_gemm_b<true>(a, terms, (hipStream_t)stream);
+  return launch_gemm_b<true>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
 }
 
 // fp32 -> (hi, lo) bf16 split of a whole array (weights once per version; the mask features once

@@ -59,21 +59,33 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const float* __restrict
   }
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nblk,
-                                   int G, double count, float eps) {
-  const int b = blockIdx.x, g = threadIdx.x;
-  if (g >= G) return;
+// one 64-lane wave per (batch, group): lanes stride over the per-block partials (fixed
+// assignment -> deterministic), then a butterfly reduction in double
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restrict__ partial,
+                                                          float* __restrict__ stats, int nblk, int G, int BG,
+                                                          double count, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int bg = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (bg >= BG) return;
+  const int b = bg / G, g = bg % G;
   double s = 0.0, q = 0.0;
-  for (int k = 0; k < nblk; ++k) {
+  for (int k = lane; k < nblk; k += 64) {
     const float* p = partial + (((long)b * nblk + k) * G + g) * 2;
     s += (double)p[0];
     q += (double)p[1];
   }
-  const double mean = s / count;
-  double var = q / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  stats[((long)b * G + g) * 2 + 0] = (float)mean;
-  stats[((long)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+  if (lane == 0) {
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(long)bg * 2 + 0] = (float)mean;
+    stats[(long)bg * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 extern "C" long occf_groupnorm_workspace(int B, long V, int C, int G) {
@@ -88,8 +100,8 @@ extern "C" int occf_groupnorm_stats(const float* x, float* stats, float* workspa
   const int nblk = occf_cdiv(V, rows);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, B), dim3(256), 0, st, x, workspace, V, C, G, rows);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, st, workspace, stats, nblk, G,
-                     (double)V * (C / G), eps);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(occf_cdiv((long)B * G * 64, 256)), dim3(256), 0, st, workspace,
+                     stats, nblk, G, B * G, (double)V * (C / G), eps);
   OCCF_LAUNCH_CHECK();
 }
 

@@ -180,6 +180,12 @@ class HipOps:
                    self._stream())
         return hi, lo
 
+    def _splitk_workspace(self, M, N, K, device):
+        need = self.lib.occf_gemm_bf16_workspace(M, N, K)
+        if need <= 0:
+            return None, 0
+        return torch.empty((need,), dtype=self.f32, device=device), need
+
     def _bf16_terms(self, K, rows, w_split):
         if self.precision == "f32" or w_split is None or K % 32 != 0 or rows < 64:
             return 0
@@ -202,10 +208,11 @@ class HipOps:
         rp = ctypes.c_void_p(r2.data_ptr()) if r2 is not None else ctypes.c_void_p(0)
         terms = self._bf16_terms(K, max(M, N), w_split)
         if terms:
+            ws, nws = self._splitk_workspace(M, N, K, x.device)
             self._call("occf_linear_bf16_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(w_split[0]),
                        self._ptr(w_split[1]), self._ptr(bias), rp, ctypes.c_void_p(out.data_ptr()), M, N, K,
                        x2.stride(0), out.stride(0), r2.stride(0) if r2 is not None else 0, int(act), terms,
-                       self._stream())
+                       self._ptr(ws), nws, self._stream())
         else:
             self._call("occf_linear_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(weight, self.f32),
                        self._ptr(bias), rp, ctypes.c_void_p(out.data_ptr()), M, N, K, x2.stride(0),
@@ -232,9 +239,10 @@ class HipOps:
                 x_cl.stride(0), x_cl.stride(1), x_cl.stride(2), x_cl.stride(3), int(act))
         terms = self._bf16_terms(Cin, B * Xo * Yo * Zo, w_split)
         if terms:
+            ws, nws = self._splitk_workspace(B * Xo * Yo * Zo, Cout, kX * kY * kZ * Cin, x_cl.device)
             self._call("occf_conv3d_bf16_fwd", ctypes.c_void_p(x_cl.data_ptr()), self._ptr(w_split[0]),
                        self._ptr(w_split[1]), self._ptr(bias), self._ptr(residual), self._ptr(out), *geom, terms,
-                       self._stream())
+                       self._ptr(ws), nws, self._stream())
         else:
             self._call("occf_conv3d_fwd", ctypes.c_void_p(x_cl.data_ptr()), self._ptr(weight_tap, self.f32),
                        self._ptr(bias), self._ptr(residual), self._ptr(out), *geom, self._stream())
@@ -289,6 +297,15 @@ class HipOps:
         self._call("occf_upsample_add", self._ptr(coarse, self.f32), self._ptr(lateral, self.f32), self._ptr(out),
                    B, X, Y, Z, X2, Y2, Z2, C, self._stream())
         return out
+
+    def deform_im2col(self, x_cl, offset, K, stride, pad, dil, groups, deform_groups):
+        """x_cl [BN, H, W, C], offset [BN, dg*2*K*K, Ho, Wo] -> col [BN*Ho*Wo, groups, K*K, C/groups]."""
+        BN, H, W, C = x_cl.shape
+        Ho, Wo = offset.shape[-2:]
+        col = torch.empty((BN * Ho * Wo, groups, K * K, C // groups), dtype=x_cl.dtype, device=x_cl.device)
+        self._call("occf_deform_im2col", self._ptr(x_cl, self.f32), self._ptr(offset, self.f32), self._ptr(col),
+                   BN, H, W, C, K, stride, pad, dil, groups, deform_groups, self._stream())
+        return col
 
 
 _ops = None

@@ -43,11 +43,11 @@ def build_voxel_csr(vox, n_vox):
     """Stable counting order of the kept points by voxel row: offsets [n_vox+1] i32 and the
     point indices sorted by (voxel, original index).  Out-of-range points (vox = -1) sort
     to the tail and are never referenced.  No host synchronisation."""
-    key = torch.where(vox < 0, torch.full_like(vox, n_vox), vox).long()
-    order = torch.sort(key, stable=True)[1]
-    counts = torch.bincount(key, minlength=n_vox + 1)[:n_vox]
-    offsets = torch.zeros(n_vox + 1, dtype=torch.int32, device=vox.device)
-    offsets[1:] = torch.cumsum(counts, 0).int()
+    key = torch.where(vox < 0, torch.full_like(vox, n_vox), vox)
+    skey, order = torch.sort(key, stable=True)
+    # offsets[v] = first position whose key >= v (binary search on the sorted keys)
+    bounds = torch.arange(n_vox + 1, dtype=skey.dtype, device=vox.device)
+    offsets = torch.searchsorted(skey, bounds, out_int32=True)
     return offsets, order.int()
 
 
@@ -65,6 +65,9 @@ class _LiftSplat(torch.autograd.Function):
         depth, feat_cl, vox = ctx.saved_tensors
         d_depth, d_feat = get_ops().lift_splat_backward(grad.contiguous(), depth, feat_cl, vox)
         return d_depth, d_feat, None, None, None, None
+
+
+_DCN_CACHE = {}
 
 
 # ------------------------------------------------------------------ DepthNet (dense 2-D part)
@@ -148,28 +151,28 @@ class DeformConv2dPack(nn.Module):
         nn.init.zeros_(self.conv_offset.weight)
         nn.init.zeros_(self.conv_offset.bias)
 
+    def _group_weights(self):
+        """weight [Cout, Cin/groups, k, k] -> per group [Cout/groups, k*k*Cin/groups] (tap-major K)."""
+        from . import fused
+        w = self.weight
+        return fused._versioned(_DCN_CACHE, w, lambda: [
+            wg.permute(0, 2, 3, 1).reshape(wg.shape[0], -1).contiguous()
+            for wg in w.detach().chunk(self.groups, 0)])
+
     def forward(self, x):
+        """x [BN, C, H, W] -> [BN, Cout, H, W]; bilinear im2col in csrc/dcn.hip, then one MFMA GEMM
+        per conv group on its contiguous K-slab."""
+        ops = get_ops()
         B, C, H, W = x.shape
-        k, pad = self.k, self.padding
-        off = self.conv_offset(x).view(B, self.deform_groups, k * k, 2, H, W)
-        ys = torch.arange(H, device=x.device, dtype=x.dtype).view(1, H, 1) - pad
-        xs = torch.arange(W, device=x.device, dtype=x.dtype).view(1, 1, W) - pad
-        cpg = C // self.deform_groups
-        cols = []
-        for t in range(k * k):
-            ky, kx = divmod(t, k)
-            parts = []
-            for g in range(self.deform_groups):
-                py = ys + ky + off[:, g, t, 0]
-                px = xs + kx + off[:, g, t, 1]
-                # grid_sample's zero padding == DCN's "corner taps outside contribute 0"
-                grid = torch.stack(((px + 0.5) / W * 2 - 1, (py + 0.5) / H * 2 - 1), -1)
-                parts.append(F.grid_sample(x[:, g * cpg:(g + 1) * cpg], grid, mode="bilinear",
-                                           padding_mode="zeros", align_corners=False))
-            cols.append(torch.cat(parts, 1))
-        col = torch.stack(cols, 2).view(B, self.groups, C // self.groups, k * k, H * W)
-        w = self.weight.view(self.groups, -1, C // self.groups, k * k)
-        return torch.einsum("bgckp,gock->bgop", col, w).reshape(B, -1, H, W)
+        k, pad, G = self.k, self.padding, self.groups
+        offset = self.conv_offset(x).contiguous()
+        col = ops.deform_im2col(x.permute(0, 2, 3, 1).contiguous(), offset, k, 1, pad, 1, G, self.deform_groups)
+        Cout = self.weight.shape[0]
+        out = torch.empty((B * H * W, Cout), dtype=x.dtype, device=x.device)
+        for g, wg in enumerate(self._group_weights()):
+            ops.linear(col[:, g].flatten(1), wg,       # row-strided view: the group's contiguous K-slab
+                       out=out[:, g * (Cout // G):(g + 1) * (Cout // G)])
+        return out.view(B, H, W, Cout).permute(0, 3, 1, 2)
 
 
 class DepthNet(nn.Module):

@@ -178,3 +178,26 @@ def test_conv3d_bf16x3(be, monkeypatch, shape, cin, cout, k, stride):
                         w_split=be.ops.split_bf16(be.to(wt))).cpu().permute(0, 4, 1, 2, 3)
     err = float((out - ref).abs().max() / ref.abs().max())
     assert err < 2e-5, err
+
+
+def test_splitk_small_m_long_k(be, monkeypatch):
+    """few output tiles + long K (coarse encoder stages) -> split-K slabs + ordered reduce"""
+    monkeypatch.setattr(be.ops, "precision", "bf16x3")
+    M, N, K = 70, 128, 2048
+    assert be.ops.lib.occf_gemm_bf16_workspace(M, N, K) > 0
+    x = paramgen.tensor("skx", (M, K), 1)
+    w = paramgen.tensor("skw", (N, K), 2, K ** -0.5)
+    b = paramgen.tensor("skb", (N,), 3)
+    r = paramgen.tensor("skr", (M, N), 4)
+    ref = (F.relu(F.linear(x.double(), w.double(), b.double())) + r.double()).float()
+    out = be.ops.linear(be.to(x), be.to(w), be.to(b), 1, be.to(r), w_split=be.ops.split_bf16(be.to(w))).cpu()
+    assert float((out - ref).abs().max() / ref.abs().max()) < 2e-5
+    # conv with Cin=64, 27 taps, tiny volume
+    xc = paramgen.tensor("skc", (1, 64, 4, 4, 2), 5)
+    wc = paramgen.tensor("skcw", (64, 64, 3, 3, 3), 6, (64 * 27) ** -0.5)
+    assert be.ops.lib.occf_gemm_bf16_workspace(32, 64, 27 * 64) > 0
+    refc = F.conv3d(xc.double(), wc.double(), padding=1).float()
+    wt = conv_weight_tapmajor(wc)
+    outc = be.ops.conv3d(be.to(xc.permute(0, 2, 3, 4, 1).contiguous()), be.to(wt), (3, 3, 3),
+                         w_split=be.ops.split_bf16(be.to(wt))).cpu().permute(0, 4, 1, 2, 3)
+    assert float((outc - refc).abs().max() / refc.abs().max()) < 2e-5

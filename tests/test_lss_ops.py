@@ -141,3 +141,21 @@ def test_lift_splat_vs_oracle(be, C):
     assert torch.allclose(dd.cpu().view_as(depth), depth_r.grad, atol=1e-5, rtol=1e-4)
     df = df.cpu().view(B * N, fH, fW, C).permute(0, 3, 1, 2)
     assert torch.allclose(df, feat_r.grad, atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("groups,dg", [(4, 1), (2, 2)])
+def test_deform_conv_vs_oracle(be, groups, dg):
+    """csrc/dcn.hip + grouped GEMM == the oracle's restatement of mmcv deform_conv2d"""
+    BN, C, H, W, Cout, k = 2, 32, 5, 7, 24, 3
+    x = paramgen.tensor("dx", (BN, C, H, W), 1)
+    off = paramgen.tensor("doff", (BN, dg * 2 * k * k, H, W), 2, 1.5)
+    w = paramgen.tensor("dw", (Cout, C // groups, k, k), 3, 0.2)
+    ref = O.deform_conv2d(x, off, w, 1, 1, 1, groups, dg)
+    col = be.ops.deform_im2col(be.to(x.permute(0, 2, 3, 1).contiguous()), be.to(off), k, 1, 1, 1, groups, dg)
+    out = torch.empty(BN * H * W, Cout)
+    out = be.to(out)
+    for g, wg in enumerate(w.chunk(groups, 0)):
+        wt = be.to(wg.permute(0, 2, 3, 1).reshape(wg.shape[0], -1).contiguous())
+        be.ops.linear(col[:, g].flatten(1), wt, out=out[:, g * (Cout // groups):(g + 1) * (Cout // groups)])
+    out = out.cpu().view(BN, H, W, Cout).permute(0, 3, 1, 2)
+    assert torch.allclose(out, ref, atol=2e-5, rtol=1e-4), float((out - ref).abs().max())
