@@ -193,6 +193,15 @@ long occf_gemm_bf16_workspace(long M, int N, int K);
 /* hi = bf16_rne(x), lo = bf16_rne(x - hi), n elements. */
 int occf_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, long n, void* stream);
 
+/* 3x3x3 / stride 1 / pad 1 convolution with an LDS-resident halo tile (same contract and weight
+ * layout as occf_conv3d_bf16_fwd restricted to that geometry): the input is staged and split to
+ * bf16 once per 32-channel chunk instead of once per tap.  Returns OCCF_ESHAPE (-2) for shapes
+ * outside its envelope (Cin % 32, Cout % 64, Z in {4, 8, 16k}); the caller then uses
+ * occf_conv3d_bf16_fwd.  x strides as in occf_conv3d_fwd; out[B*X*Y*Z, Cout] channels-last. */
+int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
+                            const float* residual, float* out, int B, int X, int Y, int Z, int Cin, int Cout,
+                            long in_sb, long in_sx, long in_sy, long in_sz, int act, int terms, void* stream);
+
 /* ------------------------------------------------------------------ DepthNet's DCN ------ */
 
 /* Deformable im2col of mmcv-full 1.4.0 `deform_conv2d` (DCNv1; third-party op behind

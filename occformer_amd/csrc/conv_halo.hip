@@ -1,0 +1,291 @@
+// 3x3x3 (stride 1, pad 1) convolution over a channels-last voxel volume with an LDS-resident
+// halo tile -- the dominant FLOP item of the hot path (1885 + 1353 GFLOP at the
+// 200-grid; dualpath_block.py:43-48, multiscale_deformattn_3d.py:101-110).
+//
+// The generic implicit-GEMM kernel (gemm_bf16.hip) re-reads and re-splits every input voxel
+// once per tap (27x) and streams it through L2; here a workgroup stages the (2+2) x (TY+2) x
+// (TZ+2) halo of a 2 x TY x TZ output tile ONCE per 32-channel chunk into LDS (already split
+// into bf16 hi/lo) and all 27 taps read their shifted A fragments straight from that tile:
+// 4.2x instead of 27x input traffic, one fp32->bf16x2 split per staged element.
+//
+// Workgroup = 512 threads = 8 waves as 4 (M) x 2 (N); output tile 256 voxels x (64*TN) channels;
+// per chunk: 27 taps x (k = 32) on v_mfma_f32_32x32x16_bf16 (3-term split or plain bf16).
+// The weight slab of one (tap, chunk) [BN x 32] (pre-split bf16) is double-buffered in LDS; the
+// next tap's slab is fetched into registers while the current tap multiplies.
+// LDS rows are 64 B with the 16-B k-slots XOR-swizzled by (row>>2)&3 (see gemm_bf16.hip).
+// Optionally emits per-workgroup GroupNorm partial sums of the raw outputs.
+#include "occf_common.h"
+#include "../../include/occformer_hip.h"
+
+struct ConvHaloArgs {
+  const float* x;
+  const uint16_t* Wh;
+  const uint16_t* Wl;
+  const float* bias;
+  const float* residual;
+  float* out;
+  int B, X, Y, Z, Cin, Cout;
+  int TY, TZ;                 // TY * TZ == 128, TZ | Z
+  long sb, sx, sy, sz;        // input element strides (channel stride 1)
+  int act;
+};
+
+__device__ __forceinline__ uint32_t ch_bf16_rne(float x) {
+#ifdef OCCF_EMU
+  uint32_t u;
+  memcpy(&u, &x, 4);
+#else
+  const uint32_t u = __float_as_uint(x);
+#endif
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float ch_bf16_up(uint32_t h) {
+#ifdef OCCF_EMU
+  uint32_t u = h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+#else
+  return __uint_as_float(h << 16);
+#endif
+}
+__device__ __forceinline__ void ch_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  const uint32_t ha = ch_bf16_rne(a), hb = ch_bf16_rne(b);
+  const uint32_t la = ch_bf16_rne(a - ch_bf16_up(ha)), lb = ch_bf16_rne(b - ch_bf16_up(hb));
+  hi = ha | (hb << 16);
+  lo = la | (lb << 16);
+}
+__device__ __forceinline__ int ch_slot(int row, int kslot) { return row * 64 + ((kslot ^ ((row >> 2) & 3)) << 4); }
+__device__ __forceinline__ float ch_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+struct ch_u4 {
+  uint32_t x, y, z, w;
+};
+struct ch_u2 {
+  uint32_t x, y;
+};
+
+template <int TN, int TERMS>
+__global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
+  constexpr int BN = 64 * TN;
+  constexpr int NBP = (BN * 4 + 511) / 512;          // 16-B weight pieces per thread per array
+  OCCF_DYN_SMEM(smem);
+  const int TY = p.TY, TZ = p.TZ;
+  const int HY = TY + 2, HZ = TZ + 2;
+  const int NH = 4 * HY * HZ;                         // halo rows (voxels)
+  unsigned char* Hh = (unsigned char*)smem;           // [NH][64 B]
+  unsigned char* Hl = Hh + (size_t)NH * 64;
+  unsigned char* Bh = Hl + (TERMS == 3 ? (size_t)NH * 64 : 0);     // [2][BN][64 B]
+  unsigned char* Bl = Bh + 2 * BN * 64;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lk = lane >> 5;
+
+  // workgroup -> (b, x-pair, y-tile, z-tile, n-tile); n fastest so the workgroups sharing a halo
+  // are neighbours, then z, y, x: an XCD's contiguous range is a slab of x-planes
+  const int n_tiles = (p.Cout + BN - 1) / BN;
+  const int zt = p.Z / TZ, yt = (p.Y + TY - 1) / TY, xt = (p.X + 1) / 2;
+  unsigned wg = occf_xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = wg % n_tiles; wg /= n_tiles;
+  const int tz0 = (wg % zt) * TZ; wg /= zt;
+  const int ty0 = (wg % yt) * TY; wg /= yt;
+  const int tx0 = (wg % xt) * 2;
+  const int b = wg / xt;
+  const int n0 = nt * BN;
+
+  // halo base index of this lane's two A rows at tap (0,0,0)
+  int hb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = wm * 64 + i * 32 + li;
+    const int tx = r >> 7, pp = r & 127;
+    hb[i] = (tx * HY + pp / TZ) * HZ + pp % TZ;
+  }
+  // weight piece bookkeeping
+  int b_n[NBP], b_slot[NBP];
+  bool b_ok[NBP];
+#pragma unroll
+  for (int i = 0; i < NBP; ++i) {
+    const int idx = tid + i * 512;
+    b_n[i] = idx >> 2;
+    b_slot[i] = idx & 3;
+    b_ok[i] = idx < BN * 4 && n0 + b_n[i] < p.Cout;
+  }
+  const long K = 27L * p.Cin;
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  ch_u4 rbh[NBP], rbl[NBP];
+  auto load_b = [&](int tap, int c0) {
+#pragma unroll
+    for (int i = 0; i < NBP; ++i) {
+      if (b_ok[i]) {
+        const long o = (long)(n0 + b_n[i]) * K + (long)tap * p.Cin + c0 + b_slot[i] * 8;
+        rbh[i] = *(const ch_u4*)(p.Wh + o);
+        if (TERMS == 3) rbl[i] = *(const ch_u4*)(p.Wl + o);
+      } else {
+        rbh[i] = ch_u4{0, 0, 0, 0};
+        if (TERMS == 3) rbl[i] = ch_u4{0, 0, 0, 0};
+      }
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NBP; ++i) {
+      if (tid + i * 512 < BN * 4) {
+        const int off = buf * BN * 64 + ch_slot(b_n[i], b_slot[i]);
+        *(ch_u4*)(Bh + off) = rbh[i];
+        if (TERMS == 3) *(ch_u4*)(Bl + off) = rbl[i];
+      }
+    }
+  };
+
+  const int n_chunks = p.Cin / 32;
+  for (int cc = 0; cc < n_chunks; ++cc) {
+    const int c0 = cc * 32;
+    load_b(0, c0);
+    __syncthreads();                     // previous chunk's last tap is done with halo and B
+    // ---- stage the halo of this chunk: NH voxels x 32 channels, 8 lanes per voxel
+    for (int idx = tid; idx < NH * 8; idx += 512) {
+      const int h = idx >> 3, kq = idx & 7;
+      const int hz = h % HZ, hy = (h / HZ) % HY, hx = h / (HZ * HY);
+      const int x = tx0 + hx - 1, y = ty0 + hy - 1, z = tz0 + hz - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x >= 0 && x < p.X && y >= 0 && y < p.Y && z >= 0 && z < p.Z)
+        v = *(const float4*)(p.x + b * p.sb + x * p.sx + y * p.sy + z * p.sz + c0 + kq * 4);
+      ch_u2 hi, lo;
+      ch_split2(v.x, v.y, hi.x, lo.x);
+      ch_split2(v.z, v.w, hi.y, lo.y);
+      const int off = ch_slot(h, kq >> 1) + (kq & 1) * 8;
+      *(ch_u2*)(Hh + off) = hi;
+      if (TERMS == 3) *(ch_u2*)(Hl + off) = lo;
+    }
+    store_b(0);
+    __syncthreads();
+    for (int tap = 0; tap < 27; ++tap) {
+      const int cur = tap & 1;
+      if (tap + 1 < 27) load_b(tap + 1, c0);
+      const int dz = tap % 3, dy = (tap / 3) % 3, dx = tap / 9;
+      const int toff = (dx * HY + dy) * HZ + dz;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int kslot = s * 2 + lk;
+        bf16x8 ah[2], al[2], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int off = ch_slot(hb[i] + toff, kslot);
+          ah[i] = *(const bf16x8*)(Hh + off);
+          if (TERMS == 3) al[i] = *(const bf16x8*)(Hl + off);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int off = cur * BN * 64 + ch_slot(wn * (BN / 2) + j * 32 + li, kslot);
+          bh[j] = *(const bf16x8*)(Bh + off);
+          if (TERMS == 3) bl[j] = *(const bf16x8*)(Bl + off);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            if (TERMS == 3) {
+              acc[i][j] = occf_mfma_bf16_32x32x16(al[i], bh[j], acc[i][j]);
+              acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bl[j], acc[i][j]);
+            }
+            acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bh[j], acc[i][j]);
+          }
+      }
+      if (tap + 1 < 27) store_b(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: row r of the tile -> voxel (tx0 + r>>7, ty0 + (r&127)/TZ, tz0 + (r&127)%TZ)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + li;
+      if (n >= p.Cout) continue;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int pp = row & 127;
+        const int x = tx0 + (row >> 7), y = ty0 + pp / TZ, z = tz0 + pp % TZ;
+        if (x >= p.X || y >= p.Y) continue;
+        const long m = (((long)b * p.X + x) * p.Y + y) * p.Z + z;
+        float v = acc[i][j][r] + bv;
+        if (p.act == 1) v = fmaxf(v, 0.f);
+        else if (p.act == 2) v = ch_gelu(v);
+        if (p.residual) v += p.residual[m * p.Cout + n];
+        p.out[m * p.Cout + n] = v;
+      }
+    }
+  }
+}
+
+static size_t conv_halo_lds(int TY, int TZ, int TN, int terms) {
+  const size_t NH = 4 * (size_t)(TY + 2) * (TZ + 2);
+  return NH * 64 * (terms == 3 ? 2 : 1) + (size_t)2 * 64 * TN * 64 * (terms == 3 ? 2 : 1);
+}
+
+template <int TN>
+static int launch_conv_halo(const ConvHaloArgs& a, int terms, unsigned grid, size_t lds, hipStream_t st) {
+  if (terms == 3) hipLaunchKernelGGL((conv3x3x3_halo_kernel<TN, 3>), dim3(grid), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((conv3x3x3_halo_kernel<TN, 1>), dim3(grid), dim3(512), lds, st, a);
+  return (int)hipGetLastError();
+}
+
+// returns OCCF_ESHAPE when the shape is outside this kernel's envelope (caller falls back to the
+// generic implicit-GEMM kernel)
+extern "C" int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
+                                       const float* bias, const float* residual, float* out, int B, int X,
+                                       int Y, int Z, int Cin, int Cout, long in_sb, long in_sx, long in_sy,
+                                       long in_sz, int act, int terms, void* stream) {
+  if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || Cin % 32 != 0 || Cout <= 0) return OCCF_ESHAPE;
+  if (terms != 1 && terms != 3) return OCCF_EINVAL;
+  if (terms == 3 && w_lo == nullptr) return OCCF_EINVAL;
+  if (in_sb % 4 || in_sx % 4 || in_sy % 4 || in_sz % 4) return OCCF_ESHAPE;
+  int TZ = Z >= 16 ? 16 : Z;
+  if (TZ != 16 && TZ != 8 && TZ != 4) return OCCF_ESHAPE;
+  if (Z % TZ != 0) return OCCF_ESHAPE;
+  const int TY = 128 / TZ;
+  // N tile: 64*TN channels; pick the widest that does not waste more than a quarter
+  int TN;
+  if (Cout % 128 == 0) TN = 2;
+  else if (Cout % 192 == 0) TN = 3;
+  else if (Cout % 64 == 0) TN = 1;
+  else return OCCF_ESHAPE;
+  const size_t lds = conv_halo_lds(TY, TZ, TN, terms);
+  if (lds > 160 * 1024) return OCCF_ESHAPE;
+  ConvHaloArgs a = {};
+  a.x = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.out = out;
+  a.B = B; a.X = X; a.Y = Y; a.Z = Z; a.Cin = Cin; a.Cout = Cout; a.TY = TY; a.TZ = TZ;
+  a.sb = in_sb; a.sx = in_sx; a.sy = in_sy; a.sz = in_sz; a.act = act;
+  const long blocks = (long)B * ((X + 1) / 2) * ((Y + TY - 1) / TY) * (Z / TZ) * ((Cout + 64 * TN - 1) / (64 * TN));
+  if (blocks >= 2147483647L) return OCCF_ESHAPE;
+#ifndef OCCF_EMU
+  static bool attr_set[4][2] = {};
+  const void* fn = nullptr;
+  if (TN == 1) fn = terms == 3 ? (const void*)conv3x3x3_halo_kernel<1, 3> : (const void*)conv3x3x3_halo_kernel<1, 1>;
+  if (TN == 2) fn = terms == 3 ? (const void*)conv3x3x3_halo_kernel<2, 3> : (const void*)conv3x3x3_halo_kernel<2, 1>;
+  if (TN == 3) fn = terms == 3 ? (const void*)conv3x3x3_halo_kernel<3, 3> : (const void*)conv3x3x3_halo_kernel<3, 1>;
+  if (!attr_set[TN][terms == 3]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set[TN][terms == 3] = true;
+  }
+#endif
+  hipStream_t st = (hipStream_t)stream;
+  if (TN == 1) return launch_conv_halo<1>(a, terms, (unsigned)blocks, lds, st);
+  if (TN == 2) return launch_conv_halo<2>(a, terms, (unsigned)blocks, lds, st);
+  return launch_conv_halo<3>(a, terms, (unsigned)blocks, lds, st);
+}

@@ -80,7 +80,7 @@ struct occf_u4 {
   uint32_t x, y, z, w;
 };
 
-template <int BN, int TERMS, bool CONV>
+template <int BN, int TERMS, bool CONV, bool SPLIT>
 __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
   constexpr int TN = BN / 64;                      // 32-wide MFMA tiles per wave along N
   constexpr int NB = BN * 4 / 256;                 // 16-B weight pieces per thread per array
@@ -138,8 +138,12 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
 
   float4 ra[4];
   occf_u4 rbh[NB], rbl[NB];
+  // K range of this workgroup (split-K: blockIdx.y selects a contiguous slice of k-tiles)
+  const int nk_all = p.K / GB_BK;
+  const int kt_begin = SPLIT ? (int)((long)blockIdx.y * nk_all / p.ksplit) : 0;
+  const int kt_end = SPLIT ? (int)((long)(blockIdx.y + 1) * nk_all / p.ksplit) : nk_all;
   auto load_tile = [&](int kt) {
-    const int k0 = kt * GB_BK;
+    const int k0 = (kt_begin + kt) * GB_BK;
     if (CONV) {
       const int tap = k0 / p.g.Cin;                 // Cin % 32 == 0: block-uniform tap
       const int c0 = k0 - tap * p.g.Cin;
@@ -205,15 +209,12 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // K range of this workgroup (split-K: blockIdx.y selects a contiguous slice of k-tiles)
-  const int nk_all = p.K / GB_BK;
-  const int kt0 = p.ksplit > 1 ? (int)((long)blockIdx.y * nk_all / p.ksplit) : 0;
-  const int nk = p.ksplit > 1 ? (int)((long)(blockIdx.y + 1) * nk_all / p.ksplit) : nk_all;
-  load_tile(kt0);
+  const int nk = kt_end - kt_begin;
+  load_tile(0);
   store_tile();
   __syncthreads();
   const int li = lane & 31, lk = lane >> 5;
-  for (int kt = kt0; kt < nk; ++kt) {
+  for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -249,30 +250,30 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
     }
   }
 
+  // ---- epilogue.  Split-K slices store raw partial sums into their slab (bias / activation /
+  // residual are applied by splitk_reduce_kernel); one code path, parameters switched up front.
+  const bool part = SPLIT;
+  const float* e_bias = part ? nullptr : p.bias;
+  const float* e_res = part ? nullptr : p.residual;
+  const int e_act = part ? 0 : p.act;
+  float* e_out = part ? p.slab + (long)blockIdx.y * p.M * p.N : p.C;
+  const long e_ldc = part ? (long)p.N : p.ldc;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * (BN / 2) + j * 32 + li;
       if (n >= p.N) continue;
-      if (p.ksplit > 1) {       // raw partial sums; bias / activation / residual in the reduce pass
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-          if (m < p.M) p.slab[((long)blockIdx.y * p.M + m) * p.N + n] = acc[i][j][r];
-        }
-        continue;
-      }
-      const float bv = p.bias ? p.bias[n] : 0.f;
+      const float bv = e_bias ? e_bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (m >= p.M) continue;
         float v = acc[i][j][r] + bv;
-        if (p.act == 1) v = fmaxf(v, 0.f);
-        else if (p.act == 2) v = occf_gelu_b(v);
-        if (p.residual) v += p.residual[m * p.ldr + n];
-        p.C[m * p.ldc + n] = v;
+        if (e_act == 1) v = fmaxf(v, 0.f);
+        else if (e_act == 2) v = occf_gelu_b(v);
+        if (e_res) v += e_res[m * p.ldr + n];
+        e_out[m * e_ldc + n] = v;
       }
     }
   }
@@ -318,13 +319,20 @@ static int launch_gemm_b(GemmArgsB a, int terms, float* workspace, long workspac
   a.ksplit = workspace ? occf_pick_ksplit(a.M, a.N, a.K, wide, workspace_floats) : 1;
   a.slab = workspace;
   const dim3 grid((unsigned)((long)mt * occf_cdiv(a.N, wide ? 128 : 64)), a.ksplit);
+  const bool sp = a.ksplit > 1;
+#define OCCF_GB_LAUNCH(BN_, T_)                                                                         \
+  do {                                                                                                  \
+    if (sp) hipLaunchKernelGGL((gemm_bf16_kernel<BN_, T_, CONV, true>), grid, dim3(256), 0, st, a);    \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<BN_, T_, CONV, false>), grid, dim3(256), 0, st, a);      \
+  } while (0)
   if (wide) {
-    if (terms == 3) hipLaunchKernelGGL((gemm_bf16_kernel<128, 3, CONV>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<128, 1, CONV>), grid, dim3(256), 0, st, a);
+    if (terms == 3) OCCF_GB_LAUNCH(128, 3);
+    else OCCF_GB_LAUNCH(128, 1);
   } else {
-    if (terms == 3) hipLaunchKernelGGL((gemm_bf16_kernel<64, 3, CONV>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<64, 1, CONV>), grid, dim3(256), 0, st, a);
+    if (terms == 3) OCCF_GB_LAUNCH(64, 3);
+    else OCCF_GB_LAUNCH(64, 1);
   }
+#undef OCCF_GB_LAUNCH
   if (a.ksplit > 1) {
     const long total = (long)a.M * a.N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, a.slab, a.bias,

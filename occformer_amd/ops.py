@@ -28,6 +28,7 @@ class HipOps:
         # arithmetic of the dense contractions: "f32" = exact fp32 MFMA; "bf16x3" = 3-term bf16
         # split (fp32-class accuracy, matrix-core rate); "bf16" = plain bf16 products
         self.precision = os.environ.get("OCCF_PRECISION", "bf16x3")
+        self.use_halo_conv = os.environ.get("OCCF_HALO_CONV", "1") == "1"
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -238,6 +239,16 @@ class HipOps:
         geom = (B, Xi, Yi, Zi, Cin, Cout, kX, kY, kZ, int(stride), int(dil), pad[0], pad[1], pad[2],
                 x_cl.stride(0), x_cl.stride(1), x_cl.stride(2), x_cl.stride(3), int(act))
         terms = self._bf16_terms(Cin, B * Xo * Yo * Zo, w_split)
+        if terms and self.use_halo_conv and (kX, kY, kZ) == (3, 3, 3) and stride == 1 and dil == 1 \
+                and tuple(pad) == (1, 1, 1):
+            rc = self.lib.occf_conv3x3x3_halo_fwd(
+                ctypes.c_void_p(x_cl.data_ptr()), self._ptr(w_split[0]), self._ptr(w_split[1]), self._ptr(bias),
+                self._ptr(residual), self._ptr(out), B, Xi, Yi, Zi, Cin, Cout, x_cl.stride(0), x_cl.stride(1),
+                x_cl.stride(2), x_cl.stride(3), int(act), terms, self._stream())
+            if rc == 0:
+                return out
+            if rc != -2:                     # -2 = shape outside the halo kernel's envelope
+                raise OccfError(f"occf_conv3x3x3_halo_fwd failed with code {rc}")
         if terms:
             ws, nws = self._splitk_workspace(B * Xo * Yo * Zo, Cout, kX * kY * kZ * Cin, x_cl.device)
             self._call("occf_conv3d_bf16_fwd", ctypes.c_void_p(x_cl.data_ptr()), self._ptr(w_split[0]),

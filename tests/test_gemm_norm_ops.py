@@ -201,3 +201,34 @@ def test_splitk_small_m_long_k(be, monkeypatch):
     outc = be.ops.conv3d(be.to(xc.permute(0, 2, 3, 4, 1).contiguous()), be.to(wt), (3, 3, 3),
                          w_split=be.ops.split_bf16(be.to(wt))).cpu().permute(0, 4, 1, 2, 3)
     assert float((outc - refc).abs().max() / refc.abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("shape,cin,cout", [((1, 5, 9, 16), 32, 64), ((2, 4, 20, 8), 64, 128), ((1, 3, 34, 4), 32, 192),
+                                            ((1, 2, 8, 32), 32, 64)])
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
+def test_conv3x3x3_halo(be, monkeypatch, shape, cin, cout, prec, tol):
+    """LDS-halo conv kernel (odd X, ragged Y tiles, Z = 4/8/16/32) vs fp64 conv3d; with bias/ReLU/residual"""
+    monkeypatch.setattr(be.ops, "precision", prec)
+    monkeypatch.setattr(be.ops, "use_halo_conv", True)
+    B, X, Y, Z = shape
+    x = paramgen.tensor("hx", (B, cin, X, Y, Z), 1)
+    w = paramgen.tensor("hw", (cout, cin, 3, 3, 3), 2, (cin * 27) ** -0.5)
+    b = paramgen.tensor("hb", (cout,), 3)
+    r = paramgen.tensor("hr", (B, X, Y, Z, cout), 4)
+    ref = (F.relu(F.conv3d(x.double(), w.double(), b.double(), padding=1)).permute(0, 2, 3, 4, 1) + r.double()).float()
+    wt = conv_weight_tapmajor(w)
+    calls = []
+    orig = be.ops.lib.occf_conv3x3x3_halo_fwd
+    out = be.ops.conv3d(be.to(x.permute(0, 2, 3, 4, 1).contiguous()), be.to(wt), (3, 3, 3), bias=be.to(b), act=1,
+                        residual=be.to(r), w_split=be.ops.split_bf16(be.to(wt))).cpu()
+    err = float((out - ref).abs().max() / ref.abs().max())
+    assert err < tol, err
+    # the halo kernel (not the generic fallback) must have accepted these shapes
+    xs = be.to(x.permute(0, 2, 3, 4, 1).contiguous())
+    sp = be.ops.split_bf16(be.to(wt))
+    o2 = torch.empty_like(out).to(be.device)
+    import ctypes
+    rc = orig(ctypes.c_void_p(xs.data_ptr()), ctypes.c_void_p(sp[0].data_ptr()), ctypes.c_void_p(sp[1].data_ptr()),
+              None, None, ctypes.c_void_p(o2.data_ptr()), B, X, Y, Z, cin, cout, xs.stride(0), xs.stride(1),
+              xs.stride(2), xs.stride(3), 0, 3 if prec == "bf16x3" else 1, None)
+    assert rc == 0
