@@ -81,10 +81,12 @@ int occf_window_attn_fwd(const float* qkv, const float* qkv_bias, const float* b
  * value[B, Nq, heads*head_dim] (projected), sampling_offsets[B, Nq, heads, L, P, 3] raw linear
  * output (last dim ordered z, y, x), attn_logits[B, Nq, heads, L*P] raw, out[B, Nq, heads*head_dim]
  * (before output_proj).  level_shapes is a HOST array [L][3] = (X, Y, Z) per level, coarse->fine
- * as the decoder concatenates them; the queries are the level cells themselves (Nq = sum XYZ). */
+ * as the decoder concatenates them; the queries are the level cells themselves (Nq = sum XYZ).
+ * value_head_major = 1: value is [B, heads, Nq, head_dim] and lanes walk the queries of one head
+ * (adjacent queries sample adjacent cells -> shared cache lines); out stays [B, Nq, heads*head_dim]. */
 int occf_msda3d_fwd(const float* value, const float* sampling_offsets, const float* attn_logits,
                     float* out, const int32_t* level_shapes, int num_levels, int B, int Nq,
-                    int heads, int head_dim, int num_points, void* stream);
+                    int heads, int head_dim, int num_points, int value_head_major, void* stream);
 
 /* ------------------------------------------------------------------ occupancy decoder -- */
 
@@ -94,6 +96,15 @@ int occf_msda3d_fwd(const float* value, const float* sampling_offsets, const flo
  * the row is open; zeroed by the callee). */
 int occf_mask_pool_fwd(const float* mask_pred, float* pooled, uint8_t* blocked, int32_t* row_open,
                        long BQ, int X, int Y, int Z, int ox, int oy, int oz, void* stream);
+
+/* Fused mask_embed x mask_feature contraction + preserve-pooling for decoder layers whose full
+ * mask logits are not consumed (every layer but the last in simple_test,
+ * mask2former_nusc_occ.py:448-466, 713-731): the [B, Q, X, Y, Z] logits are never written.
+ * mask_embed[B, Q, E] fp32, feat_hi/lo[B, V, E] = bf16 split of the channels-last mask features,
+ * outputs as occf_mask_pool_fwd (pooled[B*Q, L], blocked, row_open).  Q <= 128, E % 32 == 0. */
+int occf_mask_gemm_pool_fwd(const float* mask_embed, const uint16_t* feat_hi, const uint16_t* feat_lo,
+                            float* pooled, uint8_t* blocked, int32_t* row_open, int B, int Q, int E, int X,
+                            int Y, int Z, int ox, int oy, int oz, int terms, void* stream);
 
 /* Masked multi-head cross-attention core (scaled dot product + boolean mask + softmax + @V) of
  * the decoder layers, incl. the all-masked-row fix (mask2former_nusc_occ.py:652-667; mmcv

@@ -24,7 +24,7 @@ struct MsdaLevels {
   int X[MSDA_MAX_LEVELS], Y[MSDA_MAX_LEVELS], Z[MSDA_MAX_LEVELS], start[MSDA_MAX_LEVELS];
 };
 
-template <int VEC, int LP_MAX>
+template <int VEC, int LP_MAX, bool HM>
 __global__ void __launch_bounds__(256) msda3d_fwd_kernel(
     const float* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     float* __restrict__ out, MsdaLevels lv, int B, int Nq, int H, int Dh, int P) {
@@ -34,10 +34,19 @@ __global__ void __launch_bounds__(256) msda3d_fwd_kernel(
   if (gid >= total) return;
   const int cv = (int)(gid % lanes) * VEC;
   long r = gid / lanes;
-  const int h = (int)(r % H);
-  r /= H;
-  const int q = (int)(r % Nq);
-  const int b = (int)(r / Nq);
+  int h, q, b;
+  if (HM) {   // head-major: neighbouring lanes = neighbouring queries of ONE head -> their samples
+              // (similar offsets, adjacent cells) fall into the same / adjacent cache lines
+    q = (int)(r % Nq);
+    r /= Nq;
+    h = (int)(r % H);
+    b = (int)(r / H);
+  } else {
+    h = (int)(r % H);
+    r /= H;
+    q = (int)(r % Nq);
+    b = (int)(r / Nq);
+  }
   const int L = lv.n;
   const int LP = L * P;
 
@@ -91,15 +100,17 @@ __global__ void __launch_bounds__(256) msda3d_fwd_kernel(
     const float tz = pz - fz, ty = py - fy, tx = px - fx;
     const int iz = (int)fz, iy = (int)fy, ix = (int)fx;
     const float wgt = w[i] * inv;
-    const float* vbase = value + ((long)b * (lv.start[L - 1] + lv.X[L - 1] * lv.Y[L - 1] * lv.Z[L - 1]) +
-                                  lv.start[l]) * E + h * Dh + cv;
+    const long Nv = lv.start[L - 1] + (long)lv.X[L - 1] * lv.Y[L - 1] * lv.Z[L - 1];
+    const long kstride = HM ? Dh : E;                       // floats between consecutive keys
+    const float* vbase = HM ? value + (((long)b * H + h) * Nv + lv.start[l]) * Dh + cv
+                            : value + ((long)b * Nv + lv.start[l]) * E + h * Dh + cv;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int xx = ix + (c >> 2), yy = iy + ((c >> 1) & 1), zz = iz + (c & 1);
       if (xx < 0 || xx >= Xl || yy < 0 || yy >= Yl || zz < 0 || zz >= Zl) continue;
       const float cw = ((c >> 2) ? tx : 1.f - tx) * (((c >> 1) & 1) ? ty : 1.f - ty) *
                        ((c & 1) ? tz : 1.f - tz) * wgt;
-      const float* vp = vbase + ((long)(xx * Yl + yy) * Zl + zz) * E;
+      const float* vp = vbase + ((long)(xx * Yl + yy) * Zl + zz) * kstride;
       if (VEC == 4) {
         const float4 t = *(const float4*)vp;
         acc[0] = fmaf(cw, t.x, acc[0]);
@@ -125,7 +136,7 @@ __global__ void __launch_bounds__(256) msda3d_fwd_kernel(
 extern "C" int occf_msda3d_fwd(const float* value, const float* sampling_offsets,
                                const float* attn_logits, float* out, const int32_t* level_shapes,
                                int num_levels, int B, int Nq, int heads, int head_dim,
-                               int num_points, void* stream) {
+                               int num_points, int value_head_major, void* stream) {
   if (num_levels <= 0 || num_levels > MSDA_MAX_LEVELS || B <= 0 || heads <= 0 || head_dim <= 0 ||
       num_points <= 0 || num_levels * num_points > 16)
     return OCCF_ESHAPE;
@@ -144,12 +155,20 @@ extern "C" int occf_msda3d_fwd(const float* value, const float* sampling_offsets
   hipStream_t st = (hipStream_t)stream;
   if (head_dim % 4 == 0) {
     const long total = (long)B * Nq * heads * (head_dim / 4);
-    hipLaunchKernelGGL((msda3d_fwd_kernel<4, 16>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,
-                       sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points);
+    if (value_head_major)
+      hipLaunchKernelGGL((msda3d_fwd_kernel<4, 16, true>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,
+                         sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points);
+    else
+      hipLaunchKernelGGL((msda3d_fwd_kernel<4, 16, false>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,
+                         sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points);
   } else {
     const long total = (long)B * Nq * heads * head_dim;
-    hipLaunchKernelGGL((msda3d_fwd_kernel<1, 16>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,
-                       sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points);
+    if (value_head_major)
+      hipLaunchKernelGGL((msda3d_fwd_kernel<1, 16, true>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,
+                         sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points);
+    else
+      hipLaunchKernelGGL((msda3d_fwd_kernel<1, 16, false>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,
+                         sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points);
   }
   OCCF_LAUNCH_CHECK();
 }

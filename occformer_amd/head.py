@@ -133,15 +133,21 @@ class _Mask2FormerOccBase(nn.Module):
                 nn.init.xavier_normal_(p)
 
     # -- mask2former_nusc_occ.py:426-471
-    def forward_head(self, decoder_out, mask_feat_tok, vol_shape, target_shape, mask_feat_split=None):
+    def forward_head(self, decoder_out, mask_feat_tok, vol_shape, target_shape, mask_feat_split=None,
+                     want_mask=True, want_attn=True):
         """decoder_out [B, Q, E]; mask_feat_tok [B, V, E] channels-last tokens.
-        Returns cls [B,Q,K+1], mask_pred [B,Q,X,Y,Z], (blocked u8 [B,Q,L], row_open)."""
+        Returns cls [B,Q,K+1], mask_pred [B,Q,X,Y,Z] (None if not wanted), (blocked u8 [B,Q,L],
+        row_open) (None if not wanted).  When only the attention mask is needed the contraction
+        and the preserve-pooling run fused and the full-resolution logits are never written."""
         ops = get_ops()
         d = fused.layernorm(decoder_out.contiguous(), self.transformer_decoder.post_norm)
         cls_pred = fused.linear(d, self.cls_embed)
         me = self.mask_embed
         mask_embed = fused.linear(fused.linear(fused.linear(d, me[0], act=1), me[2], act=1), me[4])
         B, Q = mask_embed.shape[:2]
+        if not want_mask and want_attn and mask_feat_split is not None and Q <= 128:
+            _, blocked, row_open = ops.mask_gemm_pool(mask_embed, mask_feat_split, vol_shape, target_shape)
+            return cls_pred, None, (blocked, row_open)
         # einsum('bqc,bcxyz->bqxyz'): per batch a [Q, E] x [V, E]^T GEMM whose "weight" is the
         # channels-last mask feature itself
         mask_pred = torch.empty((B, Q, mask_feat_tok.shape[1]), dtype=d.dtype, device=d.device)
@@ -149,11 +155,17 @@ class _Mask2FormerOccBase(nn.Module):
             sp = None if mask_feat_split is None else (mask_feat_split[0][b], mask_feat_split[1][b])
             ops.linear(mask_embed[b], mask_feat_tok[b], out=mask_pred[b], w_split=sp)
         mask_pred = mask_pred.view(B, Q, *vol_shape)
-        _, blocked, row_open = get_ops().mask_pool(mask_pred.detach(), target_shape)
-        return cls_pred, mask_pred, (blocked, row_open)
+        am = None
+        if want_attn:
+            _, blocked, row_open = ops.mask_pool(mask_pred.detach(), target_shape)
+            am = (blocked, row_open)
+        return cls_pred, mask_pred, am
 
     # -- mask2former_nusc_occ.py:589-689
-    def forward(self, voxel_feats, img_metas=None, **kwargs):
+    def forward(self, voxel_feats, img_metas=None, last_only=False, **kwargs):
+        """Reference contract: (list[10] cls, list[10] mask_pred).  ``last_only=True`` (what
+        ``simple_test`` needs) returns one-element lists holding the final layer's predictions and
+        skips materialising the nine intermediate mask tensors."""
         mask_features = voxel_feats[0]
         memories = voxel_feats[:0:-1]
         B, E = mask_features.shape[:2]
@@ -169,19 +181,24 @@ class _Mask2FormerOccBase(nn.Module):
             shapes.append(shp)
         q = self.query_feat.weight.unsqueeze(0).expand(B, -1, -1)
         qpos = self.query_embed.weight.unsqueeze(0).expand(B, -1, -1)
-        cls_list, mask_list = [], []
         # the mask features are the "weight" of ten contractions: split them to bf16 (hi, lo) once
         mf_split = None if get_ops().precision == "f32" else get_ops().split_bf16(mask_tok)
-        cls, mp, am = self.forward_head(q, mask_tok, vol_shape, shapes[0], mf_split)
-        cls_list.append(cls)
-        mask_list.append(mp)
+        n_layers = len(self.transformer_decoder.layers)
+        cls_list, mask_list = [], []
+        cls, mp, am = self.forward_head(q, mask_tok, vol_shape, shapes[0], mf_split, want_mask=not last_only)
+        if not last_only:
+            cls_list.append(cls)
+            mask_list.append(mp)
         for i, layer in enumerate(self.transformer_decoder.layers):
             lv = i % self.num_transformer_feat_level
             q = layer(q, qpos, keys[lv], key_pos[lv], am[0], am[1])
+            last = i == n_layers - 1
             cls, mp, am = self.forward_head(q, mask_tok, vol_shape,
-                                            shapes[(i + 1) % self.num_transformer_feat_level], mf_split)
-            cls_list.append(cls)
-            mask_list.append(mp)
+                                            shapes[(i + 1) % self.num_transformer_feat_level], mf_split,
+                                            want_mask=last or not last_only, want_attn=not last)
+            if last or not last_only:
+                cls_list.append(cls)
+                mask_list.append(mp)
         return cls_list, mask_list
 
     # -- mask2former_nusc_occ.py:691-696 at mask resolution (used by callers that want it)
@@ -210,7 +227,7 @@ class Mask2FormerNuscOccHead(_Mask2FormerOccBase):
 
     # -- mask2former_nusc_occ.py:698-745
     def simple_test(self, voxel_feats, img_metas, points=None, **kwargs):
-        all_cls, all_masks = self(voxel_feats, img_metas)
+        all_cls, all_masks = self(voxel_feats, img_metas, last_only=True)
         cls, mp = all_cls[-1], all_masks[-1]
         res = {"output_voxels": [self._output_voxels(cls, mp, img_metas[0]["occ_size"])],
                "output_points": None}
@@ -223,6 +240,6 @@ class Mask2FormerNuscOccHead(_Mask2FormerOccBase):
 class Mask2FormerOccHead(_Mask2FormerOccBase):
     # -- mask2former_occ.py:673-703
     def simple_test(self, voxel_feats, img_metas, **kwargs):
-        all_cls, all_masks = self(voxel_feats, img_metas)
+        all_cls, all_masks = self(voxel_feats, img_metas, last_only=True)
         return {"output_voxels": [self._output_voxels(all_cls[-1], all_masks[-1], img_metas[0]["occ_size"])],
                 "output_points": None}

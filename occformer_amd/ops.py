@@ -116,15 +116,21 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ pixel decoder
-    def msda3d(self, value, offsets, logits, level_shapes, heads, points):
-        """value [B, Nq, E]; offsets [B, Nq, heads*L*P*3]; logits [B, Nq, heads*L*P]."""
-        B, Nq, E = value.shape
+    def msda3d(self, value, offsets, logits, level_shapes, heads, points, head_major=False):
+        """value [B, Nq, E] (or [B, heads, Nq, E/heads] with head_major); offsets [B, Nq, heads*L*P*3];
+        logits [B, Nq, heads*L*P] -> [B, Nq, E]."""
+        if head_major:
+            B, _, Nq, dh = value.shape
+            E = heads * dh
+        else:
+            B, Nq, E = value.shape
         L = len(level_shapes)
         arr = (ctypes.c_int32 * (3 * L))(*[int(v) for s in level_shapes for v in s])
-        out = torch.empty_like(value)
+        out = torch.empty((B, Nq, E), dtype=value.dtype, device=value.device)
         self._call("occf_msda3d_fwd", self._ptr(value, self.f32), self._ptr(offsets, self.f32),
                    self._ptr(logits, self.f32), self._ptr(out),
-                   ctypes.cast(arr, ctypes.c_void_p), L, B, Nq, heads, E // heads, points, self._stream())
+                   ctypes.cast(arr, ctypes.c_void_p), L, B, Nq, heads, E // heads, points, int(head_major),
+                   self._stream())
         return out
 
     # ------------------------------------------------------------------ occupancy decoder
@@ -138,6 +144,21 @@ class HipOps:
         row_open = torch.empty((B * Q,), dtype=self.i32, device=mask_pred.device)
         self._call("occf_mask_pool_fwd", self._ptr(mask_pred, self.f32), self._ptr(pooled),
                    self._ptr(blocked), self._ptr(row_open), B * Q, X, Y, Z, ox, oy, oz, self._stream())
+        return pooled, blocked, row_open
+
+    def mask_gemm_pool(self, mask_embed, feat_split, vol_shape, target):
+        """mask_embed [B, Q, E], feat_split = (hi, lo) of [B, V, E] -> pooled [B,Q,L], blocked, row_open
+        without materialising the [B, Q, X, Y, Z] logits.  Needs a bf16 precision mode."""
+        B, Q, E = mask_embed.shape
+        X, Y, Z = (int(v) for v in vol_shape)
+        ox, oy, oz = (int(t) for t in target)
+        L = ox * oy * oz
+        pooled = torch.empty((B, Q, L), dtype=self.f32, device=mask_embed.device)
+        blocked = torch.empty((B, Q, L), dtype=torch.uint8, device=mask_embed.device)
+        row_open = torch.empty((B * Q,), dtype=self.i32, device=mask_embed.device)
+        self._call("occf_mask_gemm_pool_fwd", self._ptr(mask_embed, self.f32), self._ptr(feat_split[0]),
+                   self._ptr(feat_split[1]), self._ptr(pooled), self._ptr(blocked), self._ptr(row_open), B, Q, E,
+                   X, Y, Z, ox, oy, oz, 3 if self.precision == "bf16x3" else 1, self._stream())
         return pooled, blocked, row_open
 
     def masked_attention(self, q, k, v, heads, blocked=None, row_open=None):

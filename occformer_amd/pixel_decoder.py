@@ -115,8 +115,10 @@ class MultiScaleDeformableAttention3D(nn.Module):
         w, b = self._offset_logit_weights()
         ol = ops.linear(qp, w, b, w_split=self._fused_split)
         n_off = self.sampling_offsets.out_features
-        out = ops.msda3d(value, ol[..., :n_off].contiguous(), ol[..., n_off:].contiguous(), level_shapes,
-                         self.num_heads, self.num_points)
+        B, Nq, E = value.shape
+        value_hm = value.view(B, Nq, self.num_heads, E // self.num_heads).permute(0, 2, 1, 3).contiguous()
+        out = ops.msda3d(value_hm, ol[..., :n_off].contiguous(), ol[..., n_off:].contiguous(), level_shapes,
+                         self.num_heads, self.num_points, head_major=True)
         return fused.linear(out, self.output_proj, residual=query)       # dropout = identity (eval)
 
 

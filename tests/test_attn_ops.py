@@ -56,6 +56,9 @@ def test_msda3d(be, E, heads, shapes):
     ref = O.msda3d_core(value.view(B, Nq, heads, E // heads), shapes, loc, w)
     out = be.ops.msda3d(*be.to(value, offs, logits), shapes, heads, P).cpu()
     assert torch.allclose(out, ref, **TOL), float((out - ref).abs().max())
+    vhm = value.view(B, Nq, heads, E // heads).permute(0, 2, 1, 3).contiguous()
+    out2 = be.ops.msda3d(*be.to(vhm, offs, logits), shapes, heads, P, head_major=True).cpu()
+    assert torch.equal(out2, out)
 
 
 @pytest.mark.parametrize("shape,target", [((16, 16, 8), (4, 4, 2)), ((16, 16, 8), (8, 8, 4)),
@@ -124,3 +127,28 @@ def test_lidarseg_sample(be):
         rows.append(torch.cat((torch.full((p.shape[0], 1), float(b)), g), 1))
     out = be.ops.lidarseg_sample(*be.to(mp, cls, torch.cat(rows, 0).contiguous())).cpu()
     assert torch.allclose(out, ref, **TOL), float((out - ref).abs().max())
+
+
+@pytest.mark.parametrize("shape,target,Q", [((8, 8, 16), (4, 4, 8), 20), ((8, 8, 16), (2, 2, 2), 100),
+                                            ((6, 10, 8), (3, 5, 4), 7), ((5, 7, 4), (2, 3, 2), 9),
+                                            ((4, 7, 3), (2, 3, 2), 5)])
+def test_mask_gemm_pool_fused(be, monkeypatch, shape, target, Q):
+    """fused GEMM+pool == (same split-bf16 GEMM, then the pooling kernel); incl. overlapping adaptive
+    windows, tiles straddling x-planes and the generic (Z does not divide 128) path"""
+    monkeypatch.setattr(be.ops, "precision", "bf16x3")
+    B, E = 2, 64
+    X, Y, Z = shape
+    me = paramgen.tensor("me", (B, Q, E), 1)
+    feat = paramgen.tensor("mf", (B, X * Y * Z, E), 2)
+    sp = be.ops.split_bf16(be.to(feat))
+    mp = torch.empty(B, Q, X * Y * Z)
+    mpd = be.to(mp)
+    for b in range(B):
+        be.ops.linear(be.to(me)[b], be.to(feat)[b], out=mpd[b], w_split=(sp[0][b], sp[1][b]))
+    ref_pooled, ref_blocked, ref_open = be.ops.mask_pool(mpd.view(B, Q, X, Y, Z), target)
+    pooled, blocked, row_open = be.ops.mask_gemm_pool(be.to(me), sp, shape, target)
+    assert torch.equal(pooled.cpu(), ref_pooled.cpu())
+    assert torch.equal(blocked.cpu(), ref_blocked.cpu()) and torch.equal(row_open.cpu(), ref_open.cpu())
+    # and against plain fp32 torch within the split-bf16 accuracy
+    full = torch.einsum("bqe,bve->bqv", me, feat).view(B, Q, X, Y, Z)
+    assert torch.allclose(pooled.cpu(), F.adaptive_max_pool3d(full, target).flatten(2), atol=1e-4, rtol=1e-4)
