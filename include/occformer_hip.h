@@ -140,6 +140,12 @@ int occf_linear_fwd(const float* x, const float* weight, const float* bias, cons
                     float* out, long M, int N, int K, long ldx, long ldo, long ldr, int act,
                     void* stream);
 
+/* occf_linear_fwd for tiny problems (the 100-query decoder): one thread per output, exact fp32,
+ * no tile padding.  Same arguments; intended for M <= 128 and M*N <= 256k. */
+int occf_linear_small_fwd(const float* x, const float* weight, const float* bias, const float* residual,
+                          float* out, int M, int N, int K, long ldx, long ldo, long ldr, int act,
+                          void* stream);
+
 /* Implicit-GEMM convolution over a channels-last volume (nn.Conv3d / nn.Conv2d as Zi = kZ = 1):
  * x[B, Xi, Yi, Zi, Cin] addressed by element strides (in_sb, in_sx, in_sy, in_sz; channel stride
  * 1), weight_tapmajor[Cout, kX*kY*kZ*Cin] (k = ((dx*kY + dy)*kZ + dz)*Cin + cin), zero padding,

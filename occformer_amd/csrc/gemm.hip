@@ -273,3 +273,45 @@ extern "C" int occf_conv3d_fwd(const float* x, const float* weight_tapmajor, con
   a.M = (int)M; a.N = Cout; a.K = kX * kY * kZ * Cin; a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.act = act;
   return launch_gemm<true>(a, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------
+// Tiny contractions (the 100-query decoder: M <= 128 rows, N*M <= 256k): a 128-wide MFMA tile
+// would be >75 % padding and the kernel is pure latency, so one thread computes one output
+// with 16-byte loads along K (x row broadcast across the wave, W rows L1-resident).  Exact fp32.
+__global__ void __launch_bounds__(256) linear_small_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ residual,
+                                                           float* __restrict__ out, int M, int N, int K, long ldx,
+                                                           long ldo, long ldr, int act) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)M * N) return;
+  const int n = (int)(gid % N), m = (int)(gid / N);
+  const float* xr = x + m * ldx;
+  const float* wr = w + (long)n * K;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int k = 0; k < K; k += 4) {
+    const float4 xv = *(const float4*)(xr + k);
+    const float4 wv = *(const float4*)(wr + k);
+    a0 = fmaf(xv.x, wv.x, a0);
+    a1 = fmaf(xv.y, wv.y, a1);
+    a2 = fmaf(xv.z, wv.z, a2);
+    a3 = fmaf(xv.w, wv.w, a3);
+  }
+  float v = (a0 + a1) + (a2 + a3);
+  if (bias) v += bias[n];
+  if (act == 1) v = fmaxf(v, 0.f);
+  else if (act == 2) v = occf_gelu(v);
+  if (residual) v += residual[m * ldr + n];
+  out[m * ldo + n] = v;
+}
+
+extern "C" int occf_linear_small_fwd(const float* x, const float* weight, const float* bias,
+                                     const float* residual, float* out, int M, int N, int K, long ldx,
+                                     long ldo, long ldr, int act, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 4 != 0 || ldx % 4 != 0) return OCCF_ESHAPE;
+  const long total = (long)M * N;
+  hipLaunchKernelGGL(linear_small_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     weight, bias, residual, out, M, N, K, ldx, ldo, ldr, act);
+  OCCF_LAUNCH_CHECK();
+}

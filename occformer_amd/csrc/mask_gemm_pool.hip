@@ -257,17 +257,29 @@ __global__ void __launch_bounds__(256) mask_pool_fill_kernel(int* __restrict__ e
   if (i < n) enc[i] = (int)0x80000000;
 }
 
-// decode pooled logits in place (int -> float) and emit blocked bytes + row_open
+// decode pooled logits in place (int -> float) and emit blocked bytes + row_open.  The row flag
+// is set by at most one lane per run of open lanes, and only while it still reads 0 (every open
+// element hammering the same 100 words with atomics serialises the whole kernel).
 __global__ void __launch_bounds__(256) mask_pool_decode_kernel(int* __restrict__ enc, uint8_t* __restrict__ blocked,
                                                                int* __restrict__ row_open, long BQ, long L) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= BQ * L) return;
-  const float m = mg_dec(enc[i]);
-  ((float*)enc)[i] = m;
-  const float sg = 1.0f / (1.0f + expf(-m));
-  const bool blk = sg < 0.5f;
-  blocked[i] = blk ? 1 : 0;
-  if (!blk) atomicOr((unsigned*)&row_open[i / L], 1u);
+  const bool valid = i < BQ * L;
+  bool open = false;
+  int row = -1;
+  if (valid) {
+    const float m = mg_dec(enc[i]);
+    ((float*)enc)[i] = m;
+    const float sg = 1.0f / (1.0f + expf(-m));
+    const bool blk = sg < 0.5f;
+    blocked[i] = blk ? 1 : 0;
+    open = !blk;
+    row = (int)(i / L);
+  }
+  const int lane = threadIdx.x & 63;
+  const int prev_row = __shfl_up(row, 1);
+  const int prev_open = __shfl_up((int)open, 1);
+  const bool leader = open && (lane == 0 || !prev_open || prev_row != row);
+  if (leader && row_open[row] == 0) atomicOr((unsigned*)&row_open[row], 1u);
 }
 
 extern "C" int occf_mask_gemm_pool_fwd(const float* mask_embed, const uint16_t* feat_hi, const uint16_t* feat_lo,

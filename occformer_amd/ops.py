@@ -228,6 +228,11 @@ class HipOps:
             if t is not None and (t.stride(1) != 1 or (self.strict and not t.is_cuda)):
                 raise OccfError("linear: rows must be channel-contiguous GPU tensors")
         rp = ctypes.c_void_p(r2.data_ptr()) if r2 is not None else ctypes.c_void_p(0)
+        if M <= 128 and M * N <= 262144 and K % 4 == 0:
+            self._call("occf_linear_small_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(weight, self.f32),
+                       self._ptr(bias), rp, ctypes.c_void_p(out.data_ptr()), M, N, K, x2.stride(0),
+                       out.stride(0), r2.stride(0) if r2 is not None else 0, int(act), self._stream())
+            return out.view(*x.shape[:-1], N)
         terms = self._bf16_terms(K, max(M, N), w_split)
         if terms:
             ws, nws = self._splitk_workspace(M, N, K, x.device)

@@ -152,3 +152,21 @@ def test_groupnorm_layernorm_full(hip):
     assert _rel(out[..., :16, :], ref) < 1e-4 and _rel(out[..., 16, :], ref.mean(3)) < 1e-4
     t = x.view(-1, 128)
     assert _rel(hip.ops.layernorm(t, gamma, beta), F.layer_norm(t, (128,), gamma, beta, 1e-5)) < 1e-4
+
+
+def test_mask_gemm_pool_full_equals_unfused(hip, monkeypatch):
+    """fused contraction+pooling == the same split-bf16 contraction followed by the pooling kernel,
+    bit for bit, at the 200-grid"""
+    monkeypatch.setattr(hip.ops, "precision", "bf16x3")
+    g = torch.Generator().manual_seed(9)
+    dev = hip.device
+    me = torch.randn(1, 100, 192, generator=g).to(dev)
+    feat = torch.randn(1, 200 * 200 * 16, 192, generator=g).to(dev)
+    sp = hip.ops.split_bf16(feat)
+    mp = torch.empty(1, 100, 200 * 200 * 16, device=dev)
+    hip.ops.linear(me[0], feat[0], out=mp[0], w_split=(sp[0][0], sp[1][0]))
+    for target in ((25, 25, 2), (50, 50, 4), (100, 100, 8)):
+        ref = hip.ops.mask_pool(mp.view(1, 100, 200, 200, 16), target)
+        out = hip.ops.mask_gemm_pool(me, sp, (200, 200, 16), target)
+        for a, b in zip(out, ref):
+            assert torch.equal(a, b)
