@@ -284,13 +284,17 @@ __global__ void __launch_bounds__(256) linear_small_kernel(const float* __restri
                                                            const float* __restrict__ residual,
                                                            float* __restrict__ out, int M, int N, int K, long ldx,
                                                            long ldo, long ldr, int act) {
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long)M * N) return;
-  const int n = (int)(gid % N), m = (int)(gid / N);
+  // 8 lanes per output: each lane walks K in 16-byte pieces 128 B apart (the 8 lanes read one
+  // contiguous 128-B line of the x row and of the W row), then a 3-step butterfly.
+  const long gid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  const bool valid = gid < (long)M * N;
+  const int n = valid ? (int)(gid % N) : 0, m = valid ? (int)(gid / N) : 0;
   const float* xr = x + m * ldx;
   const float* wr = w + (long)n * K;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  for (int k = 0; k < K; k += 4) {
+#pragma unroll 4
+  for (int k = sub * 4; k < K; k += 32) {
     const float4 xv = *(const float4*)(xr + k);
     const float4 wv = *(const float4*)(wr + k);
     a0 = fmaf(xv.x, wv.x, a0);
@@ -299,6 +303,10 @@ __global__ void __launch_bounds__(256) linear_small_kernel(const float* __restri
     a3 = fmaf(xv.w, wv.w, a3);
   }
   float v = (a0 + a1) + (a2 + a3);
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  if (!valid || sub != 0) return;
   if (bias) v += bias[n];
   if (act == 1) v = fmaxf(v, 0.f);
   else if (act == 2) v = occf_gelu(v);
@@ -310,7 +318,7 @@ extern "C" int occf_linear_small_fwd(const float* x, const float* weight, const 
                                      const float* residual, float* out, int M, int N, int K, long ldx,
                                      long ldo, long ldr, int act, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 4 != 0 || ldx % 4 != 0) return OCCF_ESHAPE;
-  const long total = (long)M * N;
+  const long total = (long)M * N * 8;
   hipLaunchKernelGGL(linear_small_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
                      weight, bias, residual, out, M, N, K, ldx, ldo, ldr, act);
   OCCF_LAUNCH_CHECK();

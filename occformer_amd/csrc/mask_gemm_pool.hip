@@ -257,29 +257,27 @@ __global__ void __launch_bounds__(256) mask_pool_fill_kernel(int* __restrict__ e
   if (i < n) enc[i] = (int)0x80000000;
 }
 
-// decode pooled logits in place (int -> float) and emit blocked bytes + row_open.  The row flag
-// is set by at most one lane per run of open lanes, and only while it still reads 0 (every open
-// element hammering the same 100 words with atomics serialises the whole kernel).
+// decode pooled logits in place (int -> float) and emit the blocked bytes; one workgroup per
+// (batch, query) row also reduces "any key open" for the all-masked-row fix (no atomics).
 __global__ void __launch_bounds__(256) mask_pool_decode_kernel(int* __restrict__ enc, uint8_t* __restrict__ blocked,
-                                                               int* __restrict__ row_open, long BQ, long L) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < BQ * L;
+                                                               int* __restrict__ row_open, long L) {
+  __shared__ int any_open;
+  const long row = blockIdx.x;
+  if (threadIdx.x == 0) any_open = 0;
+  __syncthreads();
   bool open = false;
-  int row = -1;
-  if (valid) {
+  for (long c = threadIdx.x; c < L; c += blockDim.x) {
+    const long i = row * L + c;
     const float m = mg_dec(enc[i]);
     ((float*)enc)[i] = m;
     const float sg = 1.0f / (1.0f + expf(-m));
     const bool blk = sg < 0.5f;
     blocked[i] = blk ? 1 : 0;
-    open = !blk;
-    row = (int)(i / L);
+    open |= !blk;
   }
-  const int lane = threadIdx.x & 63;
-  const int prev_row = __shfl_up(row, 1);
-  const int prev_open = __shfl_up((int)open, 1);
-  const bool leader = open && (lane == 0 || !prev_open || prev_row != row);
-  if (leader && row_open[row] == 0) atomicOr((unsigned*)&row_open[row], 1u);
+  if (open) any_open = 1;          // benign race: every writer stores the same value
+  __syncthreads();
+  if (threadIdx.x == 0) row_open[row] = any_open;
 }
 
 extern "C" int occf_mask_gemm_pool_fwd(const float* mask_embed, const uint16_t* feat_hi, const uint16_t* feat_lo,
@@ -292,18 +290,12 @@ extern "C" int occf_mask_gemm_pool_fwd(const float* mask_embed, const uint16_t* 
   hipStream_t st = (hipStream_t)stream;
   const long V = (long)X * Y * Z, L = (long)ox * oy * oz;
   const long BQL = (long)B * Q * L;
-#ifndef OCCF_EMU
-  hipError_t e = hipMemsetAsync(row_open, 0, sizeof(int32_t) * (size_t)B * Q, st);
-  if (e != hipSuccess) return (int)e;
-#else
-  memset(row_open, 0, sizeof(int32_t) * (size_t)B * Q);
-#endif
   hipLaunchKernelGGL(mask_pool_fill_kernel, dim3(occf_cdiv(BQL, 256)), dim3(256), 0, st, (int*)pooled, BQL);
   MaskPoolArgs a = {mask_embed, feat_hi, feat_lo, (int*)pooled, B, Q, E, X, Y, Z, ox, oy, oz};
   const dim3 grid((unsigned)occf_cdiv(V, 128), B);
   if (terms == 3) hipLaunchKernelGGL(mask_gemm_pool_kernel<3>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(mask_gemm_pool_kernel<1>, grid, dim3(256), 0, st, a);
-  hipLaunchKernelGGL(mask_pool_decode_kernel, dim3(occf_cdiv(BQL, 256)), dim3(256), 0, st, (int*)pooled, blocked,
-                     (int*)row_open, (long)B * Q, L);
+  hipLaunchKernelGGL(mask_pool_decode_kernel, dim3((unsigned)(B * Q)), dim3(256), 0, st, (int*)pooled, blocked,
+                     (int*)row_open, L);
   OCCF_LAUNCH_CHECK();
 }

@@ -165,31 +165,58 @@ __global__ void __launch_bounds__(XA_QPB) masked_xattn_partial_kernel(
   for (int d = 0; d < XA_HD; d += 4) *(float4*)(po + d) = make_float4(o[d], o[d + 1], o[d + 2], o[d + 3]);
 }
 
+// one 64-lane wave per (b, h, q): lanes stride over the key chunks (log-sum-exp merge); the
+// lane -> chunk assignment and the butterfly order are fixed, so the result is deterministic
 __global__ void __launch_bounds__(256) masked_xattn_merge_kernel(
     const float* __restrict__ part_o, const float* __restrict__ part_ml, float* __restrict__ out, int B,
     int Q, int E, int heads, int n_chunks) {
-  // thread = (b, h, q, d)
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)B * heads * Q * XA_HD;
-  if (gid >= total) return;
-  const int d = (int)(gid % XA_HD);
-  long r = gid / XA_HD;
-  const int qi = (int)(r % Q);
-  r /= Q;
-  const int h = (int)(r % heads);
-  const int b = (int)(r / heads);
-  const long base = (((long)b * heads + h) * Q + qi) * n_chunks;
+  const int lane = threadIdx.x & 63;
+  const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;      // (b, h, q)
+  if (row >= (long)B * heads * Q) return;
+  const int qi = (int)(row % Q);
+  const int h = (int)((row / Q) % heads);
+  const int b = (int)(row / ((long)Q * heads));
+  const long base = row * n_chunks;
   float M = -INFINITY;
-  for (int c = 0; c < n_chunks; ++c) M = fmaxf(M, part_ml[(base + c) * 2]);
-  float l = 0.f, o = 0.f;
-  for (int c = 0; c < n_chunks; ++c) {
+  for (int c = lane; c < n_chunks; c += 64) M = fmaxf(M, part_ml[(base + c) * 2]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
+  float l = 0.f, acc[XA_HD];
+#pragma unroll
+  for (int d = 0; d < XA_HD; ++d) acc[d] = 0.f;
+  for (int c = lane; c < n_chunks; c += 64) {
     const float mc = part_ml[(base + c) * 2];
     if (mc == -INFINITY) continue;
     const float w = expf(mc - M);
     l = fmaf(part_ml[(base + c) * 2 + 1], w, l);
-    o = fmaf(part_o[(base + c) * XA_HD + d], w, o);
+    const float* po = part_o + (base + c) * XA_HD;
+#pragma unroll
+    for (int d = 0; d < XA_HD; d += 4) {
+      const float4 t = *(const float4*)(po + d);
+      acc[d] = fmaf(t.x, w, acc[d]); acc[d + 1] = fmaf(t.y, w, acc[d + 1]);
+      acc[d + 2] = fmaf(t.z, w, acc[d + 2]); acc[d + 3] = fmaf(t.w, w, acc[d + 3]);
+    }
   }
-  out[((long)b * Q + qi) * E + h * XA_HD + d] = o / l;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    l += __shfl_xor(l, o);
+#pragma unroll
+    for (int d = 0; d < XA_HD; ++d) acc[d] += __shfl_xor(acc[d], o);
+  }
+  if (lane < XA_HD) {
+    float v = 0.f;
+#pragma unroll
+    for (int d = 0; d < XA_HD; ++d) v = (d == lane) ? acc[d] : v;
+    out[((long)b * Q + qi) * E + h * XA_HD + lane] = v / l;
+  }
+}
+
+static int occf_xattn_chunk(int B, int L, int heads) {
+  // keys per workgroup: short enough that the per-thread serial walk stays ~10 us, while the merge
+  // (one wave per row, lanes over chunks) absorbs the chunk count
+  int chunk = 256;
+  while (chunk > XA_TILE && (long)occf_cdiv(L, chunk) * heads * B < 512) chunk >>= 1;
+  return chunk;
 }
 
 extern "C" int occf_masked_xattn_fwd(const float* q, const float* k, const float* v,
@@ -198,8 +225,7 @@ extern "C" int occf_masked_xattn_fwd(const float* q, const float* k, const float
                                      int E, int heads, void* stream) {
   if (B <= 0 || Q <= 0 || L <= 0 || heads <= 0 || E != heads * XA_HD) return OCCF_ESHAPE;
   // chunking: enough workgroups to fill 256 CUs, chunks a multiple of the LDS tile
-  int chunk = 1024;
-  while (chunk > XA_TILE && (long)occf_cdiv(L, chunk) * heads * B < 512) chunk >>= 1;
+  const int chunk = occf_xattn_chunk(B, L, heads);
   const int n_chunks = occf_cdiv(L, chunk);
   const int qblocks = occf_cdiv(Q, XA_QPB);
   const long need = (long)B * heads * Q * n_chunks * (XA_HD + 2);
@@ -211,15 +237,14 @@ extern "C" int occf_masked_xattn_fwd(const float* q, const float* k, const float
   hipLaunchKernelGGL(masked_xattn_partial_kernel, dim3(n_chunks * qblocks, heads, B), dim3(XA_QPB), 0, st,
                      q, k, v, blocked, (const int*)row_open, part_o, part_ml, B, Q, L, E, heads, chunk,
                      n_chunks, scale);
-  const long total = (long)B * heads * Q * XA_HD;
+  const long total = (long)B * heads * Q * 64;
   hipLaunchKernelGGL(masked_xattn_merge_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, part_o,
                      part_ml, out, B, Q, E, heads, n_chunks);
   OCCF_LAUNCH_CHECK();
 }
 
 extern "C" long occf_masked_xattn_workspace(int B, int Q, int L, int heads) {
-  int chunk = 1024;
-  while (chunk > XA_TILE && (long)occf_cdiv(L, chunk) * heads * B < 512) chunk >>= 1;
+  const int chunk = occf_xattn_chunk(B, L, heads);
   return (long)B * heads * Q * occf_cdiv(L, chunk) * (XA_HD + 2);
 }
 

@@ -145,7 +145,7 @@ class _Mask2FormerOccBase(nn.Module):
         me = self.mask_embed
         mask_embed = fused.linear(fused.linear(fused.linear(d, me[0], act=1), me[2], act=1), me[4])
         B, Q = mask_embed.shape[:2]
-        if not want_mask and want_attn and mask_feat_split is not None and Q <= 128:
+        if not want_mask and want_attn and mask_feat_split is not None and Q <= 128 and ops.use_fused_mask_pool:
             _, blocked, row_open = ops.mask_gemm_pool(mask_embed, mask_feat_split, vol_shape, target_shape)
             return cls_pred, None, (blocked, row_open)
         # einsum('bqc,bcxyz->bqxyz'): per batch a [Q, E] x [V, E]^T GEMM whose "weight" is the

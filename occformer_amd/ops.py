@@ -29,6 +29,9 @@ class HipOps:
         # split (fp32-class accuracy, matrix-core rate); "bf16" = plain bf16 products
         self.precision = os.environ.get("OCCF_PRECISION", "bf16x3")
         self.use_halo_conv = os.environ.get("OCCF_HALO_CONV", "1") == "1"
+        # fused mask-GEMM + pooling (skips writing intermediate mask logits): measured slower than
+        # GEMM + pooling kernel on MI355X in round 1 (atomicMax rate), so off by default
+        self.use_fused_mask_pool = os.environ.get("OCCF_FUSED_MASK_POOL", "0") == "1"
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -213,7 +216,7 @@ class HipOps:
             return 0
         return 3 if self.precision == "bf16x3" else 1
 
-    def linear(self, x, weight, bias=None, act=0, residual=None, out=None, w_split=None):
+    def linear(self, x, weight, bias=None, act=0, residual=None, out=None, w_split=None, allow_small=True):
         """x [..., K] (rows contiguous along K) @ weight[N, K]^T -> [..., N].  ``w_split`` = the
         (hi, lo) bf16 split of ``weight`` enables the bf16 matrix-core path (see ``precision``)."""
         K = x.shape[-1]
@@ -228,7 +231,7 @@ class HipOps:
             if t is not None and (t.stride(1) != 1 or (self.strict and not t.is_cuda)):
                 raise OccfError("linear: rows must be channel-contiguous GPU tensors")
         rp = ctypes.c_void_p(r2.data_ptr()) if r2 is not None else ctypes.c_void_p(0)
-        if M <= 128 and M * N <= 262144 and K % 4 == 0:
+        if allow_small and M <= 128 and M * N <= 262144 and K % 4 == 0:
             self._call("occf_linear_small_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(weight, self.f32),
                        self._ptr(bias), rp, ctypes.c_void_p(out.data_ptr()), M, N, K, x2.stride(0),
                        out.stride(0), r2.stride(0) if r2 is not None else 0, int(act), self._stream())

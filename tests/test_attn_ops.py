@@ -144,7 +144,7 @@ def test_mask_gemm_pool_fused(be, monkeypatch, shape, target, Q):
     mp = torch.empty(B, Q, X * Y * Z)
     mpd = be.to(mp)
     for b in range(B):
-        be.ops.linear(be.to(me)[b], be.to(feat)[b], out=mpd[b], w_split=(sp[0][b], sp[1][b]))
+        be.ops.linear(be.to(me)[b], be.to(feat)[b], out=mpd[b], w_split=(sp[0][b], sp[1][b]), allow_small=False)
     ref_pooled, ref_blocked, ref_open = be.ops.mask_pool(mpd.view(B, Q, X, Y, Z), target)
     pooled, blocked, row_open = be.ops.mask_gemm_pool(be.to(me), sp, shape, target)
     assert torch.equal(pooled.cpu(), ref_pooled.cpu())

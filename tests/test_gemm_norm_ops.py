@@ -39,8 +39,9 @@ def test_linear_identity_asymmetric(be):
     K = 64
     x = torch.eye(K)
     w = torch.arange(96 * K, dtype=torch.float32).view(96, K) / 100.0
-    out = be.ops.linear(be.to(x), be.to(w)).cpu()
+    out = be.ops.linear(be.to(x), be.to(w), allow_small=False).cpu()
     assert torch.equal(out, w.t())
+    assert torch.equal(be.ops.linear(be.to(x), be.to(w)).cpu(), w.t())       # tiny-problem kernel
 
 
 def test_linear_strided_rows(be):
