@@ -157,6 +157,16 @@ int occf_conv3d_fwd(const float* x, const float* weight_tapmajor, const float* b
                     int kX, int kY, int kZ, int stride, int dil, int pad_x, int pad_y, int pad_z,
                     long in_sb, long in_sx, long in_sy, long in_sz, int act, void* stream);
 
+/* Fused token MLP: out = LNpost?( x + W2 . act(W1 . LNpre?(x) + b1) + b2 ), x/out[M, C] fp32,
+ * W1[H, C] / W2[C, H] pre-split bf16 (hi, lo), act 1 = ReLU, 2 = exact GELU, ln_mode 0 none /
+ * 1 pre-LN (MLP input only; SwinBlock norm2 + FFN, window_attention.py:356-361) / 2 post-LN
+ * (pixel-decoder layer 'ffn','norm').  C in {128, 192, 256}, H % 128 == 0; the [M, H] hidden
+ * activation never reaches HBM. */
+int occf_mlp_fused_fwd(const float* x, const float* ln_gamma, const float* ln_beta, const uint16_t* w1_hi,
+                       const uint16_t* w1_lo, const float* b1, const uint16_t* w2_hi, const uint16_t* w2_lo,
+                       const float* b2, float* out, long M, int C, int H, int act, int ln_mode, float eps,
+                       int terms, void* stream);
+
 /* ------------------------------------------------------------------ norms / fusion ----- */
 
 /* GroupNorm over channels-last x[B, V, C] (nn.GroupNorm, eps inside the sqrt): stats[B, G, 2] =

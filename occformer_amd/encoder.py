@@ -100,8 +100,7 @@ class SwinBlock(nn.Module):
         a = get_ops().window_attention(qkv, m.qkv.bias.detach(), m.relative_position_bias_table.detach(),
                                        B, X, Y, S, self.heads, self.attn.shift_size)
         t = fused.linear(a, m.proj, residual=t)
-        h = fused.linear(fused.layernorm(t, self.norm2), self.ffn.layers[0][0], act=2)
-        t = fused.linear(h, self.ffn.layers[1], residual=t)
+        t = fused.mlp(t, self.ffn.layers[0][0], self.ffn.layers[1], act=2, ln=self.norm2, ln_mode=1)
         return t.view(B, X, Y, S, C)
 
 

@@ -86,3 +86,17 @@ def require_eval(module):
     if module.training:
         raise NotImplementedError(f"{type(module).__name__}: the HIP forward path is inference-only in this "
                                   "round (backward kernels are the next scope row); call .eval()")
+
+
+def mlp(x, fc1, fc2, act, ln=None, ln_mode=0):
+    """Transformer feed-forward half on tokens [..., C]: one fused kernel when the shape allows
+    (hidden activation stays in LDS), otherwise LN / linear / linear."""
+    ops = get_ops()
+    C, H = fc1.in_features, fc1.out_features
+    if ops.mlp_fused_supported(C, H) and x.is_contiguous():
+        return ops.mlp_fused(x, None if ln is None else ln.weight.detach(), None if ln is None else ln.bias.detach(),
+                             split_weight(fc1.weight), fc1.bias.detach(), split_weight(fc2.weight),
+                             fc2.bias.detach(), act, ln_mode, 1e-5 if ln is None else ln.eps)
+    h = layernorm(x, ln) if ln_mode == 1 else x
+    y = linear(linear(h, fc1, act=act), fc2, residual=x)
+    return layernorm(y, ln) if ln_mode == 2 else y

@@ -32,6 +32,7 @@ class HipOps:
         # fused mask-GEMM + pooling (skips writing intermediate mask logits): measured slower than
         # GEMM + pooling kernel on MI355X in round 1 (atomicMax rate), so off by default
         self.use_fused_mask_pool = os.environ.get("OCCF_FUSED_MASK_POOL", "0") == "1"
+        self.use_fused_mlp = os.environ.get("OCCF_FUSED_MLP", "1") == "1"
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -286,6 +287,21 @@ class HipOps:
         else:
             self._call("occf_conv3d_fwd", ctypes.c_void_p(x_cl.data_ptr()), self._ptr(weight_tap, self.f32),
                        self._ptr(bias), self._ptr(residual), self._ptr(out), *geom, self._stream())
+        return out
+
+    def mlp_fused_supported(self, C, H):
+        return self.use_fused_mlp and self.precision != "f32" and C in (128, 192, 256) and H % 128 == 0
+
+    def mlp_fused(self, x, ln_w, ln_b, w1_split, b1, w2_split, b2, act, ln_mode, eps=1e-5):
+        """out = LNpost?(x + W2.act(W1.LNpre?(x) + b1) + b2); x [..., C] contiguous."""
+        C = x.shape[-1]
+        H = w1_split[0].shape[0]
+        out = torch.empty_like(x)
+        self.last_flops = 4 * (x.numel() // C) * C * H
+        self._call("occf_mlp_fused_fwd", self._ptr(x, self.f32), self._ptr(ln_w), self._ptr(ln_b),
+                   self._ptr(w1_split[0]), self._ptr(w1_split[1]), self._ptr(b1), self._ptr(w2_split[0]),
+                   self._ptr(w2_split[1]), self._ptr(b2), self._ptr(out), x.numel() // C, C, H, int(act),
+                   int(ln_mode), float(eps), 3 if self.precision == "bf16x3" else 1, self._stream())
         return out
 
     # ------------------------------------------------------------------ norms / fusion

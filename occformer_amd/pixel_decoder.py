@@ -136,8 +136,7 @@ class _EncoderLayer(nn.Module):
     def forward(self, x, pos, level_shapes):
         x = fused.layernorm(self.attentions[0](x, pos, level_shapes), self.norms[0])
         ffn = self.ffns[0].layers
-        y = fused.linear(fused.linear(x, ffn[0][0], act=1), ffn[1], residual=x)
-        return fused.layernorm(y, self.norms[1])
+        return fused.mlp(x, ffn[0][0], ffn[1], act=1, ln=self.norms[1], ln_mode=2)
 
 
 class _Encoder(nn.Module):

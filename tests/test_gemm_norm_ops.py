@@ -233,3 +233,28 @@ def test_conv3x3x3_halo(be, monkeypatch, shape, cin, cout, prec, tol):
               None, None, ctypes.c_void_p(o2.data_ptr()), B, X, Y, Z, cin, cout, xs.stride(0), xs.stride(1),
               xs.stride(2), xs.stride(3), 0, 3 if prec == "bf16x3" else 1, None)
     assert rc == 0
+
+
+@pytest.mark.parametrize("C,H,act,ln_mode,M", [(128, 128, 2, 1, 150), (192, 768, 1, 2, 70), (256, 256, 2, 1, 64),
+                                               (128, 256, 1, 0, 33)])
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 3e-5), ("bf16", 3e-2)])
+def test_mlp_fused(be, monkeypatch, C, H, act, ln_mode, M, prec, tol):
+    monkeypatch.setattr(be.ops, "precision", prec)
+    x = paramgen.tensor("mx", (M, C), 1, 1.5) + 0.3
+    w1 = paramgen.tensor("mw1", (H, C), 2, C ** -0.5)
+    b1 = paramgen.tensor("mb1", (H,), 3, 0.2)
+    w2 = paramgen.tensor("mw2", (C, H), 4, H ** -0.5)
+    b2 = paramgen.tensor("mb2", (C,), 5, 0.2)
+    g = 1 + 0.2 * paramgen.tensor("mg", (C,), 6)
+    bt = 0.1 * paramgen.tensor("mbt", (C,), 7)
+    xd = x.double()
+    h = F.layer_norm(xd, (C,), g.double(), bt.double(), 1e-5) if ln_mode == 1 else xd
+    h = F.linear(h, w1.double(), b1.double())
+    h = F.gelu(h) if act == 2 else F.relu(h)
+    ref = xd + F.linear(h, w2.double(), b2.double())
+    if ln_mode == 2:
+        ref = F.layer_norm(ref, (C,), g.double(), bt.double(), 1e-5)
+    out = be.ops.mlp_fused(be.to(x), be.to(g), be.to(bt), be.ops.split_bf16(be.to(w1)), be.to(b1),
+                           be.ops.split_bf16(be.to(w2)), be.to(b2), act, ln_mode).cpu()
+    err = float((out - ref.float()).abs().max() / ref.abs().max())
+    assert err < tol, err
