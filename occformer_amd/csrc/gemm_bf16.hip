@@ -84,10 +84,14 @@ template <int BN, int TERMS, bool CONV, bool SPLIT>
 __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
   constexpr int TN = BN / 64;                      // 32-wide MFMA tiles per wave along N
   constexpr int NB = BN * 4 / 256;                 // 16-B weight pieces per thread per array
-  __shared__ __attribute__((aligned(16))) unsigned char Ah[GB_BM * 64];
-  __shared__ __attribute__((aligned(16))) unsigned char Al[GB_BM * 64];
-  __shared__ __attribute__((aligned(16))) unsigned char Bh[BN * 64];
-  __shared__ __attribute__((aligned(16))) unsigned char Bl[BN * 64];
+  // one LDS array: operand images during the K loop, the fp32 staging tile in the epilogue
+  constexpr int LDS_OPS = (2 * GB_BM + 2 * BN) * 64;
+  constexpr int LDS_EPI = 64 * BN * 4;                    // 64 rows x BN fp32 per staging phase
+  __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_OPS > LDS_EPI ? LDS_OPS : LDS_EPI];
+  unsigned char* Ah = lds;
+  unsigned char* Al = lds + GB_BM * 64;
+  unsigned char* Bh = lds + 2 * GB_BM * 64;
+  unsigned char* Bl = Bh + BN * 64;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -252,28 +256,59 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
 
   // ---- epilogue.  Split-K slices store raw partial sums into their slab (bias / activation /
   // residual are applied by splitk_reduce_kernel); one code path, parameters switched up front.
+  // The accumulators (MFMA C layout: a lane holds one column) are staged through LDS, 64 rows at
+  // a time, so that global traffic is 16-byte stores / loads of whole row segments: dword stores
+  // from the C layout made the kernel store-issue bound on the K <= 256 (memory-bound) shapes.
   const bool part = SPLIT;
   const float* e_bias = part ? nullptr : p.bias;
   const float* e_res = part ? nullptr : p.residual;
   const int e_act = part ? 0 : p.act;
   float* e_out = part ? p.slab + (long)blockIdx.y * p.M * p.N : p.C;
   const long e_ldc = part ? (long)p.N : p.ldc;
+  float* stage = (float*)lds;                               // [64][BN]
+  const bool vec_ok = ((e_ldc & 3) == 0) && (!e_res || (p.ldr & 3) == 0) && ((p.N & 3) == 0);
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();                                        // K loop / previous phase done with LDS
+    if (wm == h) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 32 + li;
-      if (n >= p.N) continue;
-      const float bv = e_bias ? e_bias[n] : 0.f;
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (e_act == 1) v = fmaxf(v, 0.f);
-        else if (e_act == 2) v = occf_gelu_b(v);
-        if (e_res) v += e_res[m * p.ldr + n];
-        e_out[m * e_ldc + n] = v;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            stage[row * BN + wn * (BN / 2) + j * 32 + li] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * (BN / 4); idx += 256) {
+      const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+      const long m = m0 + h * 64 + row;
+      const int n = n0 + c4;
+      if (m >= p.M || n >= p.N) continue;
+      float4 v = *(const float4*)(stage + row * BN + c4);
+      float vv[4] = {v.x, v.y, v.z, v.w};
+      const int nv = p.N - n < 4 ? p.N - n : 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (e < nv) {
+          if (e_bias) vv[e] += e_bias[n + e];
+          if (e_act == 1) vv[e] = fmaxf(vv[e], 0.f);
+          else if (e_act == 2) vv[e] = occf_gelu_b(vv[e]);
+        }
+      }
+      if (vec_ok) {
+        if (e_res) {
+          const float4 rr = *(const float4*)(e_res + m * p.ldr + n);
+          vv[0] += rr.x; vv[1] += rr.y; vv[2] += rr.z; vv[3] += rr.w;
+        }
+        *(float4*)(e_out + m * e_ldc + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      } else {
+        for (int e = 0; e < nv; ++e) {
+          if (e_res) vv[e] += e_res[m * p.ldr + n + e];
+          e_out[m * e_ldc + n + e] = vv[e];
+        }
       }
     }
   }
