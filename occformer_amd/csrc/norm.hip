@@ -30,7 +30,8 @@ __global__ void __launch_bounds__(256) gn_partial_kernel(const float* __restrict
   float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
   if (rt < R) {
     const float* base = x + ((long)b * V) * C + cq * 4;
-    for (long r = r0 + rt; r < r1; r += R) {
+#pragma unroll 8
+    for (long r = r0 + rt; r < r1; r += R) {      // independent 16-B loads: keep 8 in flight
       const float4 v = *(const float4*)(base + r * C);
       sm[0] += v.x; sm[1] += v.y; sm[2] += v.z; sm[3] += v.w;
       sq[0] = fmaf(v.x, v.x, sq[0]); sq[1] = fmaf(v.y, v.y, sq[1]);
@@ -89,14 +90,14 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
 }
 
 extern "C" long occf_groupnorm_workspace(int B, long V, int C, int G) {
-  const int rows = 512;
+  const int rows = 256;
   return (long)B * occf_cdiv(V, rows) * G * 2;
 }
 
 extern "C" int occf_groupnorm_stats(const float* x, float* stats, float* workspace, int B, long V, int C,
                                     int G, float eps, void* stream) {
   if (B <= 0 || V <= 0 || C % 4 != 0 || C > 1024 || G <= 0 || G > GN_MAXG || C % G != 0) return OCCF_ESHAPE;
-  const int rows = 512;
+  const int rows = 256;
   const int nblk = occf_cdiv(V, rows);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, B), dim3(256), 0, st, x, workspace, V, C, G, rows);
@@ -132,6 +133,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(
   const float* ri = residual ? residual + bp * Z * C + cq * 4 : nullptr;
   float* oi = out + bp * Zs * C + cq * 4;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
   for (int z = 0; z < Z; ++z) {
     const float4 v = *(const float4*)(xi + (long)z * C);
     float y[4] = {fmaf(v.x, sc[0], sh[0]), fmaf(v.y, sc[1], sh[1]), fmaf(v.z, sc[2], sh[2]),
