@@ -239,6 +239,24 @@ int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, const uint16_t
 int occf_deform_im2col(const float* x, const float* offset, float* col, int BN, int H, int W, int C, int K,
                        int stride, int pad, int dil, int groups, int deform_groups, void* stream);
 
+/* ------------------------------------------------------------------ training-time sampling */
+
+/* point_sample_3d (P/occformer/mask2former/base/mmdet_utils.py:21-47 = F.grid_sample on
+ * points in [0,1]): vol[N, C, X, Y, Z], pts[N (or 1 if shared_pts), P, 3] with the last dim in
+ * grid_sample order (pts[..,0] -> Z, [..,1] -> Y, [..,2] -> X), out[N, C, P]; trilinear,
+ * align_corners flag, zeros (0) or border (1) padding. */
+int occf_point_sample_3d_fwd(const float* vol, const float* pts, float* out, int N, int C, int X, int Y, int Z,
+                             long P, int shared_pts, int align_corners, int border_padding, void* stream);
+
+/* Weighted sampling without replacement = torch.multinomial(weights, k, replacement=False) of the
+ * class-guided sampler (mmdet_utils.py:91-136): the k largest exponential-race keys
+ * weights[i] / -log(uniforms[r, i]) per row, found by radix select + wavefront compaction.
+ * weights[R (or 1 if weights_shared), V], uniforms[R, V] in (0, 1], out_indices[R, k] int64 (an
+ * unordered set), workspace: occf_sample_wor_workspace(R, V) floats. */
+long occf_sample_wor_workspace(int R, long V);
+int occf_sample_wor_fwd(const float* weights, const float* uniforms, int64_t* out_indices, float* workspace,
+                        int R, long V, long k, int weights_shared, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ HEADER = os.path.join(_ROOT, "include", "occformer_hip.h")
 _CTYPES = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
            "double": ctypes.c_double, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
            "unsigned": ctypes.c_uint, "uint16_t": ctypes.c_uint16, "uint8_t": ctypes.c_uint8}
+_CTYPES["long"] = ctypes.c_long
 
 
 def parse_header(path=HEADER):

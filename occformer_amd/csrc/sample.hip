@@ -1,0 +1,231 @@
+// Training-time sampling kernels of the occupancy head:
+//   * point_sample_3d: trilinear gather of per-query / per-GT volumes at normalised points
+//   * class-guided sampling WITHOUT replacement over ~2 M voxels (torch.multinomial semantics):
+//     exponential-race keys  key_i = w_i / e_i,  e_i ~ Exp(1)  and a radix-select of the k largest
+//     keys, compacted with wavefront ballots / prefix popcounts.
+//
+// Reference: projects/mmdet3d_plugin/occformer/mask2former/base/mmdet_utils.py
+//   point_sample_3d :21-47 (F.grid_sample wrapper), sample_valid_coords_with_frequencies :91-108,
+//   batch_sample_valid_coords_with_frequencies :110-136 (torch.multinomial(w, k, replacement=False);
+//   ATen implements that as topk(w / q, k), q ~ Exp(1)), get_uncertain_point_coords_3d_with_frequency
+//   :179-246 (torch.topk of -|logit|).
+#include "occf_common.h"
+#include "../../include/occformer_hip.h"
+
+// ---------------------------------------------------------------------------------------
+// vol[N, C, X, Y, Z]; pts[N or 1, P, 3] in [0, 1], last dim ordered like grid_sample's grid for a
+// [.., X, Y, Z] tensor: pts[..,0] -> Z, pts[..,1] -> Y, pts[..,2] -> X.  out[N, C, P].
+__global__ void __launch_bounds__(256) point_sample_3d_kernel(const float* __restrict__ vol,
+                                                              const float* __restrict__ pts,
+                                                              float* __restrict__ out, int N, int C, int X, int Y,
+                                                              int Z, long P, int shared_pts, int align_corners,
+                                                              int border) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)N * P) return;
+  const int n = (int)(gid / P);
+  const long pi = gid % P;
+  const float* pt = pts + ((shared_pts ? 0 : (long)n * P) + pi) * 3;
+  const int dims[3] = {Z, Y, X};
+  int i0[3], i1[3];
+  float t[3];
+  bool ok0[3], ok1[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float g = pt[a] * 2.0f - 1.0f;
+    float f = align_corners ? (g + 1.f) * 0.5f * (float)(dims[a] - 1) : ((g + 1.f) * (float)dims[a] - 1.f) * 0.5f;
+    if (border) f = fminf(fmaxf(f, 0.f), (float)(dims[a] - 1));
+    const float fl = floorf(f);
+    i0[a] = (int)fl;
+    i1[a] = i0[a] + 1;
+    t[a] = f - fl;
+    ok0[a] = i0[a] >= 0 && i0[a] < dims[a];
+    ok1[a] = i1[a] >= 0 && i1[a] < dims[a];
+  }
+  const long V = (long)X * Y * Z;
+  for (int c = 0; c < C; ++c) {
+    const float* v = vol + ((long)n * C + c) * V;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int bz = k & 1, by = (k >> 1) & 1, bx = k >> 2;
+      const bool ok = (bz ? ok1[0] : ok0[0]) && (by ? ok1[1] : ok0[1]) && (bx ? ok1[2] : ok0[2]);
+      if (!ok) continue;
+      const int zz = bz ? i1[0] : i0[0], yy = by ? i1[1] : i0[1], xx = bx ? i1[2] : i0[2];
+      const float w = (bz ? t[0] : 1.f - t[0]) * (by ? t[1] : 1.f - t[1]) * (bx ? t[2] : 1.f - t[2]);
+      acc = fmaf(w, v[((long)xx * Y + yy) * Z + zz], acc);
+    }
+    out[((long)n * C + c) * P + pi] = acc;
+  }
+}
+
+extern "C" int occf_point_sample_3d_fwd(const float* vol, const float* pts, float* out, int N, int C, int X, int Y,
+                                        int Z, long P, int shared_pts, int align_corners, int border_padding,
+                                        void* stream) {
+  if (N <= 0 || C <= 0 || X <= 0 || Y <= 0 || Z <= 0 || P < 0) return OCCF_EINVAL;
+  if (P == 0) return 0;
+  hipLaunchKernelGGL(point_sample_3d_kernel, dim3(occf_cdiv((long)N * P, 256)), dim3(256), 0, (hipStream_t)stream,
+                     vol, pts, out, N, C, X, Y, Z, P, shared_pts, align_corners, border_padding);
+  OCCF_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------
+// Weighted sampling without replacement: k indices per row out of V with probability ~ weights.
+// keys[r, i] = w[i] / (-log u[r, i])  (u uniform in (0,1]; w >= 0; w == 0 -> key 0, never drawn
+// before a positive weight).  Selection = the k largest keys per row:
+//   1. key kernel (one pass, also the level-0 histogram of the top 11 key bits),
+//   2. two more histogram passes (11 + 10 bits) narrow the k-th largest key to its exact value,
+//   3. compaction: every element above the threshold, plus elements equal to it until k slots
+//      are filled; slots are allocated per wave from a ballot + prefix popcount (one atomic per
+//      wave), so the output is an unordered set (torch returns it sorted by key; the consumers
+//      -- gather + top-k by uncertainty -- only use it as a set).
+#define TK_B0 11
+#define TK_B1 11
+#define TK_B2 10
+
+__device__ __forceinline__ unsigned tk_bits(float f) {
+#ifdef OCCF_EMU
+  unsigned u;
+  memcpy(&u, &f, 4);
+  return u;
+#else
+  return __float_as_uint(f);
+#endif
+}
+
+__global__ void __launch_bounds__(256) tk_keys_kernel(const float* __restrict__ w, const float* __restrict__ u,
+                                                      float* __restrict__ keys, unsigned* __restrict__ hist0,
+                                                      long V, int w_shared) {
+  __shared__ unsigned h[1 << TK_B0];
+  const int r = blockIdx.y;
+  for (int i = threadIdx.x; i < (1 << TK_B0); i += blockDim.x) h[i] = 0;
+  __syncthreads();
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (long)gridDim.x * blockDim.x) {
+    const float wi = w[(w_shared ? 0 : (long)r * V) + i];
+    const float e = -logf(u[(long)r * V + i]);
+    const float key = wi > 0.f ? wi / fmaxf(e, 1e-38f) : 0.f;
+    keys[(long)r * V + i] = key;
+    atomicAdd(&h[tk_bits(key) >> (32 - TK_B0)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (1 << TK_B0); i += blockDim.x)
+    if (h[i]) atomicAdd(&hist0[(long)r * (1 << TK_B0) + i], h[i]);
+}
+
+// histogram of the next `bits` bits among the keys whose already-fixed prefix equals state.prefix
+// state[r] = {prefix, prefix_bits, remaining_k, _}
+__global__ void __launch_bounds__(256) tk_hist_kernel(const float* __restrict__ keys, const unsigned* __restrict__ state,
+                                                      unsigned* __restrict__ hist, long V, int bits) {
+  __shared__ unsigned h[1 << TK_B0];
+  const int r = blockIdx.y;
+  const unsigned prefix = state[r * 4 + 0], pbits = state[r * 4 + 1];
+  for (int i = threadIdx.x; i < (1 << bits); i += blockDim.x) h[i] = 0;
+  __syncthreads();
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (long)gridDim.x * blockDim.x) {
+    const unsigned b = tk_bits(keys[(long)r * V + i]);
+    if ((b >> (32 - pbits)) == prefix) atomicAdd(&h[(b >> (32 - pbits - bits)) & ((1u << bits) - 1)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (1 << bits); i += blockDim.x)
+    if (h[i]) atomicAdd(&hist[(long)r * (1 << TK_B0) + i], h[i]);
+}
+
+// one workgroup per row: walk the histogram from the largest bin down, find the bin that holds the
+// remaining_k-th key; serial scan by wave 0 with a wavefront prefix sum
+__global__ void __launch_bounds__(64) tk_scan_kernel(unsigned* __restrict__ hist, unsigned* __restrict__ state,
+                                                     int bits, int first, unsigned k) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  unsigned* h = hist + (long)r * (1 << TK_B0);
+  unsigned remaining = first ? k : state[r * 4 + 2];
+  const unsigned prefix = first ? 0u : state[r * 4 + 0], pbits = first ? 0u : state[r * 4 + 1];
+  const int nb = 1 << bits;
+  int found = -1;
+  unsigned above = 0;
+  for (int base = nb - 64; base >= 0 && found < 0; base -= 64) {
+    const int bin = base + 63 - lane;                      // lane 0 = largest bin of this group
+    unsigned c = h[bin], incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {                     // inclusive wavefront scan
+      const unsigned t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    const unsigned total = __shfl(incl, 63);
+    const bool hit = above + incl >= remaining && above + incl - c < remaining;
+    const unsigned long long m = __ballot(hit);
+    if (m) {
+      const int l = __ffsll((long long)m) - 1;
+      found = base + 63 - l;
+      above += __shfl(incl - c, l);
+    } else {
+      above += total;
+    }
+  }
+  for (int i = lane; i < nb; i += 64) h[i] = 0;            // ready for the next level
+  if (lane == 0) {
+    state[r * 4 + 0] = (prefix << bits) | (unsigned)(found < 0 ? 0 : found);
+    state[r * 4 + 1] = pbits + bits;
+    state[r * 4 + 2] = remaining - above;                  // still to take inside the chosen bin
+    state[r * 4 + 3] = 0;                                  // compaction counters
+  }
+}
+
+__global__ void __launch_bounds__(256) tk_compact_kernel(const float* __restrict__ keys,
+                                                         unsigned* __restrict__ state, int* __restrict__ counters,
+                                                         int64_t* __restrict__ out, long V, unsigned k) {
+  const int r = blockIdx.y;
+  const unsigned thr = state[r * 4 + 0];                   // exact bit pattern of the k-th largest key
+  const unsigned ties = state[r * 4 + 2];                  // how many keys == thr to take
+  const int lane = threadIdx.x & 63;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i0 = (long)blockIdx.x * blockDim.x + (threadIdx.x & ~63); i0 < V; i0 += stride) {
+    const long i = i0 + lane;
+    const unsigned b = i < V ? tk_bits(keys[(long)r * V + i]) : 0u;
+    const bool gt = i < V && b > thr;
+    const bool eq = i < V && b == thr;
+    const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+    if (mg) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&counters[r * 2 + 0], __popcll(mg));
+      base = __shfl(base, 0);
+      if (gt) out[(long)r * k + base + __popcll(mg & ((1ull << lane) - 1))] = i;
+    }
+    if (me) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&counters[r * 2 + 1], __popcll(me));
+      base = __shfl(base, 0);
+      const int slot = base + __popcll(me & ((1ull << lane) - 1));
+      if (eq && slot < (int)ties) out[(long)r * k + (k - ties) + slot] = i;
+    }
+  }
+}
+
+extern "C" long occf_sample_wor_workspace(int R, long V) {
+  // keys [R*V] floats + hist [R * 2^11] + state [R*4] + counters [R*2]   (all 4-byte words)
+  return (long)R * V + (long)R * (1 << TK_B0) + (long)R * 4 + (long)R * 2;
+}
+
+extern "C" int occf_sample_wor_fwd(const float* weights, const float* uniforms, int64_t* out_indices,
+                                   float* workspace, int R, long V, long k, int weights_shared, void* stream) {
+  if (R <= 0 || V <= 0 || k <= 0 || k > V || V >= 2147483647L) return OCCF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  float* keys = workspace;
+  unsigned* hist = (unsigned*)(workspace + (long)R * V);
+  unsigned* state = hist + (long)R * (1 << TK_B0);
+  int* counters = (int*)(state + (long)R * 4);
+  const size_t zero_bytes = sizeof(unsigned) * ((size_t)R * (1 << TK_B0) + (size_t)R * 4 + (size_t)R * 2);
+#ifndef OCCF_EMU
+  hipError_t e = hipMemsetAsync(hist, 0, zero_bytes, st);
+  if (e != hipSuccess) return (int)e;
+#else
+  memset(hist, 0, zero_bytes);
+#endif
+  const dim3 grid((unsigned)(occf_cdiv(V, 256) < 1024 ? occf_cdiv(V, 256) : 1024), R);
+  hipLaunchKernelGGL(tk_keys_kernel, grid, dim3(256), 0, st, weights, uniforms, keys, hist, V, weights_shared);
+  hipLaunchKernelGGL(tk_scan_kernel, dim3(R), dim3(64), 0, st, hist, state, TK_B0, 1, (unsigned)k);
+  hipLaunchKernelGGL(tk_hist_kernel, grid, dim3(256), 0, st, keys, state, hist, V, TK_B1);
+  hipLaunchKernelGGL(tk_scan_kernel, dim3(R), dim3(64), 0, st, hist, state, TK_B1, 0, (unsigned)k);
+  hipLaunchKernelGGL(tk_hist_kernel, grid, dim3(256), 0, st, keys, state, hist, V, TK_B2);
+  hipLaunchKernelGGL(tk_scan_kernel, dim3(R), dim3(64), 0, st, hist, state, TK_B2, 0, (unsigned)k);
+  hipLaunchKernelGGL(tk_compact_kernel, grid, dim3(256), 0, st, keys, state, counters, out_indices, V,
+                     (unsigned)k);
+  OCCF_LAUNCH_CHECK();
+}

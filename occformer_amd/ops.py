@@ -363,6 +363,30 @@ class HipOps:
                    BN, H, W, C, K, stride, pad, dil, groups, deform_groups, self._stream())
         return col
 
+    # ------------------------------------------------------------------ training-time sampling
+    def point_sample_3d(self, vol, pts, align_corners=False, padding_mode="zeros"):
+        """vol [N, C, X, Y, Z]; pts [N, P, 3] (or [1, P, 3] shared by all N) in [0, 1], last dim in
+        grid_sample order (z, y, x) -> [N, C, P]."""
+        N, C, X, Y, Z = vol.shape
+        P = pts.shape[1]
+        shared = pts.shape[0] == 1 and N > 1
+        out = torch.empty((N, C, P), dtype=vol.dtype, device=vol.device)
+        self._call("occf_point_sample_3d_fwd", self._ptr(vol, self.f32), self._ptr(pts, self.f32), self._ptr(out),
+                   N, C, X, Y, Z, P, int(shared), int(align_corners), int(padding_mode == "border"),
+                   self._stream())
+        return out
+
+    def sample_without_replacement(self, weights, uniforms, k):
+        """weights [R, V] or [1, V]; uniforms [R, V] in (0, 1] -> int64 indices [R, k] (unordered)."""
+        R, V = uniforms.shape
+        need = self.lib.occf_sample_wor_workspace(R, V)
+        ws = torch.empty((need,), dtype=self.f32, device=uniforms.device)
+        out = torch.empty((R, k), dtype=torch.int64, device=uniforms.device)
+        self._call("occf_sample_wor_fwd", self._ptr(weights, self.f32), self._ptr(uniforms, self.f32),
+                   self._ptr(out), self._ptr(ws), R, V, int(k), int(weights.shape[0] == 1 and R > 1),
+                   self._stream())
+        return out
+
 
 _ops = None
 

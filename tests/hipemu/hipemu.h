@@ -180,6 +180,8 @@ static inline unsigned atomicOr(unsigned* p, unsigned v) {
   return o;
 }
 #define __expf(x) expf(x)
+#define __ffsll(x) __builtin_ffsll(x)
+#define __popcll(x) __builtin_popcountll(x)
 static inline float __fdividef(float a, float b) { return a / b; }
 
 // ---- MFMA (collective over the 64-lane wave); layouts per cdna_hip_programming.md §3

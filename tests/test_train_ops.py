@@ -1,0 +1,59 @@
+"""Training-time sampling kernels vs PyTorch / the reference semantics."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import paramgen
+
+
+@pytest.mark.parametrize("align,pad", [(False, "border"), (True, "zeros"), (False, "zeros"), (True, "border")])
+def test_point_sample_3d(be, align, pad):
+    N, C, X, Y, Z, P = 5, 2, 6, 5, 4, 300
+    vol = paramgen.tensor("psv", (N, C, X, Y, Z), 1)
+    pts = paramgen.uniform("psp", (N, P, 3), 1) * 1.3 - 0.15           # some out of range
+    ref = F.grid_sample(vol, (pts * 2 - 1).view(N, P, 1, 1, 3), mode="bilinear", padding_mode=pad,
+                        align_corners=align).view(N, C, P)
+    out = be.ops.point_sample_3d(be.to(vol), be.to(pts), align, pad).cpu()
+    assert torch.allclose(out, ref, atol=2e-5, rtol=1e-4)
+    shared = pts[:1].contiguous()
+    ref2 = F.grid_sample(vol, (shared.expand(N, -1, -1) * 2 - 1).view(N, P, 1, 1, 3), mode="bilinear",
+                         padding_mode=pad, align_corners=align).view(N, C, P)
+    out2 = be.ops.point_sample_3d(be.to(vol), be.to(shared), align, pad).cpu()
+    assert torch.allclose(out2, ref2, atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("R,V,k,shared", [(3, 5000, 700, True), (2, 4096, 4096, False), (1, 300, 1, True),
+                                          (4, 20000, 15000, True)])
+def test_sample_without_replacement_matches_exponential_race_topk(be, R, V, k, shared):
+    """same selected SET as torch's own algorithm for multinomial(replacement=False):
+    topk(w / q), q ~ Exp(1), with the exponential noise injected"""
+    w = paramgen.uniform("sw", (1 if shared else R, V), 2) ** 3
+    w[:, ::7] = 0.0                                                      # zero-weight voxels are never drawn
+    u = paramgen.uniform("su", (R, V), 3).clamp_min(1e-12)
+    keys = torch.where(w > 0, w / (-torch.log(u)).clamp_min(1e-38), torch.zeros(()))
+    kk = min(k, int((keys[0] > 0).sum())) if k < V else k
+    ref = torch.topk(keys.expand(R, V) if shared else keys, k, dim=1)[1]
+    out = be.ops.sample_without_replacement(be.to(w), be.to(u), k).cpu()
+    for r in range(R):
+        a, b = set(out[r].tolist()), set(ref[r].tolist())
+        assert len(a) == k
+        # ties among zero keys (when k exceeds the positive-weight count) may resolve differently
+        pos = {i for i in b if float(keys[r if not shared else r % keys.shape[0] if keys.shape[0] > 1 else 0, i]
+                                     if keys.shape[0] > 1 else keys[0, i]) > 0} if shared and False else None
+        kr = keys[r] if keys.shape[0] > 1 else keys[0] if shared and keys.shape[0] == 1 else keys[r]
+        a_pos = {i for i in a if float(kr[i]) > 0}
+        b_pos = {i for i in b if float(kr[i]) > 0}
+        assert a_pos == b_pos
+
+
+def test_sample_without_replacement_distribution(be):
+    """chi-square style check: empirical inclusion frequency follows the class weights"""
+    V, k, R = 2000, 200, 64
+    w = torch.ones(1, V)
+    w[:, :500] = 4.0
+    u = paramgen.uniform("sd", (R, V), 5).clamp_min(1e-12)
+    out = be.ops.sample_without_replacement(be.to(w), be.to(u), k).cpu()
+    frac_heavy = float((out < 500).float().mean())
+    # expected share of heavy items among the first 10% drawn: ~ 4*500/(4*500+1500) = 0.571 (slightly less
+    # without replacement)
+    assert 0.50 < frac_heavy < 0.60
