@@ -251,11 +251,22 @@ int occf_point_sample_3d_fwd(const float* vol, const float* pts, float* out, int
 /* Weighted sampling without replacement = torch.multinomial(weights, k, replacement=False) of the
  * class-guided sampler (mmdet_utils.py:91-136): the k largest exponential-race keys
  * weights[i] / -log(uniforms[r, i]) per row, found by radix select + wavefront compaction.
- * weights[R (or 1 if weights_shared), V], uniforms[R, V] in (0, 1], out_indices[R, k] int64 (an
+ * weights[R (or 1 if weights_shared), V], noise[R, V] = uniforms in (0, 1] or, with
+ * noise_is_exponential, the Exp(1) draws q themselves (key = w / q), out_indices[R, k] int64 (an
  * unordered set), workspace: occf_sample_wor_workspace(R, V) floats. */
 long occf_sample_wor_workspace(int R, long V);
-int occf_sample_wor_fwd(const float* weights, const float* uniforms, int64_t* out_indices, float* workspace,
-                        int R, long V, long k, int weights_shared, void* stream);
+int occf_sample_wor_fwd(const float* weights, const float* noise, int64_t* out_indices, float* workspace,
+                        int R, long V, long k, int weights_shared, int noise_is_exponential, void* stream);
+
+/* Importance sampling (mmdet_utils.py:138-177, 179-246: topk(-|logit|, k)): indices of the k values
+ * with the smallest magnitude per row; values[R, V], out_indices[R, k] int64 (unordered set),
+ * workspace as occf_sample_wor_workspace(R, V). */
+int occf_topk_smallest_abs_fwd(const float* values, int64_t* out_indices, float* workspace, int R, long V, long k,
+                               void* stream);
+
+/* Row sums behind the point-sampled mask losses (mask2former_nusc_occ.py:396-417; losses/dice_loss.py:8-61):
+ * out[R, 4] = { sum BCE-with-logits(x, t), sum sigmoid(x)*t, sum sigmoid(x), sum t } over logits/targets[R, P]. */
+int occf_point_loss_rows_fwd(const float* logits, const float* targets, float* out, int R, long P, void* stream);
 
 #ifdef __cplusplus
 }

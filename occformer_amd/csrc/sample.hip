@@ -91,18 +91,34 @@ __device__ __forceinline__ unsigned tk_bits(float f) {
   return __float_as_uint(f);
 #endif
 }
+__device__ __forceinline__ float tk_from_bits(unsigned u) {
+#ifdef OCCF_EMU
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+#else
+  return __uint_as_float(u);
+#endif
+}
 
 __global__ void __launch_bounds__(256) tk_keys_kernel(const float* __restrict__ w, const float* __restrict__ u,
                                                       float* __restrict__ keys, unsigned* __restrict__ hist0,
-                                                      long V, int w_shared) {
+                                                      long V, int w_shared, int mode) {
   __shared__ unsigned h[1 << TK_B0];
   const int r = blockIdx.y;
   for (int i = threadIdx.x; i < (1 << TK_B0); i += blockDim.x) h[i] = 0;
   __syncthreads();
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < V; i += (long)gridDim.x * blockDim.x) {
     const float wi = w[(w_shared ? 0 : (long)r * V) + i];
-    const float e = -logf(u[(long)r * V + i]);
-    const float key = wi > 0.f ? wi / fmaxf(e, 1e-38f) : 0.f;
+    float key;
+    if (mode == 0) {
+      const float e = -logf(u[(long)r * V + i]);
+      key = wi > 0.f ? wi / fmaxf(e, 1e-38f) : 0.f;
+    } else if (mode == 2) {  // the noise already is Exp(1) (ATen's multinomial: key = w / q)
+      key = wi > 0.f ? wi / u[(long)r * V + i] : 0.f;
+    } else {  // smallest |v| first: order-reversing bit pattern of |v|
+      key = tk_from_bits(0x7F800000u - (tk_bits(wi) & 0x7FFFFFFFu));
+    }
     keys[(long)r * V + i] = key;
     atomicAdd(&h[tk_bits(key) >> (32 - TK_B0)], 1u);
   }
@@ -203,8 +219,8 @@ extern "C" long occf_sample_wor_workspace(int R, long V) {
   return (long)R * V + (long)R * (1 << TK_B0) + (long)R * 4 + (long)R * 2;
 }
 
-extern "C" int occf_sample_wor_fwd(const float* weights, const float* uniforms, int64_t* out_indices,
-                                   float* workspace, int R, long V, long k, int weights_shared, void* stream) {
+static int tk_select(const float* weights, const float* uniforms, int64_t* out_indices, float* workspace, int R,
+                     long V, long k, int weights_shared, int mode, void* stream) {
   if (R <= 0 || V <= 0 || k <= 0 || k > V || V >= 2147483647L) return OCCF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   float* keys = workspace;
@@ -219,7 +235,7 @@ extern "C" int occf_sample_wor_fwd(const float* weights, const float* uniforms, 
   memset(hist, 0, zero_bytes);
 #endif
   const dim3 grid((unsigned)(occf_cdiv(V, 256) < 1024 ? occf_cdiv(V, 256) : 1024), R);
-  hipLaunchKernelGGL(tk_keys_kernel, grid, dim3(256), 0, st, weights, uniforms, keys, hist, V, weights_shared);
+  hipLaunchKernelGGL(tk_keys_kernel, grid, dim3(256), 0, st, weights, uniforms, keys, hist, V, weights_shared, mode);
   hipLaunchKernelGGL(tk_scan_kernel, dim3(R), dim3(64), 0, st, hist, state, TK_B0, 1, (unsigned)k);
   hipLaunchKernelGGL(tk_hist_kernel, grid, dim3(256), 0, st, keys, state, hist, V, TK_B1);
   hipLaunchKernelGGL(tk_scan_kernel, dim3(R), dim3(64), 0, st, hist, state, TK_B1, 0, (unsigned)k);
@@ -227,5 +243,55 @@ extern "C" int occf_sample_wor_fwd(const float* weights, const float* uniforms, 
   hipLaunchKernelGGL(tk_scan_kernel, dim3(R), dim3(64), 0, st, hist, state, TK_B2, 0, (unsigned)k);
   hipLaunchKernelGGL(tk_compact_kernel, grid, dim3(256), 0, st, keys, state, counters, out_indices, V,
                      (unsigned)k);
+  OCCF_LAUNCH_CHECK();
+}
+
+extern "C" int occf_sample_wor_fwd(const float* weights, const float* noise, int64_t* out_indices, float* workspace,
+                                   int R, long V, long k, int weights_shared, int noise_is_exponential,
+                                   void* stream) {
+  return tk_select(weights, noise, out_indices, workspace, R, V, k, weights_shared, noise_is_exponential ? 2 : 0,
+                   stream);
+}
+
+extern "C" int occf_topk_smallest_abs_fwd(const float* values, int64_t* out_indices, float* workspace, int R, long V,
+                                          long k, void* stream) {
+  return tk_select(values, values, out_indices, workspace, R, V, k, 0, 1, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row sums for the point-sampled mask losses: out[r] = { sum BCE-with-logits(x, t), sum sigmoid(x)*t,
+// sum sigmoid(x), sum t } over the P sampled points of row r.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) point_loss_rows_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                              float* __restrict__ out, long P) {
+  __shared__ float red[4][4];
+  const int r = blockIdx.x;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (long i = threadIdx.x; i < P; i += blockDim.x) {
+    const float xi = x[(long)r * P + i], ti = t[(long)r * P + i];
+    // max(x,0) - x*t + log1p(exp(-|x|))   (the form F.binary_cross_entropy_with_logits uses)
+    a0 += fmaxf(xi, 0.f) - xi * ti + log1pf(expf(-fabsf(xi)));
+    const float s = 1.f / (1.f + expf(-xi));
+    a1 += s * ti;
+    a2 += s;
+    a3 += ti;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    a0 += __shfl_down(a0, o);
+    a1 += __shfl_down(a1, o);
+    a2 += __shfl_down(a2, o);
+    a3 += __shfl_down(a3, o);
+  }
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[wv][0] = a0; red[wv][1] = a1; red[wv][2] = a2; red[wv][3] = a3; }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    out[(long)r * 4 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+extern "C" int occf_point_loss_rows_fwd(const float* logits, const float* targets, float* out, int R, long P,
+                                        void* stream) {
+  if (R <= 0 || P <= 0) return OCCF_EINVAL;
+  hipLaunchKernelGGL(point_loss_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, targets, out, P);
   OCCF_LAUNCH_CHECK();
 }

@@ -188,8 +188,14 @@ class OccupancyFormer(nn.Module):
 
     def forward_train(self, points=None, img_metas=None, img_inputs=None, gt_occ=None, points_occ=None,
                       **kwargs):
-        raise NotImplementedError("training losses (Hungarian assignment, class-guided sampling) are the "
-                                  "next rows of the scope table; the forward path is complete")
+        """occupancyformer.py:132-199 -- loss VALUES of one training step (depth BCE + the head's Hungarian
+        losses).  The HIP modules build no autograd graph (backward kernels exist for the voxel pooling only),
+        so this is the forward half of the reference's training step."""
+        voxel_feats, img_feats, depth = self.extract_feat(points=None, img=img_inputs, img_metas=img_metas)
+        losses = {"loss_depth": self.img_view_transformer.get_depth_loss(img_inputs[7], depth)}
+        losses.update(self.pts_bbox_head.forward_train(voxel_feats=voxel_feats, img_metas=img_metas, gt_occ=gt_occ,
+                                                       points=points_occ, img_feats=img_feats, **kwargs))
+        return losses
 
     def forward_test(self, img_metas=None, img_inputs=None, **kwargs):
         return self.simple_test(img_metas, img_inputs, **kwargs)

@@ -7,6 +7,7 @@ state-dict names; the mmcv/mmdet bricks underneath
 (DetrTransformerDecoder(+Layer), MultiheadAttention -> nn.MultiheadAttention, FFN) are
 folded into plain modules.  Tokens are batch-first.  Kernels: csrc/mask_head.hip.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -16,6 +17,8 @@ from .encoder import _FFN
 from .ops import get_ops
 from .pixel_decoder import SinePositionalEncoding3D
 from .registry import HEADS
+from .training import (KittiTrainingMixin, NuscTrainingMixin, OccHeadTrainingMixin,
+                       semantic_kitti_class_frequencies)
 
 
 class _MHAParams(nn.Module):
@@ -85,7 +88,7 @@ class _Decoder(nn.Module):
         self.embed_dims = E
 
 
-class _Mask2FormerOccBase(nn.Module):
+class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
     def __init__(self, feat_channels, out_channels, num_occupancy_classes=20, num_queries=100,
                  num_transformer_feat_level=3, enforce_decoder_input_project=False,
                  transformer_decoder=None, positional_encoding=None, pooling_attn_mask=True,
@@ -117,15 +120,15 @@ class _Mask2FormerOccBase(nn.Module):
         self.mask_embed = nn.Sequential(nn.Linear(feat_channels, feat_channels), nn.ReLU(inplace=True),
                                         nn.Linear(feat_channels, feat_channels), nn.ReLU(inplace=True),
                                         nn.Linear(feat_channels, out_channels))
-        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.test_cfg = test_cfg
         self.loss_cfgs = dict(cls=loss_cls, mask=loss_mask, dice=loss_dice)
-        self.class_weight = loss_cls["class_weight"] if loss_cls else None
         self.pooling_attn_mask = pooling_attn_mask
         self.align_corners = align_corners
         self.padding_mode = padding_mode
         self.sample_weight_gamma = sample_weight_gamma
         if not pooling_attn_mask:
             raise NotImplementedError("only preserve-pooling attention masks (every OccFormer config)")
+        self._init_training(train_cfg, loss_cls, loss_mask, loss_dice)
 
     def init_weights(self):
         for p in self.transformer_decoder.parameters():
@@ -211,7 +214,7 @@ class _Mask2FormerOccBase(nn.Module):
 
 
 @HEADS.register_module()
-class Mask2FormerNuscOccHead(_Mask2FormerOccBase):
+class Mask2FormerNuscOccHead(NuscTrainingMixin, _Mask2FormerOccBase):
     # -- mask2former_nusc_occ.py:505-542 (eval branch)
     def forward_lidarseg(self, cls_preds, mask_preds, points, img_metas=None):
         pc = torch.tensor(img_metas[0]["pc_range"], dtype=torch.float32, device=mask_preds.device)
@@ -237,7 +240,15 @@ class Mask2FormerNuscOccHead(_Mask2FormerOccBase):
 
 
 @HEADS.register_module()
-class Mask2FormerOccHead(_Mask2FormerOccBase):
+class Mask2FormerOccHead(KittiTrainingMixin, _Mask2FormerOccBase):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        # mask2former_occ.py:133-142: SemanticKITTI class weights 1/log(freq), normalised to class 0,
+        # background weight kept from the config
+        w = 1 / np.log(semantic_kitti_class_frequencies)
+        self.class_weight = (w / w[0]).tolist() + [self.class_weight[-1]]
+        self.get_sampling_weights()
+
     # -- mask2former_occ.py:673-703
     def simple_test(self, voxel_feats, img_metas, **kwargs):
         all_cls, all_masks = self(voxel_feats, img_metas, last_only=True)

@@ -376,15 +376,33 @@ class HipOps:
                    self._stream())
         return out
 
-    def sample_without_replacement(self, weights, uniforms, k):
-        """weights [R, V] or [1, V]; uniforms [R, V] in (0, 1] -> int64 indices [R, k] (unordered)."""
+    def sample_without_replacement(self, weights, uniforms, k, exponential=False):
+        """weights [R, V] or [1, V]; uniforms [R, V] in (0, 1] (or Exp(1) draws with exponential=True)
+        -> int64 indices [R, k] (unordered)."""
         R, V = uniforms.shape
         need = self.lib.occf_sample_wor_workspace(R, V)
         ws = torch.empty((need,), dtype=self.f32, device=uniforms.device)
         out = torch.empty((R, k), dtype=torch.int64, device=uniforms.device)
         self._call("occf_sample_wor_fwd", self._ptr(weights, self.f32), self._ptr(uniforms, self.f32),
                    self._ptr(out), self._ptr(ws), R, V, int(k), int(weights.shape[0] == 1 and R > 1),
-                   self._stream())
+                   int(exponential), self._stream())
+        return out
+
+    def topk_smallest_abs(self, values, k):
+        """values [R, V] -> int64 indices [R, k] of the k smallest |values| per row (unordered)."""
+        R, V = values.shape
+        ws = torch.empty((self.lib.occf_sample_wor_workspace(R, V),), dtype=self.f32, device=values.device)
+        out = torch.empty((R, k), dtype=torch.int64, device=values.device)
+        self._call("occf_topk_smallest_abs_fwd", self._ptr(values, self.f32), self._ptr(out), self._ptr(ws), R, V,
+                   int(k), self._stream())
+        return out
+
+    def point_loss_rows(self, logits, targets):
+        """logits/targets [R, P] -> [R, 4] = sums of {BCE, sigmoid*t, sigmoid, t}."""
+        R, P = logits.shape
+        out = torch.empty((R, 4), dtype=self.f32, device=logits.device)
+        self._call("occf_point_loss_rows_fwd", self._ptr(logits, self.f32), self._ptr(targets, self.f32),
+                   self._ptr(out), R, P, self._stream())
         return out
 
 

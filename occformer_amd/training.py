@@ -1,0 +1,403 @@
+"""Training-time target assignment and losses of the occupancy heads, forward
+values, on the HIP kernels of csrc/sample.hip:
+
+  point sampling         -> occf_point_sample_3d_fwd   (one launch for all queries / GT masks, points shared)
+  class-guided sampling  -> occf_sample_wor_fwd        (radix select of the exponential-race keys)
+  importance sampling    -> occf_topk_smallest_abs_fwd
+  matching costs         -> one fp32 MFMA GEMM [2Q, P] x [P, G] + occf_point_loss_rows_fwd
+  point losses           -> occf_point_loss_rows_fwd   (BCE / dice row sums in one pass)
+
+The function names and argument meaning mirror the reference
+(P = projects/mmdet3d_plugin/occformer/mask2former):
+  P/base/mmdet_utils.py:21-47, 71-136, 138-246, 426-475; P/assigners/mask_hungarian_assigner.py:42-126;
+  P/assigners/match_costs/match_cost.py:9-128; P/losses/dice_loss.py:8-61;
+  P/mask2former_nusc_occ.py:153-424, 547-587; P/mask2former_occ.py:158-166, 224-444, 525-567.
+
+All randomness comes from an ``rng`` object (``rand``, ``randperm``, ``exponential``) so that a run is
+reproducible and testable on injected noise; ``DeviceRNG`` is the default.  The Hungarian step runs on the
+host with scipy exactly like the reference (one host sync per image and decoder layer).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy.optimize import linear_sum_assignment
+
+from .ops import get_ops
+
+# P/../utils/semkitti.py:3-26
+semantic_kitti_class_frequencies = np.array([
+    5.41773033e09, 1.57835390e07, 1.25136000e05, 1.18809000e05, 6.46799000e05, 8.21951000e05, 2.62978000e05,
+    2.83696000e05, 2.04750000e05, 6.16887030e07, 4.50296100e06, 4.48836500e07, 2.26992300e06, 5.68402180e07,
+    1.57196520e07, 1.58442623e08, 2.06162300e06, 3.69705220e07, 1.15198800e06, 3.34146000e05])
+
+
+class DeviceRNG:
+    """noise source on the compute device (a seeded torch.Generator)"""
+
+    def __init__(self, device, seed=0):
+        self.device = torch.device(device)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed)
+
+    def rand(self, *shape):
+        return torch.rand(tuple(shape), device=self.device, generator=self.gen)
+
+    def randperm(self, n):
+        return torch.randperm(n, device=self.device, generator=self.gen)
+
+    def exponential(self, shape, dtype=torch.float32):
+        return torch.empty(tuple(shape), device=self.device, dtype=torch.float32).exponential_(1, generator=self.gen)
+
+
+# ------------------------------------------------------------------------------------------ helpers
+def point_sample_3d(input, points, align_corners=False, padding_mode="zeros"):
+    """mmdet_utils.py:21-47.  input [N, C, X, Y, Z]; points [N, P, 3] (or [1, P, 3] shared) in [0, 1]."""
+    return get_ops().point_sample_3d(input.contiguous(), points.contiguous(), align_corners, padding_mode)
+
+
+def unravel_indices(indices, shape):
+    """mmdet_utils.py:71-89"""
+    coord = []
+    for dim in reversed(shape):
+        coord.append(indices % dim)
+        indices = torch.div(indices, dim, rounding_mode="floor")
+    return torch.stack(coord[::-1], dim=-1)
+
+
+def preprocess_occupancy_gt(gt_occ, num_classes, img_metas=None):
+    """mmdet_utils.py:426-475: labels present (< num_classes) and their 0/1 int64 masks"""
+    gt_occ = gt_occ.squeeze(0)
+    labels = [l for l in torch.unique(gt_occ) if l < num_classes]
+    assert len(labels) > 0
+    return torch.stack(labels).long(), torch.stack([gt_occ == l for l in labels]).long()
+
+
+def _voxel_weights(gt_labels, gt_masks, sample_weights):
+    sw = torch.as_tensor(np.asarray(sample_weights), dtype=torch.float32, device=gt_masks.device)
+    return (sw[gt_labels].view(-1, 1) * gt_masks.reshape(gt_masks.shape[0], -1).float()).sum(0)
+
+
+def _norm_coords(idx, dims, like):
+    return unravel_indices(idx, dims).float() / (torch.tensor(dims, device=idx.device).float().view(1, 1, -1) - 1)
+
+
+def sample_valid_coords_with_frequencies(num_points, gt_labels, gt_masks, sample_weights, rng):
+    """mmdet_utils.py:91-108 -> (indices [num_points], coords [1, num_points, 3])"""
+    w = _voxel_weights(gt_labels, gt_masks, sample_weights)
+    # (the reference's weights are float64 here, so that is the dtype the noise is drawn in)
+    q = rng.exponential((w.numel(),), torch.float64).float().reshape(1, -1).to(w.device)
+    idx = get_ops().sample_without_replacement(w[None].contiguous(), q.contiguous(), num_points, exponential=True)[0]
+    return idx, _norm_coords(idx[None], gt_masks.shape[1:], gt_masks)
+
+
+def batch_sample_valid_coords_with_frequencies(num_points, gt_labels_list, gt_masks_list, sample_weights, rng):
+    """mmdet_utils.py:110-136 -> (indices [n_total_gt, num_points], coords [n_total_gt, num_points, 3]);
+    every GT row of an image shares that image's voxel weights (weights_shared launch, no repeat)"""
+    ops = get_ops()
+    n_total = sum(int(g.shape[0]) for g in gt_labels_list)
+    V = gt_masks_list[0][0].numel()
+    q = rng.exponential((n_total, V)).to(gt_masks_list[0].device)
+    out, r0 = [], 0
+    for gl, gm in zip(gt_labels_list, gt_masks_list):
+        n = int(gl.shape[0])
+        if n:
+            w = _voxel_weights(gl, gm, sample_weights)
+            out.append(ops.sample_without_replacement(w[None].contiguous(), q[r0:r0 + n].contiguous(), num_points,
+                                                      exponential=True))
+        r0 += n
+    idx = torch.cat(out, 0)
+    return idx, _norm_coords(idx, gt_masks_list[-1].shape[1:], gt_masks_list[-1])
+
+
+def get_uncertain_point_coords_3d_with_frequency(mask_pred, labels, gt_labels_list, gt_masks_list, sample_weights,
+                                                 num_points, oversample_ratio, importance_sample_ratio, rng,
+                                                 align_corners=True):
+    """mmdet_utils.py:179-246.  mask_pred [n_pos, 1, X, Y, Z]"""
+    ops = get_ops()
+    assert oversample_ratio >= 1 and 0 <= importance_sample_ratio <= 1
+    n = mask_pred.shape[0]
+    num_sampled = int(num_points * oversample_ratio)
+    idx, coords = batch_sample_valid_coords_with_frequencies(num_sampled, gt_labels_list, gt_masks_list,
+                                                             sample_weights, rng)
+    if tuple(mask_pred.shape[-3:]) == tuple(gt_masks_list[0].shape[1:]):
+        logits = torch.gather(mask_pred.reshape(n, -1), 1, idx)
+    else:
+        logits = point_sample_3d(mask_pred, coords[..., [2, 1, 0]], align_corners=True).squeeze(1)
+    n_unc = int(importance_sample_ratio * num_points)
+    top = ops.topk_smallest_abs(logits.contiguous(), n_unc)
+    idx = torch.gather(idx, 1, top)
+    coords = torch.gather(coords, 1, top[..., None].expand(-1, -1, 3))
+    if num_points - n_unc > 0:
+        ridx, rcoords = batch_sample_valid_coords_with_frequencies(num_points - n_unc, gt_labels_list, gt_masks_list,
+                                                                   np.ones_like(np.asarray(sample_weights)), rng)
+        idx, coords = torch.cat((idx, ridx), 1), torch.cat((coords, rcoords), 1)
+    return idx, coords
+
+
+def get_nusc_lidarseg_point_coords(mask_pred, gt_lidarseg_list, labels, num_points, oversample_ratio,
+                                   importance_sample_ratio, point_cloud_range, rng, padding_mode="border"):
+    """mmdet_utils.py:138-177.  mask_pred [n_pos, 1, X, Y, Z] ordered image by image; the GT rows of one image
+    share its candidate points, so the logits of an image come from ONE shared-points launch."""
+    ops = get_ops()
+    assert oversample_ratio >= 1 and 0 <= importance_sample_ratio <= 1
+    n_pos = mask_pred.shape[0]
+    num_sampled = int(num_points * oversample_ratio)
+    pcr = torch.tensor(point_cloud_range, dtype=mask_pred.dtype, device=mask_pred.device)
+    n_unc = int(importance_sample_ratio * num_points)
+    out, r0 = [], 0
+    for lidar, lab in zip(gt_lidarseg_list, labels):
+        n = int(lab.shape[0])
+        c = (lidar[:, :3].to(pcr) - pcr[:3]) / (pcr[3:] - pcr[:3])
+        c = torch.cat((c, rng.rand(num_sampled - c.shape[0], 3).to(c)), 0)
+        if n:
+            vol = mask_pred[r0:r0 + n, 0][None]                                     # [1, n, X, Y, Z]
+            logits = ops.point_sample_3d(vol.contiguous(), c[None, :, [2, 1, 0]].contiguous(), False, padding_mode)[0]
+            top = ops.topk_smallest_abs(logits.contiguous(), n_unc)                  # [n, n_unc]
+            out.append(c[top])
+        r0 += n
+    coords = torch.cat(out, 0)
+    if num_points - n_unc > 0:
+        coords = torch.cat((coords, rng.rand(n_pos, num_points - n_unc, 3).to(coords)), 1)
+    return coords
+
+
+# ------------------------------------------------------------------------------------------ matching
+class MaskHungarianAssigner:
+    """mask_hungarian_assigner.py:12-126 with ClassificationCost (mmdet), CrossEntropyLossCost
+    (match_cost.py:69-128) and DiceCost (:9-66) evaluated from one GEMM:
+        [x ; sigmoid(x)] [2Q, P] @ gt^T [P, G]  ->  x.gt  and  sigmoid(x).gt
+        BCE cost  = (sum softplus(x) - x.gt) / P          (pos - neg = -x)
+        dice cost = 1 - (2 sigmoid(x).gt + eps) / (sum sigmoid(x) + sum gt + eps)"""
+
+    def __init__(self, cls_cost=None, mask_cost=None, dice_cost=None):
+        self.w_cls = float((cls_cost or {}).get("weight", 1.0))
+        self.w_mask = float((mask_cost or {}).get("weight", 1.0))
+        dc = dice_cost or {}
+        self.w_dice = float(dc.get("weight", 1.0))
+        self.dice_eps = float(dc.get("eps", 1e-3))
+        if not dc.get("pred_act", False) or not dc.get("naive_dice", True):
+            raise NotImplementedError("DiceCost: pred_act=True / naive_dice=True is the configuration built")
+
+    def cost(self, cls_pred, mask_pred, gt_labels, gt_mask):
+        ops = get_ops()
+        x = mask_pred.flatten(1).float().contiguous()
+        g = gt_mask.flatten(1).float().contiguous()
+        Q, P = x.shape
+        rows = ops.point_loss_rows(x, torch.zeros_like(x))          # [:, 0] = sum softplus(x), [:, 2] = sum sigmoid
+        a = torch.cat((x, x.sigmoid()), 0)
+        if P % 4:
+            a, g2 = F.pad(a, (0, 4 - P % 4)), F.pad(g, (0, 4 - P % 4))
+        else:
+            g2 = g
+        prod = ops.linear(a.contiguous(), g2.contiguous(), allow_small=False)   # [2Q, G]
+        xg, sg = prod[:Q], prod[Q:]
+        bce = (rows[:, 0:1] - xg) / P
+        dice = 1 - (2 * sg + self.dice_eps) / (rows[:, 2:3] + g.sum(1)[None] + self.dice_eps)
+        cls = -cls_pred.softmax(-1)[:, gt_labels]
+        return cls * self.w_cls + bce * self.w_mask + dice * self.w_dice
+
+    def assign(self, cls_pred, mask_pred, gt_labels, gt_mask, img_meta=None):
+        """-> (assigned_gt_inds [Q] (0 = background, g+1 = matched to GT g), cost)"""
+        Q, G = mask_pred.shape[0], gt_labels.shape[0]
+        gt_inds = torch.zeros((Q,), dtype=torch.long, device=mask_pred.device)
+        if G == 0 or Q == 0:
+            return gt_inds, mask_pred.new_zeros((Q, G))
+        cost = self.cost(cls_pred, mask_pred, gt_labels, gt_mask)
+        r, c = linear_sum_assignment(cost.detach().cpu())
+        gt_inds[torch.from_numpy(r).to(gt_inds.device)] = torch.from_numpy(c).to(gt_inds.device) + 1
+        return gt_inds, cost
+
+
+# ------------------------------------------------------------------------------------------ losses
+def cross_entropy_loss(cls_scores, labels, label_weights, class_weight, avg_factor, loss_weight):
+    """mmdet 2.14.0 CrossEntropyLoss(use_sigmoid=False, class_weight, reduction='mean') with avg_factor"""
+    loss = F.cross_entropy(cls_scores, labels, weight=class_weight, reduction="none")
+    return loss_weight * (loss * label_weights.float()).sum() / avg_factor
+
+
+def point_mask_losses(point_preds, point_targets, mask_weights, num_points, dice_eps, w_mask, w_dice,
+                      weight_bce_rows):
+    """BCE (mmdet CrossEntropyLoss use_sigmoid) and naive Dice (dice_loss.py:8-61) over sampled points from one
+    pass of row sums.  ``weight_bce_rows``: KITTI weights the BCE rows by the class weight
+    (mask2former_occ.py:433-442); nuScenes divides by sum(w)*P only (mask2former_nusc_occ.py:411-417)."""
+    rows = get_ops().point_loss_rows(point_preds.contiguous(), point_targets.float().contiguous())
+    total = mask_weights.sum()
+    d = (2 * rows[:, 1] + dice_eps) / (rows[:, 2] + rows[:, 3] + dice_eps)
+    loss_dice = w_dice * ((1 - d) * mask_weights).sum() / total
+    if weight_bce_rows:
+        loss_mask = w_mask * (rows[:, 0] * mask_weights).sum() / (total * num_points)
+    else:
+        loss_mask = w_mask * rows[:, 0].sum() / (total * num_points)
+    return loss_mask, loss_dice
+
+
+def fast_hist_crop(output, target, unique_label):
+    """P/../utils/metric_util.py: confusion matrix restricted to unique_label + 1"""
+    n = int(np.max(unique_label)) + 2
+    k = (target >= 0) & (target < n)
+    hist = np.bincount(n * target[k].astype(int) + output[k], minlength=n ** 2).reshape(n, n)
+    hist = hist[unique_label + 1, :]
+    return hist[:, unique_label + 1]
+
+
+def per_class_iu(hist):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist))
+
+
+# ------------------------------------------------------------------------------------------ head mixin
+class OccHeadTrainingMixin:
+    """loss / target code shared by the two heads; the head provides num_queries, num_classes, class_weight,
+    loss weights and train_cfg fields (set up by ``_init_training``)."""
+
+    def _init_training(self, train_cfg, loss_cls, loss_mask, loss_dice):
+        self.train_cfg = train_cfg
+        self.class_weight = list((loss_cls or {}).get("class_weight", [1.0] * self.num_classes + [0.1]))
+        self.w_cls = float((loss_cls or {}).get("loss_weight", 1.0))
+        self.w_mask = float((loss_mask or {}).get("loss_weight", 1.0))
+        self.w_dice = float((loss_dice or {}).get("loss_weight", 1.0))
+        self.dice_eps = float((loss_dice or {}).get("eps", 1e-3))
+        self.rng = None
+        if train_cfg:
+            a = dict(train_cfg["assigner"])
+            a.pop("type", None)
+            self.assigner = MaskHungarianAssigner(**a)
+            self.num_points = train_cfg.get("num_points", 12544)
+            self.oversample_ratio = train_cfg.get("oversample_ratio", 3.0)
+            self.importance_sample_ratio = train_cfg.get("importance_sample_ratio", 0.75)
+
+    def _rng(self, device):
+        if self.rng is None:
+            self.rng = DeviceRNG(device)
+        return self.rng
+
+    def preprocess_gt(self, gt_occ, img_metas):
+        pairs = [preprocess_occupancy_gt(g, self.num_occupancy_classes) for g in gt_occ]
+        return [p[0] for p in pairs], [p[1] for p in pairs]
+
+    def _targets_from_assignment(self, gt_inds, cls_score, mask_pred, gt_labels, gt_masks):
+        # samplers/mask_pseudo_sampler.py: positives = matched queries in ascending order
+        pos = torch.nonzero(gt_inds > 0, as_tuple=False).squeeze(-1)
+        pos_gt = gt_inds[pos] - 1
+        labels = gt_labels.new_full((self.num_queries,), self.num_classes, dtype=torch.long)
+        labels[pos] = gt_labels[pos_gt]
+        cw = torch.tensor(self.class_weight, dtype=cls_score.dtype, device=cls_score.device)
+        mask_weights = mask_pred.new_zeros((self.num_queries,))
+        mask_weights[pos] = cw[labels[pos]]
+        return labels, torch.ones_like(mask_weights), gt_masks[pos_gt], mask_weights, pos, pos_gt
+
+    def loss(self, all_cls_scores, all_mask_preds, *gt):
+        """mask2former_nusc_occ.py:275-315 / mask2former_occ.py:294-341"""
+        per = [self.loss_single(c, m, *gt) for c, m in zip(all_cls_scores, all_mask_preds)]
+        out = {"loss_cls": per[-1][0], "loss_mask": per[-1][1], "loss_dice": per[-1][2]}
+        for i, (a, b, c) in enumerate(per[:-1]):
+            out[f"d{i}.loss_cls"], out[f"d{i}.loss_mask"], out[f"d{i}.loss_dice"] = a, b, c
+        return out
+
+    def _cls_and_select(self, cls_scores, mask_preds, targets):
+        labels = torch.stack([t[0] for t in targets]).flatten()
+        label_weights = torch.stack([t[1] for t in targets]).flatten()
+        mask_targets = torch.cat([t[2] for t in targets], 0)
+        mask_weights = torch.stack([t[3] for t in targets])
+        cw = cls_scores.new_tensor(self.class_weight)
+        loss_cls = cross_entropy_loss(cls_scores.flatten(0, 1), labels, label_weights, cw, cw[labels].sum(),
+                                      self.w_cls)
+        sel = mask_weights > 0
+        return loss_cls, mask_preds[sel], mask_weights[sel], mask_targets
+
+
+class NuscTrainingMixin(OccHeadTrainingMixin):
+    def _get_target_single(self, cls_score, mask_pred, gt_labels, gt_masks, gt_lidarseg, img_metas=None):
+        """mask2former_nusc_occ.py:196-273"""
+        rng = self._rng(cls_score.device)
+        gt_labels = gt_labels.long()
+        pcr = torch.tensor(self.point_cloud_range, dtype=torch.float32, device=cls_score.device)
+        coords = (gt_lidarseg[:, :3].float() - pcr[:3]) / (pcr[3:] - pcr[:3])
+        n_lidar = min(self.num_points // 2, coords.shape[0])
+        if n_lidar < coords.shape[0]:
+            coords = coords[rng.randperm(coords.shape[0]).to(coords.device)[:n_lidar]]
+        coords = torch.cat((coords, rng.rand(self.num_points - n_lidar, 3).to(coords)), 0)[:, [2, 1, 0]]
+        pred_pts = point_sample_3d(mask_pred[None], coords[None], padding_mode=self.padding_mode)[0]
+        if gt_labels.shape[0]:
+            gt_pts = point_sample_3d(gt_masks[None].float(), coords[None], padding_mode=self.padding_mode)[0]
+        else:
+            gt_pts = pred_pts.new_zeros((0, coords.shape[0]))
+        gt_inds, cost = self.assigner.assign(cls_score, pred_pts, gt_labels, gt_pts, img_metas)
+        return self._targets_from_assignment(gt_inds, cls_score, mask_pred, gt_labels, gt_masks) + (cost,)
+
+    def loss_single(self, cls_scores, mask_preds, gt_labels_list, gt_masks_list, gt_lidarseg_list, img_metas=None):
+        """mask2former_nusc_occ.py:317-424"""
+        targets = [self._get_target_single(cls_scores[i], mask_preds[i], gt_labels_list[i], gt_masks_list[i],
+                                           gt_lidarseg_list[i]) for i in range(cls_scores.shape[0])]
+        loss_cls, mp, mw, mask_targets = self._cls_and_select(cls_scores, mask_preds, targets)
+        if mask_targets.shape[0] == 0:
+            return loss_cls, mp.sum(), mp.sum()
+        coords = get_nusc_lidarseg_point_coords(mp.unsqueeze(1), gt_lidarseg_list, gt_labels_list, self.num_points,
+                                                self.oversample_ratio, self.importance_sample_ratio,
+                                                self.point_cloud_range, self._rng(mp.device),
+                                                padding_mode=self.padding_mode)[..., [2, 1, 0]]
+        pp = point_sample_3d(mp.unsqueeze(1), coords, padding_mode=self.padding_mode).squeeze(1)
+        pt = point_sample_3d(mask_targets.unsqueeze(1).float(), coords, padding_mode=self.padding_mode).squeeze(1)
+        loss_mask, loss_dice = point_mask_losses(pp, pt, mw, self.num_points, self.dice_eps, self.w_mask,
+                                                 self.w_dice, weight_bce_rows=False)
+        return loss_cls, loss_mask, loss_dice
+
+    def lidarseg_metric(self, cls_preds, mask_preds, points, img_metas):
+        """training branch of forward_lidarseg (mask2former_nusc_occ.py:526-540): point mIoU, no gradient"""
+        probs = self.forward_lidarseg(cls_preds, mask_preds, points, img_metas)
+        out = (torch.argmax(probs[:, 1:], 1) + 1).cpu().numpy()
+        tgt = torch.cat([p[:, -1] for p in points]).long().cpu().numpy()
+        iou = per_class_iu(fast_hist_crop(out, tgt, np.arange(16)))
+        return {"point_mean_iou": torch.tensor(np.nanmean(iou), device=probs.device)}
+
+    def forward_train(self, voxel_feats, img_metas, gt_occ, points=None, **kwargs):
+        """mask2former_nusc_occ.py:547-587 (forward values; no autograd graph is built by the HIP modules)"""
+        all_cls, all_masks = self(voxel_feats, img_metas)
+        gt_labels, gt_masks = self.preprocess_gt(gt_occ, img_metas)
+        losses = self.loss(all_cls, all_masks, gt_labels, gt_masks, points, img_metas)
+        losses.update(self.lidarseg_metric(all_cls[-1], all_masks[-1], points, img_metas))
+        return losses
+
+
+class KittiTrainingMixin(OccHeadTrainingMixin):
+    def get_sampling_weights(self):
+        """mask2former_occ.py:144-148, 158-166"""
+        base = 1 / semantic_kitti_class_frequencies
+        base = base / base.min()
+        g = self.sample_weight_gamma
+        if isinstance(g, (list, tuple)):
+            g = np.random.uniform(low=g[0], high=g[1])
+        self.sample_weights = base ** g
+
+    def _get_target_single(self, cls_score, mask_pred, gt_labels, gt_masks, img_metas=None):
+        """mask2former_occ.py:224-292"""
+        gt_labels = gt_labels.long()
+        idx, coords = sample_valid_coords_with_frequencies(self.num_points, gt_labels, gt_masks, self.sample_weights,
+                                                           self._rng(cls_score.device))
+        pred_pts = point_sample_3d(mask_pred[None], coords[..., [2, 1, 0]], align_corners=self.align_corners)[0]
+        gt_pts = gt_masks.reshape(gt_masks.shape[0], -1)[:, idx].float()
+        gt_inds, cost = self.assigner.assign(cls_score, pred_pts, gt_labels, gt_pts, img_metas)
+        return self._targets_from_assignment(gt_inds, cls_score, mask_pred, gt_labels, gt_masks) + (cost,)
+
+    def loss_single(self, cls_scores, mask_preds, gt_labels_list, gt_masks_list, img_metas=None):
+        """mask2former_occ.py:343-444"""
+        targets = [self._get_target_single(cls_scores[i], mask_preds[i], gt_labels_list[i], gt_masks_list[i])
+                   for i in range(cls_scores.shape[0])]
+        loss_cls, mp, mw, mask_targets = self._cls_and_select(cls_scores, mask_preds, targets)
+        if mask_targets.shape[0] == 0:
+            return loss_cls, mp.sum(), mp.sum()
+        idx, coords = get_uncertain_point_coords_3d_with_frequency(
+            mp.unsqueeze(1), None, gt_labels_list, gt_masks_list, self.sample_weights, self.num_points,
+            self.oversample_ratio, self.importance_sample_ratio, self._rng(mp.device))
+        pt = torch.gather(mask_targets.reshape(mask_targets.shape[0], -1), 1, idx).float()
+        pp = point_sample_3d(mp.unsqueeze(1), coords[..., [2, 1, 0]], align_corners=self.align_corners).squeeze(1)
+        loss_mask, loss_dice = point_mask_losses(pp, pt, mw, self.num_points, self.dice_eps, self.w_mask,
+                                                 self.w_dice, weight_bce_rows=True)
+        return loss_cls, loss_mask, loss_dice
+
+    def forward_train(self, voxel_feats, img_metas, gt_occ, **kwargs):
+        """mask2former_occ.py:525-567"""
+        self.get_sampling_weights()
+        all_cls, all_masks = self(voxel_feats, img_metas)
+        gt_labels, gt_masks = self.preprocess_gt(gt_occ, img_metas)
+        return self.loss(all_cls, all_masks, gt_labels, gt_masks, img_metas)

@@ -622,6 +622,72 @@ def reduce_mean(t):
     return t
 
 
+
+# --------------------------------------------------------------------------- mmdet 2.14.0 training pieces
+# (third-party, absent from the reference tree; restated from the published mmdet 2.14.0 sources:
+#  mmdet/models/losses/{utils,cross_entropy_loss}.py, mmdet/core/bbox/match_costs/match_cost.py,
+#  mmdet/core/bbox/assigners/assign_result.py, mmdet/core/bbox/samplers/{base_sampler,sampling_result}.py)
+def weight_reduce_loss(loss, weight=None, reduction="mean", avg_factor=None):
+    if weight is not None:
+        loss = loss * weight
+    if avg_factor is None:
+        return loss.mean() if reduction == "mean" else loss.sum() if reduction == "sum" else loss
+    if reduction == "mean":
+        return loss.sum() / avg_factor
+    if reduction != "none":
+        raise ValueError('avg_factor can not be used with reduction="sum"')
+    return loss
+
+
+class MMDetCrossEntropyLoss(nn.Module):
+    def __init__(self, use_sigmoid=False, use_mask=False, reduction="mean", class_weight=None, loss_weight=1.0):
+        super().__init__()
+        self.use_sigmoid, self.reduction, self.class_weight, self.loss_weight = (use_sigmoid, reduction, class_weight,
+                                                                                 loss_weight)
+
+    def forward(self, cls_score, label, weight=None, avg_factor=None, reduction_override=None, **kw):
+        reduction = reduction_override if reduction_override else self.reduction
+        class_weight = cls_score.new_tensor(self.class_weight) if self.class_weight is not None else None
+        if self.use_sigmoid:
+            if cls_score.dim() != label.dim():
+                raise NotImplementedError
+            if weight is not None:
+                weight = weight.float()
+            loss = F.binary_cross_entropy_with_logits(cls_score, label.float(), pos_weight=class_weight,
+                                                      reduction="none")
+        else:
+            loss = F.cross_entropy(cls_score, label, weight=class_weight, reduction="none")
+            if weight is not None:
+                weight = weight.float()
+        return self.loss_weight * weight_reduce_loss(loss, weight, reduction=reduction, avg_factor=avg_factor)
+
+
+class ClassificationCost:
+    def __init__(self, weight=1.0):
+        self.weight = weight
+
+    def __call__(self, cls_pred, gt_labels):
+        cls_score = cls_pred.softmax(-1)
+        return -cls_score[:, gt_labels] * self.weight
+
+
+class AssignResult:
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+
+
+class BaseAssigner:
+    pass
+
+
+class BaseSampler:
+    pass
+
+
+class SamplingResult:
+    pass
+
+
 def _not_available(*a, **k):
     raise NotImplementedError("not restated in the test shim")
 
@@ -691,8 +757,10 @@ def install():
             super().__init__()
             self.cfg = kw
 
-    for _n in ("CrossEntropyLoss", "DiceLoss", "FocalLoss"):
+    for _n in ("DiceLoss", "FocalLoss"):
         MODELS.register_module(name=_n, module=_LossStub)
+    MODELS.register_module(name="CrossEntropyLoss", module=MMDetCrossEntropyLoss)
+    MATCH_COST.register_module(name="ClassificationCost", module=ClassificationCost)
 
     def build_loss(cfg):
         return build_from_cfg(cfg, MODELS)
@@ -736,6 +804,14 @@ def install():
     _mod("mmdet.core.bbox.match_costs")
     _mod("mmdet.core.bbox.match_costs.builder", MATCH_COST=MATCH_COST,
          build_match_cost=lambda cfg, **kw: build_from_cfg(cfg, MATCH_COST, kw))
+    _mod("mmdet.core.bbox.assigners", AssignResult=AssignResult, BaseAssigner=BaseAssigner)
+    _mod("mmdet.core.bbox.samplers")
+    _mod("mmdet.core.bbox.samplers.base_sampler", BaseSampler=BaseSampler)
+    _mod("mmdet.core.bbox.samplers.sampling_result", SamplingResult=SamplingResult)
+    _mod("mmdet.core.bbox.iou_calculators", bbox_overlaps=_not_available)
+    _mod("mmdet.core.bbox.transforms", bbox_cxcywh_to_xyxy=_not_available, bbox_xyxy_to_cxcywh=_not_available)
+    _mod("mmdet.models.losses")
+    _mod("mmdet.models.losses.utils", weight_reduce_loss=weight_reduce_loss)
     _mod("mmdet.utils")
     _mod("mmdet.utils.contextmanagers", completed=_not_available)
     _mod("mmdet.models", build_loss=build_loss, **reg)
@@ -769,6 +845,13 @@ def install():
         ("projects.mmdet3d_plugin.occformer.mask2former", os.path.join(P, "occformer/mask2former")),
         ("projects.mmdet3d_plugin.occformer.mask2former.base",
          os.path.join(P, "occformer/mask2former/base")),
+        ("projects.mmdet3d_plugin.occformer.mask2former.assigners",
+         os.path.join(P, "occformer/mask2former/assigners")),
+        ("projects.mmdet3d_plugin.occformer.mask2former.assigners.match_costs",
+         os.path.join(P, "occformer/mask2former/assigners/match_costs")),
+        ("projects.mmdet3d_plugin.occformer.mask2former.samplers",
+         os.path.join(P, "occformer/mask2former/samplers")),
+        ("projects.mmdet3d_plugin.occformer.mask2former.losses", os.path.join(P, "occformer/mask2former/losses")),
         ("projects.mmdet3d_plugin.utils", os.path.join(P, "utils")),
     ]:
         m = _mod(name)

@@ -1,0 +1,185 @@
+"""Training rows: product (HIP kernels) vs the oracle on IDENTICAL injected noise, and the
+oracle vs the reference-generated fixture tests/golden/train.npz (tests/golden/make_golden_train.py)."""
+import numpy as np
+import pytest
+import torch
+
+import occformer_amd.ops as ops_mod
+from occformer_amd import training as TR
+from occformer_amd.registry import HEADS
+from oracle import occformer_train_ref as T
+from tests import paramgen, tinycfg
+from tests.conftest import golden
+from tests.golden.make_golden_train import inputs, kitti_head_cfg, oracle_cfg, train_cfg
+
+
+class ReplayRNG:
+    """feeds the product the very draws the oracle consumed (RecordingRNG.tape), in order"""
+
+    def __init__(self, tape, device):
+        self.tape, self.i, self.device = tape, 0, device
+
+    def _next(self, kind, numel):
+        k, t = self.tape[self.i]
+        self.i += 1
+        assert k == kind and t.numel() == numel, f"draw {self.i}: product asks {kind}/{numel}, oracle drew {k}/{t.numel()}"
+        return t.to(self.device)
+
+    def rand(self, *shape):
+        return self._next("rand", int(np.prod(shape))).reshape(shape)
+
+    def randperm(self, n):
+        return self._next("randperm", n)
+
+    def exponential(self, shape, dtype=torch.float32):
+        return self._next("exponential", int(np.prod(shape))).reshape(tuple(shape)).float()
+
+
+@pytest.fixture
+def bound(be, monkeypatch):
+    monkeypatch.setattr(ops_mod, "_ops", be.ops)
+    return be
+
+
+def _heads(kind):
+    model, meta = tinycfg.tiny_nusc()
+    tc = train_cfg()
+    if kind == "nusc":
+        hc = dict(model["pts_bbox_head"])
+        ocfg = oracle_cfg(hc, tc)
+    else:
+        hc = kitti_head_cfg(model)
+        ocfg = oracle_cfg(hc, tc, align_corners=True,
+                          sample_weights=T.kitti_sampling_weights(TR.semantic_kitti_class_frequencies, 0.25))
+    head = HEADS.build(dict(hc, train_cfg=tc, test_cfg=None))
+    if kind == "kitti":
+        ocfg["class_weight"] = head.class_weight
+    return head, ocfg, meta
+
+
+# ---------------------------------------------------------------------------------- oracle vs reference fixture
+def test_oracle_reproduces_reference_losses():
+    g = golden("train")
+    for kind, seed, fn in (("nusc", 11, T.nusc_loss_single), ("kitti", 21, T.kitti_loss_single)):
+        head, ocfg, meta = _heads(kind)
+        cls, masks, gt_occ, pts = inputs(kind)
+        gl, gm = zip(*[T.preprocess_occupancy_gt(o, ocfg["num_classes"]) for o in gt_occ])
+        gt = (list(gl), list(gm), pts) if kind == "nusc" else (list(gl), list(gm))
+        torch.manual_seed(seed)
+        out = T.head_loss(cls, masks, fn, *gt, cfg=ocfg)
+        for k, v in out.items():
+            assert abs(float(v) - float(g[f"{kind}.{k}"])) < 1e-5 * max(1, abs(float(v))), (kind, k)
+    assert np.allclose(np.asarray(_heads("kitti")[0].class_weight), np.asarray(g["kitti.class_weight"]))
+
+
+def test_oracle_multinomial_is_torch_multinomial():
+    w = paramgen.uniform("mn.w", (3, 4000), 9) ** 2
+    torch.manual_seed(5)
+    a = torch.multinomial(w, 700, replacement=False)
+    torch.manual_seed(5)
+    assert torch.equal(a, T.GlobalTorchRNG().multinomial(w, 700))
+
+
+# ---------------------------------------------------------------------------------- product vs oracle
+def test_match_cost_and_assignment(bound):
+    be = bound
+    Q, G, P = 20, 6, 250                       # P not a multiple of 4: exercises the GEMM padding
+    cls = paramgen.tensor("mc.cls", (Q, 18), 1, 1.5)
+    x = paramgen.tensor("mc.x", (Q, P), 1, 2.0)
+    gt = (paramgen.uniform("mc.g", (G, P), 1) < 0.3).float()
+    labels = torch.tensor([1, 3, 4, 7, 9, 16])
+    cost_o, pos_o, posgt_o = T.hungarian_assign(cls, x, labels, gt)
+    a = TR.MaskHungarianAssigner(**{k: v for k, v in train_cfg()["assigner"].items() if k != "type"})
+    gt_inds, cost = a.assign(*be.to(cls, x, labels, gt))
+    assert torch.allclose(cost.cpu(), cost_o, atol=1e-4, rtol=1e-4)
+    pos = torch.nonzero(gt_inds.cpu() > 0).squeeze(-1)
+    assert torch.equal(pos, pos_o) and torch.equal(gt_inds.cpu()[pos] - 1, posgt_o)
+    # no GT -> everything background
+    gi, _ = a.assign(*be.to(cls, x, labels[:0], gt[:0]))
+    assert int(gi.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("kind", ["nusc", "kitti"])
+def test_head_loss_matches_oracle_on_injected_noise(bound, kind):
+    be = bound
+    g = golden("train")
+    head, ocfg, meta = _heads(kind)
+    cls, masks, gt_occ, pts = inputs(kind)
+    gl, gm = zip(*[T.preprocess_occupancy_gt(o, ocfg["num_classes"]) for o in gt_occ])
+    rec = T.RecordingRNG()
+    torch.manual_seed(11 if kind == "nusc" else 21)
+    if kind == "nusc":
+        ref = T.head_loss(cls, masks, T.nusc_loss_single, list(gl), list(gm), pts, cfg=ocfg, rng=rec)
+    else:
+        ref = T.head_loss(cls, masks, T.kitti_loss_single, list(gl), list(gm), cfg=ocfg, rng=rec)
+    head.rng = ReplayRNG(rec.tape, be.device)
+    d = be.device
+    metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])] * 2
+    gl_p, gm_p = head.preprocess_gt(gt_occ.to(d), metas)
+    for a, b, c, e in zip(gl_p, gl, gm_p, gm):
+        assert torch.equal(a.cpu(), b) and torch.equal(c.cpu(), e)
+    cls_d, masks_d = [c.to(d) for c in cls], [m.to(d) for m in masks]
+    if kind == "nusc":
+        out = head.loss(cls_d, masks_d, gl_p, gm_p, [p.to(d) for p in pts], metas)
+    else:
+        out = head.loss(cls_d, masks_d, gl_p, gm_p, metas)
+    assert head.rng.i == len(rec.tape), "product and oracle consumed different numbers of draws"
+    for k, v in ref.items():
+        assert abs(float(out[k]) - float(v)) < 1e-3 * max(1.0, abs(float(v))), (k, float(out[k]), float(v))
+        # and therefore the reference's own value (the fixture was produced with the same seed)
+        assert abs(float(out[k]) - float(g[f"{kind}.{k}"])) < 1e-3 * max(1.0, abs(float(v))), k
+
+
+def test_kitti_same_resolution_branch(bound):
+    """mask logits at the GT resolution: the gather branch of get_uncertain_point_coords_3d_with_frequency"""
+    be = bound
+    g = golden("train")
+    head, ocfg, meta = _heads("kitti")
+    cls, masks, gt_occ, _ = inputs("kitti")
+    big = torch.nn.functional.interpolate(masks[0], size=(32, 32, 16), mode="trilinear")
+    gl, gm = zip(*[T.preprocess_occupancy_gt(o, 20) for o in gt_occ])
+    rec = T.RecordingRNG()
+    torch.manual_seed(22)
+    ref = T.kitti_loss_single(cls[0], big, list(gl), list(gm), ocfg, rec)
+    head.rng = ReplayRNG(rec.tape, be.device)
+    d = be.device
+    out = head.loss_single(cls[0].to(d), big.to(d), [x.to(d) for x in gl], [x.to(d) for x in gm])
+    for i, n in enumerate(("loss_cls", "loss_mask", "loss_dice")):
+        assert abs(float(out[i]) - float(ref[i])) < 1e-3 * max(1.0, abs(float(ref[i])))
+        assert abs(float(out[i]) - float(g["kitti.same." + n])) < 1e-3 * max(1.0, abs(float(ref[i])))
+
+
+def test_nusc_targets_and_lidarseg_metric(bound):
+    be = bound
+    g = golden("train")
+    head, ocfg, meta = _heads("nusc")
+    cls, masks, gt_occ, pts = inputs("nusc")
+    gl, gm = zip(*[T.preprocess_occupancy_gt(o, 17) for o in gt_occ])
+    d = be.device
+    for i in range(2):
+        rec = T.RecordingRNG()
+        torch.manual_seed(12 + 100 * i)
+        to = T.nusc_get_target_single(cls[0][i], masks[0][i], gl[i], gm[i], pts[i], ocfg, rec)
+        head.rng = ReplayRNG(rec.tape, d)
+        labels, lw, mt, mw, pos, pos_gt, cost = head._get_target_single(cls[0][i].to(d), masks[0][i].to(d),
+                                                                        gl[i].to(d), gm[i].to(d), pts[i].to(d))
+        assert torch.equal(labels.cpu(), to["labels"]) and torch.equal(pos.cpu(), to["pos_inds"])
+        assert torch.allclose(mw.cpu(), to["mask_weights"]) and torch.equal(mt.cpu(), to["mask_targets"])
+        assert torch.allclose(cost.cpu(), to["cost"], atol=2e-4, rtol=1e-4)
+    metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])] * 2
+    m = head.lidarseg_metric(cls[-1].to(d), masks[-1].to(d), [p.to(d) for p in pts], metas)
+    assert abs(float(m["point_mean_iou"]) - float(g["nusc.point_mean_iou"])) < 1e-6
+
+
+def test_depth_loss_matches_reference_fixture(bound):
+    from occformer_amd.registry import MODELS
+    be = bound
+    g = golden("train")
+    model, meta = tinycfg.tiny_nusc()
+    vt = MODELS.build(model["img_view_transformer"]).to(be.device)
+    H, W = meta["input_size"]
+    gd = paramgen.uniform("depth.gt", (2, 3, H, W), 8) * 14.0
+    gd = torch.where(paramgen.uniform("depth.keep", (2, 3, H, W), 8) < 0.03, gd, torch.zeros(()))
+    dp = paramgen.uniform("depth.pred", (6, meta["D"], meta["fH"], meta["fW"]), 8).softmax(1)
+    out = vt.get_depth_loss(gd.to(be.device), dp.to(be.device))
+    assert abs(float(out) - float(g["depth.loss"])) < 1e-5
