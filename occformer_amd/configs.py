@@ -69,6 +69,14 @@ def nusc_r50(grid="200", with_image_branch=False, num_queries=100):
             loss_dice=dict(type="DiceLoss", use_sigmoid=True, activate=True, reduction="mean",
                            naive_dice=True, eps=1.0, loss_weight=5.0),
             point_cloud_range=pc_range),
+        # occformer_nusc_r50_256x704.py:191-204
+        train_cfg=dict(pts=dict(
+            num_points=12544 * 4, oversample_ratio=3.0, importance_sample_ratio=0.75,
+            assigner=dict(type="MaskHungarianAssigner", cls_cost=dict(type="ClassificationCost", weight=2.0),
+                          mask_cost=dict(type="CrossEntropyLossCost", weight=5.0, use_sigmoid=True),
+                          dice_cost=dict(type="DiceCost", weight=5.0, pred_act=True, eps=1.0)),
+            sampler=dict(type="MaskPseudoSampler"))),
+        test_cfg=dict(pts=dict(semantic_on=True, panoptic_on=False, instance_on=False)),
     )
     if with_image_branch:
         model["img_backbone"] = dict(type="ResNet", depth=50, num_stages=4, out_indices=(0, 1, 2, 3),

@@ -17,6 +17,11 @@ timeout 900 python bench.py --steps ${STEPS:-5} --warmup 2 --check --shape-repor
 for pr in ${EXTRA_PREC:-}; do
   timeout 600 python bench.py --steps ${STEPS:-5} --warmup 2 --precision $pr --check > $O/bench_$pr.json 2> $O/bench_$pr.err ; echo "bench $pr rc=$?" ; cat $O/bench_$pr.json
 done
+if [ "${TRAIN:-0}" = "1" ]; then
+  echo "== training rows probe"
+  timeout 600 python scripts/train_probe.py > $O/train_nusc.json 2> $O/train_nusc.err ; echo "train nusc rc=$?" ; tail -2 $O/train_nusc.err ; cat $O/train_nusc.json
+  timeout 600 python scripts/train_probe.py --kitti > $O/train_kitti.json 2> $O/train_kitti.err ; echo "train kitti rc=$?" ; tail -2 $O/train_kitti.err ; cat $O/train_kitti.json
+fi
 echo "== rocprof kernel trace"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof.log 2>&1 ; echo "rocprof rc=$?" ; tail -2 $O/prof.log

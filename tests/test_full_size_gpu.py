@@ -170,3 +170,37 @@ def test_mask_gemm_pool_full_equals_unfused(hip, monkeypatch):
         out = hip.ops.mask_gemm_pool(me, sp, (200, 200, 16), target)
         for a, b in zip(out, ref):
             assert torch.equal(a, b)
+
+
+def test_class_guided_sampling_full_size(hip):
+    """SemanticKITTI sizes (SURVEY §8a row 18): 256*256*32 voxels, 3*50176 draws, 20 GT rows sharing the weights;
+    properties: no duplicates, never a zero-weight voxel, and the set equals torch.topk of the same keys."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    V, k, R = 256 * 256 * 32, 3 * 50176, 20
+    lab = torch.randint(0, 20, (V,), device="cuda", generator=g)
+    sw = torch.rand(20, device="cuda", generator=g) * 30 + 1
+    w = torch.where(torch.rand(V, device="cuda", generator=g) < 0.25, sw[lab], torch.zeros((), device="cuda"))
+    q = torch.empty((R, V), device="cuda").exponential_(1, generator=g)
+    idx = hip.ops.sample_without_replacement(w[None].contiguous(), q, k, exponential=True)
+    assert int((w[idx] <= 0).sum()) == 0
+    srt = idx.sort(1)[0]
+    assert int((srt[:, 1:] == srt[:, :-1]).sum()) == 0
+    ref = torch.topk(w[None] / q, k, dim=1)[1].sort(1)[0]
+    assert torch.equal(srt, ref)
+    # importance selection at the same scale
+    x = torch.randn((R, k), device="cuda", generator=g)
+    top = hip.ops.topk_smallest_abs(x, 37632).sort(1)[0]
+    assert torch.equal(top, torch.topk(-x.abs(), 37632, dim=1)[1].sort(1)[0])
+
+
+def test_point_sample_full_size(hip):
+    """nuScenes sizes (row 19): 100 query masks [128,128,16] sampled at 50176 shared points"""
+    g = torch.Generator(device="cuda").manual_seed(4)
+    vol = torch.randn((1, 100, 128, 128, 16), device="cuda", generator=g)
+    pts = torch.rand((1, 50176, 3), device="cuda", generator=g) * 1.1 - 0.05
+    out = hip.ops.point_sample_3d(vol, pts, False, "border")
+    ref = F.grid_sample(vol, (pts * 2 - 1).view(1, -1, 1, 1, 3), padding_mode="border", align_corners=False)
+    assert torch.allclose(out, ref.view(1, 100, -1), atol=1e-5, rtol=1e-5)
+    rows = hip.ops.point_loss_rows(out[0], (out[0] > 0).float())
+    s = out[0].sigmoid()
+    assert torch.allclose(rows[:, 2], s.sum(1), rtol=1e-4) and torch.allclose(rows[:, 3], (out[0] > 0).float().sum(1))
