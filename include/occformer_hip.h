@@ -18,6 +18,9 @@ extern "C" {
 
 /* ------------------------------------------------------------------ view transform ---- */
 
+/* crc32 of this header as the library was compiled against it; the loader refuses a mismatch. */
+int occf_abi_hash(void);
+
 /* Replaces bev_pool_ext.bev_pool_forward  (M/ops/bev_pool/src/bev_pool.cpp:22-57,
  * kernel bev_pool_cuda.cu:20-42).  x[n,c] f32 sorted by voxel rank, geom[n,4] i32 =
  * (x,y,z,b), interval starts/lengths [m] i32.  out[b,d,h,w,c] is zero-filled by the

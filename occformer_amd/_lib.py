@@ -31,6 +31,8 @@ def parse_header(path=HEADER):
         args = [_CTYPES[m.group(1)]]          # slot 0 = return type
         for a in m.group(3).split(","):
             a = " ".join(a.split())
+            if a == "void":
+                continue
             if "*" in a:
                 args.append((ctypes.c_void_p, a.split("*")[-1].strip()))
             else:
@@ -49,6 +51,11 @@ def bind(lib_path):
         fn.argtypes = [t for t, _ in args[1:]]
         fn.restype = args[0]
     lib._occf_protos = protos
+    from .csrc.build import abi_hash
+    if lib.occf_abi_hash() != abi_hash():
+        raise RuntimeError(f"{lib_path} was built against a different include/occformer_hip.h "
+                           f"(abi {lib.occf_abi_hash()} != header {abi_hash()}); rebuild it: "
+                           "python -m occformer_amd.csrc.build")
     return lib
 
 
@@ -58,8 +65,8 @@ _lib = None
 def get():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            from .csrc import build as _b
-            _b.build(verbose=False)  # raises if hipcc is unavailable
+        from .csrc import build as _b
+        if not _b.is_current():
+            _b.build(verbose=False)  # sources changed or no library yet; raises if hipcc is unavailable
         _lib = bind(LIB_PATH)
     return _lib

@@ -22,6 +22,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-I", HERE]
 
 
+def abi_hash():
+    """crc32 of the C header: compiled into the library (occf_abi_hash) and re-checked at load time, so a
+    stale .so can never be called through a newer header's prototypes."""
+    import zlib
+    return zlib.crc32(open(os.path.join(ROOT, "include", "occformer_hip.h"), "rb").read()) & 0x7FFFFFFF
+
+
+def is_current():
+    stamp = os.path.join(OBJ, "digest.txt")
+    return os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == _digest()
+
+
 def sources():
     return sorted(f for f in os.listdir(HERE) if f.endswith(".hip"))
 
@@ -47,7 +59,7 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(HERE, src), "-o", obj]
+        cmd = [HIPCC, *FLAGS, f"-DOCCF_ABI_HASH={abi_hash()}", "-c", os.path.join(HERE, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

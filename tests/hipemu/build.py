@@ -5,12 +5,15 @@ The product never loads this library."""
 import hashlib
 import os
 import subprocess
+import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "occformer_amd", "csrc")
 OUT = os.path.join(HERE, "build")
 LIB = os.path.join(OUT, "libocc_emu.so")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 CXX = "/opt/rocm/lib/llvm/bin/clang++"
 FLAGS = ["-O2", "-std=c++17", "-fPIC", "-DOCCF_EMU", "-ffp-contract=off", "-x", "c++",
          "-Wno-unused-value", "-Wno-unknown-attributes",
@@ -39,7 +42,9 @@ def build(force=False):
     for s in srcs:
         o = os.path.join(OUT, s.replace(".hip", ".o"))
         objs.append(o)
-        procs.append((s, subprocess.Popen([CXX, *FLAGS, "-c", os.path.join(CSRC, s), "-o", o],
+        from occformer_amd.csrc.build import abi_hash
+        procs.append((s, subprocess.Popen([CXX, *FLAGS, f"-DOCCF_ABI_HASH={abi_hash()}", "-c",
+                                           os.path.join(CSRC, s), "-o", o],
                                           stderr=subprocess.PIPE, text=True)))
     for s, p in procs:
         _, err = p.communicate()
