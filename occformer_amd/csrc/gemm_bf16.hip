@@ -21,6 +21,11 @@
 #include "occf_common.h"
 #include "../../include/occformer_hip.h"
 
+#ifdef OCCF_EMU
+#define OCCF_WAVES_PER_EU(n)
+#else
+#define OCCF_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
 #define GB_BK 32
 #define GB_BM 128
 
@@ -76,11 +81,14 @@ __device__ __forceinline__ float occf_gelu_b(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-struct occf_u4 {
-  uint32_t x, y, z, w;
-};
+typedef uint32_t occf_u4 __attribute__((ext_vector_type(4)));
 
-template <int BN, int TERMS, bool CONV, bool SPLIT>
+// PF = number of k-tiles of global loads kept in flight per workgroup (register ring).  All loads
+// are UNCONDITIONAL (out-of-range rows / columns / padding taps read a clamped in-bounds address
+// and are masked afterwards): a load under a divergent branch makes the compiler wait for it right
+// there (s_waitcnt vmcnt(0) before the join), which serialised the four A loads of a k-tile into
+// four full memory round trips.
+template <int BN, int TERMS, bool CONV, bool SPLIT, int PF>
 __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
   constexpr int TN = BN / 64;                      // 32-wide MFMA tiles per wave along N
   constexpr int NB = BN * 4 / 256;                 // 16-B weight pieces per thread per array
@@ -140,13 +148,13 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
     b_base[i] = (long)(b_ok[i] ? n : 0) * p.K;
   }
 
-  float4 ra[4];
-  occf_u4 rbh[NB], rbl[NB];
+  float4 ra[PF][4];
+  occf_u4 rbh[PF][NB], rbl[PF][NB];
   // K range of this workgroup (split-K: blockIdx.y selects a contiguous slice of k-tiles)
   const int nk_all = p.K / GB_BK;
   const int kt_begin = SPLIT ? (int)((long)blockIdx.y * nk_all / p.ksplit) : 0;
   const int kt_end = SPLIT ? (int)((long)(blockIdx.y + 1) * nk_all / p.ksplit) : nk_all;
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, int d) __attribute__((always_inline)) {
     const int k0 = (kt_begin + kt) * GB_BK;
     if (CONV) {
       const int tap = k0 / p.g.Cin;                 // Cin % 32 == 0: block-uniform tap
@@ -156,39 +164,33 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
       for (int i = 0; i < 4; ++i) {
         const int xi = a_x[i] + dx * p.g.dil, yi = a_y[i] + dy * p.g.dil, zi = a_z[i] + dz * p.g.dil;
         const bool ok = a_ok[i] && xi >= 0 && xi < p.g.Xi && yi >= 0 && yi < p.g.Yi && zi >= 0 && zi < p.g.Zi;
-        if (ok) {
-          ra[i] = *(const float4*)(p.A + a_base[i] + xi * p.g.sx + yi * p.g.sy + zi * p.g.sz + c0 + a_kq[i] * 4);
-        } else {
-          ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        const int xc = occf_clampi(xi, p.g.Xi - 1), yc = occf_clampi(yi, p.g.Yi - 1),
+                  zc = occf_clampi(zi, p.g.Zi - 1);
+        const float4 v = *(const float4*)(p.A + a_base[i] + xc * p.g.sx + yc * p.g.sy + zc * p.g.sz + c0 +
+                                          a_kq[i] * 4);
+        ra[d][i].x = ok ? v.x : 0.f;
+        ra[d][i].y = ok ? v.y : 0.f;
+        ra[d][i].z = ok ? v.z : 0.f;
+        ra[d][i].w = ok ? v.w : 0.f;
       }
     } else {
+      // rows >= M read row 0: their products land in accumulator rows the epilogue never stores
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (a_ok[i]) {
-          ra[i] = *(const float4*)(p.A + a_base[i] + k0 + a_kq[i] * 4);
-        } else {
-          ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
+      for (int i = 0; i < 4; ++i) ra[d][i] = *(const float4*)(p.A + a_base[i] + k0 + a_kq[i] * 4);
     }
+    // columns >= N read column 0 (never stored either)
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      if (b_ok[i]) {
-        rbh[i] = *(const occf_u4*)(p.Wh + b_base[i] + k0 + b_slot[i] * 8);
-        if (TERMS == 3) rbl[i] = *(const occf_u4*)(p.Wl + b_base[i] + k0 + b_slot[i] * 8);
-      } else {
-        rbh[i] = occf_u4{0, 0, 0, 0};
-        if (TERMS == 3) rbl[i] = occf_u4{0, 0, 0, 0};
-      }
+      rbh[d][i] = *(const occf_u4*)(p.Wh + b_base[i] + k0 + b_slot[i] * 8);
+      if (TERMS == 3) rbl[d][i] = *(const occf_u4*)(p.Wl + b_base[i] + k0 + b_slot[i] * 8);
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int d) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       uint32_t h0, l0, h1, l1;
-      occf_split2(ra[i].x, ra[i].y, h0, l0);
-      occf_split2(ra[i].z, ra[i].w, h1, l1);
+      occf_split2(ra[d][i].x, ra[d][i].y, h0, l0);
+      occf_split2(ra[d][i].z, ra[d][i].w, h1, l1);
       const int off = occf_lds_slot(a_m[i], a_kq[i] >> 1) + (a_kq[i] & 1) * 8;
       *(uint32_t*)(Ah + off) = h0;
       *(uint32_t*)(Ah + off + 4) = h1;
@@ -200,8 +202,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int off = occf_lds_slot(b_n[i], b_slot[i]);
-      *(occf_u4*)(Bh + off) = rbh[i];
-      if (TERMS == 3) *(occf_u4*)(Bl + off) = rbl[i];
+      *(occf_u4*)(Bh + off) = rbh[d][i];
+      if (TERMS == 3) *(occf_u4*)(Bl + off) = rbl[d][i];
     }
   };
 
@@ -214,12 +216,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = kt_end - kt_begin;
-  load_tile(0);
-  store_tile();
-  __syncthreads();
   const int li = lane & 31, lk = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile(kt + 1);
+  auto compute = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int kslot = s * 2 + lk;
@@ -247,10 +245,35 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
           acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bh[j], acc[i][j]);
         }
     }
-    __syncthreads();
-    if (kt + 1 < nk) {
-      store_tile();
+  };
+  // Register ring of PF k-tiles.  The prologue and the steady-state loop issue their loads
+  // UNCONDITIONALLY so that the compiler can count how many newer loads may stay in flight when it
+  // waits for the oldest slot (s_waitcnt vmcnt(8*(PF-1))); a load under `if` on any path would force
+  // a full drain.  The remainder (< 2*PF tiles) keeps conditional loads.
+#pragma unroll
+  for (int d = 0; d < PF; ++d) load_tile(d < nk ? d : nk - 1, d);
+  int kt0 = 0;
+  for (; kt0 + 2 * PF <= nk; kt0 += PF) {
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+      if (kt0 + d > 0) __syncthreads();              // the previous k-tile's fragment reads are done
+      store_tile(d);                                 // waits for exactly this slot's loads
       __syncthreads();
+      load_tile(kt0 + d + PF, d);
+      compute();
+    }
+  }
+  for (; kt0 < nk; kt0 += PF) {
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+      const int kt = kt0 + d;
+      if (kt < nk) {
+        if (kt > 0) __syncthreads();
+        store_tile(d);
+        __syncthreads();
+        if (kt + PF < nk) load_tile(kt + PF, d);
+        compute();
+      }
     }
   }
 
@@ -267,6 +290,15 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
   const long e_ldc = part ? (long)p.N : p.ldc;
   float* stage = (float*)lds;                               // [64][BN]
   const bool vec_ok = ((e_ldc & 3) == 0) && (!e_res || (p.ldr & 3) == 0) && ((p.N & 3) == 0);
+  // a thread owns one 4-column group of the staged tile and IT rows per phase; loads (bias once,
+  // the residual rows of a phase as one batch) are issued before they are consumed
+  constexpr int CG = BN / 4;                                // column groups
+  constexpr int IT = 64 * CG / 256;                         // rows per thread per phase
+  const int c4 = (tid % CG) * 4, row0 = tid / CG;
+  const int n = n0 + c4;
+  const bool n_ok = n < p.N;
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec_ok && e_bias && n_ok) b4 = *(const float4*)(e_bias + n);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     __syncthreads();                                        // K loop / previous phase done with LDS
@@ -282,32 +314,47 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
           }
     }
     __syncthreads();
-    for (int idx = tid; idx < 64 * (BN / 4); idx += 256) {
-      const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
-      const long m = m0 + h * 64 + row;
-      const int n = n0 + c4;
-      if (m >= p.M || n >= p.N) continue;
-      float4 v = *(const float4*)(stage + row * BN + c4);
-      float vv[4] = {v.x, v.y, v.z, v.w};
-      const int nv = p.N - n < 4 ? p.N - n : 4;
+    if (vec_ok) {
+      constexpr int RB = IT > 4 ? 4 : IT;                   // residual rows fetched per batch
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (e < nv) {
-          if (e_bias) vv[e] += e_bias[n + e];
-          if (e_act == 1) vv[e] = fmaxf(vv[e], 0.f);
-          else if (e_act == 2) vv[e] = occf_gelu_b(vv[e]);
+      for (int ib = 0; ib < IT; ib += RB) {
+        float4 rr[RB];
+        if (e_res) {
+#pragma unroll
+          for (int it = 0; it < RB; ++it) {
+            const long m = m0 + h * 64 + row0 + (ib + it) * (256 / CG);
+            rr[it] = *(const float4*)(e_res + (m < p.M ? m : (long)p.M - 1) * p.ldr + (n_ok ? n : 0));
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < RB; ++it) {
+          const int row = row0 + (ib + it) * (256 / CG);
+          const long m = m0 + h * 64 + row;
+          float4 v = *(const float4*)(stage + row * BN + c4);
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+          if (e_act == 1) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          } else if (e_act == 2) {
+            v.x = occf_gelu_b(v.x); v.y = occf_gelu_b(v.y); v.z = occf_gelu_b(v.z); v.w = occf_gelu_b(v.w);
+          }
+          if (e_res) { v.x += rr[it].x; v.y += rr[it].y; v.z += rr[it].z; v.w += rr[it].w; }
+          if (m < p.M && n_ok) *(float4*)(e_out + m * e_ldc + n) = v;
         }
       }
-      if (vec_ok) {
-        if (e_res) {
-          const float4 rr = *(const float4*)(e_res + m * p.ldr + n);
-          vv[0] += rr.x; vv[1] += rr.y; vv[2] += rr.z; vv[3] += rr.w;
-        }
-        *(float4*)(e_out + m * e_ldc + n) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-      } else {
+    } else {
+      for (int idx = tid; idx < 64 * CG; idx += 256) {
+        const int row = idx / CG, cc = (idx % CG) * 4;
+        const long m = m0 + h * 64 + row;
+        const int nn = n0 + cc;
+        if (m >= p.M || nn >= p.N) continue;
+        const int nv = p.N - nn < 4 ? p.N - nn : 4;
         for (int e = 0; e < nv; ++e) {
-          if (e_res) vv[e] += e_res[m * p.ldr + n + e];
-          e_out[m * e_ldc + n + e] = vv[e];
+          float v = stage[row * BN + cc + e];
+          if (e_bias) v += e_bias[nn + e];
+          if (e_act == 1) v = fmaxf(v, 0.f);
+          else if (e_act == 2) v = occf_gelu_b(v);
+          if (e_res) v += e_res[m * p.ldr + nn + e];
+          e_out[m * e_ldc + nn + e] = v;
         }
       }
     }
@@ -355,10 +402,24 @@ static int launch_gemm_b(GemmArgsB a, int terms, float* workspace, long workspac
   a.slab = workspace;
   const dim3 grid((unsigned)((long)mt * occf_cdiv(a.N, wide ? 128 : 64)), a.ksplit);
   const bool sp = a.ksplit > 1;
-#define OCCF_GB_LAUNCH(BN_, T_)                                                                         \
-  do {                                                                                                  \
-    if (sp) hipLaunchKernelGGL((gemm_bf16_kernel<BN_, T_, CONV, true>), grid, dim3(256), 0, st, a);    \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<BN_, T_, CONV, false>), grid, dim3(256), 0, st, a);      \
+  static const int pf_env = [] {
+    const char* e = getenv("OCCF_GEMM_PF");
+    return e ? atoi(e) : 3;
+  }();
+  const bool deep = pf_env >= 2;
+  // prefetch depth per variant: as deep as the 256-register budget of two waves per SIMD allows
+  // (accumulators live in AGPRs: 64 for BN = 128, 32 for BN = 64)
+#define OCCF_GB_LAUNCH(BN_, T_)                                                                              \
+  do {                                                                                                       \
+    constexpr int PF_SP = 2;                                                                                 \
+    constexpr int PF_NS = CONV ? (BN_ == 128 ? 1 : 2) : 3;                                                   \
+    if (sp) {                                                                                                \
+      if (deep) hipLaunchKernelGGL((gemm_bf16_kernel<BN_, T_, CONV, true, PF_SP>), grid, dim3(256), 0, st, a); \
+      else hipLaunchKernelGGL((gemm_bf16_kernel<BN_, T_, CONV, true, 1>), grid, dim3(256), 0, st, a);       \
+    } else {                                                                                                 \
+      if (deep) hipLaunchKernelGGL((gemm_bf16_kernel<BN_, T_, CONV, false, PF_NS>), grid, dim3(256), 0, st, a); \
+      else hipLaunchKernelGGL((gemm_bf16_kernel<BN_, T_, CONV, false, 1>), grid, dim3(256), 0, st, a);      \
+    }                                                                                                        \
   } while (0)
   if (wide) {
     if (terms == 3) OCCF_GB_LAUNCH(128, 3);

@@ -58,4 +58,7 @@ __device__ __forceinline__ unsigned occf_xcd_remap(unsigned bid, unsigned nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// clamp an index into [0, hi]: the unconditional-load idiom (read a valid address, mask afterwards)
+__device__ __forceinline__ int occf_clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
 #define OCCF_LAUNCH_CHECK() return (int)hipGetLastError()
