@@ -58,17 +58,19 @@ __device__ __forceinline__ void ch_split2(float a, float b, uint32_t& hi, uint32
 __device__ __forceinline__ int ch_slot(int row, int kslot) { return row * 64 + ((kslot ^ ((row >> 2) & 3)) << 4); }
 __device__ __forceinline__ float ch_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-struct ch_u4 {
-  uint32_t x, y, z, w;
-};
-struct ch_u2 {
-  uint32_t x, y;
-};
+typedef uint32_t ch_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t ch_u2 __attribute__((ext_vector_type(2)));
 
+// Global loads are unconditional (clamped address, masked value) and issued in batches so that the
+// compiler never has to wait inside a branch: the halo of a chunk is fetched as one batch of <= 13
+// float4 per thread -- for TN <= 2 already during the taps of the previous chunk -- and the weight slabs
+// run two taps ahead in a register ring.
 template <int TN, int TERMS>
 __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
   constexpr int BN = 64 * TN;
   constexpr int NBP = (BN * 4 + 511) / 512;          // 16-B weight pieces per thread per array
+  constexpr int NHI = 13;                             // float4 halo pieces per thread (816 * 8 / 512)
+  constexpr bool HPF = TN <= 2;                       // prefetch the next chunk's halo across the taps
   OCCF_DYN_SMEM(smem);
   const int TY = p.TY, TZ = p.TZ;
   const int HY = TY + 2, HZ = TZ + 2;
@@ -103,17 +105,36 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
     const int tx = r >> 7, pp = r & 127;
     hb[i] = (tx * HY + pp / TZ) * HZ + pp % TZ;
   }
-  // weight piece bookkeeping
-  int b_n[NBP], b_slot[NBP];
-  bool b_ok[NBP];
+  // this thread's halo pieces: clamped element offset (channel 0 of the chunk) + validity bit
+  const float* xb = p.x + (long)b * p.sb;
+  const int nhp = NH * 8;
+  int hofs[NHI];
+  unsigned hok = 0;
+#pragma unroll
+  for (int i = 0; i < NHI; ++i) {
+    const int idx = tid + i * 512;
+    const int idc = idx < nhp ? idx : nhp - 1;
+    const int h = idc >> 3, kq = idc & 7;
+    const int hz = h % HZ, hy = (h / HZ) % HY, hx = h / (HZ * HY);
+    const int x = tx0 + hx - 1, y = ty0 + hy - 1, z = tz0 + hz - 1;
+    const bool ok = idx < nhp && x >= 0 && x < p.X && y >= 0 && y < p.Y && z >= 0 && z < p.Z;
+    hofs[i] = (int)(occf_clampi(x, p.X - 1) * p.sx + occf_clampi(y, p.Y - 1) * p.sy +
+                    occf_clampi(z, p.Z - 1) * p.sz) + kq * 4;
+    hok |= (ok ? 1u : 0u) << i;
+  }
+  // weight piece bookkeeping (columns >= Cout read column Cout-1; never stored)
+  int b_slot[NBP], b_row[NBP];
+  long b_off[NBP];
+  const long K = 27L * p.Cin;
 #pragma unroll
   for (int i = 0; i < NBP; ++i) {
     const int idx = tid + i * 512;
-    b_n[i] = idx >> 2;
-    b_slot[i] = idx & 3;
-    b_ok[i] = idx < BN * 4 && n0 + b_n[i] < p.Cout;
+    const int idc = idx < BN * 4 ? idx : BN * 4 - 1;
+    b_row[i] = idc >> 2;
+    b_slot[i] = idc & 3;
+    const int n = n0 + b_row[i];
+    b_off[i] = (long)(n < p.Cout ? n : p.Cout - 1) * K + b_slot[i] * 8;
   }
-  const long K = 27L * p.Cin;
 
   f32x16 acc[2][TN];
 #pragma unroll
@@ -123,87 +144,116 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  ch_u4 rbh[NBP], rbl[NBP];
-  auto load_b = [&](int tap, int c0) {
+  constexpr int HB = HPF ? NHI : 7;                   // halo pieces per batch (register budget of TN = 3)
+  float4 hreg[HB];
+  ch_u4 rbh[2][NBP], rbl[2][NBP];
+  const int n_chunks = p.Cin / 32;
+  const int G = n_chunks * 27;                        // flat (chunk, tap) stream
+  auto load_halo = [&](int c0, int i0) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NBP; ++i) {
-      if (b_ok[i]) {
-        const long o = (long)(n0 + b_n[i]) * K + (long)tap * p.Cin + c0 + b_slot[i] * 8;
-        rbh[i] = *(const ch_u4*)(p.Wh + o);
-        if (TERMS == 3) rbl[i] = *(const ch_u4*)(p.Wl + o);
-      } else {
-        rbh[i] = ch_u4{0, 0, 0, 0};
-        if (TERMS == 3) rbl[i] = ch_u4{0, 0, 0, 0};
+    for (int i = 0; i < HB; ++i)
+      if (i0 + i < NHI) hreg[i] = *(const float4*)(xb + hofs[i0 + i] + c0);
+  };
+  auto store_halo = [&](int i0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int ii = 0; ii < HB; ++ii) {
+      const int i = i0 + ii;
+      const int idx = tid + i * 512;
+      if (i < NHI && idx < nhp) {
+        const bool ok = (hok >> i) & 1u;
+        const float4 v = hreg[ii];
+        uint32_t h0, l0, h1, l1;
+        ch_split2(ok ? v.x : 0.f, ok ? v.y : 0.f, h0, l0);
+        ch_split2(ok ? v.z : 0.f, ok ? v.w : 0.f, h1, l1);
+        const ch_u2 hi = {h0, h1}, lo = {l0, l1};
+        const int h = idx >> 3, kq = idx & 7;
+        const int off = ch_slot(h, kq >> 1) + (kq & 1) * 8;
+        *(ch_u2*)(Hh + off) = hi;
+        if (TERMS == 3) *(ch_u2*)(Hl + off) = lo;
       }
     }
   };
-  auto store_b = [&](int buf) {
+  // weight slab of stream position g (clamped to the last one) -> ring slot d
+  auto load_b = [&](int g, int d) __attribute__((always_inline)) {
+    const int gc = g < G ? g : G - 1;
+    const int cc = gc / 27, tap = gc - cc * 27;
+    const long o = (long)tap * p.Cin + cc * 32;
+#pragma unroll
+    for (int i = 0; i < NBP; ++i) {
+      rbh[d][i] = *(const ch_u4*)(p.Wh + b_off[i] + o);
+      if (TERMS == 3) rbl[d][i] = *(const ch_u4*)(p.Wl + b_off[i] + o);
+    }
+  };
+  auto store_b = [&](int buf, int d) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NBP; ++i) {
       if (tid + i * 512 < BN * 4) {
-        const int off = buf * BN * 64 + ch_slot(b_n[i], b_slot[i]);
-        *(ch_u4*)(Bh + off) = rbh[i];
-        if (TERMS == 3) *(ch_u4*)(Bl + off) = rbl[i];
+        const int off = buf * BN * 64 + ch_slot(b_row[i], b_slot[i]);
+        *(ch_u4*)(Bh + off) = rbh[d][i];
+        if (TERMS == 3) *(ch_u4*)(Bl + off) = rbl[d][i];
       }
     }
   };
 
-  const int n_chunks = p.Cin / 32;
-  for (int cc = 0; cc < n_chunks; ++cc) {
-    const int c0 = cc * 32;
-    load_b(0, c0);
-    __syncthreads();                     // previous chunk's last tap is done with halo and B
-    // ---- stage the halo of this chunk: NH voxels x 32 channels, 8 lanes per voxel
-    for (int idx = tid; idx < NH * 8; idx += 512) {
-      const int h = idx >> 3, kq = idx & 7;
-      const int hz = h % HZ, hy = (h / HZ) % HY, hx = h / (HZ * HY);
-      const int x = tx0 + hx - 1, y = ty0 + hy - 1, z = tz0 + hz - 1;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (x >= 0 && x < p.X && y >= 0 && y < p.Y && z >= 0 && z < p.Z)
-        v = *(const float4*)(p.x + b * p.sb + x * p.sx + y * p.sy + z * p.sz + c0 + kq * 4);
-      ch_u2 hi, lo;
-      ch_split2(v.x, v.y, hi.x, lo.x);
-      ch_split2(v.z, v.w, hi.y, lo.y);
-      const int off = ch_slot(h, kq >> 1) + (kq & 1) * 8;
-      *(ch_u2*)(Hh + off) = hi;
-      if (TERMS == 3) *(ch_u2*)(Hl + off) = lo;
-    }
-    store_b(0);
-    __syncthreads();
-    for (int tap = 0; tap < 27; ++tap) {
-      const int cur = tap & 1;
-      if (tap + 1 < 27) load_b(tap + 1, c0);
-      const int dz = tap % 3, dy = (tap / 3) % 3, dx = tap / 9;
-      const int toff = (dx * HY + dy) * HZ + dz;
+  // ring slot (g & 1) holds slab g; LDS buffer (g & 1) holds slab g while it is multiplied
+  if (HPF) load_halo(0, 0);
+  load_b(0, 0);
+  load_b(1, 1);
+  store_b(0, 0);
+  int cc = 0, tap = 0;
+  for (int g0 = 0; g0 < G; g0 += 2) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int kslot = s * 2 + lk;
-        bf16x8 ah[2], al[2], bh[TN], bl[TN];
+    for (int d = 0; d < 2; ++d) {
+      const int g = g0 + d;
+      if (g < G) {
+        if (g > 0) load_b(g + 1, (d + 1) & 1);          // slab g+1 (slot freed when slab g-1 went to LDS)
+        if (tap == 0) {
+          __syncthreads();                               // previous chunk's taps are done with the halo
+          if (HPF) {
+            store_halo(0);
+            load_halo((cc + 1 < n_chunks ? cc + 1 : cc) * 32, 0);
+          } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int off = ch_slot(hb[i] + toff, kslot);
-          ah[i] = *(const bf16x8*)(Hh + off);
-          if (TERMS == 3) al[i] = *(const bf16x8*)(Hl + off);
+            for (int i0 = 0; i0 < NHI; i0 += HB) {
+              load_halo(cc * 32, i0);
+              store_halo(i0);
+            }
+          }
+          __syncthreads();
         }
+        const int dz = tap % 3, dy = (tap / 3) % 3, dx = tap / 9;
+        const int toff = (dx * HY + dy) * HZ + dz;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int off = cur * BN * 64 + ch_slot(wn * (BN / 2) + j * 32 + li, kslot);
-          bh[j] = *(const bf16x8*)(Bh + off);
-          if (TERMS == 3) bl[j] = *(const bf16x8*)(Bl + off);
-        }
+        for (int s = 0; s < 2; ++s) {
+          const int kslot = s * 2 + lk;
+          bf16x8 ah[2], al[2], bh[TN], bl[TN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i) {
+            const int off = ch_slot(hb[i] + toff, kslot);
+            ah[i] = *(const bf16x8*)(Hh + off);
+            if (TERMS == 3) al[i] = *(const bf16x8*)(Hl + off);
+          }
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            if (TERMS == 3) {
-              acc[i][j] = occf_mfma_bf16_32x32x16(al[i], bh[j], acc[i][j]);
-              acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bl[j], acc[i][j]);
-            }
-            acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bh[j], acc[i][j]);
+            const int off = d * BN * 64 + ch_slot(wn * (BN / 2) + j * 32 + li, kslot);
+            bh[j] = *(const bf16x8*)(Bh + off);
+            if (TERMS == 3) bl[j] = *(const bf16x8*)(Bl + off);
           }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              if (TERMS == 3) {
+                acc[i][j] = occf_mfma_bf16_32x32x16(al[i], bh[j], acc[i][j]);
+                acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bl[j], acc[i][j]);
+              }
+              acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bh[j], acc[i][j]);
+            }
+        }
+        if (g + 1 < G) store_b((d + 1) & 1, (d + 1) & 1);
+        __syncthreads();
+        if (++tap == 27) { tap = 0; ++cc; }
       }
-      if (tap + 1 < 27) store_b(cur ^ 1);
-      __syncthreads();
     }
   }
 
@@ -213,20 +263,31 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * (BN / 2) + j * 32 + li;
-      if (n >= p.Cout) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
+      const bool n_ok = n < p.Cout;
+      const int nc = n_ok ? n : p.Cout - 1;
+      const float bv = p.bias ? p.bias[nc] : 0.f;
+      long mrow[16];
+      bool mok[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         const int pp = row & 127;
         const int x = tx0 + (row >> 7), y = ty0 + pp / TZ, z = tz0 + pp % TZ;
-        if (x >= p.X || y >= p.Y) continue;
-        const long m = (((long)b * p.X + x) * p.Y + y) * p.Z + z;
+        mok[r] = n_ok && x < p.X && y < p.Y;
+        mrow[r] = ((((long)b * p.X + occf_clampi(x, p.X - 1)) * p.Y + occf_clampi(y, p.Y - 1)) * p.Z + z) * p.Cout;
+      }
+      float rv[16];
+      if (p.residual) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = p.residual[mrow[r] + nc];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
         float v = acc[i][j][r] + bv;
         if (p.act == 1) v = fmaxf(v, 0.f);
         else if (p.act == 2) v = ch_gelu(v);
-        if (p.residual) v += p.residual[m * p.Cout + n];
-        p.out[m * p.Cout + n] = v;
+        if (p.residual) v += rv[r];
+        if (mok[r]) p.out[mrow[r] + n] = v;
       }
     }
   }
@@ -254,6 +315,7 @@ extern "C" int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, con
   if (terms != 1 && terms != 3) return OCCF_EINVAL;
   if (terms == 3 && w_lo == nullptr) return OCCF_EINVAL;
   if (in_sb % 4 || in_sx % 4 || in_sy % 4 || in_sz % 4) return OCCF_ESHAPE;
+  if ((long)X * in_sx >= 2147483647L || (long)Y * in_sy >= 2147483647L) return OCCF_ESHAPE;  // int halo offsets
   int TZ = Z >= 16 ? 16 : Z;
   if (TZ != 16 && TZ != 8 && TZ != 4) return OCCF_ESHAPE;
   if (Z % TZ != 0) return OCCF_ESHAPE;

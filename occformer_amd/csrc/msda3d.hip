@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(256) msda3d_fwd_kernel(
   float mx = -3.0e38f;
 #pragma unroll
   for (int i = 0; i < LP_MAX; ++i) {
-    w[i] = i < LP ? lg[i] : -3.0e38f;
+    const float lgi = lg[i < LP ? i : LP - 1];
+    w[i] = i < LP ? lgi : -3.0e38f;
     mx = fmaxf(mx, w[i]);
   }
   float sum = 0.f;
@@ -104,23 +105,45 @@ __global__ void __launch_bounds__(256) msda3d_fwd_kernel(
     const long kstride = HM ? Dh : E;                       // floats between consecutive keys
     const float* vbase = HM ? value + (((long)b * H + h) * Nv + lv.start[l]) * Dh + cv
                             : value + ((long)b * Nv + lv.start[l]) * E + h * Dh + cv;
+    // the 8 corner gathers of a sample are issued together and unconditionally (clamped address,
+    // zero weight outside the volume): a gather under `if (inside)` is waited for on the spot
+    float cw[8];
+    const float* vp[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int xx = ix + (c >> 2), yy = iy + ((c >> 1) & 1), zz = iz + (c & 1);
-      if (xx < 0 || xx >= Xl || yy < 0 || yy >= Yl || zz < 0 || zz >= Zl) continue;
-      const float cw = ((c >> 2) ? tx : 1.f - tx) * (((c >> 1) & 1) ? ty : 1.f - ty) *
+      const bool in = xx >= 0 && xx < Xl && yy >= 0 && yy < Yl && zz >= 0 && zz < Zl;
+      const float wc = ((c >> 2) ? tx : 1.f - tx) * (((c >> 1) & 1) ? ty : 1.f - ty) *
                        ((c & 1) ? tz : 1.f - tz) * wgt;
-      const float* vp = vbase + ((long)(xx * Yl + yy) * Zl + zz) * kstride;
-      if (VEC == 4) {
-        const float4 t = *(const float4*)vp;
-        acc[0] = fmaf(cw, t.x, acc[0]);
-        acc[1 % VEC] = fmaf(cw, t.y, acc[1 % VEC]);
-        acc[2 % VEC] = fmaf(cw, t.z, acc[2 % VEC]);
-        acc[3 % VEC] = fmaf(cw, t.w, acc[3 % VEC]);
-      } else {
+      cw[c] = in ? wc : 0.f;
+      vp[c] = vbase + ((long)(occf_clampi(xx, Xl - 1) * Yl + occf_clampi(yy, Yl - 1)) * Zl +
+                       occf_clampi(zz, Zl - 1)) * kstride;
+    }
+    if (VEC == 4) {
+      float4 t[8];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] = fmaf(cw, vp[v], acc[v]);
+      for (int c = 0; c < 8; ++c) t[c] = *(const float4*)vp[c];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (cw[c] != 0.f) {   // (keeps a non-finite value behind a zero weight out of the sum)
+          acc[0] = fmaf(cw[c], t[c].x, acc[0]);
+          acc[1 % VEC] = fmaf(cw[c], t[c].y, acc[1 % VEC]);
+          acc[2 % VEC] = fmaf(cw[c], t[c].z, acc[2 % VEC]);
+          acc[3 % VEC] = fmaf(cw[c], t[c].w, acc[3 % VEC]);
+        }
       }
+    } else {
+      float t[8][VEC];
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) t[c][v] = vp[c][v];
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (cw[c] != 0.f) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) acc[v] = fmaf(cw[c], t[c][v], acc[v]);
+        }
     }
     }
   }
