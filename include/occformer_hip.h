@@ -86,10 +86,13 @@ int occf_window_attn_fwd(const float* qkv, const float* qkv_bias, const float* b
  * (before output_proj).  level_shapes is a HOST array [L][3] = (X, Y, Z) per level, coarse->fine
  * as the decoder concatenates them; the queries are the level cells themselves (Nq = sum XYZ).
  * value_head_major = 1: value is [B, heads, Nq, head_dim] and lanes walk the queries of one head
- * (adjacent queries sample adjacent cells -> shared cache lines); out stays [B, Nq, heads*head_dim]. */
+ * (adjacent queries sample adjacent cells -> shared cache lines); out stays [B, Nq, heads*head_dim].
+ * offsets_ld / logits_ld: floats between consecutive query rows of the two inputs (0 = dense), so both
+ * may be column blocks of ONE fused projection output. */
 int occf_msda3d_fwd(const float* value, const float* sampling_offsets, const float* attn_logits,
                     float* out, const int32_t* level_shapes, int num_levels, int B, int Nq,
-                    int heads, int head_dim, int num_points, int value_head_major, void* stream);
+                    int heads, int head_dim, int num_points, int value_head_major, long offsets_ld,
+                    long logits_ld, void* stream);
 
 /* ------------------------------------------------------------------ occupancy decoder -- */
 
@@ -207,10 +210,15 @@ int occf_upsample_add(const float* coarse, const float* lateral, float* out, int
  * a = a_hi + a_lo (bf16) and a_hi*b_hi + a_hi*b_lo + a_lo*b_hi is accumulated -- fp32-class
  * accuracy (~2^-17 rel. per product) at 16/3 of the fp32-MFMA rate; terms = 1: plain bf16 (w_lo may
  * be NULL).  The weight is given pre-split (occf_split_bf16) as two bf16 arrays [N, K]; the
- * activation is split while it is staged.  K % 32 == 0 (conv: Cin % 32 == 0). */
+ * activation is split while it is staged.  K % 32 == 0 (conv: Cin % 32 == 0).
+ * out_head_dim > 0 (linear only): the output is written head-major, out[b, n / out_head_dim, q,
+ * n % out_head_dim] with row m = b * out_head_rows + q -- the layout occf_msda3d_fwd gathers from
+ * (value_head_major), produced by the projection itself instead of a transposing copy; ldo is ignored,
+ * N % out_head_dim == 0, out_head_dim % 4 == 0, no residual. */
 int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
                          const float* residual, float* out, long M, int N, int K, long ldx, long ldo,
-                         long ldr, int act, int terms, float* workspace, long workspace_floats, void* stream);
+                         long ldr, int act, int terms, float* workspace, long workspace_floats,
+                         int out_head_dim, long out_head_rows, void* stream);
 int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
                          const float* residual, float* out, int B, int Xi, int Yi, int Zi, int Cin, int Cout,
                          int kX, int kY, int kZ, int stride, int dil, int pad_x, int pad_y, int pad_z,

@@ -45,6 +45,8 @@ struct GemmArgsB {
   int act;
   int ksplit;          // > 1: blockIdx.y = K-slice, raw partial tiles go to `slab`
   float* slab;         // [ksplit][M][N]
+  int hm_dh;           // > 0: head-major output [b, n / hm_dh, q, n % hm_dh], row m = b * hm_rows + q
+  long hm_rows;
   ConvGeomB g;
 };
 
@@ -338,7 +340,15 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
             v.x = occf_gelu_b(v.x); v.y = occf_gelu_b(v.y); v.z = occf_gelu_b(v.z); v.w = occf_gelu_b(v.w);
           }
           if (e_res) { v.x += rr[it].x; v.y += rr[it].y; v.z += rr[it].z; v.w += rr[it].w; }
-          if (m < p.M && n_ok) *(float4*)(e_out + m * e_ldc + n) = v;
+          if (m < p.M && n_ok) {
+            if (!part && p.hm_dh > 0) {
+              const long bb = m / p.hm_rows, q = m - bb * p.hm_rows;
+              const int hh = n / p.hm_dh;
+              *(float4*)(e_out + ((bb * (p.N / p.hm_dh) + hh) * p.hm_rows + q) * p.hm_dh + (n - hh * p.hm_dh)) = v;
+            } else {
+              *(float4*)(e_out + m * e_ldc + n) = v;
+            }
+          }
         }
       }
     } else {
@@ -398,7 +408,7 @@ static int launch_gemm_b(GemmArgsB a, int terms, float* workspace, long workspac
   if (terms == 3 && a.Wl == nullptr) return OCCF_EINVAL;
   const int mt = occf_cdiv(a.M, GB_BM);
   const bool wide = (a.N % 128 == 0) || a.N > 512;
-  a.ksplit = workspace ? occf_pick_ksplit(a.M, a.N, a.K, wide, workspace_floats) : 1;
+  a.ksplit = (workspace && a.hm_dh == 0) ? occf_pick_ksplit(a.M, a.N, a.K, wide, workspace_floats) : 1;
   a.slab = workspace;
   const dim3 grid((unsigned)((long)mt * occf_cdiv(a.N, wide ? 128 : 64)), a.ksplit);
   const bool sp = a.ksplit > 1;
@@ -447,11 +457,15 @@ extern "C" long occf_gemm_bf16_workspace(long M, int N, int K) {
 extern "C" int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
                                     const float* bias, const float* residual, float* out, long M, int N,
                                     int K, long ldx, long ldo, long ldr, int act, int terms, float* workspace,
-                                    long workspace_floats, void* stream) {
+                                    long workspace_floats, int out_head_dim, long out_head_rows, void* stream) {
   if (M >= 2147483647L || ldx % 4 != 0) return OCCF_ESHAPE;
+  if (out_head_dim > 0 && (N % out_head_dim || out_head_dim % 4 || N % 4 || residual || out_head_rows <= 0 ||
+                           M % out_head_rows))
+    return OCCF_ESHAPE;
   GemmArgsB a = {};
   a.A = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.C = out;
-  a.M = (int)M; a.N = N; a.K = K; a.lda = ldx; a.ldc = ldo; a.ldr = ldr; a.act = act;
+  a.M = (int)M; a.N = N; a.K = K; a.lda = ldx; a.ldc = out_head_dim > 0 ? 4 : ldo; a.ldr = ldr; a.act = act;
+  a.hm_dh = out_head_dim > 0 ? out_head_dim : 0; a.hm_rows = out_head_rows;
   return launch_gemm_b<false>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
 }
 

@@ -27,7 +27,7 @@ struct MsdaLevels {
 template <int VEC, int LP_MAX, bool HM>
 __global__ void __launch_bounds__(256) msda3d_fwd_kernel(
     const float* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
-    float* __restrict__ out, MsdaLevels lv, int B, int Nq, int H, int Dh, int P) {
+    float* __restrict__ out, MsdaLevels lv, int B, int Nq, int H, int Dh, int P, long off_ld, long lg_ld) {
   const int lanes = Dh / VEC;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)B * Nq * H * lanes;
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) msda3d_fwd_kernel(
   const float rx = ((float)qx + 0.5f) / (float)lv.X[ql];
 
   // softmax over the L*P logits of this (query, head)
-  const float* lg = logits + ((long)(b * Nq + q) * H + h) * LP;
+  const float* lg = logits + (long)(b * Nq + q) * lg_ld + h * LP;
   float w[LP_MAX];
   float mx = -3.0e38f;
 #pragma unroll
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(256) msda3d_fwd_kernel(
   }
   const float inv = 1.0f / sum;
 
-  const float* of = offs + ((long)(b * Nq + q) * H + h) * LP * 3;
+  const float* of = offs + (long)(b * Nq + q) * off_ld + h * LP * 3;
   const int E = H * Dh;
   float acc[VEC];
 #pragma unroll
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) msda3d_fwd_kernel(
 extern "C" int occf_msda3d_fwd(const float* value, const float* sampling_offsets,
                                const float* attn_logits, float* out, const int32_t* level_shapes,
                                int num_levels, int B, int Nq, int heads, int head_dim,
-                               int num_points, int value_head_major, void* stream) {
+                               int num_points, int value_head_major, long offsets_ld, long logits_ld, void* stream) {
   if (num_levels <= 0 || num_levels > MSDA_MAX_LEVELS || B <= 0 || heads <= 0 || head_dim <= 0 ||
       num_points <= 0 || num_levels * num_points > 16)
     return OCCF_ESHAPE;
@@ -176,22 +176,24 @@ extern "C" int occf_msda3d_fwd(const float* value, const float* sampling_offsets
   for (int l = num_levels; l < MSDA_MAX_LEVELS; ++l) lv.X[l] = lv.Y[l] = lv.Z[l] = lv.start[l] = 0;
   if (start != Nq) return OCCF_ESHAPE;   // queries ARE the keys (encoder self-attention)
   hipStream_t st = (hipStream_t)stream;
+  const long off_ld = offsets_ld > 0 ? offsets_ld : (long)heads * num_levels * num_points * 3;
+  const long lg_ld = logits_ld > 0 ? logits_ld : (long)heads * num_levels * num_points;
   if (head_dim % 4 == 0) {
     const long total = (long)B * Nq * heads * (head_dim / 4);
     if (value_head_major)
       hipLaunchKernelGGL((msda3d_fwd_kernel<4, 16, true>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,
-                         sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points);
+                         sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
     else
       hipLaunchKernelGGL((msda3d_fwd_kernel<4, 16, false>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,
-                         sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points);
+                         sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
   } else {
     const long total = (long)B * Nq * heads * head_dim;
     if (value_head_major)
       hipLaunchKernelGGL((msda3d_fwd_kernel<1, 16, true>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,
-                         sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points);
+                         sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
     else
       hipLaunchKernelGGL((msda3d_fwd_kernel<1, 16, false>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,
-                         sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points);
+                         sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
   }
   OCCF_LAUNCH_CHECK();
 }

@@ -50,9 +50,9 @@ def channels_last_view(x):
     return v if v.is_contiguous() else v.contiguous()
 
 
-def linear(x, lin, act=0, residual=None):
+def linear(x, lin, act=0, residual=None, head_major=None):
     return get_ops().linear(x, lin.weight.detach(), None if lin.bias is None else lin.bias.detach(), act,
-                            residual, w_split=split_weight(lin.weight))
+                            residual, w_split=split_weight(lin.weight), head_major=head_major)
 
 
 def layernorm(x, ln):

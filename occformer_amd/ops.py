@@ -122,7 +122,8 @@ class HipOps:
     # ------------------------------------------------------------------ pixel decoder
     def msda3d(self, value, offsets, logits, level_shapes, heads, points, head_major=False):
         """value [B, Nq, E] (or [B, heads, Nq, E/heads] with head_major); offsets [B, Nq, heads*L*P*3];
-        logits [B, Nq, heads*L*P] -> [B, Nq, E]."""
+        logits [B, Nq, heads*L*P] -> [B, Nq, E].  offsets / logits may be column slices of one tensor
+        (unit channel stride, any row stride)."""
         if head_major:
             B, _, Nq, dh = value.shape
             E = heads * dh
@@ -131,10 +132,14 @@ class HipOps:
         L = len(level_shapes)
         arr = (ctypes.c_int32 * (3 * L))(*[int(v) for s in level_shapes for v in s])
         out = torch.empty((B, Nq, E), dtype=value.dtype, device=value.device)
-        self._call("occf_msda3d_fwd", self._ptr(value, self.f32), self._ptr(offsets, self.f32),
-                   self._ptr(logits, self.f32), self._ptr(out),
+        for t in (offsets, logits):
+            if t.stride(-1) != 1 or t.stride(0) != t.stride(1) * Nq or (self.strict and not t.is_cuda) or \
+                    t.dtype != self.f32:
+                raise OccfError("msda3d: offsets/logits must be fp32 GPU rows with unit channel stride")
+        self._call("occf_msda3d_fwd", self._ptr(value, self.f32), ctypes.c_void_p(offsets.data_ptr()),
+                   ctypes.c_void_p(logits.data_ptr()), self._ptr(out),
                    ctypes.cast(arr, ctypes.c_void_p), L, B, Nq, heads, E // heads, points, int(head_major),
-                   self._stream())
+                   offsets.stride(1), logits.stride(1), self._stream())
         return out
 
     # ------------------------------------------------------------------ occupancy decoder
@@ -217,7 +222,12 @@ class HipOps:
             return 0
         return 3 if self.precision == "bf16x3" else 1
 
-    def linear(self, x, weight, bias=None, act=0, residual=None, out=None, w_split=None, allow_small=True):
+    def head_major_supported(self, M, N, K, dh):
+        """can ``linear(..., head_major=(rows, dh))`` be used for this shape / precision mode"""
+        return self.precision != "f32" and K % 32 == 0 and max(M, N) >= 64 and dh % 4 == 0 and N % dh == 0
+
+    def linear(self, x, weight, bias=None, act=0, residual=None, out=None, w_split=None, allow_small=True,
+               head_major=None):
         """x [..., K] (rows contiguous along K) @ weight[N, K]^T -> [..., N].  ``w_split`` = the
         (hi, lo) bf16 split of ``weight`` enables the bf16 matrix-core path (see ``precision``)."""
         K = x.shape[-1]
@@ -232,18 +242,28 @@ class HipOps:
             if t is not None and (t.stride(1) != 1 or (self.strict and not t.is_cuda)):
                 raise OccfError("linear: rows must be channel-contiguous GPU tensors")
         rp = ctypes.c_void_p(r2.data_ptr()) if r2 is not None else ctypes.c_void_p(0)
-        if allow_small and M <= 128 and M * N <= 262144 and K % 4 == 0:
+        if head_major is None and allow_small and M <= 128 and M * N <= 262144 and K % 4 == 0:
             self._call("occf_linear_small_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(weight, self.f32),
                        self._ptr(bias), rp, ctypes.c_void_p(out.data_ptr()), M, N, K, x2.stride(0),
                        out.stride(0), r2.stride(0) if r2 is not None else 0, int(act), self._stream())
             return out.view(*x.shape[:-1], N)
         terms = self._bf16_terms(K, max(M, N), w_split)
+        if head_major is not None:
+            # head_major = (rows per batch, head_dim): out[b, h, q, d] written by the GEMM epilogue
+            rows, dh = head_major
+            if not terms or residual is not None:
+                raise OccfError("head-major output needs the bf16 GEMM path and no residual")
+            self._call("occf_linear_bf16_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(w_split[0]),
+                       self._ptr(w_split[1]), self._ptr(bias), ctypes.c_void_p(0), ctypes.c_void_p(out.data_ptr()),
+                       M, N, K, x2.stride(0), N, 0, int(act), terms, ctypes.c_void_p(0), 0, int(dh), int(rows),
+                       self._stream())
+            return out.view(M // rows, N // dh, rows, dh)
         if terms:
             ws, nws = self._splitk_workspace(M, N, K, x.device)
             self._call("occf_linear_bf16_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(w_split[0]),
                        self._ptr(w_split[1]), self._ptr(bias), rp, ctypes.c_void_p(out.data_ptr()), M, N, K,
                        x2.stride(0), out.stride(0), r2.stride(0) if r2 is not None else 0, int(act), terms,
-                       self._ptr(ws), nws, self._stream())
+                       self._ptr(ws), nws, 0, 0, self._stream())
         else:
             self._call("occf_linear_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(weight, self.f32),
                        self._ptr(bias), rp, ctypes.c_void_p(out.data_ptr()), M, N, K, x2.stride(0),

@@ -111,14 +111,20 @@ class MultiScaleDeformableAttention3D(nn.Module):
         fused.require_eval(self)
         ops = get_ops()
         qp = query + query_pos
-        value = fused.linear(query, self.value_proj)
+        B, Nq, E = query.shape
+        dh = E // self.num_heads
         w, b = self._offset_logit_weights()
         ol = ops.linear(qp, w, b, w_split=self._fused_split)
         n_off = self.sampling_offsets.out_features
-        B, Nq, E = value.shape
-        value_hm = value.view(B, Nq, self.num_heads, E // self.num_heads).permute(0, 2, 1, 3).contiguous()
-        out = ops.msda3d(value_hm, ol[..., :n_off].contiguous(), ol[..., n_off:].contiguous(), level_shapes,
-                         self.num_heads, self.num_points, head_major=True)
+        if ops.head_major_supported(B * Nq, E, E, dh):
+            # the value projection writes the head-major layout the sampler gathers from
+            value_hm = fused.linear(query, self.value_proj, head_major=(Nq, dh))
+        else:
+            value = fused.linear(query, self.value_proj)
+            value_hm = value.view(B, Nq, self.num_heads, dh).permute(0, 2, 1, 3).contiguous()
+        # offsets and logits stay column blocks of the fused projection output (row stride = its width)
+        out = ops.msda3d(value_hm, ol[..., :n_off], ol[..., n_off:], level_shapes, self.num_heads,
+                         self.num_points, head_major=True)
         return fused.linear(out, self.output_proj, residual=query)       # dropout = identity (eval)
 
 

@@ -258,3 +258,18 @@ def test_mlp_fused(be, monkeypatch, C, H, act, ln_mode, M, prec, tol):
                            be.ops.split_bf16(be.to(w2)), be.to(b2), act, ln_mode).cpu()
     err = float((out - ref.float()).abs().max() / ref.abs().max())
     assert err < tol, err
+
+
+def test_linear_head_major_output(be):
+    """value projection written directly as [B, heads, Nq, dh] (what msda3d gathers from)"""
+    B, Nq, E, H = 2, 150, 96, 8
+    x = paramgen.tensor("hm.x", (B, Nq, E), 1)
+    w = paramgen.tensor("hm.w", (E, E), 1, E ** -0.5)
+    b = paramgen.tensor("hm.b", (E,), 1)
+    ops = be.ops
+    if not ops.head_major_supported(B * Nq, E, E, E // H):
+        pytest.skip("precision mode without the bf16 GEMM")
+    xd, wd, bd = be.to(x, w, b)
+    out = ops.linear(xd, wd, bd, w_split=ops.split_bf16(wd), head_major=(Nq, E // H)).cpu()
+    ref = torch.nn.functional.linear(x, w, b).view(B, Nq, H, E // H).permute(0, 2, 1, 3)
+    assert out.shape == ref.shape and torch.allclose(out, ref, atol=2e-4, rtol=1e-4)
