@@ -68,6 +68,7 @@ typedef uint32_t ch_u2 __attribute__((ext_vector_type(2)));
 template <int TN, int TERMS>
 __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
   constexpr int BN = 64 * TN;
+  constexpr int NBP = (BN * 4 + 511) / 512;          // 16-B weight pieces per thread per array
   constexpr int NHI = 13;                             // float4 halo pieces per thread (816 * 8 / 512)
   constexpr bool HPF = TN <= 2;                       // prefetch the next chunk's halo across the taps
   OCCF_DYN_SMEM(smem);
@@ -76,6 +77,8 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
   const int NH = 4 * HY * HZ;                         // halo rows (voxels)
   unsigned char* Hh = (unsigned char*)smem;           // [NH][64 B]
   unsigned char* Hl = Hh + (size_t)NH * 64;
+  unsigned char* Bh = Hl + (TERMS == 3 ? (size_t)NH * 64 : 0);     // [2][BN][64 B]
+  unsigned char* Bl = Bh + 2 * BN * 64;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -119,15 +122,18 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
                     occf_clampi(z, p.Z - 1) * p.sz) + kq * 4;
     hok |= (ok ? 1u : 0u) << i;
   }
-  // weight fragments come straight from global memory (L1/L2) in MFMA operand layout: lane -> column
-  // n0 + wn*BN/2 + j*32 + li, 8 consecutive k at k-slot s*2 + lk.  The four M-waves of a column half
-  // read the same 16-byte pieces (L1 hits).  Columns >= Cout read column Cout-1 (never stored).
+  // weight piece bookkeeping (columns >= Cout read column Cout-1; never stored)
+  int b_slot[NBP], b_row[NBP];
+  long b_off[NBP];
   const long K = 27L * p.Cin;
-  long bn_off[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * (BN / 2) + j * 32 + li;
-    bn_off[j] = (long)(n < p.Cout ? n : p.Cout - 1) * K + lk * 8;
+  for (int i = 0; i < NBP; ++i) {
+    const int idx = tid + i * 512;
+    const int idc = idx < BN * 4 ? idx : BN * 4 - 1;
+    b_row[i] = idc >> 2;
+    b_slot[i] = idc & 3;
+    const int n = n0 + b_row[i];
+    b_off[i] = (long)(n < p.Cout ? n : p.Cout - 1) * K + b_slot[i] * 8;
   }
 
   f32x16 acc[2][TN];
@@ -140,8 +146,7 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
 
   constexpr int HB = HPF ? NHI : 7;                   // halo pieces per batch (register budget of TN = 3)
   float4 hreg[HB];
-  constexpr int BS = TN <= 2 ? 2 : 1;                 // weight-fragment sets in flight (taps ahead)
-  bf16x8 bqh[BS][2][TN], bql[BS][2][TN];
+  ch_u4 rbh[2][NBP], rbl[2][NBP];
   const int n_chunks = p.Cin / 32;
   const int G = n_chunks * 27;                        // flat (chunk, tap) stream
   auto load_halo = [&](int c0, int i0) __attribute__((always_inline)) {
@@ -168,33 +173,40 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
       }
     }
   };
-  // weight fragments of stream position g (clamped to the last one) -> register set d
-  auto load_bq = [&](int g, int d) __attribute__((always_inline)) {
+  // weight slab of stream position g (clamped to the last one) -> ring slot d
+  auto load_b = [&](int g, int d) __attribute__((always_inline)) {
     const int gc = g < G ? g : G - 1;
-    const int cq = gc / 27, tq = gc - cq * 27;
-    const long o = (long)tq * p.Cin + cq * 32;
+    const int cc = gc / 27, tap = gc - cc * 27;
+    const long o = (long)tap * p.Cin + cc * 32;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int i = 0; i < NBP; ++i) {
+      rbh[d][i] = *(const ch_u4*)(p.Wh + b_off[i] + o);
+      if (TERMS == 3) rbl[d][i] = *(const ch_u4*)(p.Wl + b_off[i] + o);
+    }
+  };
+  auto store_b = [&](int buf, int d) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        bqh[d][s][j] = *(const bf16x8*)(p.Wh + bn_off[j] + o + s * 16);
-        if (TERMS == 3) bql[d][s][j] = *(const bf16x8*)(p.Wl + bn_off[j] + o + s * 16);
+    for (int i = 0; i < NBP; ++i) {
+      if (tid + i * 512 < BN * 4) {
+        const int off = buf * BN * 64 + ch_slot(b_row[i], b_slot[i]);
+        *(ch_u4*)(Bh + off) = rbh[d][i];
+        if (TERMS == 3) *(ch_u4*)(Bl + off) = rbl[d][i];
       }
+    }
   };
 
-  // Only the halo lives in LDS, so the 27 taps of a chunk run without any barrier.
+  // ring slot (g & 1) holds slab g; LDS buffer (g & 1) holds slab g while it is multiplied
   if (HPF) load_halo(0, 0);
-  load_bq(0, 0);
+  load_b(0, 0);
+  load_b(1, 1);
+  store_b(0, 0);
   int cc = 0, tap = 0;
   for (int g0 = 0; g0 < G; g0 += 2) {
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
       const int g = g0 + d;
       if (g < G) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int cur = BS == 2 ? d : 0;
-        if (BS == 2) load_bq(g + 1, (d + 1) & 1);
+        if (g > 0) load_b(g + 1, (d + 1) & 1);          // slab g+1 (slot freed when slab g-1 went to LDS)
         if (tap == 0) {
           __syncthreads();                               // previous chunk's taps are done with the halo
           if (HPF) {
@@ -214,7 +226,7 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const int kslot = s * 2 + lk;
-          bf16x8 ah[2], al[2];
+          bf16x8 ah[2], al[2], bh[TN], bl[TN];
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             const int off = ch_slot(hb[i] + toff, kslot);
@@ -222,17 +234,24 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
             if (TERMS == 3) al[i] = *(const bf16x8*)(Hl + off);
           }
 #pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int off = d * BN * 64 + ch_slot(wn * (BN / 2) + j * 32 + li, kslot);
+            bh[j] = *(const bf16x8*)(Bh + off);
+            if (TERMS == 3) bl[j] = *(const bf16x8*)(Bl + off);
+          }
+#pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
               if (TERMS == 3) {
-                acc[i][j] = occf_mfma_bf16_32x32x16(al[i], bqh[cur][s][j], acc[i][j]);
-                acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bql[cur][s][j], acc[i][j]);
+                acc[i][j] = occf_mfma_bf16_32x32x16(al[i], bh[j], acc[i][j]);
+                acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bl[j], acc[i][j]);
               }
-              acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bqh[cur][s][j], acc[i][j]);
+              acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bh[j], acc[i][j]);
             }
         }
-        if (BS == 1) load_bq(g + 1, 0);
+        if (g + 1 < G) store_b((d + 1) & 1, (d + 1) & 1);
+        __syncthreads();
         if (++tap == 27) { tap = 0; ++cc; }
       }
     }
@@ -276,8 +295,7 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
 
 static size_t conv_halo_lds(int TY, int TZ, int TN, int terms) {
   const size_t NH = 4 * (size_t)(TY + 2) * (TZ + 2);
-  (void)TN;
-  return NH * 64 * (terms == 3 ? 2 : 1);
+  return NH * 64 * (terms == 3 ? 2 : 1) + (size_t)2 * 64 * TN * 64 * (terms == 3 ? 2 : 1);
 }
 
 template <int TN>

@@ -34,18 +34,7 @@ __global__ void __launch_bounds__(256) mask_pool_kernel(
   if ((YZ & 3) == 0) {
     for (int e = threadIdx.x * 4; e < YZ; e += blockDim.x * 4) {
       float4 m = *(const float4*)(src + (long)x0 * YZ + e);
-      int x = x0 + 1;
-      for (; x + 3 < x1; x += 4) {                     // four planes in flight per thread
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *(const float4*)(src + (long)(x + u) * YZ + e);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          m.x = occf_nanmax(m.x, v[u].x); m.y = occf_nanmax(m.y, v[u].y);
-          m.z = occf_nanmax(m.z, v[u].z); m.w = occf_nanmax(m.w, v[u].w);
-        }
-      }
-      for (; x < x1; ++x) {
+      for (int x = x0 + 1; x < x1; ++x) {
         const float4 v = *(const float4*)(src + (long)x * YZ + e);
         m.x = occf_nanmax(m.x, v.x); m.y = occf_nanmax(m.y, v.y);
         m.z = occf_nanmax(m.z, v.z); m.w = occf_nanmax(m.w, v.w);
@@ -265,7 +254,6 @@ extern "C" long occf_masked_xattn_workspace(int B, int Q, int L, int heads) {
 // -- one pass; the reference's [B,100,256,256,32] fp32 intermediate (839 MB) never exists.
 // mask_pred [B, Q, X, Y, Z]; cls [B, Q, K+1]; out [B, K, X2, Y2, Z2].
 #define UC_MAXQ 128
-#define UC_ZPT 4
 #define UC_MAXK 24
 
 __global__ void __launch_bounds__(256) upsample_classify_kernel(
@@ -283,84 +271,41 @@ __global__ void __launch_bounds__(256) upsample_classify_kernel(
     for (int i = 0; i < K; ++i) prob[qi * UC_MAXK + i] = expf(c[i] - mx) / sum;
   }
   __syncthreads();
-  // a thread produces UC_ZPT consecutive z outputs of one (x2, y2) column: the class probabilities read
-  // from LDS and the x/y interpolation weights are shared by them, its 8 * UC_ZPT gathers of a query are
-  // issued together, and each class row is written as one 16-byte store
   const long V2 = (long)X2 * Y2 * Z2;
-  const int zg = (Z2 + UC_ZPT - 1) / UC_ZPT;
-  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid >= (long)X2 * Y2 * zg) return;
-  const int zb = (int)(tid % zg) * UC_ZPT, y2 = (int)((tid / zg) % Y2), x2 = (int)(tid / ((long)zg * Y2));
+  const long vid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vid >= V2) return;
+  const int z2 = (int)(vid % Z2), y2 = (int)((vid / Z2) % Y2), x2 = (int)(vid / ((long)Z2 * Y2));
   // align_corners=True source coordinate: dst * (in-1)/(out-1)
   const float sx = X2 > 1 ? (float)(X - 1) / (float)(X2 - 1) : 0.f;
   const float sy = Y2 > 1 ? (float)(Y - 1) / (float)(Y2 - 1) : 0.f;
   const float sz = Z2 > 1 ? (float)(Z - 1) / (float)(Z2 - 1) : 0.f;
-  const float fx = sx * x2, fy = sy * y2;
-  const int x0 = (int)fx, y0 = (int)fy;
-  const int x1 = x0 + (x0 < X - 1), y1 = y0 + (y0 < Y - 1);
-  const float tx = fx - x0, ty = fy - y0;
-  int z0[UC_ZPT], z1[UC_ZPT];
-  float tz[UC_ZPT];
+  const float fx = sx * x2, fy = sy * y2, fz = sz * z2;
+  const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+  const int x1 = x0 + (x0 < X - 1), y1 = y0 + (y0 < Y - 1), z1 = z0 + (z0 < Z - 1);
+  const float tx = fx - x0, ty = fy - y0, tz = fz - z0;
+  float acc[UC_MAXK];
 #pragma unroll
-  for (int e = 0; e < UC_ZPT; ++e) {
-    const int z2 = zb + e < Z2 ? zb + e : Z2 - 1;
-    const float fz = sz * z2;
-    z0[e] = (int)fz;
-    z1[e] = z0[e] + (z0[e] < Z - 1);
-    tz[e] = fz - z0[e];
-  }
-  float acc[UC_ZPT][UC_MAXK];
-#pragma unroll
-  for (int e = 0; e < UC_ZPT; ++e)
-#pragma unroll
-    for (int i = 0; i < UC_MAXK; ++i) acc[e][i] = 0.f;
+  for (int i = 0; i < UC_MAXK; ++i) acc[i] = 0.f;
   const long V = (long)X * Y * Z;
   const long o00 = ((long)x0 * Y + y0) * Z, o01 = ((long)x0 * Y + y1) * Z;
   const long o10 = ((long)x1 * Y + y0) * Z, o11 = ((long)x1 * Y + y1) * Z;
   for (int qi = 0; qi < Q; ++qi) {
     const float* mp = mask_pred + ((long)b * Q + qi) * V;
-    float m[UC_ZPT][8];
-#pragma unroll
-    for (int e = 0; e < UC_ZPT; ++e) {
-      m[e][0] = mp[o00 + z0[e]]; m[e][1] = mp[o00 + z1[e]];
-      m[e][2] = mp[o01 + z0[e]]; m[e][3] = mp[o01 + z1[e]];
-      m[e][4] = mp[o10 + z0[e]]; m[e][5] = mp[o10 + z1[e]];
-      m[e][6] = mp[o11 + z0[e]]; m[e][7] = mp[o11 + z1[e]];
-    }
-    float sg[UC_ZPT];
-#pragma unroll
-    for (int e = 0; e < UC_ZPT; ++e) {
-      // same nesting as upsample_trilinear3d: x outermost, z innermost
-      const float c00 = (1.f - tz[e]) * m[e][0] + tz[e] * m[e][1];
-      const float c01 = (1.f - tz[e]) * m[e][2] + tz[e] * m[e][3];
-      const float c10 = (1.f - tz[e]) * m[e][4] + tz[e] * m[e][5];
-      const float c11 = (1.f - tz[e]) * m[e][6] + tz[e] * m[e][7];
-      const float val = (1.f - tx) * ((1.f - ty) * c00 + ty * c01) + tx * ((1.f - ty) * c10 + ty * c11);
-      sg[e] = 1.0f / (1.0f + expf(-val));
-    }
+    // same nesting as upsample_trilinear3d: x outermost, z innermost
+    const float c00 = (1.f - tz) * mp[o00 + z0] + tz * mp[o00 + z1];
+    const float c01 = (1.f - tz) * mp[o01 + z0] + tz * mp[o01 + z1];
+    const float c10 = (1.f - tz) * mp[o10 + z0] + tz * mp[o10 + z1];
+    const float c11 = (1.f - tz) * mp[o11 + z0] + tz * mp[o11 + z1];
+    const float val = (1.f - tx) * ((1.f - ty) * c00 + ty * c01) + tx * ((1.f - ty) * c10 + ty * c11);
+    const float sg = 1.0f / (1.0f + expf(-val));
     const float* pr = &prob[qi * UC_MAXK];
 #pragma unroll
     for (int i = 0; i < UC_MAXK; ++i)
-      if (i < K) {
-        const float pi = pr[i];
-#pragma unroll
-        for (int e = 0; e < UC_ZPT; ++e) acc[e][i] = fmaf(pi, sg[e], acc[e][i]);
-      }
+      if (i < K) acc[i] = fmaf(pr[i], sg, acc[i]);
   }
-  const long vid0 = ((long)x2 * Y2 + y2) * Z2 + zb;
-  const bool full = zb + UC_ZPT <= Z2 && (Z2 % UC_ZPT) == 0;
 #pragma unroll
   for (int i = 0; i < UC_MAXK; ++i)
-    if (i < K) {
-      float* o = out + ((long)b * K + i) * V2 + vid0;
-      if (UC_ZPT == 4 && full) {
-        *(float4*)o = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < UC_ZPT; ++e)
-          if (zb + e < Z2) o[e] = acc[e][i];
-      }
-    }
+    if (i < K) out[((long)b * K + i) * V2 + vid] = acc[i];
 }
 
 extern "C" int occf_upsample_classify_fwd(const float* mask_pred, const float* cls, float* out, int B,
@@ -368,7 +313,7 @@ extern "C" int occf_upsample_classify_fwd(const float* mask_pred, const float* c
                                           void* stream) {
   if (B <= 0 || Q <= 0 || Q > UC_MAXQ || K <= 0 || K > UC_MAXK) return OCCF_ESHAPE;
   const long V2 = (long)X2 * Y2 * Z2;
-  hipLaunchKernelGGL(upsample_classify_kernel, dim3(occf_cdiv((long)X2 * Y2 * ((Z2 + UC_ZPT - 1) / UC_ZPT), 256), B), dim3(256), 0,
+  hipLaunchKernelGGL(upsample_classify_kernel, dim3(occf_cdiv(V2, 256), B), dim3(256), 0,
                      (hipStream_t)stream, mask_pred, cls, out, B, Q, K, X, Y, Z, X2, Y2, Z2);
   OCCF_LAUNCH_CHECK();
 }
