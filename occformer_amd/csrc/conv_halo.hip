@@ -17,12 +17,6 @@
 #include "occf_common.h"
 #include "../../include/occformer_hip.h"
 
-#ifdef OCCF_EMU
-#define OCCF_SCHED_FENCE()
-#else
-#define OCCF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
-
 struct ConvHaloArgs {
   const float* x;
   const uint16_t* Wh;
@@ -71,16 +65,12 @@ typedef uint32_t ch_u2 __attribute__((ext_vector_type(2)));
 // compiler never has to wait inside a branch: the halo of a chunk is fetched as one batch of <= 13
 // float4 per thread -- for TN <= 2 already during the taps of the previous chunk -- and the weight slabs
 // run two taps ahead in a register ring.
-// PIPE: the A/B fragments of tap g+1 are read from LDS into a second register set WHILE tap g multiplies
-// (the weight slabs sit in a 3-deep LDS ring so that slab g+1 is complete before tap g starts); without it
-// every wave first waits for its 16 ds_read_b128 and only then feeds the matrix core, and because the
-// per-tap barrier keeps the 8 waves in phase the LDS and MFMA phases of the whole workgroup serialise.
-template <int TN, int TERMS, bool PIPE>
+template <int TN, int TERMS>
 __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
   constexpr int BN = 64 * TN;
   constexpr int NBP = (BN * 4 + 511) / 512;          // 16-B weight pieces per thread per array
   constexpr int NHI = 13;                             // float4 halo pieces per thread (816 * 8 / 512)
-  constexpr bool HPF = TN <= 2 && !PIPE;              // prefetch the next chunk's halo across the taps
+  constexpr bool HPF = TN <= 2;                       // prefetch the next chunk's halo across the taps
   OCCF_DYN_SMEM(smem);
   const int TY = p.TY, TZ = p.TZ;
   const int HY = TY + 2, HZ = TZ + 2;
@@ -88,8 +78,7 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
   unsigned char* Hh = (unsigned char*)smem;           // [NH][64 B]
   unsigned char* Hl = Hh + (size_t)NH * 64;
   unsigned char* Bh = Hl + (TERMS == 3 ? (size_t)NH * 64 : 0);     // [2][BN][64 B]
-  constexpr int NBUF = PIPE ? 3 : 2;                  // weight slabs resident in LDS
-  unsigned char* Bl = Bh + NBUF * BN * 64;
+  unsigned char* Bl = Bh + 2 * BN * 64;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -206,144 +195,66 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
     }
   };
 
-  if constexpr (PIPE) {
-    // two half-tap fragment sets: set s holds the k-slots {2s, 2s+1} of the current tap; while set 0
-    // multiplies, set 1 is read, and while set 1 multiplies, set 0 of the NEXT tap is read
-    bf16x8 fah[2][2], fal[2][2], fbh[2][TN], fbl[2][TN];                  // [s][tile]
-    auto load_frags = [&](int sh, int toff, int bbuf) __attribute__((always_inline)) {
-      const int kslot = sh * 2 + lk;
+  // ring slot (g & 1) holds slab g; LDS buffer (g & 1) holds slab g while it is multiplied
+  if (HPF) load_halo(0, 0);
+  load_b(0, 0);
+  load_b(1, 1);
+  store_b(0, 0);
+  int cc = 0, tap = 0;
+  for (int g0 = 0; g0 < G; g0 += 2) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int off = ch_slot(hb[i] + toff, kslot);
-        fah[sh][i] = *(const bf16x8*)(Hh + off);
-        if (TERMS == 3) fal[sh][i] = *(const bf16x8*)(Hl + off);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int off = bbuf * BN * 64 + ch_slot(wn * (BN / 2) + j * 32 + li, kslot);
-        fbh[sh][j] = *(const bf16x8*)(Bh + off);
-        if (TERMS == 3) fbl[sh][j] = *(const bf16x8*)(Bl + off);
-      }
-    };
-    auto mfma_half = [&](int sh) __attribute__((always_inline)) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if (TERMS == 3) {
-            acc[i][j] = occf_mfma_bf16_32x32x16(fal[sh][i], fbh[sh][j], acc[i][j]);
-            acc[i][j] = occf_mfma_bf16_32x32x16(fah[sh][i], fbl[sh][j], acc[i][j]);
-          }
-          acc[i][j] = occf_mfma_bf16_32x32x16(fah[sh][i], fbh[sh][j], acc[i][j]);
-        }
-    };
-    auto tap_offset = [&](int t) __attribute__((always_inline)) {
-      const int dz = t % 3, dy = (t / 3) % 3, dx = t / 9;
-      return (dx * HY + dy) * HZ + dz;
-    };
-    // slab g: global ring slot g & 1 -> LDS buffer g % 3; slab g+2 is written at the end of tap g
-    load_b(0, 0);
-    load_b(1, 1);
-    store_b(0, 0);
-    load_b(2, 0);
-    store_b(1, 1);
-    int cc = 0, tap = 0;
-    for (int g0 = 0; g0 < G; g0 += 6) {
-#pragma unroll
-      for (int d = 0; d < 6; ++d) {
-        const int g = g0 + d;
-        if (g < G) {
-          load_b(g + 3, (d + 1) & 1);                    // slab g+1 left this slot at the end of tap g-1
-          if (tap == 0) {
-            __syncthreads();                             // previous chunk's taps are done with the halo
+    for (int d = 0; d < 2; ++d) {
+      const int g = g0 + d;
+      if (g < G) {
+        if (g > 0) load_b(g + 1, (d + 1) & 1);          // slab g+1 (slot freed when slab g-1 went to LDS)
+        if (tap == 0) {
+          __syncthreads();                               // previous chunk's taps are done with the halo
+          if (HPF) {
+            store_halo(0);
+            load_halo((cc + 1 < n_chunks ? cc + 1 : cc) * 32, 0);
+          } else {
 #pragma unroll
             for (int i0 = 0; i0 < NHI; i0 += HB) {
               load_halo(cc * 32, i0);
               store_halo(i0);
             }
-            __syncthreads();
-            load_frags(0, tap_offset(0), d % 3);
           }
-          // (scheduling fences: keep each batch of LDS reads ahead of the MFMAs it overlaps with)
-          load_frags(1, tap_offset(tap), d % 3);
-          OCCF_SCHED_FENCE();
-          mfma_half(0);
-          OCCF_SCHED_FENCE();
-          // (unconditional: after the last tap of a chunk this reads tap 0 of the OLD halo and is discarded;
-          //  a conditional read would make the compiler drain it before the MFMAs below)
-          load_frags(0, tap_offset(tap == 26 ? 0 : tap + 1), (d + 1) % 3);
-          OCCF_SCHED_FENCE();
-          mfma_half(1);
-          OCCF_SCHED_FENCE();
-          store_b((d + 2) % 3, d & 1);                   // slab g+2 (its loads were issued at tap g-1)
           __syncthreads();
-          if (++tap == 27) { tap = 0; ++cc; }
         }
-      }
-    }
-  } else {
-    // ring slot (g & 1) holds slab g; LDS buffer (g & 1) holds slab g while it is multiplied
-    if (HPF) load_halo(0, 0);
-    load_b(0, 0);
-    load_b(1, 1);
-    store_b(0, 0);
-    int cc = 0, tap = 0;
-    for (int g0 = 0; g0 < G; g0 += 2) {
-  #pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const int g = g0 + d;
-        if (g < G) {
-          if (g > 0) load_b(g + 1, (d + 1) & 1);          // slab g+1 (slot freed when slab g-1 went to LDS)
-          if (tap == 0) {
-            __syncthreads();                               // previous chunk's taps are done with the halo
-            if (HPF) {
-              store_halo(0);
-              load_halo((cc + 1 < n_chunks ? cc + 1 : cc) * 32, 0);
-            } else {
-  #pragma unroll
-              for (int i0 = 0; i0 < NHI; i0 += HB) {
-                load_halo(cc * 32, i0);
-                store_halo(i0);
-              }
-            }
-            __syncthreads();
+        const int dz = tap % 3, dy = (tap / 3) % 3, dx = tap / 9;
+        const int toff = (dx * HY + dy) * HZ + dz;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int kslot = s * 2 + lk;
+          bf16x8 ah[2], al[2], bh[TN], bl[TN];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int off = ch_slot(hb[i] + toff, kslot);
+            ah[i] = *(const bf16x8*)(Hh + off);
+            if (TERMS == 3) al[i] = *(const bf16x8*)(Hl + off);
           }
-          const int dz = tap % 3, dy = (tap / 3) % 3, dx = tap / 9;
-          const int toff = (dx * HY + dy) * HZ + dz;
-  #pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int kslot = s * 2 + lk;
-            bf16x8 ah[2], al[2], bh[TN], bl[TN];
-  #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              const int off = ch_slot(hb[i] + toff, kslot);
-              ah[i] = *(const bf16x8*)(Hh + off);
-              if (TERMS == 3) al[i] = *(const bf16x8*)(Hl + off);
-            }
-  #pragma unroll
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int off = d * BN * 64 + ch_slot(wn * (BN / 2) + j * 32 + li, kslot);
+            bh[j] = *(const bf16x8*)(Bh + off);
+            if (TERMS == 3) bl[j] = *(const bf16x8*)(Bl + off);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
             for (int j = 0; j < TN; ++j) {
-              const int off = d * BN * 64 + ch_slot(wn * (BN / 2) + j * 32 + li, kslot);
-              bh[j] = *(const bf16x8*)(Bh + off);
-              if (TERMS == 3) bl[j] = *(const bf16x8*)(Bl + off);
-            }
-  #pragma unroll
-            for (int i = 0; i < 2; ++i)
-  #pragma unroll
-              for (int j = 0; j < TN; ++j) {
-                if (TERMS == 3) {
-                  acc[i][j] = occf_mfma_bf16_32x32x16(al[i], bh[j], acc[i][j]);
-                  acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bl[j], acc[i][j]);
-                }
-                acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bh[j], acc[i][j]);
+              if (TERMS == 3) {
+                acc[i][j] = occf_mfma_bf16_32x32x16(al[i], bh[j], acc[i][j]);
+                acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bl[j], acc[i][j]);
               }
-          }
-          if (g + 1 < G) store_b((d + 1) & 1, (d + 1) & 1);
-          __syncthreads();
-          if (++tap == 27) { tap = 0; ++cc; }
+              acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bh[j], acc[i][j]);
+            }
         }
+        if (g + 1 < G) store_b((d + 1) & 1, (d + 1) & 1);
+        __syncthreads();
+        if (++tap == 27) { tap = 0; ++cc; }
       }
     }
-
   }
 
   // ---- epilogue: row r of the tile -> voxel (tx0 + r>>7, ty0 + (r&127)/TZ, tz0 + (r&127)%TZ)
@@ -382,26 +293,15 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
   }
 }
 
-static size_t conv_halo_lds(int TY, int TZ, int TN, int terms, bool pipe) {
+static size_t conv_halo_lds(int TY, int TZ, int TN, int terms) {
   const size_t NH = 4 * (size_t)(TY + 2) * (TZ + 2);
-  return NH * 64 * (terms == 3 ? 2 : 1) + (size_t)(pipe ? 3 : 2) * 64 * TN * 64 * (terms == 3 ? 2 : 1);
+  return NH * 64 * (terms == 3 ? 2 : 1) + (size_t)2 * 64 * TN * 64 * (terms == 3 ? 2 : 1);
 }
 
-template <int TN, bool PIPE>
+template <int TN>
 static int launch_conv_halo(const ConvHaloArgs& a, int terms, unsigned grid, size_t lds, hipStream_t st) {
-#ifndef OCCF_EMU
-  // > 64 KB of dynamic LDS has to be granted per kernel function, once
-  static bool attr_set[2] = {};
-  const void* fn = terms == 3 ? (const void*)conv3x3x3_halo_kernel<TN, 3, PIPE>
-                              : (const void*)conv3x3x3_halo_kernel<TN, 1, PIPE>;
-  if (!attr_set[terms == 3]) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set[terms == 3] = true;
-  }
-#endif
-  if (terms == 3) hipLaunchKernelGGL((conv3x3x3_halo_kernel<TN, 3, PIPE>), dim3(grid), dim3(512), lds, st, a);
-  else hipLaunchKernelGGL((conv3x3x3_halo_kernel<TN, 1, PIPE>), dim3(grid), dim3(512), lds, st, a);
+  if (terms == 3) hipLaunchKernelGGL((conv3x3x3_halo_kernel<TN, 3>), dim3(grid), dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((conv3x3x3_halo_kernel<TN, 1>), dim3(grid), dim3(512), lds, st, a);
   return (int)hipGetLastError();
 }
 
@@ -426,13 +326,7 @@ extern "C" int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, con
   else if (Cout % 192 == 0) TN = 3;
   else if (Cout % 64 == 0) TN = 1;
   else return OCCF_ESHAPE;
-  static const bool pipe_env = [] {
-    const char* e = getenv("OCCF_HALO_PIPE");
-    return e ? atoi(e) != 0 : true;
-  }();
-  bool pipe = pipe_env && TN <= 2;
-  if (pipe && conv_halo_lds(TY, TZ, TN, terms, true) > 160 * 1024) pipe = false;
-  const size_t lds = conv_halo_lds(TY, TZ, TN, terms, pipe);
+  const size_t lds = conv_halo_lds(TY, TZ, TN, terms);
   if (lds > 160 * 1024) return OCCF_ESHAPE;
   ConvHaloArgs a = {};
   a.x = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.out = out;
@@ -440,10 +334,20 @@ extern "C" int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, con
   a.sb = in_sb; a.sx = in_sx; a.sy = in_sy; a.sz = in_sz; a.act = act;
   const long blocks = (long)B * ((X + 1) / 2) * ((Y + TY - 1) / TY) * (Z / TZ) * ((Cout + 64 * TN - 1) / (64 * TN));
   if (blocks >= 2147483647L) return OCCF_ESHAPE;
+#ifndef OCCF_EMU
+  static bool attr_set[4][2] = {};
+  const void* fn = nullptr;
+  if (TN == 1) fn = terms == 3 ? (const void*)conv3x3x3_halo_kernel<1, 3> : (const void*)conv3x3x3_halo_kernel<1, 1>;
+  if (TN == 2) fn = terms == 3 ? (const void*)conv3x3x3_halo_kernel<2, 3> : (const void*)conv3x3x3_halo_kernel<2, 1>;
+  if (TN == 3) fn = terms == 3 ? (const void*)conv3x3x3_halo_kernel<3, 3> : (const void*)conv3x3x3_halo_kernel<3, 1>;
+  if (!attr_set[TN][terms == 3]) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set[TN][terms == 3] = true;
+  }
+#endif
   hipStream_t st = (hipStream_t)stream;
-  if (TN == 1) return pipe ? launch_conv_halo<1, true>(a, terms, (unsigned)blocks, lds, st)
-                           : launch_conv_halo<1, false>(a, terms, (unsigned)blocks, lds, st);
-  if (TN == 2) return pipe ? launch_conv_halo<2, true>(a, terms, (unsigned)blocks, lds, st)
-                           : launch_conv_halo<2, false>(a, terms, (unsigned)blocks, lds, st);
-  return launch_conv_halo<3, false>(a, terms, (unsigned)blocks, lds, st);
+  if (TN == 1) return launch_conv_halo<1>(a, terms, (unsigned)blocks, lds, st);
+  if (TN == 2) return launch_conv_halo<2>(a, terms, (unsigned)blocks, lds, st);
+  return launch_conv_halo<3>(a, terms, (unsigned)blocks, lds, st);
 }
