@@ -28,6 +28,8 @@ struct ConvHaloArgs {
   int TY, TZ;                 // TY * TZ == 128, TZ | Z
   long sb, sx, sy, sz;        // input element strides (channel stride 1)
   int act;
+  float* gn_partial;          // optional [B][spatial tiles][G][2]: sum / sum of squares of the outputs
+  int gn_G;
 };
 
 __device__ __forceinline__ uint32_t ch_bf16_rne(float x) {
@@ -258,6 +260,9 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
   }
 
   // ---- epilogue: row r of the tile -> voxel (tx0 + r>>7, ty0 + (r&127)/TZ, tz0 + (r&127)%TZ)
+  float gs[TN], gq[TN];                                   // GroupNorm partial sums of this lane's columns
+#pragma unroll
+  for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -287,8 +292,45 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
         if (p.act == 1) v = fmaxf(v, 0.f);
         else if (p.act == 2) v = ch_gelu(v);
         if (p.residual) v += rv[r];
-        if (mok[r]) p.out[mrow[r] + n] = v;
+        if (mok[r]) {
+          p.out[mrow[r] + n] = v;
+          gs[j] += v;
+          gq[j] = fmaf(v, v, gq[j]);
+        }
       }
+    }
+  }
+  if (p.gn_partial) {
+    // deterministic workgroup reduction: lanes (lk) -> LDS [wm][channel] -> channel -> group
+    float* red = (float*)smem;                             // [4][BN][2], then [BN][2] at offset 8*BN
+    __syncthreads();                                        // every wave is out of the tap loop (halo LDS is free)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float a = gs[j] + __shfl_xor(gs[j], 32), q = gq[j] + __shfl_xor(gq[j], 32);
+      if (lk == 0) {
+        const int c = wn * (BN / 2) + j * 32 + li;
+        red[(wm * BN + c) * 2 + 0] = a;
+        red[(wm * BN + c) * 2 + 1] = q;
+      }
+    }
+    __syncthreads();
+    float* csum = red + 8 * BN;
+    if (tid < BN) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+      csum[tid * 2] = a;
+      csum[tid * 2 + 1] = q;
+    }
+    __syncthreads();
+    const int cg = p.Cout / p.gn_G;
+    if (tid < BN / cg && n0 + tid * cg < p.Cout) {
+      float a = 0.f, q = 0.f;
+      for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += csum[c * 2]; q += csum[c * 2 + 1]; }
+      const long sp = ((long)(tx0 >> 1) * yt + ty0 / TY) * zt + tz0 / TZ;
+      float* o = p.gn_partial + ((((long)b * xt * yt * zt) + sp) * p.gn_G + (n0 / cg + tid)) * 2;
+      o[0] = a;
+      o[1] = q;
     }
   }
 }
@@ -310,7 +352,8 @@ static int launch_conv_halo(const ConvHaloArgs& a, int terms, unsigned grid, siz
 extern "C" int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
                                        const float* bias, const float* residual, float* out, int B, int X,
                                        int Y, int Z, int Cin, int Cout, long in_sb, long in_sx, long in_sy,
-                                       long in_sz, int act, int terms, void* stream) {
+                                       long in_sz, int act, int terms, float* gn_partial, int gn_groups,
+                                       void* stream) {
   if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || Cin % 32 != 0 || Cout <= 0) return OCCF_ESHAPE;
   if (terms != 1 && terms != 3) return OCCF_EINVAL;
   if (terms == 3 && w_lo == nullptr) return OCCF_EINVAL;
@@ -332,6 +375,10 @@ extern "C" int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, con
   a.x = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.out = out;
   a.B = B; a.X = X; a.Y = Y; a.Z = Z; a.Cin = Cin; a.Cout = Cout; a.TY = TY; a.TZ = TZ;
   a.sb = in_sb; a.sx = in_sx; a.sy = in_sy; a.sz = in_sz; a.act = act;
+  if (gn_partial) {
+    if (gn_groups <= 0 || Cout % gn_groups || (64 * TN) % (Cout / gn_groups)) return OCCF_ESHAPE;
+    a.gn_partial = gn_partial; a.gn_G = gn_groups;
+  }
   const long blocks = (long)B * ((X + 1) / 2) * ((Y + TY - 1) / TY) * (Z / TZ) * ((Cout + 64 * TN - 1) / (64 * TN));
   if (blocks >= 2147483647L) return OCCF_ESHAPE;
 #ifndef OCCF_EMU
@@ -350,4 +397,13 @@ extern "C" int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, con
   if (TN == 1) return launch_conv_halo<1>(a, terms, (unsigned)blocks, lds, st);
   if (TN == 2) return launch_conv_halo<2>(a, terms, (unsigned)blocks, lds, st);
   return launch_conv_halo<3>(a, terms, (unsigned)blocks, lds, st);
+}
+
+// number of spatial workgroup tiles per batch element (= rows of the GroupNorm partial buffer) the halo
+// kernel uses for this volume, or -1 when it does not take the shape
+extern "C" long occf_conv3x3x3_halo_gn_blocks(int X, int Y, int Z) {
+  const int TZ = Z >= 16 ? 16 : Z;
+  if ((TZ != 16 && TZ != 8 && TZ != 4) || Z % TZ != 0) return -1;
+  const int TY = 128 / TZ;
+  return (long)((X + 1) / 2) * ((Y + TY - 1) / TY) * (Z / TZ);
 }

@@ -47,6 +47,9 @@ struct GemmArgsB {
   float* slab;         // [ksplit][M][N]
   int hm_dh;           // > 0: head-major output [b, n / hm_dh, q, n % hm_dh], row m = b * hm_rows + q
   long hm_rows;
+  float* gn_partial;   // optional [B][M-tiles per batch][G][2]: sum / sum of squares of the stored outputs
+  int gn_G;
+  long gn_rows;        // rows (voxels) per batch element, a multiple of 128
   ConvGeomB g;
 };
 
@@ -301,6 +304,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
   const bool n_ok = n < p.N;
   float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (vec_ok && e_bias && n_ok) b4 = *(const float4*)(e_bias + n);
+  float gsum[4] = {0.f, 0.f, 0.f, 0.f}, gsq[4] = {0.f, 0.f, 0.f, 0.f};   // GroupNorm partials of this thread
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     __syncthreads();                                        // K loop / previous phase done with LDS
@@ -341,6 +345,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
           }
           if (e_res) { v.x += rr[it].x; v.y += rr[it].y; v.z += rr[it].z; v.w += rr[it].w; }
           if (m < p.M && n_ok) {
+            gsum[0] += v.x; gsum[1] += v.y; gsum[2] += v.z; gsum[3] += v.w;
+            gsq[0] = fmaf(v.x, v.x, gsq[0]); gsq[1] = fmaf(v.y, v.y, gsq[1]);
+            gsq[2] = fmaf(v.z, v.z, gsq[2]); gsq[3] = fmaf(v.w, v.w, gsq[3]);
             if (!part && p.hm_dh > 0) {
               const long bb = m / p.hm_rows, q = m - bb * p.hm_rows;
               const int hh = n / p.hm_dh;
@@ -367,6 +374,38 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
           e_out[m * e_ldc + nn + e] = v;
         }
       }
+    }
+  }
+  if (!part && p.gn_partial && vec_ok) {
+    // deterministic workgroup reduction: thread rows -> LDS [row group][column] -> column -> group
+    constexpr int RG = 256 / CG;
+    float* red = (float*)lds;                               // [RG][BN][2], then [BN][2]
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[((row0 * BN) + c4 + e) * 2 + 0] = gsum[e];
+      red[((row0 * BN) + c4 + e) * 2 + 1] = gsq[e];
+    }
+    __syncthreads();
+    float* csum = red + RG * BN * 2;
+    if (tid < BN) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < RG; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+      csum[tid * 2] = a;
+      csum[tid * 2 + 1] = q;
+    }
+    __syncthreads();
+    const int cg = p.N / p.gn_G;
+    if (tid < BN / cg && n0 + tid * cg < p.N) {
+      float a = 0.f, q = 0.f;
+      for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += csum[c * 2]; q += csum[c * 2 + 1]; }
+      const long tiles_pb = p.gn_rows / GB_BM;
+      const long tile = m0 / GB_BM;                         // = b * tiles_pb + tile within the batch element
+      float* o = p.gn_partial + (tile * p.gn_G + (n0 / cg + tid)) * 2;
+      (void)tiles_pb;
+      o[0] = a;
+      o[1] = q;
     }
   }
 }
@@ -408,7 +447,13 @@ static int launch_gemm_b(GemmArgsB a, int terms, float* workspace, long workspac
   if (terms == 3 && a.Wl == nullptr) return OCCF_EINVAL;
   const int mt = occf_cdiv(a.M, GB_BM);
   const bool wide = (a.N % 128 == 0) || a.N > 512;
-  a.ksplit = (workspace && a.hm_dh == 0) ? occf_pick_ksplit(a.M, a.N, a.K, wide, workspace_floats) : 1;
+  a.ksplit = (workspace && a.hm_dh == 0 && !a.gn_partial) ? occf_pick_ksplit(a.M, a.N, a.K, wide, workspace_floats) : 1;
+  if (a.gn_partial) {
+    const int bn = wide ? 128 : 64;
+    if (a.gn_G <= 0 || a.N % a.gn_G || bn % (a.N / a.gn_G) || a.N % 4 || a.ldc % 4 || a.gn_rows <= 0 ||
+        a.gn_rows % GB_BM || a.M % a.gn_rows)
+      return OCCF_ESHAPE;
+  }
   a.slab = workspace;
   const dim3 grid((unsigned)((long)mt * occf_cdiv(a.N, wide ? 128 : 64)), a.ksplit);
   const bool sp = a.ksplit > 1;
@@ -457,7 +502,8 @@ extern "C" long occf_gemm_bf16_workspace(long M, int N, int K) {
 extern "C" int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
                                     const float* bias, const float* residual, float* out, long M, int N,
                                     int K, long ldx, long ldo, long ldr, int act, int terms, float* workspace,
-                                    long workspace_floats, int out_head_dim, long out_head_rows, void* stream) {
+                                    long workspace_floats, int out_head_dim, long out_head_rows, float* gn_partial,
+                                    int gn_groups, long gn_rows, void* stream) {
   if (M >= 2147483647L || ldx % 4 != 0) return OCCF_ESHAPE;
   if (out_head_dim > 0 && (N % out_head_dim || out_head_dim % 4 || N % 4 || residual || out_head_rows <= 0 ||
                            M % out_head_rows))
@@ -466,6 +512,7 @@ extern "C" int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const 
   a.A = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.C = out;
   a.M = (int)M; a.N = N; a.K = K; a.lda = ldx; a.ldc = out_head_dim > 0 ? 4 : ldo; a.ldr = ldr; a.act = act;
   a.hm_dh = out_head_dim > 0 ? out_head_dim : 0; a.hm_rows = out_head_rows;
+  a.gn_partial = gn_partial; a.gn_G = gn_groups; a.gn_rows = gn_rows;
   return launch_gemm_b<false>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
 }
 
@@ -474,7 +521,7 @@ extern "C" int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const 
                                     int Yi, int Zi, int Cin, int Cout, int kX, int kY, int kZ, int stride,
                                     int dil, int pad_x, int pad_y, int pad_z, long in_sb, long in_sx,
                                     long in_sy, long in_sz, int act, int terms, float* workspace,
-                                    long workspace_floats, void* stream) {
+                                    long workspace_floats, float* gn_partial, int gn_groups, void* stream) {
   if (B <= 0 || Cin % GB_BK != 0 || stride <= 0 || dil <= 0) return OCCF_ESHAPE;
   if (in_sb % 4 || in_sx % 4 || in_sy % 4 || in_sz % 4) return OCCF_ESHAPE;
   GemmArgsB a = {};
@@ -489,6 +536,7 @@ extern "C" int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const 
   if (g.Xo <= 0 || g.Yo <= 0 || g.Zo <= 0 || M >= 2147483647L) return OCCF_ESHAPE;
   a.A = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.C = out;
   a.M = (int)M; a.N = Cout; a.K = kX * kY * kZ * Cin; a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.act = act;
+  a.gn_partial = gn_partial; a.gn_G = gn_groups; a.gn_rows = (long)g.Xo * g.Yo * g.Zo;
   return launch_gemm_b<true>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
 }
 

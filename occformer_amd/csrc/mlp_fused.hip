@@ -61,20 +61,17 @@ __device__ __forceinline__ void ml_split2(float a, float b, uint32_t& hi, uint32
 }
 __device__ __forceinline__ int ml_slot(int row, int kslot) { return row * 64 + ((kslot ^ ((row >> 2) & 3)) << 4); }
 __device__ __forceinline__ float ml_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-struct ml_u4 {
-  uint32_t x, y, z, w;
-};
-struct ml_u2 {
-  uint32_t x, y;
-};
+typedef uint32_t ml_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t ml_u2 __attribute__((ext_vector_type(2)));
 
 // store 4 consecutive-k fp32 values of operand row `row` at k index `k` (multiple of 4) into a
 // [k-tile][rows][64 B] hi/lo image with `rows` rows per k-tile
 __device__ __forceinline__ void ml_put4(unsigned char* hi, unsigned char* lo, int rows, int row, int k, float a,
                                         float b, float c, float d, bool three) {
-  ml_u2 h, l;
-  ml_split2(a, b, h.x, l.x);
-  ml_split2(c, d, h.y, l.y);
+  uint32_t h0, l0, h1, l1;
+  ml_split2(a, b, h0, l0);
+  ml_split2(c, d, h1, l1);
+  const ml_u2 h = {h0, h1}, l = {l0, l1};
   const int off = (k >> 5) * rows * 64 + ml_slot(row, (k & 31) >> 3) + ((k >> 2) & 1) * 8;
   *(ml_u2*)(hi + off) = h;
   if (three) *(ml_u2*)(lo + off) = l;
@@ -106,6 +103,15 @@ __global__ void __launch_bounds__(256) mlp_fused_kernel(MlpArgs p) {
   {
     const int sub = tid & 15, rloc = tid >> 4;
     constexpr int NV = C / 64;            // float4 per lane per row
+    // all 4 * NV row pieces of this thread are fetched first (rows >= M read row M-1 and are zeroed)
+    float4 xv[4][NV];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const long m = m0 + pass * 16 + rloc;
+      const long mc = m < p.M ? m : (long)p.M - 1;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) xv[pass][j] = *(const float4*)(p.x + mc * C + (sub + 16 * j) * 4);
+    }
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
       const int row = pass * 16 + rloc;
@@ -114,7 +120,7 @@ __global__ void __launch_bounds__(256) mlp_fused_kernel(MlpArgs p) {
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
-        v[j] = m < p.M ? *(const float4*)(p.x + m * C + (sub + 16 * j) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[j] = m < p.M ? xv[pass][j] : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
       }
       if (p.ln_mode == 1) {
@@ -150,18 +156,49 @@ __global__ void __launch_bounds__(256) mlp_fused_kernel(MlpArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // weight tile loader: `rows` rows x 32 k of a row-major [*, ld] bf16 matrix -> W LDS image
-  auto load_w = [&](const uint16_t* Wgh, const uint16_t* Wgl, int rows, long row0, long ld, long k0) {
-    for (int idx = tid; idx < rows * 4; idx += 256) {
-      const int n = idx >> 2, slot = idx & 3;
-      const long o = (row0 + n) * ld + k0 + slot * 8;
-      const int off = ml_slot(n, slot);
-      *(ml_u4*)(Wh + off) = *(const ml_u4*)(Wgh + o);
-      if (three) *(ml_u4*)(Wl + off) = *(const ml_u4*)(Wgl + o);
+  // Weight tiles (`rows` rows x 32 k of a row-major bf16 matrix) form one flat stream over the chunks:
+  // per chunk KT_C tiles of W1 (rows = 128) then 4 tiles of W2 (rows = C).  Tile f+1 is fetched into
+  // registers (unconditional, batched loads) while tile f multiplies, and committed to LDS after it.
+  constexpr int NWP = WROWS * 4 / 256;                  // 16-B pieces per thread per array
+  constexpr int SPC = KT_C + 4;                          // steps (tiles) per chunk
+  const int n_chunks = p.H / 128;
+  const int n_steps = n_chunks * SPC;
+  ml_u4 wrh[NWP], wrl[NWP];
+  auto tile_rows = [&](int f) __attribute__((always_inline)) { return (f % SPC) < KT_C ? 128 : C; };
+  auto fetch_w = [&](int f) __attribute__((always_inline)) {
+    const int fc = f < n_steps ? f : n_steps - 1;
+    const int ch = fc / SPC, r = fc - ch * SPC;
+    const bool g1 = r < KT_C;
+    const uint16_t* Wgh = g1 ? p.W1h : p.W2h;
+    const uint16_t* Wgl = g1 ? p.W1l : p.W2l;
+    const int rows = g1 ? 128 : C;
+    const long row0 = g1 ? (long)ch * 128 : 0, ld = g1 ? (long)C : (long)p.H;
+    const long k0 = g1 ? (long)r * 32 : (long)ch * 128 + (r - KT_C) * 32;
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+      const int idx = tid + i * 256;
+      const int idc = idx < rows * 4 ? idx : rows * 4 - 1;
+      const long o = (row0 + (idc >> 2)) * ld + k0 + (idc & 3) * 8;
+      wrh[i] = *(const ml_u4*)(Wgh + o);
+      if (three) wrl[i] = *(const ml_u4*)(Wgl + o);
     }
   };
+  auto commit_w = [&](int rows) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < rows * 4) {
+        const int off = ml_slot(idx >> 2, idx & 3);
+        *(ml_u4*)(Wh + off) = wrh[i];
+        if (three) *(ml_u4*)(Wl + off) = wrl[i];
+      }
+    }
+  };
+  fetch_w(0);
+  commit_w(tile_rows(0));
+  __syncthreads();                                        // X image and the first weight tile are in LDS
+  int f = 0;
 
-  const int n_chunks = p.H / 128;
   for (int ch = 0; ch < n_chunks; ++ch) {
     // ---------------- GEMM1: h = act(Xn . W1[ch*128 .. +128, :]^T + b1)
     f32x16 hacc[2];
@@ -170,9 +207,7 @@ __global__ void __launch_bounds__(256) mlp_fused_kernel(MlpArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) hacc[j][r] = 0.f;
     for (int kt = 0; kt < KT_C; ++kt) {
-      __syncthreads();                                    // previous users of W (and of H) are done
-      load_w(p.W1h, p.W1l, 128, (long)ch * 128, C, (long)kt * 32);
-      __syncthreads();
+      fetch_w(f + 1);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int kslot = s * 2 + lk;
@@ -192,6 +227,12 @@ __global__ void __launch_bounds__(256) mlp_fused_kernel(MlpArgs p) {
           hacc[j] = occf_mfma_bf16_32x32x16(ah, bh, hacc[j]);
         }
       }
+      if (kt + 1 < KT_C) {
+        __syncthreads();                                  // every wave is done with this weight tile
+        commit_w(tile_rows(f + 1));
+        __syncthreads();
+        ++f;
+      }
     }
     // epilogue 1: bias + activation, re-laid as the A operand of GEMM2 (row = token, k = hidden unit)
 #pragma unroll
@@ -209,11 +250,13 @@ __global__ void __launch_bounds__(256) mlp_fused_kernel(MlpArgs p) {
         if (three) *(uint16_t*)(Hl + off) = (uint16_t)ml_bf16_rne(v - ml_bf16_up(hb));
       }
     }
+    __syncthreads();                                      // last W1 tile consumed, h written
+    commit_w(tile_rows(f + 1));
+    __syncthreads();
+    ++f;
     // ---------------- GEMM2: acc += h . W2[:, ch*128 .. +128]^T
     for (int kt = 0; kt < 4; ++kt) {
-      __syncthreads();                                    // h complete / previous W tile consumed
-      load_w(p.W2h, p.W2l, C, 0, p.H, (long)ch * 128 + kt * 32);
-      __syncthreads();
+      fetch_w(f + 1);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int kslot = s * 2 + lk;
@@ -233,6 +276,10 @@ __global__ void __launch_bounds__(256) mlp_fused_kernel(MlpArgs p) {
           acc[j] = occf_mfma_bf16_32x32x16(ah, bh, acc[j]);
         }
       }
+      __syncthreads();                                    // every wave is done with this weight tile (and h)
+      commit_w(tile_rows(f + 1));
+      __syncthreads();
+      ++f;
     }
   }
 

@@ -106,6 +106,15 @@ extern "C" int occf_groupnorm_stats(const float* x, float* stats, float* workspa
   OCCF_LAUNCH_CHECK();
 }
 
+// finalize partial sums produced elsewhere (the convolution / GEMM epilogues): partial[B][nblk][G][2]
+extern "C" int occf_groupnorm_finalize(const float* partial, float* stats, int B, long nblk, int G, double count,
+                                       float eps, void* stream) {
+  if (B <= 0 || nblk <= 0 || nblk >= 2147483647L || G <= 0 || count <= 0) return OCCF_EINVAL;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(occf_cdiv((long)B * G * 64, 256)), dim3(256), 0, (hipStream_t)stream,
+                     partial, stats, (int)nblk, G, B * G, count, eps);
+  OCCF_LAUNCH_CHECK();
+}
+
 // GroupNorm apply.  x[B, P, Z, C] -> out[B, P, Zs, C] (Zs = Z, or Z + 1 in token mode where
 // slot Z receives the mean over Z of the normalised values = the BEV slice of the dual-path
 // block).  Optional ReLU and residual (same layout as x).  Thread = (b, p, channel quad).

@@ -113,7 +113,7 @@ class _AtrousGN(nn.Module):
         nn.init.kaiming_normal_(self.atrous_conv.weight)
 
     def forward(self, x_cl):
-        return fused.group_norm(fused.conv(x_cl, self.atrous_conv), self.bn, relu=True)
+        return fused.conv_gn(x_cl, self.atrous_conv, self.bn, relu=True)
 
 
 class _ASPP(nn.Module):
@@ -139,7 +139,7 @@ class _ASPP(nn.Module):
         g = F.relu(self.global_avg_pool[2](self.global_avg_pool[1](g.reshape(B, C, 1, 1))))
         g = g.view(B, 1, 1, 1, C).expand(B, X, Y, 1, C)
         y = torch.cat((self.aspp1(x_cl), self.aspp2(x_cl), self.aspp3(x_cl), self.aspp4(x_cl), g), -1)
-        y = fused.group_norm(fused.conv(y, self.conv1), self.bn1, relu=True, residual=x_cl)
+        y = fused.conv_gn(y, self.conv1, self.bn1, relu=True, residual=x_cl)
         return y                                   # = x + dropout(relu(gn(conv1(cat))))  (eval)
 
 
@@ -161,10 +161,9 @@ class BottleNeckASPP(nn.Module):
     def forward(self, x_cl):
         """x_cl [B, X, Y, 1, C] (any row stride) -> contiguous [B, X, Y, 1, C]."""
         fused.require_eval(self)
-        y = fused.group_norm(fused.conv(x_cl, self.input_conv[0]), self.input_conv[1], relu=True)
+        y = fused.conv_gn(x_cl, self.input_conv[0], self.input_conv[1], relu=True)
         y = self.aspp(y)
-        return fused.group_norm(fused.conv(y, self.output_conv[0]), self.output_conv[1], relu=True,
-                                residual=x_cl.contiguous())
+        return fused.conv_gn(y, self.output_conv[0], self.output_conv[1], relu=True, residual=x_cl.contiguous())
 
 
 # ------------------------------------------------------------------ the block and the encoder
@@ -196,13 +195,13 @@ class DualpathTransformerBlock(nn.Module):
             raise NotImplementedError("the HIP path implements the GroupNorm blocks of the OccFormer configs")
         ops = get_ops()
         x_cl = fused.channels_last_view(x.float())
-        raw = fused.conv(x_cl, self.input_conv[0])                                  # 3^3 implicit GEMM
-        tok = fused.group_norm(raw, self.input_conv[1], relu=True, tokens=True)     # [B,X,Y,Z+1,C]
+        # 3^3 conv (its epilogue also yields the GroupNorm statistics) -> GN + ReLU -> token buffer [B,X,Y,Z+1,C]
+        tok = fused.conv_gn(x_cl, self.input_conv[0], self.input_conv[1], relu=True, tokens=True)
         Z = tok.shape[3] - 1
         tok = self.bev_encoder(tok)
         bev = self.aspp(tok[:, :, :, Z:Z + 1])                                      # [B,X,Y,1,C]
         if self.stride > 1:
-            ident = fused.group_norm(fused.conv(x_cl, self.downsample[0]), self.downsample[1])
+            ident = fused.conv_gn(x_cl, self.downsample[0], self.downsample[1])
         else:
             ident = x_cl
         cw = self.combine_coeff

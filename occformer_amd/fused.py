@@ -59,8 +59,10 @@ def layernorm(x, ln):
     return get_ops().layernorm(x, ln.weight.detach(), ln.bias.detach(), ln.eps)
 
 
-def conv(x_cl, conv, act=0):
-    """nn.Conv3d / nn.Conv2d module applied to a channels-last [B, X, Y, Z, C] tensor."""
+def conv(x_cl, conv, act=0, gn=None):
+    """nn.Conv3d / nn.Conv2d module applied to a channels-last [B, X, Y, Z, C] tensor.  ``gn``: the
+    nn.GroupNorm that follows -- its statistics are then taken from the epilogue of the convolution
+    (``get_ops().last_gn_stats``) when the kernel supports it."""
     ks = tuple(conv.kernel_size) + (1,) * (3 - len(conv.kernel_size))
     pad = tuple(conv.padding) + (0,) * (3 - len(conv.padding))
     stride = conv.stride[0]
@@ -68,16 +70,27 @@ def conv(x_cl, conv, act=0):
     assert all(s == stride for s in conv.stride) and all(d == dil for d in conv.dilation) and conv.groups == 1
     bias = None if conv.bias is None else conv.bias.detach()
     if ks == (1, 1, 1) and stride == 1 and x_cl.is_contiguous():
+        rows = x_cl.numel() // (x_cl.shape[0] * x_cl.shape[-1])
         return get_ops().linear(x_cl, conv.weight.detach().reshape(conv.out_channels, -1), bias, act,
-                                w_split=split_weight(conv.weight, lambda w: w.reshape(w.shape[0], -1)))
+                                w_split=split_weight(conv.weight, lambda w: w.reshape(w.shape[0], -1)),
+                                gn=None if gn is None else (gn.num_groups, gn.eps, rows))
     return get_ops().conv3d(x_cl, tap_major(conv), ks, stride, dil, pad, bias, act,
-                            w_split=split_weight(conv.weight, _tap_layout))
+                            w_split=split_weight(conv.weight, _tap_layout),
+                            gn=None if gn is None else (gn.num_groups, gn.eps))
 
 
-def group_norm(x_cl, gn, relu=False, tokens=False, residual=None):
+def conv_gn(x_cl, conv_mod, gn, relu=False, tokens=False, residual=None):
+    """conv -> GroupNorm (-> ReLU / token buffer / + residual) with the statistics from the conv epilogue"""
+    ops = get_ops()
+    y = conv(x_cl, conv_mod, gn=gn)
+    return group_norm(y, gn, relu, tokens, residual, stats=ops.last_gn_stats)
+
+
+def group_norm(x_cl, gn, relu=False, tokens=False, residual=None, stats=None):
     """nn.GroupNorm module on a contiguous channels-last tensor [B, ..., Z, C]."""
     ops = get_ops()
-    stats = ops.groupnorm_stats(x_cl, gn.num_groups, gn.eps)
+    if stats is None:
+        stats = ops.groupnorm_stats(x_cl, gn.num_groups, gn.eps)
     return ops.groupnorm_apply(x_cl, stats, gn.weight.detach(), gn.bias.detach(), gn.num_groups, relu, tokens,
                                residual)
 

@@ -168,7 +168,7 @@ class _ConvModule(nn.Module):
 
     def forward(self, x_cl):
         """channels-last [B, X, Y, Z, Cin] -> contiguous [B, X, Y, Z, Cout]"""
-        return fused.group_norm(fused.conv(x_cl, self.conv), self.gn, relu=self.act)
+        return fused.conv_gn(x_cl, self.conv, self.gn, relu=self.act)
 
 
 @NECKS.register_module()

@@ -231,7 +231,7 @@ def test_conv3x3x3_halo(be, monkeypatch, shape, cin, cout, prec, tol):
     import ctypes
     rc = orig(ctypes.c_void_p(xs.data_ptr()), ctypes.c_void_p(sp[0].data_ptr()), ctypes.c_void_p(sp[1].data_ptr()),
               None, None, ctypes.c_void_p(o2.data_ptr()), B, X, Y, Z, cin, cout, xs.stride(0), xs.stride(1),
-              xs.stride(2), xs.stride(3), 0, 3 if prec == "bf16x3" else 1, None)
+              xs.stride(2), xs.stride(3), 0, 3 if prec == "bf16x3" else 1, None, 0, None)
     assert rc == 0
 
 
@@ -273,3 +273,31 @@ def test_linear_head_major_output(be):
     out = ops.linear(xd, wd, bd, w_split=ops.split_bf16(wd), head_major=(Nq, E // H)).cpu()
     ref = torch.nn.functional.linear(x, w, b).view(B, Nq, H, E // H).permute(0, 2, 1, 3)
     assert out.shape == ref.shape and torch.allclose(out, ref, atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("kind", ["halo", "strided", "linear"])
+def test_groupnorm_stats_from_conv_epilogue(be, kind):
+    """the GroupNorm statistics emitted by the conv / GEMM epilogues equal groupnorm_stats of the output"""
+    ops = be.ops
+    if ops.precision == "f32":
+        pytest.skip("epilogue statistics live in the bf16 GEMM kernels")
+    G = 8
+    if kind == "linear":
+        B, V, cin, cout = 2, 256, 32, 64
+        x = paramgen.tensor("gx", (B, V, cin), 1)
+        w = paramgen.tensor("gw", (cout, cin), 2, cin ** -0.5)
+        xd, wd = be.to(x, w)
+        y = ops.linear(xd, wd, None, w_split=ops.split_bf16(wd), gn=(G, 1e-5, V))
+    else:
+        B, cin, cout = 2, 32, 64
+        X, Y, Z = (4, 16, 8) if kind == "halo" else (8, 16, 8)
+        x = paramgen.tensor("gx", (B, X, Y, Z, cin), 1)
+        w = paramgen.tensor("gw", (cout, cin, 3, 3, 3), 2, (cin * 27) ** -0.5)
+        wt = conv_weight_tapmajor(w)
+        xd, wd = be.to(x, wt)
+        y = ops.conv3d(xd, wd, (3, 3, 3), stride=1 if kind == "halo" else 2, pad=(1, 1, 1),
+                       w_split=ops.split_bf16(wd), gn=(G, 1e-5))
+    st = ops.last_gn_stats
+    assert st is not None, "the epilogue path was not taken"
+    ref = ops.groupnorm_stats(y.contiguous(), G, 1e-5)
+    assert torch.allclose(st.cpu(), ref.cpu(), rtol=2e-5, atol=2e-6)
