@@ -180,9 +180,9 @@ int occf_mlp_fused_fwd(const float* x, const float* ln_gamma, const float* ln_be
 long occf_groupnorm_workspace(int B, long V, int C, int G);
 int occf_groupnorm_stats(const float* x, float* stats, float* workspace, int B, long V, int C, int G,
                          float eps, void* stream);
-/* second stage alone, for partial sums written by a convolution / GEMM epilogue:
- * partial[B][nblk][G][2] -> stats[B, G, 2]; count = elements per (batch, group) = V * C / G. */
-int occf_groupnorm_finalize(const float* partial, float* stats, int B, long nblk, int G, double count,
+/* second stage alone, for the per-channel partial sums written by a convolution / GEMM epilogue:
+ * partial[B][nblk][C][2] -> stats[B, G, 2]; count = elements per (batch, group) = V * C / G. */
+int occf_groupnorm_finalize(const float* partial, float* stats, int B, long nblk, int C, int G, double count,
                             float eps, void* stream);
 /* y = (x - mean) * rstd * gamma + beta [ReLU] [+ residual];  x[B, P, Z, C] -> out[B, P, Zs, C].
  * tokens = 1: Zs = Z + 1 and slot Z = mean_z(y): builds the dual-path token buffer (the Z height
@@ -219,20 +219,19 @@ int occf_upsample_add(const float* coarse, const float* lateral, float* out, int
  * n % out_head_dim] with row m = b * out_head_rows + q -- the layout occf_msda3d_fwd gathers from
  * (value_head_major), produced by the projection itself instead of a transposing copy; ldo is ignored,
  * N % out_head_dim == 0, out_head_dim % 4 == 0, no residual.
- * gn_partial != NULL: the epilogue also emits GroupNorm partial sums of the stored outputs,
- * gn_partial[b][M-tile][gn_groups][2] (sum, sum of squares; M-tile = 128 rows, gn_rows = rows per batch
- * element, a multiple of 128), to be reduced by occf_groupnorm_finalize -- the statistics pass over the
+ * gn_partial != NULL: the epilogue also emits per-column partial sums of the stored outputs,
+ * gn_partial[M-tile][N][2] (sum, sum of squares; M-tile = 128 rows; a batch element must consist of whole
+ * tiles, or B = 1), to be reduced by occf_groupnorm_finalize -- the GroupNorm statistics pass over the
  * convolution output (one full read of the tensor) disappears.  No split-K in that case. */
 int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
                          const float* residual, float* out, long M, int N, int K, long ldx, long ldo,
                          long ldr, int act, int terms, float* workspace, long workspace_floats,
-                         int out_head_dim, long out_head_rows, float* gn_partial, int gn_groups, long gn_rows,
-                         void* stream);
+                         int out_head_dim, long out_head_rows, float* gn_partial, void* stream);
 int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
                          const float* residual, float* out, int B, int Xi, int Yi, int Zi, int Cin, int Cout,
                          int kX, int kY, int kZ, int stride, int dil, int pad_x, int pad_y, int pad_z,
                          long in_sb, long in_sx, long in_sy, long in_sz, int act, int terms, float* workspace,
-                         long workspace_floats, float* gn_partial, int gn_groups, void* stream);
+                         long workspace_floats, float* gn_partial, void* stream);
 /* Small-M problems (few output tiles, long K: the coarse encoder stages) are split along K over
  * blockIdx.y into partial slabs and reduced in fixed order; workspace (may be NULL = never split)
  * needs occf_gemm_bf16_workspace(M, N, K) floats (0 = this shape is not split). */
@@ -248,9 +247,9 @@ int occf_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, long n, void* st
 int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
                             const float* residual, float* out, int B, int X, int Y, int Z, int Cin, int Cout,
                             long in_sb, long in_sx, long in_sy, long in_sz, int act, int terms, float* gn_partial,
-                            int gn_groups, void* stream);
-/* gn_partial (both convolutions): like occf_linear_bf16_fwd -- [B][tiles per batch element][gn_groups][2];
- * tiles per batch element = Xo*Yo*Zo / 128 for occf_conv3d_bf16_fwd (must divide) and
+                            void* stream);
+/* gn_partial (both convolutions): like occf_linear_bf16_fwd -- [B][tiles per batch element][Cout][2];
+ * tiles per batch element = ceil(Xo*Yo*Zo / 128) for occf_conv3d_bf16_fwd (must divide unless B = 1) and
  * occf_conv3x3x3_halo_gn_blocks(X, Y, Z) for the halo kernel (-1: shape not taken). */
 long occf_conv3x3x3_halo_gn_blocks(int X, int Y, int Z);
 

@@ -28,8 +28,7 @@ struct ConvHaloArgs {
   int TY, TZ;                 // TY * TZ == 128, TZ | Z
   long sb, sx, sy, sz;        // input element strides (channel stride 1)
   int act;
-  float* gn_partial;          // optional [B][spatial tiles][G][2]: sum / sum of squares of the outputs
-  int gn_G;
+  float* gn_partial;          // optional [B][spatial tiles][Cout][2]: per-channel sum / sum of squares of the outputs
 };
 
 __device__ __forceinline__ uint32_t ch_bf16_rne(float x) {
@@ -314,21 +313,12 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
       }
     }
     __syncthreads();
-    float* csum = red + 8 * BN;
-    if (tid < BN) {
+    if (tid < BN && n0 + tid < p.Cout) {
       float a = 0.f, q = 0.f;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
-      csum[tid * 2] = a;
-      csum[tid * 2 + 1] = q;
-    }
-    __syncthreads();
-    const int cg = p.Cout / p.gn_G;
-    if (tid < BN / cg && n0 + tid * cg < p.Cout) {
-      float a = 0.f, q = 0.f;
-      for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += csum[c * 2]; q += csum[c * 2 + 1]; }
       const long sp = ((long)(tx0 >> 1) * yt + ty0 / TY) * zt + tz0 / TZ;
-      float* o = p.gn_partial + ((((long)b * xt * yt * zt) + sp) * p.gn_G + (n0 / cg + tid)) * 2;
+      float* o = p.gn_partial + ((((long)b * xt * yt * zt) + sp) * p.Cout + n0 + tid) * 2;
       o[0] = a;
       o[1] = q;
     }
@@ -352,8 +342,7 @@ static int launch_conv_halo(const ConvHaloArgs& a, int terms, unsigned grid, siz
 extern "C" int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
                                        const float* bias, const float* residual, float* out, int B, int X,
                                        int Y, int Z, int Cin, int Cout, long in_sb, long in_sx, long in_sy,
-                                       long in_sz, int act, int terms, float* gn_partial, int gn_groups,
-                                       void* stream) {
+                                       long in_sz, int act, int terms, float* gn_partial, void* stream) {
   if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || Cin % 32 != 0 || Cout <= 0) return OCCF_ESHAPE;
   if (terms != 1 && terms != 3) return OCCF_EINVAL;
   if (terms == 3 && w_lo == nullptr) return OCCF_EINVAL;
@@ -375,10 +364,7 @@ extern "C" int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, con
   a.x = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.out = out;
   a.B = B; a.X = X; a.Y = Y; a.Z = Z; a.Cin = Cin; a.Cout = Cout; a.TY = TY; a.TZ = TZ;
   a.sb = in_sb; a.sx = in_sx; a.sy = in_sy; a.sz = in_sz; a.act = act;
-  if (gn_partial) {
-    if (gn_groups <= 0 || Cout % gn_groups || (64 * TN) % (Cout / gn_groups)) return OCCF_ESHAPE;
-    a.gn_partial = gn_partial; a.gn_G = gn_groups;
-  }
+  a.gn_partial = gn_partial;
   const long blocks = (long)B * ((X + 1) / 2) * ((Y + TY - 1) / TY) * (Z / TZ) * ((Cout + 64 * TN - 1) / (64 * TN));
   if (blocks >= 2147483647L) return OCCF_ESHAPE;
 #ifndef OCCF_EMU

@@ -47,9 +47,7 @@ struct GemmArgsB {
   float* slab;         // [ksplit][M][N]
   int hm_dh;           // > 0: head-major output [b, n / hm_dh, q, n % hm_dh], row m = b * hm_rows + q
   long hm_rows;
-  float* gn_partial;   // optional [B][M-tiles per batch][G][2]: sum / sum of squares of the stored outputs
-  int gn_G;
-  long gn_rows;        // rows (voxels) per batch element, a multiple of 128
+  float* gn_partial;   // optional [M-tiles][N][2]: per-column sum / sum of squares of the stored outputs
   ConvGeomB g;
 };
 
@@ -387,23 +385,11 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
       red[((row0 * BN) + c4 + e) * 2 + 1] = gsq[e];
     }
     __syncthreads();
-    float* csum = red + RG * BN * 2;
-    if (tid < BN) {
+    if (tid < BN && n0 + tid < p.N) {
       float a = 0.f, q = 0.f;
 #pragma unroll
       for (int w = 0; w < RG; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
-      csum[tid * 2] = a;
-      csum[tid * 2 + 1] = q;
-    }
-    __syncthreads();
-    const int cg = p.N / p.gn_G;
-    if (tid < BN / cg && n0 + tid * cg < p.N) {
-      float a = 0.f, q = 0.f;
-      for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a += csum[c * 2]; q += csum[c * 2 + 1]; }
-      const long tiles_pb = p.gn_rows / GB_BM;
-      const long tile = m0 / GB_BM;                         // = b * tiles_pb + tile within the batch element
-      float* o = p.gn_partial + (tile * p.gn_G + (n0 / cg + tid)) * 2;
-      (void)tiles_pb;
+      float* o = p.gn_partial + ((m0 / GB_BM) * p.N + n0 + tid) * 2;   // tile = b * tiles_per_batch + tile in b
       o[0] = a;
       o[1] = q;
     }
@@ -448,12 +434,7 @@ static int launch_gemm_b(GemmArgsB a, int terms, float* workspace, long workspac
   const int mt = occf_cdiv(a.M, GB_BM);
   const bool wide = (a.N % 128 == 0) || a.N > 512;
   a.ksplit = (workspace && a.hm_dh == 0 && !a.gn_partial) ? occf_pick_ksplit(a.M, a.N, a.K, wide, workspace_floats) : 1;
-  if (a.gn_partial) {
-    const int bn = wide ? 128 : 64;
-    if (a.gn_G <= 0 || a.N % a.gn_G || bn % (a.N / a.gn_G) || a.N % 4 || a.ldc % 4 || a.gn_rows <= 0 ||
-        a.gn_rows % GB_BM || a.M % a.gn_rows)
-      return OCCF_ESHAPE;
-  }
+  if (a.gn_partial && (a.N % 4 || a.ldc % 4)) return OCCF_ESHAPE;
   a.slab = workspace;
   const dim3 grid((unsigned)((long)mt * occf_cdiv(a.N, wide ? 128 : 64)), a.ksplit);
   const bool sp = a.ksplit > 1;
@@ -503,7 +484,7 @@ extern "C" int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const 
                                     const float* bias, const float* residual, float* out, long M, int N,
                                     int K, long ldx, long ldo, long ldr, int act, int terms, float* workspace,
                                     long workspace_floats, int out_head_dim, long out_head_rows, float* gn_partial,
-                                    int gn_groups, long gn_rows, void* stream) {
+                                    void* stream) {
   if (M >= 2147483647L || ldx % 4 != 0) return OCCF_ESHAPE;
   if (out_head_dim > 0 && (N % out_head_dim || out_head_dim % 4 || N % 4 || residual || out_head_rows <= 0 ||
                            M % out_head_rows))
@@ -512,7 +493,7 @@ extern "C" int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const 
   a.A = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.C = out;
   a.M = (int)M; a.N = N; a.K = K; a.lda = ldx; a.ldc = out_head_dim > 0 ? 4 : ldo; a.ldr = ldr; a.act = act;
   a.hm_dh = out_head_dim > 0 ? out_head_dim : 0; a.hm_rows = out_head_rows;
-  a.gn_partial = gn_partial; a.gn_G = gn_groups; a.gn_rows = gn_rows;
+  a.gn_partial = gn_partial;
   return launch_gemm_b<false>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
 }
 
@@ -521,7 +502,7 @@ extern "C" int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const 
                                     int Yi, int Zi, int Cin, int Cout, int kX, int kY, int kZ, int stride,
                                     int dil, int pad_x, int pad_y, int pad_z, long in_sb, long in_sx,
                                     long in_sy, long in_sz, int act, int terms, float* workspace,
-                                    long workspace_floats, float* gn_partial, int gn_groups, void* stream) {
+                                    long workspace_floats, float* gn_partial, void* stream) {
   if (B <= 0 || Cin % GB_BK != 0 || stride <= 0 || dil <= 0) return OCCF_ESHAPE;
   if (in_sb % 4 || in_sx % 4 || in_sy % 4 || in_sz % 4) return OCCF_ESHAPE;
   GemmArgsB a = {};
@@ -536,7 +517,7 @@ extern "C" int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const 
   if (g.Xo <= 0 || g.Yo <= 0 || g.Zo <= 0 || M >= 2147483647L) return OCCF_ESHAPE;
   a.A = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.C = out;
   a.M = (int)M; a.N = Cout; a.K = kX * kY * kZ * Cin; a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.act = act;
-  a.gn_partial = gn_partial; a.gn_G = gn_groups; a.gn_rows = (long)g.Xo * g.Yo * g.Zo;
+  a.gn_partial = gn_partial;
   return launch_gemm_b<true>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
 }
 

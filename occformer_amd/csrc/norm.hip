@@ -106,12 +106,42 @@ extern "C" int occf_groupnorm_stats(const float* x, float* stats, float* workspa
   OCCF_LAUNCH_CHECK();
 }
 
-// finalize partial sums produced elsewhere (the convolution / GEMM epilogues): partial[B][nblk][G][2]
-extern "C" int occf_groupnorm_finalize(const float* partial, float* stats, int B, long nblk, int G, double count,
-                                       float eps, void* stream) {
-  if (B <= 0 || nblk <= 0 || nblk >= 2147483647L || G <= 0 || count <= 0) return OCCF_EINVAL;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(occf_cdiv((long)B * G * 64, 256)), dim3(256), 0, (hipStream_t)stream,
-                     partial, stats, (int)nblk, G, B * G, count, eps);
+// Second stage for per-CHANNEL partial sums written by the convolution / GEMM epilogues:
+// partial[B][nblk][C][2] -> stats[B][G][2].  One wave per (batch, group); lanes stride over the tiles.
+__global__ void __launch_bounds__(256) gn_finalize_channels_kernel(const float* __restrict__ partial,
+                                                                   float* __restrict__ stats, long nblk, int C, int G,
+                                                                   int BG, double count, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int bg = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (bg >= BG) return;
+  const int b = bg / G, g = bg % G, cg = C / G;
+  double s = 0.0, q = 0.0;
+  for (long k = lane; k < nblk; k += 64) {
+    const float* p = partial + (((long)b * nblk + k) * C + (long)g * cg) * 2;
+    for (int c = 0; c < cg; ++c) {
+      s += (double)p[c * 2];
+      q += (double)p[c * 2 + 1];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+  if (lane == 0) {
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(long)bg * 2 + 0] = (float)mean;
+    stats[(long)bg * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+extern "C" int occf_groupnorm_finalize(const float* partial, float* stats, int B, long nblk, int C, int G,
+                                       double count, float eps, void* stream) {
+  if (B <= 0 || nblk <= 0 || G <= 0 || C % G != 0 || count <= 0) return OCCF_EINVAL;
+  hipLaunchKernelGGL(gn_finalize_channels_kernel, dim3(occf_cdiv((long)B * G * 64, 256)), dim3(256), 0,
+                     (hipStream_t)stream, partial, stats, nblk, C, G, B * G, count, eps);
   OCCF_LAUNCH_CHECK();
 }
 

@@ -86,6 +86,41 @@ def conv_gn(x_cl, conv_mod, gn, relu=False, tokens=False, residual=None):
     return group_norm(y, gn, relu, tokens, residual, stats=ops.last_gn_stats)
 
 
+_FOLD_CACHE = {}
+
+
+def conv_bn(x_cl, conv_mod, bn=None, act=0, residual=None):
+    """nn.Conv2d/3d (+ eval-mode BatchNorm folded into weight and bias) on channels-last [B, X, Y, Z, C]:
+    y = act(conv'(x) + b') [+ residual], W' = W * gamma / sqrt(var + eps), b' = beta + (b - mean) * gamma / sqrt(..)."""
+    ops = get_ops()
+    w = conv_mod.weight
+    deps = [w] + ([] if conv_mod.bias is None else [conv_mod.bias]) + \
+        ([] if bn is None else [bn.weight, bn.bias, bn.running_mean, bn.running_var])
+    ver = tuple((t._version, t.data_ptr()) for t in deps) + (ops.precision, id(ops))
+    hit = _FOLD_CACHE.get(id(w))
+    if hit is None or hit[0] != ver or hit[2]() is not w:
+        with torch.no_grad():
+            wt = _tap_layout(w.detach()).float()
+            b = None if conv_mod.bias is None else conv_mod.bias.detach().float()
+            if bn is not None:
+                if bn.training:
+                    raise NotImplementedError("BatchNorm folding is the inference path; call .eval()")
+                sc = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+                wt = (wt * sc[:, None]).contiguous()
+                b = bn.bias.detach() - bn.running_mean.detach() * sc + (0 if b is None else b * sc)
+            split = None if ops.precision == "f32" else ops.split_bf16(wt)
+        hit = (ver, (wt, None if b is None else b.contiguous(), split), weakref.ref(w))
+        _FOLD_CACHE[id(w)] = hit
+    wt, b, split = hit[1]
+    ks = tuple(conv_mod.kernel_size) + (1,) * (3 - len(conv_mod.kernel_size))
+    pad = tuple(conv_mod.padding) + (0,) * (3 - len(conv_mod.padding))
+    stride, dil = conv_mod.stride[0], conv_mod.dilation[0]
+    assert all(v == stride for v in conv_mod.stride) and all(d == dil for d in conv_mod.dilation) and conv_mod.groups == 1
+    if ks == (1, 1, 1) and stride == 1 and x_cl.is_contiguous():
+        return ops.linear(x_cl, wt, b, act, residual, w_split=split)
+    return ops.conv3d(x_cl, wt, ks, stride, dil, pad, b, act, residual, w_split=split)
+
+
 def group_norm(x_cl, gn, relu=False, tokens=False, residual=None, stats=None):
     """nn.GroupNorm module on a contiguous channels-last tensor [B, ..., Z, C]."""
     ops = get_ops()

@@ -226,9 +226,9 @@ class HipOps:
         """can ``linear(..., head_major=(rows, dh))`` be used for this shape / precision mode"""
         return self.precision != "f32" and K % 32 == 0 and max(M, N) >= 64 and dh % 4 == 0 and N % dh == 0
 
-    def _gn_finalize(self, partial, B, nblk, G, count, eps):
+    def _gn_finalize(self, partial, B, nblk, C, G, count, eps):
         stats = torch.empty((B, G, 2), dtype=self.f32, device=partial.device)
-        self._call("occf_groupnorm_finalize", self._ptr(partial), self._ptr(stats), B, nblk, G, float(count),
+        self._call("occf_groupnorm_finalize", self._ptr(partial), self._ptr(stats), B, nblk, C, G, float(count),
                    float(eps), self._stream())
         return stats
 
@@ -266,21 +266,20 @@ class HipOps:
             self._call("occf_linear_bf16_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(w_split[0]),
                        self._ptr(w_split[1]), self._ptr(bias), ctypes.c_void_p(0), ctypes.c_void_p(out.data_ptr()),
                        M, N, K, x2.stride(0), N, 0, int(act), terms, ctypes.c_void_p(0), 0, int(dh), int(rows),
-                       ctypes.c_void_p(0), 0, 0, self._stream())
+                       ctypes.c_void_p(0), self._stream())
             return out.view(M // rows, N // dh, rows, dh)
         if terms:
             if gn is not None and residual is None and act == 0:
                 G, eps, rows = gn
-                if rows % 128 == 0 and M % rows == 0 and N % G == 0:
-                    nblk = rows // 128
-                    part = torch.empty((M // rows * nblk * G * 2,), dtype=self.f32, device=x.device)
+                if (rows % 128 == 0 or M == rows) and M % rows == 0 and N % G == 0:
+                    nblk = (rows + 127) // 128
+                    part = torch.empty((M // rows * nblk * N * 2,), dtype=self.f32, device=x.device)
                     rc = self.lib.occf_linear_bf16_fwd(
                         ctypes.c_void_p(x2.data_ptr()), self._ptr(w_split[0]), self._ptr(w_split[1]),
                         self._ptr(bias), rp, ctypes.c_void_p(out.data_ptr()), M, N, K, x2.stride(0), out.stride(0),
-                        0, int(act), terms, ctypes.c_void_p(0), 0, 0, 0, self._ptr(part), int(G), int(rows),
-                        self._stream())
+                        0, int(act), terms, ctypes.c_void_p(0), 0, 0, 0, self._ptr(part), self._stream())
                     if rc == 0:
-                        self.last_gn_stats = self._gn_finalize(part, M // rows, nblk, G, rows * (N // G), eps)
+                        self.last_gn_stats = self._gn_finalize(part, M // rows, nblk, N, G, rows * (N // G), eps)
                         return out.view(*x.shape[:-1], N)
                     if rc != -2:
                         raise OccfError(f"occf_linear_bf16_fwd failed with code {rc}")
@@ -288,7 +287,7 @@ class HipOps:
             self._call("occf_linear_bf16_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(w_split[0]),
                        self._ptr(w_split[1]), self._ptr(bias), rp, ctypes.c_void_p(out.data_ptr()), M, N, K,
                        x2.stride(0), out.stride(0), r2.stride(0) if r2 is not None else 0, int(act), terms,
-                       self._ptr(ws), nws, 0, 0, ctypes.c_void_p(0), 0, 0, self._stream())
+                       self._ptr(ws), nws, 0, 0, ctypes.c_void_p(0), self._stream())
         else:
             self._call("occf_linear_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(weight, self.f32),
                        self._ptr(bias), rp, ctypes.c_void_p(out.data_ptr()), M, N, K, x2.stride(0),
@@ -326,35 +325,36 @@ class HipOps:
             if want_gn:
                 nblk = self.lib.occf_conv3x3x3_halo_gn_blocks(Xi, Yi, Zi)
                 if nblk > 0 and Cout % gn[0] == 0:
-                    part = torch.empty((B * nblk * gn[0] * 2,), dtype=self.f32, device=x_cl.device)
-                    rc = self.lib.occf_conv3x3x3_halo_fwd(*halo_args, self._ptr(part), int(gn[0]), self._stream())
+                    part = torch.empty((B * nblk * Cout * 2,), dtype=self.f32, device=x_cl.device)
+                    rc = self.lib.occf_conv3x3x3_halo_fwd(*halo_args, self._ptr(part), self._stream())
                     if rc == 0:
-                        self.last_gn_stats = self._gn_finalize(part, B, nblk, gn[0],
+                        self.last_gn_stats = self._gn_finalize(part, B, nblk, Cout, gn[0],
                                                                Xo * Yo * Zo * (Cout // gn[0]), gn[1])
                         return out
             if rc == -2:
-                rc = self.lib.occf_conv3x3x3_halo_fwd(*halo_args, ctypes.c_void_p(0), 0, self._stream())
+                rc = self.lib.occf_conv3x3x3_halo_fwd(*halo_args, ctypes.c_void_p(0), self._stream())
             if rc == 0:
                 return out
             if rc != -2:                     # -2 = shape outside the halo kernel's envelope
                 raise OccfError(f"occf_conv3x3x3_halo_fwd failed with code {rc}")
         if terms:
             V = Xo * Yo * Zo
-            if want_gn and V % 128 == 0 and Cout % gn[0] == 0:
-                part = torch.empty((B * (V // 128) * gn[0] * 2,), dtype=self.f32, device=x_cl.device)
+            if want_gn and (V % 128 == 0 or B == 1) and Cout % gn[0] == 0:
+                nblk = (V + 127) // 128
+                part = torch.empty((B * nblk * Cout * 2,), dtype=self.f32, device=x_cl.device)
                 rc = self.lib.occf_conv3d_bf16_fwd(
                     ctypes.c_void_p(x_cl.data_ptr()), self._ptr(w_split[0]), self._ptr(w_split[1]), self._ptr(bias),
                     self._ptr(residual), self._ptr(out), *geom, terms, ctypes.c_void_p(0), 0, self._ptr(part),
-                    int(gn[0]), self._stream())
+                    self._stream())
                 if rc == 0:
-                    self.last_gn_stats = self._gn_finalize(part, B, V // 128, gn[0], V * (Cout // gn[0]), gn[1])
+                    self.last_gn_stats = self._gn_finalize(part, B, nblk, Cout, gn[0], V * (Cout // gn[0]), gn[1])
                     return out
                 if rc != -2:
                     raise OccfError(f"occf_conv3d_bf16_fwd failed with code {rc}")
             ws, nws = self._splitk_workspace(B * Xo * Yo * Zo, Cout, kX * kY * kZ * Cin, x_cl.device)
             self._call("occf_conv3d_bf16_fwd", ctypes.c_void_p(x_cl.data_ptr()), self._ptr(w_split[0]),
                        self._ptr(w_split[1]), self._ptr(bias), self._ptr(residual), self._ptr(out), *geom, terms,
-                       self._ptr(ws), nws, ctypes.c_void_p(0), 0, self._stream())
+                       self._ptr(ws), nws, ctypes.c_void_p(0), self._stream())
         else:
             self._call("occf_conv3d_fwd", ctypes.c_void_p(x_cl.data_ptr()), self._ptr(weight_tap, self.f32),
                        self._ptr(bias), self._ptr(residual), self._ptr(out), *geom, self._stream())

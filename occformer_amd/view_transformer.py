@@ -85,6 +85,12 @@ class _BasicBlock(nn.Module):
         y = F.relu(self.bn1(self.conv1(x)))
         return F.relu(self.bn2(self.conv2(y)) + x)
 
+    def forward_cl(self, x_cl):
+        """channels-last [BN, H, W, 1, C]; BatchNorms folded into the convolutions"""
+        from . import fused
+        y = fused.conv_bn(x_cl, self.conv1, self.bn1, act=1)
+        return fused.conv_bn(y, self.conv2, self.bn2, act=0, residual=x_cl).relu_()
+
 
 class _AtrousBranch(nn.Module):
     def __init__(self, cin, cout, k, dil):
@@ -94,6 +100,10 @@ class _AtrousBranch(nn.Module):
 
     def forward(self, x):
         return F.relu(self.bn(self.atrous_conv(x)))
+
+    def forward_cl(self, x_cl):
+        from . import fused
+        return fused.conv_bn(x_cl, self.atrous_conv, self.bn, act=1)
 
 
 class _ImageASPP(nn.Module):
@@ -116,6 +126,17 @@ class _ImageASPP(nn.Module):
         y = torch.cat((self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), g), 1)
         return self.dropout(F.relu(self.bn1(self.conv1(y))))
 
+    def forward_cl(self, x_cl):
+        """channels-last [BN, H, W, 1, C] (eval: dropout is the identity)"""
+        from . import fused
+        BN_, H, W, _, C = x_cl.shape
+        g = x_cl.mean((1, 2, 3)).view(BN_, C, 1, 1)                       # AdaptiveAvgPool2d((1, 1))
+        g = self.global_avg_pool[3](self.global_avg_pool[2](self.global_avg_pool[1](g)))   # [BN, mid, 1, 1]
+        g = g.view(BN_, 1, 1, 1, -1).expand(BN_, H, W, 1, -1)
+        y = torch.cat((self.aspp1.forward_cl(x_cl), self.aspp2.forward_cl(x_cl), self.aspp3.forward_cl(x_cl),
+                       self.aspp4.forward_cl(x_cl), g), -1)
+        return fused.conv_bn(y, self.conv1, self.bn1, act=1)
+
 
 class _CamMlp(nn.Module):
     def __init__(self, cin, hidden, cout):
@@ -135,6 +156,11 @@ class _SE(nn.Module):
 
     def forward(self, x, x_se):
         return x * torch.sigmoid(self.conv_expand(F.relu(self.conv_reduce(x_se))))
+
+    def forward_cl(self, x_cl, x_se):
+        """x_cl [BN, H, W, 1, C]; x_se [BN, C, 1, 1] (the gate is a per-camera channel vector)"""
+        gate = torch.sigmoid(self.conv_expand(F.relu(self.conv_reduce(x_se))))
+        return x_cl * gate.view(gate.shape[0], 1, 1, 1, -1)
 
 
 class DeformConv2dPack(nn.Module):
@@ -174,6 +200,20 @@ class DeformConv2dPack(nn.Module):
                        out=out[:, g * (Cout // G):(g + 1) * (Cout // G)])
         return out.view(B, H, W, Cout).permute(0, 3, 1, 2)
 
+    def forward_cl(self, x_cl):
+        """channels-last [BN, H, W, 1, C] -> [BN, H, W, 1, Cout]; conv_offset runs on the implicit-GEMM kernel"""
+        from . import fused
+        ops = get_ops()
+        B, H, W, _, C = x_cl.shape
+        k, pad, G = self.k, self.padding, self.groups
+        offset = fused.conv_bn(x_cl, self.conv_offset).view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+        col = ops.deform_im2col(x_cl.reshape(B, H, W, C), offset, k, 1, pad, 1, G, self.deform_groups)
+        Cout = self.weight.shape[0]
+        out = torch.empty((B * H * W, Cout), dtype=x_cl.dtype, device=x_cl.device)
+        for g, wg in enumerate(self._group_weights()):
+            ops.linear(col[:, g].flatten(1), wg, out=out[:, g * (Cout // G):(g + 1) * (Cout // G)])
+        return out.view(B, H, W, 1, Cout)
+
 
 class DepthNet(nn.Module):
     """ViewTransformerLSSBEVDepth.py:450-504.  Dense 2-D convolutions run through
@@ -196,11 +236,27 @@ class DepthNet(nn.Module):
             nn.Conv2d(mid_channels, depth_channels, 1))
 
     def forward(self, x, mlp_input):
+        """x [BN, C, H, W] -> [BN, D + Cctx, H, W].  Eval mode: channels-last, every convolution on the
+        implicit-GEMM kernels with its BatchNorm folded in; training mode keeps the nn.Module graph."""
+        if self.training:
+            m = self.bn(mlp_input.reshape(-1, mlp_input.shape[-1]))
+            x = self.reduce_conv(x)
+            ctx = self.context_conv(self.context_se(x, self.context_mlp(m)[..., None, None]))
+            depth = self.depth_conv(self.depth_se(x, self.depth_mlp(m)[..., None, None]))
+            return torch.cat((depth, ctx), 1)
+        from . import fused
         m = self.bn(mlp_input.reshape(-1, mlp_input.shape[-1]))
-        x = self.reduce_conv(x)
-        ctx = self.context_conv(self.context_se(x, self.context_mlp(m)[..., None, None]))
-        depth = self.depth_conv(self.depth_se(x, self.depth_mlp(m)[..., None, None]))
-        return torch.cat((depth, ctx), 1)
+        x_cl = x.permute(0, 2, 3, 1).unsqueeze(3).contiguous()                      # [BN, H, W, 1, C]
+        x_cl = fused.conv_bn(x_cl, self.reduce_conv[0], self.reduce_conv[1], act=1)
+        ctx = fused.conv_bn(self.context_se.forward_cl(x_cl, self.context_mlp(m)[..., None, None]), self.context_conv)
+        d = self.depth_se.forward_cl(x_cl, self.depth_mlp(m)[..., None, None])
+        for blk in self.depth_conv[:3]:
+            d = blk.forward_cl(d)
+        d = self.depth_conv[3].forward_cl(d)
+        d = self.depth_conv[4].forward_cl(d)
+        d = fused.conv_bn(d, self.depth_conv[5])
+        y = torch.cat((d, ctx), -1)                                                  # [BN, H, W, 1, D + Cctx]
+        return y.squeeze(3).permute(0, 3, 1, 2)                                      # logical NCHW view
 
 
 # ------------------------------------------------------------------ the registered module

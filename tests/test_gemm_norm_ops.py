@@ -231,7 +231,7 @@ def test_conv3x3x3_halo(be, monkeypatch, shape, cin, cout, prec, tol):
     import ctypes
     rc = orig(ctypes.c_void_p(xs.data_ptr()), ctypes.c_void_p(sp[0].data_ptr()), ctypes.c_void_p(sp[1].data_ptr()),
               None, None, ctypes.c_void_p(o2.data_ptr()), B, X, Y, Z, cin, cout, xs.stride(0), xs.stride(1),
-              xs.stride(2), xs.stride(3), 0, 3 if prec == "bf16x3" else 1, None, 0, None)
+              xs.stride(2), xs.stride(3), 0, 3 if prec == "bf16x3" else 1, None, None)
     assert rc == 0
 
 
@@ -275,14 +275,21 @@ def test_linear_head_major_output(be):
     assert out.shape == ref.shape and torch.allclose(out, ref, atol=2e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("kind", ["halo", "strided", "linear"])
+@pytest.mark.parametrize("kind", ["halo", "strided", "linear", "linear192"])
 def test_groupnorm_stats_from_conv_epilogue(be, kind):
     """the GroupNorm statistics emitted by the conv / GEMM epilogues equal groupnorm_stats of the output"""
     ops = be.ops
     if ops.precision == "f32":
         pytest.skip("epilogue statistics live in the bf16 GEMM kernels")
     G = 8
-    if kind == "linear":
+    if kind == "linear192":          # 6 channels per group straddle the 64-wide tiles; ragged last row tile
+        G = 32
+        B, V, cin, cout = 1, 200, 32, 192
+        x = paramgen.tensor("gx", (B, V, cin), 1)
+        w = paramgen.tensor("gw", (cout, cin), 2, cin ** -0.5)
+        xd, wd = be.to(x, w)
+        y = ops.linear(xd, wd, None, w_split=ops.split_bf16(wd), gn=(G, 1e-5, V))
+    elif kind == "linear":
         B, V, cin, cout = 2, 256, 32, 64
         x = paramgen.tensor("gx", (B, V, cin), 1)
         w = paramgen.tensor("gw", (cout, cin), 2, cin ** -0.5)
