@@ -107,10 +107,14 @@ int occf_mask_pool_fwd(const float* mask_pred, float* pooled, uint8_t* blocked, 
  * mask logits are not consumed (every layer but the last in simple_test,
  * mask2former_nusc_occ.py:448-466, 713-731): the [B, Q, X, Y, Z] logits are never written.
  * mask_embed[B, Q, E] fp32, feat_hi/lo[B, V, E] = bf16 split of the channels-last mask features,
- * outputs as occf_mask_pool_fwd (pooled[B*Q, L], blocked, row_open).  Q <= 128, E % 32 == 0. */
+ * outputs as occf_mask_pool_fwd (pooled[B*Q, L], blocked, row_open).  Uniform pooling windows only
+ * (ox | X, oy | Y, oz | Z, 128 % Z == 0, window rows dividing the 128/Z rows of a tile), Q <= 128,
+ * E % 32 == 0; otherwise OCCF_ESHAPE (-2) / workspace 0 and the caller uses GEMM + occf_mask_pool_fwd.
+ * workspace: occf_mask_gemm_pool_workspace(...) floats. */
+long occf_mask_gemm_pool_workspace(int B, int Q, int E, int X, int Y, int Z, int ox, int oy, int oz);
 int occf_mask_gemm_pool_fwd(const float* mask_embed, const uint16_t* feat_hi, const uint16_t* feat_lo,
-                            float* pooled, uint8_t* blocked, int32_t* row_open, int B, int Q, int E, int X,
-                            int Y, int Z, int ox, int oy, int oz, int terms, void* stream);
+                            float* pooled, uint8_t* blocked, int32_t* row_open, float* workspace, int B, int Q,
+                            int E, int X, int Y, int Z, int ox, int oy, int oz, int terms, void* stream);
 
 /* Masked multi-head cross-attention core (scaled dot product + boolean mask + softmax + @V) of
  * the decoder layers, incl. the all-masked-row fix (mask2former_nusc_occ.py:652-667; mmcv

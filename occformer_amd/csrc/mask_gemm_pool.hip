@@ -5,16 +5,17 @@
 //   (einsum 'bqc,bcxyz->bqxyz', F.adaptive_max_pool3d, sigmoid < 0.5).  In `simple_test` only the
 //   LAST layer's mask_pred is used (:713-731); the other nine exist only to be pooled into the next
 //   layer's attention mask.  The reference still writes and re-reads each of them (10 x 2 x 256 MB
-//   at the 200-grid); here the GEMM epilogue pools its 128-voxel tile and the [B,Q,X,Y,Z] tensor of
-//   those layers is never written.
+//   at the 200-grid); here the [B,Q,X,Y,Z] tensor of those layers is never written.
 //
-// GEMM: rows = queries (<= 128, one M tile), columns = voxels (tile of 128 consecutive voxels in
-// channels-last order = whole (y, z) rows), K = E.  Same split-bf16 MFMA core and LDS layout as
-// gemm_bf16.hip; the voxel features arrive pre-split (they are the shared "weight" of all ten
-// contractions).  Epilogue: tile -> LDS [q][voxel]; each thread folds, for one query, the
-// voxels of one pooling-cell column and merges into the global pooled logits with an ordered-int
-// atomicMax (max is order independent -> deterministic).  A second tiny kernel decodes the pooled
-// logits into the blocked bytes / row_open flags of occf_mask_pool_fwd.
+// Geometry (uniform windows: ox | X, oy | Y, oz | Z, 128 % Z == 0, (128/Z) % (Y/oy) == 0, Y % (128/Z) == 0):
+// a GEMM column tile = 128 consecutive voxels of the channels-last volume = RY = 128/Z complete z-rows of
+// one x-plane, i.e. whole (y, z) pooling windows.  A workgroup owns (batch, x-window slice, y-tile): it
+// walks the x-planes of its slice, multiplies [Q <= 128] x [128 voxels] per plane (split-bf16 MFMA core
+// and LDS layout of gemm_bf16.hip; the voxel features arrive pre-split, they are the shared "weight" of
+// all ten contractions), drops the tile into LDS and folds it into per-thread running window maxima.
+// No atomics: one writer per (query, window[, slice]); a second small kernel takes the max over the
+// slices, emits the blocked bytes and the row_open flags of occf_mask_pool_fwd.
+// Global loads are unconditional and run PF k-tiles ahead in a register ring (see gemm_bf16.hip).
 #include "occf_common.h"
 #include "../../include/occformer_hip.h"
 
@@ -24,9 +25,10 @@ struct MaskPoolArgs {
   const float* me;            // [B, Q, E]
   const uint16_t* Fh;         // [B, V, E]
   const uint16_t* Fl;
-  int* pooled_enc;            // [B, Q, L] ordered-int encoded maxima
+  float* part;                // [S][B][Q][L] window maxima of every x-slice of the pooling windows
   int B, Q, E;
   int X, Y, Z, ox, oy, oz;
+  int S;                      // x-planes of a window are split over S workgroups (load balance)
 };
 
 __device__ __forceinline__ uint32_t mg_bf16_rne(float x) {
@@ -55,37 +57,12 @@ __device__ __forceinline__ void mg_split2(float a, float b, uint32_t& hi, uint32
   lo = la | (lb << 16);
 }
 __device__ __forceinline__ int mg_slot(int row, int kslot) { return row * 64 + ((kslot ^ ((row >> 2) & 3)) << 4); }
-// monotone float -> int map (for atomicMax on floats) and its inverse
-__device__ __forceinline__ int mg_enc(float f) {
-#ifdef OCCF_EMU
-  int i;
-  memcpy(&i, &f, 4);
-#else
-  const int i = __float_as_int(f);
-#endif
-  return i >= 0 ? i : i ^ 0x7fffffff;
-}
-__device__ __forceinline__ float mg_dec(int i) {
-  const int j = i >= 0 ? i : i ^ 0x7fffffff;
-#ifdef OCCF_EMU
-  float f;
-  memcpy(&f, &j, 4);
-  return f;
-#else
-  return __int_as_float(j);
-#endif
-}
-// adaptive pooling: cell c covers [floor(c*in/out), ceil((c+1)*in/out)); the cells covering input
-// index i form the range [floor(i*out/in), ceil((i+1)*out/in) - 1] (one cell when out | in).
-__device__ __forceinline__ void mg_cells(int i, int in, int out, int& c0, int& c1) {
-  c0 = (int)(((long)i * out) / in);
-  c1 = (int)((((long)i + 1) * out + in - 1) / in) - 1;
-  if (c1 > out - 1) c1 = out - 1;
-}
+__device__ __forceinline__ float occf_nanmax_mg(float m, float v) { return (v > m || v != v) ? v : m; }
 
-struct mg_u4 {
-  uint32_t x, y, z, w;
-};
+typedef uint32_t mg_u4 __attribute__((ext_vector_type(4)));
+
+#define MG_PF 2
+#define MG_ITEMS 13          // window maxima per thread: ceil(128 q * 32 windows / 256)
 
 template <int TERMS>
 __global__ void __launch_bounds__(256) mask_gemm_pool_kernel(MaskPoolArgs p) {
@@ -94,53 +71,67 @@ __global__ void __launch_bounds__(256) mask_gemm_pool_kernel(MaskPoolArgs p) {
   unsigned char* Al = lds + 8192;
   unsigned char* Bh = lds + 16384;
   unsigned char* Bl = lds + 24576;
-  float* tile = (float*)lds;               // [128 q][128 vox] after the K loop (aliases the operands)
+  float* tile = (float*)lds;               // [128 q][128 vox] after a plane's K loop (aliases the operands)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lk = lane >> 5;
   const long V = (long)p.X * p.Y * p.Z;
-  const int b = blockIdx.y;
-  const long n0 = (long)occf_xcd_remap(blockIdx.x, gridDim.x) * 128;
+  const int RY = 128 / p.Z;                       // y-rows per tile
+  const int wx = p.X / p.ox, wy = p.Y / p.oy, wz = p.Z / p.oz;
+  const int ytiles = p.Y / RY;
+  const int ncy = RY / wy, ncz = p.oz;            // windows per tile along y, z
+  const int xs = wx / p.S;                        // x-planes per workgroup
+  // workgroup -> (b, cx, slice, ty)
+  unsigned wg = occf_xcd_remap(blockIdx.x, gridDim.x);
+  const int ty = wg % ytiles; wg /= ytiles;
+  const int sl = wg % p.S; wg /= p.S;
+  const int cx = wg % p.ox;
+  const int b = wg / p.ox;
+  const int x0 = cx * wx + sl * xs;
 
+  // A (mask_embed rows; rows >= Q read row Q-1, their outputs are never folded) and B (voxel rows)
   int a_m[4], a_kq[4];
-  bool a_ok[4];
+  long a_base[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = tid + i * 256;
     a_m[i] = idx >> 3;
     a_kq[i] = idx & 7;
-    a_ok[i] = a_m[i] < p.Q;
+    a_base[i] = ((long)b * p.Q + (a_m[i] < p.Q ? a_m[i] : p.Q - 1)) * p.E + a_kq[i] * 4;
   }
   int b_n[2], b_slot[2];
-  bool b_ok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = tid + i * 256;
     b_n[i] = idx >> 2;
     b_slot[i] = idx & 3;
-    b_ok[i] = n0 + b_n[i] < V;
   }
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int li = lane & 31, lk = lane >> 5;
   const int nk = p.E / MG_BK;
-  for (int kt = 0; kt < nk; ++kt) {
+  const int F = xs * nk;                          // flat (plane, k-tile) stream
+  float4 ra[MG_PF][4];
+  mg_u4 rbh[MG_PF][2], rbl[MG_PF][2];
+  auto load_tile = [&](int f, int d) __attribute__((always_inline)) {
+    const int fc = f < F ? f : F - 1;
+    const int xi = fc / nk, kt = fc - xi * nk;
     const int k0 = kt * MG_BK;
-    __syncthreads();
+    const long n0 = ((long)(x0 + xi) * p.Y + (long)ty * RY) * p.Z;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[d][i] = *(const float4*)(p.me + a_base[i] + k0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long o = ((long)b * V + n0 + b_n[i]) * p.E + k0 + b_slot[i] * 8;
+      rbh[d][i] = *(const mg_u4*)(p.Fh + o);
+      if (TERMS == 3) rbl[d][i] = *(const mg_u4*)(p.Fl + o);
+    }
+  };
+  auto store_tile = [&](int d) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a_ok[i]) v = *(const float4*)(p.me + ((long)b * p.Q + a_m[i]) * p.E + k0 + a_kq[i] * 4);
       uint32_t h0, l0, h1, l1;
-      mg_split2(v.x, v.y, h0, l0);
-      mg_split2(v.z, v.w, h1, l1);
+      mg_split2(ra[d][i].x, ra[d][i].y, h0, l0);
+      mg_split2(ra[d][i].z, ra[d][i].w, h1, l1);
       const int off = mg_slot(a_m[i], a_kq[i] >> 1) + (a_kq[i] & 1) * 8;
       *(uint32_t*)(Ah + off) = h0;
       *(uint32_t*)(Ah + off + 4) = h1;
@@ -151,128 +142,124 @@ __global__ void __launch_bounds__(256) mask_gemm_pool_kernel(MaskPoolArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      mg_u4 vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
-      if (b_ok[i]) {
-        const long o = ((long)b * V + n0 + b_n[i]) * p.E + k0 + b_slot[i] * 8;
-        vh = *(const mg_u4*)(p.Fh + o);
-        if (TERMS == 3) vl = *(const mg_u4*)(p.Fl + o);
-      }
       const int off = mg_slot(b_n[i], b_slot[i]);
-      *(mg_u4*)(Bh + off) = vh;
-      if (TERMS == 3) *(mg_u4*)(Bl + off) = vl;
+      *(mg_u4*)(Bh + off) = rbh[d][i];
+      if (TERMS == 3) *(mg_u4*)(Bl + off) = rbl[d][i];
     }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int kslot = s * 2 + lk;
-      bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int off = mg_slot(wm * 64 + i * 32 + li, kslot);
-        ah[i] = *(const bf16x8*)(Ah + off);
-        if (TERMS == 3) al[i] = *(const bf16x8*)(Al + off);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int off = mg_slot(wn * 64 + j * 32 + li, kslot);
-        bh[j] = *(const bf16x8*)(Bh + off);
-        if (TERMS == 3) bl[j] = *(const bf16x8*)(Bl + off);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (TERMS == 3) {
-            acc[i][j] = occf_mfma_bf16_32x32x16(al[i], bh[j], acc[i][j]);
-            acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bl[j], acc[i][j]);
-          }
-          acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bh[j], acc[i][j]);
-        }
-    }
-  }
-  __syncthreads();
-  // ---- tile -> LDS [q][voxel]; columns rotated by the row so that lanes walking the queries
-  //      (stride 128 floats) hit distinct banks
+  };
+
+  f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        tile[row * 128 + ((wn * 64 + j * 32 + li + row) & 127)] = acc[i][j][r];
-      }
-  __syncthreads();
-  const long L = (long)p.ox * p.oy * p.oz;
-  if (p.Z <= 128 && 128 % p.Z == 0) {
-    // tile = 128/Z complete z-rows.  Work item = (query, z-cell): walk the rows, keep a running
-    // max while the (x, y) cell range is unchanged, flush with one ordered-int atomicMax per cell.
-    const int rows = 128 / p.Z;
-    for (int w = tid; w < p.Q * p.oz; w += 256) {
-      const int q = w % p.Q, cz = w / p.Q;
-      const int z0 = (int)(((long)cz * p.Z) / p.oz), z1 = (int)((((long)cz + 1) * p.Z + p.oz - 1) / p.oz);
-      int* dst = p.pooled_enc + ((long)b * p.Q + q) * L + cz;
-      float m = -INFINITY;
-      int pcx0 = -1, pcx1 = -1, pcy0 = -1, pcy1 = -1;
-      for (int rr = 0; rr <= rows; ++rr) {
-        int cx0 = -2, cx1 = -2, cy0 = -2, cy1 = -2;
-        const long v0 = n0 + (long)rr * p.Z;
-        const bool valid = rr < rows && v0 < V;
-        if (valid) {
-          mg_cells((int)(v0 / ((long)p.Z * p.Y)), p.X, p.ox, cx0, cx1);
-          mg_cells((int)((v0 / p.Z) % p.Y), p.Y, p.oy, cy0, cy1);
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float wmax[MG_ITEMS];
+#pragma unroll
+  for (int t = 0; t < MG_ITEMS; ++t) wmax[t] = -INFINITY;
+  const int n_items = p.Q * ncy * ncz;            // (query, window) pairs of this tile column
+
+#pragma unroll
+  for (int d = 0; d < MG_PF; ++d) load_tile(d, d);
+  int kt = 0;
+  for (int f0 = 0; f0 < F; f0 += MG_PF) {
+#pragma unroll
+    for (int d = 0; d < MG_PF; ++d) {
+      const int f = f0 + d;
+      if (f < F) {
+        __syncthreads();                           // previous fragment reads / window folds are done
+        store_tile(d);
+        __syncthreads();
+        load_tile(f + MG_PF, d);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int kslot = s * 2 + lk;
+          bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int off = mg_slot(wm * 64 + i * 32 + li, kslot);
+            ah[i] = *(const bf16x8*)(Ah + off);
+            if (TERMS == 3) al[i] = *(const bf16x8*)(Al + off);
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int off = mg_slot(wn * 64 + j * 32 + li, kslot);
+            bh[j] = *(const bf16x8*)(Bh + off);
+            if (TERMS == 3) bl[j] = *(const bf16x8*)(Bl + off);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              if (TERMS == 3) {
+                acc[i][j] = occf_mfma_bf16_32x32x16(al[i], bh[j], acc[i][j]);
+                acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bl[j], acc[i][j]);
+              }
+              acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bh[j], acc[i][j]);
+            }
         }
-        if (pcx0 >= 0 && (cx0 != pcx0 || cx1 != pcx1 || cy0 != pcy0 || cy1 != pcy1)) {
-          const int e = mg_enc(m);
-          for (int cx = pcx0; cx <= pcx1; ++cx)
-            for (int cy = pcy0; cy <= pcy1; ++cy) atomicMax(dst + ((long)cx * p.oy + cy) * p.oz, e);
-          m = -INFINITY;
+        if (++kt == nk) {
+          // ---- one x-plane done: tile -> LDS [q][voxel] (columns rotated by the row so that lanes
+          //      walking the queries hit distinct banks), fold into the running window maxima
+          kt = 0;
+          __syncthreads();
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                tile[row * 128 + ((wn * 64 + j * 32 + li + row) & 127)] = acc[i][j][r];
+                acc[i][j][r] = 0.f;
+              }
+          __syncthreads();
+#pragma unroll
+          for (int t = 0; t < MG_ITEMS; ++t) {
+            const int w = tid + t * 256;
+            if (w < n_items) {
+              const int q = w % p.Q, c = w / p.Q;
+              const int cz = c % ncz, cyl = c / ncz;
+              float m = wmax[t];
+              for (int dy = 0; dy < wy; ++dy)
+                for (int dz = 0; dz < wz; ++dz)
+                  m = occf_nanmax_mg(m, tile[q * 128 + (((cyl * wy + dy) * p.Z + cz * wz + dz + q) & 127)]);
+              wmax[t] = m;
+            }
+          }
         }
-        if (!valid) break;
-        pcx0 = cx0; pcx1 = cx1; pcy0 = cy0; pcy1 = cy1;
-        for (int z = z0; z < z1; ++z) m = fmaxf(m, tile[q * 128 + ((rr * p.Z + z + q) & 127)]);
       }
     }
-  } else {
-    for (int w = tid; w < p.Q * 128; w += 256) {       // generic geometry: one voxel at a time
+  }
+  const long L = (long)p.ox * p.oy * p.oz;
+#pragma unroll
+  for (int t = 0; t < MG_ITEMS; ++t) {
+    const int w = tid + t * 256;
+    if (w < n_items) {
       const int q = w % p.Q, c = w / p.Q;
-      const long v = n0 + c;
-      if (v >= V) continue;
-      const int z = (int)(v % p.Z), y = (int)((v / p.Z) % p.Y), x = (int)(v / ((long)p.Z * p.Y));
-      int cx0, cx1, cy0, cy1, cz0, cz1;
-      mg_cells(x, p.X, p.ox, cx0, cx1);
-      mg_cells(y, p.Y, p.oy, cy0, cy1);
-      mg_cells(z, p.Z, p.oz, cz0, cz1);
-      const int e = mg_enc(tile[q * 128 + ((c + q) & 127)]);
-      for (int cx = cx0; cx <= cx1; ++cx)
-        for (int cy = cy0; cy <= cy1; ++cy)
-          for (int cz = cz0; cz <= cz1; ++cz)
-            atomicMax(p.pooled_enc + ((long)b * p.Q + q) * L + ((long)cx * p.oy + cy) * p.oz + cz, e);
+      const int cz = c % ncz, cyl = c / ncz;
+      p.part[(((long)sl * p.B + b) * p.Q + q) * L + ((long)cx * p.oy + ty * ncy + cyl) * p.oz + cz] = wmax[t];
     }
   }
 }
 
-__global__ void __launch_bounds__(256) mask_pool_fill_kernel(int* __restrict__ enc, long n) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) enc[i] = (int)0x80000000;
-}
-
-// decode pooled logits in place (int -> float) and emit the blocked bytes; one workgroup per
-// (batch, query) row also reduces "any key open" for the all-masked-row fix (no atomics).
-__global__ void __launch_bounds__(256) mask_pool_decode_kernel(int* __restrict__ enc, uint8_t* __restrict__ blocked,
-                                                               int* __restrict__ row_open, long L) {
+// max over the x-slices, blocked bytes, "any key open" per (batch, query) row (all-masked-row fix)
+__global__ void __launch_bounds__(256) mask_pool_finish_kernel(const float* __restrict__ part, float* __restrict__ pooled,
+                                                               uint8_t* __restrict__ blocked, int* __restrict__ row_open,
+                                                               long L, long BQ, int S) {
   __shared__ int any_open;
   const long row = blockIdx.x;
   if (threadIdx.x == 0) any_open = 0;
   __syncthreads();
   bool open = false;
   for (long c = threadIdx.x; c < L; c += blockDim.x) {
-    const long i = row * L + c;
-    const float m = mg_dec(enc[i]);
-    ((float*)enc)[i] = m;
-    const float sg = 1.0f / (1.0f + expf(-m));
+    float m = part[row * L + c];
+    for (int s = 1; s < S; ++s) m = occf_nanmax_mg(m, part[((long)s * BQ + row) * L + c]);
+    pooled[row * L + c] = m;
+    const float sg = 1.0f / (1.0f + expf(-m));              // as the reference: fp32 sigmoid, then compare
     const bool blk = sg < 0.5f;
-    blocked[i] = blk ? 1 : 0;
+    blocked[row * L + c] = blk ? 1 : 0;
     open |= !blk;
   }
   if (open) any_open = 1;          // benign race: every writer stores the same value
@@ -280,22 +267,44 @@ __global__ void __launch_bounds__(256) mask_pool_decode_kernel(int* __restrict__
   if (threadIdx.x == 0) row_open[row] = any_open;
 }
 
+static int mg_slices(int B, int X, int Y, int Z, int ox) {
+  // split a window's x-planes over S workgroups until the grid has >= ~1000 workgroups
+  const int wx = X / ox, ytiles = Y / (128 / Z);
+  int S = 1;
+  while (S * 2 <= wx && wx % (S * 2) == 0 && (long)B * ox * S * ytiles < 1000) S *= 2;
+  return S;
+}
+static bool mg_geometry_ok(int Q, int E, int X, int Y, int Z, int ox, int oy, int oz) {
+  if (Q <= 0 || Q > 128 || E % MG_BK != 0) return false;
+  if (ox <= 0 || oy <= 0 || oz <= 0 || X % ox || Y % oy || Z % oz) return false;
+  if (Z > 128 || 128 % Z) return false;
+  const int RY = 128 / Z, wy = Y / oy;
+  if (Y % RY || RY % wy) return false;
+  return (long)Q * (RY / wy) * oz <= 256L * MG_ITEMS;
+}
+
+// floats of scratch for the per-slice window maxima; 0 when the geometry is not taken by the fused kernel
+extern "C" long occf_mask_gemm_pool_workspace(int B, int Q, int E, int X, int Y, int Z, int ox, int oy, int oz) {
+  if (B <= 0 || !mg_geometry_ok(Q, E, X, Y, Z, ox, oy, oz)) return 0;
+  return (long)mg_slices(B, X, Y, Z, ox) * B * Q * ox * oy * oz;
+}
+
 extern "C" int occf_mask_gemm_pool_fwd(const float* mask_embed, const uint16_t* feat_hi, const uint16_t* feat_lo,
-                                       float* pooled, uint8_t* blocked, int32_t* row_open, int B, int Q, int E,
-                                       int X, int Y, int Z, int ox, int oy, int oz, int terms, void* stream) {
-  if (B <= 0 || Q <= 0 || Q > 128 || E % MG_BK != 0) return OCCF_ESHAPE;
-  if (ox <= 0 || oy <= 0 || oz <= 0 || ox > X || oy > Y || oz > Z) return OCCF_ESHAPE;
+                                       float* pooled, uint8_t* blocked, int32_t* row_open, float* workspace, int B,
+                                       int Q, int E, int X, int Y, int Z, int ox, int oy, int oz, int terms,
+                                       void* stream) {
+  if (B <= 0 || !mg_geometry_ok(Q, E, X, Y, Z, ox, oy, oz)) return OCCF_ESHAPE;
   if (terms != 1 && terms != 3) return OCCF_EINVAL;
-  if (terms == 3 && feat_lo == nullptr) return OCCF_EINVAL;
+  if ((terms == 3 && feat_lo == nullptr) || workspace == nullptr) return OCCF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const long V = (long)X * Y * Z, L = (long)ox * oy * oz;
-  const long BQL = (long)B * Q * L;
-  hipLaunchKernelGGL(mask_pool_fill_kernel, dim3(occf_cdiv(BQL, 256)), dim3(256), 0, st, (int*)pooled, BQL);
-  MaskPoolArgs a = {mask_embed, feat_hi, feat_lo, (int*)pooled, B, Q, E, X, Y, Z, ox, oy, oz};
-  const dim3 grid((unsigned)occf_cdiv(V, 128), B);
-  if (terms == 3) hipLaunchKernelGGL(mask_gemm_pool_kernel<3>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(mask_gemm_pool_kernel<1>, grid, dim3(256), 0, st, a);
-  hipLaunchKernelGGL(mask_pool_decode_kernel, dim3((unsigned)(B * Q)), dim3(256), 0, st, (int*)pooled, blocked,
-                     (int*)row_open, L);
+  const long L = (long)ox * oy * oz;
+  const int S = mg_slices(B, X, Y, Z, ox);
+  MaskPoolArgs a = {mask_embed, feat_hi, feat_lo, workspace, B, Q, E, X, Y, Z, ox, oy, oz, S};
+  const long blocks = (long)B * ox * S * (Y / (128 / Z));
+  if (blocks >= 2147483647L) return OCCF_ESHAPE;
+  if (terms == 3) hipLaunchKernelGGL(mask_gemm_pool_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(mask_gemm_pool_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(mask_pool_finish_kernel, dim3((unsigned)(B * Q)), dim3(256), 0, st, workspace, pooled, blocked,
+                     (int*)row_open, L, (long)B * Q, S);
   OCCF_LAUNCH_CHECK();
 }

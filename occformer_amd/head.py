@@ -149,8 +149,9 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
         mask_embed = fused.linear(fused.linear(fused.linear(d, me[0], act=1), me[2], act=1), me[4])
         B, Q = mask_embed.shape[:2]
         if not want_mask and want_attn and mask_feat_split is not None and Q <= 128 and ops.use_fused_mask_pool:
-            _, blocked, row_open = ops.mask_gemm_pool(mask_embed, mask_feat_split, vol_shape, target_shape)
-            return cls_pred, None, (blocked, row_open)
+            fusedp = ops.mask_gemm_pool(mask_embed, mask_feat_split, vol_shape, target_shape)
+            if fusedp is not None:
+                return cls_pred, None, (fusedp[1], fusedp[2])
         # einsum('bqc,bcxyz->bqxyz'): per batch a [Q, E] x [V, E]^T GEMM whose "weight" is the
         # channels-last mask feature itself
         mask_pred = torch.empty((B, Q, mask_feat_tok.shape[1]), dtype=d.dtype, device=d.device)

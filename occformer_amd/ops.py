@@ -31,7 +31,7 @@ class HipOps:
         self.use_halo_conv = os.environ.get("OCCF_HALO_CONV", "1") == "1"
         # fused mask-GEMM + pooling (skips writing intermediate mask logits): measured slower than
         # GEMM + pooling kernel on MI355X in round 1 (atomicMax rate), so off by default
-        self.use_fused_mask_pool = os.environ.get("OCCF_FUSED_MASK_POOL", "0") == "1"
+        self.use_fused_mask_pool = os.environ.get("OCCF_FUSED_MASK_POOL", "1") == "1"
         self.use_fused_mlp = os.environ.get("OCCF_FUSED_MLP", "1") == "1"
 
     # ------------------------------------------------------------------ plumbing
@@ -157,17 +157,24 @@ class HipOps:
 
     def mask_gemm_pool(self, mask_embed, feat_split, vol_shape, target):
         """mask_embed [B, Q, E], feat_split = (hi, lo) of [B, V, E] -> pooled [B,Q,L], blocked, row_open
-        without materialising the [B, Q, X, Y, Z] logits.  Needs a bf16 precision mode."""
+        without materialising the [B, Q, X, Y, Z] logits; None when the pooling geometry is not uniform
+        (the caller then runs the GEMM and mask_pool).  Needs a bf16 precision mode."""
         B, Q, E = mask_embed.shape
         X, Y, Z = (int(v) for v in vol_shape)
         ox, oy, oz = (int(t) for t in target)
+        need = self.lib.occf_mask_gemm_pool_workspace(B, Q, E, X, Y, Z, ox, oy, oz)
+        if need <= 0 or self.precision == "f32":
+            return None
         L = ox * oy * oz
+        ws = torch.empty((need,), dtype=self.f32, device=mask_embed.device)
         pooled = torch.empty((B, Q, L), dtype=self.f32, device=mask_embed.device)
         blocked = torch.empty((B, Q, L), dtype=torch.uint8, device=mask_embed.device)
         row_open = torch.empty((B * Q,), dtype=self.i32, device=mask_embed.device)
+        self.last_flops = 2 * B * Q * X * Y * Z * E
         self._call("occf_mask_gemm_pool_fwd", self._ptr(mask_embed, self.f32), self._ptr(feat_split[0]),
-                   self._ptr(feat_split[1]), self._ptr(pooled), self._ptr(blocked), self._ptr(row_open), B, Q, E,
-                   X, Y, Z, ox, oy, oz, 3 if self.precision == "bf16x3" else 1, self._stream())
+                   self._ptr(feat_split[1]), self._ptr(pooled), self._ptr(blocked), self._ptr(row_open),
+                   self._ptr(ws), B, Q, E, X, Y, Z, ox, oy, oz, 3 if self.precision == "bf16x3" else 1,
+                   self._stream())
         return pooled, blocked, row_open
 
     def masked_attention(self, q, k, v, heads, blocked=None, row_open=None):
@@ -269,7 +276,7 @@ class HipOps:
                        ctypes.c_void_p(0), self._stream())
             return out.view(M // rows, N // dh, rows, dh)
         if terms:
-            if gn is not None and residual is None and act == 0:
+            if gn is not None and residual is None and act == 0 and self.lib.occf_gemm_bf16_workspace(M, N, K) == 0:
                 G, eps, rows = gn
                 if (rows % 128 == 0 or M == rows) and M % rows == 0 and N % G == 0:
                     nblk = (rows + 127) // 128
@@ -339,7 +346,9 @@ class HipOps:
                 raise OccfError(f"occf_conv3x3x3_halo_fwd failed with code {rc}")
         if terms:
             V = Xo * Yo * Zo
-            if want_gn and (V % 128 == 0 or B == 1) and Cout % gn[0] == 0:
+            # (shapes that profit from split-K keep it; their statistics come from the separate pass)
+            if want_gn and (V % 128 == 0 or B == 1) and Cout % gn[0] == 0 and \
+                    self.lib.occf_gemm_bf16_workspace(B * V, Cout, kX * kY * kZ * Cin) == 0:
                 nblk = (V + 127) // 128
                 part = torch.empty((B * nblk * Cout * 2,), dtype=self.f32, device=x_cl.device)
                 rc = self.lib.occf_conv3d_bf16_fwd(
