@@ -129,9 +129,10 @@ long occf_masked_xattn_workspace(int B, int Q, int L, int heads);
 
 /* simple_test's tail fused: F.interpolate(mask_pred, occ_size, trilinear, align_corners=True) ->
  * sigmoid -> einsum('bqc,bqxyz->bcxyz') with softmax(cls)[..., :-1]
- * (mask2former_nusc_occ.py:725-733, 691-696).  cls[B, Q, K+1]; out[B, K, X2, Y2, Z2]. */
-int occf_upsample_classify_fwd(const float* mask_pred, const float* cls, float* out, int B, int Q,
-                               int K, int X, int Y, int Z, int X2, int Y2, int Z2, void* stream);
+ * (mask2former_nusc_occ.py:725-733, 691-696).  cls[B, Q, K+1]; out[B, K, X2, Y2, Z2]; K <= 24;
+ * workspace: B*Q*24 floats (the class probabilities). */
+int occf_upsample_classify_fwd(const float* mask_pred, const float* cls, float* out, float* workspace, int B,
+                               int Q, int K, int X, int Y, int Z, int X2, int Y2, int Z2, void* stream);
 
 /* forward_lidarseg (eval branch, mask2former_nusc_occ.py:505-542): class volume at mask
  * resolution sampled at points (bilinear=trilinear, align_corners=True, border padding) and

@@ -62,7 +62,6 @@ __device__ __forceinline__ float occf_nanmax_mg(float m, float v) { return (v > 
 typedef uint32_t mg_u4 __attribute__((ext_vector_type(4)));
 
 #define MG_PF 2
-#define MG_ITEMS 13          // window maxima per thread: ceil(128 q * 32 windows / 256)
 
 template <int TERMS>
 __global__ void __launch_bounds__(256) mask_gemm_pool_kernel(MaskPoolArgs p) {
@@ -155,9 +154,15 @@ __global__ void __launch_bounds__(256) mask_gemm_pool_kernel(MaskPoolArgs p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float wmax[MG_ITEMS];
+  // max over the x-planes commutes with the (y, z) window max: the planes are folded element-wise in
+  // registers and the window reduction runs ONCE per workgroup
+  f32x16 pmax[2][2];
 #pragma unroll
-  for (int t = 0; t < MG_ITEMS; ++t) wmax[t] = -INFINITY;
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pmax[i][j][r] = -INFINITY;
   const int n_items = p.Q * ncy * ncz;            // (query, window) pairs of this tile column
 
 #pragma unroll
@@ -168,7 +173,7 @@ __global__ void __launch_bounds__(256) mask_gemm_pool_kernel(MaskPoolArgs p) {
     for (int d = 0; d < MG_PF; ++d) {
       const int f = f0 + d;
       if (f < F) {
-        __syncthreads();                           // previous fragment reads / window folds are done
+        __syncthreads();                           // previous fragment reads are done
         store_tile(d);
         __syncthreads();
         load_tile(f + MG_PF, d);
@@ -199,72 +204,68 @@ __global__ void __launch_bounds__(256) mask_gemm_pool_kernel(MaskPoolArgs p) {
               acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bh[j], acc[i][j]);
             }
         }
-        if (++kt == nk) {
-          // ---- one x-plane done: tile -> LDS [q][voxel] (columns rotated by the row so that lanes
-          //      walking the queries hit distinct banks), fold into the running window maxima
+        if (++kt == nk) {                          // one x-plane done
           kt = 0;
-          __syncthreads();
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
               for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                tile[row * 128 + ((wn * 64 + j * 32 + li + row) & 127)] = acc[i][j][r];
+                pmax[i][j][r] = occf_nanmax_mg(pmax[i][j][r], acc[i][j][r]);
                 acc[i][j][r] = 0.f;
               }
-          __syncthreads();
-#pragma unroll
-          for (int t = 0; t < MG_ITEMS; ++t) {
-            const int w = tid + t * 256;
-            if (w < n_items) {
-              const int q = w % p.Q, c = w / p.Q;
-              const int cz = c % ncz, cyl = c / ncz;
-              float m = wmax[t];
-              for (int dy = 0; dy < wy; ++dy)
-                for (int dz = 0; dz < wz; ++dz)
-                  m = occf_nanmax_mg(m, tile[q * 128 + (((cyl * wy + dy) * p.Z + cz * wz + dz + q) & 127)]);
-              wmax[t] = m;
-            }
-          }
         }
       }
     }
   }
-  const long L = (long)p.ox * p.oy * p.oz;
+  // ---- plane maxima -> LDS [q][voxel] (columns rotated by the row so that lanes walking the queries hit
+  //      distinct banks), then one thread per (query, window) folds its wy x wz voxels
+  __syncthreads();
 #pragma unroll
-  for (int t = 0; t < MG_ITEMS; ++t) {
-    const int w = tid + t * 256;
-    if (w < n_items) {
-      const int q = w % p.Q, c = w / p.Q;
-      const int cz = c % ncz, cyl = c / ncz;
-      p.part[(((long)sl * p.B + b) * p.Q + q) * L + ((long)cx * p.oy + ty * ncy + cyl) * p.oz + cz] = wmax[t];
-    }
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        tile[row * 128 + ((wn * 64 + j * 32 + li + row) & 127)] = pmax[i][j][r];
+      }
+  __syncthreads();
+  const long L = (long)p.ox * p.oy * p.oz;
+  for (int w = tid; w < n_items; w += 256) {
+    const int q = w % p.Q, c = w / p.Q;
+    const int cz = c % ncz, cyl = c / ncz;
+    float m = -INFINITY;
+    for (int dy = 0; dy < wy; ++dy)
+      for (int dz = 0; dz < wz; ++dz)
+        m = occf_nanmax_mg(m, tile[q * 128 + (((cyl * wy + dy) * p.Z + cz * wz + dz + q) & 127)]);
+    p.part[(((long)sl * p.B + b) * p.Q + q) * L + ((long)cx * p.oy + ty * ncy + cyl) * p.oz + cz] = m;
   }
 }
 
-// max over the x-slices, blocked bytes, "any key open" per (batch, query) row (all-masked-row fix)
+// max over the x-slices, blocked bytes, "any key open" per (batch, query) row (all-masked-row fix);
+// grid = (rows, 2048-cell chunks); row_open is zeroed by the host and OR-ed (order independent)
 __global__ void __launch_bounds__(256) mask_pool_finish_kernel(const float* __restrict__ part, float* __restrict__ pooled,
                                                                uint8_t* __restrict__ blocked, int* __restrict__ row_open,
                                                                long L, long BQ, int S) {
-  __shared__ int any_open;
   const long row = blockIdx.x;
-  if (threadIdx.x == 0) any_open = 0;
-  __syncthreads();
+  const long c0 = (long)blockIdx.y * 2048;
   bool open = false;
-  for (long c = threadIdx.x; c < L; c += blockDim.x) {
-    float m = part[row * L + c];
-    for (int s = 1; s < S; ++s) m = occf_nanmax_mg(m, part[((long)s * BQ + row) * L + c]);
-    pooled[row * L + c] = m;
-    const float sg = 1.0f / (1.0f + expf(-m));              // as the reference: fp32 sigmoid, then compare
-    const bool blk = sg < 0.5f;
-    blocked[row * L + c] = blk ? 1 : 0;
-    open |= !blk;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const long c = c0 + u * 256 + threadIdx.x;
+    if (c < L) {
+      float m = part[row * L + c];
+      for (int s = 1; s < S; ++s) m = occf_nanmax_mg(m, part[((long)s * BQ + row) * L + c]);
+      pooled[row * L + c] = m;
+      const float sg = 1.0f / (1.0f + expf(-m));            // as the reference: fp32 sigmoid, then compare
+      const bool blk = sg < 0.5f;
+      blocked[row * L + c] = blk ? 1 : 0;
+      open |= !blk;
+    }
   }
-  if (open) any_open = 1;          // benign race: every writer stores the same value
-  __syncthreads();
-  if (threadIdx.x == 0) row_open[row] = any_open;
+  if (__ballot(open) != 0 && (threadIdx.x & 63) == 0) atomicOr((unsigned*)&row_open[row], 1u);
 }
 
 static int mg_slices(int B, int X, int Y, int Z, int ox) {
@@ -280,7 +281,7 @@ static bool mg_geometry_ok(int Q, int E, int X, int Y, int Z, int ox, int oy, in
   if (Z > 128 || 128 % Z) return false;
   const int RY = 128 / Z, wy = Y / oy;
   if (Y % RY || RY % wy) return false;
-  return (long)Q * (RY / wy) * oz <= 256L * MG_ITEMS;
+  return true;
 }
 
 // floats of scratch for the per-slice window maxima; 0 when the geometry is not taken by the fused kernel
@@ -304,7 +305,13 @@ extern "C" int occf_mask_gemm_pool_fwd(const float* mask_embed, const uint16_t* 
   if (blocks >= 2147483647L) return OCCF_ESHAPE;
   if (terms == 3) hipLaunchKernelGGL(mask_gemm_pool_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(mask_gemm_pool_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(mask_pool_finish_kernel, dim3((unsigned)(B * Q)), dim3(256), 0, st, workspace, pooled, blocked,
-                     (int*)row_open, L, (long)B * Q, S);
+#ifndef OCCF_EMU
+  hipError_t e = hipMemsetAsync(row_open, 0, sizeof(int32_t) * (size_t)B * Q, st);
+  if (e != hipSuccess) return (int)e;
+#else
+  memset(row_open, 0, sizeof(int32_t) * (size_t)B * Q);
+#endif
+  hipLaunchKernelGGL(mask_pool_finish_kernel, dim3((unsigned)(B * Q), (unsigned)occf_cdiv(L, 2048)), dim3(256), 0, st,
+                     workspace, pooled, blocked, (int*)row_open, L, (long)B * Q, S);
   OCCF_LAUNCH_CHECK();
 }

@@ -253,24 +253,27 @@ extern "C" long occf_masked_xattn_workspace(int B, int Q, int L, int heads) {
 // to occ_size, sigmoid, and the class-weighted sum over queries with softmax(cls)[..., :-1]
 // -- one pass; the reference's [B,100,256,256,32] fp32 intermediate (839 MB) never exists.
 // mask_pred [B, Q, X, Y, Z]; cls [B, Q, K+1]; out [B, K, X2, Y2, Z2].
-#define UC_MAXQ 128
 #define UC_MAXK 24
 
+// softmax(cls)[..., :K] of every query -> prob[B][Q][UC_MAXK] (read back by the main kernel through the
+// SCALAR cache: the table index is wave-uniform, so the 17 class weights of a query cost s_loads instead
+// of 17 LDS broadcasts per lane -- the LDS issue rate was this kernel's limiter)
+__global__ void __launch_bounds__(128) class_prob_kernel(const float* __restrict__ cls, float* __restrict__ prob, int BQ,
+                                                         int K) {
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= BQ) return;
+  const float* c = cls + (long)qi * (K + 1);
+  float mx = c[0];
+  for (int i = 1; i <= K; ++i) mx = fmaxf(mx, c[i]);
+  float sum = 0.f;
+  for (int i = 0; i <= K; ++i) sum += expf(c[i] - mx);
+  for (int i = 0; i < UC_MAXK; ++i) prob[(long)qi * UC_MAXK + i] = i < K ? expf(c[i] - mx) / sum : 0.f;
+}
+
 __global__ void __launch_bounds__(256) upsample_classify_kernel(
-    const float* __restrict__ mask_pred, const float* __restrict__ cls, float* __restrict__ out, int B,
+    const float* __restrict__ mask_pred, const float* __restrict__ prob, float* __restrict__ out, int B,
     int Q, int K, int X, int Y, int Z, int X2, int Y2, int Z2) {
-  __shared__ float prob[UC_MAXQ * UC_MAXK];
   const int b = blockIdx.y;
-  // softmax over K+1 logits per query, keep the first K
-  for (int qi = threadIdx.x; qi < Q; qi += blockDim.x) {
-    const float* c = cls + ((long)b * Q + qi) * (K + 1);
-    float mx = c[0];
-    for (int i = 1; i <= K; ++i) mx = fmaxf(mx, c[i]);
-    float sum = 0.f;
-    for (int i = 0; i <= K; ++i) sum += expf(c[i] - mx);
-    for (int i = 0; i < K; ++i) prob[qi * UC_MAXK + i] = expf(c[i] - mx) / sum;
-  }
-  __syncthreads();
   const long V2 = (long)X2 * Y2 * Z2;
   const long vid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (vid >= V2) return;
@@ -289,6 +292,7 @@ __global__ void __launch_bounds__(256) upsample_classify_kernel(
   const long V = (long)X * Y * Z;
   const long o00 = ((long)x0 * Y + y0) * Z, o01 = ((long)x0 * Y + y1) * Z;
   const long o10 = ((long)x1 * Y + y0) * Z, o11 = ((long)x1 * Y + y1) * Z;
+  const float* pb = prob + (long)b * Q * UC_MAXK;
   for (int qi = 0; qi < Q; ++qi) {
     const float* mp = mask_pred + ((long)b * Q + qi) * V;
     // same nesting as upsample_trilinear3d: x outermost, z innermost
@@ -298,23 +302,24 @@ __global__ void __launch_bounds__(256) upsample_classify_kernel(
     const float c11 = (1.f - tz) * mp[o11 + z0] + tz * mp[o11 + z1];
     const float val = (1.f - tx) * ((1.f - ty) * c00 + ty * c01) + tx * ((1.f - ty) * c10 + ty * c11);
     const float sg = 1.0f / (1.0f + expf(-val));
-    const float* pr = &prob[qi * UC_MAXK];
+    const float* pr = pb + qi * UC_MAXK;                 // wave-uniform address -> scalar loads
 #pragma unroll
-    for (int i = 0; i < UC_MAXK; ++i)
-      if (i < K) acc[i] = fmaf(pr[i], sg, acc[i]);
+    for (int i = 0; i < UC_MAXK; ++i) acc[i] = fmaf(pr[i], sg, acc[i]);
   }
 #pragma unroll
   for (int i = 0; i < UC_MAXK; ++i)
     if (i < K) out[((long)b * K + i) * V2 + vid] = acc[i];
 }
 
-extern "C" int occf_upsample_classify_fwd(const float* mask_pred, const float* cls, float* out, int B,
-                                          int Q, int K, int X, int Y, int Z, int X2, int Y2, int Z2,
+extern "C" int occf_upsample_classify_fwd(const float* mask_pred, const float* cls, float* out, float* workspace,
+                                          int B, int Q, int K, int X, int Y, int Z, int X2, int Y2, int Z2,
                                           void* stream) {
-  if (B <= 0 || Q <= 0 || Q > UC_MAXQ || K <= 0 || K > UC_MAXK) return OCCF_ESHAPE;
+  if (B <= 0 || Q <= 0 || K <= 0 || K > UC_MAXK || workspace == nullptr) return OCCF_ESHAPE;
   const long V2 = (long)X2 * Y2 * Z2;
-  hipLaunchKernelGGL(upsample_classify_kernel, dim3(occf_cdiv(V2, 256), B), dim3(256), 0,
-                     (hipStream_t)stream, mask_pred, cls, out, B, Q, K, X, Y, Z, X2, Y2, Z2);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(class_prob_kernel, dim3(occf_cdiv((long)B * Q, 128)), dim3(128), 0, st, cls, workspace, B * Q, K);
+  hipLaunchKernelGGL(upsample_classify_kernel, dim3(occf_cdiv(V2, 256), B), dim3(256), 0, st, mask_pred,
+                     (const float*)workspace, out, B, Q, K, X, Y, Z, X2, Y2, Z2);
   OCCF_LAUNCH_CHECK();
 }
 

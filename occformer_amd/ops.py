@@ -194,8 +194,9 @@ class HipOps:
         K = cls.shape[-1] - 1
         X2, Y2, Z2 = (int(t) for t in occ_size)
         out = torch.empty((B, K, X2, Y2, Z2), dtype=mask_pred.dtype, device=mask_pred.device)
+        ws = torch.empty((B * Q * 24,), dtype=self.f32, device=mask_pred.device)
         self._call("occf_upsample_classify_fwd", self._ptr(mask_pred, self.f32), self._ptr(cls, self.f32),
-                   self._ptr(out), B, Q, K, X, Y, Z, X2, Y2, Z2, self._stream())
+                   self._ptr(out), self._ptr(ws), B, Q, K, X, Y, Z, X2, Y2, Z2, self._stream())
         return out
 
     def lidarseg_sample(self, mask_pred, cls, pts):
