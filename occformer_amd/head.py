@@ -43,15 +43,18 @@ class _MHA(nn.Module):
         self.heads = heads
         self.E = E
 
-    def forward(self, query, key, value, query_pos, key_pos, blocked=None, row_open=None):
+    def forward(self, query, key, value, query_pos, key_pos, blocked=None, row_open=None, key_with_pos=None):
+        """``key_with_pos``: ``key + key_pos`` computed by the caller (the level tokens and their encodings
+        are the same for every layer that attends to that level)"""
         E = self.E
         ops = get_ops()
         w, b = self.attn.in_proj_weight.detach(), self.attn.in_proj_bias.detach()
         sp = fused.split_weight(self.attn.in_proj_weight)
         part = (lambda lo, hi: None) if sp is None else (lambda lo, hi: (sp[0][lo:hi], sp[1][lo:hi]))
         q = ops.linear(query + query_pos, w[:E], b[:E], w_split=part(0, E))
-        k = ops.linear(key + key_pos if key_pos is not None else key, w[E:2 * E], b[E:2 * E],
-                       w_split=part(E, 2 * E))
+        if key_with_pos is None:
+            key_with_pos = key + key_pos if key_pos is not None else key
+        k = ops.linear(key_with_pos, w[E:2 * E], b[E:2 * E], w_split=part(E, 2 * E))
         v = ops.linear(value, w[2 * E:], b[2 * E:], w_split=part(2 * E, 3 * E))
         o = ops.masked_attention(q, k, v, self.heads, blocked, row_open)
         return fused.linear(o, self.attn.out_proj, residual=query.contiguous())
@@ -67,8 +70,9 @@ class _DecoderLayer(nn.Module):
         self.ffns = nn.ModuleList([_FFN(E, ffn_channels, act="relu")])
         self.norms = nn.ModuleList([nn.LayerNorm(E) for _ in range(3)])
 
-    def forward(self, q, qpos, key, key_pos, blocked, row_open):
-        q = fused.layernorm(self.attentions[0](q, key, key, qpos, key_pos, blocked, row_open), self.norms[0])
+    def forward(self, q, qpos, key, key_pos, blocked, row_open, key_with_pos=None):
+        q = fused.layernorm(self.attentions[0](q, key, key, qpos, key_pos, blocked, row_open, key_with_pos),
+                            self.norms[0])
         q = fused.layernorm(self.attentions[1](q, q, q, qpos, qpos), self.norms[1])
         ffn = self.ffns[0].layers
         y = fused.linear(fused.linear(q, ffn[0][0], act=1), ffn[1], residual=q)
@@ -183,6 +187,7 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
             keys.append(t)
             key_pos.append(self.decoder_positional_encoding.for_shape(shp, m.device).unsqueeze(0))
             shapes.append(shp)
+        keys_pp = [k + kp for k, kp in zip(keys, key_pos)]          # once per level, shared by its 3 layers
         q = self.query_feat.weight.unsqueeze(0).expand(B, -1, -1)
         qpos = self.query_embed.weight.unsqueeze(0).expand(B, -1, -1)
         # the mask features are the "weight" of ten contractions: split them to bf16 (hi, lo) once
@@ -195,7 +200,7 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
             mask_list.append(mp)
         for i, layer in enumerate(self.transformer_decoder.layers):
             lv = i % self.num_transformer_feat_level
-            q = layer(q, qpos, keys[lv], key_pos[lv], am[0], am[1])
+            q = layer(q, qpos, keys[lv], key_pos[lv], am[0], am[1], keys_pp[lv])
             last = i == n_layers - 1
             cls, mp, am = self.forward_head(q, mask_tok, vol_shape,
                                             shapes[(i + 1) % self.num_transformer_feat_level], mf_split,
