@@ -359,6 +359,12 @@ static size_t mlp_lds_bytes(int C, int terms) {
   return a > o ? a : o;
 }
 
+// mlp_chain.hip: register-chained variant for C = 128 / 192
+int occf_mlp_chain_launch(const float* x, const float* ln_gamma, const float* ln_beta, const uint16_t* w1_hi,
+                          const uint16_t* w1_lo, const float* b1, const uint16_t* w2_hi, const uint16_t* w2_lo,
+                          const float* b2, float* out, long M, int C, int H, int act, int ln_mode, float eps, int terms,
+                          hipStream_t st);
+
 extern "C" int occf_mlp_fused_fwd(const float* x, const float* ln_gamma, const float* ln_beta,
                                   const uint16_t* w1_hi, const uint16_t* w1_lo, const float* b1,
                                   const uint16_t* w2_hi, const uint16_t* w2_lo, const float* b2, float* out, long M,
@@ -367,6 +373,15 @@ extern "C" int occf_mlp_fused_fwd(const float* x, const float* ln_gamma, const f
   if (terms != 1 && terms != 3) return OCCF_EINVAL;
   if (terms == 3 && (w1_lo == nullptr || w2_lo == nullptr)) return OCCF_EINVAL;
   if (ln_mode != 0 && (ln_gamma == nullptr || ln_beta == nullptr)) return OCCF_EINVAL;
+  static const bool chain = [] {
+    const char* e = getenv("OCCF_MLP_CHAIN");
+    return e ? atoi(e) != 0 : true;
+  }();
+  if (chain && (C == 128 || C == 192)) {
+    const int rc = occf_mlp_chain_launch(x, ln_gamma, ln_beta, w1_hi, w1_lo, b1, w2_hi, w2_lo, b2, out, M, C, H, act,
+                                         ln_mode, eps, terms, (hipStream_t)stream);
+    if (rc != OCCF_ESHAPE) return rc;
+  }
   MlpArgs a = {x, ln_gamma, ln_beta, w1_hi, w1_lo, b1, w2_hi, w2_lo, b2, out, M, C, H, act, ln_mode, eps};
   const size_t lds = mlp_lds_bytes(C, terms);
   const unsigned grid = (unsigned)occf_cdiv(M, 64);
