@@ -203,21 +203,28 @@ __global__ void __launch_bounds__(256) mlp_chain_kernel(MlpChainArgs p) {
     // weights of group g+1 travel to registers while group g multiplies
     fetch_w1(g + 1);
     fetch_w2(g + 1);
-    // ---- GEMM1: Ht = W1g . Xt
-    f32x16 ht;
+    // ---- GEMM1: Ht = W1g . Xt.  Three independent accumulator chains (one per split term; even/odd k-steps
+    // in plain bf16): with one wave per SIMD a single dependent MFMA chain would run at half rate.
+    f32x16 ht, hu, hv;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ht[r] = 0.f;
+    for (int r = 0; r < 16; ++r) ht[r] = hu[r] = hv[r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KC; ++ks) {
       const int off = ks * 1024 + li * 32 + lk * 16;
       const bf16x8 ah = *(const bf16x8*)(W1i + off);
       if (three) {
         const bf16x8 al = *(const bf16x8*)(W1i + WB + off);
-        ht = occf_mfma_bf16_32x32x16(al, xh[ks], ht);
-        ht = occf_mfma_bf16_32x32x16(ah, xl[ks], ht);
+        hu = occf_mfma_bf16_32x32x16(al, xh[ks], hu);
+        hv = occf_mfma_bf16_32x32x16(ah, xl[ks], hv);
+        ht = occf_mfma_bf16_32x32x16(ah, xh[ks], ht);
+      } else if (ks & 1) {
+        hu = occf_mfma_bf16_32x32x16(ah, xh[ks], hu);
+      } else {
+        ht = occf_mfma_bf16_32x32x16(ah, xh[ks], ht);
       }
-      ht = occf_mfma_bf16_32x32x16(ah, xh[ks], ht);
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ht[r] = (hu[r] + hv[r]) + ht[r];
     // ---- bias + activation in registers; registers r = 8 s2 + e are the k values of GEMM2's step s2
     bf16x8 hh[2], hl[2];
 #pragma unroll
@@ -231,20 +238,25 @@ __global__ void __launch_bounds__(256) mlp_chain_kernel(MlpChainArgs p) {
       }
       mc_split8(v, hh[s2], hl[s2]);
     }
-    // ---- GEMM2: Ot += W2g . Ht
+    // ---- GEMM2: Ot += W2g . Ht   (consecutive MFMAs go to different output tiles)
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 ah[CT], al[CT];
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
+      for (int ct = 0; ct < CT; ++ct) {
         const int off = (ct * 2 + s2) * 1024 + li * 32 + lk * 16;
-        const bf16x8 ah = *(const bf16x8*)(W2i + off);
-        if (three) {
-          const bf16x8 al = *(const bf16x8*)(W2i + WB + off);
-          acc[ct] = occf_mfma_bf16_32x32x16(al, hh[s2], acc[ct]);
-          acc[ct] = occf_mfma_bf16_32x32x16(ah, hl[s2], acc[ct]);
-        }
-        acc[ct] = occf_mfma_bf16_32x32x16(ah, hh[s2], acc[ct]);
+        ah[ct] = *(const bf16x8*)(W2i + off);
+        if (three) al[ct] = *(const bf16x8*)(W2i + WB + off);
       }
+      if (three) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = occf_mfma_bf16_32x32x16(al[ct], hh[s2], acc[ct]);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = occf_mfma_bf16_32x32x16(ah[ct], hl[s2], acc[ct]);
+      }
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct] = occf_mfma_bf16_32x32x16(ah[ct], hh[s2], acc[ct]);
+    }
     __syncthreads();                                  // every wave is done with both weight tiles and b1s
     commit_w1();
     commit_w2();

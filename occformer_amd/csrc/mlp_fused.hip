@@ -377,7 +377,8 @@ extern "C" int occf_mlp_fused_fwd(const float* x, const float* ln_gamma, const f
     const char* e = getenv("OCCF_MLP_CHAIN");
     return e ? atoi(e) != 0 : true;
   }();
-  if (chain && (C == 128 || C == 192)) {
+  // (C = 128: the LDS-resident kernel below already runs two workgroups per CU at ~1 PF; measured equal or faster)
+  if (chain && C == 192) {
     const int rc = occf_mlp_chain_launch(x, ln_gamma, ln_beta, w1_hi, w1_lo, b1, w2_hi, w2_lo, b2, out, M, C, H, act,
                                          ln_mode, eps, terms, (hipStream_t)stream);
     if (rc != OCCF_ESHAPE) return rc;
