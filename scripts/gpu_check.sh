@@ -34,7 +34,7 @@ if [ "${PMC:-0}" = "1" ]; then
     timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_$c.log 2>&1 ; echo "pmc $c rc=$?"
   done
   cd $R
-  python scripts/summarize_pmc.py $O > $O/pmc_summary.txt 2>&1 ; head -30 $O/pmc_summary.txt
+  python scripts/summarize_pmc.py $O $O/pmc_traffic.json > $O/pmc_summary.txt 2>&1 ; head -30 $O/pmc_summary.txt
   find $O -name "*counter_collection.csv" -size +30M -delete 2>/dev/null
 fi
 # keep the merged-back artefacts small

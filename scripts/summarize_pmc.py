@@ -7,9 +7,13 @@ import os
 import sys
 from collections import defaultdict
 
+import json
+
 root = sys.argv[1]
 agg = defaultdict(lambda: defaultdict(float))
 calls = defaultdict(int)
+per_grid = defaultdict(lambda: defaultdict(float))      # (kernel, grid) -> counter sums
+per_grid_calls = defaultdict(int)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(os.path.join(root, f"pmc_{c}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -17,10 +21,25 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 continue
             k = r["Kernel_Name"]
             agg[k][c] += float(r["Counter_Value"])
+            g = int(float(r.get("Grid_Size", 0) or 0))
+            per_grid[(k, g)][c] += float(r["Counter_Value"])
             if c == "FETCH_SIZE":
                 calls[k] += 1
+                per_grid_calls[(k, g)] += 1
 print(f"{'kernel':80s} {'calls':>6s} {'fetch_MB/call':>14s} {'fetch_x2':>10s} {'write_MB/call':>14s}")
 for k, v in sorted(agg.items(), key=lambda kv: -(kv[1]['FETCH_SIZE'] + kv[1]['WRITE_SIZE']))[:40]:
     n = max(calls[k], 1)
     fe, wr = v["FETCH_SIZE"] * 1024 / n / 1e6, v["WRITE_SIZE"] * 1024 / n / 1e6
     print(f"{k[:80]:80s} {n:6d} {fe:14.2f} {2 * fe:10.2f} {wr:14.2f}")
+
+# machine-readable: bytes per launch per (kernel, grid); FETCH_SIZE x2 (gfx950 correction), KiB -> bytes
+if len(sys.argv) > 2:
+    rows = []
+    for (k, g), v in per_grid.items():
+        n = max(per_grid_calls[(k, g)], 1)
+        rows.append(dict(kernel=k, grid=g, calls=n, fetch_bytes=2 * v["FETCH_SIZE"] * 1024 / n,
+                         write_bytes=v["WRITE_SIZE"] * 1024 / n))
+    rows.sort(key=lambda r: -(r["fetch_bytes"] + r["write_bytes"]) * r["calls"])
+    json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per launch; "
+                        "fetch_bytes = 2 x FETCH_SIZE KiB x 1024 (MI355X_MICROARCH.md gfx950 correction)",
+                   kernels=rows[:200]), open(sys.argv[2], "w"), indent=1)
