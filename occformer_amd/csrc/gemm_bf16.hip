@@ -432,7 +432,11 @@ static int launch_gemm_b(GemmArgsB a, int terms, float* workspace, long workspac
   if (terms != 1 && terms != 3) return OCCF_EINVAL;
   if (terms == 3 && a.Wl == nullptr) return OCCF_EINVAL;
   const int mt = occf_cdiv(a.M, GB_BM);
-  const bool wide = (a.N % 128 == 0) || a.N > 512;
+  static const int bn_env = [] {
+    const char* e = getenv("OCCF_GEMM_BN");      // diagnostics: force the tile width (64 / 128)
+    return e ? atoi(e) : 0;
+  }();
+  const bool wide = bn_env == 64 ? false : bn_env == 128 ? true : ((a.N % 128 == 0) || a.N > 512);
   a.ksplit = (workspace && a.hm_dh == 0 && !a.gn_partial) ? occf_pick_ksplit(a.M, a.N, a.K, wide, workspace_floats) : 1;
   if (a.gn_partial && (a.N % 4 || a.ldc % 4)) return OCCF_ESHAPE;
   a.slab = workspace;

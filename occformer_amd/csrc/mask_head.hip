@@ -136,24 +136,52 @@ __global__ void __launch_bounds__(XA_QPB) masked_xattn_partial_kernel(
     }
     __syncthreads();
     if (!valid) continue;
-    for (int r = 0; r < nt; ++r) {
-      if (brow != nullptr && brow[t0 + r]) continue;
-      const float* kr = &lds_k[r * XA_HD];
-      float s = 0.f;
+    // groups of 8 keys, branch-free: masked / out-of-range keys get a score of -inf (weight exp(-inf) = 0),
+    // one running-max update and one rescale of the accumulators per group
+    for (int r0 = 0; r0 < nt; r0 += 8) {
+      unsigned long long mbits = 0;                     // byte j != 0  <=>  key r0 + j is masked out
+      if (brow != nullptr) {
+        const uint8_t* bp = brow + t0 + r0;
+        if ((((unsigned long long)bp) & 7ull) == 0 && r0 + 8 <= nt) {
+          mbits = *(const unsigned long long*)bp;
+        } else {
 #pragma unroll
-      for (int d = 0; d < XA_HD; ++d) s = fmaf(qr[d], kr[d], s);
-      if (s > m) {
-        const float c = expf(m - s);       // m = -inf on first hit -> c = 0
-        l *= c;
-#pragma unroll
-        for (int d = 0; d < XA_HD; ++d) o[d] *= c;
-        m = s;
+          for (int j = 0; j < 8; ++j)
+            if (r0 + j < nt && bp[j]) mbits |= 0xFFull << (8 * j);
+        }
       }
-      const float p = expf(s - m);
-      l += p;
-      const float* vr = &lds_v[r * XA_HD];
+      float sc[8];
+      float mt = -INFINITY;
 #pragma unroll
-      for (int d = 0; d < XA_HD; ++d) o[d] = fmaf(p, vr[d], o[d]);
+      for (int j = 0; j < 8; ++j) {
+        const int r = r0 + j < nt ? r0 + j : nt - 1;
+        const float* kr = &lds_k[r * XA_HD];
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int d = 0; d < XA_HD; d += 2) {
+          a0 = fmaf(qr[d], kr[d], a0);
+          a1 = fmaf(qr[d + 1], kr[d + 1], a1);
+        }
+        const bool ok = r0 + j < nt && ((mbits >> (8 * j)) & 0xFFull) == 0;
+        sc[j] = ok ? a0 + a1 : -INFINITY;
+        mt = fmaxf(mt, sc[j]);
+      }
+      const float m_new = fmaxf(m, mt);
+      const float m_use = m_new == -INFINITY ? 0.f : m_new;    // nothing open yet: every weight is 0
+      const float c = expf(m - m_use);                          // m = -inf -> 0
+      l *= c;
+#pragma unroll
+      for (int d = 0; d < XA_HD; ++d) o[d] *= c;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = r0 + j < nt ? r0 + j : nt - 1;
+        const float pw = expf(sc[j] - m_use);                  // -inf -> 0
+        l += pw;
+        const float* vr = &lds_v[r * XA_HD];
+#pragma unroll
+        for (int d = 0; d < XA_HD; ++d) o[d] = fmaf(pw, vr[d], o[d]);
+      }
+      m = m_new;
     }
   }
   if (!valid) return;
