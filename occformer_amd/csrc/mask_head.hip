@@ -125,16 +125,38 @@ __global__ void __launch_bounds__(XA_QPB) masked_xattn_partial_kernel(
   const int k0 = ck * chunk;
   const int k1 = (k0 + chunk < L) ? k0 + chunk : L;
   const uint8_t* brow = valid && use_mask ? blocked + ((long)b * Q + qi) * L : nullptr;
+  // K / V tiles: 4 + 4 float4 per thread, fetched as one unconditional batch (rows past the end of the chunk
+  // read the last valid key) one tile AHEAD of the tile being multiplied
+  float4 rk[4], rv[4];
+  auto fetch_tile = [&](int t0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = threadIdx.x + i * XA_QPB;
+      const int r = idx >> 3, c4 = (idx & 7) * 4;
+      int key = t0 + r;
+      key = key < k1 ? key : k1 - 1;
+      key = key < k0 ? k0 : key;
+      const long src = ((long)b * L + key) * E + h * XA_HD + c4;
+      rk[i] = *(const float4*)(k + src);
+      rv[i] = *(const float4*)(v + src);
+    }
+  };
+  auto commit_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = threadIdx.x + i * XA_QPB;
+      const int r = idx >> 3, c4 = (idx & 7) * 4;
+      *(float4*)(&lds_k[r * XA_HD + c4]) = rk[i];
+      *(float4*)(&lds_v[r * XA_HD + c4]) = rv[i];
+    }
+  };
+  fetch_tile(k0);
   for (int t0 = k0; t0 < k1; t0 += XA_TILE) {
     const int nt = (k1 - t0 < XA_TILE) ? k1 - t0 : XA_TILE;
+    __syncthreads();                       // the previous tile has been consumed
+    commit_tile();
     __syncthreads();
-    for (int idx = threadIdx.x; idx < nt * (XA_HD / 4); idx += XA_QPB) {
-      const int r = idx >> 3, c4 = (idx & 7) * 4;
-      const long src = ((long)b * L + t0 + r) * E + h * XA_HD + c4;
-      *(float4*)(&lds_k[r * XA_HD + c4]) = *(const float4*)(k + src);
-      *(float4*)(&lds_v[r * XA_HD + c4]) = *(const float4*)(v + src);
-    }
-    __syncthreads();
+    fetch_tile(t0 + XA_TILE);              // next tile (clamped: a harmless re-read after the last one)
     if (!valid) continue;
     // groups of 8 keys, branch-free: masked / out-of-range keys get a score of -inf (weight exp(-inf) = 0),
     // one running-max update and one rescale of the accumulators per group
