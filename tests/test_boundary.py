@@ -92,3 +92,45 @@ def test_two_rank_gloo(tmp_path):
     outs = [p.communicate(timeout=180) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert outs[0][0].strip().splitlines()[-1] == "OK 7 2.0 2"
+
+
+def test_detector_forward_train_and_test_wiring(be, monkeypatch):
+    """OccupancyFormer built from the (tiny) reference-style config: forward(return_loss=True) returns the
+    reference's loss dictionary (depth + 3 x (n_layers + 1) head losses + lidarseg metric), forward(return_loss=
+    False) the test dictionary -- through the kernels under test (host emulation on CPU, gfx950 with -m gpu)."""
+    import occformer_amd.ops as ops_mod
+    from occformer_amd.registry import build_model
+    from tests import paramgen, tinycfg
+    monkeypatch.setattr(ops_mod, "_ops", be.ops)
+    cfg, meta = tinycfg.tiny_nusc()
+    cfg = dict(cfg)
+    cfg["train_cfg"] = dict(pts=dict(
+        num_points=128, oversample_ratio=3.0, importance_sample_ratio=0.75,
+        assigner=dict(type="MaskHungarianAssigner", cls_cost=dict(type="ClassificationCost", weight=2.0),
+                      mask_cost=dict(type="CrossEntropyLossCost", weight=5.0, use_sigmoid=True),
+                      dice_cost=dict(type="DiceCost", weight=5.0, pred_act=True, eps=1.0)),
+        sampler=dict(type="MaskPseudoSampler")))
+    model = build_model(cfg).eval().to(be.device)
+    B, N = 1, 3
+    H, W = meta["input_size"]
+    cams = paramgen.camera_rig(B, N, H, W, meta["focal"], seed=3)
+    x = paramgen.tensor("ft_x", (B, N, 32, meta["fH"], meta["fW"]), 3)
+    gt_depth = paramgen.uniform("ft_d", (B, N, H, W), 3) * 12.0
+    gt_depth = torch.where(paramgen.uniform("ft_k", (B, N, H, W), 3) < 0.05, gt_depth, torch.zeros(()))
+    img_inputs = [t.to(be.device) for t in (x, *cams, gt_depth)]
+    occ = tuple(meta["occ_size"])
+    gt_occ = (paramgen.uniform("ft_occ", (B,) + tuple(o // 4 for o in occ), 3) * 6).long()
+    gt_occ = gt_occ.repeat_interleave(4, 1).repeat_interleave(4, 2).repeat_interleave(4, 3).to(be.device)
+    lo, hi = torch.tensor(meta["pc_range"][:3]), torch.tensor(meta["pc_range"][3:])
+    pts = paramgen.uniform("ft_p", (200, 3), 3) * (hi - lo) + lo
+    pts = torch.cat((pts, (paramgen.uniform("ft_l", (200, 1), 3) * 16).floor() + 1), 1).to(be.device)
+    metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])]
+    with torch.no_grad():
+        losses = model(return_loss=True, img_metas=metas, img_inputs=img_inputs, gt_occ=gt_occ, points_occ=[pts])
+        out = model(return_loss=False, img_metas=metas, img_inputs=img_inputs, points_occ=[pts], gt_occ=gt_occ)
+    n_dec = meta["dec_layers"]
+    expect = {"loss_depth", "loss_cls", "loss_mask", "loss_dice", "point_mean_iou"} | \
+        {f"d{i}.{k}" for i in range(n_dec) for k in ("loss_cls", "loss_mask", "loss_dice")}
+    assert set(losses) == expect
+    assert all(torch.isfinite(torch.as_tensor(v)).all() for v in losses.values())
+    assert out["output_voxels"].shape[-3:] == occ and out["output_points"] is not None

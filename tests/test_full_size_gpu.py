@@ -36,14 +36,19 @@ def test_linear_large(hip):
     assert _rel(out, F.linear(x, w, b)) < 1e-4
 
 
-def test_lift_splat_r50_mass_conservation(hip):
-    """sum over voxels == sum over kept points of depth*feat, at the full R50 frustum on the 200-grid"""
+@pytest.mark.parametrize("name,input_size,focal", [("r50", (256, 704), 557.0), ("r101", (896, 1600), 1266.0)])
+def test_lift_splat_mass_conservation(hip, name, input_size, focal):
+    """sum over voxels == sum over kept points of depth*feat, at the full frustum on the 200-grid:
+    R50 (6 x 112 x 16 x 44 = 473 088 points) and R101 (6 x 112 x 56 x 100 = 3 763 200 points; the 1.93 GB
+    lifted volume of BASELINE config 5 that is never materialised)"""
     from occformer_amd.view_transformer import build_voxel_csr, pack_cameras
     from bench import synthetic_sample
     from occformer_amd import configs
     _, meta = configs.nusc_r50("200")
+    meta = dict(meta, input_size=input_size, focal=focal, fH=input_size[0] // 16, fW=input_size[1] // 16)
     img_inputs, _, _ = synthetic_sample(meta, hip.device)
     cams = img_inputs[1:7]
+    fH, fW = meta["fH"], meta["fW"]
     frustum = O.make_frustum(meta["input_size"], 16, [2.0, 58.0, 0.5]).to(hip.device)
     dx, bx, nx = O.grid_constants([-50, 50, 0.5], [-50, 50, 0.5], [-5, 3, 0.5])
     X, Y, Z = 200, 200, 16
@@ -59,8 +64,8 @@ def test_lift_splat_r50_mass_conservation(hip):
     assert mism <= 2e-4 * ref.numel(), f"{mism} voxel ids differ"
     offsets, pts = build_voxel_csr(vox, X * Y * Z)
     g = torch.Generator().manual_seed(2)
-    depth = torch.randn(6, 112, 16 * 44, generator=g).softmax(1).to(hip.device)
-    feat = torch.randn(6, 16 * 44, 128, generator=g).to(hip.device)
+    depth = torch.randn(6, 112, fH * fW, generator=g).softmax(1).to(hip.device)
+    feat = torch.randn(6, fH * fW, 128, generator=g).to(hip.device)
     out = hip.ops.lift_splat_forward(depth.contiguous(), feat.contiguous(), offsets, pts, X * Y * Z)
     k = (vox >= 0).view(6, 112, -1)
     total = torch.einsum("ndp,npc->c", (depth * k).double(), feat.double())
