@@ -261,8 +261,28 @@ __global__ void __launch_bounds__(256) masked_xattn_merge_kernel(
   }
 }
 
-static int occf_xattn_chunk(int B, int L, int heads) {
-  // keys per workgroup: short enough that the per-thread serial walk stays ~10 us, while the merge
+// xattn_mfma.hip: the matrix-core variant of the partial kernel (<= 128 queries)
+void occf_xattn_mfma_launch(const float* q, const float* k, const float* v, const uint8_t* blocked,
+                            const int* row_open, float* part_o, float* part_ml, int B, int Q, int L, int E, int heads,
+                            int chunk, int n_chunks, float scale, hipStream_t st);
+
+static bool occf_xattn_use_mfma(int Q) {
+  static const bool on = [] {
+    const char* e = getenv("OCCF_XATTN_MFMA");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return on && Q <= 128;
+}
+
+static int occf_xattn_chunk(int B, int Q, int L, int heads) {
+  if (occf_xattn_use_mfma(Q)) {
+    // keys per workgroup (a multiple of the 32-key MFMA tile): long chunks amortise the query set-up,
+    // but the grid should still cover the 256 CUs about twice
+    int chunk = 1024;
+    while (chunk > 32 && (long)occf_cdiv(L, chunk) * heads * B < 512) chunk >>= 1;
+    return chunk;
+  }
+  // scalar kernel: short enough that the per-thread serial walk stays ~10 us, while the merge
   // (one wave per row, lanes over chunks) absorbs the chunk count
   int chunk = 256;
   while (chunk > XA_TILE && (long)occf_cdiv(L, chunk) * heads * B < 512) chunk >>= 1;
@@ -275,7 +295,7 @@ extern "C" int occf_masked_xattn_fwd(const float* q, const float* k, const float
                                      int E, int heads, void* stream) {
   if (B <= 0 || Q <= 0 || L <= 0 || heads <= 0 || E != heads * XA_HD) return OCCF_ESHAPE;
   // chunking: enough workgroups to fill 256 CUs, chunks a multiple of the LDS tile
-  const int chunk = occf_xattn_chunk(B, L, heads);
+  const int chunk = occf_xattn_chunk(B, Q, L, heads);
   const int n_chunks = occf_cdiv(L, chunk);
   const int qblocks = occf_cdiv(Q, XA_QPB);
   const long need = (long)B * heads * Q * n_chunks * (XA_HD + 2);
@@ -284,9 +304,13 @@ extern "C" int occf_masked_xattn_fwd(const float* q, const float* k, const float
   float* part_ml = workspace + (long)B * heads * Q * n_chunks * XA_HD;
   const float scale = (float)(1.0 / sqrt((double)XA_HD));
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(masked_xattn_partial_kernel, dim3(n_chunks * qblocks, heads, B), dim3(XA_QPB), 0, st,
-                     q, k, v, blocked, (const int*)row_open, part_o, part_ml, B, Q, L, E, heads, chunk,
-                     n_chunks, scale);
+  if (occf_xattn_use_mfma(Q))
+    occf_xattn_mfma_launch(q, k, v, blocked, (const int*)row_open, part_o, part_ml, B, Q, L, E, heads, chunk,
+                           n_chunks, scale, st);
+  else
+    hipLaunchKernelGGL(masked_xattn_partial_kernel, dim3(n_chunks * qblocks, heads, B), dim3(XA_QPB), 0, st,
+                       q, k, v, blocked, (const int*)row_open, part_o, part_ml, B, Q, L, E, heads, chunk,
+                       n_chunks, scale);
   const long total = (long)B * heads * Q * 64;
   hipLaunchKernelGGL(masked_xattn_merge_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, part_o,
                      part_ml, out, B, Q, E, heads, n_chunks);
@@ -294,7 +318,7 @@ extern "C" int occf_masked_xattn_fwd(const float* q, const float* k, const float
 }
 
 extern "C" long occf_masked_xattn_workspace(int B, int Q, int L, int heads) {
-  const int chunk = occf_xattn_chunk(B, L, heads);
+  const int chunk = occf_xattn_chunk(B, Q, L, heads);
   return (long)B * heads * Q * occf_cdiv(L, chunk) * (XA_HD + 2);
 }
 

@@ -76,7 +76,7 @@ def test_mask_pool(be, shape, target):
 
 
 @pytest.mark.parametrize("Q,L,heads,masked", [(20, 70, 3, True), (100, 300, 2, True), (7, 1500, 1, True),
-                                              (20, 64, 2, False)])
+                                              (20, 64, 2, False), (130, 90, 1, True)])
 def test_masked_attention(be, Q, L, heads, masked):
     B, E = 2, heads * 32
     q = paramgen.tensor("q", (B, Q, E), 1)
