@@ -69,7 +69,8 @@ def test_lift_splat_mass_conservation(hip, name, input_size, focal):
     out = hip.ops.lift_splat_forward(depth.contiguous(), feat.contiguous(), offsets, pts, X * Y * Z)
     k = (vox >= 0).view(6, 112, -1)
     total = torch.einsum("ndp,npc->c", (depth * k).double(), feat.double())
-    assert torch.allclose(out.double().sum(0), total, rtol=1e-6, atol=1e-6)
+    # per-voxel sums are fp32 (as in the reference kernel); R101 folds up to ~1100 points into a voxel
+    assert torch.allclose(out.double().sum(0), total, rtol=1e-5, atol=1e-4)
     assert int((out.abs().sum(1) > 0).sum()) == int((offsets[1:] > offsets[:-1]).sum())
 
 
