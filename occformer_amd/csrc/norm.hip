@@ -257,11 +257,58 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* __restrict_
   }
 }
 
+// C = 64 * NV (128 / 192 / 256): 16 lanes per row, NV float4 per lane, 4 rows per wave -- every lane is busy
+// (one wave per row leaves half of them idle at C = 128) and a lane's NV loads are in flight together
+template <int NV>
+__global__ void __launch_bounds__(256) layernorm16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ out,
+                                                          long M, float eps) {
+  constexpr int C = 64 * NV;
+  const int sub = threadIdx.x & 15;
+  const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const long rc = row < M ? row : M - 1;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    v[j] = *(const float4*)(x + rc * C + (sub + 16 * j) * 4);
+    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
+  float q2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+    q2 += (a * a + b * b) + (c * c + d * d);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) q2 += __shfl_xor(q2, o);
+  const float rstd = 1.0f / sqrtf(q2 / (float)C + eps);
+  if (row >= M) return;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c0 = (sub + 16 * j) * 4;
+    const float4 g = *(const float4*)(gamma + c0);
+    const float4 bb = *(const float4*)(beta + c0);
+    *(float4*)(out + row * C + c0) =
+        make_float4((v[j].x - mean) * rstd * g.x + bb.x, (v[j].y - mean) * rstd * g.y + bb.y,
+                    (v[j].z - mean) * rstd * g.z + bb.z, (v[j].w - mean) * rstd * g.w + bb.w);
+  }
+}
+
 extern "C" int occf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* out,
                                   long M, int C, float eps, void* stream) {
   if (M <= 0 || C % 4 != 0 || C > 64 * 4 * LN_MAXV) return OCCF_ESHAPE;
-  hipLaunchKernelGGL(layernorm_kernel, dim3(occf_cdiv(M * 64, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                     gamma, beta, out, M, C, eps);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g16(occf_cdiv(M * 16, 256));
+  if (C == 128) hipLaunchKernelGGL(layernorm16_kernel<2>, g16, dim3(256), 0, st, x, gamma, beta, out, M, eps);
+  else if (C == 192) hipLaunchKernelGGL(layernorm16_kernel<3>, g16, dim3(256), 0, st, x, gamma, beta, out, M, eps);
+  else if (C == 256) hipLaunchKernelGGL(layernorm16_kernel<4>, g16, dim3(256), 0, st, x, gamma, beta, out, M, eps);
+  else
+    hipLaunchKernelGGL(layernorm_kernel, dim3(occf_cdiv(M * 64, 256)), dim3(256), 0, st, x, gamma, beta, out, M, C,
+                       eps);
   OCCF_LAUNCH_CHECK();
 }
 

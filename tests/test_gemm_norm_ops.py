@@ -106,7 +106,7 @@ def test_groupnorm(be, C, G, shape):
     assert torch.allclose(outr.permute(0, 4, 1, 2, 3), ref + res, **TOL)
 
 
-@pytest.mark.parametrize("C", [32, 192, 1024])
+@pytest.mark.parametrize("C", [32, 128, 192, 256, 1024])
 def test_layernorm(be, C):
     x = paramgen.tensor("lx", (37, C), 1, 3.0) + 1.0
     g = 1 + 0.2 * paramgen.tensor("lg", (C,), 2)
