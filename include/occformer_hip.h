@@ -76,6 +76,17 @@ int occf_window_attn_fwd(const float* qkv, const float* qkv_bias, const float* b
                          float* out, int B, int X, int Y, int S, int C, int heads, int shift,
                          void* stream);
 
+/* Attention half of the shared SwinBlock fused (embed_dims 128, 4 heads, 7x7 windows):
+ * out = x + proj(WindowMSA(LayerNorm(x)))  -- P/occformer/backbones/modules/window_attention.py:346-372 (first
+ * residual), :69-107, :168-242.  x/out[B*X*Y*S, 128] token rows as in occf_window_attn_fwd; wqkv[384, 128] and
+ * wproj[128, 128] pre-split bf16 (hi, lo); bias_table[(2*7-1)^2, 4].  x must not alias out.  Returns OCCF_ESHAPE
+ * (-2) for other widths (the caller composes layernorm / linear / window_attn / linear). */
+int occf_swin_attn_fused_fwd(const float* x, const float* ln_gamma, const float* ln_beta, float eps,
+                             const uint16_t* wqkv_hi, const uint16_t* wqkv_lo, const float* bqkv,
+                             const float* bias_table, const uint16_t* wproj_hi, const uint16_t* wproj_lo,
+                             const float* bproj, float* out, int B, int X, int Y, int S, int C, int heads,
+                             int shift, void* stream);
+
 /* ------------------------------------------------------------------ pixel decoder ------ */
 
 /* Sampling core of MultiScaleDeformableAttention3D: replaces the location arithmetic, the

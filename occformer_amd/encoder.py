@@ -96,6 +96,16 @@ class SwinBlock(nn.Module):
         B, X, Y, S, C = tok.shape
         t = tok.reshape(-1, C)
         m = self.attn.w_msa
+        ops = get_ops()
+        y = None
+        if m.qkv.bias is not None and m.proj.bias is not None:
+            y = ops.swin_attention_fused(t, self.norm1.weight.detach(), self.norm1.bias.detach(), self.norm1.eps,
+                                         fused.split_weight(m.qkv.weight), m.qkv.bias.detach(),
+                                         m.relative_position_bias_table.detach(), fused.split_weight(m.proj.weight),
+                                         m.proj.bias.detach(), B, X, Y, S, self.heads, self.attn.shift_size)
+        if y is not None:
+            t = fused.mlp(y, self.ffn.layers[0][0], self.ffn.layers[1], act=2, ln=self.norm2, ln_mode=1)
+            return t.view(B, X, Y, S, C)
         qkv = fused.linear(fused.layernorm(t, self.norm1), m.qkv)
         a = get_ops().window_attention(qkv, m.qkv.bias.detach(), m.relative_position_bias_table.detach(),
                                        B, X, Y, S, self.heads, self.attn.shift_size)

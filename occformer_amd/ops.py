@@ -32,6 +32,7 @@ class HipOps:
         # fused mask-GEMM + pooling (skips writing intermediate mask logits): measured slower than
         # GEMM + pooling kernel on MI355X in round 1 (atomicMax rate), so off by default
         self.use_fused_mask_pool = os.environ.get("OCCF_FUSED_MASK_POOL", "1") == "1"
+        self.use_fused_swin = os.environ.get("OCCF_FUSED_SWIN", "1") == "1"
         self.use_fused_mlp = os.environ.get("OCCF_FUSED_MLP", "1") == "1"
 
     # ------------------------------------------------------------------ plumbing
@@ -120,6 +121,26 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ pixel decoder
+    def swin_attention_fused(self, x, ln_w, ln_b, eps, wqkv_split, bqkv, bias_table, wproj_split, bproj, B, X, Y, S,
+                             heads, shift):
+        """x [B*X*Y*S, C] -> x + proj(window_msa(layernorm(x))) in one kernel, or None when the shape / precision
+        mode is outside the fused kernel (C = 128, 4 heads, 3-term split)."""
+        C = x.shape[1]
+        if not self.use_fused_swin or self.precision != "bf16x3" or C != 128 or heads != 4 or wqkv_split is None:
+            return None
+        out = torch.empty_like(x)
+        self.last_flops = 2 * x.shape[0] * C * 4 * C + 4 * x.shape[0] * 49 * C
+        rc = self.lib.occf_swin_attn_fused_fwd(
+            self._ptr(x, self.f32), self._ptr(ln_w, self.f32), self._ptr(ln_b, self.f32), float(eps),
+            self._ptr(wqkv_split[0]), self._ptr(wqkv_split[1]), self._ptr(bqkv, self.f32),
+            self._ptr(bias_table, self.f32), self._ptr(wproj_split[0]), self._ptr(wproj_split[1]),
+            self._ptr(bproj, self.f32), self._ptr(out), B, X, Y, S, C, heads, int(shift), self._stream())
+        if rc == -2:
+            return None
+        if rc != 0:
+            raise OccfError(f"occf_swin_attn_fused_fwd failed with code {rc}")
+        return out
+
     def msda3d(self, value, offsets, logits, level_shapes, heads, points, head_major=False):
         """value [B, Nq, E] (or [B, heads, Nq, E/heads] with head_major); offsets [B, Nq, heads*L*P*3];
         logits [B, Nq, heads*L*P] -> [B, Nq, E].  offsets / logits may be column slices of one tensor

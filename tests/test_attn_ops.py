@@ -163,3 +163,29 @@ def test_mask_gemm_pool_declines_non_uniform_windows(be, monkeypatch, shape, tar
     me = paramgen.tensor("me", (1, 5, 64), 1)
     feat = paramgen.tensor("mf", (1, X * Y * Z, 64), 2)
     assert be.ops.mask_gemm_pool(be.to(me), be.ops.split_bf16(be.to(feat)), shape, target) is None
+
+
+@pytest.mark.parametrize("X,Y,S,shift,B", [(14, 14, 3, 0, 1), (10, 9, 2, 3, 2), (7, 16, 1, 3, 1), (5, 5, 2, 0, 1)])
+def test_swin_attention_fused(be, monkeypatch, X, Y, S, shift, B):
+    """x + proj(window_msa(layernorm(x))) in one kernel == the oracle's LayerNorm -> ShiftWindowMSA -> residual
+    (C = 128 / 4 heads; padded, shifted and partial windows)"""
+    monkeypatch.setattr(be.ops, "precision", "bf16x3")
+    C, heads = 128, 4
+    sd = {"a.w_msa.qkv.weight": paramgen.tensor("fqkvw", (3 * C, C), 1, C ** -0.5),
+          "a.w_msa.qkv.bias": paramgen.tensor("fqkvb", (3 * C,), 1, 0.3),
+          "a.w_msa.proj.weight": paramgen.tensor("fpw", (C, C), 1, C ** -0.5),
+          "a.w_msa.proj.bias": paramgen.tensor("fpb", (C,), 1, 0.2),
+          "a.w_msa.relative_position_bias_table": paramgen.tensor("ftab", (169, heads), 1, 0.5)}
+    g = 1 + 0.2 * paramgen.tensor("flg", (C,), 2)
+    bt = 0.1 * paramgen.tensor("flb", (C,), 3)
+    x = paramgen.tensor("ftok", (B * S, X * Y, C), 2, 2.0) + 0.5           # (b s) (x y) c
+    ref = x + O.shift_window_msa(sd, "a.", F.layer_norm(x, (C,), g, bt, 1e-5), X, Y, heads, shift)
+    xk = x.view(B, S, X, Y, C).permute(0, 2, 3, 1, 4).reshape(-1, C).contiguous()
+    ops = be.ops
+    wq, wp = be.to(sd["a.w_msa.qkv.weight"], sd["a.w_msa.proj.weight"])
+    out = ops.swin_attention_fused(be.to(xk), *be.to(g, bt), 1e-5, ops.split_bf16(wq), be.to(sd["a.w_msa.qkv.bias"]),
+                                   be.to(sd["a.w_msa.relative_position_bias_table"]), ops.split_bf16(wp),
+                                   be.to(sd["a.w_msa.proj.bias"]), B, X, Y, S, heads, shift)
+    assert out is not None
+    out = out.cpu().view(B, X, Y, S, C).permute(0, 3, 1, 2, 4).reshape(B * S, X * Y, C)
+    assert torch.allclose(out, ref, atol=2e-4, rtol=2e-4), float((out - ref).abs().max())
