@@ -183,19 +183,32 @@ __global__ void __launch_bounds__(256) swin_attn_fused_kernel(SwinAttnArgs p) {
 
   // ---- projections of this head, one matrix at a time (keeps the accumulator footprint at two tiles):
   // Qt / Kt (lane = token, registers = channel d) and V (lane = channel d, registers = token), two 32-token tiles
+  // The weight fragments come straight from global memory (L2) in operand layout; a matrix' 16 fragments are
+  // fetched as ONE batch, one matrix ahead of the MFMAs that use them (one wave per SIMD: nothing else would
+  // hide 24 dependent L2 round trips).  Matrix 3 = proj, consumed after the attention.
   bf16x8 qfh[2][2], qfl[2][2], kfh[2][2], kfl[2][2], vfh[2][2], vfl[2][2];
+  bf16x8 wfh[2][8], wfl[2][8];
+  auto fetch_w = [&](int mat, int buf) __attribute__((always_inline)) {
+    const uint16_t* bh = mat < 3 ? p.Wqkv_h + ((long)(mat * C + head * SF_HD + li)) * C : p.Wp_h + ((long)(wave * 32 + li)) * C;
+    const uint16_t* bl = mat < 3 ? p.Wqkv_l + ((long)(mat * C + head * SF_HD + li)) * C : p.Wp_l + ((long)(wave * 32 + li)) * C;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      wfh[buf][ks] = *(const bf16x8*)(bh + lk * 8 + ks * 16);
+      wfl[buf][ks] = *(const bf16x8*)(bl + lk * 8 + ks * 16);
+    }
+  };
+  fetch_w(0, 0);
 #pragma unroll
   for (int mat = 0; mat < 3; ++mat) {
+    fetch_w(mat + 1, (mat + 1) & 1);
     f32x16 acc[2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
-    const uint16_t* w_h = p.Wqkv_h + ((long)(mat * C + head * SF_HD + li)) * C + lk * 8;
-    const uint16_t* w_l = p.Wqkv_l + ((long)(mat * C + head * SF_HD + li)) * C + lk * 8;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const bf16x8 wh = *(const bf16x8*)(w_h + ks * 16), wl = *(const bf16x8*)(w_l + ks * 16);
+      const bf16x8 wh = wfh[mat & 1][ks], wl = wfl[mat & 1][ks];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int off = ks * 2048 + (tt * 32 + li) * 32 + lk * 16;
@@ -312,20 +325,16 @@ __global__ void __launch_bounds__(256) swin_attn_fused_kernel(SwinAttnArgs p) {
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ao[tt][r] = 0.f;
-  {
-    const uint16_t* wp_h = p.Wp_h + ((long)(wave * 32 + li)) * C + lk * 8;
-    const uint16_t* wp_l = p.Wp_l + ((long)(wave * 32 + li)) * C + lk * 8;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const bf16x8 wh = *(const bf16x8*)(wp_h + ks * 16), wl = *(const bf16x8*)(wp_l + ks * 16);
+  for (int ks = 0; ks < 8; ++ks) {
+    const bf16x8 wh = wfh[1][ks], wl = wfl[1][ks];      // proj fragments, fetched before the attention
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int off = ks * 2048 + (tt * 32 + li) * 32 + lk * 16;
-        const bf16x8 oh = *(const bf16x8*)(img_h + off), ol = *(const bf16x8*)(img_l + off);
-        ao[tt] = occf_mfma_bf16_32x32x16(wl, oh, ao[tt]);
-        ao[tt] = occf_mfma_bf16_32x32x16(wh, ol, ao[tt]);
-        ao[tt] = occf_mfma_bf16_32x32x16(wh, oh, ao[tt]);
-      }
+    for (int tt = 0; tt < 2; ++tt) {
+      const int off = ks * 2048 + (tt * 32 + li) * 32 + lk * 16;
+      const bf16x8 oh = *(const bf16x8*)(img_h + off), ol = *(const bf16x8*)(img_l + off);
+      ao[tt] = occf_mfma_bf16_32x32x16(wl, oh, ao[tt]);
+      ao[tt] = occf_mfma_bf16_32x32x16(wh, ol, ao[tt]);
+      ao[tt] = occf_mfma_bf16_32x32x16(wh, oh, ao[tt]);
     }
   }
 #pragma unroll
