@@ -51,10 +51,7 @@ __device__ __forceinline__ float ch_bf16_up(uint32_t h) {
 #endif
 }
 __device__ __forceinline__ void ch_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-  const uint32_t ha = ch_bf16_rne(a), hb = ch_bf16_rne(b);
-  const uint32_t la = ch_bf16_rne(a - ch_bf16_up(ha)), lb = ch_bf16_rne(b - ch_bf16_up(hb));
-  hi = ha | (hb << 16);
-  lo = la | (lb << 16);
+  occf_bf16_split2(a, b, hi, lo);
 }
 __device__ __forceinline__ int ch_slot(int row, int kslot) { return row * 64 + ((kslot ^ ((row >> 2) & 3)) << 4); }
 __device__ __forceinline__ float ch_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -72,10 +72,7 @@ __device__ __forceinline__ float occf_bf16_up(uint32_t h) {
 }
 // two fp32 -> packed (hi pair, lo pair)
 __device__ __forceinline__ void occf_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-  const uint32_t ha = occf_bf16_rne(a), hb = occf_bf16_rne(b);
-  const uint32_t la = occf_bf16_rne(a - occf_bf16_up(ha)), lb = occf_bf16_rne(b - occf_bf16_up(hb));
-  hi = ha | (hb << 16);
-  lo = la | (lb << 16);
+  occf_bf16_split2(a, b, hi, lo);
 }
 __device__ __forceinline__ int occf_lds_slot(int row, int kslot) {   // byte offset inside an operand array
   return row * 64 + ((kslot ^ ((row >> 2) & 3)) << 4);

@@ -51,10 +51,7 @@ __device__ __forceinline__ float mg_bf16_up(uint32_t h) {
 #endif
 }
 __device__ __forceinline__ void mg_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
-  const uint32_t ha = mg_bf16_rne(a), hb = mg_bf16_rne(b);
-  const uint32_t la = mg_bf16_rne(a - mg_bf16_up(ha)), lb = mg_bf16_rne(b - mg_bf16_up(hb));
-  hi = ha | (hb << 16);
-  lo = la | (lb << 16);
+  occf_bf16_split2(a, b, hi, lo);
 }
 __device__ __forceinline__ int mg_slot(int row, int kslot) { return row * 64 + ((kslot ^ ((row >> 2) & 3)) << 4); }
 __device__ __forceinline__ float occf_nanmax_mg(float m, float v) { return (v > m || v != v) ? v : m; }

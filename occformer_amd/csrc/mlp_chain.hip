@@ -64,11 +64,15 @@ __device__ __forceinline__ uint32_t mc_bf16_rne(float x) {
 }
 // 8 fp32 -> bf16x8 hi and lo
 __device__ __forceinline__ void mc_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  uint32_t h[4], l[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const uint32_t h = mc_bf16_rne(v[e]);
-    hi[e] = (short)h;
-    lo[e] = (short)mc_bf16_rne(v[e] - mc_from_bits(h << 16));
+  for (int e = 0; e < 4; ++e) occf_bf16_split2(v[2 * e], v[2 * e + 1], h[e], l[e]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[2 * e] = (short)(h[e] & 0xFFFFu);
+    hi[2 * e + 1] = (short)(h[e] >> 16);
+    lo[2 * e] = (short)(l[e] & 0xFFFFu);
+    lo[2 * e + 1] = (short)(l[e] >> 16);
   }
 }
 __device__ __forceinline__ float mc_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -43,6 +43,47 @@ __device__ __forceinline__ float occf_fadd(float a, float b) { return __fadd_rn(
 
 #define OCCF_WAVE 64
 
+// ---- fp32 -> bf16 (round to nearest even) and the (hi, lo) split a = hi + lo used by the 3-term products.
+// gfx950 converts two values per v_cvt_pk_bf16_f32; the host emulation uses the integer formulation (same
+// results for finite inputs).
+#ifdef OCCF_EMU
+static inline uint32_t occf_f2u(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  return u;
+}
+static inline float occf_u2f(uint32_t u) {
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static inline uint32_t occf_bf16_1(float x) {
+  const uint32_t u = occf_f2u(x);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+static inline uint32_t occf_bf16_pack2(float a, float b) { return occf_bf16_1(a) | (occf_bf16_1(b) << 16); }
+#else
+typedef float occf_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 occf_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t occf_f2u(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ float occf_u2f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t occf_bf16_pack2(float a, float b) {
+  const occf_f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, occf_bf16x2));
+}
+__device__ __forceinline__ uint32_t occf_bf16_1(float x) { return occf_bf16_pack2(x, 0.f) & 0xFFFFu; }
+#endif
+// (a, b) -> packed hi pair and packed lo pair (lo = bf16(x - hi))
+#ifdef OCCF_EMU
+static inline
+#else
+__device__ __forceinline__
+#endif
+void occf_bf16_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = occf_bf16_pack2(a, b);
+  lo = occf_bf16_pack2(a - occf_u2f(hi << 16), b - occf_u2f(hi & 0xFFFF0000u));
+}
+
 // error codes of the C ABI (0 = ok, >0 = hipError_t, <0 = argument error)
 #define OCCF_EINVAL (-1)
 #define OCCF_ESHAPE (-2)

@@ -63,26 +63,26 @@ __device__ __forceinline__ uint32_t sf_bf16(float x) {
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 __device__ __forceinline__ void sf_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  uint32_t h[4], l[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const uint32_t h = sf_bf16(v[e]);
-    hi[e] = (short)h;
-    lo[e] = (short)sf_bf16(v[e] - sf_from_bits(h << 16));
+  for (int e = 0; e < 4; ++e) occf_bf16_split2(v[2 * e], v[2 * e + 1], h[e], l[e]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[2 * e] = (short)(h[e] & 0xFFFFu);
+    hi[2 * e + 1] = (short)(h[e] >> 16);
+    lo[2 * e] = (short)(l[e] & 0xFFFFu);
+    lo[2 * e + 1] = (short)(l[e] >> 16);
   }
 }
 // 4 consecutive channels (c .. c+3) of token row t -> operand image [ks = c>>4][row t][slot (c>>3)&1][e = c&7]
 __device__ __forceinline__ void sf_put4(unsigned char* hi, unsigned char* lo, int t, int c, float a, float b, float cc,
                                         float d) {
-  const float f[4] = {a, b, cc, d};
-  uint32_t hb[4], lb[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    hb[e] = sf_bf16(f[e]);
-    lb[e] = sf_bf16(f[e] - sf_from_bits(hb[e] << 16));
-  }
+  uint32_t h0, l0, h1, l1;
+  occf_bf16_split2(a, b, h0, l0);
+  occf_bf16_split2(cc, d, h1, l1);
   const int off = (c >> 4) * 2048 + t * 32 + ((c >> 3) & 1) * 16 + (c & 7) * 2;
-  const sf_u2 ph = {hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
-  const sf_u2 pl = {lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16)};
+  const sf_u2 ph = {h0, h1};
+  const sf_u2 pl = {l0, l1};
   *(sf_u2*)(hi + off) = ph;
   *(sf_u2*)(lo + off) = pl;
 }

@@ -41,11 +41,15 @@ __device__ __forceinline__ uint32_t xm_bf16(float x) {
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 __device__ __forceinline__ void xm_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  uint32_t h[4], l[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const uint32_t h = xm_bf16(v[e]);
-    hi[e] = (short)h;
-    lo[e] = (short)xm_bf16(v[e] - xm_from_bits(h << 16));
+  for (int e = 0; e < 4; ++e) occf_bf16_split2(v[2 * e], v[2 * e + 1], h[e], l[e]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[2 * e] = (short)(h[e] & 0xFFFFu);
+    hi[2 * e + 1] = (short)(h[e] >> 16);
+    lo[2 * e] = (short)(l[e] & 0xFFFFu);
+    lo[2 * e + 1] = (short)(l[e] >> 16);
   }
 }
 
@@ -99,10 +103,12 @@ __global__ void __launch_bounds__(256) masked_xattn_mfma_kernel(
     {
       const float f[4] = {rk.x, rk.y, rk.z, rk.w};
       uint32_t hb[4], lb[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        hb[e] = xm_bf16(f[e]);
-        lb[e] = xm_bf16(f[e] - xm_from_bits(hb[e] << 16));
+      {
+        uint32_t h0, l0, h1, l1;
+        occf_bf16_split2(f[0], f[1], h0, l0);
+        occf_bf16_split2(f[2], f[3], h1, l1);
+        hb[0] = h0 & 0xFFFFu; hb[1] = h0 >> 16; hb[2] = h1 & 0xFFFFu; hb[3] = h1 >> 16;
+        lb[0] = l0 & 0xFFFFu; lb[1] = l0 >> 16; lb[2] = l1 & 0xFFFFu; lb[3] = l1 >> 16;
       }
       const int off = (sc >> 4) * 1024 + sr * 32 + ((sc >> 3) & 1) * 16 + (sc & 7) * 2;
       const xm_u2 ph = {hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
@@ -117,8 +123,10 @@ __global__ void __launch_bounds__(256) masked_xattn_mfma_kernel(
       const int e = ((kk >> 3) << 2) | (kk & 3), lkp = (kk >> 2) & 1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint32_t hb = xm_bf16(f[j]);
-        const uint32_t lb = xm_bf16(f[j] - xm_from_bits(hb << 16));
+        uint32_t hb, lb;
+        occf_bf16_split2(f[j], 0.f, hb, lb);
+        hb &= 0xFFFFu;
+        lb &= 0xFFFFu;
         const int off = s2 * 1024 + (sc + j) * 32 + lkp * 16 + e * 2;
         *(uint16_t*)(base + 2 * XM_IMG + off) = (uint16_t)hb;
         *(uint16_t*)(base + 3 * XM_IMG + off) = (uint16_t)lb;
