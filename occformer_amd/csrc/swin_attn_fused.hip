@@ -91,9 +91,12 @@ __device__ __forceinline__ void sf_put4(unsigned char* hi, unsigned char* lo, in
 
 __global__ void __launch_bounds__(256) swin_attn_fused_kernel(SwinAttnArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char img_h[SF_IMG], img_l[SF_IMG];   // Xn, later the heads' outputs
-  __shared__ float lds_bias[4][(2 * SF_WS - 1) * (2 * SF_WS - 1)];
+  __shared__ float lds_bias[4][256];                 // 169 entries used (index 255 = padding key, value unused)
   __shared__ int lds_tok[64];
   __shared__ int lds_reg[64];
+  // [key][query] -> relative-position-bias index (bits 0..7), shift-mask flag (bit 8), 0xFFFF = padding key;
+  // built once per window by all threads (the index arithmetic used to run per score element in every head)
+  __shared__ uint16_t lds_rel[64 * 64];
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -133,6 +136,19 @@ __global__ void __launch_bounds__(256) swin_attn_fused_kernel(SwinAttnArgs p) {
   for (int t = lane; t < (2 * SF_WS - 1) * (2 * SF_WS - 1); t += 64)
     lds_bias[wave][t] = p.bias_table[(long)t * 4 + head];
   __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int idx = tid + i * 256;
+    const int key = idx >> 6, qi = idx & 63;
+    const int krow = (key * 37) >> 8, kcol = key - krow * SF_WS;      // key / 7, key % 7 for key < 64
+    const int qrow = (qi * 37) >> 8, qcol = qi - qrow * SF_WS;
+    int v = 0xFFFF;
+    if (key < SF_T) {
+      v = qi < SF_T ? (qrow - krow + SF_WS - 1) * (2 * SF_WS - 1) + (qcol - kcol + SF_WS - 1) : 0;
+      if (shift > 0 && lds_reg[key] != lds_reg[qi]) v |= 0x100;
+    }
+    lds_rel[idx] = (uint16_t)v;
+  }
 
   // ---- LayerNorm of the window's rows -> operand image (16 lanes per row; rows without a token are zero:
   // the reference pads AFTER the norm, so their q / k / v are the projection biases)
@@ -256,8 +272,6 @@ __global__ void __launch_bounds__(256) swin_attn_fused_kernel(SwinAttnArgs p) {
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const int qi = qt * 32 + li;
-    const int qrow = (qi * 37) >> 8, qcol = qi - qrow * SF_WS;        // qi / 7, qi % 7 for qi < 64
-    const int qreg = lds_reg[qi];
     f32x16 st[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -276,15 +290,10 @@ __global__ void __launch_bounds__(256) swin_attn_fused_kernel(SwinAttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const int krow = (key * 37) >> 8, kcol = key - krow * SF_WS;
-        float a = st[kt][r];
-        if (key < SF_T) {
-          const int bi = (qrow - krow + SF_WS - 1) * (2 * SF_WS - 1) + (qcol - kcol + SF_WS - 1);
-          a += lds_bias[wave][qi < SF_T ? bi : 0];
-          if (shift > 0 && lds_reg[key] != qreg) a += -100.0f;
-        } else {
-          a = -INFINITY;
-        }
+        const int tv = lds_rel[key * 64 + qi];
+        float a = st[kt][r] + lds_bias[wave][tv & 0xFF];
+        if (tv & 0x100) a += -100.0f;
+        a = tv == 0xFFFF ? -INFINITY : a;
         st[kt][r] = a;
         mx = fmaxf(mx, a);
       }
@@ -300,7 +309,7 @@ __global__ void __launch_bounds__(256) swin_attn_fused_kernel(SwinAttnArgs p) {
         float pv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          pv[e] = expf(st[kt][s2 * 8 + e] - mx);      // padding keys: exp(-inf) = 0
+          pv[e] = __expf(st[kt][s2 * 8 + e] - mx);    // padding keys: exp(-inf) = 0
           sum += pv[e];
         }
         bf16x8 ph, pl;
