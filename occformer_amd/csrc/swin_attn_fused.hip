@@ -87,9 +87,14 @@ __device__ __forceinline__ void sf_put4(unsigned char* hi, unsigned char* lo, in
   *(sf_u2*)(lo + off) = pl;
 }
 
+#ifdef OCCF_EMU
+#define SF_WAVES2
+#else
+#define SF_WAVES2 __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
 #define SF_IMG 16384     // bytes of one [8 ks][64 rows][2 x 16 B] bf16 image (hi or lo)
 
-__global__ void __launch_bounds__(256) swin_attn_fused_kernel(SwinAttnArgs p) {
+__global__ void __launch_bounds__(256) SF_WAVES2 swin_attn_fused_kernel(SwinAttnArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char img_h[SF_IMG], img_l[SF_IMG];   // Xn, later the heads' outputs
   __shared__ float lds_bias[4][256];                 // 169 entries used (index 255 = padding key, value unused)
   __shared__ int lds_tok[64];
@@ -203,7 +208,7 @@ __global__ void __launch_bounds__(256) swin_attn_fused_kernel(SwinAttnArgs p) {
   // fetched as ONE batch, one matrix ahead of the MFMAs that use them (one wave per SIMD: nothing else would
   // hide 24 dependent L2 round trips).  Matrix 3 = proj, consumed after the attention.
   bf16x8 qfh[2][2], qfl[2][2], kfh[2][2], kfl[2][2], vfh[2][2], vfl[2][2];
-  bf16x8 wfh[2][8], wfl[2][8];
+  bf16x8 wfh[1][8], wfl[1][8];
   auto fetch_w = [&](int mat, int buf) __attribute__((always_inline)) {
     const uint16_t* bh = mat < 3 ? p.Wqkv_h + ((long)(mat * C + head * SF_HD + li)) * C : p.Wp_h + ((long)(wave * 32 + li)) * C;
     const uint16_t* bl = mat < 3 ? p.Wqkv_l + ((long)(mat * C + head * SF_HD + li)) * C : p.Wp_l + ((long)(wave * 32 + li)) * C;
@@ -213,10 +218,9 @@ __global__ void __launch_bounds__(256) swin_attn_fused_kernel(SwinAttnArgs p) {
       wfl[buf][ks] = *(const bf16x8*)(bl + lk * 8 + ks * 16);
     }
   };
-  fetch_w(0, 0);
 #pragma unroll
   for (int mat = 0; mat < 3; ++mat) {
-    fetch_w(mat + 1, (mat + 1) & 1);
+    fetch_w(mat, 0);
     f32x16 acc[2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
@@ -224,7 +228,7 @@ __global__ void __launch_bounds__(256) swin_attn_fused_kernel(SwinAttnArgs p) {
       for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const bf16x8 wh = wfh[mat & 1][ks], wl = wfl[mat & 1][ks];
+      const bf16x8 wh = wfh[0][ks], wl = wfl[0][ks];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int off = ks * 2048 + (tt * 32 + li) * 32 + lk * 16;
@@ -334,9 +338,10 @@ __global__ void __launch_bounds__(256) swin_attn_fused_kernel(SwinAttnArgs p) {
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ao[tt][r] = 0.f;
+  fetch_w(3, 0);
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
-    const bf16x8 wh = wfh[1][ks], wl = wfl[1][ks];      // proj fragments, fetched before the attention
+    const bf16x8 wh = wfh[0][ks], wl = wfl[0][ks];      // proj fragments
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       const int off = ks * 2048 + (tt * 32 + li) * 32 + lk * 16;
