@@ -415,10 +415,32 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 static int occf_pick_ksplit(long M, int N, int K, bool wide, long workspace_floats) {
   const long tiles = (long)occf_cdiv(M, GB_BM) * occf_cdiv(N, wide ? 128 : 64);
   const int nk = K / GB_BK;
-  if (tiles >= 192 || nk < 32) return 1;
-  int S = (int)((512 + tiles - 1) / tiles);
-  if (S > nk / 8) S = nk / 8;
-  if (S > 16) S = 16;
+  int S;
+  const char* force = getenv("OCCF_GEMM_KSPLIT");       // diagnostics: force the K-slice count
+  if (force && atoi(force) > 0) {
+    S = atoi(force);
+    if (S > nk) S = nk;
+  } else {
+    // Cost model fitted to an S sweep on MI355X (scripts/ksplit_probe.py; profiles/r01w_ksplit_sweep.txt):
+    // two workgroups per CU share the matrix pipe, so a launch of Bk workgroups takes ceil(Bk / 256)
+    // "CU turns" of one workgroup's K loop (a lone workgroup per CU only reaches ~60% of a pair's
+    // rate); the slab reduction costs one launch plus S*M*N floats written and read back.
+    if (tiles >= 2048 || nk < 8) return 1;
+    const double t_k = wide ? 0.92 : 0.5;                 // us per k-tile of a paired workgroup
+    const double slab_us = (double)M * N * 8.0 / 5.0e6;  // per slice, at ~5 TB/s (mostly L2/MALL resident)
+    double best = 1e30;
+    S = 1;
+    const int smax = nk / 4 < 16 ? nk / 4 : 16;
+    for (int c = 1; c <= smax; ++c) {
+      const long turns = (tiles * c + 255) / 256;
+      const double eff = turns == 1 ? 1.6 : (double)turns;
+      const double t = eff * ((double)occf_cdiv(nk, c) + 5.2) * t_k + (c > 1 ? 6.0 + c * slab_us : 0.0);
+      if (t < best * 0.97) {                              // prefer fewer slices on near-ties
+        best = t;
+        S = c;
+      }
+    }
+  }
   while (S > 1 && (long)S * M * N > workspace_floats) --S;
   return S < 2 ? 1 : S;
 }

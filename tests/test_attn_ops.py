@@ -102,9 +102,12 @@ def test_masked_attention(be, Q, L, heads, masked):
     assert torch.allclose(out.cpu(), ref, **TOL), float((out.cpu() - ref).abs().max())
 
 
-@pytest.mark.parametrize("shape,occ", [((8, 8, 4), (16, 16, 8)), ((5, 6, 3), (9, 12, 5)), ((4, 4, 2), (4, 4, 2))])
-def test_upsample_classify(be, shape, occ):
-    B, Q, K = 2, 12, 17
+@pytest.mark.parametrize("shape,occ,Q,K", [((8, 8, 4), (16, 16, 8), 12, 17), ((5, 6, 3), (9, 12, 5), 12, 17),
+                                           ((4, 4, 2), (4, 4, 2), 12, 17),      # same grid: identity kernel
+                                           ((6, 5, 4), (6, 5, 4), 21, 19),      # identity, wide class bucket
+                                           ((3, 3, 3), (3, 3, 3), 9, 17)])      # odd voxel count: resampler
+def test_upsample_classify(be, shape, occ, Q, K):
+    B = 2
     mp = paramgen.tensor("mp", (B, Q, *shape), 5, 2.0)
     cls = paramgen.tensor("cls", (B, Q, K + 1), 5)
     ref = O.format_results(cls, F.interpolate(mp, size=occ, mode="trilinear", align_corners=True))

@@ -147,6 +147,18 @@ def test_upsample_classify_reference_grid(hip):
     assert _rel(out, ref) < 1e-4
 
 
+def test_upsample_classify_same_grid(hip):
+    """nuScenes head: masks are predicted at the output grid, so the resample is the identity and the
+    one-tap kernel runs."""
+    g = torch.Generator().manual_seed(17)
+    dev = hip.device
+    mp = (torch.randn(1, 100, 200, 200, 16, generator=g) * 2).to(dev)
+    cls = torch.randn(1, 100, 18, generator=g).to(dev)
+    out = hip.ops.upsample_classify(mp, cls, (200, 200, 16))
+    ref = O.format_results(cls, mp)
+    assert _rel(out, ref) < 1e-4
+
+
 def test_groupnorm_layernorm_full(hip):
     g = torch.Generator().manual_seed(8)
     dev = hip.device
