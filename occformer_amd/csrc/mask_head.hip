@@ -349,7 +349,8 @@ __global__ void __launch_bounds__(256) upsample_classify_kernel(
     int Q, int K, int X, int Y, int Z, int X2, int Y2, int Z2) {
   const int b = blockIdx.y;
   const long V2 = (long)X2 * Y2 * Z2;
-  const long vid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // x2-major workgroup order + XCD remap: the output planes that read one source plane share an L2
+  const long vid = (long)occf_xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   if (vid >= V2) return;
   const int z2 = (int)(vid % Z2), y2 = (int)((vid / Z2) % Y2), x2 = (int)(vid / ((long)Z2 * Y2));
   // align_corners=True source coordinate: dst * (in-1)/(out-1)
@@ -383,85 +384,6 @@ __global__ void __launch_bounds__(256) upsample_classify_kernel(
 #pragma unroll
   for (int i = 0; i < UC_MAXK; ++i)
     if (i < K) out[((long)b * K + i) * V2 + vid] = acc[i];
-}
-
-// Resampling + classification, two z-adjacent output voxels per thread.  The kernel is VALU-bound
-// (per voxel and query: the trilinear blend, a sigmoid and K class FMAs), so the pair is carried in
-// packed fp32 registers: 8 v_pk_fma for the blend (corner weights precomputed per thread), hardware
-// exp / rcp for the sigmoid, K v_pk_fma with the class weight broadcast from an SGPR.  The x/y taps
-// are shared by the pair; each voxel keeps its own two z taps, so any resize ratio works.
-template <int KB>
-__global__ void __launch_bounds__(256) upsample_classify_pair_kernel(
-    const float* __restrict__ mask_pred, const float* __restrict__ prob, float* __restrict__ out, int Q, int K,
-    int X, int Y, int Z, int X2, int Y2, int Z2) {
-  const int b = blockIdx.y;
-  const int ZP = Z2 >> 1;
-  const long NP = (long)X2 * Y2 * ZP;
-  const long pid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pid >= NP) return;
-  const int zp = (int)(pid % ZP), y2 = (int)((pid / ZP) % Y2), x2 = (int)(pid / ((long)ZP * Y2));
-  const float sx = X2 > 1 ? (float)(X - 1) / (float)(X2 - 1) : 0.f;
-  const float sy = Y2 > 1 ? (float)(Y - 1) / (float)(Y2 - 1) : 0.f;
-  const float sz = Z2 > 1 ? (float)(Z - 1) / (float)(Z2 - 1) : 0.f;
-  const float fx = sx * x2, fy = sy * y2, fza = sz * (2 * zp), fzb = sz * (2 * zp + 1);
-  const int x0 = (int)fx, y0 = (int)fy, za0 = (int)fza, zb0 = (int)fzb;
-  const int x1 = x0 + (x0 < X - 1), y1 = y0 + (y0 < Y - 1);
-  const int za1 = za0 + (za0 < Z - 1), zb1 = zb0 + (zb0 < Z - 1);
-  const float tx = fx - x0, ty = fy - y0, tza = fza - za0, tzb = fzb - zb0;
-  // corner c = (xbit, ybit, zbit): weight pair (voxel a, voxel b), source offsets per voxel
-  occf_f2 w[8];
-  uint32_t offa[8], offb[8];          // BYTE offsets inside one query's volume (SGPR base + 32-bit VGPR offset)
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const float wxy = ((c & 4) ? tx : 1.f - tx) * ((c & 2) ? ty : 1.f - ty);
-    w[c].x = wxy * ((c & 1) ? tza : 1.f - tza);
-    w[c].y = wxy * ((c & 1) ? tzb : 1.f - tzb);
-    const int row = (((c & 4) ? x1 : x0) * Y + ((c & 2) ? y1 : y0)) * Z;
-    offa[c] = (uint32_t)(row + ((c & 1) ? za1 : za0)) * 4u;
-    offb[c] = (uint32_t)(row + ((c & 1) ? zb1 : zb0)) * 4u;
-  }
-  occf_f2 acc[KB];
-#pragma unroll
-  for (int i = 0; i < KB; ++i) acc[i] = (occf_f2)(0.f);
-  const uint32_t Vb = (uint32_t)X * Y * Z * 4u;          // bytes per query volume (host checks Q * Vb < 2^32)
-  const occf_buf mb = occf_make_buf(mask_pred + (long)b * Q * ((long)X * Y * Z));
-  const float* pb = prob + (long)b * Q * UC_MAXK;
-  occf_f2 ma[8], mq[8];                                   // two tap sets: one in flight while the other is used
-  auto fetch = [&](occf_f2* m, int q) {
-    const uint32_t so = (uint32_t)(q < Q ? q : Q - 1) * Vb;     // past the end: re-read the last volume
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      m[c].x = occf_buf_load_f32(mb, offa[c], so);
-      m[c].y = occf_buf_load_f32(mb, offb[c], so);
-    }
-  };
-  auto consume = [&](const occf_f2* m, int q) {
-    occf_f2 val = w[0] * m[0];
-#pragma unroll
-    for (int c = 1; c < 8; ++c) val = occf_fma2(w[c], m[c], val);
-    occf_f2 e;
-    e.x = __expf(-val.x);
-    e.y = __expf(-val.y);
-    e = e + 1.0f;
-    occf_f2 sg;
-    sg.x = occf_rcp_fast(e.x);
-    sg.y = occf_rcp_fast(e.y);
-    const float* pr = pb + q * UC_MAXK;                  // wave-uniform address -> scalar loads
-#pragma unroll
-    for (int i = 0; i < KB; ++i) acc[i] = occf_fma2((occf_f2)(pr[i]), sg, acc[i]);
-  };
-  fetch(ma, 0);
-  for (int qi = 0; qi < Q; qi += 2) {
-    fetch(mq, qi + 1);
-    consume(ma, qi);
-    fetch(ma, qi + 2);
-    if (qi + 1 < Q) consume(mq, qi + 1);
-  }
-  const long V2 = (long)X2 * Y2 * Z2;
-  const long vid = ((long)x2 * Y2 + y2) * Z2 + 2 * zp;
-#pragma unroll
-  for (int i = 0; i < KB; ++i)
-    if (i < K) *reinterpret_cast<occf_f2*>(out + ((long)b * K + i) * V2 + vid) = acc[i];
 }
 
 // Same-resolution case (X2 == X ...: the nuScenes head predicts masks at the output grid): the
@@ -525,7 +447,7 @@ extern "C" int occf_upsample_classify_fwd(const float* mask_pred, const float* c
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(class_prob_kernel, dim3(occf_cdiv((long)B * Q, 128)), dim3(128), 0, st, cls, workspace, B * Q, K);
   static const bool ident_env = [] {
-    const char* e = getenv("OCCF_CLASSIFY_FAST");        // diagnostics: 0 forces the one-voxel resampling kernel
+    const char* e = getenv("OCCF_CLASSIFY_IDENTITY");    // diagnostics: 0 forces the resampling kernel
     return e == nullptr || atoi(e) != 0;
   }();
   if (ident_env && X2 == X && Y2 == Y && Z2 == Z && V2 % 2 == 0) {
@@ -536,14 +458,6 @@ extern "C" int occf_upsample_classify_fwd(const float* mask_pred, const float* c
     else
       hipLaunchKernelGGL((classify_identity_kernel<UC_MAXK, 8>), grid, dim3(256), 0, st, mask_pred,
                          (const float*)workspace, out, Q, K, V2);
-  } else if (ident_env && Z2 % 2 == 0 && (long)Q * X * Y * Z < (1L << 30)) {
-    const dim3 grid(occf_cdiv(V2 / 2, 256), B);
-    if (K <= 18)
-      hipLaunchKernelGGL((upsample_classify_pair_kernel<18>), grid, dim3(256), 0, st, mask_pred,
-                         (const float*)workspace, out, Q, K, X, Y, Z, X2, Y2, Z2);
-    else
-      hipLaunchKernelGGL((upsample_classify_pair_kernel<UC_MAXK>), grid, dim3(256), 0, st, mask_pred,
-                         (const float*)workspace, out, Q, K, X, Y, Z, X2, Y2, Z2);
   } else {
     hipLaunchKernelGGL(upsample_classify_kernel, dim3(occf_cdiv(V2, 256), B), dim3(256), 0, st, mask_pred,
                        (const float*)workspace, out, B, Q, K, X, Y, Z, X2, Y2, Z2);

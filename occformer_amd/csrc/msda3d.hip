@@ -29,7 +29,9 @@ __global__ void __launch_bounds__(256) msda3d_fwd_kernel(
     const float* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     float* __restrict__ out, MsdaLevels lv, int B, int Nq, int H, int Dh, int P, long off_ld, long lg_ld) {
   const int lanes = Dh / VEC;
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // XCD remap: a contiguous eighth of the (head-major) index space per XCD -- with 8 heads, one head's
+  // value planes per L2, walked in query (= spatial) order, instead of every XCD streaming all heads
+  const long gid = (long)occf_xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   const long total = (long)B * Nq * H * lanes;
   if (gid >= total) return;
   const int cv = (int)(gid % lanes) * VEC;

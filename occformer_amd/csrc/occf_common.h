@@ -84,39 +84,6 @@ void occf_bf16_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
   lo = occf_bf16_pack2(a - occf_u2f(hi << 16), b - occf_u2f(hi & 0xFFFF0000u));
 }
 
-// packed fp32 pairs: v_pk_fma_f32 / v_pk_mul_f32 issue two fp32 lanes per instruction (the VALU-bound
-// elementwise kernels keep two outputs per thread to use them)
-typedef float occf_f2 __attribute__((ext_vector_type(2)));
-#ifdef OCCF_EMU
-static inline float occf_rcp_fast(float x) { return 1.0f / x; }
-#else
-__device__ __forceinline__ float occf_rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }   // 1 ulp
-#endif
-#define occf_fma2(a, b, c) __builtin_elementwise_fma((a), (b), (c))
-
-// buffer-addressed loads: SGPR resource + 32-bit VGPR byte offset + SGPR byte offset, i.e. no 64-bit
-// address arithmetic per load (a gather kernel that walks many same-shaped planes keeps the per-lane
-// offsets fixed and moves only the scalar offset)
-#ifdef OCCF_EMU
-struct occf_buf {
-  const char* base;
-};
-static inline occf_buf occf_make_buf(const void* p) { return occf_buf{(const char*)p}; }
-static inline float occf_buf_load_f32(occf_buf b, uint32_t voff, uint32_t soff) {
-  float f;
-  memcpy(&f, b.base + voff + soff, 4);
-  return f;
-}
-#else
-typedef __amdgpu_buffer_rsrc_t occf_buf;
-__device__ __forceinline__ occf_buf occf_make_buf(const void* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFF, 0x00020000);
-}
-__device__ __forceinline__ float occf_buf_load_f32(occf_buf b, uint32_t voff, uint32_t soff) {
-  return occf_u2f(__builtin_amdgcn_raw_buffer_load_b32(b, voff, soff, 0));
-}
-#endif
-
 // error codes of the C ABI (0 = ok, >0 = hipError_t, <0 = argument error)
 #define OCCF_EINVAL (-1)
 #define OCCF_ESHAPE (-2)
