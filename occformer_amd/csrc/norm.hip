@@ -107,21 +107,45 @@ extern "C" int occf_groupnorm_stats(const float* x, float* stats, float* workspa
 }
 
 // Second stage for per-CHANNEL partial sums written by the convolution / GEMM epilogues:
-// partial[B][nblk][C][2] -> stats[B][G][2].  One wave per (batch, group); lanes stride over the tiles.
+// partial[B][nblk][C][2] -> stats[B][G][2].  One 256-thread workgroup per (batch, group); threads stride
+// over the tiles with independent (unrolled) loads, double accumulation, fixed reduction order.
 __global__ void __launch_bounds__(256) gn_finalize_channels_kernel(const float* __restrict__ partial,
                                                                    float* __restrict__ stats, long nblk, int C, int G,
                                                                    int BG, double count, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int bg = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  if (bg >= BG) return;
+  __shared__ double red[2][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bg = blockIdx.x;
   const int b = bg / G, g = bg % G, cg = C / G;
+  const float* base = partial + ((long)b * nblk * C + (long)g * cg) * 2;
   double s = 0.0, q = 0.0;
-  for (long k = lane; k < nblk; k += 64) {
-    const float* p = partial + (((long)b * nblk + k) * C + (long)g * cg) * 2;
-    for (int c = 0; c < cg; ++c) {
-      s += (double)p[c * 2];
-      q += (double)p[c * 2 + 1];
+  long k = threadIdx.x;
+  for (; k + 768 < nblk; k += 1024) {          // four tiles per trip: their loads are independent
+    float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float2* p = reinterpret_cast<const float2*>(base + (k + 256 * u) * C * 2);
+      for (int c = 0; c < cg; ++c) {
+        const float2 v = p[c];
+        s4[u] += v.x;
+        q4[u] += v.y;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s += (double)s4[u];
+      q += (double)q4[u];
+    }
+  }
+  for (; k < nblk; k += 256) {
+    const float2* p = reinterpret_cast<const float2*>(base + k * C * 2);
+    float s1 = 0.f, q1 = 0.f;
+    for (int c = 0; c < cg; ++c) {
+      const float2 v = p[c];
+      s1 += v.x;
+      q1 += v.y;
+    }
+    s += (double)s1;
+    q += (double)q1;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -129,6 +153,13 @@ __global__ void __launch_bounds__(256) gn_finalize_channels_kernel(const float* 
     q += __shfl_xor(q, o);
   }
   if (lane == 0) {
+    red[0][wave] = s;
+    red[1][wave] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -140,8 +171,8 @@ __global__ void __launch_bounds__(256) gn_finalize_channels_kernel(const float* 
 extern "C" int occf_groupnorm_finalize(const float* partial, float* stats, int B, long nblk, int C, int G,
                                        double count, float eps, void* stream) {
   if (B <= 0 || nblk <= 0 || G <= 0 || C % G != 0 || count <= 0) return OCCF_EINVAL;
-  hipLaunchKernelGGL(gn_finalize_channels_kernel, dim3(occf_cdiv((long)B * G * 64, 256)), dim3(256), 0,
-                     (hipStream_t)stream, partial, stats, nblk, C, G, B * G, count, eps);
+  hipLaunchKernelGGL(gn_finalize_channels_kernel, dim3(B * G), dim3(256), 0, (hipStream_t)stream, partial, stats,
+                     nblk, C, G, B * G, count, eps);
   OCCF_LAUNCH_CHECK();
 }
 
