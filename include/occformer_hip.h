@@ -308,6 +308,13 @@ int occf_topk_smallest_abs_fwd(const float* values, int64_t* out_indices, float*
  * out[R, 4] = { sum BCE-with-logits(x, t), sum sigmoid(x)*t, sum sigmoid(x), sum t } over logits/targets[R, P]. */
 int occf_point_loss_rows_fwd(const float* logits, const float* targets, float* out, int R, long P, void* stream);
 
+/* Hungarian matching (assigners/mask_hungarian_assigner.py:104-126: scipy.optimize.linear_sum_assignment on
+ * cost.cpu()): P independent problems, cost[P, Q, G] (queries x ground-truth rows, finite fp32).
+ * match_gt[P, G] int32 = query matched to GT g (-1 if G > Q left it unmatched);
+ * assigned_gt[P, Q] int32 = the reference's assigned_gt_inds (0 = background, g + 1 = matched to GT g).
+ * Minimises the same total cost as scipy (shortest augmenting paths in double); Q, G <= 1024. */
+int occf_hungarian_fwd(const float* cost, int* match_gt, int* assigned_gt, int P, int Q, int G, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

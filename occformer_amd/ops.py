@@ -507,6 +507,20 @@ class HipOps:
                    self._ptr(out), R, P, self._stream())
         return out
 
+    def hungarian(self, cost):
+        """cost [Q, G] or [P, Q, G] fp32 -> (match_gt [.., G] int32: query of GT g, assigned_gt [.., Q] int32:
+        0 = background, g + 1 = matched to GT g) -- scipy.optimize.linear_sum_assignment on the device."""
+        c = cost.detach().to(self.f32).contiguous()
+        lead = c.shape[:-2]
+        Q, G = c.shape[-2:]
+        P = 1
+        for d in lead:
+            P *= int(d)
+        match = torch.empty((*lead, G), dtype=torch.int32, device=c.device)
+        assigned = torch.empty((*lead, Q), dtype=torch.int32, device=c.device)
+        self._call("occf_hungarian_fwd", self._ptr(c, self.f32), self._ptr(match), self._ptr(assigned), P, Q, G,
+                   self._stream())
+        return match, assigned
 
 _ops = None
 

@@ -20,7 +20,6 @@ host with scipy exactly like the reference (one host sync per image and decoder 
 import numpy as np
 import torch
 import torch.nn.functional as F
-from scipy.optimize import linear_sum_assignment
 
 from .ops import get_ops
 
@@ -197,15 +196,17 @@ class MaskHungarianAssigner:
         return cls * self.w_cls + bce * self.w_mask + dice * self.w_dice
 
     def assign(self, cls_pred, mask_pred, gt_labels, gt_mask, img_meta=None):
-        """-> (assigned_gt_inds [Q] (0 = background, g+1 = matched to GT g), cost)"""
+        """-> (assigned_gt_inds [Q] (0 = background, g+1 = matched to GT g), cost).  The assignment runs on the
+        device (csrc/assign.hip) -- the reference's ``cost.cpu()`` + scipy round trip, one host sync per
+        prediction set, is gone; ``self.last_match`` [G] holds the query of every GT row."""
         Q, G = mask_pred.shape[0], gt_labels.shape[0]
-        gt_inds = torch.zeros((Q,), dtype=torch.long, device=mask_pred.device)
+        self.last_match = None
         if G == 0 or Q == 0:
-            return gt_inds, mask_pred.new_zeros((Q, G))
+            return torch.zeros((Q,), dtype=torch.long, device=mask_pred.device), mask_pred.new_zeros((Q, G))
         cost = self.cost(cls_pred, mask_pred, gt_labels, gt_mask)
-        r, c = linear_sum_assignment(cost.detach().cpu())
-        gt_inds[torch.from_numpy(r).to(gt_inds.device)] = torch.from_numpy(c).to(gt_inds.device) + 1
-        return gt_inds, cost
+        match, assigned = get_ops().hungarian(cost)
+        self.last_match = match.long()
+        return assigned.long(), cost
 
 
 # ------------------------------------------------------------------------------------------ losses
@@ -277,8 +278,14 @@ class OccHeadTrainingMixin:
 
     def _targets_from_assignment(self, gt_inds, cls_score, mask_pred, gt_labels, gt_masks):
         # samplers/mask_pseudo_sampler.py: positives = matched queries in ascending order
-        pos = torch.nonzero(gt_inds > 0, as_tuple=False).squeeze(-1)
-        pos_gt = gt_inds[pos] - 1
+        match = getattr(self.assigner, "last_match", None)
+        if match is not None and match.shape[0] <= gt_inds.shape[0]:
+            # every GT row is matched (G <= Q): the positives are the sorted matched queries -- the same
+            # tensors as nonzero(gt_inds > 0) / gt_inds[pos] - 1, without the device-to-host size query
+            pos, pos_gt = torch.sort(match)
+        else:
+            pos = torch.nonzero(gt_inds > 0, as_tuple=False).squeeze(-1)
+            pos_gt = gt_inds[pos] - 1
         labels = gt_labels.new_full((self.num_queries,), self.num_classes, dtype=torch.long)
         labels[pos] = gt_labels[pos_gt]
         cw = torch.tensor(self.class_weight, dtype=cls_score.dtype, device=cls_score.device)
@@ -302,6 +309,12 @@ class OccHeadTrainingMixin:
         cw = cls_scores.new_tensor(self.class_weight)
         loss_cls = cross_entropy_loss(cls_scores.flatten(0, 1), labels, label_weights, cw, cw[labels].sum(),
                                       self.w_cls)
+        if min(self.class_weight[:self.num_classes]) > 0:
+            # positive class weights: (mask_weights > 0) selects exactly the matched queries, image by image in
+            # ascending order = targets[b][4]; gather by index (no boolean-mask size query on the host)
+            B, Q = mask_weights.shape
+            idx = torch.cat([t[4] + b * Q for b, t in enumerate(targets)])
+            return loss_cls, mask_preds.flatten(0, 1)[idx], mask_weights.flatten()[idx], mask_targets
         sel = mask_weights > 0
         return loss_cls, mask_preds[sel], mask_weights[sel], mask_targets
 

@@ -75,3 +75,40 @@ def test_point_loss_rows(be):
     ref = torch.stack([F.binary_cross_entropy_with_logits(x, t, reduction="none").sum(1), (s * t).sum(1), s.sum(1),
                        t.sum(1)], 1)
     assert torch.allclose(out, ref, rtol=2e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("P,Q,G", [(1, 100, 17), (3, 100, 20), (2, 7, 7), (2, 5, 12), (1, 130, 1), (1, 64, 65),
+                                   (1, 300, 40)])
+def test_hungarian_matches_scipy(be, P, Q, G):
+    """mask_hungarian_assigner.py:104-126: same assignment (and total cost) as scipy.optimize.linear_sum_assignment
+    on the cost matrix the assigner builds (generic float costs: the optimum is unique)"""
+    from scipy.optimize import linear_sum_assignment
+    cost = paramgen.tensor("hc", (P, Q, G), 3, 2.0) + paramgen.uniform("hu", (P, Q, G), 4)
+    match, assigned = be.ops.hungarian(be.to(cost))
+    match, assigned = match.cpu(), assigned.cpu()
+    for p in range(P):
+        r, c = linear_sum_assignment(cost[p].numpy())
+        ref = torch.zeros(Q, dtype=torch.int32)
+        ref[torch.from_numpy(r)] = torch.from_numpy(c).int() + 1
+        assert torch.equal(assigned[p], ref)
+        for g in range(G):
+            q = int(match[p, g])
+            assert (q == -1 and g not in c) or int(ref[q]) == g + 1
+    one, _ = be.ops.hungarian(be.to(cost[0]))                            # un-batched call
+    assert torch.equal(one.cpu(), match[0])
+
+
+def test_hungarian_structured_costs(be):
+    """integer-valued costs with many ties: the assignment may differ from scipy's, its total cost may not"""
+    from scipy.optimize import linear_sum_assignment
+    g = torch.Generator().manual_seed(5)
+    cost = torch.randint(0, 4, (4, 30, 9), generator=g).float()
+    match, assigned = be.ops.hungarian(be.to(cost))
+    match, assigned = match.cpu(), assigned.cpu()
+    for p in range(cost.shape[0]):
+        r, c = linear_sum_assignment(cost[p].numpy())
+        q = match[p].long()
+        assert len(set(q.tolist())) == cost.shape[2] and (q >= 0).all()          # a full, injective matching
+        assert float(cost[p][q, torch.arange(cost.shape[2])].sum()) == float(cost[p].numpy()[r, c].sum())
+        assert torch.equal(assigned[p][q], torch.arange(cost.shape[2], dtype=torch.int32) + 1)
+        assert int((assigned[p] > 0).sum()) == cost.shape[2]
