@@ -188,7 +188,11 @@ class MaskHungarianAssigner:
             a, g2 = F.pad(a, (0, 4 - P % 4)), F.pad(g, (0, 4 - P % 4))
         else:
             g2 = g
-        prod = ops.linear(a.contiguous(), g2.contiguous(), allow_small=False)   # [2Q, G]
+        g2 = g2.contiguous()
+        # K = the sampled points (12 544): the bf16-split kernel slices K over the chip (4 tiles would otherwise
+        # walk it serially); 0/1 targets are exact in bf16, the logits keep 16 mantissa bits
+        sp = ops.split_bf16(g2) if ops.precision != "f32" and g2.shape[1] % 32 == 0 else None
+        prod = ops.linear(a.contiguous(), g2, allow_small=False, w_split=sp)   # [2Q, G]
         xg, sg = prod[:Q], prod[Q:]
         bce = (rows[:, 0:1] - xg) / P
         dice = 1 - (2 * sg + self.dice_eps) / (rows[:, 2:3] + g.sum(1)[None] + self.dice_eps)
@@ -295,6 +299,10 @@ class OccHeadTrainingMixin:
 
     def loss(self, all_cls_scores, all_mask_preds, *gt):
         """mask2former_nusc_occ.py:275-315 / mask2former_occ.py:294-341"""
+        # the GT masks are sampled as fp32 volumes by every prediction set: convert the int64 masks once per
+        # step instead of once per set (17 x 2 M voxels each time)
+        gt = list(gt)
+        gt[1] = [m.float() for m in gt[1]]
         per = [self.loss_single(c, m, *gt) for c, m in zip(all_cls_scores, all_mask_preds)]
         out = {"loss_cls": per[-1][0], "loss_mask": per[-1][1], "loss_dice": per[-1][2]}
         for i, (a, b, c) in enumerate(per[:-1]):
