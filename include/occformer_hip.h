@@ -121,11 +121,15 @@ int occf_mask_pool_fwd(const float* mask_pred, float* pooled, uint8_t* blocked, 
  * outputs as occf_mask_pool_fwd (pooled[B*Q, L], blocked, row_open).  Uniform pooling windows only
  * (ox | X, oy | Y, oz | Z, 128 % Z == 0, window rows dividing the 128/Z rows of a tile), Q <= 128,
  * E % 32 == 0; otherwise OCCF_ESHAPE (-2) / workspace 0 and the caller uses GEMM + occf_mask_pool_fwd.
- * workspace: occf_mask_gemm_pool_workspace(...) floats. */
+ * workspace: occf_mask_gemm_pool_workspace(...) floats.
+ * reverse != 0 walks the volume from the far end (results are identical): the ten prediction sets of a
+ * forward read the same features, which exceed the last-level cache -- alternating the direction between
+ * consecutive calls lets each pass start on the tail the previous one left there. */
 long occf_mask_gemm_pool_workspace(int B, int Q, int E, int X, int Y, int Z, int ox, int oy, int oz);
 int occf_mask_gemm_pool_fwd(const float* mask_embed, const uint16_t* feat_hi, const uint16_t* feat_lo,
                             float* pooled, uint8_t* blocked, int32_t* row_open, float* workspace, int B, int Q,
-                            int E, int X, int Y, int Z, int ox, int oy, int oz, int terms, void* stream);
+                            int E, int X, int Y, int Z, int ox, int oy, int oz, int terms, int reverse,
+                            void* stream);
 
 /* Masked multi-head cross-attention core (scaled dot product + boolean mask + softmax + @V) of
  * the decoder layers, incl. the all-masked-row fix (mask2former_nusc_occ.py:652-667; mmcv

@@ -241,6 +241,223 @@ __global__ void __launch_bounds__(256) mask_gemm_pool_kernel(MaskPoolArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Streaming variant (E = 16 * NS channels, Z a power of two <= 32, power-of-two windows with wy a multiple
+// of the 32/Z rows of a voxel group): the tile kernel above re-stages the (constant) mask embeddings for
+// every k-tile and synchronises twice per k-tile -- it reached 2.3 TB/s on a contraction whose only large
+// operand (the pre-split voxel features, 492 MB at the 200-grid) has to be read exactly once.  Here the
+// problem is transposed: D[voxel][query] = F[voxel][k] * M^T[k][query].
+//   * M^T lives in LDS for the whole launch as ready-made B fragments (hi and lo, 4 query tiles x NS k-slots
+//     x 64 lanes x 16 B = 96 KB for E = 192); workgroups are persistent (one per CU).
+//   * every wave streams its own 32-voxel groups: the A fragments are the voxels' bf16 rows read straight
+//     from global memory in fragment order (lane = voxel row, 16 B = 8 channels), one whole group
+//     (2 * NS loads of 16 B per lane) ahead in registers -- no LDS staging, no barriers in the main loop.
+//   * a wave owns complete pooling windows: the groups of a unit (the x-planes and y-row groups of one
+//     (x-window slice, y-window)) are folded element-wise into a running maximum; the z (and in-group y)
+//     reduction happens across the accumulator registers (+ one lane swap for z bit 2).
+struct MaskStreamArgs {
+  const float* me;            // [B, Q, E]
+  const uint16_t* Fh;         // [B, V, E]
+  const uint16_t* Fl;
+  float* part;                // [S][B][Q][L]
+  int B, Q, E;
+  int X, Y, Z, ox, oy, oz;
+  int S;                      // x-slices per window
+  int units;                  // per batch: ox * oy * S
+  int reverse;                // walk the units from the far end (see occf_mask_gemm_pool_fwd)
+  float* pooled;              // S == 1: final outputs written here, no finish kernel
+  uint8_t* blocked;
+  int* row_open;
+};
+
+template <int TERMS, int NS>
+__global__ void __launch_bounds__(256) mask_gemm_pool_stream_kernel(MaskStreamArgs p) {
+  OCCF_DYN_SMEM(smem);
+  mg_u4* Mh = reinterpret_cast<mg_u4*>(smem);                         // [4][NS][64] fragments
+  mg_u4* Ml = reinterpret_cast<mg_u4*>(smem + 4 * NS * 64 * 16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const long V = (long)p.X * p.Y * p.Z;
+  // ---- stage the mask embeddings as B fragments: entry (nt, s, l) = M[nt*32 + (l&31)][16 s + 8 (l>>5) .. +7]
+  for (int e = tid; e < 4 * NS * 64; e += 256) {
+    const int l = e & 63, s = (e >> 6) % NS, nt = e / (64 * NS);
+    const int q = nt * 32 + (l & 31);
+    const float* src = p.me + ((long)b * p.Q + (q < p.Q ? q : p.Q - 1)) * p.E + 16 * s + 8 * (l >> 5);
+    const float4 v0 = *(const float4*)src, v1 = *(const float4*)(src + 4);
+    mg_u4 h, lo;
+    uint32_t hh, ll;
+    mg_split2(v0.x, v0.y, hh, ll); h[0] = hh; lo[0] = ll;
+    mg_split2(v0.z, v0.w, hh, ll); h[1] = hh; lo[1] = ll;
+    mg_split2(v1.x, v1.y, hh, ll); h[2] = hh; lo[2] = ll;
+    mg_split2(v1.z, v1.w, hh, ll); h[3] = hh; lo[3] = ll;
+    Mh[e] = h;
+    if (TERMS == 3) Ml[e] = lo;
+  }
+  __syncthreads();
+
+  const int wx = p.X / p.ox, wy = p.Y / p.oy, wz = p.Z / p.oz;
+  const int GY = 32 / p.Z;                        // y-rows of a 32-voxel group
+  const int xs = wx / p.S, ygroups = wy / GY;
+  const int gpu = xs * ygroups;                   // groups per unit
+  const int nwaves = gridDim.x * 4;
+  const int wid = blockIdx.x * 4 + wave;
+  const int my_units = wid < p.units ? (p.units - wid + nwaves - 1) / nwaves : 0;
+  const long T = (long)my_units * gpu;            // this wave's flat (unit, group) stream
+  // voxel-row byte-free element offset of the lane inside a group: row (l & 31), channel half (l >> 5)
+  const long lane_off = (long)(lane & 31) * p.E + 8 * (lane >> 5);
+  auto group_base = [&](long t) -> long {         // element offset of the group's first voxel row
+    const long tc = t < T ? t : T - 1;
+    const int uf = wid + (int)(tc / gpu) * nwaves, g = (int)(tc % gpu);
+    const int u = p.reverse ? p.units - 1 - uf : uf;
+    const int sl = u % p.S, cy = (u / p.S) % p.oy, cx = u / (p.S * p.oy);
+    const int x = cx * wx + sl * xs + g / ygroups, y = cy * wy + (g % ygroups) * GY;
+    return ((long)b * V + ((long)x * p.Y + y) * p.Z) * p.E;
+  };
+  // A fragments of ONE group; slot s is refilled with the next group's slot s as soon as its MFMAs are
+  // issued, so a whole group of loads (2 * NS x 16 B per lane) is always in flight
+  mg_u4 ah[NS], al[NS];
+  f32x16 pm[4];
+  mg_u4 bq[2][8];                                 // embedding fragments (4 query tiles x {hi, lo}) of two k-slots
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    bq[0][nt] = Mh[(nt * NS) * 64 + lane];
+    if (TERMS == 3) bq[0][4 + nt] = Ml[(nt * NS) * 64 + lane];
+  }
+  // reduced voxel bits: v = (r & 3) + 4 (lane >> 5) + 8 (r >> 2); z = v % Z, in-group row = v / Z
+  int lwz = 0;
+  while ((1 << lwz) < wz) ++lwz;
+  const int red = ((1 << lwz) - 1) | (31 & ~(p.Z - 1));      // z bits below the window size + all row bits
+  const long L = (long)p.ox * p.oy * p.oz;
+
+  auto run = [&](long t) __attribute__((always_inline)) {
+    const int g = (int)(t % gpu);
+    const long onext = group_base(t + 1) + lane_off;          // past the end: re-reads the last group
+    if (g == 0) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pm[nt][r] = -INFINITY;
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      // The embedding fragments are loop-invariant LDS reads: without the memory fence the compiler hoists all
+      // 8 * NS of them into registers (384 VGPRs) and spills.  The fragments of slot s+1 are read while slot s
+      // is multiplied (bq double buffer; slot 0 of the next group closes the ring), and the three split
+      // products are issued term-major so that consecutive MFMAs write different accumulators (left alone,
+      // the compiler emits read-wait-3 dependent MFMAs per query tile: LDS latency and MFMA latency in series).
+      asm volatile("" ::: "memory");
+      const int sn = s + 1 < NS ? s + 1 : 0;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        bq[(s + 1) & 1][nt] = Mh[(nt * NS + sn) * 64 + lane];
+        if (TERMS == 3) bq[(s + 1) & 1][4 + nt] = Ml[(nt * NS + sn) * 64 + lane];
+      }
+      OCCF_SCHED_FENCE();
+      bf16x8 a_h, a_l, b_h[4], b_l[4];
+      __builtin_memcpy(&a_h, &ah[s], 16);
+      if (TERMS == 3) __builtin_memcpy(&a_l, &al[s], 16);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        __builtin_memcpy(&b_h[nt], &bq[s & 1][nt], 16);
+        if (TERMS == 3) __builtin_memcpy(&b_l[nt], &bq[s & 1][4 + nt], 16);
+      }
+      if (TERMS == 3) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = occf_mfma_bf16_32x32x16(a_h, b_l[nt], acc[nt]);   // feature_hi * embed_lo
+        OCCF_SCHED_FENCE();
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = occf_mfma_bf16_32x32x16(a_l, b_h[nt], acc[nt]);   // feature_lo * embed_hi
+        OCCF_SCHED_FENCE();
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = occf_mfma_bf16_32x32x16(a_h, b_h[nt], acc[nt]);
+      OCCF_SCHED_FENCE();
+      ah[s] = *(const mg_u4*)(p.Fh + onext + 16 * s);
+      if (TERMS == 3) al[s] = *(const mg_u4*)(p.Fl + onext + 16 * s);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pm[nt][r] = occf_nanmax_mg(pm[nt][r], acc[nt][r]);
+    if (g == gpu - 1) {
+      // ---- window reduction across the accumulator registers, then one value per (query, z-window)
+      const int uf = wid + (int)(t / gpu) * nwaves;
+      const int u = p.reverse ? p.units - 1 - uf : uf;
+      const int sl = u % p.S, cy = (u / p.S) % p.oy, cx = u / (p.S * p.oy);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if (red & 1) {
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) pm[nt][r] = occf_nanmax_mg(pm[nt][r], pm[nt][r + 1]);
+        }
+        if (red & 2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (!(r & 2)) pm[nt][r] = occf_nanmax_mg(pm[nt][r], pm[nt][r + 2]);
+        }
+        if (red & 8) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (!(r & 4)) pm[nt][r] = occf_nanmax_mg(pm[nt][r], pm[nt][r + 4]);
+        }
+        if (red & 16) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) pm[nt][r] = occf_nanmax_mg(pm[nt][r], pm[nt][r + 8]);
+        }
+        if (red & 4) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pm[nt][r] = occf_nanmax_mg(pm[nt][r], __shfl_xor(pm[nt][r], 32));
+        }
+        const int q = nt * 32 + (lane & 31);
+        if (q < p.Q) {
+          const long cell0 = ((long)cx * p.oy + cy) * p.oz;
+          if (p.S == 1) {
+            // no x-slices to merge: the epilogue of mask_pool_finish_kernel right here (same expressions)
+            const long row = (long)b * p.Q + q;
+            bool open = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int v = (r & 3) + 4 * (lane >> 5) + 8 * (r >> 2);
+              if ((v & red) == 0) {
+                const long c = row * L + cell0 + ((v & (p.Z - 1)) >> lwz);
+                const float m = pm[nt][r];
+                p.pooled[c] = m;
+                const float sg = 1.0f / (1.0f + expf(-m));
+                const bool blk = sg < 0.5f;
+                p.blocked[c] = blk ? 1 : 0;
+                open |= !blk;
+              }
+            }
+            if (open && p.row_open[row] == 0) atomicOr((unsigned*)&p.row_open[row], 1u);
+          } else {
+            float* dst = p.part + (((long)sl * p.B + b) * p.Q + q) * L + cell0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int v = (r & 3) + 4 * (lane >> 5) + 8 * (r >> 2);
+              if ((v & red) == 0) dst[(v & (p.Z - 1)) >> lwz] = pm[nt][r];
+            }
+          }
+        }
+      }
+    }
+  };
+
+  if (T > 0) {
+    const long o0 = group_base(0) + lane_off;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      ah[s] = *(const mg_u4*)(p.Fh + o0 + 16 * s);
+      if (TERMS == 3) al[s] = *(const mg_u4*)(p.Fl + o0 + 16 * s);
+    }
+    for (long t = 0; t < T; ++t) run(t);
+  }
+}
+
 // max over the x-slices, blocked bytes, "any key open" per (batch, query) row (all-masked-row fix);
 // grid = (rows, 2048-cell chunks); row_open is zeroed by the host and OR-ed (order independent)
 __global__ void __launch_bounds__(256) mask_pool_finish_kernel(const float* __restrict__ part, float* __restrict__ pooled,
@@ -281,27 +498,82 @@ static bool mg_geometry_ok(int Q, int E, int X, int Y, int Z, int ox, int oy, in
   return true;
 }
 
+static bool mg_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+// streaming kernel: E = 192, Z a power of two <= 32, power-of-two z windows, y windows made of whole groups
+static bool mg_stream_ok(int Q, int E, int X, int Y, int Z, int ox, int oy, int oz) {
+  static const bool on = [] {
+    const char* e = getenv("OCCF_MASK_POOL_STREAM");       // diagnostics: 0 keeps the tile kernel
+    return e == nullptr || atoi(e) != 0;
+  }();
+  if (!on || Q <= 0 || Q > 128 || E != 192) return false;
+  if (ox <= 0 || oy <= 0 || oz <= 0 || X % ox || Y % oy || Z % oz) return false;
+  if (!mg_pow2(Z) || Z > 32 || !mg_pow2(Z / oz)) return false;
+  return (Y / oy) % (32 / Z) == 0;
+}
+static int mg_stream_slices(int B, int X, int Y, int Z, int ox, int oy) {
+  // split a window's x-planes until every wave of the chip has a few units (load balance of the tail)
+  const int wx = X / ox;
+  int S = 1;
+  while (S * 2 <= wx && wx % (S * 2) == 0 && (long)ox * oy * S < 4096) S *= 2;
+  return S;
+}
+
 // floats of scratch for the per-slice window maxima; 0 when the geometry is not taken by the fused kernel
 extern "C" long occf_mask_gemm_pool_workspace(int B, int Q, int E, int X, int Y, int Z, int ox, int oy, int oz) {
-  if (B <= 0 || !mg_geometry_ok(Q, E, X, Y, Z, ox, oy, oz)) return 0;
+  if (B <= 0) return 0;
+  if (mg_stream_ok(Q, E, X, Y, Z, ox, oy, oz)) return (long)mg_stream_slices(B, X, Y, Z, ox, oy) * B * Q * ox * oy * oz;
+  if (!mg_geometry_ok(Q, E, X, Y, Z, ox, oy, oz)) return 0;
   return (long)mg_slices(B, X, Y, Z, ox) * B * Q * ox * oy * oz;
 }
 
 extern "C" int occf_mask_gemm_pool_fwd(const float* mask_embed, const uint16_t* feat_hi, const uint16_t* feat_lo,
                                        float* pooled, uint8_t* blocked, int32_t* row_open, float* workspace, int B,
                                        int Q, int E, int X, int Y, int Z, int ox, int oy, int oz, int terms,
-                                       void* stream) {
-  if (B <= 0 || !mg_geometry_ok(Q, E, X, Y, Z, ox, oy, oz)) return OCCF_ESHAPE;
+                                       int reverse, void* stream) {
+  const bool stream_k = B > 0 && mg_stream_ok(Q, E, X, Y, Z, ox, oy, oz);
+  if (B <= 0 || (!stream_k && !mg_geometry_ok(Q, E, X, Y, Z, ox, oy, oz))) return OCCF_ESHAPE;
   if (terms != 1 && terms != 3) return OCCF_EINVAL;
   if ((terms == 3 && feat_lo == nullptr) || workspace == nullptr) return OCCF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long L = (long)ox * oy * oz;
-  const int S = mg_slices(B, X, Y, Z, ox);
-  MaskPoolArgs a = {mask_embed, feat_hi, feat_lo, workspace, B, Q, E, X, Y, Z, ox, oy, oz, S};
-  const long blocks = (long)B * ox * S * (Y / (128 / Z));
-  if (blocks >= 2147483647L) return OCCF_ESHAPE;
-  if (terms == 3) hipLaunchKernelGGL(mask_gemm_pool_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(mask_gemm_pool_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  int S;
+  if (stream_k) {
+    S = mg_stream_slices(B, X, Y, Z, ox, oy);
+    MaskStreamArgs a = {mask_embed, feat_hi, feat_lo, workspace, B, Q, E, X, Y, Z, ox, oy, oz, S, ox * oy * S,
+                        reverse != 0, pooled, blocked, (int*)row_open};
+    if (S == 1) {              // the kernel writes the final outputs and ORs row_open itself
+#ifndef OCCF_EMU
+      hipError_t e0 = hipMemsetAsync(row_open, 0, sizeof(int32_t) * (size_t)B * Q, st);
+      if (e0 != hipSuccess) return (int)e0;
+#else
+      memset(row_open, 0, sizeof(int32_t) * (size_t)B * Q);
+#endif
+    }
+    const size_t lds = (size_t)4 * 12 * 64 * 16 * (terms == 3 ? 2 : 1);
+#ifndef OCCF_EMU
+    static bool attr_set[2] = {};
+    if (!attr_set[terms == 3]) {
+      const void* fn = terms == 3 ? (const void*)mask_gemm_pool_stream_kernel<3, 12>
+                                  : (const void*)mask_gemm_pool_stream_kernel<1, 12>;
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_set[terms == 3] = true;
+    }
+#endif
+    const int nblk = a.units >= 1024 ? 256 : occf_cdiv(a.units, 4);      // persistent: one workgroup per CU
+    if (terms == 3)
+      hipLaunchKernelGGL((mask_gemm_pool_stream_kernel<3, 12>), dim3(nblk, B), dim3(256), lds, st, a);
+    else
+      hipLaunchKernelGGL((mask_gemm_pool_stream_kernel<1, 12>), dim3(nblk, B), dim3(256), lds, st, a);
+    if (S == 1) OCCF_LAUNCH_CHECK();
+  } else {
+    S = mg_slices(B, X, Y, Z, ox);
+    MaskPoolArgs a = {mask_embed, feat_hi, feat_lo, workspace, B, Q, E, X, Y, Z, ox, oy, oz, S};
+    const long blocks = (long)B * ox * S * (Y / (128 / Z));
+    if (blocks >= 2147483647L) return OCCF_ESHAPE;
+    if (terms == 3) hipLaunchKernelGGL(mask_gemm_pool_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(mask_gemm_pool_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  }
 #ifndef OCCF_EMU
   hipError_t e = hipMemsetAsync(row_open, 0, sizeof(int32_t) * (size_t)B * Q, st);
   if (e != hipSuccess) return (int)e;

@@ -84,6 +84,14 @@ void occf_bf16_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
   lo = occf_bf16_pack2(a - occf_u2f(hi << 16), b - occf_u2f(hi & 0xFFFF0000u));
 }
 
+// scheduling fence: keeps the instruction groups on either side in program order (used where the
+// compiler's register-minimising order would serialise LDS latency and dependent MFMAs)
+#ifdef OCCF_EMU
+#define OCCF_SCHED_FENCE() do { } while (0)
+#else
+#define OCCF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // error codes of the C ABI (0 = ok, >0 = hipError_t, <0 = argument error)
 #define OCCF_EINVAL (-1)
 #define OCCF_ESHAPE (-2)

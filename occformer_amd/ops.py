@@ -29,9 +29,9 @@ class HipOps:
         # split (fp32-class accuracy, matrix-core rate); "bf16" = plain bf16 products
         self.precision = os.environ.get("OCCF_PRECISION", "bf16x3")
         self.use_halo_conv = os.environ.get("OCCF_HALO_CONV", "1") == "1"
-        # fused mask-GEMM + pooling (skips writing intermediate mask logits): measured slower than
-        # GEMM + pooling kernel on MI355X in round 1 (atomicMax rate), so off by default
+        # fused mask contraction + preserve-pooling (the intermediate mask logits are never written)
         self.use_fused_mask_pool = os.environ.get("OCCF_FUSED_MASK_POOL", "1") == "1"
+        self._mgp_reverse = 0
         self.use_fused_swin = os.environ.get("OCCF_FUSED_SWIN", "1") == "1"
         self.use_fused_mlp = os.environ.get("OCCF_FUSED_MLP", "1") == "1"
 
@@ -195,7 +195,8 @@ class HipOps:
         self._call("occf_mask_gemm_pool_fwd", self._ptr(mask_embed, self.f32), self._ptr(feat_split[0]),
                    self._ptr(feat_split[1]), self._ptr(pooled), self._ptr(blocked), self._ptr(row_open),
                    self._ptr(ws), B, Q, E, X, Y, Z, ox, oy, oz, 3 if self.precision == "bf16x3" else 1,
-                   self._stream())
+                   self._mgp_reverse, self._stream())
+        self._mgp_reverse ^= 1          # next call walks the features the other way (cache reuse, same results)
         return pooled, blocked, row_open
 
     def masked_attention(self, q, k, v, heads, blocked=None, row_open=None):

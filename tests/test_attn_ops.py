@@ -132,14 +132,16 @@ def test_lidarseg_sample(be):
     assert torch.allclose(out, ref, **TOL), float((out - ref).abs().max())
 
 
+@pytest.mark.parametrize("E", [64, 192])         # 192 channels: the streaming kernel (where the geometry allows)
 @pytest.mark.parametrize("shape,target,Q", [((8, 8, 16), (4, 4, 8), 20), ((8, 8, 16), (2, 2, 2), 100),
                                             ((4, 16, 8), (2, 4, 2), 9), ((8, 8, 16), (8, 8, 16), 128),
-                                            ((4, 32, 4), (1, 2, 1), 3)])
-def test_mask_gemm_pool_fused(be, monkeypatch, shape, target, Q):
+                                            ((4, 32, 4), (1, 2, 1), 3), ((2, 4, 32), (1, 2, 4), 33),
+                                            ((16, 8, 16), (2, 2, 8), 70)])
+def test_mask_gemm_pool_fused(be, monkeypatch, shape, target, Q, E):
     """fused GEMM+pool == (same split-bf16 GEMM, then the pooling kernel), bit for bit; x-window slices,
     several windows per tile, window = voxel"""
     monkeypatch.setattr(be.ops, "precision", "bf16x3")
-    B, E = 2, 64
+    B = 2
     X, Y, Z = shape
     me = paramgen.tensor("me", (B, Q, E), 1)
     feat = paramgen.tensor("mf", (B, X * Y * Z, E), 2)
@@ -150,6 +152,8 @@ def test_mask_gemm_pool_fused(be, monkeypatch, shape, target, Q):
         be.ops.linear(be.to(me)[b], be.to(feat)[b], out=mpd[b], w_split=(sp[0][b], sp[1][b]), allow_small=False)
     ref_pooled, ref_blocked, ref_open = be.ops.mask_pool(mpd.view(B, Q, X, Y, Z), target)
     pooled, blocked, row_open = be.ops.mask_gemm_pool(be.to(me), sp, shape, target)
+    again = be.ops.mask_gemm_pool(be.to(me), sp, shape, target)         # the other traversal direction
+    assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(again, (pooled, blocked, row_open)))
     assert torch.equal(pooled.cpu(), ref_pooled.cpu())
     assert torch.equal(blocked.cpu(), ref_blocked.cpu()) and torch.equal(row_open.cpu(), ref_open.cpu())
     # and against plain fp32 torch within the split-bf16 accuracy
