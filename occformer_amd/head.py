@@ -8,6 +8,8 @@ state-dict names; the mmcv/mmdet bricks underneath
 folded into plain modules.  Tokens are batch-first.  Kernels: csrc/mask_head.hip.
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -43,19 +45,24 @@ class _MHA(nn.Module):
         self.heads = heads
         self.E = E
 
-    def forward(self, query, key, value, query_pos, key_pos, blocked=None, row_open=None, key_with_pos=None):
+    def forward(self, query, key, value, query_pos, key_pos, blocked=None, row_open=None, key_with_pos=None,
+                kv=None):
         """``key_with_pos``: ``key + key_pos`` computed by the caller (the level tokens and their encodings
-        are the same for every layer that attends to that level)"""
+        are the same for every layer that attends to that level); ``kv``: this layer's projected keys / values
+        when the caller projected a level's tokens for all of its layers in one GEMM"""
         E = self.E
         ops = get_ops()
         w, b = self.attn.in_proj_weight.detach(), self.attn.in_proj_bias.detach()
         sp = fused.split_weight(self.attn.in_proj_weight)
         part = (lambda lo, hi: None) if sp is None else (lambda lo, hi: (sp[0][lo:hi], sp[1][lo:hi]))
         q = ops.linear(query + query_pos, w[:E], b[:E], w_split=part(0, E))
-        if key_with_pos is None:
-            key_with_pos = key + key_pos if key_pos is not None else key
-        k = ops.linear(key_with_pos, w[E:2 * E], b[E:2 * E], w_split=part(E, 2 * E))
-        v = ops.linear(value, w[2 * E:], b[2 * E:], w_split=part(2 * E, 3 * E))
+        if kv is not None:
+            k, v = kv
+        else:
+            if key_with_pos is None:
+                key_with_pos = key + key_pos if key_pos is not None else key
+            k = ops.linear(key_with_pos, w[E:2 * E], b[E:2 * E], w_split=part(E, 2 * E))
+            v = ops.linear(value, w[2 * E:], b[2 * E:], w_split=part(2 * E, 3 * E))
         o = ops.masked_attention(q, k, v, self.heads, blocked, row_open)
         return fused.linear(o, self.attn.out_proj, residual=query.contiguous())
 
@@ -70,8 +77,8 @@ class _DecoderLayer(nn.Module):
         self.ffns = nn.ModuleList([_FFN(E, ffn_channels, act="relu")])
         self.norms = nn.ModuleList([nn.LayerNorm(E) for _ in range(3)])
 
-    def forward(self, q, qpos, key, key_pos, blocked, row_open, key_with_pos=None):
-        q = fused.layernorm(self.attentions[0](q, key, key, qpos, key_pos, blocked, row_open, key_with_pos),
+    def forward(self, q, qpos, key, key_pos, blocked, row_open, key_with_pos=None, kv=None):
+        q = fused.layernorm(self.attentions[0](q, key, key, qpos, key_pos, blocked, row_open, key_with_pos, kv),
                             self.norms[0])
         q = fused.layernorm(self.attentions[1](q, q, q, qpos, qpos), self.norms[1])
         ffn = self.ffns[0].layers
@@ -169,6 +176,46 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
             am = (blocked, row_open)
         return cls_pred, mask_pred, am
 
+    def _project_level_tokens(self, keys, keys_pp):
+        """Key / value projections of the cross-attentions (mask2former_nusc_occ.py:657-667 via
+        nn.MultiheadAttention's in_proj): layers lv, lv + n_levels, ... attend to the same level tokens, so their
+        key (and value) projections are ONE GEMM per level with the layers' weights stacked along N; the
+        epilogue writes the stack "head-major", i.e. as one contiguous [L, E] matrix per layer.
+        -> per level (K [B, n, L, E], V [B, n, L, E]), or None when the stacked form does not apply."""
+        ops = get_ops()
+        nl = self.num_transformer_feat_level
+        layers = self.transformer_decoder.layers
+        E = self.decoder_embed_dims
+        B = keys[0].shape[0]
+        if B != 1 or len(layers) % nl or ops.precision == "f32" or os.environ.get("OCCF_STACK_KV", "1") != "1":
+            return None
+        params = [l.attentions[0].attn.in_proj_weight for l in layers] + \
+                 [l.attentions[0].attn.in_proj_bias for l in layers]
+        ver = tuple((p._version, p.data_ptr()) for p in params) + (ops.precision, id(ops))
+        cache = getattr(self, "_kv_stack", None)
+        if cache is None or cache[0] != ver:
+            per_level = []
+            with torch.no_grad():
+                for lv in range(nl):
+                    ls = layers[lv::nl]
+                    wk = torch.cat([l.attentions[0].attn.in_proj_weight.detach()[E:2 * E] for l in ls]).contiguous()
+                    wv = torch.cat([l.attentions[0].attn.in_proj_weight.detach()[2 * E:] for l in ls]).contiguous()
+                    bk = torch.cat([l.attentions[0].attn.in_proj_bias.detach()[E:2 * E] for l in ls]).contiguous()
+                    bv = torch.cat([l.attentions[0].attn.in_proj_bias.detach()[2 * E:] for l in ls]).contiguous()
+                    per_level.append((wk, bk, ops.split_bf16(wk), wv, bv, ops.split_bf16(wv)))
+            cache = (ver, per_level)
+            self._kv_stack = cache
+        out = []
+        for lv in range(nl):
+            wk, bk, spk, wv, bv, spv = cache[1][lv]
+            L = keys[lv].shape[1]
+            if not ops.head_major_supported(L, wk.shape[0], E, E):
+                return None
+            k = ops.linear(keys_pp[lv].reshape(L, E), wk, bk, w_split=spk, head_major=(L, E))
+            v = ops.linear(keys[lv].reshape(L, E), wv, bv, w_split=spv, head_major=(L, E))
+            out.append((k, v))
+        return out
+
     # -- mask2former_nusc_occ.py:589-689
     def forward(self, voxel_feats, img_metas=None, last_only=False, **kwargs):
         """Reference contract: (list[10] cls, list[10] mask_pred).  ``last_only=True`` (what
@@ -198,9 +245,14 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
         if not last_only:
             cls_list.append(cls)
             mask_list.append(mp)
+        kv_all = self._project_level_tokens(keys, keys_pp)
         for i, layer in enumerate(self.transformer_decoder.layers):
             lv = i % self.num_transformer_feat_level
-            q = layer(q, qpos, keys[lv], key_pos[lv], am[0], am[1], keys_pp[lv])
+            kv = None
+            if kv_all is not None:
+                j = i // self.num_transformer_feat_level
+                kv = (kv_all[lv][0][:, j], kv_all[lv][1][:, j])
+            q = layer(q, qpos, keys[lv], key_pos[lv], am[0], am[1], keys_pp[lv], kv)
             last = i == n_layers - 1
             cls, mp, am = self.forward_head(q, mask_tok, vol_shape,
                                             shapes[(i + 1) % self.num_transformer_feat_level], mf_split,
