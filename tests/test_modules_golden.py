@@ -92,3 +92,25 @@ def test_head(bound):
     res = head.simple_test(feats, metas, points=[bound.to(g["pts0"]), bound.to(g["pts1"])])
     _close(res["output_voxels"][0], g["output_voxels"], "output_voxels")
     _close(res["output_points"], g["output_points"], "output_points")
+
+
+@torch.no_grad()
+def test_head_stacked_kv_projection(bound, monkeypatch):
+    """batch 1: the cross-attention key / value projections of a level's layers run as one stacked GEMM; the
+    predictions must equal the per-layer projections (OCCF_STACK_KV=0) to GEMM rounding"""
+    g, gp = golden("head"), golden("pixel_decoder")
+    model, meta = tinycfg.tiny_nusc()
+    head = _build(dict(model["pts_bbox_head"], train_cfg=None, test_cfg=None), g["seed"], bound,
+                  g["param_checksum"])
+    feats = [bound.to(gp[f"out{i}"])[:1].contiguous() for i in range(4)]
+    metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])]
+    monkeypatch.setenv("OCCF_STACK_KV", "1")
+    if head._project_level_tokens(*[[f.flatten(2).transpose(1, 2).contiguous() for f in feats[1:]]] * 2) is None:
+        pytest.skip("stacked projection not applicable in this precision mode / geometry")
+    cls_a, mask_a = head(feats, metas)
+    monkeypatch.setenv("OCCF_STACK_KV", "0")
+    cls_b, mask_b = head(feats, metas)
+    for a, b in zip(cls_a + mask_a, cls_b + mask_b):
+        assert torch.allclose(a.cpu(), b.cpu(), atol=2e-4, rtol=1e-4), float((a.cpu() - b.cpu()).abs().max())
+    # and both agree with the reference's batch-2 golden output on sample 0
+    _close(mask_a[-1], g["mask_last"][:1], "mask_last (stacked, batch 1)")
