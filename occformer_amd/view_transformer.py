@@ -181,9 +181,17 @@ class DeformConv2dPack(nn.Module):
         """weight [Cout, Cin/groups, k, k] -> per group [Cout/groups, k*k*Cin/groups] (tap-major K)."""
         from . import fused
         w = self.weight
-        return fused._versioned(_DCN_CACHE, w, lambda: [
-            wg.permute(0, 2, 3, 1).reshape(wg.shape[0], -1).contiguous()
-            for wg in w.detach().chunk(self.groups, 0)])
+        ops = get_ops()
+
+        def make():
+            ws = [wg.permute(0, 2, 3, 1).reshape(wg.shape[0], -1).contiguous() for wg in w.detach().chunk(self.groups, 0)]
+            # (hi, lo) bf16 split per group: K = 9 * Cin/groups is sliced over the chip by the split-K GEMM
+            return [(wg, None if ops.precision == "f32" else ops.split_bf16(wg)) for wg in ws], ops.precision
+        hit = fused._versioned(_DCN_CACHE, w, make)
+        if hit[1] != ops.precision:                  # precision mode switched since the cache entry was made
+            _DCN_CACHE.pop(id(w), None)
+            hit = fused._versioned(_DCN_CACHE, w, make)
+        return hit[0]
 
     def forward(self, x):
         """x [BN, C, H, W] -> [BN, Cout, H, W]; bilinear im2col in csrc/dcn.hip, then one MFMA GEMM
@@ -195,9 +203,9 @@ class DeformConv2dPack(nn.Module):
         col = ops.deform_im2col(x.permute(0, 2, 3, 1).contiguous(), offset, k, 1, pad, 1, G, self.deform_groups)
         Cout = self.weight.shape[0]
         out = torch.empty((B * H * W, Cout), dtype=x.dtype, device=x.device)
-        for g, wg in enumerate(self._group_weights()):
+        for g, (wg, sp) in enumerate(self._group_weights()):
             ops.linear(col[:, g].flatten(1), wg,       # row-strided view: the group's contiguous K-slab
-                       out=out[:, g * (Cout // G):(g + 1) * (Cout // G)])
+                       out=out[:, g * (Cout // G):(g + 1) * (Cout // G)], w_split=sp)
         return out.view(B, H, W, Cout).permute(0, 3, 1, 2)
 
     def forward_cl(self, x_cl):
@@ -210,8 +218,8 @@ class DeformConv2dPack(nn.Module):
         col = ops.deform_im2col(x_cl.reshape(B, H, W, C), offset, k, 1, pad, 1, G, self.deform_groups)
         Cout = self.weight.shape[0]
         out = torch.empty((B * H * W, Cout), dtype=x_cl.dtype, device=x_cl.device)
-        for g, wg in enumerate(self._group_weights()):
-            ops.linear(col[:, g].flatten(1), wg, out=out[:, g * (Cout // G):(g + 1) * (Cout // G)])
+        for g, (wg, sp) in enumerate(self._group_weights()):
+            ops.linear(col[:, g].flatten(1), wg, out=out[:, g * (Cout // G):(g + 1) * (Cout // G)], w_split=sp)
         return out.view(B, H, W, 1, Cout)
 
 
