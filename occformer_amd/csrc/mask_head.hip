@@ -344,15 +344,38 @@ __global__ void __launch_bounds__(128) class_prob_kernel(const float* __restrict
   for (int i = 0; i < UC_MAXK; ++i) prob[(long)qi * UC_MAXK + i] = i < K ? expf(c[i] - mx) / sum : 0.f;
 }
 
+// One output voxel per lane with z fastest: the 64 lanes of a wave cover 2 output rows, so each of the 8
+// tap loads touches 2-4 cache lines (variants with 2 / 4 outputs per lane spread a wave over 4 / 8 rows and
+// became bound by the lines per gather instead).  What is left is VALU work, kept to ~35 instructions per
+// (voxel, query): corner weights precomputed (8 FMAs for the blend), hardware exp / rcp for the sigmoid, KB
+// class FMAs with the class weights in SGPRs, buffer-addressed gathers (fixed 32-bit lane offsets, the
+// query's plane offset is scalar) and the next query's taps in flight while this one is consumed.
+template <int KB>
 __global__ void __launch_bounds__(256) upsample_classify_kernel(
     const float* __restrict__ mask_pred, const float* __restrict__ prob, float* __restrict__ out, int B,
     int Q, int K, int X, int Y, int Z, int X2, int Y2, int Z2) {
   const int b = blockIdx.y;
   const long V2 = (long)X2 * Y2 * Z2;
   // x2-major workgroup order + XCD remap: the output planes that read one source plane share an L2
-  const long vid = (long)occf_xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-  if (vid >= V2) return;
-  const int z2 = (int)(vid % Z2), y2 = (int)((vid / Z2) % Y2), x2 = (int)(vid / ((long)Z2 * Y2));
+  const long wg = occf_xcd_remap(blockIdx.x, gridDim.x);
+  int x2, y2, z2;
+  long vid;
+  if (Z2 == 32 && (X2 & 1) == 0 && (Y2 & 3) == 0) {
+    // workgroup = 2 x-planes x 4 y-rows x 32 z: both output planes blend the same two source planes and the
+    // 4 rows need ~3 source rows -- 6 source lines per query instead of 10 for 8 rows of one plane (the
+    // kernel is bound by the L2 -> L1 line traffic of its gathers)
+    const int yb = Y2 >> 2;
+    z2 = threadIdx.x & 31;
+    y2 = (int)(wg % yb) * 4 + ((threadIdx.x >> 5) & 3);
+    x2 = (int)(wg / yb) * 2 + (threadIdx.x >> 7);
+    vid = ((long)x2 * Y2 + y2) * Z2 + z2;
+  } else {
+    vid = wg * blockDim.x + threadIdx.x;
+    if (vid >= V2) return;
+    z2 = (int)(vid % Z2);
+    y2 = (int)((vid / Z2) % Y2);
+    x2 = (int)(vid / ((long)Z2 * Y2));
+  }
   // align_corners=True source coordinate: dst * (in-1)/(out-1)
   const float sx = X2 > 1 ? (float)(X - 1) / (float)(X2 - 1) : 0.f;
   const float sy = Y2 > 1 ? (float)(Y - 1) / (float)(Y2 - 1) : 0.f;
@@ -361,28 +384,43 @@ __global__ void __launch_bounds__(256) upsample_classify_kernel(
   const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
   const int x1 = x0 + (x0 < X - 1), y1 = y0 + (y0 < Y - 1), z1 = z0 + (z0 < Z - 1);
   const float tx = fx - x0, ty = fy - y0, tz = fz - z0;
-  float acc[UC_MAXK];
+  float w[8];
+  uint32_t off[8];                   // byte offsets of the 8 taps inside one query's volume
 #pragma unroll
-  for (int i = 0; i < UC_MAXK; ++i) acc[i] = 0.f;
-  const long V = (long)X * Y * Z;
-  const long o00 = ((long)x0 * Y + y0) * Z, o01 = ((long)x0 * Y + y1) * Z;
-  const long o10 = ((long)x1 * Y + y0) * Z, o11 = ((long)x1 * Y + y1) * Z;
+  for (int c = 0; c < 8; ++c) {
+    w[c] = ((c & 4) ? tx : 1.f - tx) * ((c & 2) ? ty : 1.f - ty) * ((c & 1) ? tz : 1.f - tz);
+    off[c] = (uint32_t)((((c & 4) ? x1 : x0) * Y + ((c & 2) ? y1 : y0)) * Z + ((c & 1) ? z1 : z0)) * 4u;
+  }
+  float acc[KB];
+#pragma unroll
+  for (int i = 0; i < KB; ++i) acc[i] = 0.f;
+  const uint32_t Vb = (uint32_t)X * Y * Z * 4u;          // bytes per query volume (host checks Q * Vb < 2^32)
+  const occf_buf mb = occf_make_buf(mask_pred + (long)b * Q * ((long)X * Y * Z));
   const float* pb = prob + (long)b * Q * UC_MAXK;
-  for (int qi = 0; qi < Q; ++qi) {
-    const float* mp = mask_pred + ((long)b * Q + qi) * V;
-    // same nesting as upsample_trilinear3d: x outermost, z innermost
-    const float c00 = (1.f - tz) * mp[o00 + z0] + tz * mp[o00 + z1];
-    const float c01 = (1.f - tz) * mp[o01 + z0] + tz * mp[o01 + z1];
-    const float c10 = (1.f - tz) * mp[o10 + z0] + tz * mp[o10 + z1];
-    const float c11 = (1.f - tz) * mp[o11 + z0] + tz * mp[o11 + z1];
-    const float val = (1.f - tx) * ((1.f - ty) * c00 + ty * c01) + tx * ((1.f - ty) * c10 + ty * c11);
-    const float sg = 1.0f / (1.0f + expf(-val));
-    const float* pr = pb + qi * UC_MAXK;                 // wave-uniform address -> scalar loads
+  float ma[8], mq[8];                // two tap sets: one in flight while the other is used
+  auto fetch = [&](float* m, int q) {
+    const uint32_t so = (uint32_t)(q < Q ? q : Q - 1) * Vb;     // past the end: re-read the last volume
 #pragma unroll
-    for (int i = 0; i < UC_MAXK; ++i) acc[i] = fmaf(pr[i], sg, acc[i]);
+    for (int c = 0; c < 8; ++c) m[c] = occf_buf_load_f32(mb, off[c], so);
+  };
+  auto consume = [&](const float* m, int q) {
+    float val = w[0] * m[0];
+#pragma unroll
+    for (int c = 1; c < 8; ++c) val = fmaf(w[c], m[c], val);
+    const float sg = occf_rcp_fast(1.0f + __expf(-val));
+    const float* pr = pb + q * UC_MAXK;                  // wave-uniform address -> scalar loads
+#pragma unroll
+    for (int i = 0; i < KB; ++i) acc[i] = fmaf(pr[i], sg, acc[i]);
+  };
+  fetch(ma, 0);
+  for (int qi = 0; qi < Q; qi += 2) {
+    fetch(mq, qi + 1);
+    consume(ma, qi);
+    fetch(ma, qi + 2);
+    if (qi + 1 < Q) consume(mq, qi + 1);
   }
 #pragma unroll
-  for (int i = 0; i < UC_MAXK; ++i)
+  for (int i = 0; i < KB; ++i)
     if (i < K) out[((long)b * K + i) * V2 + vid] = acc[i];
 }
 
@@ -459,8 +497,13 @@ extern "C" int occf_upsample_classify_fwd(const float* mask_pred, const float* c
       hipLaunchKernelGGL((classify_identity_kernel<UC_MAXK, 8>), grid, dim3(256), 0, st, mask_pred,
                          (const float*)workspace, out, Q, K, V2);
   } else {
-    hipLaunchKernelGGL(upsample_classify_kernel, dim3(occf_cdiv(V2, 256), B), dim3(256), 0, st, mask_pred,
-                       (const float*)workspace, out, B, Q, K, X, Y, Z, X2, Y2, Z2);
+    if ((long)Q * X * Y * Z >= (1L << 30)) return OCCF_ESHAPE;      // 32-bit byte offsets inside the mask volume
+    if (K <= 18)
+      hipLaunchKernelGGL((upsample_classify_kernel<18>), dim3(occf_cdiv(V2, 256), B), dim3(256), 0, st, mask_pred,
+                         (const float*)workspace, out, B, Q, K, X, Y, Z, X2, Y2, Z2);
+    else
+      hipLaunchKernelGGL((upsample_classify_kernel<UC_MAXK>), dim3(occf_cdiv(V2, 256), B), dim3(256), 0, st,
+                         mask_pred, (const float*)workspace, out, B, Q, K, X, Y, Z, X2, Y2, Z2);
   }
   OCCF_LAUNCH_CHECK();
 }

@@ -92,6 +92,31 @@ void occf_bf16_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
 #define OCCF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// buffer-addressed loads: SGPR resource + 32-bit VGPR byte offset + SGPR byte offset, i.e. no 64-bit
+// address arithmetic per load (a gather kernel that walks many same-shaped planes keeps the per-lane
+// offsets fixed and moves only the scalar offset)
+#ifdef OCCF_EMU
+struct occf_buf {
+  const char* base;
+};
+static inline occf_buf occf_make_buf(const void* p) { return occf_buf{(const char*)p}; }
+static inline float occf_buf_load_f32(occf_buf b, uint32_t voff, uint32_t soff) {
+  float f;
+  memcpy(&f, b.base + voff + soff, 4);
+  return f;
+}
+static inline float occf_rcp_fast(float x) { return 1.0f / x; }
+#else
+typedef __amdgpu_buffer_rsrc_t occf_buf;
+__device__ __forceinline__ occf_buf occf_make_buf(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ float occf_buf_load_f32(occf_buf b, uint32_t voff, uint32_t soff) {
+  return occf_u2f(__builtin_amdgcn_raw_buffer_load_b32(b, voff, soff, 0));
+}
+__device__ __forceinline__ float occf_rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }   // 1 ulp
+#endif
+
 // error codes of the C ABI (0 = ok, >0 = hipError_t, <0 = argument error)
 #define OCCF_EINVAL (-1)
 #define OCCF_ESHAPE (-2)
