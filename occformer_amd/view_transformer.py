@@ -224,8 +224,9 @@ class DeformConv2dPack(nn.Module):
 
 
 class DepthNet(nn.Module):
-    """ViewTransformerLSSBEVDepth.py:450-504.  Dense 2-D convolutions run through
-    PyTorch-ROCm (MIOpen); SURVEY.md §8a row 2 keeps them outside the custom-kernel scope."""
+    """ViewTransformerLSSBEVDepth.py:450-504.  Eval mode runs channels-last on the
+    library's implicit-GEMM / split-K kernels with the BatchNorms folded in and the DCN on csrc/dcn.hip; only
+    the [BN, C] camera-MLP vectors stay on ATen.  Training mode keeps the plain nn.Module graph."""
 
     def __init__(self, in_channels, mid_channels, context_channels, depth_channels, cam_channels=27):
         super().__init__()
