@@ -121,17 +121,23 @@ __global__ void __launch_bounds__(256) msda3d_fwd_kernel(
       vp[c] = vbase + ((long)(occf_clampi(xx, Xl - 1) * Yl + occf_clampi(yy, Yl - 1)) * Zl +
                        occf_clampi(zz, Zl - 1)) * kstride;
     }
-    if (VEC == 4) {
-      float4 t[8];
+    if (VEC % 4 == 0) {
+      constexpr int NV4 = VEC / 4 > 0 ? VEC / 4 : 1;
+      float4 t[8][NV4];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) t[c] = *(const float4*)vp[c];
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int u = 0; u < NV4; ++u) t[c][u] = *(const float4*)(vp[c] + 4 * u);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         if (cw[c] != 0.f) {   // (keeps a non-finite value behind a zero weight out of the sum)
-          acc[0] = fmaf(cw[c], t[c].x, acc[0]);
-          acc[1 % VEC] = fmaf(cw[c], t[c].y, acc[1 % VEC]);
-          acc[2 % VEC] = fmaf(cw[c], t[c].z, acc[2 % VEC]);
-          acc[3 % VEC] = fmaf(cw[c], t[c].w, acc[3 % VEC]);
+#pragma unroll
+          for (int u = 0; u < NV4; ++u) {
+            acc[(4 * u + 0) % VEC] = fmaf(cw[c], t[c][u].x, acc[(4 * u + 0) % VEC]);
+            acc[(4 * u + 1) % VEC] = fmaf(cw[c], t[c][u].y, acc[(4 * u + 1) % VEC]);
+            acc[(4 * u + 2) % VEC] = fmaf(cw[c], t[c][u].z, acc[(4 * u + 2) % VEC]);
+            acc[(4 * u + 3) % VEC] = fmaf(cw[c], t[c][u].w, acc[(4 * u + 3) % VEC]);
+          }
         }
       }
     } else {
@@ -150,8 +156,11 @@ __global__ void __launch_bounds__(256) msda3d_fwd_kernel(
     }
   }
   float* o = out + (long)(b * Nq + q) * E + h * Dh + cv;
-  if (VEC == 4) {
-    *(float4*)o = make_float4(acc[0], acc[1 % VEC], acc[2 % VEC], acc[3 % VEC]);
+  if (VEC % 4 == 0) {
+#pragma unroll
+    for (int u = 0; u < (VEC / 4 > 0 ? VEC / 4 : 1); ++u)
+      *(float4*)(o + 4 * u) = make_float4(acc[(4 * u) % VEC], acc[(4 * u + 1) % VEC], acc[(4 * u + 2) % VEC],
+                                          acc[(4 * u + 3) % VEC]);
   } else {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) o[v] = acc[v];
@@ -180,14 +189,32 @@ extern "C" int occf_msda3d_fwd(const float* value, const float* sampling_offsets
   hipStream_t st = (hipStream_t)stream;
   const long off_ld = offsets_ld > 0 ? offsets_ld : (long)heads * num_levels * num_points * 3;
   const long lg_ld = logits_ld > 0 ? logits_ld : (long)heads * num_levels * num_points;
+  // channels per lane: the location / softmax / corner-weight arithmetic is repeated by every lane of a
+  // (query, head), so wider lanes trade gather parallelism for less redundant VALU work (head_dim 24: 12
+  // channels per lane = 2 lanes per (query, head) instead of 6: 2.86 -> 2.22 ms per step)
+  static const int vec_env = [] {
+    const char* e = getenv("OCCF_MSDA_VEC");
+    return e ? atoi(e) : 0;
+  }();
+  int vec = head_dim % 12 == 0 ? 12 : head_dim % 8 == 0 ? 8 : 4;
+  if (vec_env > 0 && vec_env % 4 == 0 && head_dim % vec_env == 0 && (vec_env == 4 || vec_env == 8 || vec_env == 12 || vec_env == 24)) vec = vec_env;
   if (head_dim % 4 == 0) {
-    const long total = (long)B * Nq * heads * (head_dim / 4);
-    if (value_head_major)
-      hipLaunchKernelGGL((msda3d_fwd_kernel<4, 16, true>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,
-                         sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
-    else
-      hipLaunchKernelGGL((msda3d_fwd_kernel<4, 16, false>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,
-                         sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
+    const long total = (long)B * Nq * heads * (head_dim / vec);
+#define OCCF_MSDA_LAUNCH(V_, HM_)                                                                                  \
+    hipLaunchKernelGGL((msda3d_fwd_kernel<V_, 16, HM_>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,     \
+                       sampling_offsets, attn_logits, out, lv, B, Nq, heads, head_dim, num_points, off_ld, lg_ld)
+    if (value_head_major) {
+      if (vec == 24) OCCF_MSDA_LAUNCH(24, true);
+      else if (vec == 12) OCCF_MSDA_LAUNCH(12, true);
+      else if (vec == 8) OCCF_MSDA_LAUNCH(8, true);
+      else OCCF_MSDA_LAUNCH(4, true);
+    } else {
+      if (vec == 24) OCCF_MSDA_LAUNCH(24, false);
+      else if (vec == 12) OCCF_MSDA_LAUNCH(12, false);
+      else if (vec == 8) OCCF_MSDA_LAUNCH(8, false);
+      else OCCF_MSDA_LAUNCH(4, false);
+    }
+#undef OCCF_MSDA_LAUNCH
   } else {
     const long total = (long)B * Nq * heads * head_dim;
     if (value_head_major)

@@ -41,7 +41,8 @@ def test_window_mask_and_index_tables():
 
 @pytest.mark.parametrize("E,heads,shapes", [(96, 8, [(2, 2, 1), (4, 4, 2), (8, 8, 4)]),
                                             (48, 4, [(3, 2, 2), (5, 4, 3)]),
-                                            (40, 8, [(2, 3, 1), (4, 4, 2), (6, 5, 3)])])
+                                            (40, 8, [(2, 3, 1), (4, 4, 2), (6, 5, 3)]),
+                                            (192, 8, [(2, 2, 1), (4, 3, 2)])])     # head dim 24 as in the configs
 def test_msda3d(be, E, heads, shapes):
     B, P = 2, 4
     L = len(shapes)
