@@ -87,10 +87,14 @@ __global__ void __launch_bounds__(256) msda3d_fwd_kernel(
 #pragma unroll
   for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
 
+  // 24-bit multiplies (full rate; every factor here is < 2^24) and 32-bit element offsets from one 64-bit base
+  // per level: the generic 64-bit index arithmetic per corner was ~45 % of this VALU-bound kernel
+  const long Nv = lv.start[L - 1] + (long)lv.X[L - 1] * lv.Y[L - 1] * lv.Z[L - 1];
+  const int kstride = HM ? Dh : E;                        // floats between consecutive keys
+  int l = 0, pl = 0;                                      // level / point-in-level of sample i (no division)
 #pragma unroll
   for (int i = 0; i < LP_MAX; ++i) {
     if (i < LP) {
-    const int l = i / P;
     const int Xl = lv.X[l], Yl = lv.Y[l], Zl = lv.Z[l];
     // loc = ref + off / (Z, Y, X);  grid = 2 loc - 1;  pixel = ((grid + 1) * size - 1) / 2
     const float lz = rz + of[i * 3 + 0] / (float)Zl;
@@ -103,55 +107,70 @@ __global__ void __launch_bounds__(256) msda3d_fwd_kernel(
     const float tz = pz - fz, ty = py - fy, tx = px - fx;
     const int iz = (int)fz, iy = (int)fy, ix = (int)fx;
     const float wgt = w[i] * inv;
-    const long Nv = lv.start[L - 1] + (long)lv.X[L - 1] * lv.Y[L - 1] * lv.Z[L - 1];
-    const long kstride = HM ? Dh : E;                       // floats between consecutive keys
     const float* vbase = HM ? value + (((long)b * H + h) * Nv + lv.start[l]) * Dh + cv
                             : value + ((long)b * Nv + lv.start[l]) * E + h * Dh + cv;
-    // the 8 corner gathers of a sample are issued together and unconditionally (clamped address,
-    // zero weight outside the volume): a gather under `if (inside)` is waited for on the spot
+    // per axis: the two taps, clamped into the volume, and whether each lies inside it
+    const bool vx[2] = {(unsigned)ix < (unsigned)Xl, (unsigned)(ix + 1) < (unsigned)Xl};
+    const bool vy[2] = {(unsigned)iy < (unsigned)Yl, (unsigned)(iy + 1) < (unsigned)Yl};
+    const bool vz[2] = {(unsigned)iz < (unsigned)Zl, (unsigned)(iz + 1) < (unsigned)Zl};
+    const uint32_t cx[2] = {(uint32_t)occf_clampi(ix, Xl - 1), (uint32_t)occf_clampi(ix + 1, Xl - 1)};
+    const uint32_t cy[2] = {(uint32_t)occf_clampi(iy, Yl - 1), (uint32_t)occf_clampi(iy + 1, Yl - 1)};
+    const uint32_t zk[2] = {occf_umul24((uint32_t)occf_clampi(iz, Zl - 1), (uint32_t)kstride),
+                            occf_umul24((uint32_t)occf_clampi(iz + 1, Zl - 1), (uint32_t)kstride)};
+    const uint32_t rowx[2] = {occf_umul24(cx[0], (uint32_t)Yl), occf_umul24(cx[1], (uint32_t)Yl)};
+    const uint32_t zs = occf_umul24((uint32_t)Zl, (uint32_t)kstride);
+    // the 8 corner gathers of a sample are issued together and unconditionally (clamped address): a gather
+    // under `if (inside)` is waited for on the spot
     float cw[8];
-    const float* vp[8];
+    uint32_t vo[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const int xx = ix + (c >> 2), yy = iy + ((c >> 1) & 1), zz = iz + (c & 1);
-      const bool in = xx >= 0 && xx < Xl && yy >= 0 && yy < Yl && zz >= 0 && zz < Zl;
-      const float wc = ((c >> 2) ? tx : 1.f - tx) * (((c >> 1) & 1) ? ty : 1.f - ty) *
-                       ((c & 1) ? tz : 1.f - tz) * wgt;
-      cw[c] = in ? wc : 0.f;
-      vp[c] = vbase + ((long)(occf_clampi(xx, Xl - 1) * Yl + occf_clampi(yy, Yl - 1)) * Zl +
-                       occf_clampi(zz, Zl - 1)) * kstride;
+      const int bx = c >> 2, by = (c >> 1) & 1, bz = c & 1;
+      cw[c] = (bx ? tx : 1.f - tx) * (by ? ty : 1.f - ty) * (bz ? tz : 1.f - tz) * wgt;
+      vo[c] = occf_umul24(rowx[bx] + cy[by], zs) + zk[bz];
     }
+    constexpr int NV4 = VEC % 4 == 0 ? VEC / 4 : 1;
+    constexpr int NS = VEC % 4 == 0 ? 1 : VEC;
+    float4 t4[8][NV4];
+    float t1[8][NS];
     if (VEC % 4 == 0) {
-      constexpr int NV4 = VEC / 4 > 0 ? VEC / 4 : 1;
-      float4 t[8][NV4];
 #pragma unroll
       for (int c = 0; c < 8; ++c)
 #pragma unroll
-        for (int u = 0; u < NV4; ++u) t[c][u] = *(const float4*)(vp[c] + 4 * u);
-#pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        if (cw[c] != 0.f) {   // (keeps a non-finite value behind a zero weight out of the sum)
-#pragma unroll
-          for (int u = 0; u < NV4; ++u) {
-            acc[(4 * u + 0) % VEC] = fmaf(cw[c], t[c][u].x, acc[(4 * u + 0) % VEC]);
-            acc[(4 * u + 1) % VEC] = fmaf(cw[c], t[c][u].y, acc[(4 * u + 1) % VEC]);
-            acc[(4 * u + 2) % VEC] = fmaf(cw[c], t[c][u].z, acc[(4 * u + 2) % VEC]);
-            acc[(4 * u + 3) % VEC] = fmaf(cw[c], t[c][u].w, acc[(4 * u + 3) % VEC]);
-          }
-        }
-      }
+        for (int u = 0; u < NV4; ++u) t4[c][u] = *(const float4*)(vbase + vo[c] + 4 * u);
     } else {
-      float t[8][VEC];
 #pragma unroll
       for (int c = 0; c < 8; ++c)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) t[c][v] = vp[c][v];
+        for (int v = 0; v < VEC; ++v) t1[c][v] = vbase[vo[c] + v];
+    }
+    auto add_corner = [&](int c) __attribute__((always_inline)) {
+      if (VEC % 4 == 0) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
-        if (cw[c] != 0.f) {
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) acc[v] = fmaf(cw[c], t[c][v], acc[v]);
+        for (int u = 0; u < NV4; ++u) {
+          acc[(4 * u + 0) % VEC] = fmaf(cw[c], t4[c][u].x, acc[(4 * u + 0) % VEC]);
+          acc[(4 * u + 1) % VEC] = fmaf(cw[c], t4[c][u].y, acc[(4 * u + 1) % VEC]);
+          acc[(4 * u + 2) % VEC] = fmaf(cw[c], t4[c][u].z, acc[(4 * u + 2) % VEC]);
+          acc[(4 * u + 3) % VEC] = fmaf(cw[c], t4[c][u].w, acc[(4 * u + 3) % VEC]);
         }
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = fmaf(cw[c], t1[c][v], acc[v]);
+      }
+    };
+    if (vx[0] && vx[1] && vy[0] && vy[1] && vz[0] && vz[1]) {
+      // all 8 taps inside (the common case): plain weighted sum, as grid_sample computes it
+#pragma unroll
+      for (int c = 0; c < 8; ++c) add_corner(c);
+    } else {
+      // zeros padding: a tap outside the volume contributes nothing (its clamped stand-in was only loaded)
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (vx[c >> 2] && vy[(c >> 1) & 1] && vz[c & 1]) add_corner(c);
+    }
+    if (++pl == P) {
+      pl = 0;
+      ++l;
     }
     }
   }

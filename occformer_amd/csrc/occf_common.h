@@ -117,6 +117,13 @@ __device__ __forceinline__ float occf_buf_load_f32(occf_buf b, uint32_t voff, ui
 __device__ __forceinline__ float occf_rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }   // 1 ulp
 #endif
 
+// 24-bit unsigned multiply (v_mul_u32_u24: full rate, v_mul_lo_u32 is quarter rate); operands must be < 2^24
+#ifdef OCCF_EMU
+static inline uint32_t occf_umul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+#else
+__device__ __forceinline__ uint32_t occf_umul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+#endif
+
 // error codes of the C ABI (0 = ok, >0 = hipError_t, <0 = argument error)
 #define OCCF_EINVAL (-1)
 #define OCCF_ESHAPE (-2)
