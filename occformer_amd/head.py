@@ -268,6 +268,9 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
                                            mask_pred_results.shape[-3:])
 
     def _output_voxels(self, cls, mask_pred, occ_size):
+        if not self.align_corners:
+            raise NotImplementedError("the fused resample + classify kernel implements align_corners=True "
+                                      "(the value of every OccFormer config)")
         return get_ops().upsample_classify(mask_pred.contiguous(), cls.contiguous(), tuple(occ_size))
 
 
