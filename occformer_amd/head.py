@@ -278,16 +278,23 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
 class Mask2FormerNuscOccHead(NuscTrainingMixin, _Mask2FormerOccBase):
     # -- mask2former_nusc_occ.py:505-542 (eval branch)
     def forward_lidarseg(self, cls_preds, mask_preds, points, img_metas=None):
-        pc = torch.tensor(img_metas[0]["pc_range"], dtype=torch.float32, device=mask_preds.device)
-        lo, ext = pc[:3], pc[3:] - pc[:3]
-        rows = []
-        for b, p in enumerate(points):
-            g = (p[:, :3].float() - lo) / ext * 2 - 1
-            rows.append(torch.cat((torch.full((p.shape[0], 1), float(b), device=g.device), g), 1))
+        """As the reference: the class volume at mask resolution (format_results), then a trilinear
+        grid_sample of it at the LiDAR points, then softmax.  The class volume comes from the one-tap classify
+        kernel (256 MB of logits read once, sequentially) and the point kernel gathers 8 taps x K classes per
+        point -- instead of 8 taps x 100 queries per point straight from the query logits."""
         if self.padding_mode != "border" or not self.align_corners:
             raise NotImplementedError("lidarseg sampling is built for border padding / align_corners=True")
-        return get_ops().lidarseg_sample(mask_preds.contiguous(), cls_preds.contiguous(),
-                                         torch.cat(rows, 0).contiguous())
+        ops = get_ops()
+        pc = torch.tensor(img_metas[0]["pc_range"], dtype=torch.float32, device=mask_preds.device)
+        lo, ext = pc[:3], pc[3:] - pc[:3]
+        vol = self.format_results(cls_preds, mask_preds)                       # [B, K, X, Y, Z]
+        logits = []
+        for b, p in enumerate(points):
+            # grid_sample's (x, y, z) order for a [.., X, Y, Z] volume is the reversed axis order; the point
+            # kernel takes [0, 1] coordinates (align_corners / border clamp applied inside)
+            g = ((p[:, :3].float() - lo) / ext)[:, [2, 1, 0]].contiguous()
+            logits.append(ops.point_sample_3d(vol[b:b + 1], g[None], True, "border")[0].t())
+        return torch.softmax(torch.cat(logits, 0), dim=1)
 
     # -- mask2former_nusc_occ.py:698-745
     def simple_test(self, voxel_feats, img_metas, points=None, **kwargs):
