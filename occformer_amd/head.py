@@ -285,14 +285,20 @@ class Mask2FormerNuscOccHead(NuscTrainingMixin, _Mask2FormerOccBase):
         if self.padding_mode != "border" or not self.align_corners:
             raise NotImplementedError("lidarseg sampling is built for border padding / align_corners=True")
         ops = get_ops()
-        pc = torch.tensor(img_metas[0]["pc_range"], dtype=torch.float32, device=mask_preds.device)
-        lo, ext = pc[:3], pc[3:] - pc[:3]
+        # (cached per device: building a device tensor from a Python list is a blocking host-to-device copy,
+        # i.e. a host sync in the middle of an otherwise asynchronous forward)
+        key = (tuple(float(v) for v in img_metas[0]["pc_range"]), str(mask_preds.device))
+        cache = self.__dict__.setdefault("_pc_range_cache", {})
+        if key not in cache:
+            pc = torch.tensor(key[0], dtype=torch.float32, device=mask_preds.device)
+            cache[key] = (pc[:3].clone(), (pc[3:] - pc[:3]).clone())
+        lo, ext = cache[key]
         vol = self.format_results(cls_preds, mask_preds)                       # [B, K, X, Y, Z]
         logits = []
         for b, p in enumerate(points):
             # grid_sample's (x, y, z) order for a [.., X, Y, Z] volume is the reversed axis order; the point
             # kernel takes [0, 1] coordinates (align_corners / border clamp applied inside)
-            g = ((p[:, :3].float() - lo) / ext)[:, [2, 1, 0]].contiguous()
+            g = ((p[:, :3].float() - lo) / ext).flip(-1).contiguous()      # (flip, not a list index: no H2D copy)
             logits.append(ops.point_sample_3d(vol[b:b + 1], g[None], True, "border")[0].t())
         return torch.softmax(torch.cat(logits, 0), dim=1)
 
