@@ -12,7 +12,6 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import fused
 from .encoder import _FFN

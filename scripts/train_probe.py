@@ -12,7 +12,6 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from occformer_amd import configs                     # noqa: E402
 from occformer_amd.registry import HEADS              # noqa: E402
-from occformer_amd import training as TR              # noqa: E402
 
 
 def main():
