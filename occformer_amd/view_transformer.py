@@ -21,14 +21,16 @@ def pack_cameras(rots, trans, intrins, post_rots, post_trans, bda):
     in the same order as get_geometry (ViewTransformerLSSBEVDepth.py:126-141).
     Returns cam [B*N, 27] and bda12 [B, 12] (3x4 row-major)."""
     B, N = trans.shape[:2]
-    ipr = torch.inverse(post_rots)
+    # linalg.inv_ex = torch.inverse without the singularity check, whose `info` read-back is a device-to-host
+    # synchronisation at the very start of every forward (same LU, same values)
+    ipr = torch.linalg.inv_ex(post_rots)[0]
     if intrins.shape[-1] == 4:
         shift = intrins[:, :, :3, 3]
         K = intrins[:, :, :3, :3]
     else:
         shift = torch.zeros_like(trans)
         K = intrins
-    comb = rots.matmul(torch.inverse(K))
+    comb = rots.matmul(torch.linalg.inv_ex(K)[0])
     cam = torch.cat((ipr.reshape(B, N, 9), post_trans.reshape(B, N, 3), comb.reshape(B, N, 9),
                      trans.reshape(B, N, 3), shift.reshape(B, N, 3)), -1).reshape(B * N, 27)
     bda12 = torch.zeros(B, 3, 4, dtype=torch.float32, device=bda.device)

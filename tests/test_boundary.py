@@ -134,3 +134,40 @@ def test_detector_forward_train_and_test_wiring(be, monkeypatch):
     assert set(losses) == expect
     assert all(torch.isfinite(torch.as_tensor(v)).all() for v in losses.values())
     assert out["output_voxels"].shape[-3:] == occ and out["output_points"] is not None
+
+
+@pytest.mark.gpu
+def test_inference_forward_has_no_host_sync(hip, monkeypatch):
+    """The test-time forward (extract_feat -> simple_test with LiDAR points) must stay asynchronous: no
+    .item(), no nonzero, no pageable host<->device copy.  A single such call makes the host wait for the device
+    at every step, after which the next step starts on an empty queue (round 1 found a `torch.tensor(list,
+    device=...)`, a list index and `torch.inverse`'s error check doing exactly that)."""
+    import occformer_amd.ops as ops_mod
+    from occformer_amd.registry import build_model
+    from tests import paramgen, tinycfg
+    monkeypatch.setattr(ops_mod, "_ops", hip.ops)
+    cfg, meta = tinycfg.tiny_nusc()
+    model = build_model(dict(cfg)).eval().to(hip.device)
+    B, N = 1, 3
+    H, W = meta["input_size"]
+    cams = paramgen.camera_rig(B, N, H, W, meta["focal"], seed=3)
+    x = paramgen.tensor("ns_x", (B, N, 32, meta["fH"], meta["fW"]), 3)
+    img_inputs = [t.to(hip.device) for t in (x, *cams)]
+    lo, hi_ = torch.tensor(meta["pc_range"][:3]), torch.tensor(meta["pc_range"][3:])
+    pts = (paramgen.uniform("ns_p", (200, 3), 3) * (hi_ - lo) + lo).to(hip.device)
+    metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])]
+
+    def step():
+        with torch.no_grad():
+            vox, _, _ = model.extract_feat(None, img_inputs, metas)
+            return model.pts_bbox_head.simple_test(vox, metas, points=[pts])
+
+    step()                                   # first call: weight caches, kernel attributes (may synchronise)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out = step()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["output_voxels"][0]).all() and torch.isfinite(out["output_points"]).all()
