@@ -250,6 +250,25 @@ def per_class_iu(hist):
         return np.diag(hist) / (hist.sum(1) + hist.sum(0) - np.diag(hist))
 
 
+def fast_hist_crop_device(output, target, num_labels):
+    """fast_hist_crop(output, target, arange(num_labels)) on the tensors' own device, int64 counts, with no
+    data-dependent shape (so no host synchronisation): the validity mask becomes the increment of a scatter-add
+    instead of a boolean selection."""
+    n = num_labels + 1                                   # = max(unique_label) + 2
+    valid = (target >= 0) & (target < n) & (output >= 0) & (output < n)
+    idx = torch.where(valid, n * target + output, torch.zeros_like(target))
+    hist = torch.zeros(n * n, dtype=torch.int64, device=target.device)
+    hist.scatter_add_(0, idx, valid.long())
+    return hist.view(n, n)[1:, 1:]
+
+
+def mean_iou_device(hist):
+    """nanmean(per_class_iu(hist)) in float64 on the device (0/0 -> nan -> ignored, as numpy's nanmean)"""
+    h = hist.double()
+    d = torch.diagonal(h)
+    return torch.nanmean(d / (h.sum(1) + h.sum(0) - d))
+
+
 # ------------------------------------------------------------------------------------------ head mixin
 class OccHeadTrainingMixin:
     """loss / target code shared by the two heads; the head provides num_queries, num_classes, class_weight,
@@ -366,10 +385,10 @@ class NuscTrainingMixin(OccHeadTrainingMixin):
     def lidarseg_metric(self, cls_preds, mask_preds, points, img_metas):
         """training branch of forward_lidarseg (mask2former_nusc_occ.py:526-540): point mIoU, no gradient"""
         probs = self.forward_lidarseg(cls_preds, mask_preds, points, img_metas)
-        out = (torch.argmax(probs[:, 1:], 1) + 1).cpu().numpy()
-        tgt = torch.cat([p[:, -1] for p in points]).long().cpu().numpy()
-        iou = per_class_iu(fast_hist_crop(out, tgt, np.arange(16)))
-        return {"point_mean_iou": torch.tensor(np.nanmean(iou), device=probs.device)}
+        out = torch.argmax(probs[:, 1:], 1) + 1
+        tgt = torch.cat([p[:, -1] for p in points]).long()
+        # confusion matrix and mean IoU stay on the device (the reference round-trips through numpy here)
+        return {"point_mean_iou": mean_iou_device(fast_hist_crop_device(out, tgt, 16))}
 
     def forward_train(self, voxel_feats, img_metas, gt_occ, points=None, **kwargs):
         """mask2former_nusc_occ.py:547-587 (forward values; no autograd graph is built by the HIP modules)"""

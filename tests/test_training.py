@@ -183,3 +183,19 @@ def test_depth_loss_matches_reference_fixture(bound):
     dp = paramgen.uniform("depth.pred", (6, meta["D"], meta["fH"], meta["fW"]), 8).softmax(1)
     out = vt.get_depth_loss(gd.to(be.device), dp.to(be.device))
     assert abs(float(out) - float(g["depth.loss"])) < 1e-5
+
+
+def test_device_confusion_matrix_and_miou_match_numpy():
+    """P/utils/metric_util.py semantics (fast_hist_crop / per_class_iu / nanmean) without leaving the device"""
+    import numpy as np
+    from occformer_amd import training as TR
+    g = torch.Generator().manual_seed(11)
+    out = torch.randint(1, 17, (5000,), generator=g)
+    tgt = torch.randint(-1, 19, (5000,), generator=g)                 # some labels outside 0..16
+    tgt[tgt == 7] = 3                                                 # an absent class -> nan IoU, ignored
+    out[out == 7] = 2
+    ref_hist = TR.fast_hist_crop(out.numpy(), tgt.numpy(), np.arange(16))
+    hist = TR.fast_hist_crop_device(out, tgt, 16)
+    assert np.array_equal(hist.numpy(), ref_hist)
+    ref = np.nanmean(TR.per_class_iu(ref_hist))
+    assert abs(float(TR.mean_iou_device(hist)) - ref) < 1e-12
