@@ -9,4 +9,4 @@ from . import registry  # noqa: F401
 from .registry import (ATTENTION, BACKBONES, DETECTORS, HEADS, MODELS, NECKS, Config, ConfigDict,  # noqa: F401
                        build_model)
 from . import view_transformer  # noqa: F401
-from . import encoder, pixel_decoder, head, detector  # noqa: F401,E402
+from . import encoder, pixel_decoder, head, detector, efficientnet  # noqa: F401,E402

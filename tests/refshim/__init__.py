@@ -249,7 +249,47 @@ def build_conv_layer(cfg, *args, **kwargs):
         return nn.Conv3d(*args, **kwargs, **cfg)
     if t == "DCN":
         return DeformConv2dPackZeroOffset(*args, **kwargs, **cfg)
+    if t == "Conv2dAdaptivePadding":
+        return Conv2dAdaptivePadding(*args, **kwargs, **cfg)
     raise KeyError(t)
+
+
+class Conv2dAdaptivePadding(nn.Conv2d):
+    """mmcv/cnn/bricks/conv2d_adaptive_padding.py (restated): TensorFlow "SAME" padding computed from the input
+    size at call time, extra row / column at the bottom / right; the ``padding`` argument is ignored."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True):
+        super().__init__(in_channels, out_channels, kernel_size, stride, 0, dilation, groups, bias)
+
+    def forward(self, x):
+        import math
+        img_h, img_w = x.size()[-2:]
+        kernel_h, kernel_w = self.weight.size()[-2:]
+        stride_h, stride_w = self.stride
+        output_h = math.ceil(img_h / stride_h)
+        output_w = math.ceil(img_w / stride_w)
+        pad_h = max((output_h - 1) * self.stride[0] + (kernel_h - 1) * self.dilation[0] + 1 - img_h, 0)
+        pad_w = max((output_w - 1) * self.stride[1] + (kernel_w - 1) * self.dilation[1] + 1 - img_w, 0)
+        if pad_h > 0 or pad_w > 0:
+            x = F.pad(x, [pad_w // 2, pad_w - pad_w // 2, pad_h // 2, pad_h - pad_h // 2])
+        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+
+class Swish(nn.Module):
+    """mmcv/cnn/bricks/swish.py"""
+
+    def forward(self, x):
+        return x * torch.sigmoid(x)
+
+
+def make_divisible(value, divisor, min_value=None, min_ratio=0.9):
+    """mmdet/models/utils/make_divisible.py"""
+    if min_value is None:
+        min_value = divisor
+    new_value = max(min_value, int(value + divisor / 2) // divisor * divisor)
+    if new_value < min_ratio * value:
+        new_value += divisor
+    return new_value
 
 
 class ConvModule(nn.Module):
@@ -268,8 +308,14 @@ class ConvModule(nn.Module):
             self.norm_name, norm = build_norm_layer(norm_cfg, out_channels)
             self.add_module(self.norm_name, norm)
         if self.with_activation:
-            assert act_cfg["type"] == "ReLU"
-            self.activate = nn.ReLU(inplace=inplace)
+            if act_cfg["type"] == "ReLU":
+                self.activate = nn.ReLU(inplace=inplace)
+            elif act_cfg["type"] == "Swish":
+                self.activate = Swish()
+            elif act_cfg["type"] == "Sigmoid":
+                self.activate = nn.Sigmoid()
+            else:
+                raise KeyError(act_cfg["type"])
         # mmcv ConvModule.init_weights: kaiming for conv, constant 1/0 for norm
         nn.init.kaiming_normal_(self.conv.weight, a=0, mode="fan_out", nonlinearity="relu")
         if self.conv.bias is not None:
@@ -305,6 +351,28 @@ class DropPath(nn.Module):
         shape = (x.shape[0],) + (1,) * (x.ndim - 1)
         r = keep + torch.rand(shape, dtype=x.dtype, device=x.device)
         return x.div(keep) * r.floor()
+
+
+class SELayer(BaseModule):
+    """mmdet/models/utils/se_layer.py (restated): global average -> 1x1 conv (channels / ratio, first activation)
+    -> 1x1 conv (channels, second activation) -> channel-wise gate"""
+
+    def __init__(self, channels, ratio=16, conv_cfg=None, act_cfg=(dict(type="ReLU"), dict(type="Sigmoid")),
+                 init_cfg=None):
+        super().__init__(init_cfg)
+        if isinstance(act_cfg, dict):
+            act_cfg = (act_cfg, act_cfg)
+        self.global_avgpool = nn.AdaptiveAvgPool2d(1)
+        self.conv1 = ConvModule(in_channels=channels, out_channels=int(channels / ratio), kernel_size=1, stride=1,
+                                conv_cfg=conv_cfg, act_cfg=act_cfg[0])
+        self.conv2 = ConvModule(in_channels=int(channels / ratio), out_channels=channels, kernel_size=1, stride=1,
+                                conv_cfg=conv_cfg, act_cfg=act_cfg[1])
+
+    def forward(self, x):
+        out = self.global_avgpool(x)
+        out = self.conv1(out)
+        out = self.conv2(out)
+        return x * out
 
 
 def build_dropout(cfg, default_args=None):
@@ -776,7 +844,7 @@ def install():
          xavier_init=xavier_init, normal_init=normal_init, kaiming_init=kaiming_init,
          caffe2_xavier_init=caffe2_xavier_init, trunc_normal_init=trunc_normal_init,
          build_plugin_layer=_not_available)
-    _mod("mmcv.cnn.bricks")
+    _mod("mmcv.cnn.bricks", ConvModule=ConvModule, DropPath=DropPath)
     _mod("mmcv.cnn.bricks.registry", ATTENTION=ATTENTION, POSITIONAL_ENCODING=POSITIONAL_ENCODING,
          TRANSFORMER_LAYER=TRANSFORMER_LAYER, TRANSFORMER_LAYER_SEQUENCE=TRANSFORMER_LAYER_SEQUENCE,
          FEEDFORWARD_NETWORK=FEEDFORWARD_NETWORK)
@@ -815,6 +883,7 @@ def install():
     _mod("mmdet.utils")
     _mod("mmdet.utils.contextmanagers", completed=_not_available)
     _mod("mmdet.models", build_loss=build_loss, **reg)
+    _mod("mmdet.models.utils", SELayer=SELayer, make_divisible=make_divisible)
     _mod("mmdet.models.builder", build_loss=build_loss, **reg)
     _mod("mmdet.models.backbones")
     _mod("mmdet.models.backbones.resnet", BasicBlock=BasicBlock)

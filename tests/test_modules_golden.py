@@ -114,3 +114,37 @@ def test_head_stacked_kv_projection(bound, monkeypatch):
         assert torch.allclose(a.cpu(), b.cpu(), atol=2e-4, rtol=1e-4), float((a.cpu() - b.cpu()).abs().max())
     # and both agree with the reference's batch-2 golden output on sample 0
     _close(mask_a[-1], g["mask_last"][:1], "mask_last (stacked, batch 1)")
+
+
+@torch.no_grad()
+def test_view_transformer_kitti(bound):
+    """SemanticKITTI form (BASELINE configs 0-1): one camera, 4x4 intrinsics / BEV augmentation, 33 camera
+    scalars -- against the reference's own module (tests/golden/make_golden_kitti.py)"""
+    g = golden("view_transformer_kitti")
+    model, meta = tinycfg.tiny_nusc(ncams=1)
+    vt = _build(dict(model["img_view_transformer"], cam_channels=33), g["seed"], bound, g["param_checksum"])
+    cams = bound.to(g["rots"], g["trans"], g["intrins"], g["post_rots"], g["post_trans"], g["bda"])
+    mlp = vt.get_mlp_input(*cams)
+    assert mlp.shape[-1] == 33
+    _close(mlp, g["mlp_input"], "mlp_input")
+    vox, depth = vt([bound.to(g["x"]), *cams, mlp])
+    _close(depth, g["depth"], "depth")
+    _close(vox, g["voxel"], "voxel")
+
+
+@torch.no_grad()
+def test_head_kitti(bound):
+    """Mask2FormerOccHead.simple_test (SemanticKITTI: 20 classes, no LiDAR branch) against the reference's own
+    module on the pixel-decoder vectors (tests/golden/make_golden_kitti.py)"""
+    from tests.golden.make_golden_train import kitti_head_cfg
+    g, gp = golden("head_kitti"), golden("pixel_decoder")
+    model, meta = tinycfg.tiny_nusc()
+    head = _build(dict(kitti_head_cfg(model), train_cfg=None, test_cfg=None), g["seed"], bound, g["param_checksum"])
+    feats = [bound.to(gp[f"out{i}"]) for i in range(4)]
+    metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"]) for _ in range(2)]
+    cls_list, mask_list = head(feats, metas)
+    _close(cls_list[-1], g["cls_last"], "cls_last")
+    _close(mask_list[-1], g["mask_last"], "mask_last")
+    res = head.simple_test(feats, metas)
+    assert res["output_points"] is None
+    _close(res["output_voxels"][0], g["output_voxels"], "output_voxels")
