@@ -1,5 +1,6 @@
-"""Detector glue, registry names ``OccupancyFormer`` (+ the 2-D image branch ``ResNet`` /
-``SECONDFPN`` so the unchanged nuScenes configs build).
+"""Detector glue, registry names ``OccupancyFormer`` (+ the 2-D image branch ``ResNet`` (optionally with DCNv2
+stages) / ``SECONDFPN`` so the unchanged nuScenes configs build; ``CustomEfficientNet`` of the SemanticKITTI
+configs lives in efficientnet.py).
 
 Host-side mirror of projects/mmdet3d_plugin/occformer/detectors/occupancyformer.py
 (:14-254) on top of BEVDet.__init__ (detectors/bevdepth.py:16-34) and
@@ -20,15 +21,72 @@ from .registry import BACKBONES, DETECTORS, MODELS, NECKS
 
 
 # ------------------------------------------------------------------ 2-D image branch (non-hot-path)
+class ModulatedDeformConv2dPack(nn.Module):
+    """DCNv2 of the R101-DCN config's image backbone (``dcn=dict(type='DCNv2', deform_groups=1, ...)`` in
+    occformer_nusc_r101_896x1600.py:78; mmcv.ops.ModulatedDeformConv2dPack, restated -- mmcv itself is not
+    available offline): ``conv_offset`` (zero-initialised, with bias) predicts per output position and deform
+    group 2*k*k offsets -- channel 2t = dy, 2t+1 = dx of tap t, after the op's chunk(3) / cat of the first two
+    thirds -- and k*k modulation logits; tap t samples the input bilinearly (zero outside the image) at its
+    regular position + offset, the sample is scaled by sigmoid(logit), then the ordinary weighted sum over taps and
+    input channels.  Image-branch glue on PyTorch ops (grid_sample), not a hand-written kernel."""
+
+    def __init__(self, cin, cout, kernel_size=3, stride=1, padding=1, dilation=1, groups=1, deform_groups=1,
+                 bias=False):
+        super().__init__()
+        if groups != 1:
+            raise NotImplementedError("grouped DCNv2 is not used by the OccFormer configs")
+        self.k, self.stride, self.padding, self.dilation, self.dg = kernel_size, stride, padding, dilation, deform_groups
+        self.weight = nn.Parameter(torch.empty(cout, cin, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, nonlinearity="relu")
+        self.conv_offset = nn.Conv2d(cin, deform_groups * 3 * kernel_size * kernel_size, kernel_size, stride=stride,
+                                     padding=padding, dilation=dilation, bias=True)
+        nn.init.zeros_(self.conv_offset.weight)
+        nn.init.zeros_(self.conv_offset.bias)
+
+    def forward(self, x):
+        B, C, H, W = x.shape
+        k, dg = self.k, self.dg
+        o1, o2, logit = torch.chunk(self.conv_offset(x), 3, dim=1)
+        offset = torch.cat((o1, o2), 1)                                  # [B, dg * 2 * k*k, Ho, Wo]
+        mask = torch.sigmoid(logit)                                       # [B, dg * k*k, Ho, Wo]
+        Ho, Wo = offset.shape[-2:]
+        ys = (torch.arange(Ho, device=x.device, dtype=x.dtype) * self.stride - self.padding).view(1, Ho, 1)
+        xs = (torch.arange(Wo, device=x.device, dtype=x.dtype) * self.stride - self.padding).view(1, 1, Wo)
+        offset = offset.view(B, dg, k * k, 2, Ho, Wo)
+        mask = mask.view(B, dg, k * k, Ho, Wo)
+        cpg = C // dg
+        cols = []
+        for t in range(k * k):
+            ky, kx = divmod(t, k)
+            per_group = []
+            for g in range(dg):
+                py = ys + ky * self.dilation + offset[:, g, t, 0]
+                px = xs + kx * self.dilation + offset[:, g, t, 1]
+                # pixel coordinates -> grid_sample's align_corners=True convention (zeros outside)
+                grid = torch.stack((2 * px / max(W - 1, 1) - 1, 2 * py / max(H - 1, 1) - 1), -1)
+                smp = F.grid_sample(x[:, g * cpg:(g + 1) * cpg], grid, mode="bilinear", padding_mode="zeros",
+                                    align_corners=True)
+                per_group.append(smp * mask[:, g, t].unsqueeze(1))
+            cols.append(torch.cat(per_group, 1))
+        col = torch.stack(cols, 2)                                        # [B, C, k*k, Ho, Wo]
+        out = torch.einsum("bcthw,oct->bohw", col, self.weight.flatten(2))
+        return out if self.bias is None else out + self.bias.view(1, -1, 1, 1)
+
+
 class _Bottleneck(nn.Module):
     expansion = 4
 
-    def __init__(self, cin, planes, stride=1, downsample=None, style="pytorch"):
+    def __init__(self, cin, planes, stride=1, downsample=None, style="pytorch", dcn=None):
         super().__init__()
         s1, s2 = (1, stride) if style == "pytorch" else (stride, 1)
         self.conv1 = nn.Conv2d(cin, planes, 1, stride=s1, bias=False)
         self.bn1 = nn.BatchNorm2d(planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=s2, padding=1, bias=False)
+        if dcn is not None:
+            self.conv2 = ModulatedDeformConv2dPack(planes, planes, 3, stride=s2, padding=1,
+                                                   deform_groups=dcn.get("deform_groups", 1), bias=False)
+        else:
+            self.conv2 = nn.Conv2d(planes, planes, 3, stride=s2, padding=1, bias=False)
         self.bn2 = nn.BatchNorm2d(planes)
         self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
         self.bn3 = nn.BatchNorm2d(planes * 4)
@@ -51,10 +109,12 @@ class ResNet(nn.Module):
                  norm_eval=False, style="pytorch", pretrained=None, with_cp=False, dcn=None,
                  stage_with_dcn=None, init_cfg=None, **kwargs):
         super().__init__()
-        if dcn is not None:
-            raise NotImplementedError("DCNv2 image backbones (R101-DCN config) are a next-round row (SURVEY §8f.1)")
+        if dcn is not None and (dcn.get("type") != "DCNv2" or dcn.get("fallback_on_stride", False)):
+            raise NotImplementedError("image-backbone dcn: DCNv2 without fallback_on_stride (the R101-DCN config)")
+        stage_with_dcn = tuple(stage_with_dcn) if stage_with_dcn is not None else (False,) * num_stages
         self.out_indices = tuple(out_indices)
         self.norm_eval = norm_eval
+        self.frozen_stages = frozen_stages
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         cin = 64
@@ -66,10 +126,26 @@ class ResNet(nn.Module):
                 if j == 0 and (stride != 1 or cin != planes * 4):
                     ds = nn.Sequential(nn.Conv2d(cin, planes * 4, 1, stride=stride, bias=False),
                                        nn.BatchNorm2d(planes * 4))
-                blocks.append(_Bottleneck(cin, planes, stride if j == 0 else 1, ds, style))
+                blocks.append(_Bottleneck(cin, planes, stride if j == 0 else 1, ds, style,
+                                          dcn if dcn is not None and stage_with_dcn[i] else None))
                 cin = planes * 4
             setattr(self, f"layer{i + 1}", nn.Sequential(*blocks))
         self.num_stages = num_stages
+
+    def train(self, mode=True):
+        """mmdet ResNet.train: stem + the first ``frozen_stages`` stages stay in eval mode without gradients;
+        ``norm_eval`` keeps every BatchNorm on its running statistics"""
+        super().train(mode)
+        if self.frozen_stages >= 0:
+            for m in [self.conv1, self.bn1] + [getattr(self, f"layer{i}") for i in range(1, self.frozen_stages + 1)]:
+                m.eval()
+                for p in m.parameters():
+                    p.requires_grad = False
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.eval()
+        return self
 
     def forward(self, x):
         x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)

@@ -60,3 +60,73 @@ def test_kitti_reference_config_loads_unchanged():
                    "img_bev_encoder_neck.", "pts_bbox_head.transformer_decoder.layers.0.attentions.0.attn.in_proj_weight"):
         assert any(n.startswith(prefix) for n in names), prefix
     assert m.pts_bbox_head.num_occupancy_classes == 20 and m.img_view_transformer.cam_channels == 33
+
+
+# ------------------------------------------------------------------ DCNv2 of the R101-DCN image backbone
+def _dcn(cin=6, cout=5, stride=1, dg=1):
+    from occformer_amd.detector import ModulatedDeformConv2dPack
+    m = ModulatedDeformConv2dPack(cin, cout, 3, stride=stride, padding=1, deform_groups=dg)
+    with torch.no_grad():
+        m.weight.copy_(paramgen.tensor("dcn.w", m.weight.shape, 1, 0.3))
+    return m
+
+
+@torch.no_grad()
+def test_dcnv2_zero_init_is_half_a_convolution():
+    """freshly built (conv_offset = 0): no displacement, modulation sigmoid(0) = 0.5"""
+    for stride in (1, 2):
+        m = _dcn(stride=stride)
+        x = paramgen.tensor("dcn.x", (2, 6, 9, 11), 2)
+        ref = 0.5 * torch.nn.functional.conv2d(x, m.weight, None, stride, 1)
+        assert torch.allclose(m(x), ref, atol=1e-5, rtol=1e-5)
+
+
+@torch.no_grad()
+def test_dcnv2_against_direct_bilinear_loops():
+    """random offsets / modulation: every output element recomputed with explicit bilinear taps (zero outside)"""
+    import math
+    m = _dcn(cin=4, cout=3, stride=2, dg=2)
+    m.conv_offset.weight.copy_(paramgen.tensor("dcn.ow", m.conv_offset.weight.shape, 3, 0.15))
+    m.conv_offset.bias.copy_(paramgen.tensor("dcn.ob", m.conv_offset.bias.shape, 3, 0.8))
+    x = paramgen.tensor("dcn.x2", (1, 4, 6, 7), 4)
+    out = m(x)
+    raw = m.conv_offset(x)
+    o1, o2, logit = torch.chunk(raw, 3, 1)
+    off, mask = torch.cat((o1, o2), 1), torch.sigmoid(logit)
+    B, C, H, W = x.shape
+    Ho, Wo = out.shape[-2:]
+
+    def tap(c, y, xx):
+        y0, x0 = math.floor(y), math.floor(xx)
+        v = 0.0
+        for yy, wy in ((y0, 1 - (y - y0)), (y0 + 1, y - y0)):
+            for xc, wx in ((x0, 1 - (xx - x0)), (x0 + 1, xx - x0)):
+                if 0 <= yy < H and 0 <= xc < W:
+                    v += wy * wx * float(x[0, c, yy, xc])
+        return v
+
+    ref = torch.zeros_like(out)
+    for oy in range(Ho):
+        for ox in range(Wo):
+            for t in range(9):
+                ky, kx = divmod(t, 3)
+                for c in range(C):
+                    g = c // (C // 2)
+                    dy = float(off[0, g * 18 + 2 * t, oy, ox])
+                    dx = float(off[0, g * 18 + 2 * t + 1, oy, ox])
+                    v = tap(c, oy * 2 - 1 + ky + dy, ox * 2 - 1 + kx + dx) * float(mask[0, g * 9 + t, oy, ox])
+                    ref[0, :, oy, ox] += m.weight[:, c, ky, kx] * v
+    assert torch.allclose(out, ref, atol=1e-5, rtol=1e-4), float((out - ref).abs().max())
+
+
+@pytest.mark.skipif(not refshim.available(), reason="needs /root/reference (build container)")
+def test_r101_dcn_reference_config_loads_unchanged():
+    cfg = Config.fromfile(os.path.join(refshim.REFERENCE_ROOT,
+                                       "projects/configs/occformer_nusc/occformer_nusc_r101_896x1600.py"))
+    assert cfg.model.img_backbone.dcn.type == "DCNv2"
+    m = build_model(cfg.model, train_cfg=cfg.get("train_cfg"), test_cfg=cfg.get("test_cfg"))
+    names = set(m.state_dict())
+    # DCN in stages 3 and 4 only, with mmdet's parameter names
+    assert "img_backbone.layer3.0.conv2.conv_offset.weight" in names and "img_backbone.layer4.2.conv2.weight" in names
+    assert "img_backbone.layer2.0.conv2.conv_offset.weight" not in names
+    assert m.img_backbone.layer3[0].conv2.conv_offset.out_channels == 27 and len(m.img_backbone.layer3) == 23
