@@ -171,3 +171,50 @@ def test_inference_forward_has_no_host_sync(hip, monkeypatch):
         torch.cuda.set_sync_debug_mode("default")
     torch.cuda.synchronize()
     assert torch.isfinite(out["output_voxels"][0]).all() and torch.isfinite(out["output_points"]).all()
+
+
+def test_kitti_detector_with_image_branch_wiring(be, monkeypatch):
+    """SemanticKITTI-shaped OccupancyFormer end to end from RAW IMAGES: CustomEfficientNet (b0) -> SECONDFPN
+    (down-sampling deblocks as in occformer_kitti.py) -> one-camera view transformer with 4x4 camera matrices ->
+    encoder -> pixel decoder -> Mask2FormerOccHead (20 classes, class-guided sampling in the loss):
+    forward(return_loss=False) and forward(return_loss=True) run through the kernels under test."""
+    import occformer_amd.ops as ops_mod
+    from occformer_amd.registry import build_model
+    from tests import paramgen, tinycfg
+    from tests.golden.make_golden_train import kitti_head_cfg
+    monkeypatch.setattr(ops_mod, "_ops", be.ops)
+    cfg, meta = tinycfg.tiny_nusc(ncams=1)
+    cfg = dict(cfg)
+    cfg["img_backbone"] = dict(type="CustomEfficientNet", arch="b0", drop_path_rate=0.2, frozen_stages=0,
+                               norm_eval=False, out_indices=(2, 3, 4), with_cp=True)
+    # (the tiny image is not a multiple of 32, so only the stride-4/8/16 maps are fused here)
+    cfg["img_neck"] = dict(type="SECONDFPN", in_channels=[24, 40, 112], upsample_strides=[0.25, 0.5, 1],
+                           out_channels=[8, 8, 16])
+    cfg["img_view_transformer"] = dict(cfg["img_view_transformer"], cam_channels=33)       # numC_input = 32 = sum
+    cfg["pts_bbox_head"] = kitti_head_cfg(cfg)
+    cfg["train_cfg"] = dict(pts=dict(
+        num_points=128, oversample_ratio=3.0, importance_sample_ratio=0.75,
+        assigner=dict(type="MaskHungarianAssigner", cls_cost=dict(type="ClassificationCost", weight=2.0),
+                      mask_cost=dict(type="CrossEntropyLossCost", weight=5.0, use_sigmoid=True),
+                      dice_cost=dict(type="DiceCost", weight=5.0, pred_act=True, eps=1.0)),
+        sampler=dict(type="MaskPseudoSampler")))
+    model = build_model(cfg).eval().to(be.device)
+    B, N = 1, 1
+    H, W = meta["input_size"]
+    cams = paramgen.camera_rig(B, N, H, W, meta["focal"], seed=5, kitti=True)
+    imgs = paramgen.tensor("kd_img", (B, N, 3, H, W), 5)
+    gt_depth = paramgen.uniform("kd_d", (B, N, H, W), 5) * 8.0 + 2.0
+    img_inputs = [t.to(be.device) for t in (imgs, *cams, gt_depth)]
+    occ = tuple(meta["occ_size"])
+    gt_occ = (paramgen.uniform("kd_occ", (B,) + tuple(o // 4 for o in occ), 5) * 8).long()
+    gt_occ = gt_occ.repeat_interleave(4, 1).repeat_interleave(4, 2).repeat_interleave(4, 3).to(be.device)
+    metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])]
+    with torch.no_grad():
+        feats = model.image_encoder(img_inputs[0])
+        assert tuple(feats.shape) == (B, N, 32, meta["fH"], meta["fW"])      # stride-16 neck features
+        out = model(return_loss=False, img_metas=metas, img_inputs=img_inputs, gt_occ=gt_occ)
+        losses = model(return_loss=True, img_metas=metas, img_inputs=img_inputs, gt_occ=gt_occ)
+    assert out["output_voxels"].shape[1] == 20 and out["output_voxels"].shape[-3:] == occ
+    assert out["output_points"] is None and torch.isfinite(out["output_voxels"]).all()
+    assert {"loss_depth", "loss_cls", "loss_mask", "loss_dice"} <= set(losses)
+    assert all(torch.isfinite(torch.as_tensor(v)).all() for v in losses.values())
