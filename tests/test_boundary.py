@@ -182,6 +182,11 @@ def test_kitti_detector_with_image_branch_wiring(be, monkeypatch):
     from occformer_amd.registry import build_model
     from tests import paramgen, tinycfg
     from tests.golden.make_golden_train import kitti_head_cfg
+    if be.kind == "hip":
+        # the image branch is plain PyTorch: on a fresh GPU box MIOpen would first compile ~80 distinct
+        # (depthwise / same-padded) convolution configurations; the hot-path pieces of this wiring have their own
+        # GPU tests (test_view_transformer_kitti, test_head_kitti, the training rows)
+        pytest.skip("image-branch wiring is exercised on the CPU run")
     monkeypatch.setattr(ops_mod, "_ops", be.ops)
     cfg, meta = tinycfg.tiny_nusc(ncams=1)
     cfg = dict(cfg)
