@@ -31,35 +31,8 @@ BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 
 
 def synthetic_sample(meta, device, seed=0):
-    """seeded neck features, 6-camera surround rig, uniform LiDAR points."""
-    import math
-    g = torch.Generator().manual_seed(seed)
-    B, N = 1, meta["ncams"]
-    x = torch.randn(B, N, meta["neck_channels"], meta["fH"], meta["fW"], generator=g)
-    yaws = [55.0, 0.0, -55.0, 110.0, 180.0, -110.0][:N]
-    rots, trans = [], []
-    for yaw in yaws:
-        a = math.radians(yaw)
-        fwd = torch.tensor([math.cos(a), math.sin(a), 0.0])
-        right = torch.tensor([math.sin(a), -math.cos(a), 0.0])
-        down = torch.tensor([0.0, 0.0, -1.0])
-        rots.append(torch.stack((right, down, fwd), 1))
-        trans.append(torch.tensor([1.5 * math.cos(a), 1.5 * math.sin(a), 1.5]))
-    rots = torch.stack(rots).unsqueeze(0)
-    trans = torch.stack(trans).unsqueeze(0)
-    H, W = meta["input_size"]
-    K = torch.tensor([[meta["focal"], 0.0, W / 2.0], [0.0, meta["focal"], 60.0], [0.0, 0.0, 1.0]])
-    intr = K.view(1, 1, 3, 3).repeat(B, N, 1, 1)
-    post_rots = torch.eye(3).view(1, 1, 3, 3).repeat(B, N, 1, 1)
-    post_trans = torch.zeros(B, N, 3)
-    bda = torch.eye(3).view(1, 3, 3)
-    lo = torch.tensor(meta["pc_range"][:3])
-    hi = torch.tensor(meta["pc_range"][3:])
-    pts = torch.rand(34720, 3, generator=g) * (hi - lo) + lo
-    pts = torch.cat((pts, torch.zeros(34720, 1)), 1)
-    img_inputs = [t.to(device) for t in (x, rots, trans, intr, post_rots, post_trans, bda)]
-    metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])]
-    return img_inputs, metas, [pts.to(device)]
+    from occformer_amd import configs
+    return configs.synthetic_sample(meta, device, seed)
 
 
 class KernelCensus:
@@ -185,16 +158,26 @@ def cpu_baseline(model, meta, img_inputs, points):
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     x = img_inputs[0].cpu()
     cams = tuple(t.cpu() for t in img_inputs[1:7])
-    cfg = dict(D=meta["D"], C=meta["C"], occ_size=meta["occ_size"], pc_range=meta["pc_range"], groups=32)
+    from occformer_amd import configs
+    cfg = configs.oracle_cfg(meta)
     cores = min(os.cpu_count() or 1, 32)     # torch CPU ops stop scaling (and oversubscribe) beyond this
     torch.set_num_threads(cores)
     t0 = time.perf_counter()
     with torch.no_grad():
-        res = O.occformer_forward(sd, x, cams, cfg, [p.cpu() for p in points])
+        res = O.occformer_forward(sd, x, cams, cfg, None if points is None else [p.cpu() for p in points])
     dt = time.perf_counter() - t0
     return dict(value=1.0 / dt, unit="samples/s", cores=cores, kind="port",
                 sample="1 sample of the same workload (oracle/occformer_ref.occformer_forward, fp32, "
                        f"torch CPU, {cores} threads): {dt:.1f} s"), res
+
+
+WORKLOAD_DESC = {
+    "nusc_r50_200": "nuScenes R50 256x704, 200x200x16 voxels",
+    "nusc_r50_ref128": "nuScenes R50 256x704, 128x128x16 voxels (the reference's shipped grid)",
+    "kitti_effb7_128": "SemanticKITTI EfficientNetB7 mono 384x1280, 128x128x16 voxels (output 256x256x32)",
+    "kitti_effb7_256lit": "SemanticKITTI EfficientNetB7 mono 384x1280, 256x256x32 voxels (lss_downsample 1)",
+    "nusc_r101": "nuScenes R101-DCN 896x1600, 200x200x16 voxels",
+}
 
 
 def main():
@@ -202,7 +185,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--grid", default="200", choices=["200", "reference"])
+    ap.add_argument("--workload", default="nusc_r50_200",
+                    choices=["nusc_r50_200", "nusc_r50_ref128", "kitti_effb7_128", "kitti_effb7_256lit", "nusc_r101"],
+                    help="BASELINE.json configs: [2]/[3] nusc_r50_200 (the metric's grid; default), the reference's "
+                         "own 128-grid, [0] kitti_effb7_128, [1] kitti_effb7_256lit, [4] nusc_r101")
+    ap.add_argument("--grid", default=None, choices=["200", "reference"], help="(legacy) nusc_r50 grid")
     ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the dense contractions (default: the library default, bf16x3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -229,7 +216,9 @@ def main():
         get_ops().precision = args.precision
     prec = get_ops().precision
     torch.manual_seed(0)
-    cfg, meta = configs.nusc_r50(args.grid)
+    if args.grid:
+        args.workload = {"200": "nusc_r50_200", "reference": "nusc_r50_ref128"}[args.grid]
+    cfg, meta = configs.workload(args.workload)
     model = build_model(cfg).eval().to(device)
     img_inputs, metas, points = synthetic_sample(meta, device, seed=rank)
 
@@ -275,15 +264,15 @@ def main():
         return
     roof = roofline(timed_census, kernels, prec, args.steps)
     out = {
-        "metric": "samples/sec (6-cam frame) forward, nuScenes R50 256x704, 200x200x16 voxels, hot path "
+        "metric": f"samples/sec ({meta['ncams']}-cam frame) forward, {WORKLOAD_DESC[args.workload]}, hot path "
                   "(LSS voxel pooling -> dual-path encoder -> pixel decoder -> occupancy decoder)",
         "value": world * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
         "dtype": {"f32": "f32", "bf16x3": "f32 (contractions as 3-term bf16 split on the bf16 matrix cores, fp32 "
                   "accumulate)", "bf16": "bf16 products, fp32 accumulate"}[prec], "data": "synthetic",
-        "config": {"workload": f"nusc_r50_256x704_6cam_grid{'200x200x16' if args.grid == '200' else '128x128x16'}"
-                               "_forward_from_neck_features", "global_batch": world,
+        "config": {"workload": f"{args.workload}_forward_from_neck_features", "grid": list(meta["grid"]),
+                   "input_size": list(meta["input_size"]), "global_batch": world,
                    "parallelism": f"dp{world} (independent samples, no data-path collective)"},
         "roofline": roof,
         "kernels": {k: {"calls": v["calls"], "total_ms": round(v["total_ms"], 3), "avg_ms": round(v["avg_ms"], 4),
@@ -298,9 +287,8 @@ def main():
         if args.check:
             a, b = res_gpu["output_voxels"][0].cpu(), res_cpu["output_voxels"]
             out["check"] = {"output_voxels_max_abs_err": float((a - b).abs().max()),
-                            "output_points_max_abs_err": float((res_gpu["output_points"].cpu() -
-                                                                res_cpu["output_points"]).abs().max()),
-                            "voxel_feat_max_abs_err": None}
+                            "output_points_max_abs_err": None if res_cpu["output_points"] is None else float(
+                                (res_gpu["output_points"].cpu() - res_cpu["output_points"]).abs().max())}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

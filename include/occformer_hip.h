@@ -319,6 +319,62 @@ int occf_point_loss_rows_fwd(const float* logits, const float* targets, float* o
  * Minimises the same total cost as scipy (shortest augmenting paths in double); Q, G <= 1024. */
 int occf_hungarian_fwd(const float* cost, int* match_gt, int* assigned_gt, int P, int Q, int G, void* stream);
 
+/* ================================================================== training step: backward kernels
+ * The reference's training step is ATen autograd through the modules above plus QuickCumsumCuda.backward
+ * (M/ops/bev_pool/bev_pool.py:63-80; P/occformer/detectors/occupancyformer.py:132-199,
+ * P/occformer/apis/mmdet_train.py:72-80).  Each forward entry point of the path has its backward here; the host
+ * side wraps the pairs as torch.autograd.Function (occformer_amd/autograd.py). */
+
+/* out[N] = sum over rows of x[M, N] (row stride ldx): bias gradients.  workspace: occf_colsum_workspace floats. */
+long occf_colsum_workspace(long M, int N);
+int occf_colsum(const float* x, float* out, float* workspace, long M, int N, long ldx, void* stream);
+
+/* nn.LayerNorm backward: x/dy/dx[M, C]; dgamma/dbeta[C] (deterministic two-stage sums).
+ * workspace: occf_layernorm_bwd_workspace floats. */
+long occf_layernorm_bwd_workspace(long M, int C);
+int occf_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,
+                       float* workspace, long M, int C, float eps, void* stream);
+
+/* Backward of occf_groupnorm_apply (same x / stats / flags): dy[B, P, Zs, C] (Zs = Z + 1 in token mode: the
+ * gradient of the z-mean slot is spread over the Z slices), dx[B, P, Z, C], dgamma/dbeta[C]; dresidual (may be
+ * NULL) receives the gradient of the forward's residual operand.  workspace: occf_groupnorm_bwd_workspace. */
+long occf_groupnorm_bwd_workspace(int B, long V, int C, int G);
+int occf_groupnorm_bwd(const float* x, const float* stats, const float* gamma, const float* beta, const float* dy,
+                       float* dx, float* dgamma, float* dbeta, float* dresidual, float* workspace, int B, long P,
+                       int Z, int C, int G, int relu, int tokens, void* stream);
+
+/* y = act(x) / dx = dy * act'(x), act 1 = ReLU, 2 = exact GELU (mmcv FFN of the SwinBlock, window_attention.py
+ * :336-344); n % 4 == 0. */
+int occf_act_fwd(const float* x, float* y, long n, int act, void* stream);
+int occf_act_bwd(const float* x, const float* dy, float* dx, long n, int act, void* stream);
+
+/* DropPath of the shared SwinBlock in training mode (window_attention.py:311,332): out = identity + branch *
+ * scale[sample]; token row ((b*XY + xy)*S + s) belongs to sample b*S + s (the block's batch are the slices of
+ * the token buffer); scale = 0 or 1 / keep_prob.  identity == NULL: out = branch * scale (= the backward). */
+int occf_droppath(const float* identity, const float* branch, const float* scale, float* out, long rows, int C,
+                  long XY, int S, void* stream);
+
+/* Backward of occf_dualpath_combine: dtokens[BP, Z+1, C] (slot Z zero-filled), dbev[BP, C], dweight[C], dbias[1];
+ * the identity operand's gradient is dout itself.  workspace: occf_dualpath_combine_bwd_workspace floats. */
+long occf_dualpath_combine_bwd_workspace(long BP, int C);
+int occf_dualpath_combine_bwd(const float* tokens, const float* bev, const float* coeff_weight,
+                              const float* coeff_bias, const float* dout, float* dtokens, float* dbev,
+                              float* dweight, float* dbias, float* workspace, long BP, int Z, int C, void* stream);
+
+/* Backward of occf_upsample_add w.r.t. the coarse operand (gather form, no atomics); the lateral operand's
+ * gradient is dout itself.  dout[B, X2, Y2, Z2, C] -> dcoarse[B, X, Y, Z, C]. */
+int occf_upsample_add_bwd(const float* dout, float* dcoarse, int B, int X, int Y, int Z, int X2, int Y2, int Z2,
+                          int C, void* stream);
+
+/* Backward of occf_point_sample_3d_fwd w.r.t. the volume (F.grid_sample's input gradient): dout[N, C, P] scattered
+ * into dvol[N, C, X, Y, Z], which the CALLER zero-fills. */
+int occf_point_sample_3d_bwd(const float* dout, const float* pts, float* dvol, int N, int C, int X, int Y, int Z,
+                             long P, int shared_pts, int align_corners, int border_padding, void* stream);
+
+/* Backward of occf_point_loss_rows_fwd: grad_rows[R, 4] = d(loss)/d(out) -> dlogits[R, P]. */
+int occf_point_loss_rows_bwd(const float* logits, const float* targets, const float* grad_rows, float* dlogits,
+                             int R, long P, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@ The reference's own .py configs load through ``occformer_amd.registry.Config.fro
 """
 
 
-def nusc_r50(grid="200", with_image_branch=False, num_queries=100):
+def nusc_r50(grid="200", with_image_branch=False, num_queries=100, input_size=(256, 704), focal=557.0):
     if grid == "reference":
         pc_range, occ_size = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0], [256, 256, 32]
     elif grid == "200":
@@ -17,7 +17,7 @@ def nusc_r50(grid="200", with_image_branch=False, num_queries=100):
     ds = [2, 2, 2]
     vs = [(pc_range[3 + i] - pc_range[i]) / occ_size[i] for i in range(3)]
     data_config = dict(cams=["CAM_FRONT_LEFT", "CAM_FRONT", "CAM_FRONT_RIGHT", "CAM_BACK_LEFT", "CAM_BACK",
-                             "CAM_BACK_RIGHT"], Ncams=6, input_size=(256, 704), src_size=(900, 1600))
+                             "CAM_BACK_RIGHT"], Ncams=6, input_size=tuple(input_size), src_size=(900, 1600))
     grid_config = dict(xbound=[pc_range[0], pc_range[3], vs[0] * ds[0]],
                        ybound=[pc_range[1], pc_range[4], vs[1] * ds[1]],
                        zbound=[pc_range[2], pc_range[5], vs[2] * ds[2]], dbound=[2.0, 58.0, 0.5])
@@ -85,6 +85,109 @@ def nusc_r50(grid="200", with_image_branch=False, num_queries=100):
         model["img_neck"] = dict(type="SECONDFPN", in_channels=[256, 512, 1024, 2048],
                                  upsample_strides=[0.25, 0.5, 1, 2], out_channels=[128, 128, 128, 128])
     meta = dict(pc_range=pc_range, occ_size=occ_size, D=112, C=numC_Trans, groups=32, heads=E // 32,
-                fH=16, fW=44, neck_channels=512, ncams=6, grid=tuple(o // d for o, d in zip(occ_size, ds)),
-                focal=557.0, input_size=(256, 704))
+                fH=input_size[0] // 16, fW=input_size[1] // 16, neck_channels=512, ncams=6,
+                grid=tuple(o // d for o, d in zip(occ_size, ds)), focal=focal, input_size=tuple(input_size),
+                kitti=False, lidar_points=34720)
     return model, meta
+
+
+def kitti_effb7(lss_downsample=2):
+    """projects/configs/occformer_kitti/occformer_kitti.py:22-205 from the neck features on: one camera,
+    384x1280 image, 640 neck channels, 33 camera scalars (4x4 intrinsics / BEV augmentation), 20 classes,
+    ``Mask2FormerOccHead``.  ``lss_downsample=2`` is the shipped config (LSS / encoder grid 128x128x16, output
+    256x256x32: BASELINE config 0); ``lss_downsample=1`` is the literal reading of BASELINE config 1 (encoder grid
+    256x256x32 -- supported by the config, never run by the reference)."""
+    model, meta = nusc_r50("reference")
+    pc_range, occ_size = [0.0, -25.6, -2.0, 51.2, 25.6, 4.4], [256, 256, 32]
+    ds = [int(lss_downsample)] * 3
+    vs = [(pc_range[3 + i] - pc_range[i]) / occ_size[i] for i in range(3)]
+    num_class = 20
+    vt = model["img_view_transformer"]
+    vt.update(numC_input=640, cam_channels=33,
+              grid_config=dict(xbound=[pc_range[0], pc_range[3], vs[0] * ds[0]],
+                               ybound=[pc_range[1], pc_range[4], vs[1] * ds[1]],
+                               zbound=[pc_range[2], pc_range[5], vs[2] * ds[2]], dbound=[2.0, 58.0, 0.5]),
+              data_config=dict(input_size=(384, 1280), resize=(-0.06, 0.11), rot=(-5.4, 5.4), flip=True,
+                               crop_h=(0.0, 0.0), resize_test=0.0))
+    head = model["pts_bbox_head"]
+    head.update(type="Mask2FormerOccHead", num_occupancy_classes=num_class, point_cloud_range=pc_range)
+    head["loss_cls"]["class_weight"] = [1.0] * num_class + [0.1]
+    meta.update(pc_range=pc_range, occ_size=occ_size, fH=24, fW=80, neck_channels=640, ncams=1,
+                grid=tuple(o // d for o, d in zip(occ_size, ds)), focal=738.0, input_size=(384, 1280), kitti=True,
+                lidar_points=0)
+    return model, meta
+
+
+WORKLOADS = {
+    # BASELINE.json configs[2] (and [3] under DDP): the grid the metric is quoted on
+    "nusc_r50_200": lambda: nusc_r50("200"),
+    # the reference's own shipped grid for the same config (occformer_nusc_r50_256x704.py:17-46)
+    "nusc_r50_ref128": lambda: nusc_r50("reference"),
+    # BASELINE.json configs[0]: the shipped SemanticKITTI config (encoder grid 128x128x16)
+    "kitti_effb7_128": lambda: kitti_effb7(2),
+    # BASELINE.json configs[1] read literally (encoder grid 256x256x32)
+    "kitti_effb7_256lit": lambda: kitti_effb7(1),
+    # BASELINE.json configs[4]: R101-DCN 896x1600 (fH x fW = 56 x 100, 3.76 M frustum points), 200-grid
+    "nusc_r101": lambda: nusc_r50("200", input_size=(896, 1600), focal=1266.0),
+}
+
+
+def workload(name):
+    """(model config, meta) of a named bench / parity workload (all start at the image-neck features)"""
+    cfg, meta = WORKLOADS[name]()
+    meta["workload"] = name
+    return cfg, meta
+
+
+def oracle_cfg(meta):
+    """keyword dict of oracle.occformer_ref.occformer_forward for a workload"""
+    return dict(D=meta["D"], C=meta["C"], occ_size=meta["occ_size"], pc_range=meta["pc_range"], groups=32)
+
+
+def synthetic_sample(meta, device, seed=0):
+    """seeded neck features, the 6-camera surround rig (or the one forward camera with 4x4
+    intrinsics / BEV augmentation of SemanticKITTI), uniform LiDAR points.
+    -> (img_inputs [x, rots, trans, intrins, post_rots, post_trans, bda], img_metas, points or None)"""
+    import math
+
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    B, N = 1, meta["ncams"]
+    x = torch.randn(B, N, meta["neck_channels"], meta["fH"], meta["fW"], generator=g)
+    yaws = [0.0] if N == 1 else [55.0, 0.0, -55.0, 110.0, 180.0, -110.0][:N]
+    rots, trans = [], []
+    for yaw in yaws:
+        a = math.radians(yaw)
+        fwd = torch.tensor([math.cos(a), math.sin(a), 0.0])
+        right = torch.tensor([math.sin(a), -math.cos(a), 0.0])
+        down = torch.tensor([0.0, 0.0, -1.0])
+        rots.append(torch.stack((right, down, fwd), 1))
+        trans.append(torch.tensor([1.5 * math.cos(a), 1.5 * math.sin(a), 1.5]))
+    rots = torch.stack(rots).unsqueeze(0)
+    trans = torch.stack(trans).unsqueeze(0)
+    H, W = meta["input_size"]
+    # principal point 60 px below the top at 256 rows (SURVEY §8d), scaled with the image height
+    cy = 188.0 if meta.get("kitti") else 60.0 * H / 256.0
+    K = torch.tensor([[meta["focal"], 0.0, W / 2.0], [0.0, meta["focal"], cy], [0.0, 0.0, 1.0]])
+    if meta.get("kitti"):
+        K4 = torch.eye(4)
+        K4[:3, :3] = K
+        K4[:3, 3] = torch.tensor([46.9, 0.2, 0.003])
+        intr = K4.view(1, 1, 4, 4).repeat(B, N, 1, 1)
+        bda = torch.eye(4).view(1, 4, 4).clone()
+        bda[0, :3, 3] = torch.tensor([0.1, -0.2, 0.05])
+    else:
+        intr = K.view(1, 1, 3, 3).repeat(B, N, 1, 1)
+        bda = torch.eye(3).view(1, 3, 3)
+    post_rots = torch.eye(3).view(1, 1, 3, 3).repeat(B, N, 1, 1)
+    post_trans = torch.zeros(B, N, 3)
+    points = None
+    if meta.get("lidar_points", 0):
+        lo = torch.tensor(meta["pc_range"][:3])
+        hi = torch.tensor(meta["pc_range"][3:])
+        n = meta["lidar_points"]
+        pts = torch.rand(n, 3, generator=g) * (hi - lo) + lo
+        points = [torch.cat((pts, torch.zeros(n, 1)), 1).to(device)]
+    img_inputs = [t.to(device) for t in (x, rots, trans, intr, post_rots, post_trans, bda)]
+    metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])]
+    return img_inputs, metas, points

@@ -51,3 +51,13 @@ def sum_confusion(hist, device="cpu"):
     if world() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+def reduce_mean(t):
+    """mmdet.core.reduce_mean (mask2former_nusc_occ.py:408; mask2former_occ.py:425,437): all-reduce(SUM) / world
+    of a loss normaliser; identity for a single process."""
+    if world() == 1:
+        return t
+    t = t.clone()
+    dist.all_reduce(t.div_(world()), op=dist.ReduceOp.SUM)
+    return t

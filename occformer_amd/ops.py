@@ -94,6 +94,8 @@ class HipOps:
         """depth [BN, D, HW] f32, feat_cl [BN, HW, C] f32 -> [n_vox, C]."""
         BN, D, HW = depth.shape
         C = feat_cl.shape[-1]
+        if tuple(feat_cl.shape[:2]) != (BN, HW) or offsets.numel() != n_vox + 1 or sorted_pts.numel() != BN * D * HW:
+            raise OccfError("lift_splat: depth / feature / CSR sizes disagree (the kernel does no bounds checks)")
         out = torch.empty((n_vox, C), dtype=depth.dtype, device=depth.device)
         self._call("occf_lift_splat_fwd", self._ptr(depth, self.f32), self._ptr(feat_cl, self.f32),
                    self._ptr(offsets, self.i32), self._ptr(sorted_pts, self.i32), self._ptr(out),
@@ -103,6 +105,8 @@ class HipOps:
     def lift_splat_backward(self, out_grad, depth, feat_cl, vox):
         BN, D, HW = depth.shape
         C = feat_cl.shape[-1]
+        if tuple(feat_cl.shape[:2]) != (BN, HW) or vox.numel() != BN * D * HW:
+            raise OccfError("lift_splat: depth / feature / voxel-index sizes disagree")
         d_depth = torch.empty_like(depth)
         d_feat = torch.empty_like(feat_cl)
         self._call("occf_lift_splat_bwd", self._ptr(out_grad, self.f32), self._ptr(depth, self.f32),

@@ -15,12 +15,17 @@ The function names and argument meaning mirror the reference
 
 All randomness comes from an ``rng`` object (``rand``, ``randperm``, ``exponential``) so that a run is
 reproducible and testable on injected noise; ``DeviceRNG`` is the default.  The Hungarian step runs on the
-host with scipy exactly like the reference (one host sync per image and decoder layer).
+device (csrc/assign.hip: shortest augmenting paths, what scipy's linear_sum_assignment implements) -- the
+reference's ``cost.cpu()`` + scipy round trip (one host sync per image and decoder layer) is gone.  A cost matrix
+with non-finite entries (a diverged step; scipy raises there) leaves GT rows unmatched: that is recorded in a
+device flag and raised as ``FloatingPointError`` by ``OccHeadTrainingMixin.loss`` one step later (no host sync in
+the step itself).
 """
 import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import dist_utils
 from .ops import get_ops
 
 # P/../utils/semkitti.py:3-26
@@ -174,6 +179,7 @@ class MaskHungarianAssigner:
         dc = dice_cost or {}
         self.w_dice = float(dc.get("weight", 1.0))
         self.dice_eps = float(dc.get("eps", 1e-3))
+        self.infeasible = None
         if not dc.get("pred_act", False) or not dc.get("naive_dice", True):
             raise NotImplementedError("DiceCost: pred_act=True / naive_dice=True is the configuration built")
 
@@ -209,6 +215,13 @@ class MaskHungarianAssigner:
             return torch.zeros((Q,), dtype=torch.long, device=mask_pred.device), mask_pred.new_zeros((Q, G))
         cost = self.cost(cls_pred, mask_pred, gt_labels, gt_mask)
         match, assigned = get_ops().hungarian(cost)
+        if G <= Q:
+            # every GT row must have found a query; -1 = the row was infeasible (NaN / inf costs: scipy raises
+            # "cost matrix is infeasible" there).  Recorded on the device, raised by the head one step later;
+            # the index is clamped so that the targets of this (already meaningless) step stay in bounds
+            bad = (match < 0).any()
+            self.infeasible = bad if self.infeasible is None else (self.infeasible | bad)
+            match = match.clamp_min(0)
         self.last_match = match.long()
         return assigned.long(), cost
 
@@ -226,7 +239,8 @@ def point_mask_losses(point_preds, point_targets, mask_weights, num_points, dice
     pass of row sums.  ``weight_bce_rows``: KITTI weights the BCE rows by the class weight
     (mask2former_occ.py:433-442); nuScenes divides by sum(w)*P only (mask2former_nusc_occ.py:411-417)."""
     rows = get_ops().point_loss_rows(point_preds.contiguous(), point_targets.float().contiguous())
-    total = mask_weights.sum()
+    # reduce_mean(mask_weights.sum()) across ranks (mask2former_nusc_occ.py:408; mask2former_occ.py:425,437)
+    total = dist_utils.reduce_mean(mask_weights.sum().detach()).clamp_min(1e-12)
     d = (2 * rows[:, 1] + dice_eps) / (rows[:, 2] + rows[:, 3] + dice_eps)
     loss_dice = w_dice * ((1 - d) * mask_weights).sum() / total
     if weight_bce_rows:
@@ -281,7 +295,15 @@ class OccHeadTrainingMixin:
         self.w_mask = float((loss_mask or {}).get("loss_weight", 1.0))
         self.w_dice = float((loss_dice or {}).get("loss_weight", 1.0))
         self.dice_eps = float((loss_dice or {}).get("eps", 1e-3))
+        ld, lm = loss_dice or {}, loss_mask or {}
+        if not ld.get("naive_dice", True) or not ld.get("activate", True) or not ld.get("use_sigmoid", True) or \
+                ld.get("reduction", "mean") != "mean" or not lm.get("use_sigmoid", True) or \
+                lm.get("reduction", "mean") != "mean" or (loss_cls or {}).get("use_sigmoid", False):
+            raise NotImplementedError("the loss kernels implement the OccFormer configs' options: DiceLoss("
+                                      "use_sigmoid, activate, naive_dice, mean), BCE mask loss (use_sigmoid, mean), "
+                                      "softmax CE classification loss")
         self.rng = None
+        self._infeasible_pending = None
         if train_cfg:
             a = dict(train_cfg["assigner"])
             a.pop("type", None)
@@ -322,11 +344,38 @@ class OccHeadTrainingMixin:
         # step instead of once per set (17 x 2 M voxels each time)
         gt = list(gt)
         gt[1] = [m.float() for m in gt[1]]
+        self._raise_if_infeasible()
         per = [self.loss_single(c, m, *gt) for c, m in zip(all_cls_scores, all_mask_preds)]
+        self._post_infeasible_flag()
         out = {"loss_cls": per[-1][0], "loss_mask": per[-1][1], "loss_dice": per[-1][2]}
         for i, (a, b, c) in enumerate(per[:-1]):
             out[f"d{i}.loss_cls"], out[f"d{i}.loss_mask"], out[f"d{i}.loss_dice"] = a, b, c
         return out
+
+    def _post_infeasible_flag(self):
+        """copy the assigner's device flag to pinned host memory without blocking; read it at the next step"""
+        flag = getattr(self.assigner, "infeasible", None)
+        self.assigner.infeasible = None
+        if flag is None:
+            return
+        if flag.is_cuda:
+            host = torch.empty((), dtype=torch.bool, pin_memory=True)
+            host.copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._infeasible_pending = (host, ev)
+        else:
+            self._infeasible_pending = (flag, None)
+
+    def _raise_if_infeasible(self):
+        pend, self._infeasible_pending = getattr(self, "_infeasible_pending", None), None
+        if pend is None:
+            return
+        if pend[1] is not None:
+            pend[1].synchronize()
+        if bool(pend[0]):
+            raise FloatingPointError("Hungarian assignment: non-finite matching costs in the previous training step "
+                                     "(scipy.optimize.linear_sum_assignment raises 'cost matrix is infeasible')")
 
     def _cls_and_select(self, cls_scores, mask_preds, targets):
         labels = torch.stack([t[0] for t in targets]).flatten()

@@ -276,8 +276,7 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
     def __init__(self, loss_depth_weight, grid_config=None, data_config=None, numC_input=512,
                  numC_Trans=64, downsample=16, cam_channels=27, point_cloud_range=None,
                  loss_depth_type="bce", loss_depth_reg_weight=0.0, use_voxel_net=False,
-                 accelerate=False, use_bev_pool=True, vp_megvii=False, vp_stero=False,
-                 cache_geometry=False, **kwargs):
+                 accelerate=False, use_bev_pool=True, vp_megvii=False, vp_stero=False, **kwargs):
         super().__init__()
         if grid_config is None:
             grid_config = dict(xbound=[-51.2, 51.2, 0.8], ybound=[-51.2, 51.2, 0.8],
@@ -311,8 +310,6 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         self.numC_input = numC_input
         self.numC_Trans = numC_Trans
         self.depth_net = DepthNet(numC_input, numC_input, numC_Trans, self.D, cam_channels=cam_channels)
-        self.cache_geometry = cache_geometry
-        self._geom_cache = None
 
     # -- ViewTransformerLSSBEVDepth.py:591-646
     def get_mlp_input(self, rot, tran, intrin, post_rot, post_tran, bda=None):
@@ -339,24 +336,20 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         """(vox [B*N*D*fH*fW] i32, offsets, sorted_pts): frustum -> voxel rows + CSR."""
         B, N = trans.shape[:2]
         X, Y, Z = self.grid_size
-        key = None
-        if self.cache_geometry:
-            key = tuple(t.data_ptr() for t in (rots, trans, intrins, post_rots, post_trans, bda))
-            if self._geom_cache is not None and self._geom_cache[0] == key:
-                return self._geom_cache[1]
         cam, bda12 = pack_cameras(rots, trans, intrins, post_rots, post_trans, bda)
         grid = torch.cat((self.bx - self.dx / 2.0, self.dx, self.nx)).float()
         vox = get_ops().lss_voxel_index(self.frustum.reshape(-1, 3), cam, bda12, grid, B, N, X, Y, Z,
                                         bda.shape[-1] == 4)
         offsets, pts = build_voxel_csr(vox, B * X * Y * Z)
-        res = (vox, offsets, pts)
-        if self.cache_geometry:
-            self._geom_cache = (key, res)
-        return res
+        return vox, offsets, pts
 
     def forward(self, input):
         x, rots, trans, intrins, post_rots, post_trans, bda, mlp_input = input[:8]
         B, N, C, H, W = x.shape
+        if (H, W) != tuple(self.frustum.shape[1:3]):
+            # the reference fails with a shape error here; the splat kernels index B*N*D*fH*fW points unchecked
+            raise ValueError(f"image features are {H}x{W} but the frustum (data_config.input_size // downsample) "
+                             f"is {tuple(self.frustum.shape[1:3])}")
         y = self.depth_net(x.view(B * N, C, H, W), mlp_input)
         depth_prob = self.get_depth_dist(y[:, :self.D])
         feat_cl = y[:, self.D:self.D + self.numC_Trans].permute(0, 2, 3, 1).reshape(B * N, H * W, -1)

@@ -52,7 +52,9 @@ def test_lift_splat_mass_conservation(hip, name, input_size, focal):
     frustum = O.make_frustum(meta["input_size"], 16, [2.0, 58.0, 0.5]).to(hip.device)
     dx, bx, nx = O.grid_constants([-50, 50, 0.5], [-50, 50, 0.5], [-5, 3, 0.5])
     X, Y, Z = 200, 200, 16
-    cam, bda12 = pack_cameras(*cams)
+    # per-camera constants from the same torch CPU ops the reference's get_geometry runs (inverse, 3x3 matmul):
+    # with identical constants the voxel ids must be bit-exact at the full frustum
+    cam, bda12 = (t.to(hip.device) for t in pack_cameras(*[c.cpu() for c in cams]))
     grid = torch.cat((bx - dx / 2.0, dx, nx)).float().to(hip.device)
     vox = hip.ops.lss_voxel_index(frustum.reshape(-1, 3).contiguous(), cam, bda12, grid, 1, 6, X, Y, Z, False)
     # geometry parity against the oracle's restatement of get_geometry + voxel_pooling, on the GPU
@@ -61,7 +63,14 @@ def test_lift_splat_mass_conservation(hip, name, input_size, focal):
     ref = torch.where(kept, ((coords[:, 3] * X + coords[:, 0]) * Y + coords[:, 1]) * Z + coords[:, 2],
                       torch.full_like(coords[:, 0], -1)).int()
     mism = int((vox.cpu() != ref).sum())
-    assert mism <= 2e-4 * ref.numel(), f"{mism} voxel ids differ"
+    assert mism == 0, f"{mism} voxel ids differ"
+    # the same with the constants packed on the GPU (torch.linalg.inv_ex / matmul on the device differ from the
+    # CPU LU in the last bit -- exactly as the reference differs between its own CPU and CUDA runs): report it
+    vox_g = hip.ops.lss_voxel_index(frustum.reshape(-1, 3).contiguous(), *pack_cameras(*cams), grid, 1, 6, X, Y, Z,
+                                    False)
+    flips = int((vox_g.cpu() != ref).sum())
+    print(f"[{name}] voxel-id flips with device-side camera constants: {flips} of {ref.numel()}")
+    assert flips <= 2e-4 * ref.numel()
     offsets, pts = build_voxel_csr(vox, X * Y * Z)
     g = torch.Generator().manual_seed(2)
     depth = torch.randn(6, 112, fH * fW, generator=g).softmax(1).to(hip.device)
