@@ -375,6 +375,47 @@ int occf_point_sample_3d_bwd(const float* dout, const float* pts, float* dvol, i
 int occf_point_loss_rows_bwd(const float* logits, const float* targets, const float* grad_rows, float* dlogits,
                              int R, long P, void* stream);
 
+/* Weight (and bias) gradient of occf_linear_*: dw[N, K] = dy[M, N]^T x[M, K], dbias[N] = column sums of dy (NULL
+ * to skip); bf16 matrix cores with terms = 3 (fp32-class) or 1, M split into slabs reduced in fixed order.
+ * workspace: occf_linear_wgrad_workspace floats (0: none needed).  Small or odd shapes (M <= 1024, N or K not a
+ * multiple of 4) run an exact fp32 kernel. */
+long occf_linear_wgrad_workspace(long M, int N, int K);
+int occf_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias, float* workspace,
+                      long workspace_floats, long M, int N, int K, long ldy, long ldx, int terms, void* stream);
+
+/* Weight gradient of occf_conv3d_*_fwd in the tap-major layout dw[Cout, kX*kY*kZ*Cin]; x addressed by strides as in
+ * the forward, dy[B*Xo*Yo*Zo, Cout] contiguous. */
+long occf_conv3d_wgrad_workspace(int B, int Xi, int Yi, int Zi, int Cin, int Cout, int kX, int kY, int kZ, int stride,
+                                 int dil, int pad_x, int pad_y, int pad_z);
+int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapmajor, float* dbias, float* workspace,
+                      long workspace_floats, int B, int Xi, int Yi, int Zi, int Cin, int Cout, int kX, int kY, int kZ,
+                      int stride, int dil, int pad_x, int pad_y, int pad_z, long in_sb, long in_sx, long in_sy,
+                      long in_sz, int terms, void* stream);
+
+/* Data gradient of occf_conv3d_bf16_fwd (any stride / dilation): dy[B, Xo, Yo, Zo, Cout] contiguous ->
+ * dx[B, Xi, Yi, Zi, Cin] contiguous; wt = the weight re-laid as [Cin, taps*Cout] (k = tap*Cout + co), pre-split.
+ * Cout % 32 == 0.  (The 3^3 / stride-1 case is also served by occf_conv3x3x3_halo_fwd on the tap-flipped weight.) */
+int occf_conv3d_bf16_dgrad(const float* dy, const uint16_t* wt_hi, const uint16_t* wt_lo, float* dx, int B, int Xi,
+                           int Yi, int Zi, int Cin, int Cout, int kX, int kY, int kZ, int stride, int dil, int pad_x,
+                           int pad_y, int pad_z, int terms, float* workspace, long workspace_floats, void* stream);
+
+/* Backward of occf_window_attn_fwd (and of the attention core inside occf_swin_attn_fused_fwd): qkv / qkv_bias /
+ * bias_table as in the forward, attn_out = the forward's output, dout its gradient.  dqkv[n_tok, 3C] (every row
+ * written once); dqkv_bias[3C] receives ONLY the key / value gradients of zero-padded window positions (whose
+ * qkv is the bias) and must be ZERO-FILLED by the caller -- the bias gradient of the projection itself is the
+ * column sum of dqkv; dbias_table[(2*7-1)^2, heads].  workspace: occf_window_attn_bwd_workspace floats. */
+long occf_window_attn_bwd_workspace(int B, int X, int Y, int S, int heads);
+int occf_window_attn_bwd(const float* qkv, const float* qkv_bias, const float* bias_table, const float* attn_out,
+                         const float* dout, float* dqkv, float* dqkv_bias, float* dbias_table, float* workspace,
+                         int B, int X, int Y, int S, int C, int heads, int shift, void* stream);
+
+/* Backward of occf_masked_xattn_fwd: out = the forward's output, dout its gradient; dq[B, Q, E], dk/dv[B, L, E].
+ * Q <= 128, head_dim 32.  workspace: occf_masked_xattn_bwd_workspace floats. */
+long occf_masked_xattn_bwd_workspace(int B, int Q, int L, int heads);
+int occf_masked_xattn_bwd(const float* q, const float* k, const float* v, const uint8_t* blocked,
+                          const int32_t* row_open, const float* out, const float* dout, float* dq, float* dk,
+                          float* dv, float* workspace, int B, int Q, int L, int E, int heads, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,522 @@
+// Backward of the two attention cores of the path (training step; ATen autograd through
+// WindowMSA.forward / nn.MultiheadAttention in the reference: window_attention.py:69-107,168-242;
+// mask2former_nusc_occ.py:652-667):
+//   * occf_window_attn_bwd   -- 7x7 shifted-window attention of the shared SwinBlock
+//   * occf_masked_xattn_bwd  -- masked multi-head cross / self attention of the occupancy decoder
+// Both recompute the probabilities from q, k (flash-style: nothing of size [rows, keys] is saved by the forward)
+// and use D_i = <dO_i, O_i> for the softmax Jacobian.  fp32 VALU arithmetic; parameter gradients (relative
+// position table, the qkv bias seen by zero-padded window tokens) as per-workgroup partials reduced in fixed
+// order, except the few padded-token bias rows (float atomics).
+#include "occf_common.h"
+#include "../../include/occformer_hip.h"
+
+#define WB_WS 7
+#define WB_T 49
+#define WB_HD 32
+#define WB_NB 169          // (2*7-1)^2 relative positions
+#define WB_HPB 2           // heads (= waves) per workgroup
+
+// --------------------------------------------------------------------------------------------- window attention
+// One wave per (window, head); lane t < 49 first acts as QUERY row t (P, dS rows in registers, dQ), then as KEY
+// row t (dK, dV as sums over the queries, read from the LDS copies of P / dS).  A workgroup walks `wpb`
+// consecutive windows and keeps the relative-position-bias gradient of its heads in registers.
+__global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
+    const float* __restrict__ attn_out, const float* __restrict__ dout, float* __restrict__ dqkv,
+    float* __restrict__ dqkv_bias, float* __restrict__ dtable_partial, int B, int X, int Y, int S, int C, int heads,
+    int shift, float scale, int wpb, long n_windows) {
+  __shared__ __attribute__((aligned(16))) float lds_k[WB_HPB][WB_T * WB_HD];
+  __shared__ __attribute__((aligned(16))) float lds_v[WB_HPB][WB_T * WB_HD];
+  __shared__ float lds_m[WB_HPB][WB_T * WB_T];
+  __shared__ float lds_bias[WB_HPB][WB_NB];
+  __shared__ int lds_tok[WB_HPB][WB_T];
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nwx = (X + WB_WS - 1) / WB_WS, nwy = (Y + WB_WS - 1) / WB_WS;
+  const int Xp = nwx * WB_WS, Yp = nwy * WB_WS;
+  const int head = blockIdx.y * WB_HPB + wave;
+  const bool active = head < heads;
+  const int C3 = 3 * C;
+  if (active)
+    for (int t = lane; t < WB_NB; t += 64) lds_bias[wave][t] = bias_table[(long)t * heads + head];
+  float dtab[3] = {0.f, 0.f, 0.f};                           // bins lane, lane + 64, lane + 128
+
+  for (int wi = 0; wi < wpb; ++wi) {
+    const long win = (long)blockIdx.x * wpb + wi;
+    if (win >= n_windows) break;                               // uniform over the workgroup
+    long w = win;
+    const int wy = (int)(w % nwy);
+    w /= nwy;
+    const int wx = (int)(w % nwx);
+    w /= nwx;
+    const int s = (int)(w % S);
+    const int b = (int)(w / S);
+
+    int my_tok = -1, my_region = 0;
+    if (lane < WB_T) {
+      const int i = lane / WB_WS, j = lane % WB_WS;
+      const int px = wx * WB_WS + i, py = wy * WB_WS + j;
+      int sx = px + shift, sy = py + shift;
+      if (sx >= Xp) sx -= Xp;
+      if (sy >= Yp) sy -= Yp;
+      if (sx < X && sy < Y) my_tok = (int)((((long)b * X + sx) * Y + sy) * S + s);
+      if (shift > 0) {
+        const int rx = px < Xp - WB_WS ? 0 : (px < Xp - shift ? 1 : 2);
+        const int ry = py < Yp - WB_WS ? 0 : (py < Yp - shift ? 1 : 2);
+        my_region = rx * 3 + ry;
+      }
+    }
+    __syncthreads();                                           // previous window's LDS reads are done
+    if (lane < WB_T) lds_tok[wave][lane] = my_tok;
+    __syncthreads();
+    if (active) {
+      for (int idx = lane; idx < WB_T * (WB_HD / 4); idx += 64) {
+        const int t = idx >> 3, q4 = (idx & 7) * 4;
+        const int tok = lds_tok[wave][t];
+        const float* src = tok >= 0 ? qkv + (long)tok * C3 : qkv_bias;
+        *(float4*)(&lds_k[wave][t * WB_HD + q4]) = *(const float4*)(src + C + head * WB_HD + q4);
+        *(float4*)(&lds_v[wave][t * WB_HD + q4]) = *(const float4*)(src + 2 * C + head * WB_HD + q4);
+      }
+    }
+    __syncthreads();
+
+    // ---- query role.  Padded query rows are cropped by the forward: P = dS = 0, no dQ.
+    const bool qrow = active && lane < WB_T && my_tok >= 0;
+    float q[WB_HD], go[WB_HD], dq[WB_HD];
+    float sc[WB_T];
+    float Dq = 0.f;
+#pragma unroll
+    for (int d = 0; d < WB_HD; ++d) q[d] = go[d] = dq[d] = 0.f;
+    if (qrow) {
+      const float* src = qkv + (long)my_tok * C3 + head * WB_HD;
+      const float* gsrc = dout + (long)my_tok * C + head * WB_HD;
+      const float* osrc = attn_out + (long)my_tok * C + head * WB_HD;
+#pragma unroll
+      for (int d = 0; d < WB_HD; d += 4) {
+        const float4 t = *(const float4*)(src + d);
+        const float4 g = *(const float4*)(gsrc + d);
+        const float4 o = *(const float4*)(osrc + d);
+        q[d] = t.x * scale; q[d + 1] = t.y * scale; q[d + 2] = t.z * scale; q[d + 3] = t.w * scale;
+        go[d] = g.x; go[d + 1] = g.y; go[d + 2] = g.z; go[d + 3] = g.w;
+        Dq += (g.x * o.x + g.y * o.y) + (g.z * o.z + g.w * o.w);
+      }
+    }
+    const int qi = lane / WB_WS, qj = lane % WB_WS;
+    if (lane < WB_T) {
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int j = 0; j < WB_T; ++j) {
+        const float* kr = &lds_k[wave][j * WB_HD];
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < WB_HD; ++d) a = fmaf(q[d], kr[d], a);
+        const int ki = j / WB_WS, kj = j % WB_WS;
+        a += lds_bias[wave][(qi - ki + WB_WS - 1) * (2 * WB_WS - 1) + (qj - kj + WB_WS - 1)];
+        if (shift > 0) {
+          const int px = wx * WB_WS + ki, py = wy * WB_WS + kj;
+          const int rx = px < Xp - WB_WS ? 0 : (px < Xp - shift ? 1 : 2);
+          const int ry = py < Yp - WB_WS ? 0 : (py < Yp - shift ? 1 : 2);
+          if (rx * 3 + ry != my_region) a += -100.0f;
+        }
+        sc[j] = a;
+        mx = fmaxf(mx, a);
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < WB_T; ++j) {
+        sc[j] = expf(sc[j] - mx);
+        sum += sc[j];
+      }
+      const float inv = qrow ? 1.0f / sum : 0.f;
+#pragma unroll
+      for (int j = 0; j < WB_T; ++j) {
+        sc[j] *= inv;                                          // P[i][j]
+        lds_m[wave][lane * WB_T + j] = sc[j];
+      }
+      // dS = P * (dO . V_j - D);  dQ = scale * sum_j dS K_j
+#pragma unroll
+      for (int j = 0; j < WB_T; ++j) {
+        const float* vr = &lds_v[wave][j * WB_HD];
+        const float* kr = &lds_k[wave][j * WB_HD];
+        float dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < WB_HD; ++d) dp = fmaf(go[d], vr[d], dp);
+        const float ds = sc[j] * (dp - Dq);
+        sc[j] = ds;
+#pragma unroll
+        for (int d = 0; d < WB_HD; ++d) dq[d] = fmaf(ds, kr[d], dq[d]);
+      }
+      if (qrow) {
+        float* dst = dqkv + (long)my_tok * C3 + head * WB_HD;
+#pragma unroll
+        for (int d = 0; d < WB_HD; d += 4)
+          *(float4*)(dst + d) = make_float4(dq[d] * scale, dq[d + 1] * scale, dq[d + 2] * scale, dq[d + 3] * scale);
+      }
+    }
+    __syncthreads();                                           // every lane is done with K / V
+    // scaled queries -> K buffer, dO -> V buffer
+    if (lane < WB_T) {
+#pragma unroll
+      for (int d = 0; d < WB_HD; d += 4) {
+        *(float4*)(&lds_k[wave][lane * WB_HD + d]) = make_float4(q[d], q[d + 1], q[d + 2], q[d + 3]);
+        *(float4*)(&lds_v[wave][lane * WB_HD + d]) = make_float4(go[d], go[d + 1], go[d + 2], go[d + 3]);
+      }
+    }
+    __syncthreads();
+    // ---- key role: dV_j = sum_i P[i][j] dO_i
+    float acc[WB_HD];
+    if (active && lane < WB_T) {
+#pragma unroll
+      for (int d = 0; d < WB_HD; ++d) acc[d] = 0.f;
+      for (int i = 0; i < WB_T; ++i) {
+        const float pij = lds_m[wave][i * WB_T + lane];
+        const float* gr = &lds_v[wave][i * WB_HD];
+#pragma unroll
+        for (int d = 0; d < WB_HD; ++d) acc[d] = fmaf(pij, gr[d], acc[d]);
+      }
+      if (my_tok >= 0) {
+        float* dst = dqkv + (long)my_tok * C3 + 2 * C + head * WB_HD;
+#pragma unroll
+        for (int d = 0; d < WB_HD; d += 4) *(float4*)(dst + d) = make_float4(acc[d], acc[d + 1], acc[d + 2], acc[d + 3]);
+      } else {
+#pragma unroll
+        for (int d = 0; d < WB_HD; ++d) atomicAdd(dqkv_bias + 2 * C + head * WB_HD + d, acc[d]);
+      }
+    }
+    __syncthreads();                                           // P has been consumed
+    if (lane < WB_T) {
+#pragma unroll
+      for (int j = 0; j < WB_T; ++j) lds_m[wave][lane * WB_T + j] = sc[j];    // dS[i][j]
+    }
+    __syncthreads();
+    if (active && lane < WB_T) {
+#pragma unroll
+      for (int d = 0; d < WB_HD; ++d) acc[d] = 0.f;
+      for (int i = 0; i < WB_T; ++i) {
+        const float dij = lds_m[wave][i * WB_T + lane];
+        const float* qr = &lds_k[wave][i * WB_HD];
+#pragma unroll
+        for (int d = 0; d < WB_HD; ++d) acc[d] = fmaf(dij, qr[d], acc[d]);
+      }
+      if (my_tok >= 0) {
+        float* dst = dqkv + (long)my_tok * C3 + C + head * WB_HD;
+#pragma unroll
+        for (int d = 0; d < WB_HD; d += 4) *(float4*)(dst + d) = make_float4(acc[d], acc[d + 1], acc[d + 2], acc[d + 3]);
+      } else {
+#pragma unroll
+        for (int d = 0; d < WB_HD; ++d) atomicAdd(dqkv_bias + C + head * WB_HD + d, acc[d]);
+      }
+    }
+    // ---- relative-position bias: bin r = (di + 6) * 13 + (dj + 6) collects dS[(ki+di, kj+dj)][(ki, kj)]
+    if (active) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int r = lane + u * 64;
+        if (r < WB_NB) {
+          const int di = r / (2 * WB_WS - 1) - (WB_WS - 1), dj = r % (2 * WB_WS - 1) - (WB_WS - 1);
+          float a = 0.f;
+          for (int ki = 0; ki < WB_WS; ++ki) {
+            const int qi2 = ki + di;
+            if (qi2 < 0 || qi2 >= WB_WS) continue;
+            for (int kj = 0; kj < WB_WS; ++kj) {
+              const int qj2 = kj + dj;
+              if (qj2 < 0 || qj2 >= WB_WS) continue;
+              a += lds_m[wave][(qi2 * WB_WS + qj2) * WB_T + ki * WB_WS + kj];
+            }
+          }
+          dtab[u] += a;
+        }
+      }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int r = lane + u * 64;
+      if (r < WB_NB) dtable_partial[((long)blockIdx.x * heads + head) * WB_NB + r] = dtab[u];
+    }
+  }
+}
+
+// dtable[r][head] = sum_x partial[x][head][r]
+__global__ void __launch_bounds__(256) window_table_reduce_kernel(const float* __restrict__ partial,
+                                                                  float* __restrict__ dtable, long nblk, int heads) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= WB_NB * heads) return;
+  const int r = t / heads, h = t % heads;
+  double s = 0.0;
+  for (long x = 0; x < nblk; ++x) s += (double)partial[(x * heads + h) * WB_NB + r];
+  dtable[t] = (float)s;
+}
+
+static int wb_windows_per_block(long n_windows) {
+  long w = (n_windows + 2047) / 2048;
+  return w < 1 ? 1 : (w > 64 ? 64 : (int)w);
+}
+extern "C" long occf_window_attn_bwd_workspace(int B, int X, int Y, int S, int heads) {
+  const long nwin = (long)B * S * ((X + 6) / 7) * ((Y + 6) / 7);
+  return (long)occf_cdiv(nwin, wb_windows_per_block(nwin)) * heads * WB_NB;
+}
+
+extern "C" int occf_window_attn_bwd(const float* qkv, const float* qkv_bias, const float* bias_table,
+                                    const float* attn_out, const float* dout, float* dqkv, float* dqkv_bias,
+                                    float* dbias_table, float* workspace, int B, int X, int Y, int S, int C,
+                                    int heads, int shift, void* stream) {
+  if (B <= 0 || X <= 0 || Y <= 0 || S <= 0 || heads <= 0 || C != heads * WB_HD) return OCCF_ESHAPE;
+  if (shift < 0 || shift >= WB_WS) return OCCF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const long nwin = (long)B * S * ((X + 6) / 7) * ((Y + 6) / 7);
+  const int wpb = wb_windows_per_block(nwin);
+  const int nblk = occf_cdiv(nwin, wpb);
+  hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(nblk, occf_cdiv(heads, WB_HPB)), dim3(64 * WB_HPB), 0, st, qkv,
+                     qkv_bias, bias_table, attn_out, dout, dqkv, dqkv_bias, workspace, B, X, Y, S, C, heads, shift,
+                     1.0f / sqrtf((float)WB_HD), wpb, nwin);
+  hipLaunchKernelGGL(window_table_reduce_kernel, dim3(occf_cdiv(WB_NB * heads, 256)), dim3(256), 0, st, workspace,
+                     dbias_table, (long)nblk, heads);
+  OCCF_LAUNCH_CHECK();
+}
+
+// --------------------------------------------------------------------------------------------- masked attention
+#define XB_HD 32
+#define XB_QMAX 128
+#define XB_TILE 32
+
+// lse[b, h, q] and D[b, h, q] = <dO, O>:  partial (m, l) per key chunk, then merged
+__global__ void __launch_bounds__(XB_QMAX) xattn_stats_partial_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const uint8_t* __restrict__ blocked,
+    const int* __restrict__ row_open, float* __restrict__ part_ml, int B, int Q, int L, int E, int heads, int chunk,
+    int n_chunks, float scale) {
+  __shared__ __attribute__((aligned(16))) float lds_k[XB_TILE * XB_HD];
+  const int ck = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int qi = threadIdx.x;
+  const bool valid = qi < Q;
+  float qr[XB_HD];
+  bool use_mask = false;
+  if (valid) {
+    const float* qp = q + ((long)b * Q + qi) * E + h * XB_HD;
+#pragma unroll
+    for (int d = 0; d < XB_HD; ++d) qr[d] = qp[d] * scale;
+    use_mask = blocked != nullptr && row_open[b * Q + qi] != 0;
+  } else {
+#pragma unroll
+    for (int d = 0; d < XB_HD; ++d) qr[d] = 0.f;
+  }
+  const int k0 = ck * chunk;
+  const int k1 = (k0 + chunk < L) ? k0 + chunk : L;
+  const uint8_t* brow = valid && use_mask ? blocked + ((long)b * Q + qi) * L : nullptr;
+  float m = -INFINITY, l = 0.f;
+  for (int t0 = k0; t0 < k1; t0 += XB_TILE) {
+    const int nt = (k1 - t0 < XB_TILE) ? k1 - t0 : XB_TILE;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < XB_TILE * (XB_HD / 4); idx += XB_QMAX) {
+      const int r = idx >> 3, c4 = (idx & 7) * 4;
+      int key = t0 + r;
+      key = key < k1 ? key : k1 - 1;
+      *(float4*)(&lds_k[r * XB_HD + c4]) = *(const float4*)(k + ((long)b * L + key) * E + h * XB_HD + c4);
+    }
+    __syncthreads();
+    if (!valid) continue;
+    for (int r = 0; r < nt; ++r) {
+      if (brow != nullptr && brow[t0 + r]) continue;
+      const float* kr = &lds_k[r * XB_HD];
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < XB_HD; ++d) a = fmaf(qr[d], kr[d], a);
+      const float mn = fmaxf(m, a);
+      l = l * expf(m - mn) + expf(a - mn);
+      m = mn;
+    }
+  }
+  if (!valid) return;
+  const long slot = (((long)b * heads + h) * Q + qi) * n_chunks + ck;
+  part_ml[slot * 2] = m;
+  part_ml[slot * 2 + 1] = l;
+}
+
+__global__ void __launch_bounds__(256) xattn_stats_merge_kernel(const float* __restrict__ part_ml,
+                                                                const float* __restrict__ out,
+                                                                const float* __restrict__ dout, float* __restrict__ lse,
+                                                                float* __restrict__ Dv, int B, int Q, int E, int heads,
+                                                                int n_chunks) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)B * heads * Q) return;
+  const int qi = (int)(gid % Q);
+  const int h = (int)((gid / Q) % heads);
+  const int b = (int)(gid / ((long)Q * heads));
+  float m = -INFINITY;
+  for (int c = 0; c < n_chunks; ++c) m = fmaxf(m, part_ml[(gid * n_chunks + c) * 2]);
+  float l = 0.f;
+  for (int c = 0; c < n_chunks; ++c) {
+    const float mc = part_ml[(gid * n_chunks + c) * 2];
+    if (mc != -INFINITY) l += part_ml[(gid * n_chunks + c) * 2 + 1] * expf(mc - m);
+  }
+  lse[gid] = m + logf(l);
+  const float* o = out + ((long)b * Q + qi) * E + h * XB_HD;
+  const float* g = dout + ((long)b * Q + qi) * E + h * XB_HD;
+  float d = 0.f;
+#pragma unroll
+  for (int e = 0; e < XB_HD; ++e) d = fmaf(o[e], g[e], d);
+  Dv[gid] = d;
+}
+
+// Main pass: a workgroup owns a contiguous key chunk of one (batch, head).  Threads first act as QUERIES
+// (P, dS of the current 32-key tile -> LDS; dQ accumulated in registers over the chunk), then as (key, 8-dim
+// slice) pairs for dK / dV.  dQ leaves as one partial per chunk (reduced afterwards in fixed order).
+__global__ void __launch_bounds__(XB_QMAX) xattn_bwd_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+    const uint8_t* __restrict__ blocked, const int* __restrict__ row_open, const float* __restrict__ dout,
+    const float* __restrict__ lse, const float* __restrict__ Dv, float* __restrict__ dq_part, float* __restrict__ dk,
+    float* __restrict__ dv, int B, int Q, int L, int E, int heads, int chunk, int n_chunks, float scale) {
+  __shared__ __attribute__((aligned(16))) float lds_k[XB_TILE * XB_HD];
+  __shared__ __attribute__((aligned(16))) float lds_v[XB_TILE * XB_HD];
+  __shared__ __attribute__((aligned(16))) float lds_q[XB_QMAX * XB_HD];      // scaled queries
+  __shared__ __attribute__((aligned(16))) float lds_g[XB_QMAX * XB_HD];      // dO
+  __shared__ float lds_p[XB_QMAX * (XB_TILE + 1)];
+  __shared__ float lds_s[XB_QMAX * (XB_TILE + 1)];
+  const int ck = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int qi = threadIdx.x;
+  const bool valid = qi < Q;
+  float qr[XB_HD], go[XB_HD], dq[XB_HD];
+  float my_lse = 0.f, my_D = 0.f;
+  bool use_mask = false;
+#pragma unroll
+  for (int d = 0; d < XB_HD; ++d) qr[d] = go[d] = dq[d] = 0.f;
+  if (valid) {
+    const float* qp = q + ((long)b * Q + qi) * E + h * XB_HD;
+    const float* gp = dout + ((long)b * Q + qi) * E + h * XB_HD;
+#pragma unroll
+    for (int d = 0; d < XB_HD; ++d) {
+      qr[d] = qp[d] * scale;
+      go[d] = gp[d];
+    }
+    const long sidx = ((long)b * heads + h) * Q + qi;
+    my_lse = lse[sidx];
+    my_D = Dv[sidx];
+    use_mask = blocked != nullptr && row_open[b * Q + qi] != 0;
+  }
+#pragma unroll
+  for (int d = 0; d < XB_HD; d += 4) {
+    *(float4*)(&lds_q[qi * XB_HD + d]) = make_float4(qr[d], qr[d + 1], qr[d + 2], qr[d + 3]);
+    *(float4*)(&lds_g[qi * XB_HD + d]) = make_float4(go[d], go[d + 1], go[d + 2], go[d + 3]);
+  }
+  const int k0 = ck * chunk;
+  const int k1 = (k0 + chunk < L) ? k0 + chunk : L;
+  const uint8_t* brow = valid && use_mask ? blocked + ((long)b * Q + qi) * L : nullptr;
+  const int kj = threadIdx.x & 31, dpart = (threadIdx.x >> 5) * 8;          // key role: key kj, dims dpart..+7
+  for (int t0 = k0; t0 < k1; t0 += XB_TILE) {
+    const int nt = (k1 - t0 < XB_TILE) ? k1 - t0 : XB_TILE;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < XB_TILE * (XB_HD / 4); idx += XB_QMAX) {
+      const int r = idx >> 3, c4 = (idx & 7) * 4;
+      int key = t0 + r;
+      key = key < k1 ? key : k1 - 1;
+      const long src = ((long)b * L + key) * E + h * XB_HD + c4;
+      *(float4*)(&lds_k[r * XB_HD + c4]) = *(const float4*)(k + src);
+      *(float4*)(&lds_v[r * XB_HD + c4]) = *(const float4*)(v + src);
+    }
+    __syncthreads();
+    for (int r = 0; r < XB_TILE; ++r) {
+      float p = 0.f, ds = 0.f;
+      if (valid && r < nt && !(brow != nullptr && brow[t0 + r])) {
+        const float* kr = &lds_k[r * XB_HD];
+        const float* vr = &lds_v[r * XB_HD];
+        float a = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < XB_HD; ++d) {
+          a = fmaf(qr[d], kr[d], a);
+          dp = fmaf(go[d], vr[d], dp);
+        }
+        p = expf(a - my_lse);
+        ds = p * (dp - my_D);
+#pragma unroll
+        for (int d = 0; d < XB_HD; ++d) dq[d] = fmaf(ds, kr[d], dq[d]);
+      }
+      lds_p[qi * (XB_TILE + 1) + r] = p;
+      lds_s[qi * (XB_TILE + 1) + r] = ds;
+    }
+    __syncthreads();
+    // key role: dV[kj][dpart..] = sum_q P[q][kj] dO[q][..];  dK[kj][..] = sum_q dS[q][kj] (q * scale)[..]
+    if (kj < nt) {
+      float av[8], ak[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) av[e] = ak[e] = 0.f;
+      for (int qq = 0; qq < Q; ++qq) {
+        const float p = lds_p[qq * (XB_TILE + 1) + kj];
+        const float ds = lds_s[qq * (XB_TILE + 1) + kj];
+        const float* gr = &lds_g[qq * XB_HD + dpart];
+        const float* qs = &lds_q[qq * XB_HD + dpart];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          av[e] = fmaf(p, gr[e], av[e]);
+          ak[e] = fmaf(ds, qs[e], ak[e]);
+        }
+      }
+      const long dst = ((long)b * L + t0 + kj) * E + h * XB_HD + dpart;
+      *(float4*)(dv + dst) = make_float4(av[0], av[1], av[2], av[3]);
+      *(float4*)(dv + dst + 4) = make_float4(av[4], av[5], av[6], av[7]);
+      *(float4*)(dk + dst) = make_float4(ak[0], ak[1], ak[2], ak[3]);
+      *(float4*)(dk + dst + 4) = make_float4(ak[4], ak[5], ak[6], ak[7]);
+    }
+  }
+  if (!valid) return;
+  float* po = dq_part + ((((long)b * heads + h) * Q + qi) * n_chunks + ck) * XB_HD;
+#pragma unroll
+  for (int d = 0; d < XB_HD; d += 4)
+    *(float4*)(po + d) = make_float4(dq[d] * scale, dq[d + 1] * scale, dq[d + 2] * scale, dq[d + 3] * scale);
+}
+
+__global__ void __launch_bounds__(256) xattn_dq_reduce_kernel(const float* __restrict__ dq_part, float* __restrict__ dq,
+                                                              int B, int Q, int E, int heads, int n_chunks) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)B * heads * Q * XB_HD) return;
+  const int d = (int)(gid % XB_HD);
+  const long row = gid / XB_HD;                       // (b, h, q)
+  const int qi = (int)(row % Q);
+  const int h = (int)((row / Q) % heads);
+  const int b = (int)(row / ((long)Q * heads));
+  float s = 0.f;
+  for (int c = 0; c < n_chunks; ++c) s += dq_part[(row * n_chunks + c) * XB_HD + d];
+  dq[((long)b * Q + qi) * E + h * XB_HD + d] = s;
+}
+
+static void xb_chunks(int B, int L, int heads, int& chunk, int& n_chunks) {
+  // enough workgroups to fill the chip, at least 4 tiles per chunk
+  long want = 1024 / ((long)B * heads > 0 ? (long)B * heads : 1);
+  if (want < 1) want = 1;
+  long c = (L + want - 1) / want;
+  c = (c + XB_TILE - 1) / XB_TILE * XB_TILE;
+  if (c < 4 * XB_TILE) c = 4 * XB_TILE;
+  chunk = (int)c;
+  n_chunks = (L + chunk - 1) / chunk;
+}
+
+extern "C" long occf_masked_xattn_bwd_workspace(int B, int Q, int L, int heads) {
+  int chunk, nc;
+  xb_chunks(B, L, heads, chunk, nc);
+  const long rows = (long)B * heads * Q;
+  return rows * nc * 2 + rows * 2 + rows * nc * XB_HD;
+}
+
+extern "C" int occf_masked_xattn_bwd(const float* q, const float* k, const float* v, const uint8_t* blocked,
+                                     const int32_t* row_open, const float* out, const float* dout, float* dq, float* dk,
+                                     float* dv, float* workspace, int B, int Q, int L, int E, int heads, void* stream) {
+  if (B <= 0 || Q <= 0 || Q > XB_QMAX || L <= 0 || E != heads * XB_HD) return OCCF_ESHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  int chunk, nc;
+  xb_chunks(B, L, heads, chunk, nc);
+  const long rows = (long)B * heads * Q;
+  float* part_ml = workspace;
+  float* lse = part_ml + rows * nc * 2;
+  float* Dv = lse + rows;
+  float* dq_part = Dv + rows;
+  const float scale = 1.0f / sqrtf((float)XB_HD);
+  hipLaunchKernelGGL(xattn_stats_partial_kernel, dim3(nc, heads, B), dim3(XB_QMAX), 0, st, q, k, blocked,
+                     (const int*)row_open, part_ml, B, Q, L, E, heads, chunk, nc, scale);
+  hipLaunchKernelGGL(xattn_stats_merge_kernel, dim3(occf_cdiv(rows, 256)), dim3(256), 0, st, part_ml, out, dout, lse,
+                     Dv, B, Q, E, heads, nc);
+  hipLaunchKernelGGL(xattn_bwd_kernel, dim3(nc, heads, B), dim3(XB_QMAX), 0, st, q, k, v, blocked,
+                     (const int*)row_open, dout, lse, Dv, dq_part, dk, dv, B, Q, L, E, heads, chunk, nc, scale);
+  hipLaunchKernelGGL(xattn_dq_reduce_kernel, dim3(occf_cdiv(rows * XB_HD, 256)), dim3(256), 0, st, dq_part, dq, B, Q,
+                     E, heads, nc);
+  OCCF_LAUNCH_CHECK();
+}

@@ -32,6 +32,10 @@
 struct ConvGeomB {
   int Xo, Yo, Zo, Xi, Yi, Zi, kX, kY, kZ, stride, dil, pad_x, pad_y, pad_z, Cin;
   long sb, sx, sy, sz;
+  // transposed = 1: the data-gradient of a convolution (rows = the forward's INPUT voxels, the tensor read is dY
+  // with dims Xi/Yi/Zi = the forward's output dims): tap (dx,dy,dz) of row x reads dY[(x + pad - dx*dil) / stride]
+  // when that division is exact and in range
+  int transposed;
 };
 struct GemmArgsB {
   const float* A;
@@ -127,9 +131,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
       const int xo = (int)((mm / ((long)p.g.Zo * p.g.Yo)) % p.g.Xo);
       const long b = mm / ((long)p.g.Zo * p.g.Yo * p.g.Xo);
       a_base[i] = b * p.g.sb;
-      a_x[i] = xo * p.g.stride - p.g.pad_x;
-      a_y[i] = yo * p.g.stride - p.g.pad_y;
-      a_z[i] = zo * p.g.stride - p.g.pad_z;
+      a_x[i] = p.g.transposed ? xo + p.g.pad_x : xo * p.g.stride - p.g.pad_x;
+      a_y[i] = p.g.transposed ? yo + p.g.pad_y : yo * p.g.stride - p.g.pad_y;
+      a_z[i] = p.g.transposed ? zo + p.g.pad_z : zo * p.g.stride - p.g.pad_z;
     } else {
       a_base[i] = (a_ok[i] ? m : 0) * p.lda;
       a_x[i] = a_y[i] = a_z[i] = 0;
@@ -162,8 +166,15 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
       const int dz = tap % p.g.kZ, dy = (tap / p.g.kZ) % p.g.kY, dx = tap / (p.g.kZ * p.g.kY);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int xi = a_x[i] + dx * p.g.dil, yi = a_y[i] + dy * p.g.dil, zi = a_z[i] + dz * p.g.dil;
-        const bool ok = a_ok[i] && xi >= 0 && xi < p.g.Xi && yi >= 0 && yi < p.g.Yi && zi >= 0 && zi < p.g.Zi;
+        int xi = a_x[i] + dx * p.g.dil, yi = a_y[i] + dy * p.g.dil, zi = a_z[i] + dz * p.g.dil;
+        bool ok = a_ok[i];
+        if (p.g.transposed) {
+          xi = a_x[i] - dx * p.g.dil; yi = a_y[i] - dy * p.g.dil; zi = a_z[i] - dz * p.g.dil;
+          const int s = p.g.stride;
+          ok = ok && xi >= 0 && yi >= 0 && zi >= 0 && xi % s == 0 && yi % s == 0 && zi % s == 0;
+          xi = xi >= 0 ? xi / s : -1; yi = yi >= 0 ? yi / s : -1; zi = zi >= 0 ? zi / s : -1;
+        }
+        ok = ok && xi >= 0 && xi < p.g.Xi && yi >= 0 && yi < p.g.Yi && zi >= 0 && zi < p.g.Zi;
         const int xc = occf_clampi(xi, p.g.Xi - 1), yc = occf_clampi(yi, p.g.Yi - 1),
                   zc = occf_clampi(zi, p.g.Zi - 1);
         const float4 v = *(const float4*)(p.A + a_base[i] + xc * p.g.sx + yc * p.g.sy + zc * p.g.sz + c0 +
@@ -541,6 +552,33 @@ extern "C" int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const 
   a.A = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.C = out;
   a.M = (int)M; a.N = Cout; a.K = kX * kY * kZ * Cin; a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.act = act;
   a.gn_partial = gn_partial;
+  return launch_gemm_b<true>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
+}
+
+// Data gradient of occf_conv3d_bf16_fwd: dx[B, Xi, Yi, Zi, Cin] = sum over taps / output channels of
+// dy[(x + pad - tap*dil) / stride] * W  -- the same implicit GEMM with the transposed loader; the weight comes
+// re-laid as [Cin, taps*Cout] (k = tap*Cout + co), pre-split.
+extern "C" int occf_conv3d_bf16_dgrad(const float* dy, const uint16_t* wt_hi, const uint16_t* wt_lo, float* dx, int B,
+                                      int Xi, int Yi, int Zi, int Cin, int Cout, int kX, int kY, int kZ, int stride,
+                                      int dil, int pad_x, int pad_y, int pad_z, int terms, float* workspace,
+                                      long workspace_floats, void* stream) {
+  if (B <= 0 || Cout % GB_BK != 0 || stride <= 0 || dil <= 0) return OCCF_ESHAPE;
+  GemmArgsB a = {};
+  ConvGeomB& g = a.g;
+  const int Xo = (Xi + 2 * pad_x - dil * (kX - 1) - 1) / stride + 1;
+  const int Yo = (Yi + 2 * pad_y - dil * (kY - 1) - 1) / stride + 1;
+  const int Zo = (Zi + 2 * pad_z - dil * (kZ - 1) - 1) / stride + 1;
+  if (Xo <= 0 || Yo <= 0 || Zo <= 0) return OCCF_ESHAPE;
+  g.transposed = 1;
+  g.Xo = Xi; g.Yo = Yi; g.Zo = Zi;            // rows of this GEMM: the forward's input voxels
+  g.Xi = Xo; g.Yi = Yo; g.Zi = Zo;            // tensor read: dy
+  g.kX = kX; g.kY = kY; g.kZ = kZ; g.stride = stride; g.dil = dil; g.pad_x = pad_x; g.pad_y = pad_y; g.pad_z = pad_z;
+  g.Cin = Cout;
+  g.sz = Cout; g.sy = (long)Zo * Cout; g.sx = (long)Yo * Zo * Cout; g.sb = (long)Xo * Yo * Zo * Cout;
+  const long M = (long)B * Xi * Yi * Zi;
+  if (M >= 2147483647L) return OCCF_ESHAPE;
+  a.A = dy; a.Wh = wt_hi; a.Wl = wt_lo; a.C = dx;
+  a.M = (int)M; a.N = Cin; a.K = kX * kY * kZ * Cout; a.lda = 0; a.ldc = Cin; a.ldr = Cin; a.act = 0;
   return launch_gemm_b<true>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
 }
 

@@ -1,0 +1,364 @@
+// Weight-gradient contraction ("TN" GEMM) for gfx950: dW[n, tap*Cin + c] = sum_m dY[m, n] * X_tap[m, c]
+// -- the weight gradient of every nn.Linear / 1^3 / 3^3 / dilated / strided convolution of the path
+// (ATen autograd in the reference: occupancyformer.py:132-199 -> loss.backward()).  Optionally also
+// db[n] = sum_m dY[m, n] from the same pass over dY.
+//
+// Both operands are "k-major": the contraction index m (voxels / tokens, up to 680 000) is the SLOW index of
+// the two row-major activations, the fast index is the channel.  v_mfma_f32_32x32x16_bf16 wants 8 consecutive
+// k per lane, so the staging transposes on the way into LDS: a thread loads float4 from RPT consecutive rows,
+// packs ROW PAIRS to bf16x2 (hi and lo halves of the 3-term split) and writes 16 B per pair-row; LDS holds
+// [m / 2][channel] dwords, a fragment is four ds_read_b32 with consecutive lanes on consecutive dwords -- both
+// directions bank-conflict free without padding.
+//
+// Workgroup = 4 waves (2 x 2), tile 128 (n) x BC (c, 128 or 64) of ONE tap, walks 64-row chunks of its M-slice
+// with the next chunk's global loads in flight (issued unconditionally, clamped).  M is split over blockIdx.y
+// into slabs reduced in fixed order (deterministic).  fp32 accumulate; terms = 3: hi*hi + hi*lo + lo*hi.
+#include "occf_common.h"
+#include "../../include/occformer_hip.h"
+
+struct WgGeom {
+  int B, Xo, Yo, Zo, Xi, Yi, Zi, kX, kY, kZ, stride, dil, pad_x, pad_y, pad_z;
+  long sb, sx, sy, sz;
+};
+struct WgArgs {
+  const float* dY;
+  const float* X;
+  float* out;        // [S][N][taps * Cin]
+  float* bias_out;   // [S][N] or NULL
+  long M;
+  int N, Cin, taps;
+  long ldy, ldx;
+  int conv;
+  long rows_per_split;
+  WgGeom g;
+};
+
+typedef uint32_t wg_u4 __attribute__((ext_vector_type(4)));
+
+template <int BC, int TERMS>
+__global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
+  constexpr int TC = BC / 64;                 // 32-wide tiles per wave along c
+  constexpr int QB = BC / 4;                  // channel quads of the X tile
+  constexpr int RPT = 64 * QB / 256;          // rows per thread of the X tile (8 or 4)
+  __shared__ __attribute__((aligned(16))) uint32_t Ah[32 * 128], Al[32 * 128], Bh[32 * BC], Bl[32 * BC];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c_tiles = (p.Cin + BC - 1) / BC;
+  int bx = blockIdx.x;
+  const int ct = bx % c_tiles;
+  bx /= c_tiles;
+  const int tap = bx % p.taps;
+  const int nt = bx / p.taps;
+  const int n0 = nt * 128, c0 = ct * BC;
+  const long m_begin = (long)blockIdx.y * p.rows_per_split;
+  long m_end = m_begin + p.rows_per_split;
+  if (m_end > p.M) m_end = p.M;
+  const int nchunks = m_end > m_begin ? (int)((m_end - m_begin + 63) / 64) : 0;
+
+  // ---- loader roles
+  const int a_c4 = tid & 31, a_rg = tid >> 5;                 // dY: 8 rows x 4 columns per thread
+  const int a_col = n0 + a_c4 * 4;
+  const bool a_col_ok = a_col < p.N;
+  const int b_c4 = tid % QB, b_rg = tid / QB;                 // X: RPT rows x 4 channels per thread
+  const int b_ch = c0 + b_c4 * 4;
+  const bool b_ch_ok = b_ch < p.Cin;
+  int tdx = 0, tdy = 0, tdz = 0;
+  if (p.conv) {
+    tdz = tap % p.g.kZ;
+    tdy = (tap / p.g.kZ) % p.g.kY;
+    tdx = tap / (p.g.kZ * p.g.kY);
+  }
+
+  float4 ra[8], rb[RPT];
+  auto load_chunk = [&](int ck) __attribute__((always_inline)) {
+    const long mb = m_begin + (long)ck * 64;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      long m = mb + a_rg * 8 + j;
+      const bool ok = m < m_end && a_col_ok;
+      if (m >= p.M) m = p.M - 1;
+      const float4 v = *(const float4*)(p.dY + m * p.ldy + (a_col_ok ? a_col : 0));
+      ra[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (p.conv) {
+      long m = mb + b_rg * RPT;
+      if (m >= p.M) m = p.M - 1;
+      int zo = (int)(m % p.g.Zo);
+      long t = m / p.g.Zo;
+      int yo = (int)(t % p.g.Yo);
+      t /= p.g.Yo;
+      int xo = (int)(t % p.g.Xo);
+      long b = t / p.g.Xo;
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        const int xi = xo * p.g.stride - p.g.pad_x + tdx * p.g.dil, yi = yo * p.g.stride - p.g.pad_y + tdy * p.g.dil,
+                  zi = zo * p.g.stride - p.g.pad_z + tdz * p.g.dil;
+        const bool ok = b_ch_ok && xi >= 0 && xi < p.g.Xi && yi >= 0 && yi < p.g.Yi && zi >= 0 && zi < p.g.Zi;
+        const int xc = occf_clampi(xi, p.g.Xi - 1), yc = occf_clampi(yi, p.g.Yi - 1), zc = occf_clampi(zi, p.g.Zi - 1);
+        const long bc = b < p.g.B ? b : p.g.B - 1;
+        const float4 v = *(const float4*)(p.X + bc * p.g.sb + xc * p.g.sx + yc * p.g.sy + zc * p.g.sz +
+                                          (b_ch_ok ? b_ch : 0));
+        rb[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        // next output voxel (rows beyond M carry zero dY rows; their batch index is clamped at the address)
+        if (++zo == p.g.Zo) {
+          zo = 0;
+          if (++yo == p.g.Yo) {
+            yo = 0;
+            if (++xo == p.g.Xo) {
+              xo = 0;
+              ++b;
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < RPT; ++j) {
+        long m = mb + b_rg * RPT + j;
+        if (m >= p.M) m = p.M - 1;
+        const float4 v = *(const float4*)(p.X + m * p.ldx + (b_ch_ok ? b_ch : 0));
+        rb[j] = b_ch_ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = p.bias_out != nullptr && tap == 0 && ct == 0;
+  auto store_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      wg_u4 h, l;
+      uint32_t hh, ll;
+      occf_bf16_split2(ra[j].x, ra[j + 1].x, hh, ll); h.x = hh; l.x = ll;
+      occf_bf16_split2(ra[j].y, ra[j + 1].y, hh, ll); h.y = hh; l.y = ll;
+      occf_bf16_split2(ra[j].z, ra[j + 1].z, hh, ll); h.z = hh; l.z = ll;
+      occf_bf16_split2(ra[j].w, ra[j + 1].w, hh, ll); h.w = hh; l.w = ll;
+      const int off = (a_rg * 4 + (j >> 1)) * 128 + a_c4 * 4;
+      *(wg_u4*)(Ah + off) = h;
+      if (TERMS == 3) *(wg_u4*)(Al + off) = l;
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { bsum[0] += ra[j].x; bsum[1] += ra[j].y; bsum[2] += ra[j].z; bsum[3] += ra[j].w; }
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; j += 2) {
+      wg_u4 h, l;
+      uint32_t hh, ll;
+      occf_bf16_split2(rb[j].x, rb[j + 1].x, hh, ll); h.x = hh; l.x = ll;
+      occf_bf16_split2(rb[j].y, rb[j + 1].y, hh, ll); h.y = hh; l.y = ll;
+      occf_bf16_split2(rb[j].z, rb[j + 1].z, hh, ll); h.z = hh; l.z = ll;
+      occf_bf16_split2(rb[j].w, rb[j + 1].w, hh, ll); h.w = hh; l.w = ll;
+      const int off = (b_rg * (RPT / 2) + (j >> 1)) * BC + b_c4 * 4;
+      *(wg_u4*)(Bh + off) = h;
+      if (TERMS == 3) *(wg_u4*)(Bl + off) = l;
+    }
+  };
+
+  f32x16 acc[2][TC];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TC; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int li = lane & 31, lk = lane >> 5;
+  auto frag = [&](const uint32_t* base, int ld, int col, int ks) __attribute__((always_inline)) -> bf16x8 {
+    const uint32_t* q = base + (ks * 8 + lk * 4) * ld + col;
+    wg_u4 v;
+    v.x = q[0];
+    v.y = q[ld];
+    v.z = q[2 * ld];
+    v.w = q[3 * ld];
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto compute = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 ah[2], al[2], bh[TC], bl[TC];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = frag(Ah, 128, wm * 64 + i * 32 + li, ks);
+        if (TERMS == 3) al[i] = frag(Al, 128, wm * 64 + i * 32 + li, ks);
+      }
+#pragma unroll
+      for (int j = 0; j < TC; ++j) {
+        bh[j] = frag(Bh, BC, wn * (BC / 2) + j * 32 + li, ks);
+        if (TERMS == 3) bl[j] = frag(Bl, BC, wn * (BC / 2) + j * 32 + li, ks);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TC; ++j) {
+          if (TERMS == 3) {
+            acc[i][j] = occf_mfma_bf16_32x32x16(al[i], bh[j], acc[i][j]);
+            acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bl[j], acc[i][j]);
+          }
+          acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bh[j], acc[i][j]);
+        }
+    }
+  };
+
+  if (nchunks > 0) load_chunk(0);
+  for (int ck = 0; ck < nchunks; ++ck) {
+    if (ck > 0) __syncthreads();              // previous chunk's fragment reads are done
+    store_chunk();
+    __syncthreads();
+    load_chunk(ck + 1 < nchunks ? ck + 1 : ck);   // unconditional (the last one re-reads its own chunk)
+    compute();
+  }
+
+  // ---- epilogue: raw partial sums of this M-slice
+  const int Kt = p.taps * p.Cin;
+  float* o = p.out + (long)blockIdx.y * p.N * Kt;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+      const int c = c0 + wn * (BC / 2) + j * 32 + li;
+      if (c >= p.Cin) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (n < p.N) o[(long)n * Kt + (long)tap * p.Cin + c] = acc[i][j][r];
+      }
+    }
+  if (do_bias) {
+    __syncthreads();
+    float* red = (float*)Ah;                   // [8 row groups][128 columns]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[a_rg * 128 + a_c4 * 4 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 128 && n0 + tid < p.N) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) s += red[r * 128 + tid];
+      p.bias_out[(long)blockIdx.y * p.N + n0 + tid] = s;
+    }
+  }
+}
+
+// out[i] = sum_s slab[s][i]  (fixed order)
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                           long n, int S) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += slab[(long)s * n + i];
+  out[i] = v;
+}
+
+// small problems (M <= 1024 rows, or shapes the tile kernel does not take): one thread per output, exact fp32
+__global__ void __launch_bounds__(256) wgrad_small_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                          float* __restrict__ dW, float* __restrict__ db, long M, int N,
+                                                          int K, long ldy, long ldx) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < (long)N * K) {
+    const int n = (int)(gid / K), k = (int)(gid % K);
+    float s = 0.f;
+    for (long m = 0; m < M; ++m) s = fmaf(dY[m * ldy + n], X[m * ldx + k], s);
+    dW[gid] = s;
+  }
+  if (db && gid < N) {
+    float s = 0.f;
+    for (long m = 0; m < M; ++m) s += dY[m * ldy + gid];
+    db[gid] = s;
+  }
+}
+
+static int wg_pick_splits(long M, int N, int Cin, int taps, int BC) {
+  const long tiles = (long)occf_cdiv(N, 128) * occf_cdiv(Cin, BC) * taps;
+  const long chunks = (M + 63) / 64;
+  long S = (1024 + tiles - 1) / tiles;
+  if (S > chunks / 4) S = chunks / 4;
+  if (S < 1) S = 1;
+  if (S > 256) S = 256;
+  return (int)S;
+}
+static int wg_bc(int Cin) { return Cin % 128 == 0 ? 128 : 64; }
+
+static long wg_workspace(long M, int N, int Cin, int taps) {
+  const int S = wg_pick_splits(M, N, Cin, taps, wg_bc(Cin));
+  return S > 1 ? (long)S * N * ((long)taps * Cin + 1) : 0;
+}
+
+static int wg_launch(WgArgs a, float* dW, float* db, float* workspace, long workspace_floats, int terms, hipStream_t st) {
+  const int BC = wg_bc(a.Cin);
+  int S = wg_pick_splits(a.M, a.N, a.Cin, a.taps, BC);
+  const long Kt = (long)a.taps * a.Cin;
+  while (S > 1 && (long)S * a.N * (Kt + 1) > workspace_floats) --S;
+  if (S > 1 && !workspace) S = 1;
+  long rows = (a.M + S - 1) / S;
+  rows = (rows + 63) / 64 * 64;
+  S = (int)((a.M + rows - 1) / rows);
+  a.rows_per_split = rows;
+  a.out = S > 1 ? workspace : dW;
+  a.bias_out = db ? (S > 1 ? workspace + (long)S * a.N * Kt : db) : nullptr;
+  const dim3 grid((unsigned)((long)occf_cdiv(a.N, 128) * occf_cdiv(a.Cin, BC) * a.taps), S);
+  if (BC == 128) {
+    if (terms == 3) hipLaunchKernelGGL((wgrad_kernel<128, 3>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<128, 1>), grid, dim3(256), 0, st, a);
+  } else {
+    if (terms == 3) hipLaunchKernelGGL((wgrad_kernel<64, 3>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<64, 1>), grid, dim3(256), 0, st, a);
+  }
+  if (S > 1) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(occf_cdiv((long)a.N * Kt, 256)), dim3(256), 0, st, workspace, dW,
+                       (long)a.N * Kt, S);
+    if (db)
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(occf_cdiv(a.N, 256)), dim3(256), 0, st, a.bias_out, db, (long)a.N, S);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" long occf_linear_wgrad_workspace(long M, int N, int K) {
+  if (M <= 1024 || N % 4 || K % 4) return 0;
+  return wg_workspace(M, N, K, 1);
+}
+
+extern "C" int occf_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias, float* workspace,
+                                 long workspace_floats, long M, int N, int K, long ldy, long ldx, int terms,
+                                 void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return OCCF_EINVAL;
+  if (terms != 1 && terms != 3) return OCCF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (M <= 1024 || N % 4 || K % 4 || ldy % 4 || ldx % 4) {
+    if (M > 65536) return OCCF_ESHAPE;
+    const long total = (long)N * K > N ? (long)N * K : N;
+    hipLaunchKernelGGL(wgrad_small_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, dy, x, dw, dbias, M, N, K,
+                       ldy, ldx);
+    return (int)hipGetLastError();
+  }
+  WgArgs a = {};
+  a.dY = dy; a.X = x; a.M = M; a.N = N; a.Cin = K; a.taps = 1; a.ldy = ldy; a.ldx = ldx; a.conv = 0;
+  return wg_launch(a, dw, dbias, workspace, workspace_floats, terms, st);
+}
+
+extern "C" long occf_conv3d_wgrad_workspace(int B, int Xi, int Yi, int Zi, int Cin, int Cout, int kX, int kY, int kZ,
+                                            int stride, int dil, int pad_x, int pad_y, int pad_z) {
+  const int Xo = (Xi + 2 * pad_x - dil * (kX - 1) - 1) / stride + 1;
+  const int Yo = (Yi + 2 * pad_y - dil * (kY - 1) - 1) / stride + 1;
+  const int Zo = (Zi + 2 * pad_z - dil * (kZ - 1) - 1) / stride + 1;
+  return wg_workspace((long)B * Xo * Yo * Zo, Cout, Cin, kX * kY * kZ);
+}
+
+extern "C" int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapmajor, float* dbias, float* workspace,
+                                 long workspace_floats, int B, int Xi, int Yi, int Zi, int Cin, int Cout, int kX,
+                                 int kY, int kZ, int stride, int dil, int pad_x, int pad_y, int pad_z, long in_sb,
+                                 long in_sx, long in_sy, long in_sz, int terms, void* stream) {
+  if (B <= 0 || Cin % 4 || Cout % 4 || stride <= 0 || dil <= 0) return OCCF_ESHAPE;
+  if (in_sb % 4 || in_sx % 4 || in_sy % 4 || in_sz % 4) return OCCF_ESHAPE;
+  if (terms != 1 && terms != 3) return OCCF_EINVAL;
+  WgArgs a = {};
+  WgGeom& g = a.g;
+  g.B = B; g.Xi = Xi; g.Yi = Yi; g.Zi = Zi; g.kX = kX; g.kY = kY; g.kZ = kZ; g.stride = stride; g.dil = dil;
+  g.pad_x = pad_x; g.pad_y = pad_y; g.pad_z = pad_z;
+  g.Xo = (Xi + 2 * pad_x - dil * (kX - 1) - 1) / stride + 1;
+  g.Yo = (Yi + 2 * pad_y - dil * (kY - 1) - 1) / stride + 1;
+  g.Zo = (Zi + 2 * pad_z - dil * (kZ - 1) - 1) / stride + 1;
+  g.sb = in_sb; g.sx = in_sx; g.sy = in_sy; g.sz = in_sz;
+  if (g.Xo <= 0 || g.Yo <= 0 || g.Zo <= 0) return OCCF_ESHAPE;
+  a.dY = dy; a.X = x; a.M = (long)B * g.Xo * g.Yo * g.Zo; a.N = Cout; a.Cin = Cin; a.taps = kX * kY * kZ;
+  a.ldy = Cout; a.ldx = 0; a.conv = 1;
+  return wg_launch(a, dw_tapmajor, dbias, workspace, workspace_floats, terms, (hipStream_t)stream);
+}

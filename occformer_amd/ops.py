@@ -527,6 +527,186 @@ class HipOps:
                    self._stream())
         return match, assigned
 
+
+    # ------------------------------------------------------------------ backward kernels (training step)
+    def _ws(self, n, device):
+        return torch.empty((max(int(n), 1),), dtype=self.f32, device=device)
+
+    def colsum(self, x2):
+        """x2 [M, N] (unit column stride) -> [N] column sums (bias gradients)"""
+        M, N = x2.shape
+        out = torch.empty((N,), dtype=self.f32, device=x2.device)
+        ws = self._ws(self.lib.occf_colsum_workspace(M, N), x2.device)
+        if x2.stride(1) != 1:
+            raise OccfError("colsum: rows must be channel-contiguous")
+        self._call("occf_colsum", ctypes.c_void_p(x2.data_ptr()), self._ptr(out), self._ptr(ws), M, N, x2.stride(0),
+                   self._stream())
+        return out
+
+    def layernorm_backward(self, x, gamma, dy, eps=1e-5):
+        C = x.shape[-1]
+        M = x.numel() // C
+        dx = torch.empty_like(x)
+        dg = torch.empty((C,), dtype=self.f32, device=x.device)
+        db = torch.empty((C,), dtype=self.f32, device=x.device)
+        ws = self._ws(self.lib.occf_layernorm_bwd_workspace(M, C), x.device)
+        self._call("occf_layernorm_bwd", self._ptr(x, self.f32), self._ptr(gamma, self.f32), self._ptr(dy, self.f32),
+                   self._ptr(dx), self._ptr(dg), self._ptr(db), self._ptr(ws), M, C, float(eps), self._stream())
+        return dx, dg, db
+
+    def groupnorm_backward(self, x_cl, stats, gamma, beta, dy, groups, relu=False, tokens=False, want_residual=False):
+        """backward of groupnorm_apply -> (dx, dgamma, dbeta, dresidual or None)"""
+        B, C, Z = x_cl.shape[0], x_cl.shape[-1], x_cl.shape[-2]
+        P = x_cl.numel() // (B * C * Z)
+        dx = torch.empty_like(x_cl)
+        dg = torch.empty((C,), dtype=self.f32, device=x_cl.device)
+        db = torch.empty((C,), dtype=self.f32, device=x_cl.device)
+        dres = torch.empty_like(x_cl) if want_residual else None
+        ws = self._ws(self.lib.occf_groupnorm_bwd_workspace(B, P * Z, C, groups), x_cl.device)
+        if dy.numel() != B * P * (Z + 1 if tokens else Z) * C:
+            raise OccfError("groupnorm_backward: dy has the wrong size")
+        self._call("occf_groupnorm_bwd", self._ptr(x_cl, self.f32), self._ptr(stats, self.f32),
+                   self._ptr(gamma, self.f32), self._ptr(beta, self.f32), self._ptr(dy, self.f32), self._ptr(dx),
+                   self._ptr(dg), self._ptr(db), self._ptr(dres), self._ptr(ws), B, P, Z, C, groups, int(relu),
+                   int(tokens), self._stream())
+        return dx, dg, db, dres
+
+    def act_forward(self, x, act):
+        y = torch.empty_like(x)
+        self._call("occf_act_fwd", self._ptr(x, self.f32), self._ptr(y), x.numel(), int(act), self._stream())
+        return y
+
+    def act_backward(self, x, dy, act):
+        dx = torch.empty_like(x)
+        self._call("occf_act_bwd", self._ptr(x, self.f32), self._ptr(dy, self.f32), self._ptr(dx), x.numel(), int(act),
+                   self._stream())
+        return dx
+
+    def droppath(self, identity, branch, scale, XY, S):
+        """out = identity + branch * scale[b*S + s] for token rows ((b*XY + xy)*S + s); identity may be None"""
+        C = branch.shape[-1]
+        out = torch.empty_like(branch)
+        self._call("occf_droppath", self._ptr(identity), self._ptr(branch, self.f32), self._ptr(scale, self.f32),
+                   self._ptr(out), branch.numel() // C, C, int(XY), int(S), self._stream())
+        return out
+
+    def dualpath_combine_backward(self, tokens, bev, w, b, dout):
+        B, X, Y, Zs, C = tokens.shape
+        BP = B * X * Y
+        dtok = torch.empty_like(tokens)
+        dbev = torch.empty((B, X, Y, C), dtype=self.f32, device=tokens.device)
+        dw = torch.empty((C,), dtype=self.f32, device=tokens.device)
+        dbias = torch.empty((1,), dtype=self.f32, device=tokens.device)
+        ws = self._ws(self.lib.occf_dualpath_combine_bwd_workspace(BP, C), tokens.device)
+        self._call("occf_dualpath_combine_bwd", self._ptr(tokens, self.f32), self._ptr(bev, self.f32),
+                   self._ptr(w, self.f32), self._ptr(b), self._ptr(dout, self.f32), self._ptr(dtok), self._ptr(dbev),
+                   self._ptr(dw), self._ptr(dbias), self._ptr(ws), BP, Zs - 1, C, self._stream())
+        return dtok, dbev, dw, dbias
+
+    def upsample_add_backward(self, dout, coarse_shape):
+        B, X, Y, Z, C = coarse_shape
+        _, X2, Y2, Z2, _ = dout.shape
+        dc = torch.empty(tuple(coarse_shape), dtype=self.f32, device=dout.device)
+        self._call("occf_upsample_add_bwd", self._ptr(dout, self.f32), self._ptr(dc), B, X, Y, Z, X2, Y2, Z2, C,
+                   self._stream())
+        return dc
+
+    def point_sample_3d_backward(self, dout, pts, vol_shape, align_corners=False, padding_mode="zeros"):
+        N, C, X, Y, Z = vol_shape
+        P = pts.shape[1]
+        shared = pts.shape[0] == 1 and N > 1
+        dvol = torch.zeros(tuple(vol_shape), dtype=self.f32, device=dout.device)
+        self._call("occf_point_sample_3d_bwd", self._ptr(dout, self.f32), self._ptr(pts, self.f32), self._ptr(dvol),
+                   N, C, X, Y, Z, P, int(shared), int(align_corners), int(padding_mode == "border"), self._stream())
+        return dvol
+
+    def point_loss_rows_backward(self, logits, targets, grad_rows):
+        R, P = logits.shape
+        dx = torch.empty_like(logits)
+        self._call("occf_point_loss_rows_bwd", self._ptr(logits, self.f32), self._ptr(targets, self.f32),
+                   self._ptr(grad_rows, self.f32), self._ptr(dx), R, P, self._stream())
+        return dx
+
+    def _grad_terms(self):
+        return 1 if self.precision == "bf16" else 3
+
+    def linear_wgrad(self, dy2, x2, want_bias=True):
+        """dy2 [M, N], x2 [M, K] (unit column strides) -> (dW [N, K], db [N] or None)"""
+        M, N = dy2.shape
+        K = x2.shape[1]
+        if x2.shape[0] != M or dy2.stride(1) != 1 or x2.stride(1) != 1:
+            raise OccfError("linear_wgrad: row-major operands with equal row counts expected")
+        dw = torch.empty((N, K), dtype=self.f32, device=x2.device)
+        db = torch.empty((N,), dtype=self.f32, device=x2.device) if want_bias else None
+        need = self.lib.occf_linear_wgrad_workspace(M, N, K)
+        ws = self._ws(need, x2.device)
+        self.last_flops = 2 * M * N * K
+        self._call("occf_linear_wgrad", ctypes.c_void_p(dy2.data_ptr()), ctypes.c_void_p(x2.data_ptr()),
+                   self._ptr(dw), self._ptr(db), self._ptr(ws), need, M, N, K, dy2.stride(0), x2.stride(0),
+                   self._grad_terms(), self._stream())
+        return dw, db
+
+    def conv3d_wgrad(self, dy, x_cl, ksize, stride=1, dil=1, pad=None, want_bias=False):
+        """dy [B, Xo, Yo, Zo, Cout] contiguous, x_cl [B, Xi, Yi, Zi, Cin] (unit channel stride)
+        -> (dW tap-major [Cout, taps*Cin], db or None)"""
+        B, Xi, Yi, Zi, Cin = x_cl.shape
+        Cout = dy.shape[-1]
+        kX, kY, kZ = ksize
+        if pad is None:
+            pad = tuple(dil * (k - 1) // 2 for k in ksize)
+        dw = torch.empty((Cout, kX * kY * kZ * Cin), dtype=self.f32, device=dy.device)
+        db = torch.empty((Cout,), dtype=self.f32, device=dy.device) if want_bias else None
+        geom = (B, Xi, Yi, Zi, Cin, Cout, kX, kY, kZ, int(stride), int(dil), pad[0], pad[1], pad[2])
+        need = self.lib.occf_conv3d_wgrad_workspace(*geom)
+        ws = self._ws(need, dy.device)
+        self.last_flops = 2 * dy.numel() * kX * kY * kZ * Cin
+        self._call("occf_conv3d_wgrad", self._ptr(dy, self.f32), ctypes.c_void_p(x_cl.data_ptr()), self._ptr(dw),
+                   self._ptr(db), self._ptr(ws), need, *geom, x_cl.stride(0), x_cl.stride(1), x_cl.stride(2),
+                   x_cl.stride(3), self._grad_terms(), self._stream())
+        return dw, db
+
+    def conv3d_dgrad(self, dy, wt_split, in_shape, ksize, stride=1, dil=1, pad=None):
+        """dy [B, Xo, Yo, Zo, Cout] contiguous; wt_split = (hi, lo) of the weight as [Cin, taps*Cout]
+        -> dx [B, Xi, Yi, Zi, Cin]"""
+        B, Xi, Yi, Zi, Cin = in_shape
+        Cout = dy.shape[-1]
+        kX, kY, kZ = ksize
+        if pad is None:
+            pad = tuple(dil * (k - 1) // 2 for k in ksize)
+        dx = torch.empty(tuple(in_shape), dtype=self.f32, device=dy.device)
+        K = kX * kY * kZ * Cout
+        ws, nws = self._splitk_workspace(B * Xi * Yi * Zi, Cin, K, dy.device)
+        self.last_flops = 2 * B * Xi * Yi * Zi * Cin * K
+        self._call("occf_conv3d_bf16_dgrad", self._ptr(dy, self.f32), self._ptr(wt_split[0]), self._ptr(wt_split[1]),
+                   self._ptr(dx), B, Xi, Yi, Zi, Cin, Cout, kX, kY, kZ, int(stride), int(dil), pad[0], pad[1], pad[2],
+                   self._grad_terms(), self._ptr(ws), nws, self._stream())
+        return dx
+
+    def window_attention_backward(self, qkv, qkv_bias, bias_table, attn_out, dout, B, X, Y, S, heads, shift):
+        """-> (dqkv [n_tok, 3C], dqkv_bias_pad [3C] (padded-token part only), dbias_table [169, heads])"""
+        C = qkv.shape[1] // 3
+        dqkv = torch.empty_like(qkv)
+        dpad = torch.zeros((3 * C,), dtype=self.f32, device=qkv.device)
+        dtab = torch.empty_like(bias_table)
+        ws = self._ws(self.lib.occf_window_attn_bwd_workspace(B, X, Y, S, heads), qkv.device)
+        self._call("occf_window_attn_bwd", self._ptr(qkv, self.f32), self._ptr(qkv_bias, self.f32),
+                   self._ptr(bias_table, self.f32), self._ptr(attn_out, self.f32), self._ptr(dout, self.f32),
+                   self._ptr(dqkv), self._ptr(dpad), self._ptr(dtab), self._ptr(ws), B, X, Y, S, C, heads, int(shift),
+                   self._stream())
+        return dqkv, dpad, dtab
+
+    def masked_attention_backward(self, q, k, v, heads, out, dout, blocked=None, row_open=None):
+        B, Q, E = q.shape
+        L = k.shape[1]
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        ws = self._ws(self.lib.occf_masked_xattn_bwd_workspace(B, Q, L, heads), q.device)
+        self._call("occf_masked_xattn_bwd", self._ptr(q, self.f32), self._ptr(k, self.f32), self._ptr(v, self.f32),
+                   self._ptr(blocked, torch.uint8), self._ptr(row_open, self.i32), self._ptr(out, self.f32),
+                   self._ptr(dout, self.f32), self._ptr(dq), self._ptr(dk), self._ptr(dv), self._ptr(ws), B, Q, L, E,
+                   heads, self._stream())
+        return dq, dk, dv
+
+
 _ops = None
 
 

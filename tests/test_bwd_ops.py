@@ -1,0 +1,259 @@
+"""Backward kernels (csrc/bwd_elem.hip, wgrad.hip, attn_bwd.hip, msda3d.hip, dcn.hip) through the C ABI against
+torch.autograd of the plain fp32 PyTorch formulation of the same op (the reference's training step is ATen autograd
+through exactly these ops).  'emu' = host emulation of the same kernel sources (CPU), 'hip' = the real library."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import paramgen
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+def _t(key, shape, seed=0, scale=1.0):
+    return paramgen.tensor(key, shape, seed, scale)
+
+
+def test_colsum(be):
+    for M, N in ((1000, 192), (37, 18), (5000, 1536)):
+        x = _t("cs", (M, N), M)
+        out = be.ops.colsum(be.to(x)).cpu()
+        assert _rel(out, x.sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("C", [128, 192, 96, 1024])
+def test_layernorm_backward(be, C):
+    M = 333
+    x = _t("ln_x", (M, C), C).requires_grad_()
+    g = (_t("ln_g", (C,), C) * 0.2 + 1).requires_grad_()
+    b = _t("ln_b", (C,), C + 1).requires_grad_()
+    dy = _t("ln_dy", (M, C), C + 2)
+    F.layer_norm(x, (C,), g, b, 1e-5).backward(dy)
+    dx, dg, db = be.ops.layernorm_backward(*be.to(x.detach(), g.detach(), dy), 1e-5)
+    assert _rel(dx.cpu(), x.grad) < 1e-4 and _rel(dg.cpu(), g.grad) < 1e-4 and _rel(db.cpu(), b.grad) < 1e-4
+
+
+@pytest.mark.parametrize("relu,tokens,res", [(True, True, False), (False, False, False), (True, False, True),
+                                             (False, False, True)])
+def test_groupnorm_backward(be, relu, tokens, res):
+    B, X, Y, Z, C, G = 2, 5, 6, 4, 64, 8
+    x = _t("gn_x", (B, X, Y, Z, C), 3).requires_grad_()
+    g = (_t("gn_g", (C,), 4) * 0.2 + 1).requires_grad_()
+    b = (_t("gn_b", (C,), 5) * 0.3).requires_grad_()
+    r = _t("gn_r", (B, X, Y, Z, C), 6).requires_grad_() if res else None
+    y = F.group_norm(x.permute(0, 4, 1, 2, 3), G, g, b, 1e-5).permute(0, 2, 3, 4, 1)
+    if relu:
+        y = F.relu(y)
+    if res:
+        y = y + r
+    if tokens:
+        y = torch.cat((y, y.mean(3, keepdim=True)), 3)
+    dy = _t("gn_dy", tuple(y.shape), 7)
+    y.backward(dy)
+    xd, gd, bd, dyd = be.to(x.detach().contiguous(), g.detach(), b.detach(), dy.contiguous())
+    stats = be.ops.groupnorm_stats(xd, G, 1e-5)
+    # forward consistency of the op under test
+    out = be.ops.groupnorm_apply(xd, stats, gd, bd, G, relu, tokens, None if r is None else be.to(r.detach()))
+    assert _rel(out.cpu(), y.detach()) < 1e-4
+    dx, dg, db, dres = be.ops.groupnorm_backward(xd, stats, gd, bd, dyd, G, relu, tokens, want_residual=res)
+    assert _rel(dx.cpu(), x.grad) < 2e-4
+    assert _rel(dg.cpu(), g.grad) < 2e-4 and _rel(db.cpu(), b.grad) < 2e-4
+    if res:
+        assert _rel(dres.cpu(), r.grad) < 1e-5
+
+
+@pytest.mark.parametrize("act", [1, 2])
+def test_activation(be, act):
+    x = _t("act_x", (50, 64), act, 2.0).requires_grad_()
+    dy = _t("act_dy", (50, 64), act + 5)
+    y = F.relu(x) if act == 1 else F.gelu(x)
+    y.backward(dy)
+    assert _rel(be.ops.act_forward(be.to(x.detach()), act).cpu(), y.detach()) < 1e-5
+    assert _rel(be.ops.act_backward(*be.to(x.detach(), dy), act).cpu(), x.grad) < 1e-5
+
+
+def test_droppath(be):
+    B, X, Y, S, C = 2, 3, 4, 5, 32
+    ident = _t("dp_i", (B, X, Y, S, C), 1)
+    br = _t("dp_b", (B, X, Y, S, C), 2)
+    keep = (paramgen.uniform("dp_k", (B, S), 3) < 0.7).float() / 0.7
+    ref = ident + br * keep.view(B, 1, 1, S, 1)
+    out = be.ops.droppath(*be.to(ident, br, keep.reshape(-1).contiguous()), X * Y, S)
+    assert _rel(out.cpu(), ref) < 1e-6
+    out = be.ops.droppath(None, *be.to(br, keep.reshape(-1).contiguous()), X * Y, S)
+    assert _rel(out.cpu(), br * keep.view(B, 1, 1, S, 1)) < 1e-6
+
+
+@pytest.mark.parametrize("C,bias", [(64, True), (192, False)])
+def test_dualpath_combine_backward(be, C, bias):
+    B, X, Y, Z = 2, 3, 5, 4
+    tok = _t("dc_t", (B, X, Y, Z + 1, C), 1).requires_grad_()
+    bev = _t("dc_b", (B, X, Y, C), 2).requires_grad_()
+    w = (_t("dc_w", (C,), 3) * 0.2).requires_grad_()
+    b = (_t("dc_bias", (1,), 4)).requires_grad_() if bias else None
+    ident = _t("dc_i", (B, X, Y, Z, C), 5)
+    s = (tok[:, :, :, :Z] * w).sum(-1, keepdim=True) + (b if bias else 0)
+    out = tok[:, :, :, :Z] + torch.sigmoid(s) * bev.unsqueeze(3) + ident
+    dout = _t("dc_do", tuple(out.shape), 6)
+    out.backward(dout)
+    args = be.to(tok.detach(), bev.detach(), w.detach())
+    fwd = be.ops.dualpath_combine(*args, None if b is None else be.to(b.detach()), be.to(ident))
+    assert _rel(fwd.cpu(), out.detach()) < 1e-5
+    dtok, dbev, dw, db = be.ops.dualpath_combine_backward(*args, None if b is None else be.to(b.detach()), be.to(dout))
+    assert _rel(dtok.cpu(), tok.grad) < 1e-4 and _rel(dbev.cpu(), bev.grad) < 1e-4
+    assert _rel(dw.cpu(), w.grad) < 1e-4
+    if bias:
+        assert _rel(db.cpu(), b.grad) < 1e-4
+    assert float(dtok[:, :, :, Z].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape,shape2", [((4, 5, 2), (8, 10, 4)), ((3, 4, 2), (7, 9, 5)), ((2, 2, 1), (4, 4, 2))])
+def test_upsample_add_backward(be, shape, shape2):
+    B, C = 2, 8
+    coarse = _t("ua_c", (B, C, *shape), 1).requires_grad_()
+    out = F.interpolate(coarse, size=shape2, mode="trilinear", align_corners=False)
+    dout = _t("ua_do", (B, *shape2, C), 2)
+    out.backward(dout.permute(0, 4, 1, 2, 3))
+    dc = be.ops.upsample_add_backward(be.to(dout), (B, *shape, C))
+    assert _rel(dc.cpu(), coarse.grad.permute(0, 2, 3, 4, 1)) < 1e-5
+
+
+@pytest.mark.parametrize("align,mode,shared", [(False, "border", False), (True, "zeros", False), (False, "zeros", True)])
+def test_point_sample_backward(be, align, mode, shared):
+    N, C, X, Y, Z, P = 3, 2, 6, 5, 4, 200
+    vol = _t("ps_v", (N, C, X, Y, Z), 1).requires_grad_()
+    pts = paramgen.uniform("ps_p", (1 if shared else N, P, 3), 2) * 1.2 - 0.1
+    grid = (pts * 2 - 1).view(pts.shape[0], P, 1, 1, 3).expand(N, P, 1, 1, 3)
+    out = F.grid_sample(vol, grid, mode="bilinear", padding_mode=mode, align_corners=align).view(N, C, P)
+    dout = _t("ps_do", (N, C, P), 3)
+    out.backward(dout)
+    fwd = be.ops.point_sample_3d(be.to(vol.detach()), be.to(pts.contiguous()), align, mode)
+    assert _rel(fwd.cpu(), out.detach()) < 1e-5
+    dv = be.ops.point_sample_3d_backward(be.to(dout), be.to(pts.contiguous()), (N, C, X, Y, Z), align, mode)
+    assert _rel(dv.cpu(), vol.grad) < 1e-4
+
+
+def test_point_loss_rows_backward(be):
+    R, P = 5, 300
+    x = _t("pl_x", (R, P), 1, 2.0).requires_grad_()
+    t = (paramgen.uniform("pl_t", (R, P), 2) < 0.3).float()
+    s = x.sigmoid()
+    rows = torch.stack((F.binary_cross_entropy_with_logits(x, t, reduction="none").sum(1), (s * t).sum(1), s.sum(1),
+                        t.sum(1)), 1)
+    g = _t("pl_g", (R, 4), 3)
+    rows.backward(g)
+    assert _rel(be.ops.point_loss_rows(*be.to(x.detach(), t)).cpu(), rows.detach()) < 1e-5
+    dx = be.ops.point_loss_rows_backward(*be.to(x.detach(), t, g))
+    assert _rel(dx.cpu(), x.grad) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(1500, 192, 128), (2100, 128, 384), (4000, 96, 192), (100, 18, 192), (1300, 288, 64)])
+def test_linear_wgrad(be, M, N, K):
+    dy = _t("wg_dy", (M, N), M)
+    x = _t("wg_x", (M, K), M + 1)
+    dw, db = be.ops.linear_wgrad(*be.to(dy, x))
+    assert _rel(dw.cpu(), dy.t() @ x) < 1e-4
+    assert _rel(db.cpu(), dy.sum(0)) < 1e-4
+
+
+def test_linear_wgrad_strided(be):
+    """operands that are column blocks of wider matrices (row stride > width)"""
+    M, N, K = 1200, 64, 128
+    dyw = _t("wgs_dy", (M, 2 * N), 1)
+    xw = _t("wgs_x", (M, 3 * K), 2)
+    dw, db = be.ops.linear_wgrad(be.to(dyw)[:, N:], be.to(xw)[:, K:2 * K])
+    assert _rel(dw.cpu(), dyw[:, N:].t() @ xw[:, K:2 * K]) < 1e-4 and _rel(db.cpu(), dyw[:, N:].sum(0)) < 1e-4
+
+
+CONV_CASES = [
+    # B, dims, Cin, Cout, k, stride, dil
+    (1, (10, 9, 4), 32, 64, (3, 3, 3), 1, 1),
+    (2, (8, 8, 4), 64, 32, (3, 3, 3), 2, 1),
+    (1, (12, 11, 1), 32, 32, (3, 3, 1), 1, 3),
+    (1, (8, 6, 4), 64, 128, (1, 1, 1), 2, 1),
+    (1, (7, 9, 8), 192, 64, (3, 3, 3), 1, 1),
+]
+
+
+def _conv_ref(x, w, k, stride, dil):
+    pad = tuple(dil * (kk - 1) // 2 for kk in k)
+    return F.conv3d(x, w, stride=stride, dilation=dil, padding=pad)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3d_wgrad_dgrad(be, case):
+    B, dims, Cin, Cout, k, stride, dil = case
+    x = _t("cv_x", (B, Cin, *dims), Cin).requires_grad_()
+    w = (_t("cv_w", (Cout, Cin, *k), Cout) * (Cin * k[0] * k[1] * k[2]) ** -0.5).requires_grad_()
+    y = _conv_ref(x, w, k, stride, dil)
+    dy = _t("cv_dy", tuple(y.shape), 9)
+    y.backward(dy)
+    x_cl = x.detach().permute(0, 2, 3, 4, 1).contiguous()
+    dy_cl = dy.permute(0, 2, 3, 4, 1).contiguous()
+    dw, _ = be.ops.conv3d_wgrad(be.to(dy_cl), be.to(x_cl), k, stride, dil)
+    ref_dw = w.grad.permute(0, 2, 3, 4, 1).reshape(Cout, -1)
+    assert _rel(dw.cpu(), ref_dw) < 1e-4
+    # data gradient: weight re-laid as [Cin, taps * Cout]
+    wt = w.detach().permute(1, 2, 3, 4, 0).reshape(Cin, -1).contiguous()
+    sp = be.ops.split_bf16(be.to(wt))
+    dx = be.ops.conv3d_dgrad(be.to(dy_cl), sp, (B, *dims, Cin), k, stride, dil)
+    assert _rel(dx.cpu(), x.grad.permute(0, 2, 3, 4, 1)) < 1e-4
+
+
+@pytest.mark.parametrize("X,Y,S,heads,shift,B", [(14, 14, 3, 1, 0, 1), (10, 9, 2, 2, 3, 2), (7, 16, 1, 4, 3, 1),
+                                                 (5, 5, 2, 3, 0, 1)])
+def test_window_attention_backward(be, X, Y, S, heads, shift, B):
+    from oracle import occformer_ref as O
+    C = heads * 32
+    wq = paramgen.tensor("wb_qkvw", (3 * C, C), 1, C ** -0.5).requires_grad_()
+    bq = paramgen.tensor("wb_qkvb", (3 * C,), 1, 0.3).requires_grad_()
+    tab = paramgen.tensor("wb_tab", (169, heads), 1, 0.5).requires_grad_()
+    y = paramgen.tensor("wb_tokens", (B * S, X * Y, C), 2).requires_grad_()
+    sd = {"a.w_msa.qkv.weight": wq, "a.w_msa.qkv.bias": bq, "a.w_msa.proj.weight": torch.eye(C),
+          "a.w_msa.proj.bias": torch.zeros(C), "a.w_msa.relative_position_bias_table": tab}
+    ref = O.shift_window_msa(sd, "a.", y, X, Y, heads, shift)            # [(b s), x*y, C]
+    dref = paramgen.tensor("wb_do", tuple(ref.shape), 3)
+    ref.backward(dref)
+    to_k = lambda t: t.view(B, S, X, Y, C).permute(0, 2, 3, 1, 4).reshape(-1, C).contiguous()
+    yk = to_k(y.detach())
+    qkv = F.linear(yk, wq.detach(), bq.detach()).contiguous()
+    args = be.to(qkv, bq.detach(), tab.detach())
+    out = be.ops.window_attention(*args, B, X, Y, S, heads, shift)
+    dqkv, dpad, dtab = be.ops.window_attention_backward(*args, out, be.to(to_k(dref)), B, X, Y, S, heads, shift)
+    dqkv, dpad, dtab = dqkv.cpu(), dpad.cpu(), dtab.cpu()
+    assert _rel(dtab, tab.grad) < 2e-4
+    assert _rel(dqkv @ wq.detach(), to_k(y.grad)) < 2e-4
+    assert _rel(dqkv.t() @ yk, wq.grad) < 2e-4
+    assert _rel(dqkv.sum(0) + dpad, bq.grad) < 2e-4
+    if X % 7 == 0 and Y % 7 == 0:
+        assert float(dpad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("Q,L,heads,masked", [(20, 100, 3, True), (100, 37, 2, True), (100, 100, 6, False),
+                                              (7, 300, 1, True)])
+def test_masked_attention_backward(be, Q, L, heads, masked):
+    B, E = 2, heads * 32
+    q = _t("xb_q", (B, Q, E), 1).requires_grad_()
+    k = _t("xb_k", (B, L, E), 2).requires_grad_()
+    v = _t("xb_v", (B, L, E), 3).requires_grad_()
+    blocked = row_open = None
+    bias = None
+    if masked:
+        blocked = paramgen.uniform("xb_m", (B, Q, L), 4) < 0.6
+        blocked[0, 1] = True                                            # fully blocked row -> unmasked
+        row_open = (~blocked.all(-1)).int().reshape(-1)
+        eff = blocked & ~blocked.all(-1, keepdim=True)
+        bias = torch.zeros(B, 1, Q, L).masked_fill(eff.unsqueeze(1), float("-inf"))
+    sp = lambda t: t.view(B, -1, heads, 32).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q), sp(k), sp(v), attn_mask=bias).transpose(1, 2).reshape(B, Q, E)
+    dout = _t("xb_do", (B, Q, E), 5)
+    ref.backward(dout)
+    a = be.to(q.detach(), k.detach(), v.detach())
+    bl = None if blocked is None else be.to(blocked.to(torch.uint8).contiguous())
+    ro = None if row_open is None else be.to(row_open.contiguous())
+    out = be.ops.masked_attention(*a, heads, bl, ro)
+    assert _rel(out.cpu(), ref.detach()) < 1e-4
+    dq, dk, dv = be.ops.masked_attention_backward(*a, heads, out, be.to(dout), bl, ro)
+    assert _rel(dq.cpu(), q.grad) < 2e-4 and _rel(dk.cpu(), k.grad) < 2e-4 and _rel(dv.cpu(), v.grad) < 2e-4
