@@ -416,6 +416,21 @@ int occf_masked_xattn_bwd(const float* q, const float* k, const float* v, const 
                           const int32_t* row_open, const float* out, const float* dout, float* dq, float* dk,
                           float* dv, float* workspace, int B, int Q, int L, int E, int heads, void* stream);
 
+/* Backward of occf_msda3d_fwd.  dout[B, Nq, heads*head_dim]; dvalue[B, Nq, heads*head_dim] TOKEN-major (whatever
+ * layout `value` has) and ZERO-FILLED by the caller (scatter with float atomics, as F.grid_sample's backward);
+ * doffsets / dlogits in the forward's layouts with their own row strides (0 = dense). */
+int occf_msda3d_bwd(const float* value, const float* sampling_offsets, const float* attn_logits, const float* dout,
+                    float* dvalue, float* doffsets, float* dlogits, const int32_t* level_shapes, int num_levels, int B,
+                    int Nq, int heads, int head_dim, int num_points, int value_head_major, long offsets_ld,
+                    long logits_ld, long doffsets_ld, long dlogits_ld, void* stream);
+
+/* Backward of occf_deform_im2col (mmcv deformable_col2im + deformable_col2im_coord): dcol in the forward's column
+ * layout -> dx[BN, H, W, C] (scatter with float atomics, ZERO-FILLED by the caller) and doffset in conv_offset's
+ * layout (every element written). */
+int occf_deform_col2im(const float* x, const float* offset, const float* dcol, float* dx, float* doffset, int BN,
+                       int H, int W, int C, int K, int stride, int pad, int dil, int groups, int deform_groups,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -69,3 +69,85 @@ extern "C" int occf_deform_im2col(const float* x, const float* offset, float* co
                      offset, col, BN, H, W, C, Ho, Wo, K, stride, pad, dil, groups, deform_groups);
   OCCF_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the deformable im2col (mmcv `deformable_col2im` + `deformable_col2im_coord`): dcol in the forward's
+// column layout -> dx (bilinear scatter, float atomics; ZERO-FILLED by the caller) and doffset[BN, dg*2*K*K, Ho, Wo]
+// (every element written).  One wave per (output pixel, tap, deform group): lanes stride over the channel quads of
+// the group, the two coordinate gradients are wave reductions.
+__global__ void __launch_bounds__(256) deform_col2im_kernel(
+    const float* __restrict__ x, const float* __restrict__ offset, const float* __restrict__ dcol,
+    float* __restrict__ dx, float* __restrict__ doffset, int BN, int H, int W, int C, int Ho, int Wo, int K, int stride,
+    int pad, int dil, int groups, int dgroups) {
+  const int KK = K * K;
+  const int lane = threadIdx.x & 63;
+  const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long total = (long)BN * Ho * Wo * KK * dgroups;
+  if (wid >= total) return;
+  long r = wid;
+  const int dg = (int)(r % dgroups);
+  r /= dgroups;
+  const int t = (int)(r % KK);
+  r /= KK;
+  const int wo = (int)(r % Wo);
+  r /= Wo;
+  const int ho = (int)(r % Ho);
+  const int bn = (int)(r / Ho);
+  const int ky = t / K, kx = t % K;
+  const long obase = (((long)bn * dgroups + dg) * 2 * KK + 2 * t) * Ho * Wo + (long)ho * Wo + wo;
+  const float py = (float)(ho * stride - pad + ky * dil) + offset[obase];
+  const float px = (float)(wo * stride - pad + kx * dil) + offset[obase + (long)Ho * Wo];
+  float gy = 0.f, gx = 0.f;
+  if (py > -1.f && px > -1.f && py < (float)H && px < (float)W) {
+    const float fy = floorf(py), fx = floorf(px);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const float ly = py - fy, lx = px - fx;
+    const int cd = C / dgroups, cpg = C / groups;
+    const long pix = ((long)bn * Ho + ho) * Wo + wo;
+    for (int cq = lane; cq < cd / 4; cq += 64) {
+      const int c = dg * cd + cq * 4;
+      const int g = c / cpg, cg = c - g * cpg;
+      const float4 gc = *(const float4*)(dcol + (pix * groups + g) * KK * cpg + (long)t * cpg + cg);
+      const float* xb = x + (long)bn * H * W * C + c;
+      float* db = dx + (long)bn * H * W * C + c;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const float wy = (k >> 1) ? ly : 1.f - ly, wx = (k & 1) ? lx : 1.f - lx;
+        const float4 v = *(const float4*)(xb + ((long)yy * W + xx) * C);
+        const float dot = (gc.x * v.x + gc.y * v.y) + (gc.z * v.z + gc.w * v.w);
+        gy = fmaf(((k >> 1) ? 1.f : -1.f) * wx, dot, gy);
+        gx = fmaf(((k & 1) ? 1.f : -1.f) * wy, dot, gx);
+        float* d = db + ((long)yy * W + xx) * C;
+        const float wgt = wy * wx;
+        atomicAdd(d + 0, wgt * gc.x);
+        atomicAdd(d + 1, wgt * gc.y);
+        atomicAdd(d + 2, wgt * gc.z);
+        atomicAdd(d + 3, wgt * gc.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    gy += __shfl_xor(gy, o);
+    gx += __shfl_xor(gx, o);
+  }
+  if (lane == 0) {
+    doffset[obase] = gy;
+    doffset[obase + (long)Ho * Wo] = gx;
+  }
+}
+
+extern "C" int occf_deform_col2im(const float* x, const float* offset, const float* dcol, float* dx, float* doffset,
+                                  int BN, int H, int W, int C, int K, int stride, int pad, int dil, int groups,
+                                  int deform_groups, void* stream) {
+  if (BN <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || groups <= 0 || deform_groups <= 0) return OCCF_EINVAL;
+  if (C % groups || C % deform_groups || (C / groups) % 4 || (C / deform_groups) % 4) return OCCF_ESHAPE;
+  const int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  const int Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  const long waves = (long)BN * Ho * Wo * K * K * deform_groups;
+  hipLaunchKernelGGL(deform_col2im_kernel, dim3(occf_cdiv(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     offset, dcol, dx, doffset, BN, H, W, C, Ho, Wo, K, stride, pad, dil, groups, deform_groups);
+  OCCF_LAUNCH_CHECK();
+}

@@ -245,3 +245,182 @@ extern "C" int occf_msda3d_fwd(const float* value, const float* sampling_offsets
   }
   OCCF_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of the sampling core (ATen autograd through softmax + F.grid_sample in the reference,
+// multi_scale_deform_attn_3d.py:17-80,246-273).  With S_i[c] the trilinear sample of point i and a = softmax:
+//   out[c] = sum_i a_i S_i[c]
+//   g_i = <dout, S_i>;   dlogit_i = a_i (g_i - sum_j a_j g_j)
+//   dvalue[corner, c] += a_i w_corner dout[c]                  (scatter, float atomics -- as grid_sample's backward)
+//   doffset_i = a_i <dout, dS_i/dpos>   (pixel position = loc * size - 0.5 and loc = ref + off / size: d pos/d off = 1)
+// LPG lanes share a (query, head), each owns VEC = Dh / LPG consecutive channels: the atomics of a corner cover
+// one contiguous head row (coalesced at the L2), the channel sums are LPG-wide butterfly reductions.
+// dvalue is TOKEN-major [B, Nv, H*Dh] (what the value projection's backward consumes) and zero-filled by the caller.
+template <int VEC, int LP_MAX, bool HM>
+__global__ void __launch_bounds__(256) msda3d_bwd_kernel(
+    const float* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
+    const float* __restrict__ dout, float* __restrict__ dvalue, float* __restrict__ doffs, float* __restrict__ dlogits,
+    MsdaLevels lv, int B, int Nq, int H, int Dh, int P, int LPG, long off_ld, long lg_ld, long doff_ld, long dlg_ld) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * Nq * H * LPG;
+  const bool live = gid < total;
+  const long g2 = live ? gid : total - 1;                  // idle lanes shadow the last group (no stores)
+  const int sub = (int)(g2 % LPG);
+  const int cv = sub * VEC;
+  long r = g2 / LPG;
+  const int q = (int)(r % Nq);
+  r /= Nq;
+  const int h = (int)(r % H);
+  const int b = (int)(r / H);
+  const int L = lv.n;
+  const int LP = L * P;
+  int ql = 0;
+  while (ql + 1 < L && q >= lv.start[ql + 1]) ++ql;
+  const int local = q - lv.start[ql];
+  const int qz = local % lv.Z[ql];
+  const int qy = (local / lv.Z[ql]) % lv.Y[ql];
+  const int qx = local / (lv.Z[ql] * lv.Y[ql]);
+  const float rz = ((float)qz + 0.5f) / (float)lv.Z[ql];
+  const float ry = ((float)qy + 0.5f) / (float)lv.Y[ql];
+  const float rx = ((float)qx + 0.5f) / (float)lv.X[ql];
+  const float* lg = logits + (long)(b * Nq + q) * lg_ld + h * LP;
+  float w[LP_MAX], gi[LP_MAX];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < LP_MAX; ++i) {
+    const float lgi = lg[i < LP ? i : LP - 1];
+    w[i] = i < LP ? lgi : -3.0e38f;
+    mx = fmaxf(mx, w[i]);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP_MAX; ++i) {
+    w[i] = i < LP ? expf(w[i] - mx) : 0.f;
+    sum += w[i];
+  }
+  const float inv = 1.0f / sum;
+  const float* of = offs + (long)(b * Nq + q) * off_ld + h * LP * 3;
+  float* dof = doffs + (long)(b * Nq + q) * doff_ld + h * LP * 3;
+  const int E = H * Dh;
+  const long Nv = lv.start[L - 1] + (long)lv.X[L - 1] * lv.Y[L - 1] * lv.Z[L - 1];
+  float go[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) go[v] = dout[(long)(b * Nq + q) * E + h * Dh + cv + v];
+  int l = 0, pl = 0;
+#pragma unroll
+  for (int i = 0; i < LP_MAX; ++i) {
+    gi[i] = 0.f;
+    if (i < LP) {
+      const int Xl = lv.X[l], Yl = lv.Y[l], Zl = lv.Z[l];
+      const float lz = rz + of[i * 3 + 0] / (float)Zl;
+      const float ly = ry + of[i * 3 + 1] / (float)Yl;
+      const float lx = rx + of[i * 3 + 2] / (float)Xl;
+      const float pz = ((2.f * lz - 1.f + 1.f) * (float)Zl - 1.f) * 0.5f;
+      const float py = ((2.f * ly - 1.f + 1.f) * (float)Yl - 1.f) * 0.5f;
+      const float px = ((2.f * lx - 1.f + 1.f) * (float)Xl - 1.f) * 0.5f;
+      const float fz = floorf(pz), fy = floorf(py), fx = floorf(px);
+      const float tz = pz - fz, ty = py - fy, tx = px - fx;
+      const int iz = (int)fz, iy = (int)fy, ix = (int)fx;
+      const float a = w[i] * inv;
+      const long kstride = HM ? Dh : E;
+      const float* vbase = HM ? value + (((long)b * H + h) * Nv + lv.start[l]) * Dh + cv
+                              : value + ((long)b * Nv + lv.start[l]) * E + h * Dh + cv;
+      float* dvb = dvalue + ((long)b * Nv + lv.start[l]) * E + h * Dh + cv;
+      float s_acc = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int bx = c >> 2, by = (c >> 1) & 1, bz = c & 1;
+        const int xx = ix + bx, yy = iy + by, zz = iz + bz;
+        if ((unsigned)xx >= (unsigned)Xl || (unsigned)yy >= (unsigned)Yl || (unsigned)zz >= (unsigned)Zl) continue;
+        const float wx = bx ? tx : 1.f - tx, wy = by ? ty : 1.f - ty, wz = bz ? tz : 1.f - tz;
+        const long key = ((long)xx * Yl + yy) * Zl + zz;
+        float dot = 0.f;                                  // <dout, v[corner]> over this lane's channels
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) dot = fmaf(go[v], vbase[key * kstride + v], dot);
+        s_acc = fmaf(wx * wy * wz, dot, s_acc);
+        gx = fmaf((bx ? 1.f : -1.f) * wy * wz, dot, gx);
+        gy = fmaf((by ? 1.f : -1.f) * wx * wz, dot, gy);
+        gz = fmaf((bz ? 1.f : -1.f) * wx * wy, dot, gz);
+        if (live) {
+          const float cw = a * wx * wy * wz;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) atomicAdd(dvb + key * E + v, cw * go[v]);
+        }
+      }
+      for (int o = 1; o < LPG; o <<= 1) {
+        s_acc += __shfl_xor(s_acc, o);
+        gx += __shfl_xor(gx, o);
+        gy += __shfl_xor(gy, o);
+        gz += __shfl_xor(gz, o);
+      }
+      gi[i] = s_acc;
+      if (live && sub == 0) {
+        dof[i * 3 + 0] = a * gz;
+        dof[i * 3 + 1] = a * gy;
+        dof[i * 3 + 2] = a * gx;
+      }
+      if (++pl == P) {
+        pl = 0;
+        ++l;
+      }
+    }
+  }
+  float mean = 0.f;
+#pragma unroll
+  for (int i = 0; i < LP_MAX; ++i) mean = fmaf(w[i] * inv, gi[i], mean);
+  if (live && sub == 0) {
+    float* dl = dlogits + (long)(b * Nq + q) * dlg_ld + h * LP;
+#pragma unroll
+    for (int i = 0; i < LP_MAX; ++i)
+      if (i < LP) dl[i] = w[i] * inv * (gi[i] - mean);
+  }
+}
+
+extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets, const float* attn_logits,
+                               const float* dout, float* dvalue, float* doffsets, float* dlogits,
+                               const int32_t* level_shapes, int num_levels, int B, int Nq, int heads, int head_dim,
+                               int num_points, int value_head_major, long offsets_ld, long logits_ld, long doffsets_ld,
+                               long dlogits_ld, void* stream) {
+  if (num_levels <= 0 || num_levels > MSDA_MAX_LEVELS || B <= 0 || heads <= 0 || head_dim <= 0 ||
+      num_points <= 0 || num_levels * num_points > 16)
+    return OCCF_ESHAPE;
+  MsdaLevels lv;
+  lv.n = num_levels;
+  int start = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    lv.X[l] = level_shapes[l * 3 + 0];
+    lv.Y[l] = level_shapes[l * 3 + 1];
+    lv.Z[l] = level_shapes[l * 3 + 2];
+    lv.start[l] = start;
+    start += lv.X[l] * lv.Y[l] * lv.Z[l];
+  }
+  for (int l = num_levels; l < MSDA_MAX_LEVELS; ++l) lv.X[l] = lv.Y[l] = lv.Z[l] = lv.start[l] = 0;
+  if (start != Nq) return OCCF_ESHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const long LP3 = (long)heads * num_levels * num_points * 3, LP1 = (long)heads * num_levels * num_points;
+  const long off_ld = offsets_ld > 0 ? offsets_ld : LP3, lg_ld = logits_ld > 0 ? logits_ld : LP1;
+  const long doff_ld = doffsets_ld > 0 ? doffsets_ld : LP3, dlg_ld = dlogits_ld > 0 ? dlogits_ld : LP1;
+  int lpg = head_dim % 8 == 0 ? 8 : head_dim % 4 == 0 ? 4 : head_dim % 2 == 0 ? 2 : 1;
+  int vec = head_dim / lpg;
+  while (vec > 6 && lpg < 8) { lpg *= 2; vec = head_dim / lpg; }
+  if (head_dim % lpg != 0 || vec > 6) { lpg = 1; vec = head_dim; }
+  const long total = (long)B * Nq * heads * lpg;
+#define OCCF_MSDB_LAUNCH(V_, HM_)                                                                                   \
+  hipLaunchKernelGGL((msda3d_bwd_kernel<V_, 16, HM_>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,        \
+                     sampling_offsets, attn_logits, dout, dvalue, doffsets, dlogits, lv, B, Nq, heads, head_dim,    \
+                     num_points, lpg, off_ld, lg_ld, doff_ld, dlg_ld)
+#define OCCF_MSDB_VEC(HM_)                     \
+  switch (vec) {                               \
+    case 1: OCCF_MSDB_LAUNCH(1, HM_); break;   \
+    case 2: OCCF_MSDB_LAUNCH(2, HM_); break;   \
+    case 3: OCCF_MSDB_LAUNCH(3, HM_); break;   \
+    case 4: OCCF_MSDB_LAUNCH(4, HM_); break;   \
+    case 5: OCCF_MSDB_LAUNCH(5, HM_); break;   \
+    case 6: OCCF_MSDB_LAUNCH(6, HM_); break;   \
+    default: return OCCF_ESHAPE;               \
+  }
+  if (value_head_major) { OCCF_MSDB_VEC(true) } else { OCCF_MSDB_VEC(false) }
+#undef OCCF_MSDB_VEC
+#undef OCCF_MSDB_LAUNCH
+  OCCF_LAUNCH_CHECK();
+}

@@ -706,6 +706,40 @@ class HipOps:
                    heads, self._stream())
         return dq, dk, dv
 
+    def msda3d_backward(self, value, offsets, logits, dout, level_shapes, heads, points, head_major=False, d_ol=None,
+                        n_off=None):
+        """-> (dvalue [B, Nq, E] token-major, doffsets, dlogits).  ``d_ol`` [B, Nq, n_off + n_logits]: write the two
+        parameter-side gradients as column blocks of this one tensor (the fused offset/logit projection)."""
+        if head_major:
+            B, _, Nq, dh = value.shape
+            E = heads * dh
+        else:
+            B, Nq, E = value.shape
+        L = len(level_shapes)
+        arr = (ctypes.c_int32 * (3 * L))(*[int(v) for s in level_shapes for v in s])
+        dvalue = torch.zeros((B, Nq, E), dtype=self.f32, device=value.device)
+        if d_ol is None:
+            doff = torch.empty((B, Nq, heads * L * points * 3), dtype=self.f32, device=value.device)
+            dlg = torch.empty((B, Nq, heads * L * points), dtype=self.f32, device=value.device)
+        else:
+            doff, dlg = d_ol[..., :n_off], d_ol[..., n_off:]
+        self._call("occf_msda3d_bwd", self._ptr(value, self.f32), ctypes.c_void_p(offsets.data_ptr()),
+                   ctypes.c_void_p(logits.data_ptr()), self._ptr(dout, self.f32), self._ptr(dvalue),
+                   ctypes.c_void_p(doff.data_ptr()), ctypes.c_void_p(dlg.data_ptr()), ctypes.cast(arr, ctypes.c_void_p),
+                   L, B, Nq, heads, E // heads, points, int(head_major), offsets.stride(1), logits.stride(1),
+                   doff.stride(1), dlg.stride(1), self._stream())
+        return dvalue, doff, dlg
+
+    def deform_col2im(self, x_cl, offset, dcol, K, stride, pad, dil, groups, deform_groups):
+        """backward of deform_im2col -> (dx [BN, H, W, C], doffset like offset)"""
+        BN, H, W, C = x_cl.shape
+        dx = torch.zeros_like(x_cl)
+        doff = torch.empty_like(offset)
+        self._call("occf_deform_col2im", self._ptr(x_cl, self.f32), self._ptr(offset, self.f32),
+                   self._ptr(dcol, self.f32), self._ptr(dx), self._ptr(doff), BN, H, W, C, K, stride, pad, dil, groups,
+                   deform_groups, self._stream())
+        return dx, doff
+
 
 _ops = None
 

@@ -257,3 +257,54 @@ def test_masked_attention_backward(be, Q, L, heads, masked):
     assert _rel(out.cpu(), ref.detach()) < 1e-4
     dq, dk, dv = be.ops.masked_attention_backward(*a, heads, out, be.to(dout), bl, ro)
     assert _rel(dq.cpu(), q.grad) < 2e-4 and _rel(dk.cpu(), k.grad) < 2e-4 and _rel(dv.cpu(), v.grad) < 2e-4
+
+
+@pytest.mark.parametrize("E,heads,shapes", [(96, 8, [(2, 2, 1), (4, 4, 2), (8, 8, 4)]), (48, 4, [(3, 2, 2), (5, 4, 3)]),
+                                            (40, 8, [(2, 3, 1), (4, 4, 2), (6, 5, 3)]), (192, 8, [(2, 2, 1), (4, 3, 2)])])
+def test_msda3d_backward(be, E, heads, shapes):
+    from oracle import occformer_ref as O
+    B, P = 2, 4
+    L = len(shapes)
+    Nq = sum(x * y * z for x, y, z in shapes)
+    value = paramgen.tensor("mb_value", (B, Nq, E), 1).requires_grad_()
+    offs = paramgen.tensor("mb_offs", (B, Nq, heads * L * P * 3), 1, 2.0).requires_grad_()
+    logits = paramgen.tensor("mb_logits", (B, Nq, heads * L * P), 1).requires_grad_()
+    ref_pts = torch.cat([O.reference_points_3d(s) for s in shapes], 0)[None, :, None, :].expand(B, -1, L, -1)
+    norm = torch.tensor([[s[2], s[1], s[0]] for s in shapes], dtype=torch.float32)
+    loc = ref_pts[:, :, None, :, None, :] + offs.view(B, Nq, heads, L, P, 3) / norm[None, None, None, :, None, :]
+    w = logits.view(B, Nq, heads, L * P).softmax(-1).view(B, Nq, heads, L, P)
+    ref = O.msda3d_core(value.view(B, Nq, heads, E // heads), shapes, loc, w)
+    dout = paramgen.tensor("mb_do", tuple(ref.shape), 2)
+    ref.backward(dout)
+    for hm in (False, True):
+        v = value.detach()
+        if hm:
+            v = v.view(B, Nq, heads, E // heads).permute(0, 2, 1, 3).contiguous()
+        dv, doff, dlg = be.ops.msda3d_backward(*be.to(v, offs.detach(), logits.detach(), dout), shapes, heads, P,
+                                               head_major=hm)
+        assert _rel(dv.cpu(), value.grad) < 2e-4
+        assert _rel(doff.cpu(), offs.grad) < 2e-4 and _rel(dlg.cpu(), logits.grad) < 2e-4
+
+
+@pytest.mark.parametrize("groups,dg", [(4, 1), (2, 2)])
+def test_deform_col2im(be, groups, dg):
+    from oracle import occformer_ref as O
+    BN, C, H, W, K = 2, 32, 6, 7, 3
+    x = _t("dc2_x", (BN, C, H, W), 1).requires_grad_()
+    off = (_t("dc2_off", (BN, dg * 2 * K * K, H, W), 2) * 1.5).requires_grad_()
+    wgt = _t("dc2_w", (C, C // groups, K, K), 3, 0.2).requires_grad_()
+    y = O.deform_conv2d(x, off, wgt, 1, 1, 1, groups, dg)
+    dy = _t("dc2_dy", tuple(y.shape), 4)
+    y.backward(dy)
+    # forward columns and the grouped contraction's gradient w.r.t. the columns, in plain torch
+    x_cl = x.detach().permute(0, 2, 3, 1).contiguous()
+    col = be.ops.deform_im2col(be.to(x_cl), be.to(off.detach()), K, 1, 1, 1, groups, dg).cpu()
+    cpg = C // groups
+    w_g = wgt.detach().view(groups, C // groups, cpg, K * K).permute(0, 1, 3, 2)      # [g, co, tap, c]
+    out = torch.einsum("pgtc,gotc->pgo", col, w_g).reshape(BN, H, W, C).permute(0, 3, 1, 2)
+    assert _rel(out, y.detach()) < 1e-4
+    dy_p = dy.permute(0, 2, 3, 1).reshape(BN * H * W, groups, C // groups)
+    dcol = torch.einsum("pgo,gotc->pgtc", dy_p, w_g).contiguous()
+    dx, doff = be.ops.deform_col2im(be.to(x_cl), be.to(off.detach()), be.to(dcol), K, 1, 1, 1, groups, dg)
+    assert _rel(dx.cpu().permute(0, 3, 1, 2), x.grad) < 2e-4
+    assert _rel(doff.cpu(), off.grad) < 2e-4
