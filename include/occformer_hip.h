@@ -367,9 +367,11 @@ int occf_upsample_add_bwd(const float* dout, float* dcoarse, int B, int X, int Y
                           int C, void* stream);
 
 /* Backward of occf_point_sample_3d_fwd w.r.t. the volume (F.grid_sample's input gradient): dout[N, C, P] scattered
- * into dvol[N, C, X, Y, Z], which the CALLER zero-fills. */
+ * into dvol[N, C, X, Y, Z], which the CALLER zero-fills.  voxel_major_ld > 0: dvol is [X*Y*Z, voxel_major_ld] with
+ * column n*C + c instead (voxel-major, the operand layout of the mask-logit contraction's backward). */
 int occf_point_sample_3d_bwd(const float* dout, const float* pts, float* dvol, int N, int C, int X, int Y, int Z,
-                             long P, int shared_pts, int align_corners, int border_padding, void* stream);
+                             long P, int shared_pts, int align_corners, int border_padding, long voxel_major_ld,
+                             void* stream);
 
 /* Backward of occf_point_loss_rows_fwd: grad_rows[R, 4] = d(loss)/d(out) -> dlogits[R, P]. */
 int occf_point_loss_rows_bwd(const float* logits, const float* targets, const float* grad_rows, float* dlogits,

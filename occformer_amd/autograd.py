@@ -1,0 +1,431 @@
+"""torch.autograd.Function wrappers that pair every forward entry point of liboccformer_hip.so with its hand-written
+backward (csrc/bwd_elem.hip, wgrad.hip, attn_bwd.hip, msda3d.hip, dcn.hip, lss.hip) -- the training step of the path.
+
+The reference's counterpart is ATen autograd through the PyTorch modules plus ``QuickCumsumCuda``
+(mmdet3d/ops/bev_pool/bev_pool.py:37-80); ``loss.backward()`` of ``OccupancyFormer.forward_train``
+(projects/mmdet3d_plugin/occformer/detectors/occupancyformer.py:132-199) runs through these Functions here.
+torch is used for the graph bookkeeping, device memory and streams only; every gradient is computed by a kernel of
+the library.  Parameters enter as Function inputs so autograd accumulates into their ``.grad`` (what DDP hooks).
+"""
+import torch
+
+from . import fused
+from .ops import get_ops
+
+_WT_CACHE = {}
+_FLIP_CACHE = {}
+_DG_CACHE = {}
+
+
+def _split(t):
+    ops = get_ops()
+    return None if ops.precision == "f32" else ops.split_bf16(t)
+
+
+def _w2d(w):
+    return w.reshape(w.shape[0], -1)
+
+
+def _wt(weight):
+    """W^T [K, N] (+ bf16 split) of a linear weight [N, K(, 1, 1, 1)], cached per parameter version"""
+    def make():
+        wt = _w2d(weight.detach()).t().contiguous()
+        return wt, _split(wt)
+    return fused._versioned(_WT_CACHE, weight, make)
+
+
+class Linear(torch.autograd.Function):
+    """y = act(x W^T + b) [+ residual]; act in {0, 1 = ReLU} (ReLU only without residual).  ``weight`` is the
+    PARAMETER ([N, K], or a 1x1(x1) convolution weight [N, K, 1, 1(, 1)]): its identity / version keys the cached
+    bf16 split and transpose."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, residual, rows=None):
+        """``rows = (lo, hi)``: use weight[lo:hi] / bias[lo:hi] (the q / k / v blocks of nn.MultiheadAttention's
+        in_proj_weight); the gradients come back full-size, zero outside the block"""
+        assert not (act and residual is not None) and act in (0, 1)
+        ops = get_ops()
+        w2 = _w2d(weight.detach())
+        b = None if bias is None else bias.detach()
+        sp = fused.split_weight(weight, _w2d)
+        if rows is not None:
+            lo, hi = rows
+            w2, b = w2[lo:hi], (None if b is None else b[lo:hi])
+            sp = None if sp is None else (sp[0][lo:hi], sp[1][lo:hi])
+        y = ops.linear(x, w2, b, act, None if residual is None else residual.detach(), w_split=sp, allow_small=True)
+        ctx.save_for_backward(x, weight, y if act else None)
+        ctx.has_bias, ctx.has_res, ctx.act, ctx.rows = bias is not None, residual is not None, act, rows
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        ops = get_ops()
+        Nfull, K = weight.shape[0], weight.numel() // weight.shape[0]
+        lo, hi = ctx.rows if ctx.rows is not None else (0, Nfull)
+        N = hi - lo
+        g = dy.contiguous()
+        if ctx.act:
+            g = ops.act_backward(y, g, 1)
+        g2, x2 = g.reshape(-1, N), x.reshape(-1, K)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt, sp = _wt(weight)
+            if ctx.rows is not None:                     # W[lo:hi]^T = columns lo:hi of W^T: made contiguous per call
+                wt = wt[:, lo:hi].contiguous()
+                sp = _split(wt)
+            dx = ops.linear(g2, wt, None, w_split=sp).view(x.shape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = ops.linear_wgrad(g2, x2 if x2.stride(1) == 1 else x2.contiguous(), want_bias=ctx.has_bias)
+            if ctx.rows is not None:
+                full = torch.zeros((Nfull, K), dtype=dw.dtype, device=dw.device)
+                full[lo:hi] = dw
+                dw = full
+                if db is not None:
+                    fb = torch.zeros((Nfull,), dtype=db.dtype, device=db.device)
+                    fb[lo:hi] = db
+                    db = fb
+            dw = dw.view(weight.shape)
+        return dx, dw, db, None, (dy if ctx.has_res else None), None
+
+
+def linear(x, lin, act=0, residual=None):
+    return Linear.apply(x, lin.weight, lin.bias, act, residual, None)
+
+
+def _conv_geometry(conv):
+    ks = tuple(conv.kernel_size) + (1,) * (3 - len(conv.kernel_size))
+    pad = tuple(conv.padding) + (0,) * (3 - len(conv.padding))
+    stride, dil = conv.stride[0], conv.dilation[0]
+    assert all(s == stride for s in conv.stride) and all(d == dil for d in conv.dilation) and conv.groups == 1
+    return ks, stride, dil, pad
+
+
+class Conv3d(torch.autograd.Function):
+    """channels-last convolution y = conv(x) + b on the implicit-GEMM / halo kernels; weight in nn.Conv layout"""
+
+    @staticmethod
+    def forward(ctx, x_cl, weight, bias, ks, stride, dil, pad):
+        ops = get_ops()
+        w2 = fused._versioned(fused._TAP_CACHE, weight, lambda: fused._tap_layout(weight.detach()))
+        y = ops.conv3d(x_cl, w2, ks, stride, dil, pad, None if bias is None else bias.detach(),
+                       w_split=fused.split_weight(weight, fused._tap_layout))
+        ctx.save_for_backward(x_cl, weight)
+        ctx.geom = (ks, stride, dil, pad)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cl, weight = ctx.saved_tensors
+        ks, stride, dil, pad = ctx.geom
+        ops = get_ops()
+        g = dy.contiguous()
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if stride == 1:
+                # the data gradient of a stride-1 convolution is a convolution of dy with the taps flipped and the
+                # channel roles swapped (padding dil*(k-1) - pad): the 3^3 case runs on the LDS-halo kernel
+                def make():
+                    w5 = weight.detach() if weight.dim() == 5 else weight.detach().unsqueeze(-1)
+                    wf = w5.flip(2, 3, 4).permute(1, 2, 3, 4, 0).reshape(Cin, -1).contiguous()   # [Cin, taps*Cout]
+                    return wf, _split(wf)
+                wf, sp = fused._versioned(_FLIP_CACHE, weight, make)
+                dpad = tuple(dil * (k - 1) - p for k, p in zip(ks, pad))
+                dx = ops.conv3d(g, wf, ks, 1, dil, dpad, None, w_split=sp)
+            else:
+                def make():
+                    w5 = weight.detach() if weight.dim() == 5 else weight.detach().unsqueeze(-1)
+                    wt = w5.permute(1, 2, 3, 4, 0).reshape(Cin, -1).contiguous()                   # [Cin, taps*Cout]
+                    return wt, ops.split_bf16(wt)
+                wt, sp = fused._versioned(_DG_CACHE, weight, make)
+                dx = ops.conv3d_dgrad(g, sp, tuple(x_cl.shape), ks, stride, dil, pad)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw2, db = ops.conv3d_wgrad(g, x_cl, ks, stride, dil, pad, want_bias=ctx.has_bias)
+            dw = dw2.view(Cout, *ks, Cin).permute(0, 4, 1, 2, 3)
+            if weight.dim() == 4:
+                dw = dw.squeeze(-1)
+            dw = dw.contiguous()
+        return dx, dw, db, None, None, None, None
+
+
+def conv(x_cl, conv_mod):
+    """nn.Conv3d / nn.Conv2d module on channels-last [B, X, Y, Z, C] (no activation; bias included)"""
+    ks, stride, dil, pad = _conv_geometry(conv_mod)
+    if ks == (1, 1, 1) and stride == 1 and x_cl.is_contiguous():
+        return Linear.apply(x_cl, conv_mod.weight, conv_mod.bias, 0, None, None)   # [Cout, Cin, 1, 1(, 1)] read as [Cout, Cin]
+    return Conv3d.apply(x_cl, conv_mod.weight, conv_mod.bias, ks, stride, dil, pad)
+
+
+class GroupNorm(torch.autograd.Function):
+    """occf_groupnorm_apply: y = relu?(GN(x)) [+ residual], token mode appends the z-mean slot"""
+
+    @staticmethod
+    def forward(ctx, x_cl, weight, bias, groups, eps, relu, tokens, residual):
+        ops = get_ops()
+        x_cl = x_cl.contiguous()
+        stats = ops.groupnorm_stats(x_cl, groups, eps)
+        y = ops.groupnorm_apply(x_cl, stats, weight.detach(), bias.detach(), groups, relu, tokens,
+                                None if residual is None else residual.detach().contiguous())
+        ctx.save_for_backward(x_cl, stats, weight, bias)
+        ctx.cfg = (groups, relu, tokens, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cl, stats, weight, bias = ctx.saved_tensors
+        groups, relu, tokens, has_res = ctx.cfg
+        dx, dg, db, dres = get_ops().groupnorm_backward(x_cl, stats, weight.detach(), bias.detach(), dy.contiguous(),
+                                                        groups, relu, tokens, want_residual=has_res)
+        return dx, dg, db, None, None, None, None, dres
+
+
+def group_norm(x_cl, gn, relu=False, tokens=False, residual=None):
+    return GroupNorm.apply(x_cl, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, tokens, residual)
+
+
+def conv_gn(x_cl, conv_mod, gn, relu=False, tokens=False, residual=None):
+    return group_norm(conv(x_cl, conv_mod), gn, relu, tokens, residual)
+
+
+class LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x.contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.eps = eps
+        return get_ops().layernorm(x, weight.detach(), bias.detach(), eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx, dg, db = get_ops().layernorm_backward(x, weight.detach(), dy.contiguous(), ctx.eps)
+        return dx, dg, db, None
+
+
+def layernorm(x, ln):
+    return LayerNorm.apply(x, ln.weight, ln.bias, ln.eps)
+
+
+class Act(torch.autograd.Function):
+    """1 = ReLU, 2 = exact GELU"""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return get_ops().act_forward(x, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return get_ops().act_backward(x, dy.contiguous(), ctx.act), None
+
+
+class DropPathAdd(torch.autograd.Function):
+    """identity + branch * scale[sample] over the token buffer (sample = (batch, slice))"""
+
+    @staticmethod
+    def forward(ctx, identity, branch, scale, XY, S):
+        ctx.save_for_backward(scale)
+        ctx.geom = (XY, S)
+        return get_ops().droppath(identity.contiguous(), branch.contiguous(), scale, XY, S)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (scale,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        return dy, get_ops().droppath(None, dy, scale, *ctx.geom), None, None, None
+
+
+class WindowAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, qkv_bias, table, B, X, Y, S, heads, shift):
+        ops = get_ops()
+        qkv = qkv.contiguous()
+        out = ops.window_attention(qkv, qkv_bias.detach(), table.detach(), B, X, Y, S, heads, shift)
+        ctx.save_for_backward(qkv, qkv_bias, table, out)
+        ctx.geom = (B, X, Y, S, heads, shift)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, qkv_bias, table, out = ctx.saved_tensors
+        dqkv, dpad, dtab = get_ops().window_attention_backward(qkv, qkv_bias.detach(), table.detach(), out,
+                                                               dout.contiguous(), *ctx.geom)
+        return dqkv, dpad, dtab, None, None, None, None, None, None
+
+
+class DualpathCombine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tok, bev, weight, bias, identity):
+        """tok [B,X,Y,Z+1,C], bev [B,X,Y,C], weight = combine_coeff.weight [1,C,1,1,1], identity [B,X,Y,Z,C]"""
+        w = weight.detach().reshape(-1)
+        ctx.save_for_backward(tok, bev, weight, bias)
+        return get_ops().dualpath_combine(tok, bev, w, None if bias is None else bias.detach(), identity.contiguous())
+
+    @staticmethod
+    def backward(ctx, dout):
+        tok, bev, weight, bias = ctx.saved_tensors
+        dtok, dbev, dw, db = get_ops().dualpath_combine_backward(tok, bev, weight.detach().reshape(-1),
+                                                                 None if bias is None else bias.detach(),
+                                                                 dout.contiguous())
+        return dtok, dbev, dw.view(weight.shape), (db if bias is not None else None), dout
+
+
+class MSDA(torch.autograd.Function):
+    """sampling core; ``ol`` = the fused offset / logit projection output [B, Nq, n_off + n_logits]"""
+
+    @staticmethod
+    def forward(ctx, value, ol, n_off, shapes, heads, points):
+        ops = get_ops()
+        value, ol = value.contiguous(), ol.contiguous()
+        ctx.save_for_backward(value, ol)
+        ctx.cfg = (n_off, tuple(shapes), heads, points)
+        return ops.msda3d(value, ol[..., :n_off], ol[..., n_off:], shapes, heads, points, head_major=False)
+
+    @staticmethod
+    def backward(ctx, dout):
+        value, ol = ctx.saved_tensors
+        n_off, shapes, heads, points = ctx.cfg
+        d_ol = torch.empty_like(ol)
+        dvalue, _, _ = get_ops().msda3d_backward(value, ol[..., :n_off], ol[..., n_off:], dout.contiguous(), shapes,
+                                                 heads, points, head_major=False, d_ol=d_ol, n_off=n_off)
+        return dvalue, d_ol, None, None, None, None
+
+
+class UpsampleAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, coarse, lateral):
+        ctx.cshape = tuple(coarse.shape)
+        return get_ops().upsample_add(coarse.contiguous(), lateral.contiguous())
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        return get_ops().upsample_add_backward(dout, ctx.cshape), dout
+
+
+class MaskedAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, heads, blocked, row_open):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out = get_ops().masked_attention(q, k, v, heads, blocked, row_open)
+        ctx.save_for_backward(q, k, v, out)
+        ctx.mask = (blocked, row_open)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out = ctx.saved_tensors
+        dq, dk, dv = get_ops().masked_attention_backward(q, k, v, ctx.heads, out, dout.contiguous(), *ctx.mask)
+        return dq, dk, dv, None, None, None
+
+
+class PointSample3d(torch.autograd.Function):
+    """point_sample_3d with a gradient w.r.t. the volume (the points come from no_grad sampling)"""
+
+    @staticmethod
+    def forward(ctx, vol, pts, align_corners, padding_mode):
+        pts = pts.contiguous()
+        ctx.save_for_backward(pts)
+        ctx.cfg = (tuple(vol.shape), align_corners, padding_mode)
+        return get_ops().point_sample_3d(vol.contiguous(), pts, align_corners, padding_mode)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (pts,) = ctx.saved_tensors
+        shape, align, mode = ctx.cfg
+        return get_ops().point_sample_3d_backward(dout.contiguous(), pts, shape, align, mode), None, None, None
+
+
+class PointLossRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets):
+        logits, targets = logits.contiguous(), targets.contiguous()
+        ctx.save_for_backward(logits, targets)
+        return get_ops().point_loss_rows(logits, targets)
+
+    @staticmethod
+    def backward(ctx, grows):
+        logits, targets = ctx.saved_tensors
+        return get_ops().point_loss_rows_backward(logits, targets, grows.contiguous()), None
+
+
+class DeformConv(torch.autograd.Function):
+    """DCNv1: bilinear im2col (csrc/dcn.hip) + grouped contraction; x_cl [BN, H, W, C], offset [BN, dg*2*K*K, H, W],
+    weight [Cout, Cin/groups, K, K] -> [BN*H*W, Cout]"""
+
+    @staticmethod
+    def forward(ctx, x_cl, offset, weight, K, pad, groups, dgroups):
+        ops = get_ops()
+        x_cl, offset = x_cl.contiguous(), offset.contiguous()
+        col = ops.deform_im2col(x_cl, offset, K, 1, pad, 1, groups, dgroups)
+        Cout = weight.shape[0]
+        out = torch.empty((col.shape[0], Cout), dtype=x_cl.dtype, device=x_cl.device)
+        og = Cout // groups
+        for g, wg in enumerate(weight.detach().chunk(groups, 0)):
+            w2 = wg.permute(0, 2, 3, 1).reshape(og, -1).contiguous()
+            ops.linear(col[:, g].flatten(1), w2, out=out[:, g * og:(g + 1) * og], w_split=_split(w2))
+        ctx.save_for_backward(x_cl, offset, weight, col)
+        ctx.cfg = (K, pad, groups, dgroups)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x_cl, offset, weight, col = ctx.saved_tensors
+        K, pad, groups, dgroups = ctx.cfg
+        ops = get_ops()
+        dout = dout.contiguous()
+        Cout = weight.shape[0]
+        og, cpg = Cout // groups, weight.shape[1]
+        dcol = torch.empty_like(col)
+        dws = []
+        for g, wg in enumerate(weight.detach().chunk(groups, 0)):
+            w2 = wg.permute(0, 2, 3, 1).reshape(og, -1).contiguous()              # [og, K*K*cpg]
+            wt = w2.t().contiguous()
+            dy_g = dout[:, g * og:(g + 1) * og]
+            ops.linear(dy_g, wt, None, out=dcol[:, g].flatten(1), w_split=_split(wt))
+            dw2, _ = ops.linear_wgrad(dy_g, col[:, g].flatten(1), want_bias=False)
+            dws.append(dw2.view(og, K, K, cpg).permute(0, 3, 1, 2))
+        dx, doff = ops.deform_col2im(x_cl, offset, dcol, K, 1, pad, 1, groups, dgroups)
+        return dx, doff, torch.cat(dws, 0).contiguous(), None, None, None, None
+
+
+class SampledMaskLogits(torch.autograd.Function):
+    """point_sample_3d(mask_pred[rows], coords) as a function of (mask_embed rows, mask features): the mask logits
+    are einsum('qc,cxyz->qxyz') (mask2former_nusc_occ.py:455), and trilinear sampling is linear in the volume, so the
+    loss gradient reaches ``mask_embed`` and the mask features through the SAMPLED rows only.  The forward reads the
+    (detached, already materialised) logits of the matched rows; the backward scatters the [rows, P] gradient into a
+    voxel-major [V, rows] buffer and contracts it twice -- the dense [Q, X, Y, Z] gradient of the reference (256 MB per
+    prediction set at the 200-grid) never exists.
+
+    vol_rows [n, X, Y, Z] detached logits of the matched rows; embed_rows [n, E]; feat_tok [V, E]; pts [n, P, 3]"""
+
+    @staticmethod
+    def forward(ctx, vol_rows, embed_rows, feat_tok, pts, align_corners, padding_mode):
+        pts = pts.contiguous()
+        ctx.save_for_backward(embed_rows, feat_tok, pts)
+        ctx.cfg = (tuple(vol_rows.shape), align_corners, padding_mode)
+        return get_ops().point_sample_3d(vol_rows.unsqueeze(1).contiguous(), pts, align_corners, padding_mode)[:, 0]
+
+    @staticmethod
+    def backward(ctx, dout):
+        embed_rows, feat_tok, pts = ctx.saved_tensors
+        (n, X, Y, Z), align, mode = ctx.cfg
+        ops = get_ops()
+        npad = (n + 3) // 4 * 4
+        # dMP^T [V, npad]: the matched rows' logit gradient, voxel-major
+        dmt = ops.point_sample_3d_backward(dout.contiguous().unsqueeze(1), pts, (n, 1, X, Y, Z), align, mode,
+                                           voxel_major_cols=npad)
+        d_embed = d_feat = None
+        if ctx.needs_input_grad[1]:
+            d_embed = ops.linear_wgrad(dmt, feat_tok.contiguous(), want_bias=False)[0][:n].contiguous()   # [n, E]
+        if ctx.needs_input_grad[2]:
+            et = torch.zeros((embed_rows.shape[1], npad), dtype=embed_rows.dtype, device=embed_rows.device)
+            et[:, :n] = embed_rows.detach().t()
+            d_feat = ops.linear(dmt, et, None, allow_small=False)                                          # [V, E]
+        return None, d_embed, d_feat, None, None, None

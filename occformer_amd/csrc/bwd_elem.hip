@@ -269,7 +269,9 @@ __global__ void __launch_bounds__(256) gn_bwd_partial_kernel(const float* __rest
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float xh = (xx[e] - mean[e]) * rstd[e];
-        const float ge = (relu && fmaf(xh, gm[e], bt[e]) <= 0.f) ? 0.f : gg[e];
+        // the ReLU mask from the forward's own expression y = fma(x, rstd*gamma, beta - mean*rstd*gamma)
+        const float sc = rstd[e] * gm[e];
+        const float ge = (relu && fmaf(xx[e], sc, bt[e] - mean[e] * sc) <= 0.f) ? 0.f : gg[e];
         a[e] += ge;
         bb[e] = fmaf(ge, xh, bb[e]);
       }
@@ -357,7 +359,8 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
     const float* t = gs + (b * G + grp) * 2;
     const float gm = gamma[c0 + e];
     const float xh = (xx[e] - s[0]) * s[1];
-    const float ge = (relu && fmaf(xh, gm, beta[c0 + e]) <= 0.f) ? 0.f : gg[e];
+    const float sc = s[1] * gm;
+    const float ge = (relu && fmaf(xx[e], sc, beta[c0 + e] - s[0] * sc) <= 0.f) ? 0.f : gg[e];
     o[e] = s[1] * (ge * gm - t[0] - xh * t[1]);
   }
   *(float4*)(dx + (b * V + r) * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
@@ -656,7 +659,7 @@ extern "C" int occf_upsample_add_bwd(const float* dout, float* dcoarse, int B, i
 __global__ void __launch_bounds__(256) point_sample_3d_bwd_kernel(const float* __restrict__ dout,
                                                                   const float* __restrict__ pts, float* __restrict__ dvol,
                                                                   int N, int C, int X, int Y, int Z, long P, int shared_pts,
-                                                                  int align_corners, int border) {
+                                                                  int align_corners, int border, long voxel_major_ld) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)N * P) return;
   const int n = (int)(gid / P);
@@ -679,8 +682,11 @@ __global__ void __launch_bounds__(256) point_sample_3d_bwd_kernel(const float* _
     ok1[a] = i1[a] >= 0 && i1[a] < dims[a];
   }
   const long V = (long)X * Y * Z;
+  // voxel_major_ld > 0: dvol is [V, ld] with column n*C + c (the layout the mask-logit contraction's backward
+  // consumes as a row-major [voxels, rows] operand); otherwise [N, C, V]
+  const long vstride = voxel_major_ld > 0 ? voxel_major_ld : 1;
   for (int c = 0; c < C; ++c) {
-    float* v = dvol + ((long)n * C + c) * V;
+    float* v = voxel_major_ld > 0 ? dvol + ((long)n * C + c) : dvol + ((long)n * C + c) * V;
     const float g = dout[((long)n * C + c) * P + pi];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -689,17 +695,18 @@ __global__ void __launch_bounds__(256) point_sample_3d_bwd_kernel(const float* _
       if (!ok) continue;
       const int zz = bz ? i1[0] : i0[0], yy = by ? i1[1] : i0[1], xx = bx ? i1[2] : i0[2];
       const float w = (bz ? t[0] : 1.f - t[0]) * (by ? t[1] : 1.f - t[1]) * (bx ? t[2] : 1.f - t[2]);
-      if (w != 0.f) atomicAdd(v + ((long)xx * Y + yy) * Z + zz, w * g);
+      if (w != 0.f) atomicAdd(v + (((long)xx * Y + yy) * Z + zz) * vstride, w * g);
     }
   }
 }
 extern "C" int occf_point_sample_3d_bwd(const float* dout, const float* pts, float* dvol, int N, int C, int X, int Y,
                                         int Z, long P, int shared_pts, int align_corners, int border_padding,
-                                        void* stream) {
+                                        long voxel_major_ld, void* stream) {
   if (N <= 0 || C <= 0 || X <= 0 || Y <= 0 || Z <= 0 || P < 0) return OCCF_EINVAL;
+  if (voxel_major_ld != 0 && voxel_major_ld < (long)N * C) return OCCF_EINVAL;
   if (P == 0) return 0;
   hipLaunchKernelGGL(point_sample_3d_bwd_kernel, dim3(occf_cdiv((long)N * P, 256)), dim3(256), 0, (hipStream_t)stream,
-                     dout, pts, dvol, N, C, X, Y, Z, P, shared_pts, align_corners, border_padding);
+                     dout, pts, dvol, N, C, X, Y, Z, P, shared_pts, align_corners, border_padding, voxel_major_ld);
   OCCF_LAUNCH_CHECK();
 }
 

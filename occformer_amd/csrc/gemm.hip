@@ -314,11 +314,42 @@ __global__ void __launch_bounds__(256) linear_small_kernel(const float* __restri
   out[m * ldo + n] = v;
 }
 
+// any K / row stride (scalar loads): the data gradient of a classifier head has K = number of classes
+__global__ void __launch_bounds__(256) linear_small_scalar_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ w,
+                                                                  const float* __restrict__ bias,
+                                                                  const float* __restrict__ residual,
+                                                                  float* __restrict__ out, int M, int N, int K, long ldx,
+                                                                  long ldo, long ldr, int act) {
+  const long gid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  const bool valid = gid < (long)M * N;
+  const int n = valid ? (int)(gid % N) : 0, m = valid ? (int)(gid / N) : 0;
+  const float* xr = x + m * ldx;
+  const float* wr = w + (long)n * K;
+  float v = 0.f;
+  for (int k = sub; k < K; k += 8) v = fmaf(xr[k], wr[k], v);
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  if (!valid || sub != 0) return;
+  if (bias) v += bias[n];
+  if (act == 1) v = fmaxf(v, 0.f);
+  else if (act == 2) v = occf_gelu(v);
+  if (residual) v += residual[m * ldr + n];
+  out[m * ldo + n] = v;
+}
+
 extern "C" int occf_linear_small_fwd(const float* x, const float* weight, const float* bias,
                                      const float* residual, float* out, int M, int N, int K, long ldx,
                                      long ldo, long ldr, int act, void* stream) {
-  if (M <= 0 || N <= 0 || K <= 0 || K % 4 != 0 || ldx % 4 != 0) return OCCF_ESHAPE;
+  if (M <= 0 || N <= 0 || K <= 0) return OCCF_ESHAPE;
   const long total = (long)M * N * 8;
+  if (K % 4 != 0 || ldx % 4 != 0) {
+    hipLaunchKernelGGL(linear_small_scalar_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       weight, bias, residual, out, M, N, K, ldx, ldo, ldr, act);
+    OCCF_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(linear_small_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
                      weight, bias, residual, out, M, N, K, ldx, ldo, ldr, act);
   OCCF_LAUNCH_CHECK();

@@ -264,9 +264,10 @@ class OccupancyFormer(nn.Module):
 
     def forward_train(self, points=None, img_metas=None, img_inputs=None, gt_occ=None, points_occ=None,
                       **kwargs):
-        """occupancyformer.py:132-199 -- loss VALUES of one training step (depth BCE + the head's Hungarian
-        losses).  The HIP modules build no autograd graph (backward kernels exist for the voxel pooling only),
-        so this is the forward half of the reference's training step."""
+        """occupancyformer.py:132-199: depth BCE + the head's Hungarian losses.  In ``train()`` mode every module of
+        the path runs as a graph of forward / backward kernel pairs (occformer_amd/autograd.py), so the returned
+        losses carry ``grad_fn`` and ``sum(losses).backward()`` produces every parameter gradient -- the reference's
+        training step.  In ``eval()`` mode the fused inference kernels run and the losses are plain values."""
         voxel_feats, img_feats, depth = self.extract_feat(points=None, img=img_inputs, img_metas=img_metas)
         losses = {"loss_depth": self.img_view_transformer.get_depth_loss(img_inputs[7], depth)}
         losses.update(self.pts_bbox_head.forward_train(voxel_feats=voxel_feats, img_metas=img_metas, gt_occ=gt_occ,

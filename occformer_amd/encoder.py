@@ -15,7 +15,8 @@ import torch.utils.checkpoint
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import fused
+from . import autograd as A
+from . import fused, noise
 from .ops import get_ops
 from .registry import BACKBONES
 
@@ -92,7 +93,8 @@ class SwinBlock(nn.Module):
     def forward(self, tok):
         """tok [B, X, Y, S, C] contiguous -> same shape.  LN / qkv / proj+residual / FFN(+GELU,
         +residual) all run in the HIP kernels; DropPath is the identity in eval mode."""
-        fused.require_eval(self)
+        if self.training:
+            return self._forward_train(tok)
         B, X, Y, S, C = tok.shape
         t = tok.reshape(-1, C)
         m = self.attn.w_msa
@@ -114,6 +116,39 @@ class SwinBlock(nn.Module):
         return t.view(B, X, Y, S, C)
 
 
+    def _drop_path(self, B, S, device):
+        """one DropPath draw of the block: the reference's batch is cat(B BEV maps, (b z) height slices)
+        (dualpath_block.py:72-76), i.e. noise index b -> slice (b, S-1) and B + b*Z + z -> slice (b, z); returned in
+        token-buffer order [b*S + s]"""
+        sc = noise.drop_path_scale(B * S, self.drop_path_rate, device)
+        if sc is None:
+            return None
+        Z = S - 1
+        return torch.cat((sc[B:].view(B, Z), sc[:B].view(B, 1)), 1).reshape(-1).contiguous()
+
+    def _forward_train(self, tok):
+        """the same block as a differentiable graph of the library's forward / backward kernel pairs
+        (occformer_amd/autograd.py), with the DropPath of the training mode (window_attention.py:311,332)"""
+        B, X, Y, S, C = tok.shape
+        t = tok.reshape(-1, C)
+        m = self.attn.w_msa
+        qkv = A.linear(A.layernorm(t, self.norm1), m.qkv)
+        a = A.WindowAttention.apply(qkv, m.qkv.bias, m.relative_position_bias_table, B, X, Y, S, self.heads,
+                                    self.attn.shift_size)
+        sc = self._drop_path(B, S, tok.device)
+        if sc is None:
+            t = A.linear(a, m.proj, residual=t)
+        else:
+            t = A.DropPathAdd.apply(t, A.linear(a, m.proj), sc, X * Y, S)
+        f = A.Act.apply(A.linear(A.layernorm(t, self.norm2), self.ffn.layers[0][0]), 2)
+        sc = self._drop_path(B, S, tok.device)
+        if sc is None:
+            t = A.linear(f, self.ffn.layers[1], residual=t)
+        else:
+            t = A.DropPathAdd.apply(t, A.linear(f, self.ffn.layers[1]), sc, X * Y, S)
+        return t.view(B, X, Y, S, C)
+
+
 # ------------------------------------------------------------------ BEV ASPP (global path)
 class _AtrousGN(nn.Module):
     def __init__(self, cin, cout, k, dil, groups):
@@ -123,6 +158,8 @@ class _AtrousGN(nn.Module):
         nn.init.kaiming_normal_(self.atrous_conv.weight)
 
     def forward(self, x_cl):
+        if self.training:
+            return A.conv_gn(x_cl, self.atrous_conv, self.bn, relu=True)
         return fused.conv_gn(x_cl, self.atrous_conv, self.bn, relu=True)
 
 
@@ -149,6 +186,12 @@ class _ASPP(nn.Module):
         g = F.relu(self.global_avg_pool[2](self.global_avg_pool[1](g.reshape(B, C, 1, 1))))
         g = g.view(B, 1, 1, 1, C).expand(B, X, Y, 1, C)
         y = torch.cat((self.aspp1(x_cl), self.aspp2(x_cl), self.aspp3(x_cl), self.aspp4(x_cl), g), -1)
+        if self.training:
+            y = A.conv_gn(y, self.conv1, self.bn1, relu=True)
+            mask = noise.dropout_mask((B, C, X, Y), self.dropout.p, x_cl.device)     # aspp.py:103,122
+            if mask is not None:
+                y = y * mask.permute(0, 2, 3, 1).unsqueeze(3)
+            return x_cl + y
         y = fused.conv_gn(y, self.conv1, self.bn1, relu=True, residual=x_cl)
         return y                                   # = x + dropout(relu(gn(conv1(cat))))  (eval)
 
@@ -170,7 +213,10 @@ class BottleNeckASPP(nn.Module):
 
     def forward(self, x_cl):
         """x_cl [B, X, Y, 1, C] (any row stride) -> contiguous [B, X, Y, 1, C]."""
-        fused.require_eval(self)
+        if self.training:
+            y = A.conv_gn(x_cl, self.input_conv[0], self.input_conv[1], relu=True)
+            y = self.aspp(y)
+            return A.conv_gn(y, self.output_conv[0], self.output_conv[1], relu=True, residual=x_cl)
         y = fused.conv_gn(x_cl, self.input_conv[0], self.input_conv[1], relu=True)
         y = self.aspp(y)
         return fused.conv_gn(y, self.output_conv[0], self.output_conv[1], relu=True, residual=x_cl.contiguous())
@@ -200,11 +246,19 @@ class DualpathTransformerBlock(nn.Module):
 
     def forward(self, x):
         """x logical [B, Cin, X, Y, Z] -> logical [B, C, X', Y', Z'] over channels-last memory."""
-        fused.require_eval(self)
         if not isinstance(self.input_conv[1], nn.GroupNorm):
             raise NotImplementedError("the HIP path implements the GroupNorm blocks of the OccFormer configs")
         ops = get_ops()
         x_cl = fused.channels_last_view(x.float())
+        if self.training:
+            tok = A.conv_gn(x_cl, self.input_conv[0], self.input_conv[1], relu=True, tokens=True)
+            Z = tok.shape[3] - 1
+            tok = self.bev_encoder(tok)
+            bev = self.aspp(tok[:, :, :, Z:Z + 1])
+            ident = A.conv_gn(x_cl, self.downsample[0], self.downsample[1]) if self.stride > 1 else x_cl
+            out = A.DualpathCombine.apply(tok, bev.reshape(*bev.shape[:3], -1), self.combine_coeff.weight,
+                                          self.combine_coeff.bias, ident)
+            return out.permute(0, 4, 1, 2, 3)
         # 3^3 conv (its epilogue also yields the GroupNorm statistics) -> GN + ReLU -> token buffer [B,X,Y,Z+1,C]
         tok = fused.conv_gn(x_cl, self.input_conv[0], self.input_conv[1], relu=True, tokens=True)
         Z = tok.shape[3] - 1
@@ -246,10 +300,8 @@ class OccupancyEncoder(nn.Module):
     def forward(self, x):
         outs = []
         for i, layer in enumerate(self.layers):
-            if self.with_cp and x.requires_grad:
-                x = torch.utils.checkpoint.checkpoint(layer, x, use_reentrant=False)
-            else:
-                x = layer(x)
+            # with_cp (occnet.py:67-68) exists to fit 24 GB cards; with 288 GB of HBM every activation stays resident
+            x = layer(x)
             if i in self.out_indices:
                 outs.append(x)
         return outs

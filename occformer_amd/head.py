@@ -13,12 +13,13 @@ import os
 import torch
 import torch.nn as nn
 
+from . import autograd as A
 from . import fused
 from .encoder import _FFN
 from .ops import get_ops
 from .pixel_decoder import SinePositionalEncoding3D
 from .registry import HEADS
-from .training import (KittiTrainingMixin, NuscTrainingMixin, OccHeadTrainingMixin,
+from .training import (KittiTrainingMixin, LazyMask, NuscTrainingMixin, OccHeadTrainingMixin,
                        semantic_kitti_class_frequencies)
 
 
@@ -51,6 +52,15 @@ class _MHA(nn.Module):
         when the caller projected a level's tokens for all of its layers in one GEMM"""
         E = self.E
         ops = get_ops()
+        if self.training:
+            W, bv = self.attn.in_proj_weight, self.attn.in_proj_bias
+            if key_with_pos is None:
+                key_with_pos = key + key_pos if key_pos is not None else key
+            q = A.Linear.apply(query + query_pos, W, bv, 0, None, (0, E))
+            k = A.Linear.apply(key_with_pos, W, bv, 0, None, (E, 2 * E))
+            v = A.Linear.apply(value, W, bv, 0, None, (2 * E, 3 * E))
+            o = A.MaskedAttention.apply(q, k, v, self.heads, blocked, row_open)
+            return A.linear(o, self.attn.out_proj, residual=query)
         w, b = self.attn.in_proj_weight.detach(), self.attn.in_proj_bias.detach()
         sp = fused.split_weight(self.attn.in_proj_weight)
         part = (lambda lo, hi: None) if sp is None else (lambda lo, hi: (sp[0][lo:hi], sp[1][lo:hi]))
@@ -77,6 +87,13 @@ class _DecoderLayer(nn.Module):
         self.norms = nn.ModuleList([nn.LayerNorm(E) for _ in range(3)])
 
     def forward(self, q, qpos, key, key_pos, blocked, row_open, key_with_pos=None, kv=None):
+        if self.training:
+            q = A.layernorm(self.attentions[0](q, key, key, qpos, key_pos, blocked, row_open, key_with_pos),
+                            self.norms[0])
+            q = A.layernorm(self.attentions[1](q, q, q, qpos, qpos), self.norms[1])
+            ffn = self.ffns[0].layers
+            y = A.linear(A.linear(q, ffn[0][0], act=1), ffn[1], residual=q)
+            return A.layernorm(y, self.norms[2])
         q = fused.layernorm(self.attentions[0](q, key, key, qpos, key_pos, blocked, row_open, key_with_pos, kv),
                             self.norms[0])
         q = fused.layernorm(self.attentions[1](q, q, q, qpos, qpos), self.norms[1])
@@ -153,6 +170,9 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
         row_open) (None if not wanted).  When only the attention mask is needed the contraction
         and the preserve-pooling run fused and the full-resolution logits are never written."""
         ops = get_ops()
+        if self.training:
+            return self._forward_head_train(decoder_out, mask_feat_tok, vol_shape, target_shape, mask_feat_split,
+                                            want_attn)
         d = fused.layernorm(decoder_out.contiguous(), self.transformer_decoder.post_norm)
         cls_pred = fused.linear(d, self.cls_embed)
         me = self.mask_embed
@@ -175,6 +195,29 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
             am = (blocked, row_open)
         return cls_pred, mask_pred, am
 
+    def _forward_head_train(self, decoder_out, mask_feat_tok, vol_shape, target_shape, mask_feat_split, want_attn):
+        """training-step variant: class / mask-embedding branches as differentiable kernel pairs; the mask logits
+        are materialised DETACHED (attention mask, target assignment, importance sampling) and handed on as a
+        ``LazyMask`` whose gradient route is the point-sampled contraction (training.LazyMask)"""
+        ops = get_ops()
+        d = A.layernorm(decoder_out, self.transformer_decoder.post_norm)
+        cls_pred = A.linear(d, self.cls_embed)
+        me = self.mask_embed
+        mask_embed = A.linear(A.linear(A.linear(d, me[0], act=1), me[2], act=1), me[4])
+        B, Q = mask_embed.shape[:2]
+        with torch.no_grad():
+            dense = torch.empty((B, Q, mask_feat_tok.shape[1]), dtype=d.dtype, device=d.device)
+            for b in range(B):
+                sp = None if mask_feat_split is None else (mask_feat_split[0][b], mask_feat_split[1][b])
+                ops.linear(mask_embed[b].detach(), mask_feat_tok[b].detach(), out=dense[b], w_split=sp,
+                           allow_small=False)
+            dense = dense.view(B, Q, *vol_shape)
+            am = None
+            if want_attn:
+                _, blocked, row_open = ops.mask_pool(dense, target_shape)
+                am = (blocked, row_open)
+        return cls_pred, LazyMask(dense, mask_embed, mask_feat_tok), am
+
     def _project_level_tokens(self, keys, keys_pp):
         """Key / value projections of the cross-attentions (mask2former_nusc_occ.py:657-667 via
         nn.MultiheadAttention's in_proj): layers lv, lv + n_levels, ... attend to the same level tokens, so their
@@ -186,7 +229,8 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
         layers = self.transformer_decoder.layers
         E = self.decoder_embed_dims
         B = keys[0].shape[0]
-        if B != 1 or len(layers) % nl or ops.precision == "f32" or os.environ.get("OCCF_STACK_KV", "1") != "1":
+        if B != 1 or len(layers) % nl or ops.precision == "f32" or os.environ.get("OCCF_STACK_KV", "1") != "1" or \
+                self.training:
             return None
         params = [l.attentions[0].attn.in_proj_weight for l in layers] + \
                  [l.attentions[0].attn.in_proj_bias for l in layers]
@@ -237,7 +281,10 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
         q = self.query_feat.weight.unsqueeze(0).expand(B, -1, -1)
         qpos = self.query_embed.weight.unsqueeze(0).expand(B, -1, -1)
         # the mask features are the "weight" of ten contractions: split them to bf16 (hi, lo) once
-        mf_split = None if get_ops().precision == "f32" else get_ops().split_bf16(mask_tok)
+        mf_split = None if get_ops().precision == "f32" else get_ops().split_bf16(mask_tok.detach().contiguous())
+        if self.training:
+            last_only = False
+            mask_tok = mask_tok.contiguous()
         n_layers = len(self.transformer_decoder.layers)
         cls_list, mask_list = [], []
         cls, mp, am = self.forward_head(q, mask_tok, vol_shape, shapes[0], mf_split, want_mask=not last_only)

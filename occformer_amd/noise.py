@@ -1,0 +1,40 @@
+"""Noise source of the training step.  Every stochastic op of the path's training forward -- DropPath of the shared
+SwinBlock (window_attention.py:311,332), the Dropout of the BEV ASPP (aspp.py:103,122) and of DepthNet's ASPP
+(ViewTransformerLSSBEVDepth.py:407), the point / class-guided sampling of the occupancy heads (mmdet_utils.py:91-246)
+-- draws from ONE injectable object with ``rand`` / ``randperm`` / ``exponential`` methods, in a fixed call order,
+so that a step is reproducible and can be replayed against the CPU oracle on identical draws (bitwise parity with
+torch's own generator streams is not defined across devices)."""
+import torch
+
+_rng = None
+
+
+def set_rng(rng):
+    """install a noise source (None = a seeded device generator created on first use)"""
+    global _rng
+    _rng = rng
+
+
+def get_rng(device):
+    global _rng
+    if _rng is None:
+        from .training import DeviceRNG
+        _rng = DeviceRNG(device)
+    return _rng
+
+
+def drop_path_scale(n_samples, drop_prob, device):
+    """mmcv DropPath: per sample floor(keep + U) / keep; None when the op is the identity"""
+    if drop_prob <= 0.0:
+        return None
+    keep = 1.0 - drop_prob
+    u = get_rng(device).rand(n_samples).to(device=device, dtype=torch.float32)
+    return torch.floor(keep + u) / keep
+
+
+def dropout_mask(shape, p, device):
+    """nn.Dropout as an explicit mask: (U >= p) / (1 - p), drawn in the REFERENCE's tensor layout ``shape``"""
+    if p <= 0.0:
+        return None
+    u = get_rng(device).rand(*shape).to(device=device, dtype=torch.float32)
+    return (u >= p).float() / (1.0 - p)

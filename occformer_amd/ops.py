@@ -286,7 +286,7 @@ class HipOps:
             if t is not None and (t.stride(1) != 1 or (self.strict and not t.is_cuda)):
                 raise OccfError("linear: rows must be channel-contiguous GPU tensors")
         rp = ctypes.c_void_p(r2.data_ptr()) if r2 is not None else ctypes.c_void_p(0)
-        if head_major is None and allow_small and M <= 128 and M * N <= 262144 and K % 4 == 0:
+        if head_major is None and M * N <= 262144 and ((allow_small and M <= 128) or K % 4 != 0 or x2.stride(0) % 4 != 0):
             self._call("occf_linear_small_fwd", ctypes.c_void_p(x2.data_ptr()), self._ptr(weight, self.f32),
                        self._ptr(bias), rp, ctypes.c_void_p(out.data_ptr()), M, N, K, x2.stride(0),
                        out.stride(0), r2.stride(0) if r2 is not None else 0, int(act), self._stream())
@@ -611,13 +611,18 @@ class HipOps:
                    self._stream())
         return dc
 
-    def point_sample_3d_backward(self, dout, pts, vol_shape, align_corners=False, padding_mode="zeros"):
+    def point_sample_3d_backward(self, dout, pts, vol_shape, align_corners=False, padding_mode="zeros",
+                                 voxel_major_cols=0):
+        """-> dvol [N, C, X, Y, Z], or with ``voxel_major_cols`` = ld > 0 the voxel-major [X*Y*Z, ld] (column n*C+c,
+        the columns beyond N*C stay zero)"""
         N, C, X, Y, Z = vol_shape
         P = pts.shape[1]
         shared = pts.shape[0] == 1 and N > 1
-        dvol = torch.zeros(tuple(vol_shape), dtype=self.f32, device=dout.device)
+        shape = (X * Y * Z, int(voxel_major_cols)) if voxel_major_cols else tuple(vol_shape)
+        dvol = torch.zeros(shape, dtype=self.f32, device=dout.device)
         self._call("occf_point_sample_3d_bwd", self._ptr(dout, self.f32), self._ptr(pts, self.f32), self._ptr(dvol),
-                   N, C, X, Y, Z, P, int(shared), int(align_corners), int(padding_mode == "border"), self._stream())
+                   N, C, X, Y, Z, P, int(shared), int(align_corners), int(padding_mode == "border"),
+                   int(voxel_major_cols), self._stream())
         return dvol
 
     def point_loss_rows_backward(self, logits, targets, grad_rows):

@@ -13,6 +13,7 @@ import math
 import torch
 import torch.nn as nn
 
+from . import autograd as A
 from . import fused
 from .encoder import _FFN
 from .ops import get_ops
@@ -107,7 +108,8 @@ class MultiScaleDeformableAttention3D(nn.Module):
 
     def forward(self, query, query_pos, level_shapes):
         """query/query_pos [B, Nq, E]; queries are the cells of ``level_shapes`` in order."""
-        fused.require_eval(self)
+        if self.training:
+            return self._forward_train(query, query_pos, level_shapes)
         ops = get_ops()
         B, Nq, E = query.shape
         dh = E // self.num_heads
@@ -132,6 +134,18 @@ class MultiScaleDeformableAttention3D(nn.Module):
         return fused.linear(out, self.output_proj, residual=query)       # dropout = identity (eval)
 
 
+    def _forward_train(self, query, query_pos, level_shapes):
+        """differentiable graph of forward / backward kernel pairs (occformer_amd/autograd.py)"""
+        if self.dropout.p > 0:
+            raise NotImplementedError("MultiScaleDeformableAttention3D dropout > 0 (every OccFormer config uses 0.0)")
+        qp = query + query_pos
+        ol = torch.cat((A.linear(qp, self.sampling_offsets), A.linear(qp, self.attention_weights)), -1)
+        value = A.linear(query, self.value_proj)
+        out = A.MSDA.apply(value, ol, self.sampling_offsets.out_features, tuple(level_shapes), self.num_heads,
+                           self.num_points)
+        return A.linear(out, self.output_proj, residual=query)
+
+
 class _EncoderLayer(nn.Module):
     """mmcv BaseTransformerLayer with operation_order ('self_attn','norm','ffn','norm')."""
 
@@ -144,8 +158,12 @@ class _EncoderLayer(nn.Module):
         self.norms = nn.ModuleList([nn.LayerNorm(embed_dims), nn.LayerNorm(embed_dims)])
 
     def forward(self, x, pos, level_shapes):
-        x = fused.layernorm(self.attentions[0](x, pos, level_shapes), self.norms[0])
         ffn = self.ffns[0].layers
+        if self.training:
+            x = A.layernorm(self.attentions[0](x, pos, level_shapes), self.norms[0])
+            y = A.linear(A.linear(x, ffn[0][0], act=1), ffn[1], residual=x)
+            return A.layernorm(y, self.norms[1])
+        x = fused.layernorm(self.attentions[0](x, pos, level_shapes), self.norms[0])
         return fused.mlp(x, ffn[0][0], ffn[1], act=1, ln=self.norms[1], ln_mode=2)
 
 
@@ -172,6 +190,8 @@ class _ConvModule(nn.Module):
 
     def forward(self, x_cl):
         """channels-last [B, X, Y, Z, Cin] -> contiguous [B, X, Y, Z, Cout]"""
+        if self.training:
+            return A.conv_gn(x_cl, self.conv, self.gn, relu=self.act)
         return fused.conv_gn(x_cl, self.conv, self.gn, relu=self.act)
 
 
@@ -222,7 +242,6 @@ class MSDeformAttnPixelDecoder3D(nn.Module):
             layer.attentions[0].init_weights()
 
     def forward(self, feats):
-        fused.require_eval(self)
         ops = get_ops()
         B = feats[0].shape[0]
         n_in, n_enc = self.num_input_levels, self.num_encoder_levels
@@ -239,10 +258,13 @@ class MSDeformAttnPixelDecoder3D(nn.Module):
         x = torch.cat(toks, 1).contiguous()
         lw = self.level_encoding.weight
         pkey = (tuple(shapes), B, lw._version, lw.data_ptr(), str(x.device))
-        if getattr(self, "_pos_cache_key", None) != pkey:
-            self._pos_cache = torch.cat(poss, 1).contiguous()
-            self._pos_cache_key = pkey
-        pos = self._pos_cache
+        if self.training:
+            pos = torch.cat(poss, 1).contiguous()        # carries the level-encoding gradient
+        else:
+            if getattr(self, "_pos_cache_key", None) != pkey:
+                self._pos_cache = torch.cat(poss, 1).contiguous().detach()
+                self._pos_cache_key = pkey
+            pos = self._pos_cache
         for layer in self.encoder.layers:
             x = layer(x, pos, shapes)
         outs, start = [], 0
@@ -252,8 +274,8 @@ class MSDeformAttnPixelDecoder3D(nn.Module):
             start += n
         for j, i in enumerate(range(n_in - n_enc - 1, -1, -1)):
             cur = self.lateral_convs[j](feats_cl[i])
-            y = ops.upsample_add(outs[-1].contiguous(), cur)
+            y = A.UpsampleAdd.apply(outs[-1], cur) if self.training else ops.upsample_add(outs[-1].contiguous(), cur)
             outs.append(self.output_convs[j](y))
-        outs[-1] = fused.conv(outs[-1], self.mask_feature)
+        outs[-1] = A.conv(outs[-1], self.mask_feature) if self.training else fused.conv(outs[-1], self.mask_feature)
         # logical [B, E, X, Y, Z] views over channels-last memory, fine -> coarse
         return [o.permute(0, 4, 1, 2, 3) for o in outs[::-1]]

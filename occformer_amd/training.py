@@ -25,6 +25,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import autograd as A
 from . import dist_utils
 from .ops import get_ops
 
@@ -51,6 +52,68 @@ class DeviceRNG:
 
     def exponential(self, shape, dtype=torch.float32):
         return torch.empty(tuple(shape), device=self.device, dtype=torch.float32).exponential_(1, generator=self.gen)
+
+
+# ------------------------------------------------------------------------------------------ lazy mask logits
+class LazyMask:
+    """The mask logits of one prediction set in the training step: ``dense`` [B, Q, X, Y, Z] are the materialised,
+    DETACHED logits (what target assignment, importance sampling and the attention masks read -- none of them
+    carries a gradient in the reference either); the differentiable route to the parameters goes through
+    ``embed`` [B, Q, E] (mask_embed output) and ``feat_tok`` [B, V, E] (channels-last mask features) by
+    ``autograd.SampledMaskLogits``: einsum('bqc,bcxyz->bqxyz') followed by point sampling is linear in both, so the
+    dense [B, Q, X, Y, Z] gradient of the reference never has to exist.  Indexing by image gives the per-image view."""
+
+    def __init__(self, dense, embed, feat_tok):
+        self.dense, self.embed, self.feat_tok = dense, embed, feat_tok
+
+    @property
+    def shape(self):
+        return self.dense.shape
+
+    def __getitem__(self, b):
+        return LazyMask(self.dense[b], self.embed[b], self.feat_tok[b])
+
+    def rows(self, idx_per_image):
+        """matched rows: idx_per_image[b] = query indices of image b (ascending) -> LazyRows"""
+        return LazyRows([self.dense[b][i] for b, i in enumerate(idx_per_image)],
+                        [self.embed[b][i] for b, i in enumerate(idx_per_image)],
+                        [self.feat_tok[b] for b in range(len(idx_per_image))])
+
+
+class LazyRows:
+    """selected rows of a LazyMask, image by image"""
+
+    def __init__(self, dense, embed, feat_tok):
+        self.dense_list, self.embed_list, self.feat_list = dense, embed, feat_tok
+        self.dense = torch.cat(dense, 0)                       # [n_pos, X, Y, Z] detached
+
+    @property
+    def shape(self):
+        return self.dense.shape
+
+    def sample(self, coords, align_corners, padding_mode):
+        """coords [n_pos, P, 3] (grid_sample order) -> logits [n_pos, P] with the gradient route"""
+        out, r0 = [], 0
+        for d, e, f in zip(self.dense_list, self.embed_list, self.feat_list):
+            n = d.shape[0]
+            if n:
+                out.append(A.SampledMaskLogits.apply(d, e, f, coords[r0:r0 + n], align_corners, padding_mode))
+            r0 += n
+        return torch.cat(out, 0)
+
+
+def _dense(mp):
+    return mp.dense if isinstance(mp, (LazyMask, LazyRows)) else mp.detach()
+
+
+def sample_logits(mp, coords, align_corners=False, padding_mode="zeros"):
+    """point_sample_3d(mp.unsqueeze(1), coords).squeeze(1) for rows ``mp`` [n, X, Y, Z] (tensor or LazyRows), with
+    the backward kernels attached when a gradient is wanted"""
+    if isinstance(mp, LazyRows):
+        return mp.sample(coords, align_corners, padding_mode)
+    if mp.requires_grad and torch.is_grad_enabled():
+        return A.PointSample3d.apply(mp.unsqueeze(1), coords, align_corners, padding_mode).squeeze(1)
+    return point_sample_3d(mp.unsqueeze(1), coords, align_corners, padding_mode).squeeze(1)
 
 
 # ------------------------------------------------------------------------------------------ helpers
@@ -238,7 +301,10 @@ def point_mask_losses(point_preds, point_targets, mask_weights, num_points, dice
     """BCE (mmdet CrossEntropyLoss use_sigmoid) and naive Dice (dice_loss.py:8-61) over sampled points from one
     pass of row sums.  ``weight_bce_rows``: KITTI weights the BCE rows by the class weight
     (mask2former_occ.py:433-442); nuScenes divides by sum(w)*P only (mask2former_nusc_occ.py:411-417)."""
-    rows = get_ops().point_loss_rows(point_preds.contiguous(), point_targets.float().contiguous())
+    if point_preds.requires_grad and torch.is_grad_enabled():
+        rows = A.PointLossRows.apply(point_preds, point_targets.float())
+    else:
+        rows = get_ops().point_loss_rows(point_preds.contiguous(), point_targets.float().contiguous())
     # reduce_mean(mask_weights.sum()) across ranks (mask2former_nusc_occ.py:408; mask2former_occ.py:425,437)
     total = dist_utils.reduce_mean(mask_weights.sum().detach()).clamp_min(1e-12)
     d = (2 * rows[:, 1] + dice_eps) / (rows[:, 2] + rows[:, 3] + dice_eps)
@@ -313,9 +379,10 @@ class OccHeadTrainingMixin:
             self.importance_sample_ratio = train_cfg.get("importance_sample_ratio", 0.75)
 
     def _rng(self, device):
-        if self.rng is None:
-            self.rng = DeviceRNG(device)
-        return self.rng
+        if self.rng is not None:
+            return self.rng
+        from . import noise
+        return noise.get_rng(device)
 
     def preprocess_gt(self, gt_occ, img_metas):
         pairs = [preprocess_occupancy_gt(g, self.num_occupancy_classes) for g in gt_occ]
@@ -334,7 +401,7 @@ class OccHeadTrainingMixin:
         labels = gt_labels.new_full((self.num_queries,), self.num_classes, dtype=torch.long)
         labels[pos] = gt_labels[pos_gt]
         cw = torch.tensor(self.class_weight, dtype=cls_score.dtype, device=cls_score.device)
-        mask_weights = mask_pred.new_zeros((self.num_queries,))
+        mask_weights = cls_score.new_zeros((self.num_queries,))
         mask_weights[pos] = cw[labels[pos]]
         return labels, torch.ones_like(mask_weights), gt_masks[pos_gt], mask_weights, pos, pos_gt
 
@@ -390,7 +457,11 @@ class OccHeadTrainingMixin:
             # ascending order = targets[b][4]; gather by index (no boolean-mask size query on the host)
             B, Q = mask_weights.shape
             idx = torch.cat([t[4] + b * Q for b, t in enumerate(targets)])
+            if isinstance(mask_preds, LazyMask):
+                return loss_cls, mask_preds.rows([t[4] for t in targets]), mask_weights.flatten()[idx], mask_targets
             return loss_cls, mask_preds.flatten(0, 1)[idx], mask_weights.flatten()[idx], mask_targets
+        if isinstance(mask_preds, LazyMask):
+            raise NotImplementedError("zero class weights with lazy mask logits")
         sel = mask_weights > 0
         return loss_cls, mask_preds[sel], mask_weights[sel], mask_targets
 
@@ -406,6 +477,7 @@ class NuscTrainingMixin(OccHeadTrainingMixin):
         if n_lidar < coords.shape[0]:
             coords = coords[rng.randperm(coords.shape[0]).to(coords.device)[:n_lidar]]
         coords = torch.cat((coords, rng.rand(self.num_points - n_lidar, 3).to(coords)), 0)[:, [2, 1, 0]]
+        cls_score, mask_pred = cls_score.detach(), _dense(mask_pred)        # targets carry no gradient
         pred_pts = point_sample_3d(mask_pred[None], coords[None], padding_mode=self.padding_mode)[0]
         if gt_labels.shape[0]:
             gt_pts = point_sample_3d(gt_masks[None].float(), coords[None], padding_mode=self.padding_mode)[0]
@@ -416,17 +488,21 @@ class NuscTrainingMixin(OccHeadTrainingMixin):
 
     def loss_single(self, cls_scores, mask_preds, gt_labels_list, gt_masks_list, gt_lidarseg_list, img_metas=None):
         """mask2former_nusc_occ.py:317-424"""
-        targets = [self._get_target_single(cls_scores[i], mask_preds[i], gt_labels_list[i], gt_masks_list[i],
-                                           gt_lidarseg_list[i]) for i in range(cls_scores.shape[0])]
+        with torch.no_grad():
+            targets = [self._get_target_single(cls_scores[i], mask_preds[i], gt_labels_list[i], gt_masks_list[i],
+                                               gt_lidarseg_list[i]) for i in range(cls_scores.shape[0])]
         loss_cls, mp, mw, mask_targets = self._cls_and_select(cls_scores, mask_preds, targets)
         if mask_targets.shape[0] == 0:
-            return loss_cls, mp.sum(), mp.sum()
-        coords = get_nusc_lidarseg_point_coords(mp.unsqueeze(1), gt_lidarseg_list, gt_labels_list, self.num_points,
-                                                self.oversample_ratio, self.importance_sample_ratio,
-                                                self.point_cloud_range, self._rng(mp.device),
-                                                padding_mode=self.padding_mode)[..., [2, 1, 0]]
-        pp = point_sample_3d(mp.unsqueeze(1), coords, padding_mode=self.padding_mode).squeeze(1)
-        pt = point_sample_3d(mask_targets.unsqueeze(1).float(), coords, padding_mode=self.padding_mode).squeeze(1)
+            z = cls_scores.sum() * 0
+            return loss_cls, z, z
+        with torch.no_grad():
+            mpd = _dense(mp)
+            coords = get_nusc_lidarseg_point_coords(mpd.unsqueeze(1), gt_lidarseg_list, gt_labels_list, self.num_points,
+                                                    self.oversample_ratio, self.importance_sample_ratio,
+                                                    self.point_cloud_range, self._rng(mpd.device),
+                                                    padding_mode=self.padding_mode)[..., [2, 1, 0]].contiguous()
+            pt = point_sample_3d(mask_targets.unsqueeze(1).float(), coords, padding_mode=self.padding_mode).squeeze(1)
+        pp = sample_logits(mp, coords, False, self.padding_mode)
         loss_mask, loss_dice = point_mask_losses(pp, pt, mw, self.num_points, self.dice_eps, self.w_mask,
                                                  self.w_dice, weight_bce_rows=False)
         return loss_cls, loss_mask, loss_dice
@@ -440,11 +516,13 @@ class NuscTrainingMixin(OccHeadTrainingMixin):
         return {"point_mean_iou": mean_iou_device(fast_hist_crop_device(out, tgt, 16))}
 
     def forward_train(self, voxel_feats, img_metas, gt_occ, points=None, **kwargs):
-        """mask2former_nusc_occ.py:547-587 (forward values; no autograd graph is built by the HIP modules)"""
+        """mask2former_nusc_occ.py:547-587.  In train() mode the head's forward builds the differentiable graph
+        (occformer_amd/autograd.py) and the returned losses carry grad_fn; in eval() mode these are loss VALUES."""
         all_cls, all_masks = self(voxel_feats, img_metas)
         gt_labels, gt_masks = self.preprocess_gt(gt_occ, img_metas)
         losses = self.loss(all_cls, all_masks, gt_labels, gt_masks, points, img_metas)
-        losses.update(self.lidarseg_metric(all_cls[-1], all_masks[-1], points, img_metas))
+        with torch.no_grad():
+            losses.update(self.lidarseg_metric(all_cls[-1].detach(), _dense(all_masks[-1]), points, img_metas))
         return losses
 
 
@@ -463,6 +541,7 @@ class KittiTrainingMixin(OccHeadTrainingMixin):
         gt_labels = gt_labels.long()
         idx, coords = sample_valid_coords_with_frequencies(self.num_points, gt_labels, gt_masks, self.sample_weights,
                                                            self._rng(cls_score.device))
+        cls_score, mask_pred = cls_score.detach(), _dense(mask_pred)        # targets carry no gradient
         pred_pts = point_sample_3d(mask_pred[None], coords[..., [2, 1, 0]], align_corners=self.align_corners)[0]
         gt_pts = gt_masks.reshape(gt_masks.shape[0], -1)[:, idx].float()
         gt_inds, cost = self.assigner.assign(cls_score, pred_pts, gt_labels, gt_pts, img_metas)
@@ -470,16 +549,20 @@ class KittiTrainingMixin(OccHeadTrainingMixin):
 
     def loss_single(self, cls_scores, mask_preds, gt_labels_list, gt_masks_list, img_metas=None):
         """mask2former_occ.py:343-444"""
-        targets = [self._get_target_single(cls_scores[i], mask_preds[i], gt_labels_list[i], gt_masks_list[i])
-                   for i in range(cls_scores.shape[0])]
+        with torch.no_grad():
+            targets = [self._get_target_single(cls_scores[i], mask_preds[i], gt_labels_list[i], gt_masks_list[i])
+                       for i in range(cls_scores.shape[0])]
         loss_cls, mp, mw, mask_targets = self._cls_and_select(cls_scores, mask_preds, targets)
         if mask_targets.shape[0] == 0:
-            return loss_cls, mp.sum(), mp.sum()
-        idx, coords = get_uncertain_point_coords_3d_with_frequency(
-            mp.unsqueeze(1), None, gt_labels_list, gt_masks_list, self.sample_weights, self.num_points,
-            self.oversample_ratio, self.importance_sample_ratio, self._rng(mp.device))
-        pt = torch.gather(mask_targets.reshape(mask_targets.shape[0], -1), 1, idx).float()
-        pp = point_sample_3d(mp.unsqueeze(1), coords[..., [2, 1, 0]], align_corners=self.align_corners).squeeze(1)
+            z = cls_scores.sum() * 0
+            return loss_cls, z, z
+        with torch.no_grad():
+            mpd = _dense(mp)
+            idx, coords = get_uncertain_point_coords_3d_with_frequency(
+                mpd.unsqueeze(1), None, gt_labels_list, gt_masks_list, self.sample_weights, self.num_points,
+                self.oversample_ratio, self.importance_sample_ratio, self._rng(mpd.device))
+            pt = torch.gather(mask_targets.reshape(mask_targets.shape[0], -1), 1, idx).float()
+        pp = sample_logits(mp, coords[..., [2, 1, 0]].contiguous(), self.align_corners, "zeros")
         loss_mask, loss_dice = point_mask_losses(pp, pt, mw, self.num_points, self.dice_eps, self.w_mask,
                                                  self.w_dice, weight_bce_rows=True)
         return loss_cls, loss_mask, loss_dice

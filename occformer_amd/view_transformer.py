@@ -126,7 +126,13 @@ class _ImageASPP(nn.Module):
     def forward(self, x):
         g = self.global_avg_pool(x).expand(-1, -1, *x.shape[2:])
         y = torch.cat((self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), g), 1)
-        return self.dropout(F.relu(self.bn1(self.conv1(y))))
+        y = F.relu(self.bn1(self.conv1(y)))
+        if self.training:
+            # nn.Dropout(0.5) as an explicit mask from the injectable noise source (occformer_amd/noise.py)
+            from . import noise
+            mask = noise.dropout_mask(tuple(y.shape), self.dropout.p, y.device)
+            return y if mask is None else y * mask
+        return y
 
     def forward_cl(self, x_cl):
         """channels-last [BN, H, W, 1, C] (eval: dropout is the identity)"""
@@ -201,6 +207,11 @@ class DeformConv2dPack(nn.Module):
         ops = get_ops()
         B, C, H, W = x.shape
         k, pad, G = self.k, self.padding, self.groups
+        if self.training:
+            from . import autograd as A
+            out = A.DeformConv.apply(x.permute(0, 2, 3, 1), self.conv_offset(x), self.weight, k, pad, G,
+                                     self.deform_groups)
+            return out.view(B, H, W, -1).permute(0, 3, 1, 2)
         offset = self.conv_offset(x).contiguous()
         col = ops.deform_im2col(x.permute(0, 2, 3, 1).contiguous(), offset, k, 1, pad, 1, G, self.deform_groups)
         Cout = self.weight.shape[0]

@@ -157,8 +157,49 @@ def lift_splat(depth_prob, img_feat, geom, dx, bx, nx):
     return out.permute(0, 4, 2, 3, 1).contiguous()                    # [B,C,X,Y,Z]
 
 
+# ---------------------------------------------------------------------------- training mode
+# The functions below restate the modules' eval-mode forward; inside ``training_mode(...)`` they restate the
+# train-mode forward of the reference's training step (occupancyformer.py:132-199): BatchNorm on batch statistics,
+# DropPath in the SwinBlock (window_attention.py:311,332; mmcv DropPath: floor(keep + U) / keep per sample),
+# Dropout in the two ASPPs (aspp.py:103,122; ViewTransformerLSSBEVDepth.py:407) as explicit masks (U >= p) / (1 - p).
+# All noise comes from ``rng.rand`` in call order (oracle/occformer_train_ref.GlobalTorchRNG or a recording
+# subclass), so that the product can replay the identical draws.
+_TRAIN = None
+
+
+class training_mode:
+    def __init__(self, rng, drop_path=0.2, aspp_drop=0.1, depth_aspp_drop=0.5):
+        self.cfg = dict(rng=rng, drop_path=drop_path, aspp_drop=aspp_drop, depth_aspp_drop=depth_aspp_drop)
+
+    def __enter__(self):
+        global _TRAIN
+        self.prev, _TRAIN = _TRAIN, self.cfg
+        return self
+
+    def __exit__(self, *exc):
+        global _TRAIN
+        _TRAIN = self.prev
+
+
+def _drop_path(x, p):
+    """mmcv DropPath on x [Bp, ...]"""
+    if _TRAIN is None or p <= 0:
+        return x
+    keep = 1.0 - p
+    u = _TRAIN["rng"].rand(x.shape[0])
+    return x * (torch.floor(keep + u) / keep).view(-1, *([1] * (x.dim() - 1)))
+
+
+def _dropout(x, p):
+    if _TRAIN is None or p <= 0:
+        return x
+    return x * ((_TRAIN["rng"].rand(*x.shape) >= p).float() / (1.0 - p))
+
+
 # ---------------------------------------------------------------------------- DepthNet (row 2)
 def _bn(sd, p, x, eps=1e-5):
+    if _TRAIN is not None:
+        return F.batch_norm(x, None, None, sd[p + "weight"], sd[p + "bias"], True, 0.0, eps)
     return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"],
                         sd[p + "bias"], False, 0.0, eps)
 
@@ -228,7 +269,7 @@ def _aspp2d_bn(sd, p, x):
     g = F.relu(_bn(sd, p + "global_avg_pool.2.", _conv2d(sd, p + "global_avg_pool.1.", g)))
     outs.append(g.expand(-1, -1, *x.shape[2:]))
     y = _conv2d(sd, p + "conv1.", torch.cat(outs, 1))
-    return F.relu(_bn(sd, p + "bn1.", y))
+    return _dropout(F.relu(_bn(sd, p + "bn1.", y)), _TRAIN["depth_aspp_drop"] if _TRAIN else 0.0)
 
 
 def _se(sd, p, x, x_se):
@@ -244,9 +285,7 @@ def _cam_mlp(sd, p, x):
 def depthnet(sd, p, x, mlp_input, dcn_groups=4):
     """ViewTransformerLSSBEVDepth.py:450-504 (DepthNet.forward), eval-mode BN.
     x [B*N, Cin, fH, fW] -> [B*N, D + C, fH, fW] (depth logits first, then context)."""
-    m = F.batch_norm(mlp_input.reshape(-1, mlp_input.shape[-1]), sd[p + "bn.running_mean"],
-                     sd[p + "bn.running_var"], sd[p + "bn.weight"], sd[p + "bn.bias"],
-                     False, 0.0, 1e-5)
+    m = _bn(sd, p + "bn.", mlp_input.reshape(-1, mlp_input.shape[-1]))
     x = F.relu(_bn(sd, p + "reduce_conv.1.", _conv2d(sd, p + "reduce_conv.0.", x, padding=1)))
     ctx = _se(sd, p + "context_se.", x, _cam_mlp(sd, p + "context_mlp.", m)[..., None, None])
     ctx = _conv2d(sd, p + "context_conv.", ctx)
@@ -341,10 +380,11 @@ def swin_block(sd, p, x, heads, shift, ws=7):
     Bp, C, H, W = x.shape
     t = x.permute(0, 2, 3, 1).reshape(Bp, H * W, C)
     y = F.layer_norm(t, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5)
-    t = t + shift_window_msa(sd, p + "attn.", y, H, W, heads, ws // 2 if shift else 0, ws)
+    dp = _TRAIN["drop_path"] if _TRAIN else 0.0
+    t = t + _drop_path(shift_window_msa(sd, p + "attn.", y, H, W, heads, ws // 2 if shift else 0, ws), dp)
     y = F.layer_norm(t, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)
     y = _linear(sd, p + "ffn.layers.1.", F.gelu(_linear(sd, p + "ffn.layers.0.0.", y)))
-    t = t + y
+    t = t + _drop_path(y, dp)
     return t.view(Bp, H, W, C).permute(0, 3, 1, 2).contiguous()
 
 
@@ -370,7 +410,7 @@ def bottleneck_aspp(sd, p, x, groups=32):
     g = F.relu(_gn(sd, a + "global_avg_pool.2.", _conv2d(sd, a + "global_avg_pool.1.", g), g_aspp))
     outs.append(g.expand(-1, -1, *y.shape[2:]))
     z = F.relu(_gn(sd, a + "bn1.", _conv2d(sd, a + "conv1.", torch.cat(outs, 1)), g_aspp))
-    y = y + z
+    y = y + _dropout(z, _TRAIN["aspp_drop"] if _TRAIN else 0.0)
     y = F.relu(_gn(sd, p + "output_conv.1.", _conv2d(sd, p + "output_conv.0.", y), groups))
     return x + y
 

