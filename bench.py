@@ -65,8 +65,8 @@ class KernelCensus:
                 tensors = [t for t in list(a) + list(kw.values()) + list(outs) if torch.is_tensor(t)]
                 nbytes = sum(t.numel() * t.element_size() for t in {t.data_ptr(): t for t in tensors}.values())
                 self.records.setdefault(_name, []).append((e0, e1, nbytes, self.ops.last_flops))
-                if _name in ("linear", "conv3d"):
-                    shp = (tuple(a[0].shape), tuple(a[1].shape))
+                if _name in ("linear", "conv3d", "conv3d_wgrad", "conv3d_dgrad"):
+                    shp = (tuple(a[0].shape), tuple(a[1].shape) if torch.is_tensor(a[1]) else tuple(a[2]))
                     self.shapes.setdefault((_name, shp), []).append((e0, e1, self.ops.last_flops))
                 return out
 
@@ -117,8 +117,9 @@ def pmc_traffic(kernel_substr, grid_size):
 
 
 def roofline(timed_census, kernels, prec, steps):
-    """The dominant kernel = the (op, shape) with the largest total time among the convolution launches of the
-    timed region (HIP events on the launching stream); priced on ALGORITHMIC flops against the dense MFMA peak."""
+    """The dominant kernel = the (op, shape) with the largest total time among the convolution launches (forward,
+    data gradient, weight gradient) of the timed region (HIP events on the launching stream); priced on ALGORITHMIC
+    flops against the dense MFMA peak."""
     torch.cuda.synchronize()
     best = None
     for (name, shp), recs in timed_census.shapes.items():
@@ -131,34 +132,44 @@ def roofline(timed_census, kernels, prec, steps):
     avg_ms = tot / len(ms)
     achieved = flops / (avg_ms * 1e-3) / 1e12
     peak = F32_MFMA_PEAK_TF if prec == "f32" else BF16_MFMA_PEAK_TF
-    B, X, Y, Z, Cin = shp[0]
-    Cout = shp[1][0]
-    halo = shp[1][1] == 27 * Cin and Cin % 32 == 0 and prec != "f32"
-    kname = (f"conv3x3x3_halo_kernel<{2 if Cout % 128 == 0 else 3 if Cout % 192 == 0 else 1}, "
-             f"{3 if prec == 'bf16x3' else 1}>") if halo else "gemm_bf16_kernel"
-    traffic, src = (None, None)
-    if halo:
-        tz = 16 if Z >= 16 else Z
-        ty = 128 // tz
-        bn = 128 if Cout % 128 == 0 else 192 if Cout % 192 == 0 else 64
-        grid = B * ((X + 1) // 2) * ((Y + ty - 1) // ty) * (Z // tz) * ((Cout + bn - 1) // bn) * 512
-        traffic, src = pmc_traffic(kname, grid)
-    return {"bound": "mfma", "kernel": f"{kname}  [{name} x{list(shp[0])} w{list(shp[1])}]", "achieved": achieved,
+    terms = 3 if prec == "bf16x3" else 1
+    traffic, src, nbytes = None, None, None
+    if name == "conv3d":
+        B, X, Y, Z, Cin = shp[0]
+        Cout = shp[1][0]
+        halo = shp[1][1] == 27 * Cin and Cin % 32 == 0 and prec != "f32"
+        kname = (f"conv3x3x3_halo_kernel<{2 if Cout % 128 == 0 else 3 if Cout % 192 == 0 else 1}, {terms}>"
+                 if halo else "gemm_bf16_kernel<CONV>")
+        nbytes = 4 * (B * X * Y * Z * (Cin + Cout)) + 4 * Cout * shp[1][1]
+        if halo:
+            tz = 16 if Z >= 16 else Z
+            ty = 128 // tz
+            bn = 128 if Cout % 128 == 0 else 192 if Cout % 192 == 0 else 64
+            grid = B * ((X + 1) // 2) * ((Y + ty - 1) // ty) * (Z // tz) * ((Cout + bn - 1) // bn) * 512
+            traffic, src = pmc_traffic(kname, grid)
+    elif name == "conv3d_wgrad":
+        B, X, Y, Z, Cout = shp[0]
+        Cin = shp[1][-1]
+        kname = f"wgrad_kernel<{128 if Cin % 128 == 0 else 64}, {terms}>"
+        taps = flops // max(2 * B * X * Y * Z * Cout * Cin, 1)
+        nbytes = 4 * (B * X * Y * Z * Cout) + 4 * int(torch.tensor(shp[1]).prod()) + 4 * Cout * taps * Cin
+    else:
+        kname = "gemm_bf16_kernel<CONV, transposed loader>"
+    return {"bound": "mfma", "kernel": f"{kname}  [{name} {list(shp[0])} {list(shp[1])}]", "achieved": achieved,
             "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": src,
             "mfma_products_per_algorithmic_product": {"f32": 1, "bf16x3": 3, "bf16": 1}[prec],
             "avg_kernel_ms": avg_ms, "algorithmic_flops_per_launch": flops, "launches_timed": len(ms),
-            "launches_per_step": len(ms) // max(steps, 1),
-            "algorithmic_bytes_per_launch": 4 * (B * X * Y * Z * (Cin + Cout)) + 4 * Cout * 27 * Cin}
+            "launches_per_step": len(ms) // max(steps, 1), "algorithmic_bytes_per_launch": nbytes}
 
 
 def cpu_baseline(model, meta, img_inputs, points):
     """The oracle (CPU fp32 restatement of the reference path, pinned against the reference's
-    own Python) on the host cores: one sample of the same workload."""
+    own Python) on the host cores: one sample of the same workload, forward."""
     from oracle import occformer_ref as O
+    from occformer_amd import configs
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     x = img_inputs[0].cpu()
     cams = tuple(t.cpu() for t in img_inputs[1:7])
-    from occformer_amd import configs
     cfg = configs.oracle_cfg(meta)
     cores = min(os.cpu_count() or 1, 32)     # torch CPU ops stop scaling (and oversubscribe) beyond this
     torch.set_num_threads(cores)
@@ -169,6 +180,33 @@ def cpu_baseline(model, meta, img_inputs, points):
     return dict(value=1.0 / dt, unit="samples/s", cores=cores, kind="port",
                 sample="1 sample of the same workload (oracle/occformer_ref.occformer_forward, fp32, "
                        f"torch CPU, {cores} threads): {dt:.1f} s"), res
+
+
+def cpu_baseline_train(model, cfg, meta, img_inputs, targets):
+    """The oracle's training step (train-mode forward + torch.autograd backward of the summed losses,
+    oracle/occformer_train_ref.train_step) on the host cores: one sample of the same workload."""
+    from oracle import occformer_train_ref as T
+    gt_occ, points, gt_depths = targets
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    head = cfg["pts_bbox_head"]
+    tc = cfg["train_cfg"]["pts"]
+    ocfg = dict(D=meta["D"], C=meta["C"], groups=32, heads=6, pd_layers=6, dec_layers=9, downsample=16,
+                dbound=cfg["img_view_transformer"]["grid_config"]["dbound"],
+                head=dict(point_cloud_range=head.get("point_cloud_range"), num_points=tc["num_points"],
+                          oversample_ratio=tc["oversample_ratio"], importance_sample_ratio=tc["importance_sample_ratio"],
+                          padding_mode="border", num_classes=head["num_occupancy_classes"],
+                          class_weight=head["loss_cls"]["class_weight"]))
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    t0 = time.perf_counter()
+    losses, grads = T.train_step(sd, img_inputs[0].cpu(), tuple(t.cpu() for t in img_inputs[1:7]), gt_depths.cpu(),
+                                 gt_occ.cpu(), [p.cpu() for p in points], ocfg)
+    dt = time.perf_counter() - t0
+    return dict(value=1.0 / dt, unit="samples/s", cores=cores, kind="port",
+                sample="1 training step (fwd + bwd) of the same workload on the CPU oracle "
+                       f"(oracle/occformer_train_ref.train_step, fp32, torch CPU autograd, {cores} threads): {dt:.1f} s"), \
+        {k: float(v) for k, v in losses.items()}
 
 
 WORKLOAD_DESC = {
@@ -185,6 +223,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="train", choices=["train", "forward"],
+                    help="train (default) = BASELINE.json's metric: forward + backward + gradient all-reduce + clip + "
+                         "AdamW step of OccupancyFormer.forward_train; forward = the inference hot path (simple_test)")
     ap.add_argument("--workload", default="nusc_r50_200",
                     choices=["nusc_r50_200", "nusc_r50_ref128", "kitti_effb7_128", "kitti_effb7_256lit", "nusc_r101"],
                     help="BASELINE.json configs: [2]/[3] nusc_r50_200 (the metric's grid; default), the reference's "
@@ -219,10 +260,14 @@ def main():
     if args.grid:
         args.workload = {"200": "nusc_r50_200", "reference": "nusc_r50_ref128"}[args.grid]
     cfg, meta = configs.workload(args.workload)
-    model = build_model(cfg).eval().to(device)
+    train = args.mode == "train"
+    if train and meta.get("kitti"):
+        cfg["train_cfg"] = dict(pts=configs.train_cfg_pts())
+    model = build_model(cfg).to(device)
     img_inputs, metas, points = synthetic_sample(meta, device, seed=rank)
+    targets = configs.synthetic_targets(meta, device, seed=rank) if train else None
 
-    def step_full():
+    def step_forward():
         with torch.no_grad():
             vox, img_feats, depth = model.extract_feat(None, img_inputs, metas)
             t = model._tick("", 0.0)
@@ -230,65 +275,132 @@ def main():
             model._tick("mask2former_head", t)
             return res
 
-    for _ in range(args.warmup):
-        step_full()
+    census_ops = ("conv3d",)
+    if train:
+        # the reference's training step (P/occformer/apis/mmdet_train.py:72-80, occformer_nusc_r50_256x704.py:284-301):
+        # DDP (gradient all-reduce over RCCL, overlapped with backward), grad-clip 5 (nuScenes) / 20 (KITTI), AdamW
+        model.train()
+        net = model
+        if world > 1:
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
+                                                            gradient_as_bucket_view=True, bucket_cap_mb=64)
+        params = [p for p in model.parameters() if p.requires_grad]
+        try:
+            opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+        except Exception:
+            opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, foreach=True)
+        max_norm = 20.0 if meta.get("kitti") else 5.0
+        gt_occ, gt_points, gt_depths = targets
+        train_inputs = list(img_inputs) + [gt_depths]
+        census_ops = ("conv3d", "conv3d_wgrad", "conv3d_dgrad")
+
+        def step_train():
+            opt.zero_grad(set_to_none=True)
+            losses = net(return_loss=True, img_metas=metas, img_inputs=train_inputs, gt_occ=gt_occ, points_occ=gt_points)
+            total = sum(v for k, v in losses.items() if "loss" in k)
+            total.backward()
+            torch.nn.utils.clip_grad_norm_(params, max_norm)
+            opt.step()
+            return losses
+        step = step_train
+    else:
+        model.eval()
+        step = step_forward
+
+    for i in range(args.warmup):
+        step()
+        if train and i == 0:
+            missing = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
+            if missing:
+                raise SystemExit(f"parameters without a gradient after backward (DDP would stall): {missing[:8]}")
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     # the timed region; the convolution launches (the dominant kernels) carry HIP events on the launching
     # stream so that `roofline` is measured over exactly these K steps
-    with KernelCensus(get_ops(), only=("conv3d",)) as timed_census:
+    with KernelCensus(get_ops(), only=census_ops) as timed_census:
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step_full()
+            last = step()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         dt = time.perf_counter() - t0
     dt = dist_utils.max_over_ranks(dt, device)
+    mem_gb = torch.cuda.max_memory_allocated() / 2 ** 30
 
     # stage timers (the reference's own stage names) + per-kernel census on ONE more step
-    model.record_time = True
+    model.record_time = not train
     model.time_stats.clear()
     with KernelCensus(get_ops()) as census:
-        res_gpu = step_full()
+        res_gpu = step()
     model.record_time = False
     kernels = census.summary()
     if args.shape_report and rank == 0:
         shape_report(census, args.shape_report)
     stages = {k: round(1e3 * sum(v) / len(v), 3) for k, v in model.time_stats.items() if k}
 
+    # the other mode's number from the same process (informational)
+    other = None
+    if train and rank == 0 and world == 1:
+        model.eval()
+        for _ in range(2):
+            step_forward()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step_forward()
+        torch.cuda.synchronize()
+        other = 5.0 / (time.perf_counter() - t1)
+        model.train()
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
     roof = roofline(timed_census, kernels, prec, args.steps)
+    what = "fwd+bwd" if train else "forward"
     out = {
-        "metric": f"samples/sec ({meta['ncams']}-cam frame) forward, {WORKLOAD_DESC[args.workload]}, hot path "
-                  "(LSS voxel pooling -> dual-path encoder -> pixel decoder -> occupancy decoder)",
+        "metric": f"samples/sec ({meta['ncams']}-cam frame) {what}, {WORKLOAD_DESC[args.workload]}, "
+                  + ("training step of the hot path from image-neck features (forward_train + backward + gradient "
+                     "all-reduce + grad-clip + AdamW)" if train else
+                     "hot path (LSS voxel pooling -> dual-path encoder -> pixel decoder -> occupancy decoder)"),
         "value": world * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
         "dtype": {"f32": "f32", "bf16x3": "f32 (contractions as 3-term bf16 split on the bf16 matrix cores, fp32 "
                   "accumulate)", "bf16": "bf16 products, fp32 accumulate"}[prec], "data": "synthetic",
-        "config": {"workload": f"{args.workload}_forward_from_neck_features", "grid": list(meta["grid"]),
-                   "input_size": list(meta["input_size"]), "global_batch": world,
-                   "parallelism": f"dp{world} (independent samples, no data-path collective)"},
+        "config": {"workload": f"{args.workload}_{'train_step' if train else 'forward'}_from_neck_features",
+                   "grid": list(meta["grid"]), "input_size": list(meta["input_size"]), "global_batch": world,
+                   "parallelism": f"dp{world} " + ("(DDP: one RCCL gradient all-reduce per step, bucketed, overlapped "
+                                                   "with backward; BatchNorm on per-rank batch statistics)" if train else
+                                                   "(independent samples, no data-path collective)")},
         "roofline": roof,
         "kernels": {k: {"calls": v["calls"], "total_ms": round(v["total_ms"], 3), "avg_ms": round(v["avg_ms"], 4),
                         "GBps": round(v["bytes_per_call"] / (v["avg_ms"] * 1e-3) / 1e9, 1),
                         "TFLOPs": round(v["flops_per_call"] / (v["avg_ms"] * 1e-3) / 1e12, 2)}
                     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"])},
-        "stages_ms": stages,
+        "stages_ms": stages, "peak_memory_GiB": round(mem_gb, 2),
     }
+    if train:
+        out["losses"] = {k: round(float(v), 5) for k, v in res_gpu.items()}
+        out["forward_samples_per_s_same_run"] = other
     if world == 1 and not args.no_cpu_baseline:
-        base, res_cpu = cpu_baseline(model, meta, img_inputs, points)
-        out["cpu_baseline"] = base
-        if args.check:
-            a, b = res_gpu["output_voxels"][0].cpu(), res_cpu["output_voxels"]
-            out["check"] = {"output_voxels_max_abs_err": float((a - b).abs().max()),
-                            "output_points_max_abs_err": None if res_cpu["output_points"] is None else float(
-                                (res_gpu["output_points"].cpu() - res_cpu["output_points"]).abs().max())}
+        if train:
+            try:
+                out["cpu_baseline"], out["cpu_losses"] = cpu_baseline_train(model, cfg, meta, img_inputs, targets)
+            except (MemoryError, RuntimeError) as e:       # host RAM: fall back to the forward leg
+                base, _ = cpu_baseline(model, meta, img_inputs, points)
+                base["sample"] = "FORWARD ONLY (the CPU training step did not fit: %s); " % type(e).__name__ + base["sample"]
+                out["cpu_baseline"] = base
+        else:
+            base, res_cpu = cpu_baseline(model, meta, img_inputs, points)
+            out["cpu_baseline"] = base
+            if args.check:
+                a, b = res_gpu["output_voxels"][0].cpu(), res_cpu["output_voxels"]
+                out["check"] = {"output_voxels_max_abs_err": float((a - b).abs().max()),
+                                "output_points_max_abs_err": None if res_cpu["output_points"] is None else float(
+                                    (res_gpu["output_points"].cpu() - res_cpu["output_points"]).abs().max())}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -191,3 +191,39 @@ def synthetic_sample(meta, device, seed=0):
     img_inputs = [t.to(device) for t in (x, rots, trans, intr, post_rots, post_trans, bda)]
     metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])]
     return img_inputs, metas, points
+
+
+
+def synthetic_targets(meta, device, seed=0):
+    """ground truth of one synthetic training sample (occupancyformer.py:132-140 inputs): a blocky semantic label
+    volume gt_occ [1, X2, Y2, Z2] (classes 1..16 + 0 = free + 255 = unknown for nuScenes; 0..19 + 255 for KITTI),
+    LiDAR points with labels [P, 4] and sparse LiDAR depth maps gt_depths [1, N, H, W] (0 = no return)."""
+    import torch
+    g = torch.Generator().manual_seed(1000 + seed)
+    X2, Y2, Z2 = meta["occ_size"]
+    ncls = 20 if meta.get("kitti") else 17
+    blk = 16
+    lab = torch.randint(0, ncls + 2, (1, X2 // blk + 1, Y2 // blk + 1, max(Z2 // 8, 1)), generator=g)
+    lab = torch.where(lab >= ncls, torch.full_like(lab, 255 if not meta.get("kitti") else 0), lab)
+    gt_occ = lab.repeat_interleave(blk, 1).repeat_interleave(blk, 2).repeat_interleave(8, 3)[:, :X2, :Y2, :Z2]
+    points = None
+    if meta.get("lidar_points", 0):
+        lo = torch.tensor(meta["pc_range"][:3])
+        hi = torch.tensor(meta["pc_range"][3:])
+        n = meta["lidar_points"]
+        pts = torch.rand(n, 3, generator=g) * (hi - lo) + lo
+        pl = torch.randint(1, 17, (n, 1), generator=g).float()
+        points = [torch.cat((pts, pl), 1).to(device)]
+    H, W = meta["input_size"]
+    d = torch.rand(1, meta["ncams"], H, W, generator=g) * 55.0 + 2.0
+    d = torch.where(torch.rand(1, meta["ncams"], H, W, generator=g) < 0.03, d, torch.zeros_like(d))
+    return gt_occ.contiguous().to(device), points, d.to(device)
+
+
+def train_cfg_pts():
+    """occformer_nusc_r50_256x704.py:191-204 / occformer_kitti.py train_cfg.pts"""
+    return dict(num_points=12544 * 4, oversample_ratio=3.0, importance_sample_ratio=0.75,
+                assigner=dict(type="MaskHungarianAssigner", cls_cost=dict(type="ClassificationCost", weight=2.0),
+                              mask_cost=dict(type="CrossEntropyLossCost", weight=5.0, use_sigmoid=True),
+                              dice_cost=dict(type="DiceCost", weight=5.0, pred_act=True, eps=1.0)),
+                sampler=dict(type="MaskPseudoSampler"))

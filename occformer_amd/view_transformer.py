@@ -261,7 +261,16 @@ class DepthNet(nn.Module):
         """x [BN, C, H, W] -> [BN, D + Cctx, H, W].  Eval mode: channels-last, every convolution on the
         implicit-GEMM kernels with its BatchNorm folded in; training mode keeps the nn.Module graph."""
         if self.training:
-            m = self.bn(mlp_input.reshape(-1, mlp_input.shape[-1]))
+            m = mlp_input.reshape(-1, mlp_input.shape[-1])
+            if m.shape[0] > 1:
+                m = self.bn(m)
+            else:
+                # one camera vector per rank (SemanticKITTI: batch 1, one camera): batch statistics do not exist;
+                # the reference gets them from SyncBatchNorm over the 8 ranks (tools/train.py:221-223) -- with
+                # per-rank statistics (the only collective kept is the gradient all-reduce) this layer uses its
+                # running statistics
+                m = F.batch_norm(m, self.bn.running_mean, self.bn.running_var, self.bn.weight, self.bn.bias, False,
+                                 0.0, self.bn.eps)
             x = self.reduce_conv(x)
             ctx = self.context_conv(self.context_se(x, self.context_mlp(m)[..., None, None]))
             depth = self.depth_conv(self.depth_se(x, self.depth_mlp(m)[..., None, None]))

@@ -373,3 +373,34 @@ def depth_bce_loss(gt_depths, depth_preds, downsample, dbound, D, loss_depth_wei
     fg = lab.max(1).values > 0.0
     loss = F.binary_cross_entropy(pred[fg], lab[fg], reduction="none").sum() / max(1.0, float(fg.sum()))
     return loss_depth_weight * loss
+
+
+# ----------------------------------------------------------------------------------------- one training step
+def train_step(sd, img_feats, cams, gt_depths, gt_occ, points, cfg, rng=None, drop_path=0.2, aspp_drop=0.1,
+               depth_aspp_drop=0.5):
+    """occupancyformer.py:132-199 (forward_train) + loss.backward() on the restated reference path in TRAIN mode
+    (oracle.occformer_ref.training_mode): depth BCE + the ten Hungarian prediction-set losses of the nuScenes head,
+    then torch.autograd of their sum w.r.t. every trainable parameter.
+    cfg: D, C, groups, heads, pd_layers, dec_layers, downsample, dbound, head (= oracle_cfg dict of the head's
+    training rows: point_cloud_range, num_points, oversample_ratio, importance_sample_ratio, padding_mode,
+    num_classes, class_weight).  -> (losses dict, {name: grad})"""
+    from . import occformer_ref as O
+    rng = rng or GlobalTorchRNG()
+    frozen = ("running_mean", "running_var", "num_batches_tracked", ".frustum", ".dx", ".bx", ".nx",
+              "relative_position_index")
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(frozen) else v)
+              for k, v in sd.items()}
+    g = cfg.get("groups", 32)
+    with O.training_mode(rng, drop_path, aspp_drop, depth_aspp_drop):
+        vox, depth = O.view_transformer(params, "img_view_transformer.", img_feats, cams, cfg["D"], cfg["C"])
+        enc = O.occupancy_encoder(params, "img_bev_encoder_backbone.", vox, groups=g)
+        dec = O.pixel_decoder(params, "img_bev_encoder_neck.", enc, groups=g, num_layers=cfg.get("pd_layers", 6))
+        cls_list, mask_list = O.mask2former_head(params, "pts_bbox_head.", dec, heads=cfg.get("heads", 6),
+                                                 num_layers=cfg.get("dec_layers", 9))
+    losses = {"loss_depth": depth_bce_loss(gt_depths, depth, cfg.get("downsample", 16), cfg["dbound"], cfg["D"])}
+    gl, gm = zip(*[preprocess_occupancy_gt(o, cfg["head"]["num_classes"]) for o in gt_occ])
+    losses.update(head_loss(cls_list, mask_list, nusc_loss_single, list(gl), list(gm), points, cfg=cfg["head"],
+                            rng=rng))
+    names = [k for k, v in params.items() if torch.is_tensor(v) and v.requires_grad]
+    grads = torch.autograd.grad(sum(losses.values()), [params[k] for k in names], allow_unused=True)
+    return losses, dict(zip(names, grads))

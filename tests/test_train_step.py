@@ -55,26 +55,10 @@ def _setup(B=2, N=2):
 
 
 def _oracle_step(cfg, meta, tc, sd, cams, x, gt_occ, pts, gd, rng):
-    params = {k: v.clone().requires_grad_(v.is_floating_point() and not k.endswith(("running_mean", "running_var")))
-              for k, v in sd.items()}
-    for k in ("img_view_transformer.frustum", "img_view_transformer.dx", "img_view_transformer.bx",
-              "img_view_transformer.nx"):
-        params[k].requires_grad_(False)
-    ocfg = oracle_cfg(cfg["pts_bbox_head"], tc)
-    with O.training_mode(rng):
-        vox, depth = O.view_transformer(params, "img_view_transformer.", x, cams, meta["D"], meta["C"])
-        enc = O.occupancy_encoder(params, "img_bev_encoder_backbone.", vox, groups=meta["groups"])
-        dec = O.pixel_decoder(params, "img_bev_encoder_neck.", enc, groups=meta["groups"], num_layers=meta["pd_layers"])
-        cls_list, mask_list = O.mask2former_head(params, "pts_bbox_head.", dec, heads=meta["heads"],
-                                                 num_layers=meta["dec_layers"])
-    losses = {"loss_depth": T.depth_bce_loss(gd, depth, 16, cfg["img_view_transformer"]["grid_config"]["dbound"],
-                                             meta["D"])}
-    gl, gm = zip(*[T.preprocess_occupancy_gt(o, 17) for o in gt_occ])
-    losses.update(T.head_loss(cls_list, mask_list, T.nusc_loss_single, list(gl), list(gm), pts, cfg=ocfg, rng=rng))
-    total = sum(losses.values())
-    names = [k for k, v in params.items() if v.requires_grad]
-    grads = torch.autograd.grad(total, [params[k] for k in names], allow_unused=True)
-    return losses, dict(zip(names, grads))
+    ocfg = dict(D=meta["D"], C=meta["C"], groups=meta["groups"], heads=meta["heads"], pd_layers=meta["pd_layers"],
+                dec_layers=meta["dec_layers"], downsample=16,
+                dbound=cfg["img_view_transformer"]["grid_config"]["dbound"], head=oracle_cfg(cfg["pts_bbox_head"], tc))
+    return T.train_step(sd, x, cams, gd, gt_occ, pts, ocfg, rng=rng)
 
 
 def test_training_step_gradients_vs_oracle(bound):
