@@ -107,9 +107,15 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_kernel(
 #pragma unroll
       for (int j = 0; j < WB_T; ++j) {
         const float* kr = &lds_k[wave][j * WB_HD];
-        float a = 0.f;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;           // four independent chains (FMA latency)
 #pragma unroll
-        for (int d = 0; d < WB_HD; ++d) a = fmaf(q[d], kr[d], a);
+        for (int d = 0; d < WB_HD; d += 4) {
+          a0 = fmaf(q[d], kr[d], a0);
+          a1 = fmaf(q[d + 1], kr[d + 1], a1);
+          a2 = fmaf(q[d + 2], kr[d + 2], a2);
+          a3 = fmaf(q[d + 3], kr[d + 3], a3);
+        }
+        float a = (a0 + a1) + (a2 + a3);
         const int ki = j / WB_WS, kj = j % WB_WS;
         a += lds_bias[wave][(qi - ki + WB_WS - 1) * (2 * WB_WS - 1) + (qj - kj + WB_WS - 1)];
         if (shift > 0) {
@@ -138,9 +144,15 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_kernel(
       for (int j = 0; j < WB_T; ++j) {
         const float* vr = &lds_v[wave][j * WB_HD];
         const float* kr = &lds_k[wave][j * WB_HD];
-        float dp = 0.f;
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
 #pragma unroll
-        for (int d = 0; d < WB_HD; ++d) dp = fmaf(go[d], vr[d], dp);
+        for (int d = 0; d < WB_HD; d += 4) {
+          p0 = fmaf(go[d], vr[d], p0);
+          p1 = fmaf(go[d + 1], vr[d + 1], p1);
+          p2 = fmaf(go[d + 2], vr[d + 2], p2);
+          p3 = fmaf(go[d + 3], vr[d + 3], p3);
+        }
+        const float dp = (p0 + p1) + (p2 + p3);
         const float ds = sc[j] * (dp - Dq);
         sc[j] = ds;
 #pragma unroll
@@ -233,24 +245,32 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_kernel(
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int r = lane + u * 64;
-      if (r < WB_NB) dtable_partial[((long)blockIdx.x * heads + head) * WB_NB + r] = dtab[u];
+      if (r < WB_NB) dtable_partial[((long)blockIdx.x * WB_NB + r) * heads + head] = dtab[u];
     }
   }
 }
 
-// dtable[r][head] = sum_x partial[x][head][r]
-__global__ void __launch_bounds__(256) window_table_reduce_kernel(const float* __restrict__ partial,
-                                                                  float* __restrict__ dtable, long nblk, int heads) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= WB_NB * heads) return;
-  const int r = t / heads, h = t % heads;
+// dtable[r][head] = sum_x partial[x][r][head]: 64 columns x 16 row groups per workgroup, double accumulation
+__global__ void __launch_bounds__(1024) window_table_reduce_kernel(const float* __restrict__ partial,
+                                                                   float* __restrict__ dtable, long nblk, int C) {
+  __shared__ double red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
   double s = 0.0;
-  for (long x = 0; x < nblk; ++x) s += (double)partial[(x * heads + h) * WB_NB + r];
-  dtable[t] = (float)s;
+  if (c < C)
+    for (long k = ty; k < nblk; k += 16) s += (double)partial[k * C + c];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    double t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t += red[r][tx];
+    dtable[c] = (float)t;
+  }
 }
 
 static int wb_windows_per_block(long n_windows) {
-  long w = (n_windows + 2047) / 2048;
+  long w = (n_windows + 1023) / 1024;
   return w < 1 ? 1 : (w > 64 ? 64 : (int)w);
 }
 extern "C" long occf_window_attn_bwd_workspace(int B, int X, int Y, int S, int heads) {
@@ -271,8 +291,8 @@ extern "C" int occf_window_attn_bwd(const float* qkv, const float* qkv_bias, con
   hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(nblk, occf_cdiv(heads, WB_HPB)), dim3(64 * WB_HPB), 0, st, qkv,
                      qkv_bias, bias_table, attn_out, dout, dqkv, dqkv_bias, workspace, B, X, Y, S, C, heads, shift,
                      1.0f / sqrtf((float)WB_HD), wpb, nwin);
-  hipLaunchKernelGGL(window_table_reduce_kernel, dim3(occf_cdiv(WB_NB * heads, 256)), dim3(256), 0, st, workspace,
-                     dbias_table, (long)nblk, heads);
+  hipLaunchKernelGGL(window_table_reduce_kernel, dim3(occf_cdiv(WB_NB * heads, 64)), dim3(1024), 0, st, workspace,
+                     dbias_table, (long)nblk, WB_NB * heads);
   OCCF_LAUNCH_CHECK();
 }
 

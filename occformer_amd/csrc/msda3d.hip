@@ -260,8 +260,11 @@ template <int VEC, int LP_MAX, bool HM>
 __global__ void __launch_bounds__(256) msda3d_bwd_kernel(
     const float* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     const float* __restrict__ dout, float* __restrict__ dvalue, float* __restrict__ doffs, float* __restrict__ dlogits,
-    MsdaLevels lv, int B, int Nq, int H, int Dh, int P, int LPG, long off_ld, long lg_ld, long doff_ld, long dlg_ld) {
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    MsdaLevels lv, int B, int Nq, int H, int Dh, int P, int LPG, long off_ld, long lg_ld, long doff_ld, long dlg_ld,
+    int do_value) {
+  // XCD remap as in the forward: a contiguous eighth of the (batch, head, query) space per XCD, i.e. with 8 heads the
+  // scatter of one head stays on one L2
+  const long gid = (long)occf_xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   const long total = (long)B * Nq * H * LPG;
   const bool live = gid < total;
   const long g2 = live ? gid : total - 1;                  // idle lanes shadow the last group (no stores)
@@ -341,7 +344,7 @@ __global__ void __launch_bounds__(256) msda3d_bwd_kernel(
         gx = fmaf((bx ? 1.f : -1.f) * wy * wz, dot, gx);
         gy = fmaf((by ? 1.f : -1.f) * wx * wz, dot, gy);
         gz = fmaf((bz ? 1.f : -1.f) * wx * wy, dot, gz);
-        if (live) {
+        if (live && do_value) {
           const float cw = a * wx * wy * wz;
 #pragma unroll
           for (int v = 0; v < VEC; ++v) atomicAdd(dvb + key * E + v, cw * go[v]);
@@ -376,6 +379,171 @@ __global__ void __launch_bounds__(256) msda3d_bwd_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// d(value) with LDS privatisation.  The plain scatter above issues B*Nq*H*L*P*8*Dh float atomics (1.7e9 per call
+// at the 200-grid) onto 91 250 x 192 addresses -- ~770 contributions per address, serialised at the L2 (12.6 ms per
+// call, 76 ms per training step).  Here a workgroup owns a TILE of one sampled level (T x T columns, all Z) of one
+// head, accumulates in LDS (region = tile + M margin cells, CH channels of the head per pass) the contributions of
+// every query whose own cell centre falls into the tile (queries of ALL levels: the levels are nested grids), and
+// flushes the non-zero part of the region once.  A sample that leaves the region (offsets larger than the margin)
+// falls back to the global atomic, so the result does not depend on the offsets being small.
+struct MsdaTileCfg {
+  int ls, T, M, tiles_x, tiles_y, groups;   // groups > 1: the level is ONE tile, its queries are split over `groups`
+  int CH, passes, lpg;                      // channels per pass, passes per head, lanes per query (CH = 3 * lpg)
+};
+
+__device__ __forceinline__ int msda_cdiv_pos(long num, long den) { return num <= 0 ? 0 : (int)((num + den - 1) / den); }
+
+__global__ void __launch_bounds__(256) msda3d_bwd_value_tile_kernel(
+    const float* __restrict__ offs, const float* __restrict__ logits, const float* __restrict__ dout,
+    float* __restrict__ dvalue, MsdaLevels lv, MsdaTileCfg tc, int B, int Nq, int H, int Dh, int P, long off_ld,
+    long lg_ld) {
+  OCCF_DYN_SMEM(smem_raw);
+  float* tile = (float*)smem_raw;
+  const int L = lv.n, LP = L * P;
+  const int ls = tc.ls;
+  const int Xs = lv.X[ls], Ys = lv.Y[ls], Zs = lv.Z[ls];
+  int bx = blockIdx.x;
+  const int pass = bx % tc.passes;
+  bx /= tc.passes;
+  const int grp = bx % tc.groups;
+  bx /= tc.groups;
+  const int ty_ = bx % tc.tiles_y, tx_ = bx / tc.tiles_y;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int tx0 = tx_ * tc.T, ty0 = ty_ * tc.T;
+  const int rx0 = tx0 - tc.M, ry0 = ty0 - tc.M;
+  const int RX = tc.T + 2 * tc.M, RY = RX;
+  const int CH = tc.CH, ch0 = pass * CH;
+  const long ncell = (long)RX * RY * Zs;
+  for (long i = threadIdx.x; i < ncell * CH; i += 256) tile[i] = 0.f;
+  __syncthreads();
+
+  // query boxes per query level: cell(q) = floor((2q + 1) * Xs / (2 * Xq)) in [tx0, tx0 + T)
+  int qx_lo[MSDA_MAX_LEVELS], qy_lo[MSDA_MAX_LEVELS], nqx[MSDA_MAX_LEVELS], nqy[MSDA_MAX_LEVELS], cum[MSDA_MAX_LEVELS + 1];
+  cum[0] = 0;
+  for (int lq = 0; lq < MSDA_MAX_LEVELS; ++lq) {
+    if (lq < L) {
+      const int Xq = lv.X[lq], Yq = lv.Y[lq];
+      int a0 = msda_cdiv_pos(2L * tx0 * Xq - Xs, 2L * Xs), a1 = msda_cdiv_pos(2L * (tx0 + tc.T) * Xq - Xs, 2L * Xs);
+      int c0 = msda_cdiv_pos(2L * ty0 * Yq - Ys, 2L * Ys), c1 = msda_cdiv_pos(2L * (ty0 + tc.T) * Yq - Ys, 2L * Ys);
+      a1 = a1 > Xq ? Xq : a1;
+      c1 = c1 > Yq ? Yq : c1;
+      if (tx0 + tc.T >= Xs) a1 = Xq;
+      if (ty0 + tc.T >= Ys) c1 = Yq;
+      qx_lo[lq] = a0; qy_lo[lq] = c0;
+      nqx[lq] = a1 > a0 ? a1 - a0 : 0;
+      nqy[lq] = c1 > c0 ? c1 - c0 : 0;
+      cum[lq + 1] = cum[lq] + nqx[lq] * nqy[lq] * lv.Z[lq];
+    } else {
+      qx_lo[lq] = qy_lo[lq] = nqx[lq] = nqy[lq] = 0;
+      cum[lq + 1] = cum[lq];
+    }
+  }
+  const int n_items = cum[L];
+  const int lpg = tc.lpg, slots = 256 / lpg;
+  const int slot = threadIdx.x / lpg, sub = threadIdx.x % lpg;
+  const int E = H * Dh;
+  const long Nv = lv.start[L - 1] + (long)lv.X[L - 1] * lv.Y[L - 1] * lv.Z[L - 1];
+  // this group's share of the items
+  const int per = (n_items + tc.groups - 1) / tc.groups;
+  const int it_begin = grp * per, it_end = it_begin + per < n_items ? it_begin + per : n_items;
+  for (int it = it_begin + slot; it < it_end; it += slots) {
+    int lq = 0;
+    while (lq + 1 < L && it >= cum[lq + 1]) ++lq;
+    int r = it - cum[lq];
+    const int Zq = lv.Z[lq];
+    const int qz = r % Zq;
+    r /= Zq;
+    const int qy = qy_lo[lq] + r % nqy[lq], qx = qx_lo[lq] + r / nqy[lq];
+    const int q = lv.start[lq] + (qx * lv.Y[lq] + qy) * Zq + qz;
+    const float rz = ((float)qz + 0.5f) / (float)Zq;
+    const float ry = ((float)qy + 0.5f) / (float)lv.Y[lq];
+    const float rx = ((float)qx + 0.5f) / (float)lv.X[lq];
+    const float* lg = logits + (long)(b * Nq + q) * lg_ld + h * LP;
+    float mx = -3.0e38f;
+    for (int i = 0; i < LP; ++i) mx = fmaxf(mx, lg[i]);
+    float sum = 0.f;
+    for (int i = 0; i < LP; ++i) sum += expf(lg[i] - mx);
+    const float inv = 1.0f / sum;
+    const float* of = offs + (long)(b * Nq + q) * off_ld + h * LP * 3;
+    const float* gp = dout + (long)(b * Nq + q) * E + h * Dh + ch0 + sub * 3;
+    const float g0 = gp[0], g1 = gp[1], g2 = gp[2];
+    float* dvb = dvalue + ((long)b * Nv + lv.start[ls]) * E + h * Dh + ch0 + sub * 3;
+    for (int k = 0; k < P; ++k) {
+      const int i = ls * P + k;
+      const float lz = rz + of[i * 3 + 0] / (float)Zs;
+      const float ly = ry + of[i * 3 + 1] / (float)Ys;
+      const float lx = rx + of[i * 3 + 2] / (float)Xs;
+      const float pz = ((2.f * lz - 1.f + 1.f) * (float)Zs - 1.f) * 0.5f;
+      const float py = ((2.f * ly - 1.f + 1.f) * (float)Ys - 1.f) * 0.5f;
+      const float px = ((2.f * lx - 1.f + 1.f) * (float)Xs - 1.f) * 0.5f;
+      const float fz = floorf(pz), fy = floorf(py), fx = floorf(px);
+      const float tz = pz - fz, ty = py - fy, tx = px - fx;
+      const int iz = (int)fz, iy = (int)fy, ix = (int)fx;
+      const float a = expf(lg[i] - mx) * inv;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const int cbx = c >> 2, cby = (c >> 1) & 1, cbz = c & 1;
+        const int xx = ix + cbx, yy = iy + cby, zz = iz + cbz;
+        if ((unsigned)xx >= (unsigned)Xs || (unsigned)yy >= (unsigned)Ys || (unsigned)zz >= (unsigned)Zs) continue;
+        const float cw = a * (cbx ? tx : 1.f - tx) * (cby ? ty : 1.f - ty) * (cbz ? tz : 1.f - tz);
+        const int lx_ = xx - rx0, ly_ = yy - ry0;
+        if ((unsigned)lx_ < (unsigned)RX && (unsigned)ly_ < (unsigned)RY) {
+          float* t = tile + (((long)lx_ * RY + ly_) * Zs + zz) * CH + sub * 3;
+          atomicAdd(t + 0, cw * g0);
+          atomicAdd(t + 1, cw * g1);
+          atomicAdd(t + 2, cw * g2);
+        } else {
+          float* d = dvb + (((long)xx * Ys + yy) * Zs + zz) * E;
+          atomicAdd(d + 0, cw * g0);
+          atomicAdd(d + 1, cw * g1);
+          atomicAdd(d + 2, cw * g2);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // flush: non-zero entries of the in-volume part of the region
+  float* dvb = dvalue + ((long)b * Nv + lv.start[ls]) * E + h * Dh + ch0;
+  for (long i = threadIdx.x; i < ncell * CH; i += 256) {
+    const float v = tile[i];
+    if (v == 0.f) continue;
+    const int ch = (int)(i % CH);
+    long cidx = i / CH;
+    const int zz = (int)(cidx % Zs);
+    cidx /= Zs;
+    const int yy = ry0 + (int)(cidx % RY), xx = rx0 + (int)(cidx / RY);
+    if ((unsigned)xx >= (unsigned)Xs || (unsigned)yy >= (unsigned)Ys) continue;
+    atomicAdd(dvb + (((long)xx * Ys + yy) * Zs + zz) * E + ch, v);
+  }
+}
+
+static bool msda_tile_cfg(const MsdaLevels& lv, int ls, int Dh, MsdaTileCfg& tc) {
+  const long budget = 100 * 1024;                       // bytes of LDS per workgroup
+  const int X = lv.X[ls], Y = lv.Y[ls], Z = lv.Z[ls];
+  tc.ls = ls;
+  tc.lpg = Dh == 24 ? 4 : Dh / 3;                       // 12 channels per pass at head_dim 24, all of them at 12
+  tc.CH = 3 * tc.lpg;
+  tc.passes = Dh / tc.CH;
+  if ((long)X * Y * Z * tc.CH * 4 <= budget) {          // the whole level as one tile, its queries split over groups
+    tc.T = X > Y ? X : Y;
+    tc.M = 0;
+    tc.tiles_x = tc.tiles_y = 1;
+    tc.groups = 32;
+    return true;
+  }
+  tc.M = 5;
+  tc.groups = 1;
+  int T = 16;
+  while (T > 2 && (long)(T + 2 * tc.M) * (T + 2 * tc.M) * Z * tc.CH * 4 > budget) --T;
+  if ((long)(T + 2 * tc.M) * (T + 2 * tc.M) * Z * tc.CH * 4 > budget) return false;
+  tc.T = T;
+  tc.tiles_x = (X + T - 1) / T;
+  tc.tiles_y = (Y + T - 1) / T;
+  return true;
+}
+
 extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets, const float* attn_logits,
                                const float* dout, float* dvalue, float* doffsets, float* dlogits,
                                const int32_t* level_shapes, int num_levels, int B, int Nq, int heads, int head_dim,
@@ -400,6 +568,35 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
   const long LP3 = (long)heads * num_levels * num_points * 3, LP1 = (long)heads * num_levels * num_points;
   const long off_ld = offsets_ld > 0 ? offsets_ld : LP3, lg_ld = logits_ld > 0 ? logits_ld : LP1;
   const long doff_ld = doffsets_ld > 0 ? doffsets_ld : LP3, dlg_ld = dlogits_ld > 0 ? dlogits_ld : LP1;
+  // d(value): LDS-privatised tiles when the head width allows it (12 / 24 channels), else the plain scatter
+  static const int tiled_env = [] {
+    const char* e = getenv("OCCF_MSDA_TILED");
+    return e ? atoi(e) : 1;
+  }();
+  int do_value = 1;
+  if (tiled_env && (head_dim == 12 || head_dim == 24)) {
+    MsdaTileCfg cfgs[MSDA_MAX_LEVELS];
+    bool ok = true;
+    for (int l = 0; l < num_levels; ++l) ok = ok && msda_tile_cfg(lv, l, head_dim, cfgs[l]);
+    if (ok) {
+      do_value = 0;
+      for (int l = 0; l < num_levels; ++l) {
+        const MsdaTileCfg& tc = cfgs[l];
+        const size_t lds = (size_t)(tc.T + 2 * tc.M) * (tc.T + 2 * tc.M) * lv.Z[l] * tc.CH * 4;
+#ifndef OCCF_EMU
+        static size_t lds_max = 0;
+        if (lds > lds_max) {
+          hipFuncSetAttribute((const void*)msda3d_bwd_value_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+          lds_max = lds;
+        }
+#endif
+        const dim3 grid((unsigned)(tc.tiles_x * tc.tiles_y * tc.groups * tc.passes), heads, B);
+        hipLaunchKernelGGL(msda3d_bwd_value_tile_kernel, grid, dim3(256), lds, st, sampling_offsets, attn_logits, dout,
+                           dvalue, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
+      }
+    }
+  }
   int lpg = head_dim % 8 == 0 ? 8 : head_dim % 4 == 0 ? 4 : head_dim % 2 == 0 ? 2 : 1;
   int vec = head_dim / lpg;
   while (vec > 6 && lpg < 8) { lpg *= 2; vec = head_dim / lpg; }
@@ -408,7 +605,7 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
 #define OCCF_MSDB_LAUNCH(V_, HM_)                                                                                   \
   hipLaunchKernelGGL((msda3d_bwd_kernel<V_, 16, HM_>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,        \
                      sampling_offsets, attn_logits, dout, dvalue, doffsets, dlogits, lv, B, Nq, heads, head_dim,    \
-                     num_points, lpg, off_ld, lg_ld, doff_ld, dlg_ld)
+                     num_points, lpg, off_ld, lg_ld, doff_ld, dlg_ld, do_value)
 #define OCCF_MSDB_VEC(HM_)                     \
   switch (vec) {                               \
     case 1: OCCF_MSDB_LAUNCH(1, HM_); break;   \

@@ -5,10 +5,11 @@
 //
 // Both operands are "k-major": the contraction index m (voxels / tokens, up to 680 000) is the SLOW index of
 // the two row-major activations, the fast index is the channel.  v_mfma_f32_32x32x16_bf16 wants 8 consecutive
-// k per lane, so the staging transposes on the way into LDS: a thread loads float4 from RPT consecutive rows,
-// packs ROW PAIRS to bf16x2 (hi and lo halves of the 3-term split) and writes 16 B per pair-row; LDS holds
-// [m / 2][channel] dwords, a fragment is four ds_read_b32 with consecutive lanes on consecutive dwords -- both
-// directions bank-conflict free without padding.
+// k per lane, so the staging transposes in REGISTERS on the way into LDS: a thread loads float4 from 8 (or 4)
+// consecutive rows, packs the 8 row values of each of its 4 columns to bf16x8 (hi and lo halves of the 3-term split)
+// and writes them as 16-byte (8-byte) pieces; LDS holds [m / 8][channel] 16-byte groups, so a fragment is ONE
+// ds_read_b128 with consecutive lanes on consecutive 16-byte slots -- both directions bank-conflict free without
+// padding (four ds_read_b32 per fragment made the kernel LDS-issue bound).
 //
 // Workgroup = 4 waves (2 x 2), tile 128 (n) x BC (c, 128 or 64) of ONE tap, walks 64-row chunks of its M-slice
 // with the next chunk's global loads in flight (issued unconditionally, clamped).  M is split over blockIdx.y
@@ -40,7 +41,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
   constexpr int TC = BC / 64;                 // 32-wide tiles per wave along c
   constexpr int QB = BC / 4;                  // channel quads of the X tile
   constexpr int RPT = 64 * QB / 256;          // rows per thread of the X tile (8 or 4)
-  __shared__ __attribute__((aligned(16))) uint32_t Ah[32 * 128], Al[32 * 128], Bh[32 * BC], Bl[32 * BC];
+  // [8 row groups][columns] of 16-byte groups (8 bf16 = 8 consecutive rows of one column)
+  __shared__ __attribute__((aligned(16))) wg_u4 Ah[8 * 128], Al[8 * 128], Bh[8 * BC], Bl[8 * BC];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -82,14 +84,15 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
       ra[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (p.conv) {
-      long m = mb + b_rg * RPT;
-      if (m >= p.M) m = p.M - 1;
-      int zo = (int)(m % p.g.Zo);
-      long t = m / p.g.Zo;
-      int yo = (int)(t % p.g.Yo);
-      t /= p.g.Yo;
-      int xo = (int)(t % p.g.Xo);
-      long b = t / p.g.Xo;
+      long ml = mb + b_rg * RPT;
+      if (ml >= p.M) ml = p.M - 1;
+      const unsigned m = (unsigned)ml;                      // M < 2^31: 32-bit divisions
+      int zo = (int)(m % (unsigned)p.g.Zo);
+      unsigned t = m / (unsigned)p.g.Zo;
+      int yo = (int)(t % (unsigned)p.g.Yo);
+      t /= (unsigned)p.g.Yo;
+      int xo = (int)(t % (unsigned)p.g.Xo);
+      long b = t / (unsigned)p.g.Xo;
 #pragma unroll
       for (int j = 0; j < RPT; ++j) {
         const int xi = xo * p.g.stride - p.g.pad_x + tdx * p.g.dil, yi = yo * p.g.stride - p.g.pad_y + tdy * p.g.dil,
@@ -125,33 +128,55 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool do_bias = p.bias_out != nullptr && tap == 0 && ct == 0;
   auto store_chunk = [&]() __attribute__((always_inline)) {
+    // dY: rows a_rg*8 .. +7 of columns a_c4*4 .. +3 -> four 16-byte groups (one per column) in row group a_rg
+    {
+      const float cx[4][8] = {{ra[0].x, ra[1].x, ra[2].x, ra[3].x, ra[4].x, ra[5].x, ra[6].x, ra[7].x},
+                              {ra[0].y, ra[1].y, ra[2].y, ra[3].y, ra[4].y, ra[5].y, ra[6].y, ra[7].y},
+                              {ra[0].z, ra[1].z, ra[2].z, ra[3].z, ra[4].z, ra[5].z, ra[6].z, ra[7].z},
+                              {ra[0].w, ra[1].w, ra[2].w, ra[3].w, ra[4].w, ra[5].w, ra[6].w, ra[7].w}};
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      wg_u4 h, l;
-      uint32_t hh, ll;
-      occf_bf16_split2(ra[j].x, ra[j + 1].x, hh, ll); h.x = hh; l.x = ll;
-      occf_bf16_split2(ra[j].y, ra[j + 1].y, hh, ll); h.y = hh; l.y = ll;
-      occf_bf16_split2(ra[j].z, ra[j + 1].z, hh, ll); h.z = hh; l.z = ll;
-      occf_bf16_split2(ra[j].w, ra[j + 1].w, hh, ll); h.w = hh; l.w = ll;
-      const int off = (a_rg * 4 + (j >> 1)) * 128 + a_c4 * 4;
-      *(wg_u4*)(Ah + off) = h;
-      if (TERMS == 3) *(wg_u4*)(Al + off) = l;
+      for (int e = 0; e < 4; ++e) {
+        wg_u4 h, l;
+        uint32_t hh, ll;
+        occf_bf16_split2(cx[e][0], cx[e][1], hh, ll); h.x = hh; l.x = ll;
+        occf_bf16_split2(cx[e][2], cx[e][3], hh, ll); h.y = hh; l.y = ll;
+        occf_bf16_split2(cx[e][4], cx[e][5], hh, ll); h.z = hh; l.z = ll;
+        occf_bf16_split2(cx[e][6], cx[e][7], hh, ll); h.w = hh; l.w = ll;
+        const int off = a_rg * 128 + a_c4 * 4 + e;
+        Ah[off] = h;
+        if (TERMS == 3) Al[off] = l;
+      }
     }
     if (do_bias) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { bsum[0] += ra[j].x; bsum[1] += ra[j].y; bsum[2] += ra[j].z; bsum[3] += ra[j].w; }
     }
+    // X: RPT = 8 -> whole 16-byte groups; RPT = 4 -> the thread owns half a group (rows 4*(b_rg&1) .. +3)
+    {
+      float cx[4][RPT];
 #pragma unroll
-    for (int j = 0; j < RPT; j += 2) {
-      wg_u4 h, l;
-      uint32_t hh, ll;
-      occf_bf16_split2(rb[j].x, rb[j + 1].x, hh, ll); h.x = hh; l.x = ll;
-      occf_bf16_split2(rb[j].y, rb[j + 1].y, hh, ll); h.y = hh; l.y = ll;
-      occf_bf16_split2(rb[j].z, rb[j + 1].z, hh, ll); h.z = hh; l.z = ll;
-      occf_bf16_split2(rb[j].w, rb[j + 1].w, hh, ll); h.w = hh; l.w = ll;
-      const int off = (b_rg * (RPT / 2) + (j >> 1)) * BC + b_c4 * 4;
-      *(wg_u4*)(Bh + off) = h;
-      if (TERMS == 3) *(wg_u4*)(Bl + off) = l;
+      for (int j = 0; j < RPT; ++j) { cx[0][j] = rb[j].x; cx[1][j] = rb[j].y; cx[2][j] = rb[j].z; cx[3][j] = rb[j].w; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uint32_t hh[RPT / 2], ll[RPT / 2];
+#pragma unroll
+        for (int j = 0; j < RPT; j += 2) occf_bf16_split2(cx[e][j], cx[e][j + 1], hh[j / 2], ll[j / 2]);
+        if (RPT == 8) {
+          const int off = b_rg * BC + b_c4 * 4 + e;
+          wg_u4 h, l;
+          h.x = hh[0]; h.y = hh[1]; h.z = hh[RPT / 2 - 2]; h.w = hh[RPT / 2 - 1];
+          l.x = ll[0]; l.y = ll[1]; l.z = ll[RPT / 2 - 2]; l.w = ll[RPT / 2 - 1];
+          Bh[off] = h;
+          if (TERMS == 3) Bl[off] = l;
+        } else {
+          const int off = (b_rg >> 1) * BC + b_c4 * 4 + e;
+          uint32_t* dh = (uint32_t*)(Bh + off) + (b_rg & 1) * 2;
+          uint32_t* dl = (uint32_t*)(Bl + off) + (b_rg & 1) * 2;
+          dh[0] = hh[0];
+          dh[1] = hh[1];
+          if (TERMS == 3) { dl[0] = ll[0]; dl[1] = ll[1]; }
+        }
+      }
     }
   };
 
@@ -163,14 +188,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int li = lane & 31, lk = lane >> 5;
-  auto frag = [&](const uint32_t* base, int ld, int col, int ks) __attribute__((always_inline)) -> bf16x8 {
-    const uint32_t* q = base + (ks * 8 + lk * 4) * ld + col;
-    wg_u4 v;
-    v.x = q[0];
-    v.y = q[ld];
-    v.z = q[2 * ld];
-    v.w = q[3 * ld];
-    return __builtin_bit_cast(bf16x8, v);
+  auto frag = [&](const wg_u4* base, int ld, int col, int ks) __attribute__((always_inline)) -> bf16x8 {
+    return __builtin_bit_cast(bf16x8, base[(ks * 2 + lk) * ld + col]);
   };
   auto compute = [&]() __attribute__((always_inline)) {
 #pragma unroll

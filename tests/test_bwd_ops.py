@@ -260,7 +260,10 @@ def test_masked_attention_backward(be, Q, L, heads, masked):
 
 
 @pytest.mark.parametrize("E,heads,shapes", [(96, 8, [(2, 2, 1), (4, 4, 2), (8, 8, 4)]), (48, 4, [(3, 2, 2), (5, 4, 3)]),
-                                            (40, 8, [(2, 3, 1), (4, 4, 2), (6, 5, 3)]), (192, 8, [(2, 2, 1), (4, 3, 2)])])
+                                            (40, 8, [(2, 3, 1), (4, 4, 2), (6, 5, 3)]), (192, 8, [(2, 2, 1), (4, 3, 2)]),
+                                            # levels too large for one LDS tile: the tiled value-gradient path with
+                                            # margins, and offsets (scale 2 x 4 cells) that leave the region -> fallback
+                                            (24, 2, [(11, 10, 2), (22, 20, 4), (44, 40, 8)])])
 def test_msda3d_backward(be, E, heads, shapes):
     from oracle import occformer_ref as O
     B, P = 2, 4
