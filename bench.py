@@ -105,10 +105,19 @@ def pmc_traffic(kernel_substr, grid_size):
     (profiles/*_pmc_traffic.json, written by scripts/summarize_pmc.py; FETCH_SIZE already x2-corrected for
     gfx950 per MI355X_MICROARCH.md).  None when no summary is present."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime)
     if not files:
         return None, None
-    rows = json.load(open(files[-1]))["kernels"]
+    doc = json.load(open(files[-1]))
+    # a counter summary is only valid for the kernels it was collected on: scripts/summarize_pmc.py stamps the
+    # digest of the kernel sources; a summary from other sources is refused (traffic = null) rather than quoted
+    try:
+        from occformer_amd.csrc.build import _digest
+        if doc.get("source_digest") not in (None, _digest()):
+            return None, os.path.basename(files[-1]) + " (stale: kernel sources changed since)"
+    except Exception:
+        pass
+    rows = doc["kernels"]
     best = [r for r in rows if kernel_substr in r["kernel"] and (grid_size is None or r["grid"] == grid_size)]
     if not best:
         return None, None

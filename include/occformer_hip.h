@@ -283,6 +283,13 @@ long occf_conv3x3x3_halo_gn_blocks(int X, int Y, int Z);
 int occf_deform_im2col(const float* x, const float* offset, float* col, int BN, int H, int W, int C, int K,
                        int stride, int pad, int dil, int groups, int deform_groups, void* stream);
 
+/* DCNv2 (mmcv-full 1.4.0 `modulated_deform_conv2d`, third-party op behind `dcn=dict(type='DCNv2', ...)` of the
+ * R101-DCN image backbone, projects/configs/occformer_nusc/occformer_nusc_r101_896x1600.py:78-79): the same
+ * columns with every tap's sample scaled by mask[BN, dg*K*K, Ho, Wo] (sigmoid already applied). */
+int occf_modulated_deform_im2col(const float* x, const float* offset, const float* mask, float* col, int BN, int H,
+                                 int W, int C, int K, int stride, int pad, int dil, int groups, int deform_groups,
+                                 void* stream);
+
 /* ------------------------------------------------------------------ training-time sampling */
 
 /* point_sample_3d (P/occformer/mask2former/base/mmdet_utils.py:21-47 = F.grid_sample on

@@ -14,8 +14,12 @@
 #include "occf_common.h"
 #include "../../include/occformer_hip.h"
 
+// `mask` != NULL: DCNv2 (mmcv ModulatedDeformConv2dPack, the R101-DCN image backbone of
+// occformer_nusc_r101_896x1600.py:78-79): the sample of tap t is scaled by mask[bn, dg*K*K + t, ho, wo]
+// (already sigmoid-ed by the caller, as mmcv does).
 __global__ void __launch_bounds__(256) deform_im2col_kernel(
-    const float* __restrict__ x, const float* __restrict__ offset, float* __restrict__ col, int BN, int H,
+    const float* __restrict__ x, const float* __restrict__ offset, const float* __restrict__ mask,
+    float* __restrict__ col, int BN, int H,
     int W, int C, int Ho, int Wo, int K, int stride, int pad, int dil, int groups, int dgroups) {
   const int Q = C / 4, KK = K * K;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,6 +55,10 @@ __global__ void __launch_bounds__(256) deform_im2col_kernel(
       acc[2] = fmaf(wgt, v.z, acc[2]); acc[3] = fmaf(wgt, v.w, acc[3]);
     }
   }
+  if (mask) {
+    const float mk = mask[(((long)bn * dgroups + dg) * KK + t) * Ho * Wo + (long)ho * Wo + wo];
+    acc[0] *= mk; acc[1] *= mk; acc[2] *= mk; acc[3] *= mk;
+  }
   const int cpg = C / groups;
   const int g = c / cpg, cg = c - g * cpg;
   const long pix = ((long)bn * Ho + ho) * Wo + wo;
@@ -66,7 +74,20 @@ extern "C" int occf_deform_im2col(const float* x, const float* offset, float* co
   const int Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
   const long total = (long)BN * Ho * Wo * K * K * (C / 4);
   hipLaunchKernelGGL(deform_im2col_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                     offset, col, BN, H, W, C, Ho, Wo, K, stride, pad, dil, groups, deform_groups);
+                     offset, (const float*)nullptr, col, BN, H, W, C, Ho, Wo, K, stride, pad, dil, groups, deform_groups);
+  OCCF_LAUNCH_CHECK();
+}
+
+extern "C" int occf_modulated_deform_im2col(const float* x, const float* offset, const float* mask, float* col, int BN,
+                                            int H, int W, int C, int K, int stride, int pad, int dil, int groups,
+                                            int deform_groups, void* stream) {
+  if (BN <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || groups <= 0 || deform_groups <= 0 || !mask) return OCCF_EINVAL;
+  if (C % groups || C % deform_groups || (C / groups) % 4 || (C / deform_groups) % 4) return OCCF_ESHAPE;
+  const int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  const int Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  const long total = (long)BN * Ho * Wo * K * K * (C / 4);
+  hipLaunchKernelGGL(deform_im2col_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     offset, mask, col, BN, H, W, C, Ho, Wo, K, stride, pad, dil, groups, deform_groups);
   OCCF_LAUNCH_CHECK();
 }
 

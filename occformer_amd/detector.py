@@ -28,7 +28,9 @@ class ModulatedDeformConv2dPack(nn.Module):
     group 2*k*k offsets -- channel 2t = dy, 2t+1 = dx of tap t, after the op's chunk(3) / cat of the first two
     thirds -- and k*k modulation logits; tap t samples the input bilinearly (zero outside the image) at its
     regular position + offset, the sample is scaled by sigmoid(logit), then the ordinary weighted sum over taps and
-    input channels.  Image-branch glue on PyTorch ops (grid_sample), not a hand-written kernel."""
+    input channels.  GPU tensors without autograd run the hand-written bilinear im2col (csrc/dcn.hip, with the
+    modulation) + the split-bf16 MFMA GEMM; the grid_sample formulation below is the differentiable / CPU statement
+    of the same op."""
 
     def __init__(self, cin, cout, kernel_size=3, stride=1, padding=1, dilation=1, groups=1, deform_groups=1,
                  bias=False):
@@ -44,12 +46,30 @@ class ModulatedDeformConv2dPack(nn.Module):
         nn.init.zeros_(self.conv_offset.weight)
         nn.init.zeros_(self.conv_offset.bias)
 
+    def _forward_hip(self, x, offset, mask):
+        """csrc/dcn.hip: x [B, C, H, W] fp32 on the GPU -> [B, Cout, Ho, Wo]"""
+        from . import fused
+        from .ops import get_ops
+        ops = get_ops()
+        B, C, H, W = x.shape
+        Ho, Wo = offset.shape[-2:]
+        col = ops.deform_im2col(x.permute(0, 2, 3, 1).contiguous(), offset.contiguous(), self.k, self.stride,
+                                self.padding, self.dilation, 1, self.dg, mask=mask.contiguous())
+        tap = lambda w: w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()      # k = tap * C + c
+        w2 = fused._versioned(fused._TAP_CACHE, self.weight, lambda: tap(self.weight.detach()))
+        out = ops.linear(col.flatten(1), w2, None if self.bias is None else self.bias.detach(),
+                         w_split=fused.split_weight(self.weight, tap))
+        return out.view(B, Ho, Wo, -1).permute(0, 3, 1, 2)
+
     def forward(self, x):
         B, C, H, W = x.shape
         k, dg = self.k, self.dg
         o1, o2, logit = torch.chunk(self.conv_offset(x), 3, dim=1)
         offset = torch.cat((o1, o2), 1)                                  # [B, dg * 2 * k*k, Ho, Wo]
         mask = torch.sigmoid(logit)                                       # [B, dg * k*k, Ho, Wo]
+        if x.is_cuda and x.dtype == torch.float32 and (C // dg) % 4 == 0 and \
+                not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
+            return self._forward_hip(x, offset, mask)
         Ho, Wo = offset.shape[-2:]
         ys = (torch.arange(Ho, device=x.device, dtype=x.dtype) * self.stride - self.padding).view(1, Ho, 1)
         xs = (torch.arange(Wo, device=x.device, dtype=x.dtype) * self.stride - self.padding).view(1, 1, Wo)

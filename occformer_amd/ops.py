@@ -461,13 +461,19 @@ class HipOps:
                    B, X, Y, Z, X2, Y2, Z2, C, self._stream())
         return out
 
-    def deform_im2col(self, x_cl, offset, K, stride, pad, dil, groups, deform_groups):
-        """x_cl [BN, H, W, C], offset [BN, dg*2*K*K, Ho, Wo] -> col [BN*Ho*Wo, groups, K*K, C/groups]."""
+    def deform_im2col(self, x_cl, offset, K, stride, pad, dil, groups, deform_groups, mask=None):
+        """x_cl [BN, H, W, C], offset [BN, dg*2*K*K, Ho, Wo] (, mask [BN, dg*K*K, Ho, Wo]: DCNv2)
+        -> col [BN*Ho*Wo, groups, K*K, C/groups]."""
         BN, H, W, C = x_cl.shape
         Ho, Wo = offset.shape[-2:]
         col = torch.empty((BN * Ho * Wo, groups, K * K, C // groups), dtype=x_cl.dtype, device=x_cl.device)
-        self._call("occf_deform_im2col", self._ptr(x_cl, self.f32), self._ptr(offset, self.f32), self._ptr(col),
-                   BN, H, W, C, K, stride, pad, dil, groups, deform_groups, self._stream())
+        if mask is None:
+            self._call("occf_deform_im2col", self._ptr(x_cl, self.f32), self._ptr(offset, self.f32), self._ptr(col),
+                       BN, H, W, C, K, stride, pad, dil, groups, deform_groups, self._stream())
+        else:
+            self._call("occf_modulated_deform_im2col", self._ptr(x_cl, self.f32), self._ptr(offset, self.f32),
+                       self._ptr(mask, self.f32), self._ptr(col), BN, H, W, C, K, stride, pad, dil, groups,
+                       deform_groups, self._stream())
         return col
 
     # ------------------------------------------------------------------ training-time sampling

@@ -40,6 +40,8 @@ if len(sys.argv) > 2:
         rows.append(dict(kernel=k, grid=g, calls=n, fetch_bytes=2 * v["FETCH_SIZE"] * 1024 / n,
                          write_bytes=v["WRITE_SIZE"] * 1024 / n))
     rows.sort(key=lambda r: -(r["fetch_bytes"] + r["write_bytes"]) * r["calls"])
-    json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per launch; "
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from occformer_amd.csrc.build import _digest
+    json.dump(dict(source_digest=_digest(), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes per launch; "
                         "fetch_bytes = 2 x FETCH_SIZE KiB x 1024 (MI355X_MICROARCH.md gfx950 correction)",
                    kernels=rows[:200]), open(sys.argv[2], "w"), indent=1)

@@ -31,6 +31,8 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 def build():
     cfg, meta = tinycfg.tiny_nusc(ncams=2)
     cfg["pts_bbox_head"]["transformer_decoder"]["num_layers"] = 3
+    cfg["img_bev_encoder_backbone"]["block_numbers"] = [1, 1, 1, 1]
+    cfg["img_bev_encoder_neck"]["encoder"]["num_layers"] = 1
     cfg["train_cfg"] = dict(pts=train_cfg(num_points=64)); cfg["test_cfg"] = None
     m = build_model(cfg)
     m.load_state_dict(paramgen.fill_state_dict(m.state_dict(), 91))

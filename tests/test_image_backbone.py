@@ -130,3 +130,36 @@ def test_r101_dcn_reference_config_loads_unchanged():
     assert "img_backbone.layer3.0.conv2.conv_offset.weight" in names and "img_backbone.layer4.2.conv2.weight" in names
     assert "img_backbone.layer2.0.conv2.conv_offset.weight" not in names
     assert m.img_backbone.layer3[0].conv2.conv_offset.out_channels == 27 and len(m.img_backbone.layer3) == 23
+
+
+@pytest.mark.parametrize("stride,dg", [(1, 1), (2, 2)])
+def test_dcnv2_hip_im2col_vs_grid_sample_formulation(be, stride, dg):
+    """DCNv2 on the kernels (csrc/dcn.hip modulated im2col + GEMM) against the module's own differentiable
+    grid_sample statement, which test_dcnv2_against_direct_bilinear_loops pins to explicit bilinear loops"""
+    m = _dcn(cin=16, cout=8, stride=stride, dg=dg)
+    with torch.no_grad():
+        m.conv_offset.weight.copy_(paramgen.tensor("dcn2.ow", m.conv_offset.weight.shape, 3, 0.1))
+        m.conv_offset.bias.copy_(paramgen.tensor("dcn2.ob", m.conv_offset.bias.shape, 3, 0.8))
+        x = paramgen.tensor("dcn2.x", (2, 16, 9, 11), 4)
+        ref = m(x)                                                     # CPU tensors: grid_sample path
+        o1, o2, logit = torch.chunk(m.conv_offset(x), 3, dim=1)
+        off, mask = torch.cat((o1, o2), 1).contiguous(), torch.sigmoid(logit).contiguous()
+        col = be.ops.deform_im2col(be.to(x.permute(0, 2, 3, 1).contiguous()), be.to(off), 3, stride, 1, 1, 1, dg,
+                                   mask=be.to(mask))
+        w2 = m.weight.permute(0, 2, 3, 1).reshape(8, -1).contiguous()
+        out = be.ops.linear(col.flatten(1), be.to(w2)).cpu()
+    Ho, Wo = ref.shape[-2:]
+    assert torch.allclose(out.view(2, Ho, Wo, 8).permute(0, 3, 1, 2), ref, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_dcnv2_module_on_gpu_uses_the_kernel(hip):
+    """ModulatedDeformConv2dPack on a GPU tensor (R101 stage-3 width) == its CPU grid_sample statement"""
+    m = _dcn(cin=256, cout=256, stride=1, dg=1)
+    with torch.no_grad():
+        m.conv_offset.weight.copy_(paramgen.tensor("dcn3.ow", m.conv_offset.weight.shape, 3, 0.02))
+        m.conv_offset.bias.copy_(paramgen.tensor("dcn3.ob", m.conv_offset.bias.shape, 3, 0.8))
+        x = paramgen.tensor("dcn3.x", (2, 256, 14, 25), 4)
+        ref = m(x)
+        out = m.to(hip.device)(x.to(hip.device)).cpu()
+    assert float((out - ref).abs().max() / ref.abs().max()) < 1e-4

@@ -1,0 +1,65 @@
+"""Every OCCF_* switch of the host layer (ops.py reads them at construction) selects a different kernel path for the
+same math: the tiny forward must give the same outputs under each value, so the non-default paths cannot rot
+unnoticed.  Runs on the host emulation (CPU) and on the real library (-m gpu)."""
+import pytest
+import torch
+
+import occformer_amd  # noqa: F401
+import occformer_amd.ops as ops_mod
+from occformer_amd.registry import MODELS
+from tests import paramgen, tinycfg
+
+SWITCHES = [
+    {},                                        # defaults
+    {"use_halo_conv": False},                  # OCCF_HALO_CONV=0
+    {"use_fused_swin": False},                 # OCCF_FUSED_SWIN=0
+    {"use_fused_mlp": False},                  # OCCF_FUSED_MLP=0
+    {"use_fused_mask_pool": False},            # OCCF_FUSED_MASK_POOL=0
+    {"precision": "f32"},                      # OCCF_PRECISION=f32
+]
+
+
+def _forward(dev):
+    cfg, meta = tinycfg.tiny_nusc()
+    cfg["pts_bbox_head"].update(train_cfg=None, test_cfg=None)
+    mods = {}
+    for i, key in enumerate(("img_view_transformer", "img_bev_encoder_backbone", "img_bev_encoder_neck",
+                             "pts_bbox_head")):
+        m = MODELS.build(cfg[key])
+        m.load_state_dict(paramgen.fill_state_dict(m.state_dict(), 10 + i))
+        mods[key] = m.eval().to(dev)
+    cams = [c.to(dev) for c in paramgen.camera_rig(1, 3, *meta["input_size"], meta["focal"], seed=3)]
+    x = paramgen.tensor("sw_x", (1, 3, 32, meta["fH"], meta["fW"]), 3).to(dev)
+    lo, hi = torch.tensor(meta["pc_range"][:3]), torch.tensor(meta["pc_range"][3:])
+    pts = [(paramgen.uniform("sw_pts", (200, 3), 3) * (hi - lo) + lo).to(dev)]
+    metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])]
+    with torch.no_grad():
+        vt = mods["img_view_transformer"]
+        vox, _ = vt([x, *cams, vt.get_mlp_input(*cams)])
+        feats = mods["img_bev_encoder_neck"](mods["img_bev_encoder_backbone"](vox))
+        res = mods["pts_bbox_head"].simple_test(feats, metas, points=pts)
+    return res["output_voxels"][0].cpu(), res["output_points"].cpu()
+
+
+def test_every_switch_gives_the_same_forward(be, monkeypatch):
+    monkeypatch.setattr(ops_mod, "_ops", be.ops)
+    saved = {k: getattr(be.ops, k) for s in SWITCHES for k in s}
+    # (the host emulation is ~100x slower than the chip: the CPU run covers the three paths with their own kernels,
+    # the GPU run all six)
+    todo = SWITCHES if be.kind == "hip" else [SWITCHES[0], SWITCHES[1], SWITCHES[2], SWITCHES[5]]
+    try:
+        ref = None
+        for sw in todo:
+            for k, v in saved.items():
+                setattr(be.ops, k, v)
+            for k, v in sw.items():
+                setattr(be.ops, k, v)
+            out = _forward(be.device)
+            if ref is None:
+                ref = out
+            else:
+                assert float((out[0] - ref[0]).abs().max()) < 1e-3, sw
+                assert float((out[1] - ref[1]).abs().max()) < 1e-3, sw
+    finally:
+        for k, v in saved.items():
+            setattr(be.ops, k, v)
