@@ -242,6 +242,11 @@ def main():
     ap.add_argument("--grid", default=None, choices=["200", "reference"], help="(legacy) nusc_r50 grid")
     ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the dense contractions (default: the library default, bf16x3)")
+    ap.add_argument("--from-images", action="store_true",
+                    help="forward mode, nusc_r50 workloads: start at the raw images [1, 6, 3, 256, 704] -- the R50 + "
+                         "SECONDFPN image branch (PyTorch-ROCm / MIOpen, bf16 channels_last) runs inside the timed "
+                         "region and is reported as stage img_encoder")
+    ap.add_argument("--image-dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shape-report", default=None, help="write a per-shape GEMM/conv timing table here")
     ap.add_argument("--check", action="store_true", help="also report max abs err vs the oracle output")
@@ -270,10 +275,22 @@ def main():
         args.workload = {"200": "nusc_r50_200", "reference": "nusc_r50_ref128"}[args.grid]
     cfg, meta = configs.workload(args.workload)
     train = args.mode == "train"
+    if args.from_images:
+        if train or not args.workload.startswith("nusc_r50"):
+            raise SystemExit("--from-images: forward mode on the nusc_r50 workloads")
+        cfg, meta2 = configs.nusc_r50("200" if args.workload == "nusc_r50_200" else "reference", with_image_branch=True)
+        args.no_cpu_baseline = True            # the oracle starts at the neck features
     if train and meta.get("kitti"):
         cfg["train_cfg"] = dict(pts=configs.train_cfg_pts())
     model = build_model(cfg).to(device)
     img_inputs, metas, points = synthetic_sample(meta, device, seed=rank)
+    if args.from_images:
+        g = torch.Generator().manual_seed(7 + rank)
+        img_inputs[0] = torch.randn(1, meta["ncams"], 3, *meta["input_size"], generator=g).to(device)
+        if args.image_dtype == "bf16":
+            model.image_dtype = torch.bfloat16
+            model.img_backbone.to(memory_format=torch.channels_last)
+            model.img_neck.to(memory_format=torch.channels_last)
     targets = configs.synthetic_targets(meta, device, seed=rank) if train else None
 
     def step_forward():
@@ -373,13 +390,16 @@ def main():
         "metric": f"samples/sec ({meta['ncams']}-cam frame) {what}, {WORKLOAD_DESC[args.workload]}, "
                   + ("training step of the hot path from image-neck features (forward_train + backward + gradient "
                      "all-reduce + grad-clip + AdamW)" if train else
+                     ("raw images -> R50 + SECONDFPN image branch (MIOpen, %s) -> " % args.image_dtype
+                      if args.from_images else "") +
                      "hot path (LSS voxel pooling -> dual-path encoder -> pixel decoder -> occupancy decoder)"),
         "value": world * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
         "dtype": {"f32": "f32", "bf16x3": "f32 (contractions as 3-term bf16 split on the bf16 matrix cores, fp32 "
                   "accumulate)", "bf16": "bf16 products, fp32 accumulate"}[prec], "data": "synthetic",
-        "config": {"workload": f"{args.workload}_{'train_step' if train else 'forward'}_from_neck_features",
+        "config": {"workload": f"{args.workload}_{'train_step' if train else 'forward'}_from_" +
+                               (f"images_{args.image_dtype}_image_branch" if args.from_images else "neck_features"),
                    "grid": list(meta["grid"]), "input_size": list(meta["input_size"]), "global_batch": world,
                    "parallelism": f"dp{world} " + ("(DDP: one RCCL gradient all-reduce per step, bucketed, overlapped "
                                                    "with backward; BatchNorm on per-rank batch statistics)" if train else

@@ -224,6 +224,9 @@ class OccupancyFormer(nn.Module):
         self.img_bev_encoder_backbone = MODELS.build(img_bev_encoder_backbone)
         self.img_bev_encoder_neck = MODELS.build(img_bev_encoder_neck)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        # dtype of the 2-D image branch (ResNet / EfficientNet + SECONDFPN on PyTorch-ROCm / MIOpen, SURVEY.md §8f
+        # row 3): None = fp32 as the reference runs it; torch.bfloat16 = autocast + channels_last
+        self.image_dtype = None
         self.record_time = False
         self.time_stats = collections.defaultdict(list)
 
@@ -243,11 +246,22 @@ class OccupancyFormer(nn.Module):
         if self.img_backbone is None:            # caller already supplies neck features [B,N,C,fH,fW]
             return img
         B, N, C, H, W = img.shape
-        x = self.img_backbone(img.view(B * N, C, H, W))
-        if self.with_img_neck:
-            x = self.img_neck(x)
-            if isinstance(x, (list, tuple)):
-                x = x[0]
+        x = img.view(B * N, C, H, W)
+        if self.image_dtype is not None and x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)
+            with torch.autocast("cuda", dtype=self.image_dtype):
+                x = self.img_backbone(x)
+                if self.with_img_neck:
+                    x = self.img_neck(x)
+                    if isinstance(x, (list, tuple)):
+                        x = x[0]
+            x = x.float().contiguous()
+        else:
+            x = self.img_backbone(x)
+            if self.with_img_neck:
+                x = self.img_neck(x)
+                if isinstance(x, (list, tuple)):
+                    x = x[0]
         return x.view(B, N, *x.shape[1:])
 
     def bev_encoder(self, x):

@@ -163,3 +163,26 @@ def test_dcnv2_module_on_gpu_uses_the_kernel(hip):
         ref = m(x)
         out = m.to(hip.device)(x.to(hip.device)).cpu()
     assert float((out - ref).abs().max() / ref.abs().max()) < 1e-4
+
+
+@pytest.mark.gpu
+def test_image_branch_gpu_vs_cpu(hip):
+    """R50 + SECONDFPN (the nuScenes image branch, PyTorch-ROCm / MIOpen glue outside the hand-written path) on the
+    GPU: fp32 equals the CPU run of the same module; the bf16 channels_last mode of `bench.py --from-images` stays
+    within bf16 accuracy.  (First use compiles / looks up the MIOpen solvers: the test warms them itself.)"""
+    from occformer_amd import configs
+    from occformer_amd.registry import build_model
+    torch.manual_seed(0)
+    cfg, meta = configs.nusc_r50("reference", with_image_branch=True)
+    model = build_model(cfg).eval()
+    img = paramgen.tensor("imgbr.x", (1, 2, 3, 128, 352), 1)
+    with torch.no_grad():
+        ref = model.image_encoder(img)
+        model = model.to(hip.device)
+        out = model.image_encoder(img.to(hip.device)).cpu()
+        assert float((out - ref).abs().max() / ref.abs().max()) < 1e-3
+        model.image_dtype = torch.bfloat16
+        model.img_backbone.to(memory_format=torch.channels_last)
+        model.img_neck.to(memory_format=torch.channels_last)
+        out16 = model.image_encoder(img.to(hip.device)).cpu()
+        assert float((out16 - ref).abs().max() / ref.abs().max()) < 5e-2
