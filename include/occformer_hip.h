@@ -427,11 +427,15 @@ int occf_masked_xattn_bwd(const float* q, const float* k, const float* v, const 
 
 /* Backward of occf_msda3d_fwd.  dout[B, Nq, heads*head_dim]; dvalue[B, Nq, heads*head_dim] TOKEN-major (whatever
  * layout `value` has) and ZERO-FILLED by the caller (scatter with float atomics, as F.grid_sample's backward);
- * doffsets / dlogits in the forward's layouts with their own row strides (0 = dense). */
+ * doffsets / dlogits in the forward's layouts with their own row strides (0 = dense).
+ * workspace (occf_msda3d_bwd_workspace floats; 0 / NULL = plain atomic scatter): with head_dim 12 / 24 the value
+ * gradient is accumulated in LDS tiles of the sampled level and reduced deterministically from per-tile slabs. */
+long occf_msda3d_bwd_workspace(const int32_t* level_shapes, int num_levels, int B, int heads, int head_dim);
 int occf_msda3d_bwd(const float* value, const float* sampling_offsets, const float* attn_logits, const float* dout,
                     float* dvalue, float* doffsets, float* dlogits, const int32_t* level_shapes, int num_levels, int B,
                     int Nq, int heads, int head_dim, int num_points, int value_head_major, long offsets_ld,
-                    long logits_ld, long doffsets_ld, long dlogits_ld, void* stream);
+                    long logits_ld, long doffsets_ld, long dlogits_ld, float* workspace, long workspace_floats,
+                    void* stream);
 
 /* Backward of occf_deform_im2col (mmcv deformable_col2im + deformable_col2im_coord): dcol in the forward's column
  * layout -> dx[BN, H, W, C] (scatter with float atomics, ZERO-FILLED by the caller) and doffset in conv_offset's

@@ -250,6 +250,333 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_kernel(
   }
 }
 
+
+// --------------------------------------------------------------------------------------------- matrix-core variant
+// Same contract as window_attn_bwd_kernel; the five 64 x 64 x 32 contractions per (window, head) run on
+// v_mfma_f32_32x32x16_bf16 (3-term bf16 split, fp32 accumulate) instead of ~7 800 VALU FMAs per lane (the VALU kernel
+// ran at 6 % of the vector rate: 12.8 ms per stage-0 call, 50 ms per training step).  With D = A . B returning
+// lane -> column, registers -> rows (r&3) + 8 (r>>2) + 4 (lane>>5), and an operand lane supplying 8 consecutive k:
+//   orientation 1 (lane = query):  St  = K . Q^T,  dPt = V . dO^T   (A = key rows, B = query rows; k = d)
+//        -> P, dS per query column in registers (the softmax statistics of a query sit in ONE lane pair)
+//        dQt[d][query] = K^T[d][key] . dSt[key][query]               (A = K^T image in LDS, B = dSt from registers)
+//   orientation 2 (lane = key):    S'  = Q . K^T,  dP' = dO . V^T   (the same row operands with the roles swapped)
+//        -> P', dS' per key column, using the lse / D of orientation 1 (LDS)
+//        dVt[d][key] = dO^T[d][query] . P'[query][key],  dKt[d][key] = Qs^T[d][query] . dS'[query][key]
+// Row operands (K, V, scaled Q, dO: 8 consecutive d of one token) come straight from global memory; only the three
+// transposed images (K^T, dO^T, Qs^T: [4 k-steps][32 d][2 slots][8 tokens], hi / lo) live in LDS: 24 KB per wave.
+typedef uint32_t wbm_u2 __attribute__((ext_vector_type(2)));
+#define WBM_IMG 4096            // bytes of one transposed image half (hi or lo)
+
+__device__ __forceinline__ void wbm_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) occf_bf16_split2(v[2 * e], v[2 * e + 1], h[e], l[e]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[2 * e] = (short)(h[e] & 0xFFFFu);
+    hi[2 * e + 1] = (short)(h[e] >> 16);
+    lo[2 * e] = (short)(l[e] & 0xFFFFu);
+    lo[2 * e + 1] = (short)(l[e] >> 16);
+  }
+}
+// token t, head channel d -> byte offset of its bf16 in a transposed image (token order inside a 16-token k-step:
+// t & 15 = 8 (e >> 2) + 4 slot + (e & 3), the order in which a C-layout register file hands its rows on as B operand)
+__device__ __forceinline__ int wbm_toff(int t, int d) {
+  const int kk = t & 15;
+  const int e = ((kk >> 3) << 2) | (kk & 3), slot = (kk >> 2) & 1;
+  return (t >> 4) * 1024 + d * 32 + slot * 16 + e * 2;
+}
+
+__global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_mfma_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
+    const float* __restrict__ attn_out, const float* __restrict__ dout, float* __restrict__ dqkv,
+    float* __restrict__ dqkv_bias, float* __restrict__ dtable_partial, int B, int X, int Y, int S, int C, int heads,
+    int shift, float scale, int wpb, long n_windows) {
+  __shared__ __attribute__((aligned(16))) unsigned char img[WB_HPB][6 * WBM_IMG];   // K^T h|l, dO^T h|l, Qs^T h|l
+  __shared__ float lds_bias[WB_HPB][WB_NB];
+  __shared__ float lds_dtab[WB_HPB][WB_NB + 3];
+  __shared__ float lds_lse[WB_HPB][64], lds_D[WB_HPB][64];
+  __shared__ int lds_tok[WB_HPB][64], lds_reg[WB_HPB][64];
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 31, lk = lane >> 5;
+  const int nwx = (X + WB_WS - 1) / WB_WS, nwy = (Y + WB_WS - 1) / WB_WS;
+  const int Xp = nwx * WB_WS, Yp = nwy * WB_WS;
+  const int head_raw = blockIdx.y * WB_HPB + wave;
+  const bool active = head_raw < heads;
+  const int head = active ? head_raw : heads - 1;
+  const int C3 = 3 * C;
+  unsigned char* base = img[wave];
+  for (int t = lane; t < WB_NB; t += 64) {
+    lds_bias[wave][t] = bias_table[(long)t * heads + head];
+    lds_dtab[wave][t] = 0.f;
+  }
+
+  for (int wi = 0; wi < wpb; ++wi) {
+    const long win = (long)blockIdx.x * wpb + wi;
+    if (win >= n_windows) break;
+    long w = win;
+    const int wy = (int)(w % nwy);
+    w /= nwy;
+    const int wx = (int)(w % nwx);
+    w /= nwx;
+    const int s = (int)(w % S);
+    const int b = (int)(w / S);
+    __syncthreads();                                           // previous window's LDS contents are consumed
+    {
+      int tok = -1, region = 0;
+      if (lane < WB_T) {
+        const int i = lane / WB_WS, j = lane % WB_WS;
+        const int px = wx * WB_WS + i, py = wy * WB_WS + j;
+        int sx = px + shift, sy = py + shift;
+        if (sx >= Xp) sx -= Xp;
+        if (sy >= Yp) sy -= Yp;
+        if (sx < X && sy < Y) tok = (int)((((long)b * X + sx) * Y + sy) * S + s);
+        if (shift > 0) {
+          const int rx = px < Xp - WB_WS ? 0 : (px < Xp - shift ? 1 : 2);
+          const int ry = py < Yp - WB_WS ? 0 : (py < Yp - shift ? 1 : 2);
+          region = rx * 3 + ry;
+        }
+      }
+      lds_tok[wave][lane] = tok;
+      lds_reg[wave][lane] = region;
+    }
+    __syncthreads();
+
+    // ---- row operands of this lane's two tokens (tile tt: token 32 tt + li), 8 consecutive d at lk*8 + 16 ks.
+    // rows 49..63 are zero; padded window positions (t < 49, no token) take the bias row for k / v and have no
+    // query / dO (the forward crops them)
+    bf16x8 Kh[2][2], Kl[2][2], Vh[2][2], Vl[2][2], Qh[2][2], Ql[2][2], Gh[2][2], Gl[2][2];
+    int tokt[2];
+    float Dpart[2] = {0.f, 0.f};
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = tt * 32 + li;
+      const int tok = lds_tok[wave][t];
+      tokt[tt] = tok;
+      const bool real = t < WB_T;
+      const float* src = (tok >= 0 ? qkv + (long)tok * C3 : qkv_bias) + head * WB_HD + lk * 8;
+      const float* gsrc = dout + (long)(tok >= 0 ? tok : 0) * C + head * WB_HD + lk * 8;
+      const float* osrc = attn_out + (long)(tok >= 0 ? tok : 0) * C + head * WB_HD + lk * 8;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float4 q0 = *(const float4*)(src + ks * 16), q1 = *(const float4*)(src + ks * 16 + 4);
+        const float4 k0 = *(const float4*)(src + C + ks * 16), k1 = *(const float4*)(src + C + ks * 16 + 4);
+        const float4 v0 = *(const float4*)(src + 2 * C + ks * 16), v1 = *(const float4*)(src + 2 * C + ks * 16 + 4);
+        const float4 g0 = *(const float4*)(gsrc + ks * 16), g1 = *(const float4*)(gsrc + ks * 16 + 4);
+        const float4 o0 = *(const float4*)(osrc + ks * 16), o1 = *(const float4*)(osrc + ks * 16 + 4);
+        const float km = real ? 1.f : 0.f, qm = (real && tok >= 0) ? 1.f : 0.f;
+        const float fk[8] = {k0.x * km, k0.y * km, k0.z * km, k0.w * km, k1.x * km, k1.y * km, k1.z * km, k1.w * km};
+        const float fv[8] = {v0.x * km, v0.y * km, v0.z * km, v0.w * km, v1.x * km, v1.y * km, v1.z * km, v1.w * km};
+        const float fq[8] = {q0.x * scale * qm, q0.y * scale * qm, q0.z * scale * qm, q0.w * scale * qm,
+                             q1.x * scale * qm, q1.y * scale * qm, q1.z * scale * qm, q1.w * scale * qm};
+        const float fg[8] = {g0.x * qm, g0.y * qm, g0.z * qm, g0.w * qm, g1.x * qm, g1.y * qm, g1.z * qm, g1.w * qm};
+        Dpart[tt] += qm * ((g0.x * o0.x + g0.y * o0.y) + (g0.z * o0.z + g0.w * o0.w) +
+                           (g1.x * o1.x + g1.y * o1.y) + (g1.z * o1.z + g1.w * o1.w));
+        wbm_split8(fk, Kh[tt][ks], Kl[tt][ks]);
+        wbm_split8(fv, Vh[tt][ks], Vl[tt][ks]);
+        wbm_split8(fq, Qh[tt][ks], Ql[tt][ks]);
+        wbm_split8(fg, Gh[tt][ks], Gl[tt][ks]);
+        // transposed images: this lane's 8 channels d = 16 ks + 8 lk + e of token t
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int d = ks * 16 + lk * 8 + e;
+          const int off = wbm_toff(t, d);
+          *(uint16_t*)(base + 0 * WBM_IMG + off) = (uint16_t)Kh[tt][ks][e];
+          *(uint16_t*)(base + 1 * WBM_IMG + off) = (uint16_t)Kl[tt][ks][e];
+          *(uint16_t*)(base + 2 * WBM_IMG + off) = (uint16_t)Gh[tt][ks][e];
+          *(uint16_t*)(base + 3 * WBM_IMG + off) = (uint16_t)Gl[tt][ks][e];
+          *(uint16_t*)(base + 4 * WBM_IMG + off) = (uint16_t)Qh[tt][ks][e];
+          *(uint16_t*)(base + 5 * WBM_IMG + off) = (uint16_t)Ql[tt][ks][e];
+        }
+      }
+      Dpart[tt] += __shfl_xor(Dpart[tt], 32);
+    }
+    __syncthreads();                                           // images complete
+
+    // ================= orientation 1: lane = query column qi
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int qi = qt * 32 + li;
+      const int qrow = (qi * 37) >> 8, qcol = qi - qrow * WB_WS;
+      const bool qreal = qi < WB_T && tokt[qt] >= 0;
+      const int qreg = lds_reg[wave][qi];
+      f32x16 st[2], dp[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kt][r] = dp[kt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          st[kt] = occf_mfma_bf16_32x32x16(Kl[kt][ks], Qh[qt][ks], st[kt]);
+          st[kt] = occf_mfma_bf16_32x32x16(Kh[kt][ks], Ql[qt][ks], st[kt]);
+          st[kt] = occf_mfma_bf16_32x32x16(Kh[kt][ks], Qh[qt][ks], st[kt]);
+          dp[kt] = occf_mfma_bf16_32x32x16(Vl[kt][ks], Gh[qt][ks], dp[kt]);
+          dp[kt] = occf_mfma_bf16_32x32x16(Vh[kt][ks], Gl[qt][ks], dp[kt]);
+          dp[kt] = occf_mfma_bf16_32x32x16(Vh[kt][ks], Gh[qt][ks], dp[kt]);
+        }
+      }
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const int krow = (key * 37) >> 8, kcol = key - krow * WB_WS;
+          float a = st[kt][r];
+          if (key < WB_T) {
+            const int bi = (qrow - krow + WB_WS - 1) * (2 * WB_WS - 1) + (qcol - kcol + WB_WS - 1);
+            a += lds_bias[wave][qi < WB_T ? bi : 0];
+            if (shift > 0 && lds_reg[wave][key] != qreg) a += -100.0f;
+          } else {
+            a = -INFINITY;
+          }
+          st[kt][r] = a;
+          mx = fmaxf(mx, a);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          st[kt][r] = expf(st[kt][r] - mx);
+          sum += st[kt][r];
+        }
+      sum += __shfl_xor(sum, 32);
+      const float inv = qreal ? 1.0f / sum : 0.f;
+      const float Dq = Dpart[qt];
+      if (lk == 0) {
+        lds_lse[wave][qi] = qreal ? mx + logf(sum) : INFINITY;          // exp(x - inf) = 0: padded queries drop out
+        lds_D[wave][qi] = Dq;
+      }
+      // dS = P (dP - D); relative-position-bias gradient; dSt as B operand of dQt = K^T . dSt
+      bf16x8 sh[4], sl[4];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          float dv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int r = s2 * 8 + e;
+            const float ds = st[kt][r] * inv * (dp[kt][r] - Dq);
+            dv[e] = ds;
+            const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            if (active && qreal && key < WB_T) {
+              const int krow = (key * 37) >> 8, kcol = key - krow * WB_WS;
+              atomicAdd(&lds_dtab[wave][(qrow - krow + WB_WS - 1) * (2 * WB_WS - 1) + (qcol - kcol + WB_WS - 1)], ds);
+            }
+          }
+          wbm_split8(dv, sh[kt * 2 + s2], sl[kt * 2 + s2]);
+        }
+      f32x16 dq;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+#pragma unroll
+      for (int kst = 0; kst < 4; ++kst) {
+        const int off = kst * 1024 + li * 32 + lk * 16;
+        const bf16x8 ah = *(const bf16x8*)(base + 0 * WBM_IMG + off), al = *(const bf16x8*)(base + 1 * WBM_IMG + off);
+        dq = occf_mfma_bf16_32x32x16(al, sh[kst], dq);
+        dq = occf_mfma_bf16_32x32x16(ah, sl[kst], dq);
+        dq = occf_mfma_bf16_32x32x16(ah, sh[kst], dq);
+      }
+      if (active && qreal) {
+        float* dst = dqkv + (long)tokt[qt] * C3 + head * WB_HD + 4 * lk;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(float4*)(dst + 8 * g) = make_float4(dq[g * 4 + 0] * scale, dq[g * 4 + 1] * scale, dq[g * 4 + 2] * scale,
+                                                dq[g * 4 + 3] * scale);
+      }
+    }
+    __syncthreads();                                           // lse / D of every query are in LDS
+
+    // ================= orientation 2: lane = key column ki
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int ki = kt * 32 + li;
+      const int krow = (ki * 37) >> 8, kcol = ki - krow * WB_WS;
+      const bool kreal = ki < WB_T;
+      const int kreg = lds_reg[wave][ki];
+      bf16x8 ph[4], pl[4], sh[4], sl[4];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x16 st, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          st = occf_mfma_bf16_32x32x16(Ql[qt][ks], Kh[kt][ks], st);
+          st = occf_mfma_bf16_32x32x16(Qh[qt][ks], Kl[kt][ks], st);
+          st = occf_mfma_bf16_32x32x16(Qh[qt][ks], Kh[kt][ks], st);
+          dp = occf_mfma_bf16_32x32x16(Gl[qt][ks], Vh[kt][ks], dp);
+          dp = occf_mfma_bf16_32x32x16(Gh[qt][ks], Vl[kt][ks], dp);
+          dp = occf_mfma_bf16_32x32x16(Gh[qt][ks], Vh[kt][ks], dp);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          float pv[8], dv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int r = s2 * 8 + e;
+            const int qi = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+            const int qrow = (qi * 37) >> 8, qcol = qi - qrow * WB_WS;
+            float a = st[r];
+            float pp = 0.f;
+            if (kreal) {
+              const int bi = (qrow - krow + WB_WS - 1) * (2 * WB_WS - 1) + (qcol - kcol + WB_WS - 1);
+              a += lds_bias[wave][qi < WB_T ? bi : 0];
+              if (shift > 0 && lds_reg[wave][qi] != kreg) a += -100.0f;
+              pp = expf(a - lds_lse[wave][qi]);
+            }
+            pv[e] = pp;
+            dv[e] = pp * (dp[r] - lds_D[wave][qi]);
+          }
+          wbm_split8(pv, ph[qt * 2 + s2], pl[qt * 2 + s2]);
+          wbm_split8(dv, sh[qt * 2 + s2], sl[qt * 2 + s2]);
+        }
+      }
+      f32x16 dvt, dkt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dvt[r] = dkt[r] = 0.f;
+#pragma unroll
+      for (int kst = 0; kst < 4; ++kst) {
+        const int off = kst * 1024 + li * 32 + lk * 16;
+        const bf16x8 gh = *(const bf16x8*)(base + 2 * WBM_IMG + off), gl = *(const bf16x8*)(base + 3 * WBM_IMG + off);
+        const bf16x8 qh = *(const bf16x8*)(base + 4 * WBM_IMG + off), ql = *(const bf16x8*)(base + 5 * WBM_IMG + off);
+        dvt = occf_mfma_bf16_32x32x16(gl, ph[kst], dvt);
+        dvt = occf_mfma_bf16_32x32x16(gh, pl[kst], dvt);
+        dvt = occf_mfma_bf16_32x32x16(gh, ph[kst], dvt);
+        dkt = occf_mfma_bf16_32x32x16(ql, sh[kst], dkt);
+        dkt = occf_mfma_bf16_32x32x16(qh, sl[kst], dkt);
+        dkt = occf_mfma_bf16_32x32x16(qh, sh[kst], dkt);
+      }
+      if (active && kreal) {
+        if (tokt[kt] >= 0) {
+          float* dk = dqkv + (long)tokt[kt] * C3 + C + head * WB_HD + 4 * lk;
+          float* dvp = dk + C;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            *(float4*)(dk + 8 * g) = make_float4(dkt[g * 4 + 0], dkt[g * 4 + 1], dkt[g * 4 + 2], dkt[g * 4 + 3]);
+            *(float4*)(dvp + 8 * g) = make_float4(dvt[g * 4 + 0], dvt[g * 4 + 1], dvt[g * 4 + 2], dvt[g * 4 + 3]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int d = (r & 3) + 8 * (r >> 2) + 4 * lk;
+            atomicAdd(dqkv_bias + C + head * WB_HD + d, dkt[r]);
+            atomicAdd(dqkv_bias + 2 * C + head * WB_HD + d, dvt[r]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (active)
+    for (int r = lane; r < WB_NB; r += 64)
+      dtable_partial[((long)blockIdx.x * WB_NB + r) * heads + head] = lds_dtab[wave][r];
+}
+
 // dtable[r][head] = sum_x partial[x][r][head]: 64 columns x 16 row groups per workgroup, double accumulation
 __global__ void __launch_bounds__(1024) window_table_reduce_kernel(const float* __restrict__ partial,
                                                                    float* __restrict__ dtable, long nblk, int C) {
@@ -288,9 +615,18 @@ extern "C" int occf_window_attn_bwd(const float* qkv, const float* qkv_bias, con
   const long nwin = (long)B * S * ((X + 6) / 7) * ((Y + 6) / 7);
   const int wpb = wb_windows_per_block(nwin);
   const int nblk = occf_cdiv(nwin, wpb);
-  hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(nblk, occf_cdiv(heads, WB_HPB)), dim3(64 * WB_HPB), 0, st, qkv,
-                     qkv_bias, bias_table, attn_out, dout, dqkv, dqkv_bias, workspace, B, X, Y, S, C, heads, shift,
-                     1.0f / sqrtf((float)WB_HD), wpb, nwin);
+  static const bool mfma = [] {
+    const char* e = getenv("OCCF_WATTN_BWD_MFMA");
+    return e ? atoi(e) != 0 : true;
+  }();
+  if (mfma)
+    hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, dim3(nblk, occf_cdiv(heads, WB_HPB)), dim3(64 * WB_HPB), 0, st, qkv,
+                       qkv_bias, bias_table, attn_out, dout, dqkv, dqkv_bias, workspace, B, X, Y, S, C, heads, shift,
+                       1.0f / sqrtf((float)WB_HD), wpb, nwin);
+  else
+    hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(nblk, occf_cdiv(heads, WB_HPB)), dim3(64 * WB_HPB), 0, st, qkv,
+                       qkv_bias, bias_table, attn_out, dout, dqkv, dqkv_bias, workspace, B, X, Y, S, C, heads, shift,
+                       1.0f / sqrtf((float)WB_HD), wpb, nwin);
   hipLaunchKernelGGL(window_table_reduce_kernel, dim3(occf_cdiv(WB_NB * heads, 64)), dim3(1024), 0, st, workspace,
                      dbias_table, (long)nblk, WB_NB * heads);
   OCCF_LAUNCH_CHECK();

@@ -397,8 +397,8 @@ __device__ __forceinline__ int msda_cdiv_pos(long num, long den) { return num <=
 
 __global__ void __launch_bounds__(256) msda3d_bwd_value_tile_kernel(
     const float* __restrict__ offs, const float* __restrict__ logits, const float* __restrict__ dout,
-    float* __restrict__ dvalue, MsdaLevels lv, MsdaTileCfg tc, int B, int Nq, int H, int Dh, int P, long off_ld,
-    long lg_ld) {
+    float* __restrict__ dvalue, float* __restrict__ scratch, MsdaLevels lv, MsdaTileCfg tc, int B, int Nq, int H, int Dh,
+    int P, long off_ld, long lg_ld) {
   OCCF_DYN_SMEM(smem_raw);
   float* tile = (float*)smem_raw;
   const int L = lv.n, LP = L * P;
@@ -504,19 +504,52 @@ __global__ void __launch_bounds__(256) msda3d_bwd_value_tile_kernel(
     }
   }
   __syncthreads();
-  // flush: non-zero entries of the in-volume part of the region
-  float* dvb = dvalue + ((long)b * Nv + lv.start[ls]) * E + h * Dh + ch0;
-  for (long i = threadIdx.x; i < ncell * CH; i += 256) {
-    const float v = tile[i];
-    if (v == 0.f) continue;
-    const int ch = (int)(i % CH);
-    long cidx = i / CH;
-    const int zz = (int)(cidx % Zs);
-    cidx /= Zs;
-    const int yy = ry0 + (int)(cidx % RY), xx = rx0 + (int)(cidx / RY);
-    if ((unsigned)xx >= (unsigned)Xs || (unsigned)yy >= (unsigned)Ys) continue;
-    atomicAdd(dvb + (((long)xx * Ys + yy) * Zs + zz) * E + ch, v);
-  }
+  // hand the region over: plain coalesced stores into this workgroup's slab of the scratch buffer; the gather
+  // kernel below sums, for every cell, the (at most 9) regions that cover it -- no atomics, fixed order
+  float* slab = scratch + (((long)b * H + h) * gridDim.x + blockIdx.x) * (ncell * CH);
+  for (long i = threadIdx.x; i < ncell * CH; i += 256) slab[i] = tile[i];
+}
+
+// dvalue[cell, h*Dh + ch] += sum over the regions that contain the cell (tiles: <= 3 per axis; whole-level mode: the
+// `groups` copies).  thread = (b, h, cell of level ls, channel)
+__global__ void __launch_bounds__(256) msda3d_bwd_value_gather_kernel(const float* __restrict__ scratch,
+                                                                      float* __restrict__ dvalue, MsdaLevels lv,
+                                                                      MsdaTileCfg tc, int B, int H, int Dh) {
+  const int ls = tc.ls;
+  const int Xs = lv.X[ls], Ys = lv.Y[ls], Zs = lv.Z[ls];
+  const long cells = (long)Xs * Ys * Zs;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)B * H * cells * Dh) return;
+  const int ch = (int)(gid % Dh);
+  long r = gid / Dh;
+  const long cell = r % cells;
+  r /= cells;
+  const int h = (int)(r % H);
+  const int b = (int)(r / H);
+  const int z = (int)(cell % Zs);
+  const int y = (int)((cell / Zs) % Ys), x = (int)(cell / ((long)Zs * Ys));
+  const int pass = ch / tc.CH, chl = ch - pass * tc.CH;
+  const int RX = tc.T + 2 * tc.M, RY = RX;
+  const long region = (long)RX * RY * Zs * tc.CH;
+  const long nblk = (long)tc.tiles_x * tc.tiles_y * tc.groups * tc.passes;
+  const float* base = scratch + ((long)b * H + h) * nblk * region;
+  int tx_lo = (x - tc.M - tc.T + 1), ty_lo = (y - tc.M - tc.T + 1);
+  tx_lo = tx_lo <= 0 ? 0 : (tx_lo + tc.T - 1) / tc.T;
+  ty_lo = ty_lo <= 0 ? 0 : (ty_lo + tc.T - 1) / tc.T;
+  int tx_hi = (x + tc.M) / tc.T, ty_hi = (y + tc.M) / tc.T;
+  tx_hi = tx_hi > tc.tiles_x - 1 ? tc.tiles_x - 1 : tx_hi;
+  ty_hi = ty_hi > tc.tiles_y - 1 ? tc.tiles_y - 1 : ty_hi;
+  float s = 0.f;
+  for (int tx = tx_lo; tx <= tx_hi; ++tx)
+    for (int ty = ty_lo; ty <= ty_hi; ++ty) {
+      const long local = (((long)(x - (tx * tc.T - tc.M)) * RY + (y - (ty * tc.T - tc.M))) * Zs + z) * tc.CH + chl;
+      for (int g = 0; g < tc.groups; ++g) {
+        const long blk = (((long)tx * tc.tiles_y + ty) * tc.groups + g) * tc.passes + pass;
+        s += base[blk * region + local];
+      }
+    }
+  const long Nv = lv.start[lv.n - 1] + (long)lv.X[lv.n - 1] * lv.Y[lv.n - 1] * lv.Z[lv.n - 1];
+  dvalue[((long)b * Nv + lv.start[ls] + cell) * ((long)H * Dh) + h * Dh + ch] += s;
 }
 
 static bool msda_tile_cfg(const MsdaLevels& lv, int ls, int Dh, MsdaTileCfg& tc) {
@@ -544,11 +577,46 @@ static bool msda_tile_cfg(const MsdaLevels& lv, int ls, int Dh, MsdaTileCfg& tc)
   return true;
 }
 
+static long msda_scratch_floats(const MsdaLevels& lv, const MsdaTileCfg& tc, int B, int heads) {
+  const long region = (long)(tc.T + 2 * tc.M) * (tc.T + 2 * tc.M) * lv.Z[tc.ls] * tc.CH;
+  return (long)B * heads * tc.tiles_x * tc.tiles_y * tc.groups * tc.passes * region;
+}
+
+static void msda_levels(const int32_t* level_shapes, int num_levels, MsdaLevels& lv, int& total) {
+  lv.n = num_levels;
+  int start = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    lv.X[l] = level_shapes[l * 3 + 0];
+    lv.Y[l] = level_shapes[l * 3 + 1];
+    lv.Z[l] = level_shapes[l * 3 + 2];
+    lv.start[l] = start;
+    start += lv.X[l] * lv.Y[l] * lv.Z[l];
+  }
+  for (int l = num_levels; l < MSDA_MAX_LEVELS; ++l) lv.X[l] = lv.Y[l] = lv.Z[l] = lv.start[l] = 0;
+  total = start;
+}
+
+// floats of scratch for occf_msda3d_bwd (the largest level's region slabs; the levels run one after the other)
+extern "C" long occf_msda3d_bwd_workspace(const int32_t* level_shapes, int num_levels, int B, int heads, int head_dim) {
+  if (num_levels <= 0 || num_levels > MSDA_MAX_LEVELS || (head_dim != 12 && head_dim != 24)) return 0;
+  MsdaLevels lv;
+  int total;
+  msda_levels(level_shapes, num_levels, lv, total);
+  long need = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    MsdaTileCfg tc;
+    if (!msda_tile_cfg(lv, l, head_dim, tc)) return 0;
+    const long n = msda_scratch_floats(lv, tc, B, heads);
+    need = n > need ? n : need;
+  }
+  return need;
+}
+
 extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets, const float* attn_logits,
                                const float* dout, float* dvalue, float* doffsets, float* dlogits,
                                const int32_t* level_shapes, int num_levels, int B, int Nq, int heads, int head_dim,
                                int num_points, int value_head_major, long offsets_ld, long logits_ld, long doffsets_ld,
-                               long dlogits_ld, void* stream) {
+                               long dlogits_ld, float* workspace, long workspace_floats, void* stream) {
   if (num_levels <= 0 || num_levels > MSDA_MAX_LEVELS || B <= 0 || heads <= 0 || head_dim <= 0 ||
       num_points <= 0 || num_levels * num_points > 16)
     return OCCF_ESHAPE;
@@ -574,10 +642,11 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
     return e ? atoi(e) : 1;
   }();
   int do_value = 1;
-  if (tiled_env && (head_dim == 12 || head_dim == 24)) {
+  if (tiled_env && workspace && (head_dim == 12 || head_dim == 24)) {
     MsdaTileCfg cfgs[MSDA_MAX_LEVELS];
     bool ok = true;
-    for (int l = 0; l < num_levels; ++l) ok = ok && msda_tile_cfg(lv, l, head_dim, cfgs[l]);
+    for (int l = 0; l < num_levels; ++l)
+      ok = ok && msda_tile_cfg(lv, l, head_dim, cfgs[l]) && msda_scratch_floats(lv, cfgs[l], B, heads) <= workspace_floats;
     if (ok) {
       do_value = 0;
       for (int l = 0; l < num_levels; ++l) {
@@ -593,7 +662,10 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
 #endif
         const dim3 grid((unsigned)(tc.tiles_x * tc.tiles_y * tc.groups * tc.passes), heads, B);
         hipLaunchKernelGGL(msda3d_bwd_value_tile_kernel, grid, dim3(256), lds, st, sampling_offsets, attn_logits, dout,
-                           dvalue, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
+                           dvalue, workspace, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
+        const long total = (long)B * heads * lv.X[l] * lv.Y[l] * lv.Z[l] * head_dim;
+        hipLaunchKernelGGL(msda3d_bwd_value_gather_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, workspace,
+                           dvalue, lv, tc, B, heads, head_dim);
       }
     }
   }

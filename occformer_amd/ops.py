@@ -734,11 +734,13 @@ class HipOps:
             dlg = torch.empty((B, Nq, heads * L * points), dtype=self.f32, device=value.device)
         else:
             doff, dlg = d_ol[..., :n_off], d_ol[..., n_off:]
+        need = self.lib.occf_msda3d_bwd_workspace(ctypes.cast(arr, ctypes.c_void_p), L, B, heads, E // heads)
+        ws = self._ws(need, value.device) if need > 0 else None
         self._call("occf_msda3d_bwd", self._ptr(value, self.f32), ctypes.c_void_p(offsets.data_ptr()),
                    ctypes.c_void_p(logits.data_ptr()), self._ptr(dout, self.f32), self._ptr(dvalue),
                    ctypes.c_void_p(doff.data_ptr()), ctypes.c_void_p(dlg.data_ptr()), ctypes.cast(arr, ctypes.c_void_p),
                    L, B, Nq, heads, E // heads, points, int(head_major), offsets.stride(1), logits.stride(1),
-                   doff.stride(1), dlg.stride(1), self._stream())
+                   doff.stride(1), dlg.stride(1), self._ptr(ws), need, self._stream())
         return dvalue, doff, dlg
 
     def deform_col2im(self, x_cl, offset, dcol, K, stride, pad, dil, groups, deform_groups):
