@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
   *(float4*)(dx + (b * V + r) * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
-#define GNB_ROWS 1024
+#define GNB_ROWS 256
 extern "C" long occf_groupnorm_bwd_workspace(int B, long V, int C, int G) {
   return (long)B * occf_cdiv(V, GNB_ROWS) * C * 2 + (long)B * C * 2 + (long)B * G * 2;
 }

@@ -36,6 +36,12 @@ struct WgArgs {
 
 typedef uint32_t wg_u4 __attribute__((ext_vector_type(4)));
 
+// 16-byte LDS slot of column `col` inside a row group: XOR swizzle that makes BOTH access patterns hit eight
+// distinct 16-byte bank groups per eight lanes -- the staging writes (a thread owns 4 consecutive columns, so one
+// store instruction covers columns 4*lane + e: stride 4) and the fragment reads (32 consecutive columns).  Unswizzled,
+// every staging store was a 4-way bank conflict.
+__device__ __forceinline__ int wg_swz(int col) { return col ^ ((col >> 3) & 3); }
+
 template <int BC, int TERMS>
 __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
   constexpr int TC = BC / 64;                 // 32-wide tiles per wave along c
@@ -142,7 +148,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
         occf_bf16_split2(cx[e][2], cx[e][3], hh, ll); h.y = hh; l.y = ll;
         occf_bf16_split2(cx[e][4], cx[e][5], hh, ll); h.z = hh; l.z = ll;
         occf_bf16_split2(cx[e][6], cx[e][7], hh, ll); h.w = hh; l.w = ll;
-        const int off = a_rg * 128 + a_c4 * 4 + e;
+        const int off = a_rg * 128 + wg_swz(a_c4 * 4 + e);
         Ah[off] = h;
         if (TERMS == 3) Al[off] = l;
       }
@@ -162,14 +168,14 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
 #pragma unroll
         for (int j = 0; j < RPT; j += 2) occf_bf16_split2(cx[e][j], cx[e][j + 1], hh[j / 2], ll[j / 2]);
         if (RPT == 8) {
-          const int off = b_rg * BC + b_c4 * 4 + e;
+          const int off = b_rg * BC + wg_swz(b_c4 * 4 + e);
           wg_u4 h, l;
           h.x = hh[0]; h.y = hh[1]; h.z = hh[RPT / 2 - 2]; h.w = hh[RPT / 2 - 1];
           l.x = ll[0]; l.y = ll[1]; l.z = ll[RPT / 2 - 2]; l.w = ll[RPT / 2 - 1];
           Bh[off] = h;
           if (TERMS == 3) Bl[off] = l;
         } else {
-          const int off = (b_rg >> 1) * BC + b_c4 * 4 + e;
+          const int off = (b_rg >> 1) * BC + wg_swz(b_c4 * 4 + e);
           uint32_t* dh = (uint32_t*)(Bh + off) + (b_rg & 1) * 2;
           uint32_t* dl = (uint32_t*)(Bl + off) + (b_rg & 1) * 2;
           dh[0] = hh[0];
@@ -189,7 +195,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int li = lane & 31, lk = lane >> 5;
   auto frag = [&](const wg_u4* base, int ld, int col, int ks) __attribute__((always_inline)) -> bf16x8 {
-    return __builtin_bit_cast(bf16x8, base[(ks * 2 + lk) * ld + col]);
+    return __builtin_bit_cast(bf16x8, base[(ks * 2 + lk) * ld + wg_swz(col)]);
   };
   auto compute = [&]() __attribute__((always_inline)) {
 #pragma unroll
