@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_mfma_kernel(
     int shift, float scale, int wpb, long n_windows) {
   __shared__ __attribute__((aligned(16))) unsigned char img[WB_HPB][6 * WBM_IMG];   // K^T h|l, dO^T h|l, Qs^T h|l
   __shared__ float lds_bias[WB_HPB][WB_NB];
-  __shared__ float lds_dtab[WB_HPB][WB_NB + 3];
+  __shared__ float lds_m[WB_HPB][WB_T * 64];          // dS[key][query] of the current window (bias-table gradient)
   __shared__ float lds_lse[WB_HPB][64], lds_D[WB_HPB][64];
   __shared__ int lds_tok[WB_HPB][64], lds_reg[WB_HPB][64];
 
@@ -307,10 +307,8 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_mfma_kernel(
   const int head = active ? head_raw : heads - 1;
   const int C3 = 3 * C;
   unsigned char* base = img[wave];
-  for (int t = lane; t < WB_NB; t += 64) {
-    lds_bias[wave][t] = bias_table[(long)t * heads + head];
-    lds_dtab[wave][t] = 0.f;
-  }
+  for (int t = lane; t < WB_NB; t += 64) lds_bias[wave][t] = bias_table[(long)t * heads + head];
+  float dtab[3] = {0.f, 0.f, 0.f};                    // bins lane, lane + 64, lane + 128 (LDS float atomics are slow)
 
   for (int wi = 0; wi < wpb; ++wi) {
     const long win = (long)blockIdx.x * wpb + wi;
@@ -463,10 +461,7 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_mfma_kernel(
             const float ds = st[kt][r] * inv * (dp[kt][r] - Dq);
             dv[e] = ds;
             const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (active && qreal && key < WB_T) {
-              const int krow = (key * 37) >> 8, kcol = key - krow * WB_WS;
-              atomicAdd(&lds_dtab[wave][(qrow - krow + WB_WS - 1) * (2 * WB_WS - 1) + (qcol - kcol + WB_WS - 1)], ds);
-            }
+            if (key < WB_T) lds_m[wave][key * 64 + qi] = qreal ? ds : 0.f;
           }
           wbm_split8(dv, sh[kt * 2 + s2], sl[kt * 2 + s2]);
         }
@@ -489,7 +484,28 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_mfma_kernel(
                                                 dq[g * 4 + 3] * scale);
       }
     }
-    __syncthreads();                                           // lse / D of every query are in LDS
+    __syncthreads();                                           // lse / D / dS of every query are in LDS
+    // relative-position-bias gradient: bin r = (di + 6) * 13 + (dj + 6) collects dS[(ki+di, kj+dj)][(ki, kj)]
+    if (active) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int r = lane + u * 64;
+        if (r < WB_NB) {
+          const int di = r / (2 * WB_WS - 1) - (WB_WS - 1), dj = r % (2 * WB_WS - 1) - (WB_WS - 1);
+          float a = 0.f;
+          for (int ki = 0; ki < WB_WS; ++ki) {
+            const int qi2 = ki + di;
+            if (qi2 < 0 || qi2 >= WB_WS) continue;
+            for (int kj = 0; kj < WB_WS; ++kj) {
+              const int qj2 = kj + dj;
+              if (qj2 < 0 || qj2 >= WB_WS) continue;
+              a += lds_m[wave][(ki * WB_WS + kj) * 64 + qi2 * WB_WS + qj2];
+            }
+          }
+          dtab[u] += a;
+        }
+      }
+    }
 
     // ================= orientation 2: lane = key column ki
 #pragma unroll
@@ -571,10 +587,13 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_mfma_kernel(
       }
     }
   }
-  __syncthreads();
-  if (active)
-    for (int r = lane; r < WB_NB; r += 64)
-      dtable_partial[((long)blockIdx.x * WB_NB + r) * heads + head] = lds_dtab[wave][r];
+  if (active) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int r = lane + u * 64;
+      if (r < WB_NB) dtable_partial[((long)blockIdx.x * WB_NB + r) * heads + head] = dtab[u];
+    }
+  }
 }
 
 // dtable[r][head] = sum_x partial[x][r][head]: 64 columns x 16 row groups per workgroup, double accumulation

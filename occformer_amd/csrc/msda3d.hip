@@ -388,6 +388,21 @@ __global__ void __launch_bounds__(256) msda3d_bwd_kernel(
 // every query whose own cell centre falls into the tile (queries of ALL levels: the levels are nested grids), and
 // flushes the non-zero part of the region once.  A sample that leaves the region (offsets larger than the margin)
 // falls back to the global atomic, so the result does not depend on the offsets being small.
+// LDS float atomics (ds_add_f32) serialise the 64 lanes on gfx950: 768 cycles per wave instruction against 30 for
+// ds_add_u32 / ds_add_u64 (scripts/lds_atomic_probe.hip).  The tiles therefore accumulate in 64-bit FIXED POINT:
+// contribution * 2^40 / max|dout| as a signed integer -- |contribution| <= max|dout|, so 2^23 of them fit, the
+// resolution is 2^-40 of the largest gradient entry, and the sum is order-independent (deterministic).
+__global__ void __launch_bounds__(256) msda_absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax((int*)out, (int)occf_f2u(m));       // non-negative floats order like ints
+}
+
+__global__ void msda_zero_word_kernel(unsigned* p) { p[0] = 0u; }
+
 struct MsdaTileCfg {
   int ls, T, M, tiles_x, tiles_y, groups;   // groups > 1: the level is ONE tile, its queries are split over `groups`
   int CH, passes, lpg;                      // channels per pass, passes per head, lanes per query (CH = 3 * lpg)
@@ -397,10 +412,13 @@ __device__ __forceinline__ int msda_cdiv_pos(long num, long den) { return num <=
 
 __global__ void __launch_bounds__(256) msda3d_bwd_value_tile_kernel(
     const float* __restrict__ offs, const float* __restrict__ logits, const float* __restrict__ dout,
-    float* __restrict__ dvalue, float* __restrict__ scratch, MsdaLevels lv, MsdaTileCfg tc, int B, int Nq, int H, int Dh,
-    int P, long off_ld, long lg_ld) {
+    float* __restrict__ dvalue, float* __restrict__ scratch, const unsigned* __restrict__ absmax_bits, MsdaLevels lv,
+    MsdaTileCfg tc, int B, int Nq, int H, int Dh, int P, long off_ld, long lg_ld) {
   OCCF_DYN_SMEM(smem_raw);
-  float* tile = (float*)smem_raw;
+  unsigned long long* tile = (unsigned long long*)smem_raw;
+  const float gmax = occf_u2f(absmax_bits[0]);
+  const float fx_scale = gmax > 0.f ? 1099511627776.0f / gmax : 1.0f;       // 2^40 / max|dout|
+  const float fx_inv = 1.0f / fx_scale;
   const int L = lv.n, LP = L * P;
   const int ls = tc.ls;
   const int Xs = lv.X[ls], Ys = lv.Y[ls], Zs = lv.Z[ls];
@@ -416,7 +434,7 @@ __global__ void __launch_bounds__(256) msda3d_bwd_value_tile_kernel(
   const int RX = tc.T + 2 * tc.M, RY = RX;
   const int CH = tc.CH, ch0 = pass * CH;
   const long ncell = (long)RX * RY * Zs;
-  for (long i = threadIdx.x; i < ncell * CH; i += 256) tile[i] = 0.f;
+  for (long i = threadIdx.x; i < ncell * CH; i += 256) tile[i] = 0ull;
   __syncthreads();
 
   // query boxes per query level: cell(q) = floor((2q + 1) * Xs / (2 * Xq)) in [tx0, tx0 + T)
@@ -490,10 +508,11 @@ __global__ void __launch_bounds__(256) msda3d_bwd_value_tile_kernel(
         const float cw = a * (cbx ? tx : 1.f - tx) * (cby ? ty : 1.f - ty) * (cbz ? tz : 1.f - tz);
         const int lx_ = xx - rx0, ly_ = yy - ry0;
         if ((unsigned)lx_ < (unsigned)RX && (unsigned)ly_ < (unsigned)RY) {
-          float* t = tile + (((long)lx_ * RY + ly_) * Zs + zz) * CH + sub * 3;
-          atomicAdd(t + 0, cw * g0);
-          atomicAdd(t + 1, cw * g1);
-          atomicAdd(t + 2, cw * g2);
+          unsigned long long* t = tile + (((long)lx_ * RY + ly_) * Zs + zz) * CH + sub * 3;
+          const float cs = cw * fx_scale;
+          atomicAdd(t + 0, (unsigned long long)(long long)llrintf(cs * g0));
+          atomicAdd(t + 1, (unsigned long long)(long long)llrintf(cs * g1));
+          atomicAdd(t + 2, (unsigned long long)(long long)llrintf(cs * g2));
         } else {
           float* d = dvb + (((long)xx * Ys + yy) * Zs + zz) * E;
           atomicAdd(d + 0, cw * g0);
@@ -507,7 +526,7 @@ __global__ void __launch_bounds__(256) msda3d_bwd_value_tile_kernel(
   // hand the region over: plain coalesced stores into this workgroup's slab of the scratch buffer; the gather
   // kernel below sums, for every cell, the (at most 9) regions that cover it -- no atomics, fixed order
   float* slab = scratch + (((long)b * H + h) * gridDim.x + blockIdx.x) * (ncell * CH);
-  for (long i = threadIdx.x; i < ncell * CH; i += 256) slab[i] = tile[i];
+  for (long i = threadIdx.x; i < ncell * CH; i += 256) slab[i] = (float)((double)(long long)tile[i] * (double)fx_inv);
 }
 
 // dvalue[cell, h*Dh + ch] += sum over the regions that contain the cell (tiles: <= 3 per axis; whole-level mode: the
@@ -553,28 +572,33 @@ __global__ void __launch_bounds__(256) msda3d_bwd_value_gather_kernel(const floa
 }
 
 static bool msda_tile_cfg(const MsdaLevels& lv, int ls, int Dh, MsdaTileCfg& tc) {
-  const long budget = 100 * 1024;                       // bytes of LDS per workgroup
+  const long budget = 124 * 1024;                       // bytes of LDS per workgroup (8 bytes per element)
   const int X = lv.X[ls], Y = lv.Y[ls], Z = lv.Z[ls];
   tc.ls = ls;
-  tc.lpg = Dh == 24 ? 4 : Dh / 3;                       // 12 channels per pass at head_dim 24, all of them at 12
-  tc.CH = 3 * tc.lpg;
-  tc.passes = Dh / tc.CH;
-  if ((long)X * Y * Z * tc.CH * 4 <= budget) {          // the whole level as one tile, its queries split over groups
-    tc.T = X > Y ? X : Y;
-    tc.M = 0;
-    tc.tiles_x = tc.tiles_y = 1;
-    tc.groups = 32;
+  tc.M = 5;
+  // channels per pass: 12 (4 lanes per query) if a tile of at least 4 x 4 columns fits, else 6
+  for (int lpg = Dh >= 12 ? 4 : Dh / 3; lpg >= 2; lpg >>= 1) {
+    if (Dh % (3 * lpg)) continue;
+    tc.lpg = lpg;
+    tc.CH = 3 * lpg;
+    tc.passes = Dh / tc.CH;
+    if ((long)X * Y * Z * tc.CH * 8 <= budget) {        // the whole level as one tile, its queries split over groups
+      tc.T = X > Y ? X : Y;
+      tc.M = 0;
+      tc.tiles_x = tc.tiles_y = 1;
+      tc.groups = 32;
+      return true;
+    }
+    int T = 16;
+    while (T > 2 && (long)(T + 2 * tc.M) * (T + 2 * tc.M) * Z * tc.CH * 8 > budget) --T;
+    if ((long)(T + 2 * tc.M) * (T + 2 * tc.M) * Z * tc.CH * 8 > budget || (T < 4 && lpg > 2)) continue;
+    tc.groups = 1;
+    tc.T = T;
+    tc.tiles_x = (X + T - 1) / T;
+    tc.tiles_y = (Y + T - 1) / T;
     return true;
   }
-  tc.M = 5;
-  tc.groups = 1;
-  int T = 16;
-  while (T > 2 && (long)(T + 2 * tc.M) * (T + 2 * tc.M) * Z * tc.CH * 4 > budget) --T;
-  if ((long)(T + 2 * tc.M) * (T + 2 * tc.M) * Z * tc.CH * 4 > budget) return false;
-  tc.T = T;
-  tc.tiles_x = (X + T - 1) / T;
-  tc.tiles_y = (Y + T - 1) / T;
-  return true;
+  return false;
 }
 
 static long msda_scratch_floats(const MsdaLevels& lv, const MsdaTileCfg& tc, int B, int heads) {
@@ -609,7 +633,7 @@ extern "C" long occf_msda3d_bwd_workspace(const int32_t* level_shapes, int num_l
     const long n = msda_scratch_floats(lv, tc, B, heads);
     need = n > need ? n : need;
   }
-  return need;
+  return need + 4;                                       // + the max|dout| word
 }
 
 extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets, const float* attn_logits,
@@ -646,12 +670,16 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
     MsdaTileCfg cfgs[MSDA_MAX_LEVELS];
     bool ok = true;
     for (int l = 0; l < num_levels; ++l)
-      ok = ok && msda_tile_cfg(lv, l, head_dim, cfgs[l]) && msda_scratch_floats(lv, cfgs[l], B, heads) <= workspace_floats;
+      ok = ok && msda_tile_cfg(lv, l, head_dim, cfgs[l]) &&
+           msda_scratch_floats(lv, cfgs[l], B, heads) + 4 <= workspace_floats;
     if (ok) {
       do_value = 0;
+      unsigned* absmax = (unsigned*)(workspace + workspace_floats - 4);
+      hipLaunchKernelGGL(msda_zero_word_kernel, dim3(1), dim3(1), 0, st, absmax);
+      hipLaunchKernelGGL(msda_absmax_kernel, dim3(512), dim3(256), 0, st, dout, (long)B * Nq * heads * head_dim, absmax);
       for (int l = 0; l < num_levels; ++l) {
         const MsdaTileCfg& tc = cfgs[l];
-        const size_t lds = (size_t)(tc.T + 2 * tc.M) * (tc.T + 2 * tc.M) * lv.Z[l] * tc.CH * 4;
+        const size_t lds = (size_t)(tc.T + 2 * tc.M) * (tc.T + 2 * tc.M) * lv.Z[l] * tc.CH * 8;
 #ifndef OCCF_EMU
         static size_t lds_max = 0;
         if (lds > lds_max) {
@@ -662,7 +690,7 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
 #endif
         const dim3 grid((unsigned)(tc.tiles_x * tc.tiles_y * tc.groups * tc.passes), heads, B);
         hipLaunchKernelGGL(msda3d_bwd_value_tile_kernel, grid, dim3(256), lds, st, sampling_offsets, attn_logits, dout,
-                           dvalue, workspace, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
+                           dvalue, workspace, absmax, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
         const long total = (long)B * heads * lv.X[l] * lv.Y[l] * lv.Z[l] * head_dim;
         hipLaunchKernelGGL(msda3d_bwd_value_gather_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, workspace,
                            dvalue, lv, tc, B, heads, head_dim);

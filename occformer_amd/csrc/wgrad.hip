@@ -30,6 +30,7 @@ struct WgArgs {
   int N, Cin, taps;
   long ldy, ldx;
   int conv;
+  int swz;           // 3 = XOR-swizzled LDS slots, 0 = plain (diagnostic switch OCCF_WG_SWZ)
   long rows_per_split;
   WgGeom g;
 };
@@ -40,7 +41,7 @@ typedef uint32_t wg_u4 __attribute__((ext_vector_type(4)));
 // distinct 16-byte bank groups per eight lanes -- the staging writes (a thread owns 4 consecutive columns, so one
 // store instruction covers columns 4*lane + e: stride 4) and the fragment reads (32 consecutive columns).  Unswizzled,
 // every staging store was a 4-way bank conflict.
-__device__ __forceinline__ int wg_swz(int col) { return col ^ ((col >> 3) & 3); }
+__device__ __forceinline__ int wg_swz(int col, int on) { return col ^ (((col >> 3) & 3) & on); }
 
 template <int BC, int TERMS>
 __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
         occf_bf16_split2(cx[e][2], cx[e][3], hh, ll); h.y = hh; l.y = ll;
         occf_bf16_split2(cx[e][4], cx[e][5], hh, ll); h.z = hh; l.z = ll;
         occf_bf16_split2(cx[e][6], cx[e][7], hh, ll); h.w = hh; l.w = ll;
-        const int off = a_rg * 128 + wg_swz(a_c4 * 4 + e);
+        const int off = a_rg * 128 + wg_swz(a_c4 * 4 + e, p.swz);
         Ah[off] = h;
         if (TERMS == 3) Al[off] = l;
       }
@@ -168,14 +169,14 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
 #pragma unroll
         for (int j = 0; j < RPT; j += 2) occf_bf16_split2(cx[e][j], cx[e][j + 1], hh[j / 2], ll[j / 2]);
         if (RPT == 8) {
-          const int off = b_rg * BC + wg_swz(b_c4 * 4 + e);
+          const int off = b_rg * BC + wg_swz(b_c4 * 4 + e, p.swz);
           wg_u4 h, l;
           h.x = hh[0]; h.y = hh[1]; h.z = hh[RPT / 2 - 2]; h.w = hh[RPT / 2 - 1];
           l.x = ll[0]; l.y = ll[1]; l.z = ll[RPT / 2 - 2]; l.w = ll[RPT / 2 - 1];
           Bh[off] = h;
           if (TERMS == 3) Bl[off] = l;
         } else {
-          const int off = (b_rg >> 1) * BC + wg_swz(b_c4 * 4 + e);
+          const int off = (b_rg >> 1) * BC + wg_swz(b_c4 * 4 + e, p.swz);
           uint32_t* dh = (uint32_t*)(Bh + off) + (b_rg & 1) * 2;
           uint32_t* dl = (uint32_t*)(Bl + off) + (b_rg & 1) * 2;
           dh[0] = hh[0];
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int li = lane & 31, lk = lane >> 5;
   auto frag = [&](const wg_u4* base, int ld, int col, int ks) __attribute__((always_inline)) -> bf16x8 {
-    return __builtin_bit_cast(bf16x8, base[(ks * 2 + lk) * ld + wg_swz(col)]);
+    return __builtin_bit_cast(bf16x8, base[(ks * 2 + lk) * ld + wg_swz(col, p.swz)]);
   };
   auto compute = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -294,7 +295,14 @@ __global__ void __launch_bounds__(256) wgrad_small_kernel(const float* __restric
 static int wg_pick_splits(long M, int N, int Cin, int taps, int BC) {
   const long tiles = (long)occf_cdiv(N, 128) * occf_cdiv(Cin, BC) * taps;
   const long chunks = (M + 63) / 64;
-  long S = (1024 + tiles - 1) / tiles;
+  static const int target = [] {
+    const char* e = getenv("OCCF_WG_TARGET");          // diagnostics: workgroups aimed at per launch
+    return e ? atoi(e) : 0;
+  }();
+  // measured (scripts/bwd_probe.py, r02 probes): the 27-tap convolutions want ~2048 workgroups (3.95 vs 4.92 ms at
+  // 128 -> 128), a plain linear with 3 tiles pays for every extra slab in the reduction (0.63 ms at 512 vs 0.83)
+  const int tgt = target > 0 ? target : (taps > 1 ? 2048 : 512);
+  long S = (tgt + tiles - 1) / tiles;
   if (S > chunks / 4) S = chunks / 4;
   if (S < 1) S = 1;
   if (S > 256) S = 256;
@@ -309,6 +317,11 @@ static long wg_workspace(long M, int N, int Cin, int taps) {
 
 static int wg_launch(WgArgs a, float* dW, float* db, float* workspace, long workspace_floats, int terms, hipStream_t st) {
   const int BC = wg_bc(a.Cin);
+  static const int swz_env = [] {
+    const char* e = getenv("OCCF_WG_SWZ");
+    return e ? atoi(e) : 1;
+  }();
+  a.swz = swz_env ? 3 : 0;
   int S = wg_pick_splits(a.M, a.N, a.Cin, a.taps, BC);
   const long Kt = (long)a.taps * a.Cin;
   while (S > 1 && (long)S * a.N * (Kt + 1) > workspace_floats) --S;

@@ -1,0 +1,48 @@
+"""micro-benchmarks of the three heaviest backward kernels at the 200-grid sizes (HIP events, 5 repeats)"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from occformer_amd.ops import get_ops
+ops = get_ops()
+g = torch.Generator().manual_seed(0)
+what = sys.argv[1:] or ["wgrad", "window", "msda"]
+
+def timeit(name, fn, n=5):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"{name:60s} {e0.elapsed_time(e1) / n:8.3f} ms", flush=True)
+
+if "wgrad" in what:
+    for C in (128, 192):
+        dy = torch.randn(1, 200, 200, 16, C, generator=g).cuda()
+        x = torch.randn(1, 200, 200, 16, C, generator=g).cuda()
+        timeit(f"conv3d_wgrad 3^3 {C}->{C} 200x200x16", lambda: ops.conv3d_wgrad(dy, x, (3, 3, 3), 1, 1))
+    dy = torch.randn(680000, 384, generator=g).cuda()
+    x = torch.randn(680000, 128, generator=g).cuda()
+    timeit("linear_wgrad 680000 x (384, 128)", lambda: ops.linear_wgrad(dy, x))
+if "window" in what:
+    B, X, Y, S, heads = 1, 200, 200, 17, 4
+    C = heads * 32
+    n = B * X * Y * S
+    qkv = torch.randn(n, 3 * C, generator=g).cuda()
+    qb = torch.randn(3 * C, generator=g).cuda()
+    tab = torch.randn(169, heads, generator=g).cuda()
+    out = ops.window_attention(qkv, qb, tab, B, X, Y, S, heads, 3)
+    dout = torch.randn(n, C, generator=g).cuda()
+    timeit("window_attention_backward stage 0 (shift 3)",
+           lambda: ops.window_attention_backward(qkv, qb, tab, out, dout, B, X, Y, S, heads, 3))
+if "msda" in what:
+    shapes = [(25, 25, 2), (50, 50, 4), (100, 100, 8)]
+    Nq = sum(a * b * c for a, b, c in shapes)
+    value = torch.randn(1, Nq, 192, generator=g).cuda()
+    offs = (torch.randn(1, Nq, 8 * 3 * 4 * 3, generator=g) * 2).cuda()
+    lg = torch.randn(1, Nq, 96, generator=g).cuda()
+    dout = torch.randn(1, Nq, 192, generator=g).cuda()
+    timeit("msda3d_backward 91250 queries, 8 heads x 24",
+           lambda: ops.msda3d_backward(value, offs, lg, dout, shapes, 8, 4))
