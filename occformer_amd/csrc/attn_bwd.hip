@@ -44,13 +44,17 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_kernel(
   for (int wi = 0; wi < wpb; ++wi) {
     const long win = (long)blockIdx.x * wpb + wi;
     if (win >= n_windows) break;                               // uniform over the workgroup
+    // slice index fastest: the S slices of one spatial window are S ADJACENT token rows per window position (26 KB
+    // contiguous at 17 x 384 floats), so the windows a workgroup walks reuse the same pages and cache lines -- with
+    // y fastest every window touched 49 fresh 4 KB pages per tensor and the kernel sat in s_waitcnt (61 % of the
+    // wave cycles, PMC r02 probe)
     long w = win;
+    const int s = (int)(w % S);
+    w /= S;
     const int wy = (int)(w % nwy);
     w /= nwy;
     const int wx = (int)(w % nwx);
-    w /= nwx;
-    const int s = (int)(w % S);
-    const int b = (int)(w / S);
+    const int b = (int)(w / nwx);
 
     int my_tok = -1, my_region = 0;
     if (lane < WB_T) {
@@ -313,13 +317,17 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_mfma_kernel(
   for (int wi = 0; wi < wpb; ++wi) {
     const long win = (long)blockIdx.x * wpb + wi;
     if (win >= n_windows) break;
+    // slice index fastest: the S slices of one spatial window are S ADJACENT token rows per window position (26 KB
+    // contiguous at 17 x 384 floats), so the windows a workgroup walks reuse the same pages and cache lines -- with
+    // y fastest every window touched 49 fresh 4 KB pages per tensor and the kernel sat in s_waitcnt (61 % of the
+    // wave cycles, PMC r02 probe)
     long w = win;
+    const int s = (int)(w % S);
+    w /= S;
     const int wy = (int)(w % nwy);
     w /= nwy;
     const int wx = (int)(w % nwx);
-    w /= nwx;
-    const int s = (int)(w % S);
-    const int b = (int)(w / S);
+    const int b = (int)(w / nwx);
     __syncthreads();                                           // previous window's LDS contents are consumed
     {
       int tok = -1, region = 0;

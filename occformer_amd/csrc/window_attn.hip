@@ -41,12 +41,12 @@ __global__ void __launch_bounds__(256) window_attn_kernel(
   long bid = blockIdx.x;
   const int hg = (int)(bid % head_groups);
   bid /= head_groups;
+  const int s = (int)(bid % S);          // slice fastest: the S slices of a spatial window are adjacent token rows
+  bid /= S;
   const int wy = (int)(bid % nwy);
   bid /= nwy;
   const int wx = (int)(bid % nwx);
-  bid /= nwx;
-  const int s = (int)(bid % S);
-  const int b = (int)(bid / S);
+  const int b = (int)(bid / nwx);
   const int head = hg * 4 + wave;
   const bool active = head < heads;   // whole wave uniform
   const int C3 = 3 * C;
@@ -205,12 +205,12 @@ __global__ void __launch_bounds__(256) window_attn_mfma_kernel(
   long bid = blockIdx.x;
   const int hg = (int)(bid % head_groups);
   bid /= head_groups;
+  const int s = (int)(bid % S);          // slice fastest: the S slices of a spatial window are adjacent token rows
+  bid /= S;
   const int wy = (int)(bid % nwy);
   bid /= nwy;
   const int wx = (int)(bid % nwx);
-  bid /= nwx;
-  const int s = (int)(bid % S);
-  const int b = (int)(bid / S);
+  const int b = (int)(bid / nwx);
   const int head = hg * 4 + wave;
   const bool active = head < heads;   // whole wave uniform
   const int hd = active ? head : heads - 1;

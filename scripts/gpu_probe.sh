@@ -2,10 +2,10 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-echo "== LDS atomics"; scripts/build/lds_atomic_probe
-echo "== wgrad default"; python scripts/bwd_probe.py wgrad
-echo "== wgrad OCCF_WG_SWZ=1"; OCCF_WG_SWZ=1 python scripts/bwd_probe.py wgrad
-echo "== wgrad OCCF_WG_TARGET=2048"; OCCF_WG_TARGET=2048 python scripts/bwd_probe.py wgrad
-echo "== wgrad OCCF_WG_TARGET=512"; OCCF_WG_TARGET=512 python scripts/bwd_probe.py wgrad
-echo "== window mfma / valu"; python scripts/bwd_probe.py window; OCCF_WATTN_BWD_MFMA=0 python scripts/bwd_probe.py window
-echo "== msda tiled / plain"; python scripts/bwd_probe.py msda; OCCF_MSDA_TILED=0 python scripts/bwd_probe.py msda
+echo "== kernels"; python scripts/bwd_probe.py window
+echo "== forward bench"; timeout 600 python bench.py --mode forward --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','ms_per_step')}); [print(k,v) for k,v in list(d['kernels'].items())[:12]]"
+echo "== train bench"; timeout 600 python bench.py --mode train --steps 3 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','ms_per_step')}); [print(k,v) for k,v in list(d['kernels'].items())[:8]]"
