@@ -355,22 +355,42 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_mfma_kernel(
     bf16x8 Kh[2][2], Kl[2][2], Vh[2][2], Vl[2][2], Qh[2][2], Ql[2][2], Gh[2][2], Gl[2][2];
     int tokt[2];
     float Dpart[2] = {0.f, 0.f};
+    // all 40 row loads of the window are issued before the first conversion (one memory round trip instead of one
+    // per operand group: at one wave per SIMD nothing else hides the latency)
+    float4 ld[2][2][10];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       const int t = tt * 32 + li;
       const int tok = lds_tok[wave][t];
       tokt[tt] = tok;
-      const bool real = t < WB_T;
       const float* src = (tok >= 0 ? qkv + (long)tok * C3 : qkv_bias) + head * WB_HD + lk * 8;
       const float* gsrc = dout + (long)(tok >= 0 ? tok : 0) * C + head * WB_HD + lk * 8;
       const float* osrc = attn_out + (long)(tok >= 0 ? tok : 0) * C + head * WB_HD + lk * 8;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const float4 q0 = *(const float4*)(src + ks * 16), q1 = *(const float4*)(src + ks * 16 + 4);
-        const float4 k0 = *(const float4*)(src + C + ks * 16), k1 = *(const float4*)(src + C + ks * 16 + 4);
-        const float4 v0 = *(const float4*)(src + 2 * C + ks * 16), v1 = *(const float4*)(src + 2 * C + ks * 16 + 4);
-        const float4 g0 = *(const float4*)(gsrc + ks * 16), g1 = *(const float4*)(gsrc + ks * 16 + 4);
-        const float4 o0 = *(const float4*)(osrc + ks * 16), o1 = *(const float4*)(osrc + ks * 16 + 4);
+        ld[tt][ks][0] = *(const float4*)(src + ks * 16);
+        ld[tt][ks][1] = *(const float4*)(src + ks * 16 + 4);
+        ld[tt][ks][2] = *(const float4*)(src + C + ks * 16);
+        ld[tt][ks][3] = *(const float4*)(src + C + ks * 16 + 4);
+        ld[tt][ks][4] = *(const float4*)(src + 2 * C + ks * 16);
+        ld[tt][ks][5] = *(const float4*)(src + 2 * C + ks * 16 + 4);
+        ld[tt][ks][6] = *(const float4*)(gsrc + ks * 16);
+        ld[tt][ks][7] = *(const float4*)(gsrc + ks * 16 + 4);
+        ld[tt][ks][8] = *(const float4*)(osrc + ks * 16);
+        ld[tt][ks][9] = *(const float4*)(osrc + ks * 16 + 4);
+      }
+    }
+    OCCF_SCHED_FENCE();
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = tt * 32 + li;
+      const int tok = tokt[tt];
+      const bool real = t < WB_T;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float4 q0 = ld[tt][ks][0], q1 = ld[tt][ks][1], k0 = ld[tt][ks][2], k1 = ld[tt][ks][3];
+        const float4 v0 = ld[tt][ks][4], v1 = ld[tt][ks][5], g0 = ld[tt][ks][6], g1 = ld[tt][ks][7];
+        const float4 o0 = ld[tt][ks][8], o1 = ld[tt][ks][9];
         const float km = real ? 1.f : 0.f, qm = (real && tok >= 0) ? 1.f : 0.f;
         const float fk[8] = {k0.x * km, k0.y * km, k0.z * km, k0.w * km, k1.x * km, k1.y * km, k1.z * km, k1.w * km};
         const float fv[8] = {v0.x * km, v0.y * km, v0.z * km, v0.w * km, v1.x * km, v1.y * km, v1.z * km, v1.w * km};
@@ -383,7 +403,6 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_mfma_kernel(
         wbm_split8(fv, Vh[tt][ks], Vl[tt][ks]);
         wbm_split8(fq, Qh[tt][ks], Ql[tt][ks]);
         wbm_split8(fg, Gh[tt][ks], Gl[tt][ks]);
-        // transposed images: this lane's 8 channels d = 16 ks + 8 lk + e of token t
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int d = ks * 16 + lk * 8 + e;

@@ -30,7 +30,14 @@ struct WgArgs {
   int N, Cin, taps;
   long ldy, ldx;
   int conv;
-  int swz;           // 3 = XOR-swizzled LDS slots, 0 = plain (diagnostic switch OCCF_WG_SWZ)
+  int swz;           // 7 = XOR-swizzled LDS slots, 0 = plain (diagnostic switch OCCF_WG_SWZ)
+  // pre-split operands (bf16 hi / lo arrays, same shapes / strides in ELEMENTS as dY / X): the 27 taps of a
+  // convolution stage the same rows 27 x (n, c tiles) times -- splitting once up front takes the fp32 -> (hi, lo)
+  // conversion (4 VALU per element, 60 % of the kernel's issue slots by PMC) out of the loop and halves its loads
+  const uint16_t* dYh;
+  const uint16_t* dYl;
+  const uint16_t* Xh;
+  const uint16_t* Xl;
   long rows_per_split;
   WgGeom g;
 };
@@ -41,9 +48,26 @@ typedef uint32_t wg_u4 __attribute__((ext_vector_type(4)));
 // distinct 16-byte bank groups per eight lanes -- the staging writes (a thread owns 4 consecutive columns, so one
 // store instruction covers columns 4*lane + e: stride 4) and the fragment reads (32 consecutive columns).  Unswizzled,
 // every staging store was a 4-way bank conflict.
-__device__ __forceinline__ int wg_swz(int col, int on) { return col ^ (((col >> 3) & 3) & on); }
+__device__ __forceinline__ int wg_swz(int col, int on) { return col ^ (((col >> 3) & 7) & on); }
 
-template <int BC, int TERMS>
+// bf16 pair packing for the pre-split path: a dword holds two ADJACENT COLUMNS of one row; the LDS group wants two
+// ADJACENT ROWS of one column.  lo16(a) | lo16(b) << 16 and hi16(a) | hi16(b) << 16 (v_perm_b32 on the GPU).
+__device__ __forceinline__ uint32_t wg_pack_lo(uint32_t a, uint32_t b) {
+#ifdef OCCF_EMU
+  return (a & 0xFFFFu) | (b << 16);
+#else
+  return __builtin_amdgcn_perm(b, a, 0x05040100u);
+#endif
+}
+__device__ __forceinline__ uint32_t wg_pack_hi(uint32_t a, uint32_t b) {
+#ifdef OCCF_EMU
+  return (a >> 16) | (b & 0xFFFF0000u);
+#else
+  return __builtin_amdgcn_perm(b, a, 0x07060302u);
+#endif
+}
+
+template <int BC, int TERMS, bool PRE>
 __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
   constexpr int TC = BC / 64;                 // 32-wide tiles per wave along c
   constexpr int QB = BC / 4;                  // channel quads of the X tile
@@ -78,6 +102,98 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
     tdy = (tap / p.g.kZ) % p.g.kY;
     tdx = tap / (p.g.kZ * p.g.kY);
   }
+
+  // ---- pre-split loader roles: threads 0..127 stage the hi halves, 128..255 the lo halves; a thread owns 8 rows x
+  // 8 columns (one 16-byte load per row)
+  const int p_half = tid >> 7, p_t = tid & 127;
+  const int pa_c8 = p_t & 15, pa_rg = p_t >> 4;
+  const int pa_col = n0 + pa_c8 * 8;
+  const bool pa_ok = pa_col < p.N;
+  constexpr int PBQ = BC / 8;                                  // 8-column groups of the X tile
+  const int pb_c8 = p_t % PBQ, pb_rg = p_t / PBQ;
+  const bool pb_act = pb_rg < 8;
+  const int pb_ch = c0 + pb_c8 * 8;
+  const bool pb_ok = pb_act && pb_ch < p.Cin;
+  wg_u4 pa[8], pb[8];
+  auto load_chunk_pre = [&](int ck) __attribute__((always_inline)) {
+    const long mb = m_begin + (long)ck * 64;
+    const uint16_t* ya = p_half ? p.dYl : p.dYh;
+    const uint16_t* xa = p_half ? p.Xl : p.Xh;
+    const wg_u4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      long m = mb + pa_rg * 8 + j;
+      const bool ok = m < m_end && pa_ok;
+      if (m >= p.M) m = p.M - 1;
+      const wg_u4 v = *(const wg_u4*)(ya + m * p.ldy + (pa_ok ? pa_col : 0));
+      pa[j] = ok ? v : z4;
+    }
+    if (p.conv) {
+      long ml = mb + (pb_act ? pb_rg : 0) * 8;
+      if (ml >= p.M) ml = p.M - 1;
+      const unsigned m = (unsigned)ml;
+      int zo = (int)(m % (unsigned)p.g.Zo);
+      unsigned t = m / (unsigned)p.g.Zo;
+      int yo = (int)(t % (unsigned)p.g.Yo);
+      t /= (unsigned)p.g.Yo;
+      int xo = (int)(t % (unsigned)p.g.Xo);
+      long b = t / (unsigned)p.g.Xo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int xi = xo * p.g.stride - p.g.pad_x + tdx * p.g.dil, yi = yo * p.g.stride - p.g.pad_y + tdy * p.g.dil,
+                  zi = zo * p.g.stride - p.g.pad_z + tdz * p.g.dil;
+        const bool ok = pb_ok && xi >= 0 && xi < p.g.Xi && yi >= 0 && yi < p.g.Yi && zi >= 0 && zi < p.g.Zi;
+        const int xc = occf_clampi(xi, p.g.Xi - 1), yc = occf_clampi(yi, p.g.Yi - 1), zc = occf_clampi(zi, p.g.Zi - 1);
+        const long bc = b < p.g.B ? b : p.g.B - 1;
+        const wg_u4 v = *(const wg_u4*)(xa + bc * p.g.sb + xc * p.g.sx + yc * p.g.sy + zc * p.g.sz + (pb_ok ? pb_ch : 0));
+        pb[j] = ok ? v : z4;
+        if (++zo == p.g.Zo) {
+          zo = 0;
+          if (++yo == p.g.Yo) {
+            yo = 0;
+            if (++xo == p.g.Xo) {
+              xo = 0;
+              ++b;
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        long m = mb + (pb_act ? pb_rg : 0) * 8 + j;
+        if (m >= p.M) m = p.M - 1;
+        const wg_u4 v = *(const wg_u4*)(xa + m * p.ldx + (pb_ok ? pb_ch : 0));
+        pb[j] = pb_ok ? v : z4;
+      }
+    }
+  };
+  auto store_chunk_pre = [&]() __attribute__((always_inline)) {
+    wg_u4* Ad = p_half ? Al : Ah;
+    wg_u4* Bd = p_half ? Bl : Bh;
+    const uint32_t* ar = (const uint32_t*)pa;                  // [row j][dword d]: columns 2d, 2d + 1
+    const uint32_t* br = (const uint32_t*)pb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      wg_u4 v, w;
+      const int d = e >> 1;
+      if (e & 1) {
+        v.x = wg_pack_hi(ar[0 * 4 + d], ar[1 * 4 + d]); v.y = wg_pack_hi(ar[2 * 4 + d], ar[3 * 4 + d]);
+        v.z = wg_pack_hi(ar[4 * 4 + d], ar[5 * 4 + d]); v.w = wg_pack_hi(ar[6 * 4 + d], ar[7 * 4 + d]);
+        w.x = wg_pack_hi(br[0 * 4 + d], br[1 * 4 + d]); w.y = wg_pack_hi(br[2 * 4 + d], br[3 * 4 + d]);
+        w.z = wg_pack_hi(br[4 * 4 + d], br[5 * 4 + d]); w.w = wg_pack_hi(br[6 * 4 + d], br[7 * 4 + d]);
+      } else {
+        v.x = wg_pack_lo(ar[0 * 4 + d], ar[1 * 4 + d]); v.y = wg_pack_lo(ar[2 * 4 + d], ar[3 * 4 + d]);
+        v.z = wg_pack_lo(ar[4 * 4 + d], ar[5 * 4 + d]); v.w = wg_pack_lo(ar[6 * 4 + d], ar[7 * 4 + d]);
+        w.x = wg_pack_lo(br[0 * 4 + d], br[1 * 4 + d]); w.y = wg_pack_lo(br[2 * 4 + d], br[3 * 4 + d]);
+        w.z = wg_pack_lo(br[4 * 4 + d], br[5 * 4 + d]); w.w = wg_pack_lo(br[6 * 4 + d], br[7 * 4 + d]);
+      }
+      if (TERMS == 3 || p_half == 0) {
+        Ad[pa_rg * 128 + wg_swz(pa_c8 * 8 + e, p.swz)] = v;
+        if (pb_act) Bd[pb_rg * BC + wg_swz(pb_c8 * 8 + e, p.swz)] = w;
+      }
+    }
+  };
 
   float4 ra[8], rb[RPT];
   auto load_chunk = [&](int ck) __attribute__((always_inline)) {
@@ -133,7 +249,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
     }
   };
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = p.bias_out != nullptr && tap == 0 && ct == 0;
+  const bool do_bias = !PRE && p.bias_out != nullptr && tap == 0 && ct == 0;
   auto store_chunk = [&]() __attribute__((always_inline)) {
     // dY: rows a_rg*8 .. +7 of columns a_c4*4 .. +3 -> four 16-byte groups (one per column) in row group a_rg
     {
@@ -225,13 +341,24 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
     }
   };
 
-  if (nchunks > 0) load_chunk(0);
-  for (int ck = 0; ck < nchunks; ++ck) {
-    if (ck > 0) __syncthreads();              // previous chunk's fragment reads are done
-    store_chunk();
-    __syncthreads();
-    load_chunk(ck + 1 < nchunks ? ck + 1 : ck);   // unconditional (the last one re-reads its own chunk)
-    compute();
+  if (PRE) {
+    if (nchunks > 0) load_chunk_pre(0);
+    for (int ck = 0; ck < nchunks; ++ck) {
+      if (ck > 0) __syncthreads();
+      store_chunk_pre();
+      __syncthreads();
+      load_chunk_pre(ck + 1 < nchunks ? ck + 1 : ck);
+      compute();
+    }
+  } else {
+    if (nchunks > 0) load_chunk(0);
+    for (int ck = 0; ck < nchunks; ++ck) {
+      if (ck > 0) __syncthreads();              // previous chunk's fragment reads are done
+      store_chunk();
+      __syncthreads();
+      load_chunk(ck + 1 < nchunks ? ck + 1 : ck);   // unconditional (the last one re-reads its own chunk)
+      compute();
+    }
   }
 
   // ---- epilogue: raw partial sums of this M-slice
@@ -274,21 +401,27 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   out[i] = v;
 }
 
-// small problems (M <= 1024 rows, or shapes the tile kernel does not take): one thread per output, exact fp32
+// small problems (M <= 1024 rows, or shapes the tile kernel does not take): exact fp32, 8 lanes per output walk
+// the rows (stride 8) and combine with a 3-step butterfly -- the decoder's 100-row linears launch ~120 of these
+// per training step
 __global__ void __launch_bounds__(256) wgrad_small_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                           float* __restrict__ dW, float* __restrict__ db, long M, int N,
                                                           int K, long ldy, long ldx) {
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid < (long)N * K) {
-    const int n = (int)(gid / K), k = (int)(gid % K);
-    float s = 0.f;
-    for (long m = 0; m < M; ++m) s = fmaf(dY[m * ldy + n], X[m * ldx + k], s);
-    dW[gid] = s;
+  const long gid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  const long NK = (long)N * K;
+  const bool w_ok = gid < NK, b_ok = db != nullptr && gid < N;
+  const int n = w_ok ? (int)(gid / K) : 0, k = w_ok ? (int)(gid % K) : 0;
+  float s = 0.f, sb = 0.f;
+  for (long m = sub; m < M; m += 8) {
+    s = fmaf(dY[m * ldy + n], X[m * ldx + k], s);
+    if (b_ok) sb += dY[m * ldy + gid];
   }
-  if (db && gid < N) {
-    float s = 0.f;
-    for (long m = 0; m < M; ++m) s += dY[m * ldy + gid];
-    db[gid] = s;
+  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+  sb += __shfl_xor(sb, 1); sb += __shfl_xor(sb, 2); sb += __shfl_xor(sb, 4);
+  if (sub == 0) {
+    if (w_ok) dW[gid] = s;
+    if (b_ok) db[gid] = sb;
   }
 }
 
@@ -308,7 +441,16 @@ static int wg_pick_splits(long M, int N, int Cin, int taps, int BC) {
   if (S > 256) S = 256;
   return (int)S;
 }
-static int wg_bc(int Cin) { return Cin % 128 == 0 ? 128 : 64; }
+static int wg_bc(int Cin) {
+  static const int env = [] {
+    const char* e = getenv("OCCF_WG_BC");               // diagnostics: force the channel tile (64 / 128)
+    return e ? atoi(e) : 0;
+  }();
+  if (env == 64 || env == 128) return env;
+  // 192 channels: two 128-wide tiles (the second half-masked) stage dY twice instead of three times -- the kernel is
+  // bound by its staging, not by the matrix cores
+  return (Cin % 128 == 0 || Cin > 128) ? 128 : 64;
+}
 
 static long wg_workspace(long M, int N, int Cin, int taps) {
   const int S = wg_pick_splits(M, N, Cin, taps, wg_bc(Cin));
@@ -321,7 +463,7 @@ static int wg_launch(WgArgs a, float* dW, float* db, float* workspace, long work
     const char* e = getenv("OCCF_WG_SWZ");
     return e ? atoi(e) : 1;
   }();
-  a.swz = swz_env ? 3 : 0;
+  a.swz = swz_env ? 7 : 0;
   int S = wg_pick_splits(a.M, a.N, a.Cin, a.taps, BC);
   const long Kt = (long)a.taps * a.Cin;
   while (S > 1 && (long)S * a.N * (Kt + 1) > workspace_floats) --S;
@@ -333,13 +475,20 @@ static int wg_launch(WgArgs a, float* dW, float* db, float* workspace, long work
   a.out = S > 1 ? workspace : dW;
   a.bias_out = db ? (S > 1 ? workspace + (long)S * a.N * Kt : db) : nullptr;
   const dim3 grid((unsigned)((long)occf_cdiv(a.N, 128) * occf_cdiv(a.Cin, BC) * a.taps), S);
+  const bool pre = a.dYh != nullptr;
+#define OCCF_WG_LAUNCH(BC_, T_)                                                                        \
+  do {                                                                                                 \
+    if (pre) hipLaunchKernelGGL((wgrad_kernel<BC_, T_, true>), grid, dim3(256), 0, st, a);             \
+    else hipLaunchKernelGGL((wgrad_kernel<BC_, T_, false>), grid, dim3(256), 0, st, a);                \
+  } while (0)
   if (BC == 128) {
-    if (terms == 3) hipLaunchKernelGGL((wgrad_kernel<128, 3>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_kernel<128, 1>), grid, dim3(256), 0, st, a);
+    if (terms == 3) OCCF_WG_LAUNCH(128, 3);
+    else OCCF_WG_LAUNCH(128, 1);
   } else {
-    if (terms == 3) hipLaunchKernelGGL((wgrad_kernel<64, 3>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_kernel<64, 1>), grid, dim3(256), 0, st, a);
+    if (terms == 3) OCCF_WG_LAUNCH(64, 3);
+    else OCCF_WG_LAUNCH(64, 1);
   }
+#undef OCCF_WG_LAUNCH
   if (S > 1) {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(occf_cdiv((long)a.N * Kt, 256)), dim3(256), 0, st, workspace, dW,
                        (long)a.N * Kt, S);
@@ -362,7 +511,7 @@ extern "C" int occf_linear_wgrad(const float* dy, const float* x, float* dw, flo
   hipStream_t st = (hipStream_t)stream;
   if (M <= 1024 || N % 4 || K % 4 || ldy % 4 || ldx % 4) {
     if (M > 65536) return OCCF_ESHAPE;
-    const long total = (long)N * K > N ? (long)N * K : N;
+    const long total = ((long)N * K > N ? (long)N * K : N) * 8;
     hipLaunchKernelGGL(wgrad_small_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, dy, x, dw, dbias, M, N, K,
                        ldy, ldx);
     return (int)hipGetLastError();
@@ -372,12 +521,34 @@ extern "C" int occf_linear_wgrad(const float* dy, const float* x, float* dw, flo
   return wg_launch(a, dw, dbias, workspace, workspace_floats, terms, st);
 }
 
+// hi = bf16_rne(x), lo = bf16_rne(x - hi)  (the same split as occf_split_bf16; local copy: separate translation unit)
+__global__ void __launch_bounds__(256) wg_split_kernel(const float* __restrict__ x, uint16_t* __restrict__ hi,
+                                                       uint16_t* __restrict__ lo, long n2) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n2) return;
+  uint32_t h, l;
+  occf_bf16_split2(x[2 * i], x[2 * i + 1], h, l);
+  ((uint32_t*)hi)[i] = h;
+  ((uint32_t*)lo)[i] = l;
+}
+
+static bool wg_presplit_ok(int Cin, int Cout, int taps) {
+  static const int env = [] {
+    const char* e = getenv("OCCF_WG_PRESPLIT");
+    return e ? atoi(e) : 1;
+  }();
+  return env && taps >= 9 && Cin % 8 == 0 && Cout % 8 == 0;
+}
+
 extern "C" long occf_conv3d_wgrad_workspace(int B, int Xi, int Yi, int Zi, int Cin, int Cout, int kX, int kY, int kZ,
                                             int stride, int dil, int pad_x, int pad_y, int pad_z) {
   const int Xo = (Xi + 2 * pad_x - dil * (kX - 1) - 1) / stride + 1;
   const int Yo = (Yi + 2 * pad_y - dil * (kY - 1) - 1) / stride + 1;
   const int Zo = (Zi + 2 * pad_z - dil * (kZ - 1) - 1) / stride + 1;
-  return wg_workspace((long)B * Xo * Yo * Zo, Cout, Cin, kX * kY * kZ);
+  long need = wg_workspace((long)B * Xo * Yo * Zo, Cout, Cin, kX * kY * kZ);
+  if (wg_presplit_ok(Cin, Cout, kX * kY * kZ))        // bf16 (hi, lo) copies of dy and x: 4 bytes per element
+    need += (long)B * Xo * Yo * Zo * Cout + (long)B * Xi * Yi * Zi * Cin;
+  return need;
 }
 
 extern "C" int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapmajor, float* dbias, float* workspace,
@@ -398,5 +569,20 @@ extern "C" int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapm
   if (g.Xo <= 0 || g.Yo <= 0 || g.Zo <= 0) return OCCF_ESHAPE;
   a.dY = dy; a.X = x; a.M = (long)B * g.Xo * g.Yo * g.Zo; a.N = Cout; a.Cin = Cin; a.taps = kX * kY * kZ;
   a.ldy = Cout; a.ldx = 0; a.conv = 1;
-  return wg_launch(a, dw_tapmajor, dbias, workspace, workspace_floats, terms, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  // pre-split operands: dense x only (the strides then address the bf16 copy unchanged), no bias sum
+  const long nx = (long)B * Xi * Yi * Zi * Cin, ny = a.M * Cout;
+  const bool dense = in_sz == Cin && in_sy == (long)Zi * Cin && in_sx == (long)Yi * Zi * Cin &&
+                     in_sb == (long)Xi * Yi * Zi * Cin;
+  if (wg_presplit_ok(Cin, Cout, a.taps) && dense && !dbias && workspace && workspace_floats >= nx + ny) {
+    uint16_t* yh = (uint16_t*)(workspace + workspace_floats - (nx + ny));
+    uint16_t* yl = yh + ny;
+    uint16_t* xh = yl + ny;
+    uint16_t* xl = xh + nx;
+    hipLaunchKernelGGL(wg_split_kernel, dim3(occf_cdiv(ny / 2, 256)), dim3(256), 0, st, dy, yh, yl, ny / 2);
+    hipLaunchKernelGGL(wg_split_kernel, dim3(occf_cdiv(nx / 2, 256)), dim3(256), 0, st, x, xh, xl, nx / 2);
+    a.dYh = yh; a.dYl = yl; a.Xh = xh; a.Xl = xl;
+    workspace_floats -= nx + ny;
+  }
+  return wg_launch(a, dw_tapmajor, dbias, workspace, workspace_floats, terms, st);
 }
