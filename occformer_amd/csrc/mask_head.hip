@@ -424,6 +424,88 @@ __global__ void __launch_bounds__(256) upsample_classify_kernel(
     if (i < K) out[((long)b * K + i) * V2 + vid] = acc[i];
 }
 
+
+// LDS-staged variant (2x upsampling, Z = 16 -> Z2 = 32).  PMC on the gather kernel above (profiles/
+// r02e_upsample_classify_pmc_summary.txt): 64.6 M VMEM read instructions and 264 M L1 tag lookups per launch,
+// SQ_WAIT_INST_ANY = 67 % of the wave cycles -- it is bound by the ISSUE of its 4-byte gathers (8 per voxel and
+// query, 4.1 cache lines each), not by VALU or HBM.  Here a workgroup (2 output x-planes x 4 y-rows x 32 z) stages the
+// <= 3 x 4 x 16 source cells it blends per query through LDS with ONE 16-byte load per lane (48 lanes per query, four
+// queries per round, next round's loads in flight), and the 8 taps become ds_read2_b32 pairs: 1/170 of the vector
+// memory instructions.
+#define UCL_QG 4                 // queries per round (one per wave)
+#define UCL_CELLS 192            // 3 x 4 x 16 floats per query
+template <int KB>
+__global__ void __launch_bounds__(256) upsample_classify_lds_kernel(
+    const float* __restrict__ mask_pred, const float* __restrict__ prob, float* __restrict__ out, int B,
+    int Q, int K, int X, int Y, int X2, int Y2) {
+  constexpr int Z = 16, Z2 = 32;
+  __shared__ __attribute__((aligned(16))) float tile[2][UCL_QG][UCL_CELLS];
+  const int b = blockIdx.y;
+  const long V2 = (long)X2 * Y2 * Z2;
+  const long wg = occf_xcd_remap(blockIdx.x, gridDim.x);
+  const int yb = Y2 >> 2;
+  const int z2 = threadIdx.x & 31;
+  const int y2 = (int)(wg % yb) * 4 + ((threadIdx.x >> 5) & 3);
+  const int x2 = (int)(wg / yb) * 2 + (threadIdx.x >> 7);
+  const long vid = ((long)x2 * Y2 + y2) * Z2 + z2;
+  const float sx = X2 > 1 ? (float)(X - 1) / (float)(X2 - 1) : 0.f;
+  const float sy = Y2 > 1 ? (float)(Y - 1) / (float)(Y2 - 1) : 0.f;
+  const float sz = (float)(Z - 1) / (float)(Z2 - 1);
+  const float fx = sx * x2, fy = sy * y2, fz = sz * z2;
+  const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+  const int x1 = x0 + (x0 < X - 1), y1 = y0 + (y0 < Y - 1), z1 = z0 + (z0 < Z - 1);
+  const float tx = fx - x0, ty = fy - y0, tz = fz - z0;
+  // region origin of this workgroup (first output plane / row): every tap lies in [xa, xa+2] x [ya, ya+3]
+  const int xa = (int)(sx * (float)((int)(wg / yb) * 2)), ya = (int)(sy * (float)((int)(wg % yb) * 4));
+  float w[8];
+  int off[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    w[c] = ((c & 4) ? tx : 1.f - tx) * ((c & 2) ? ty : 1.f - ty) * ((c & 1) ? tz : 1.f - tz);
+    off[c] = ((((c & 4) ? x1 : x0) - xa) * 4 + (((c & 2) ? y1 : y0) - ya)) * Z + ((c & 1) ? z1 : z0);
+  }
+  float acc[KB];
+#pragma unroll
+  for (int i = 0; i < KB; ++i) acc[i] = 0.f;
+  // loader role: wave wv fetches query (round * 4 + wv); lane l < 48 -> (rx, ry, z quad)
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const int lrx = ln >> 4, lry = (ln >> 2) & 3, lzq = ln & 3;
+  const int lx = occf_clampi(xa + lrx, X - 1), ly = occf_clampi(ya + lry, Y - 1);
+  const float* src0 = mask_pred + (long)b * Q * ((long)X * Y * Z) + ((long)lx * Y + ly) * Z + lzq * 4;
+  const long qstride = (long)X * Y * Z;
+  const float* pb = prob + (long)b * Q * UC_MAXK;
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](int q) __attribute__((always_inline)) {
+    const int qq = q < Q ? q : Q - 1;
+    if (ln < 48) r = *(const float4*)(src0 + (long)qq * qstride);
+  };
+  fetch(wv);
+  const int rounds = (Q + UCL_QG - 1) / UCL_QG;
+  for (int rd = 0; rd < rounds; ++rd) {
+    float* dst = &tile[rd & 1][wv][0];
+    if (ln < 48) *(float4*)(dst + (lrx * 4 + lry) * Z + lzq * 4) = r;
+    __syncthreads();                                     // round rd is staged (the other buffer is free again)
+    fetch((rd + 1) * UCL_QG + wv);
+#pragma unroll
+    for (int u = 0; u < UCL_QG; ++u) {
+      const int q = rd * UCL_QG + u;
+      if (q < Q) {
+        const float* m = &tile[rd & 1][u][0];
+        float val = w[0] * m[off[0]];
+#pragma unroll
+        for (int c = 1; c < 8; ++c) val = fmaf(w[c], m[off[c]], val);
+        const float sg = occf_rcp_fast(1.0f + __expf(-val));
+        const float* pr = pb + q * UC_MAXK;                // wave-uniform address -> scalar loads
+#pragma unroll
+        for (int i = 0; i < KB; ++i) acc[i] = fmaf(pr[i], sg, acc[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < KB; ++i)
+    if (i < K) out[((long)b * K + i) * V2 + vid] = acc[i];
+}
+
 // Same-resolution case (X2 == X ...: the nuScenes head predicts masks at the output grid): the
 // align_corners resample is the identity, so every output voxel needs ONE mask value per query instead
 // of 8 taps.  A thread owns 2 consecutive voxels (float2 loads, fully coalesced), keeps UQ queries'
@@ -498,6 +580,22 @@ extern "C" int occf_upsample_classify_fwd(const float* mask_pred, const float* c
                          (const float*)workspace, out, Q, K, V2);
   } else {
     if ((long)Q * X * Y * Z >= (1L << 30)) return OCCF_ESHAPE;      // 32-bit byte offsets inside the mask volume
+    static const bool lds_env = [] {
+      const char* e = getenv("OCCF_CLASSIFY_LDS");        // diagnostics: 0 forces the gather kernel
+      return e == nullptr || atoi(e) != 0;
+    }();
+    // 2x (or coarser-to-finer) upsampling with 16 -> 32 slices: the LDS-staged kernel
+    if (lds_env && Z == 16 && Z2 == 32 && (X2 & 1) == 0 && (Y2 & 3) == 0 && X2 >= 2 * X - 1 && Y2 >= 2 * Y - 1 &&
+        K <= UC_MAXK) {
+      const dim3 grid((unsigned)((long)(X2 / 2) * (Y2 / 4)), B);
+      if (K <= 18)
+        hipLaunchKernelGGL((upsample_classify_lds_kernel<18>), grid, dim3(256), 0, st, mask_pred,
+                           (const float*)workspace, out, B, Q, K, X, Y, X2, Y2);
+      else
+        hipLaunchKernelGGL((upsample_classify_lds_kernel<UC_MAXK>), grid, dim3(256), 0, st, mask_pred,
+                           (const float*)workspace, out, B, Q, K, X, Y, X2, Y2);
+      OCCF_LAUNCH_CHECK();
+    }
     if (K <= 18)
       hipLaunchKernelGGL((upsample_classify_kernel<18>), dim3(occf_cdiv(V2, 256), B), dim3(256), 0, st, mask_pred,
                          (const float*)workspace, out, B, Q, K, X, Y, Z, X2, Y2, Z2);

@@ -124,7 +124,16 @@ class _ImageASPP(nn.Module):
         self.dropout = nn.Dropout(0.5)
 
     def forward(self, x):
-        g = self.global_avg_pool(x).expand(-1, -1, *x.shape[2:])
+        gp = self.global_avg_pool
+        g = gp[1](gp[0](x))
+        if self.training and g.numel() == g.shape[1]:
+            # one pooled value per channel on this rank (SemanticKITTI: batch 1, one camera): batch statistics do
+            # not exist -- the reference gets them from SyncBatchNorm over its 8 ranks; per-rank policy:
+            # this layer normalises with its running statistics
+            g = F.batch_norm(g, gp[2].running_mean, gp[2].running_var, gp[2].weight, gp[2].bias, False, 0.0, gp[2].eps)
+        else:
+            g = gp[2](g)
+        g = gp[3](g).expand(-1, -1, *x.shape[2:])
         y = torch.cat((self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), g), 1)
         y = F.relu(self.bn1(self.conv1(y)))
         if self.training:

@@ -106,7 +106,9 @@ def test_masked_attention(be, Q, L, heads, masked):
 @pytest.mark.parametrize("shape,occ,Q,K", [((8, 8, 4), (16, 16, 8), 12, 17), ((5, 6, 3), (9, 12, 5), 12, 17),
                                            ((4, 4, 2), (4, 4, 2), 12, 17),      # same grid: identity kernel
                                            ((6, 5, 4), (6, 5, 4), 21, 19),      # identity, wide class bucket
-                                           ((2, 4, 16), (4, 8, 32), 7, 17),     # Z2 = 32: 2 x 4 x 32 workgroups
+                                           ((2, 4, 16), (4, 8, 32), 7, 17),     # Z2 = 32: LDS-staged kernel
+                                           ((5, 6, 16), (10, 12, 32), 9, 17),   # LDS-staged, several workgroups, odd Q
+                                           ((4, 6, 16), (10, 16, 32), 5, 20),   # LDS-staged, more than 2x upsampling
                                            ((3, 3, 3), (3, 3, 3), 9, 17)])      # odd voxel count: resampler
 def test_upsample_classify(be, shape, occ, Q, K):
     B = 2
