@@ -257,19 +257,21 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_kernel(
 
 // --------------------------------------------------------------------------------------------- matrix-core variant
 // Same contract as window_attn_bwd_kernel; the five 64 x 64 x 32 contractions per (window, head) run on
-// v_mfma_f32_32x32x16_bf16 (3-term bf16 split, fp32 accumulate) instead of ~7 800 VALU FMAs per lane (the VALU kernel
-// ran at 6 % of the vector rate: 12.8 ms per stage-0 call, 50 ms per training step).  With D = A . B returning
-// lane -> column, registers -> rows (r&3) + 8 (r>>2) + 4 (lane>>5), and an operand lane supplying 8 consecutive k:
-//   orientation 1 (lane = query):  St  = K . Q^T,  dPt = V . dO^T   (A = key rows, B = query rows; k = d)
-//        -> P, dS per query column in registers (the softmax statistics of a query sit in ONE lane pair)
-//        dQt[d][query] = K^T[d][key] . dSt[key][query]               (A = K^T image in LDS, B = dSt from registers)
-//   orientation 2 (lane = key):    S'  = Q . K^T,  dP' = dO . V^T   (the same row operands with the roles swapped)
-//        -> P', dS' per key column, using the lse / D of orientation 1 (LDS)
+// v_mfma_f32_32x32x16_bf16 (3-term bf16 split, fp32 accumulate).  With D = A . B returning lane -> column,
+// registers -> rows (r&3) + 8 (r>>2) + 4 (lane>>5), and an operand lane supplying 8 consecutive k, the transposed
+// products need P / dS with the lane on the QUERY for dQ and on the KEY for dK, dV.  Two kernels, one per orientation:
+//   window_attn_bwd_q_kernel  (lane = query):  St = K . Q^T,  dPt = V . dO^T  -> softmax statistics of a query in ONE
+//        lane pair -> lse, D = <dO, O> (stored for the second kernel), dS;  dQt[d][query] = K^T[d][key] . dSt[key][query];
+//        relative-position-bias gradient from an LDS copy of dS
+//   window_attn_bwd_kv_kernel (lane = key):    S' = Q . K^T,  dP' = dO . V^T,  P' = exp(S' - lse), dS' = P' (dP' - D);
 //        dVt[d][key] = dO^T[d][query] . P'[query][key],  dKt[d][key] = Qs^T[d][query] . dS'[query][key]
-// Row operands (K, V, scaled Q, dO: 8 consecutive d of one token) come straight from global memory; only the three
-// transposed images (K^T, dO^T, Qs^T: [4 k-steps][32 d][2 slots][8 tokens], hi / lo) live in LDS: 24 KB per wave.
+// Every operand comes straight from global memory: row operands (8 consecutive d of one token) as two 16-byte loads,
+// transposed operands (8 tokens of one d) as 8 dword loads -- the 32 d-lanes of a half wave read one 128-byte row
+// segment, fully coalesced; the rows were just read by the other loads (L1 / L2 hits).  The first version of this
+// kernel (r02c..r02f) did both orientations in one wave with three transposed LDS images: 478 VGPRs and 38 KB of LDS
+// per wave = ONE wave per SIMD, every LDS / memory latency exposed (61 % of the wave cycles in s_waitcnt, 3.85 ms
+// per call, 31 ms per training step).  Split, each kernel stays below 256 registers and 14 KB of LDS per wave.
 typedef uint32_t wbm_u2 __attribute__((ext_vector_type(2)));
-#define WBM_IMG 4096            // bytes of one transposed image half (hi or lo)
 
 __device__ __forceinline__ void wbm_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
   uint32_t h[4], l[4];
@@ -283,149 +285,143 @@ __device__ __forceinline__ void wbm_split8(const float (&v)[8], bf16x8& hi, bf16
     lo[2 * e + 1] = (short)(l[e] >> 16);
   }
 }
-// token t, head channel d -> byte offset of its bf16 in a transposed image (token order inside a 16-token k-step:
-// t & 15 = 8 (e >> 2) + 4 slot + (e & 3), the order in which a C-layout register file hands its rows on as B operand)
-__device__ __forceinline__ int wbm_toff(int t, int d) {
-  const int kk = t & 15;
-  const int e = ((kk >> 3) << 2) | (kk & 3), slot = (kk >> 2) & 1;
-  return (t >> 4) * 1024 + d * 32 + slot * 16 + e * 2;
+// 8 consecutive floats of a row, scaled, as hi / lo operand
+__device__ __forceinline__ void wbm_row8(const float* __restrict__ p, float m, bf16x8& hi, bf16x8& lo) {
+  const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  const float f[8] = {a.x * m, a.y * m, a.z * m, a.w * m, b.x * m, b.y * m, b.z * m, b.w * m};
+  wbm_split8(f, hi, lo);
 }
+// token of element e of 16-token k-step kst for the lane half lk: the order in which a C-layout register file hands
+// its rows on as B operand (t & 15 = 8 (e >> 2) + 4 lk + (e & 3))
+__device__ __forceinline__ int wbm_ktok(int kst, int e, int lk) { return kst * 16 + 8 * (e >> 2) + 4 * lk + (e & 3); }
 
-__global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_mfma_kernel(
-    const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
-    const float* __restrict__ attn_out, const float* __restrict__ dout, float* __restrict__ dqkv,
-    float* __restrict__ dqkv_bias, float* __restrict__ dtable_partial, int B, int X, int Y, int S, int C, int heads,
-    int shift, float scale, int wpb, long n_windows) {
-  __shared__ __attribute__((aligned(16))) unsigned char img[WB_HPB][6 * WBM_IMG];   // K^T h|l, dO^T h|l, Qs^T h|l
-  __shared__ float lds_bias[WB_HPB][WB_NB];
-  __shared__ float lds_m[WB_HPB][WB_T * 64];          // dS[key][query] of the current window (bias-table gradient)
-  __shared__ float lds_lse[WB_HPB][64], lds_D[WB_HPB][64];
-  __shared__ int lds_tok[WB_HPB][64], lds_reg[WB_HPB][64];
-
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int li = lane & 31, lk = lane >> 5;
+// window decode shared by both kernels: token index (or -1) and shift-mask region of window position `lane`
+__device__ __forceinline__ void wbm_window_tokens(long win, int lane, int B, int X, int Y, int S, int shift, int& tok,
+                                                  int& region) {
   const int nwx = (X + WB_WS - 1) / WB_WS, nwy = (Y + WB_WS - 1) / WB_WS;
   const int Xp = nwx * WB_WS, Yp = nwy * WB_WS;
-  const int head_raw = blockIdx.y * WB_HPB + wave;
-  const bool active = head_raw < heads;
-  const int head = active ? head_raw : heads - 1;
+  // slice index fastest: the S slices of one spatial window are S adjacent token rows per window position
+  long w = win;
+  const int s = (int)(w % S);
+  w /= S;
+  const int wy = (int)(w % nwy);
+  w /= nwy;
+  const int wx = (int)(w % nwx);
+  const int b = (int)(w / nwx);
+  tok = -1;
+  region = 0;
+  if (lane < WB_T) {
+    const int i = lane / WB_WS, j = lane % WB_WS;
+    const int px = wx * WB_WS + i, py = wy * WB_WS + j;
+    int sx = px + shift, sy = py + shift;
+    if (sx >= Xp) sx -= Xp;
+    if (sy >= Yp) sy -= Yp;
+    if (sx < X && sy < Y) tok = (int)((((long)b * X + sx) * Y + sy) * S + s);
+    if (shift > 0) {
+      const int rx = px < Xp - WB_WS ? 0 : (px < Xp - shift ? 1 : 2);
+      const int ry = py < Yp - WB_WS ? 0 : (py < Yp - shift ? 1 : 2);
+      region = rx * 3 + ry;
+    }
+  }
+}
+
+#define WBM_MSTR 64                       // row stride of the dS copy [key][query]
+#define WBM_MPAD 48                       // |query - key| offsets of a bin reach +-48: guard floats on both sides
+#define WBM_MSIZE (WBM_MPAD + WB_T * WBM_MSTR + WBM_MSTR + WBM_MPAD)
+
+// workgroup = the two 32-query tiles of ONE (window, head): wave = query tile (K, V, K^T operands are loaded by
+// both waves; the second read hits the L1), the dS copy and the 169 bins are shared
+__global__ void __launch_bounds__(128, 2) window_attn_bwd_q_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
+    const float* __restrict__ attn_out, const float* __restrict__ dout, float* __restrict__ dqkv,
+    float* __restrict__ dtable_partial, float* __restrict__ ws_stats, int B, int X, int Y, int S, int C, int heads,
+    int shift, float scale, int wpb, long n_windows) {
+  __shared__ float lds_bias[WB_NB];
+  __shared__ float lds_m[WBM_MSIZE];                  // dS[key][query] of the current window (bias-table gradient)
+  __shared__ int lds_tok[64], lds_reg[64];
+
+  const int qt = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 31, lk = lane >> 5;
+  const int head = blockIdx.y;
   const int C3 = 3 * C;
-  unsigned char* base = img[wave];
-  for (int t = lane; t < WB_NB; t += 64) lds_bias[wave][t] = bias_table[(long)t * heads + head];
-  float dtab[3] = {0.f, 0.f, 0.f};                    // bins lane, lane + 64, lane + 128 (LDS float atomics are slow)
+  for (int t = threadIdx.x; t < WB_NB; t += 128) lds_bias[t] = bias_table[(long)t * heads + head];
+  for (int t = threadIdx.x; t < WBM_MSIZE; t += 128) lds_m[t] = 0.f;
+  // bins tid, tid + 128 of the table gradient: offset query - key of the bin and the keys it is valid for
+  float dtab[2] = {0.f, 0.f};
+  int bin_off[2];
+  unsigned long long bin_keys[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r = (int)threadIdx.x + u * 128;
+    bin_off[u] = 0;
+    bin_keys[u] = 0ull;
+    if (r < WB_NB) {
+      const int di = r / (2 * WB_WS - 1) - (WB_WS - 1), dj = r % (2 * WB_WS - 1) - (WB_WS - 1);
+      bin_off[u] = di * WB_WS + dj;
+      for (int ki = 0; ki < WB_WS; ++ki)
+        for (int kj = 0; kj < WB_WS; ++kj)
+          if (ki + di >= 0 && ki + di < WB_WS && kj + dj >= 0 && kj + dj < WB_WS)
+            bin_keys[u] |= 1ull << (ki * WB_WS + kj);
+    }
+  }
 
   for (int wi = 0; wi < wpb; ++wi) {
     const long win = (long)blockIdx.x * wpb + wi;
     if (win >= n_windows) break;
-    // slice index fastest: the S slices of one spatial window are S ADJACENT token rows per window position (26 KB
-    // contiguous at 17 x 384 floats), so the windows a workgroup walks reuse the same pages and cache lines -- with
-    // y fastest every window touched 49 fresh 4 KB pages per tensor and the kernel sat in s_waitcnt (61 % of the
-    // wave cycles, PMC r02 probe)
-    long w = win;
-    const int s = (int)(w % S);
-    w /= S;
-    const int wy = (int)(w % nwy);
-    w /= nwy;
-    const int wx = (int)(w % nwx);
-    const int b = (int)(w / nwx);
     __syncthreads();                                           // previous window's LDS contents are consumed
     {
-      int tok = -1, region = 0;
-      if (lane < WB_T) {
-        const int i = lane / WB_WS, j = lane % WB_WS;
-        const int px = wx * WB_WS + i, py = wy * WB_WS + j;
-        int sx = px + shift, sy = py + shift;
-        if (sx >= Xp) sx -= Xp;
-        if (sy >= Yp) sy -= Yp;
-        if (sx < X && sy < Y) tok = (int)((((long)b * X + sx) * Y + sy) * S + s);
-        if (shift > 0) {
-          const int rx = px < Xp - WB_WS ? 0 : (px < Xp - shift ? 1 : 2);
-          const int ry = py < Yp - WB_WS ? 0 : (py < Yp - shift ? 1 : 2);
-          region = rx * 3 + ry;
-        }
+      int tok, region;
+      wbm_window_tokens(win, lane, B, X, Y, S, shift, tok, region);
+      if (qt == 0) {
+        lds_tok[lane] = tok;
+        lds_reg[lane] = region;
       }
-      lds_tok[wave][lane] = tok;
-      lds_reg[wave][lane] = region;
     }
     __syncthreads();
 
-    // ---- row operands of this lane's two tokens (tile tt: token 32 tt + li), 8 consecutive d at lk*8 + 16 ks.
-    // rows 49..63 are zero; padded window positions (t < 49, no token) take the bias row for k / v and have no
-    // query / dO (the forward crops them)
-    bf16x8 Kh[2][2], Kl[2][2], Vh[2][2], Vl[2][2], Qh[2][2], Ql[2][2], Gh[2][2], Gl[2][2];
-    int tokt[2];
-    float Dpart[2] = {0.f, 0.f};
-    // all 40 row loads of the window are issued before the first conversion (one memory round trip instead of one
-    // per operand group: at one wave per SIMD nothing else hides the latency)
-    float4 ld[2][2][10];
+    // ---- A operands: K, V rows of this lane's two key tokens (tile kt: token 32 kt + li), d = 16 ks + 8 lk ..+8.
+    // rows 49..63 are zero; padded window positions (t < 49, no token) take the bias row (the forward pads x with
+    // zeros BEFORE the qkv projection)
+    bf16x8 Kh[2][2], Kl[2][2], Vh[2][2], Vl[2][2];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int t = tt * 32 + li;
-      const int tok = lds_tok[wave][t];
-      tokt[tt] = tok;
+    for (int kt = 0; kt < 2; ++kt) {
+      const int t = kt * 32 + li;
+      const int tok = lds_tok[t];
+      const float km = t < WB_T ? 1.f : 0.f;
       const float* src = (tok >= 0 ? qkv + (long)tok * C3 : qkv_bias) + head * WB_HD + lk * 8;
-      const float* gsrc = dout + (long)(tok >= 0 ? tok : 0) * C + head * WB_HD + lk * 8;
-      const float* osrc = attn_out + (long)(tok >= 0 ? tok : 0) * C + head * WB_HD + lk * 8;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        ld[tt][ks][0] = *(const float4*)(src + ks * 16);
-        ld[tt][ks][1] = *(const float4*)(src + ks * 16 + 4);
-        ld[tt][ks][2] = *(const float4*)(src + C + ks * 16);
-        ld[tt][ks][3] = *(const float4*)(src + C + ks * 16 + 4);
-        ld[tt][ks][4] = *(const float4*)(src + 2 * C + ks * 16);
-        ld[tt][ks][5] = *(const float4*)(src + 2 * C + ks * 16 + 4);
-        ld[tt][ks][6] = *(const float4*)(gsrc + ks * 16);
-        ld[tt][ks][7] = *(const float4*)(gsrc + ks * 16 + 4);
-        ld[tt][ks][8] = *(const float4*)(osrc + ks * 16);
-        ld[tt][ks][9] = *(const float4*)(osrc + ks * 16 + 4);
+        wbm_row8(src + C + ks * 16, km, Kh[kt][ks], Kl[kt][ks]);
+        wbm_row8(src + 2 * C + ks * 16, km, Vh[kt][ks], Vl[kt][ks]);
       }
     }
-    OCCF_SCHED_FENCE();
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int t = tt * 32 + li;
-      const int tok = tokt[tt];
-      const bool real = t < WB_T;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const float4 q0 = ld[tt][ks][0], q1 = ld[tt][ks][1], k0 = ld[tt][ks][2], k1 = ld[tt][ks][3];
-        const float4 v0 = ld[tt][ks][4], v1 = ld[tt][ks][5], g0 = ld[tt][ks][6], g1 = ld[tt][ks][7];
-        const float4 o0 = ld[tt][ks][8], o1 = ld[tt][ks][9];
-        const float km = real ? 1.f : 0.f, qm = (real && tok >= 0) ? 1.f : 0.f;
-        const float fk[8] = {k0.x * km, k0.y * km, k0.z * km, k0.w * km, k1.x * km, k1.y * km, k1.z * km, k1.w * km};
-        const float fv[8] = {v0.x * km, v0.y * km, v0.z * km, v0.w * km, v1.x * km, v1.y * km, v1.z * km, v1.w * km};
-        const float fq[8] = {q0.x * scale * qm, q0.y * scale * qm, q0.z * scale * qm, q0.w * scale * qm,
-                             q1.x * scale * qm, q1.y * scale * qm, q1.z * scale * qm, q1.w * scale * qm};
-        const float fg[8] = {g0.x * qm, g0.y * qm, g0.z * qm, g0.w * qm, g1.x * qm, g1.y * qm, g1.z * qm, g1.w * qm};
-        Dpart[tt] += qm * ((g0.x * o0.x + g0.y * o0.y) + (g0.z * o0.z + g0.w * o0.w) +
-                           (g1.x * o1.x + g1.y * o1.y) + (g1.z * o1.z + g1.w * o1.w));
-        wbm_split8(fk, Kh[tt][ks], Kl[tt][ks]);
-        wbm_split8(fv, Vh[tt][ks], Vl[tt][ks]);
-        wbm_split8(fq, Qh[tt][ks], Ql[tt][ks]);
-        wbm_split8(fg, Gh[tt][ks], Gl[tt][ks]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int d = ks * 16 + lk * 8 + e;
-          const int off = wbm_toff(t, d);
-          *(uint16_t*)(base + 0 * WBM_IMG + off) = (uint16_t)Kh[tt][ks][e];
-          *(uint16_t*)(base + 1 * WBM_IMG + off) = (uint16_t)Kl[tt][ks][e];
-          *(uint16_t*)(base + 2 * WBM_IMG + off) = (uint16_t)Gh[tt][ks][e];
-          *(uint16_t*)(base + 3 * WBM_IMG + off) = (uint16_t)Gl[tt][ks][e];
-          *(uint16_t*)(base + 4 * WBM_IMG + off) = (uint16_t)Qh[tt][ks][e];
-          *(uint16_t*)(base + 5 * WBM_IMG + off) = (uint16_t)Ql[tt][ks][e];
-        }
-      }
-      Dpart[tt] += __shfl_xor(Dpart[tt], 32);
-    }
-    __syncthreads();                                           // images complete
-
-    // ================= orientation 1: lane = query column qi
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    {
       const int qi = qt * 32 + li;
+      const int qtok = lds_tok[qi];
+      const bool qreal = qi < WB_T && qtok >= 0;
+      const float qm = qreal ? 1.f : 0.f;
       const int qrow = (qi * 37) >> 8, qcol = qi - qrow * WB_WS;
-      const bool qreal = qi < WB_T && tokt[qt] >= 0;
-      const int qreg = lds_reg[wave][qi];
+      const int qreg = lds_reg[qi];
+      // B operands: scaled q and dO rows of the query token; D = <dO, O>
+      bf16x8 Qh[2], Ql[2], Gh[2], Gl[2];
+      float Dq = 0.f;
+      {
+        const long row = qtok >= 0 ? qtok : 0;
+        const float* qsrc = qkv + row * C3 + head * WB_HD + lk * 8;
+        const float* gsrc = dout + row * C + head * WB_HD + lk * 8;
+        const float* osrc = attn_out + row * C + head * WB_HD + lk * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          wbm_row8(qsrc + ks * 16, scale * qm, Qh[ks], Ql[ks]);
+          const float4 g0 = *(const float4*)(gsrc + ks * 16), g1 = *(const float4*)(gsrc + ks * 16 + 4);
+          const float4 o0 = *(const float4*)(osrc + ks * 16), o1 = *(const float4*)(osrc + ks * 16 + 4);
+          const float fg[8] = {g0.x * qm, g0.y * qm, g0.z * qm, g0.w * qm, g1.x * qm, g1.y * qm, g1.z * qm, g1.w * qm};
+          wbm_split8(fg, Gh[ks], Gl[ks]);
+          Dq += qm * ((g0.x * o0.x + g0.y * o0.y) + (g0.z * o0.z + g0.w * o0.w) +
+                      (g1.x * o1.x + g1.y * o1.y) + (g1.z * o1.z + g1.w * o1.w));
+        }
+        Dq += __shfl_xor(Dq, 32);
+      }
       f32x16 st[2], dp[2];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
@@ -433,12 +429,12 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_mfma_kernel(
         for (int r = 0; r < 16; ++r) st[kt][r] = dp[kt][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          st[kt] = occf_mfma_bf16_32x32x16(Kl[kt][ks], Qh[qt][ks], st[kt]);
-          st[kt] = occf_mfma_bf16_32x32x16(Kh[kt][ks], Ql[qt][ks], st[kt]);
-          st[kt] = occf_mfma_bf16_32x32x16(Kh[kt][ks], Qh[qt][ks], st[kt]);
-          dp[kt] = occf_mfma_bf16_32x32x16(Vl[kt][ks], Gh[qt][ks], dp[kt]);
-          dp[kt] = occf_mfma_bf16_32x32x16(Vh[kt][ks], Gl[qt][ks], dp[kt]);
-          dp[kt] = occf_mfma_bf16_32x32x16(Vh[kt][ks], Gh[qt][ks], dp[kt]);
+          st[kt] = occf_mfma_bf16_32x32x16(Kl[kt][ks], Qh[ks], st[kt]);
+          st[kt] = occf_mfma_bf16_32x32x16(Kh[kt][ks], Ql[ks], st[kt]);
+          st[kt] = occf_mfma_bf16_32x32x16(Kh[kt][ks], Qh[ks], st[kt]);
+          dp[kt] = occf_mfma_bf16_32x32x16(Vl[kt][ks], Gh[ks], dp[kt]);
+          dp[kt] = occf_mfma_bf16_32x32x16(Vh[kt][ks], Gl[ks], dp[kt]);
+          dp[kt] = occf_mfma_bf16_32x32x16(Vh[kt][ks], Gh[ks], dp[kt]);
         }
       }
       float mx = -3.0e38f;
@@ -451,8 +447,8 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_mfma_kernel(
           float a = st[kt][r];
           if (key < WB_T) {
             const int bi = (qrow - krow + WB_WS - 1) * (2 * WB_WS - 1) + (qcol - kcol + WB_WS - 1);
-            a += lds_bias[wave][qi < WB_T ? bi : 0];
-            if (shift > 0 && lds_reg[wave][key] != qreg) a += -100.0f;
+            a += lds_bias[qi < WB_T ? bi : 0];
+            if (shift > 0 && lds_reg[key] != qreg) a += -100.0f;
           } else {
             a = -INFINITY;
           }
@@ -470,12 +466,12 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_mfma_kernel(
         }
       sum += __shfl_xor(sum, 32);
       const float inv = qreal ? 1.0f / sum : 0.f;
-      const float Dq = Dpart[qt];
       if (lk == 0) {
-        lds_lse[wave][qi] = qreal ? mx + logf(sum) : INFINITY;          // exp(x - inf) = 0: padded queries drop out
-        lds_D[wave][qi] = Dq;
+        float* wsp = ws_stats + ((win * heads + head) * 2) * 64;
+        wsp[qi] = qreal ? mx + logf(sum) : INFINITY;                  // exp(x - inf) = 0: padded queries drop out
+        wsp[64 + qi] = Dq;
       }
-      // dS = P (dP - D); relative-position-bias gradient; dSt as B operand of dQt = K^T . dSt
+      // dS = P (dP - D); copy for the relative-position-bias gradient; dSt as B operand of dQt = K^T . dSt
       bf16x8 sh[4], sl[4];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
@@ -488,76 +484,165 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_mfma_kernel(
             const float ds = st[kt][r] * inv * (dp[kt][r] - Dq);
             dv[e] = ds;
             const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-            if (key < WB_T) lds_m[wave][key * 64 + qi] = qreal ? ds : 0.f;
+            if (key < WB_T) lds_m[WBM_MPAD + key * WBM_MSTR + qi] = ds;
           }
           wbm_split8(dv, sh[kt * 2 + s2], sl[kt * 2 + s2]);
         }
+      // A operand of dQt = K^T . dSt: lane = channel li, the 8 key tokens of a k-step (loaded only now: the score
+      // accumulators are dead, the kernel stays below 256 registers = two waves per SIMD)
+      OCCF_SCHED_FENCE();
       f32x16 dq;
 #pragma unroll
       for (int r = 0; r < 16; ++r) dq[r] = 0.f;
 #pragma unroll
       for (int kst = 0; kst < 4; ++kst) {
-        const int off = kst * 1024 + li * 32 + lk * 16;
-        const bf16x8 ah = *(const bf16x8*)(base + 0 * WBM_IMG + off), al = *(const bf16x8*)(base + 1 * WBM_IMG + off);
-        dq = occf_mfma_bf16_32x32x16(al, sh[kst], dq);
-        dq = occf_mfma_bf16_32x32x16(ah, sl[kst], dq);
-        dq = occf_mfma_bf16_32x32x16(ah, sh[kst], dq);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int t = wbm_ktok(kst, e, lk);
+          const int tok = lds_tok[t];
+          const float x = (tok >= 0 ? qkv + (long)tok * C3 : qkv_bias)[C + head * WB_HD + li];
+          v[e] = t < WB_T ? x : 0.f;
+        }
+        bf16x8 Th, Tl;
+        wbm_split8(v, Th, Tl);
+        dq = occf_mfma_bf16_32x32x16(Tl, sh[kst], dq);
+        dq = occf_mfma_bf16_32x32x16(Th, sl[kst], dq);
+        dq = occf_mfma_bf16_32x32x16(Th, sh[kst], dq);
       }
-      if (active && qreal) {
-        float* dst = dqkv + (long)tokt[qt] * C3 + head * WB_HD + 4 * lk;
+      if (qreal) {
+        float* dst = dqkv + (long)qtok * C3 + head * WB_HD + 4 * lk;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           *(float4*)(dst + 8 * g) = make_float4(dq[g * 4 + 0] * scale, dq[g * 4 + 1] * scale, dq[g * 4 + 2] * scale,
                                                 dq[g * 4 + 3] * scale);
       }
     }
-    __syncthreads();                                           // lse / D / dS of every query are in LDS
-    // relative-position-bias gradient: bin r = (di + 6) * 13 + (dj + 6) collects dS[(ki+di, kj+dj)][(ki, kj)]
-    if (active) {
+    __syncthreads();                                           // dS of every query is in LDS
+    // relative-position-bias gradient: bin (di, dj) collects dS[key + (di, dj)][key] over the keys it is valid for;
+    // the key loop is uniform (constant LDS offsets), invalid lanes read a guard / neighbouring float and drop it
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const int r = lane + u * 64;
-        if (r < WB_NB) {
-          const int di = r / (2 * WB_WS - 1) - (WB_WS - 1), dj = r % (2 * WB_WS - 1) - (WB_WS - 1);
-          float a = 0.f;
-          for (int ki = 0; ki < WB_WS; ++ki) {
-            const int qi2 = ki + di;
-            if (qi2 < 0 || qi2 >= WB_WS) continue;
-            for (int kj = 0; kj < WB_WS; ++kj) {
-              const int qj2 = kj + dj;
-              if (qj2 < 0 || qj2 >= WB_WS) continue;
-              a += lds_m[wave][(ki * WB_WS + kj) * 64 + qi2 * WB_WS + qj2];
-            }
-          }
-          dtab[u] += a;
-        }
+    for (int u = 0; u < 2; ++u) {
+      const float* mp = &lds_m[WBM_MPAD + bin_off[u]];
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int key = 0; key < WB_T; ++key) {
+        const float x = mp[key * (WBM_MSTR + 1)];
+        const float y = (bin_keys[u] >> key) & 1ull ? x : 0.f;
+        if (key & 1) a1 += y; else a0 += y;
       }
+      dtab[u] += a0 + a1;
     }
+  }
+  {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = (int)threadIdx.x + u * 128;
+      if (r < WB_NB) dtable_partial[((long)blockIdx.x * WB_NB + r) * heads + head] = dtab[u];
+    }
+  }
+}
 
-    // ================= orientation 2: lane = key column ki
+__global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_kv_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ qkv_bias, const float* __restrict__ bias_table,
+    const float* __restrict__ dout, float* __restrict__ dqkv, float* __restrict__ dbias_partial,
+    const float* __restrict__ ws_stats, int B, int X, int Y, int S, int C, int heads, int shift, float scale, int wpb,
+    long n_windows) {
+  __shared__ float lds_bias[WB_HPB][WB_NB];
+  __shared__ float lds_lse[WB_HPB][64], lds_D[WB_HPB][64];
+  __shared__ float lds_bacc[WB_HPB][64];              // d(qkv bias) of this head through padded key positions: k | v
+  __shared__ int lds_tok[WB_HPB][64], lds_reg[WB_HPB][64];
+
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 31, lk = lane >> 5;
+  const int head_raw = blockIdx.y * WB_HPB + wave;
+  const bool active = head_raw < heads;
+  const int head = active ? head_raw : heads - 1;
+  const int C3 = 3 * C;
+  for (int t = lane; t < WB_NB; t += 64) lds_bias[wave][t] = bias_table[(long)t * heads + head];
+  lds_bacc[wave][lane] = 0.f;
+
+  for (int wi = 0; wi < wpb; ++wi) {
+    const long win = (long)blockIdx.x * wpb + wi;
+    if (win >= n_windows) break;
+    __syncthreads();
+    {
+      int tok, region;
+      wbm_window_tokens(win, lane, B, X, Y, S, shift, tok, region);
+      lds_tok[wave][lane] = tok;
+      lds_reg[wave][lane] = region;
+      const float* wsp = ws_stats + ((win * heads + head) * 2) * 64;
+      lds_lse[wave][lane] = wsp[lane];
+      lds_D[wave][lane] = wsp[64 + lane];
+    }
+    __syncthreads();
+
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       const int ki = kt * 32 + li;
-      const int krow = (ki * 37) >> 8, kcol = ki - krow * WB_WS;
+      const int ktok = lds_tok[wave][ki];
       const bool kreal = ki < WB_T;
+      const int krow = (ki * 37) >> 8, kcol = ki - krow * WB_WS;
       const int kreg = lds_reg[wave][ki];
-      bf16x8 ph[4], pl[4], sh[4], sl[4];
+      // B operands: K, V rows of the key token
+      bf16x8 Kh[2], Kl[2], Vh[2], Vl[2];
+      {
+        const float km = kreal ? 1.f : 0.f;
+        const float* src = (ktok >= 0 ? qkv + (long)ktok * C3 : qkv_bias) + head * WB_HD + lk * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          wbm_row8(src + C + ks * 16, km, Kh[ks], Kl[ks]);
+          wbm_row8(src + 2 * C + ks * 16, km, Vh[ks], Vl[ks]);
+        }
+      }
+      f32x16 dvt, dkt;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dvt[r] = dkt[r] = 0.f;
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
+        // A operands: scaled q and dO rows of query token 32 qt + li
+        bf16x8 Qh[2], Ql[2], Gh[2], Gl[2];
+        {
+          const int t = qt * 32 + li;
+          const int tok = lds_tok[wave][t];
+          const float qm = (t < WB_T && tok >= 0) ? 1.f : 0.f;
+          const long row = tok >= 0 ? tok : 0;
+          const float* qsrc = qkv + row * C3 + head * WB_HD + lk * 8;
+          const float* gsrc = dout + row * C + head * WB_HD + lk * 8;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            wbm_row8(qsrc + ks * 16, scale * qm, Qh[ks], Ql[ks]);
+            wbm_row8(gsrc + ks * 16, qm, Gh[ks], Gl[ks]);
+          }
+        }
         f32x16 st, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          st = occf_mfma_bf16_32x32x16(Ql[qt][ks], Kh[kt][ks], st);
-          st = occf_mfma_bf16_32x32x16(Qh[qt][ks], Kl[kt][ks], st);
-          st = occf_mfma_bf16_32x32x16(Qh[qt][ks], Kh[kt][ks], st);
-          dp = occf_mfma_bf16_32x32x16(Gl[qt][ks], Vh[kt][ks], dp);
-          dp = occf_mfma_bf16_32x32x16(Gh[qt][ks], Vl[kt][ks], dp);
-          dp = occf_mfma_bf16_32x32x16(Gh[qt][ks], Vh[kt][ks], dp);
+          st = occf_mfma_bf16_32x32x16(Ql[ks], Kh[ks], st);
+          st = occf_mfma_bf16_32x32x16(Qh[ks], Kl[ks], st);
+          st = occf_mfma_bf16_32x32x16(Qh[ks], Kh[ks], st);
+          dp = occf_mfma_bf16_32x32x16(Gl[ks], Vh[ks], dp);
+          dp = occf_mfma_bf16_32x32x16(Gh[ks], Vl[ks], dp);
+          dp = occf_mfma_bf16_32x32x16(Gh[ks], Vh[ks], dp);
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
+          const int kst = qt * 2 + s2;
+          // A operands of dVt / dKt: dO^T and (scaled q)^T, lane = channel li, the 8 query tokens of this k-step
+          float gt[8], qtv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int t = wbm_ktok(kst, e, lk);
+            const int tok = lds_tok[wave][t];
+            const bool ok = t < WB_T && tok >= 0;
+            const long row = tok >= 0 ? tok : 0;
+            const float g = dout[row * C + head * WB_HD + li];
+            const float q = qkv[row * C3 + head * WB_HD + li];
+            gt[e] = ok ? g : 0.f;
+            qtv[e] = ok ? q * scale : 0.f;
+          }
           float pv[8], dv[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -575,52 +660,54 @@ __global__ void __launch_bounds__(64 * WB_HPB) window_attn_bwd_mfma_kernel(
             pv[e] = pp;
             dv[e] = pp * (dp[r] - lds_D[wave][qi]);
           }
-          wbm_split8(pv, ph[qt * 2 + s2], pl[qt * 2 + s2]);
-          wbm_split8(dv, sh[qt * 2 + s2], sl[qt * 2 + s2]);
+          bf16x8 ph, pl, sh, sl, gh, gl, qh, ql;
+          wbm_split8(pv, ph, pl);
+          wbm_split8(dv, sh, sl);
+          wbm_split8(gt, gh, gl);
+          wbm_split8(qtv, qh, ql);
+          dvt = occf_mfma_bf16_32x32x16(gl, ph, dvt);
+          dvt = occf_mfma_bf16_32x32x16(gh, pl, dvt);
+          dvt = occf_mfma_bf16_32x32x16(gh, ph, dvt);
+          dkt = occf_mfma_bf16_32x32x16(ql, sh, dkt);
+          dkt = occf_mfma_bf16_32x32x16(qh, sl, dkt);
+          dkt = occf_mfma_bf16_32x32x16(qh, sh, dkt);
         }
       }
-      f32x16 dvt, dkt;
+      if (active && kreal && ktok >= 0) {
+        float* dk = dqkv + (long)ktok * C3 + C + head * WB_HD + 4 * lk;
+        float* dvp = dk + C;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dvt[r] = dkt[r] = 0.f;
-#pragma unroll
-      for (int kst = 0; kst < 4; ++kst) {
-        const int off = kst * 1024 + li * 32 + lk * 16;
-        const bf16x8 gh = *(const bf16x8*)(base + 2 * WBM_IMG + off), gl = *(const bf16x8*)(base + 3 * WBM_IMG + off);
-        const bf16x8 qh = *(const bf16x8*)(base + 4 * WBM_IMG + off), ql = *(const bf16x8*)(base + 5 * WBM_IMG + off);
-        dvt = occf_mfma_bf16_32x32x16(gl, ph[kst], dvt);
-        dvt = occf_mfma_bf16_32x32x16(gh, pl[kst], dvt);
-        dvt = occf_mfma_bf16_32x32x16(gh, ph[kst], dvt);
-        dkt = occf_mfma_bf16_32x32x16(ql, sh[kst], dkt);
-        dkt = occf_mfma_bf16_32x32x16(qh, sl[kst], dkt);
-        dkt = occf_mfma_bf16_32x32x16(qh, sh[kst], dkt);
+        for (int g = 0; g < 4; ++g) {
+          *(float4*)(dk + 8 * g) = make_float4(dkt[g * 4 + 0], dkt[g * 4 + 1], dkt[g * 4 + 2], dkt[g * 4 + 3]);
+          *(float4*)(dvp + 8 * g) = make_float4(dvt[g * 4 + 0], dvt[g * 4 + 1], dvt[g * 4 + 2], dvt[g * 4 + 3]);
+        }
       }
-      if (active && kreal) {
-        if (tokt[kt] >= 0) {
-          float* dk = dqkv + (long)tokt[kt] * C3 + C + head * WB_HD + 4 * lk;
-          float* dvp = dk + C;
+      // padded window positions (edge windows only) have no token: their k / v are the bias row, so their dK / dV
+      // rows belong to d(qkv bias).  Summed over the key lanes here and kept per wave in LDS -- float atomics on the
+      // 2 x 32 bias entries of a head serialised ~5 M same-line atomics per call at the L2 (most of the 8.7 ms of
+      // the r02c..r02f kernel)
+      const bool pad = kreal && ktok < 0;
+      if (__ballot(pad) != 0ull) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            *(float4*)(dk + 8 * g) = make_float4(dkt[g * 4 + 0], dkt[g * 4 + 1], dkt[g * 4 + 2], dkt[g * 4 + 3]);
-            *(float4*)(dvp + 8 * g) = make_float4(dvt[g * 4 + 0], dvt[g * 4 + 1], dvt[g * 4 + 2], dvt[g * 4 + 3]);
+        for (int r = 0; r < 16; ++r) {
+          float a = pad ? dkt[r] : 0.f, b = pad ? dvt[r] : 0.f;
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o);
+            b += __shfl_xor(b, o);
           }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
+          if (li == 0) {
             const int d = (r & 3) + 8 * (r >> 2) + 4 * lk;
-            atomicAdd(dqkv_bias + C + head * WB_HD + d, dkt[r]);
-            atomicAdd(dqkv_bias + 2 * C + head * WB_HD + d, dvt[r]);
+            lds_bacc[wave][d] += a;
+            lds_bacc[wave][32 + d] += b;
           }
         }
       }
     }
   }
-  if (active) {
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int r = lane + u * 64;
-      if (r < WB_NB) dtable_partial[((long)blockIdx.x * WB_NB + r) * heads + head] = dtab[u];
-    }
-  }
+  // per-workgroup partial of d(qkv bias)[C .. 3C): column kv * C + head * 32 + d
+  __syncthreads();
+  if (active) dbias_partial[(long)blockIdx.x * 2 * C + (lane >> 5) * C + head * WB_HD + (lane & 31)] = lds_bacc[wave][lane];
 }
 
 // dtable[r][head] = sum_x partial[x][r][head]: 64 columns x 16 row groups per workgroup, double accumulation
@@ -646,9 +733,12 @@ static int wb_windows_per_block(long n_windows) {
   long w = (n_windows + 1023) / 1024;
   return w < 1 ? 1 : (w > 64 ? 64 : (int)w);
 }
+// floats: the per-workgroup partial bias-table gradients, the per-workgroup partial d(qkv bias) of the k / v thirds,
+// then lse / D of every (window, head, query)
 extern "C" long occf_window_attn_bwd_workspace(int B, int X, int Y, int S, int heads) {
   const long nwin = (long)B * S * ((X + 6) / 7) * ((Y + 6) / 7);
-  return (long)occf_cdiv(nwin, wb_windows_per_block(nwin)) * heads * WB_NB;
+  const long nblk = occf_cdiv(nwin, wb_windows_per_block(nwin));
+  return nblk * heads * WB_NB + nblk * 2 * heads * WB_HD + nwin * heads * 128;
 }
 
 extern "C" int occf_window_attn_bwd(const float* qkv, const float* qkv_bias, const float* bias_table,
@@ -665,11 +755,18 @@ extern "C" int occf_window_attn_bwd(const float* qkv, const float* qkv_bias, con
     const char* e = getenv("OCCF_WATTN_BWD_MFMA");
     return e ? atoi(e) != 0 : true;
   }();
-  if (mfma)
-    hipLaunchKernelGGL(window_attn_bwd_mfma_kernel, dim3(nblk, occf_cdiv(heads, WB_HPB)), dim3(64 * WB_HPB), 0, st, qkv,
-                       qkv_bias, bias_table, attn_out, dout, dqkv, dqkv_bias, workspace, B, X, Y, S, C, heads, shift,
-                       1.0f / sqrtf((float)WB_HD), wpb, nwin);
-  else
+  if (mfma) {
+    float* bias_part = workspace + (long)nblk * heads * WB_NB;
+    float* stats = bias_part + (long)nblk * 2 * C;
+    const dim3 grid(nblk, occf_cdiv(heads, WB_HPB)), block(64 * WB_HPB);
+    const float scale = 1.0f / sqrtf((float)WB_HD);
+    hipLaunchKernelGGL(window_attn_bwd_q_kernel, dim3(nblk, heads), dim3(128), 0, st, qkv, qkv_bias, bias_table, attn_out, dout, dqkv,
+                       workspace, stats, B, X, Y, S, C, heads, shift, scale, wpb, nwin);
+    hipLaunchKernelGGL(window_attn_bwd_kv_kernel, grid, block, 0, st, qkv, qkv_bias, bias_table, dout, dqkv, bias_part,
+                       stats, B, X, Y, S, C, heads, shift, scale, wpb, nwin);
+    hipLaunchKernelGGL(window_table_reduce_kernel, dim3(occf_cdiv(2 * C, 64)), dim3(1024), 0, st, bias_part,
+                       dqkv_bias + C, (long)nblk, 2 * C);
+  } else
     hipLaunchKernelGGL(window_attn_bwd_kernel, dim3(nblk, occf_cdiv(heads, WB_HPB)), dim3(64 * WB_HPB), 0, st, qkv,
                        qkv_bias, bias_table, attn_out, dout, dqkv, dqkv_bias, workspace, B, X, Y, S, C, heads, shift,
                        1.0f / sqrtf((float)WB_HD), wpb, nwin);

@@ -406,16 +406,31 @@ __global__ void msda_zero_word_kernel(unsigned* p) { p[0] = 0u; }
 struct MsdaTileCfg {
   int ls, T, M, tiles_x, tiles_y, groups;   // groups > 1: the level is ONE tile, its queries are split over `groups`
   int CH, passes, lpg;                      // channels per pass, passes per head, lanes per query (CH = 3 * lpg)
+  int stride;                               // 1: strided walk over the queries (conflict spreading), 0: linear
 };
 
 __device__ __forceinline__ int msda_cdiv_pos(long num, long den) { return num <= 0 ? 0 : (int)((num + den - 1) / den); }
 
-__global__ void __launch_bounds__(256) msda3d_bwd_value_tile_kernel(
+// signed 64-bit fixed point of x (|x| <= 2^41): rint(x) = rint(x / 2^20) * 2^20 + rint(remainder), both pieces exact
+// in fp32 and inside int32 -- a handful of VALU instructions instead of the generic float -> int64 conversion
+__device__ __forceinline__ unsigned long long msda_fx(float x) {
+  const float hi = rintf(x * 9.5367431640625e-07f);                 // 2^-20
+  const float lo = rintf(fmaf(-hi, 1048576.0f, x));
+  return (unsigned long long)(((long long)(int)hi << 20) + (long long)(int)lo);
+}
+
+// workgroup = 1024 threads (16 waves: the tile takes most of the CU's LDS, so the waves that hide the VALU work
+// behind the LDS atomics have to come from ONE workgroup); work item = (query, sampling point), `lpg` lanes each
+// (3 channels per lane).  Items are walked with a large odd stride so that the lanes of one wave instruction
+// belong to queries far apart (neighbouring queries hit the same cells: same-address atomics serialise).
+#define MSDA_TILE_THREADS 1024
+__global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kernel(
     const float* __restrict__ offs, const float* __restrict__ logits, const float* __restrict__ dout,
     float* __restrict__ dvalue, float* __restrict__ scratch, const unsigned* __restrict__ absmax_bits, MsdaLevels lv,
     MsdaTileCfg tc, int B, int Nq, int H, int Dh, int P, long off_ld, long lg_ld) {
   OCCF_DYN_SMEM(smem_raw);
   unsigned long long* tile = (unsigned long long*)smem_raw;
+  const int NT = blockDim.x;
   const float gmax = occf_u2f(absmax_bits[0]);
   const float fx_scale = gmax > 0.f ? 1099511627776.0f / gmax : 1.0f;       // 2^40 / max|dout|
   const float fx_inv = 1.0f / fx_scale;
@@ -434,7 +449,7 @@ __global__ void __launch_bounds__(256) msda3d_bwd_value_tile_kernel(
   const int RX = tc.T + 2 * tc.M, RY = RX;
   const int CH = tc.CH, ch0 = pass * CH;
   const long ncell = (long)RX * RY * Zs;
-  for (long i = threadIdx.x; i < ncell * CH; i += 256) tile[i] = 0ull;
+  for (long i = threadIdx.x; i < ncell * CH; i += NT) tile[i] = 0ull;
   __syncthreads();
 
   // query boxes per query level: cell(q) = floor((2q + 1) * Xs / (2 * Xq)) in [tx0, tx0 + T)
@@ -459,14 +474,21 @@ __global__ void __launch_bounds__(256) msda3d_bwd_value_tile_kernel(
     }
   }
   const int n_items = cum[L];
-  const int lpg = tc.lpg, slots = 256 / lpg;
+  const int lpg = tc.lpg, slots = NT / lpg;
   const int slot = threadIdx.x / lpg, sub = threadIdx.x % lpg;
   const int E = H * Dh;
   const long Nv = lv.start[L - 1] + (long)lv.X[L - 1] * lv.Y[L - 1] * lv.Z[L - 1];
-  // this group's share of the items
+  // this group's share of the queries; units = (query, point)
   const int per = (n_items + tc.groups - 1) / tc.groups;
   const int it_begin = grp * per, it_end = it_begin + per < n_items ? it_begin + per : n_items;
-  for (int it = it_begin + slot; it < it_end; it += slots) {
+  const int n_q = it_end > it_begin ? it_end - it_begin : 0;
+  unsigned stride = 1u;                                     // coprime with n_q; j * stride stays below 2^32
+  if (tc.stride > 0 && n_q > 1 && n_q < 1000000) stride = (unsigned)(((n_q % 4099) ? 4099 : 4111) % n_q);
+  const int n_units = n_q * P;
+  float* dvb = dvalue + ((long)b * Nv + lv.start[ls]) * E + h * Dh + ch0 + sub * 3;
+  for (int u = slot; u < n_units; u += slots) {
+    const int k = u / n_q;
+    const int it = it_begin + (int)(((unsigned)(u - k * n_q) * stride) % (unsigned)n_q);
     int lq = 0;
     while (lq + 1 < L && it >= cum[lq + 1]) ++lq;
     int r = it - cum[lq];
@@ -487,38 +509,35 @@ __global__ void __launch_bounds__(256) msda3d_bwd_value_tile_kernel(
     const float* of = offs + (long)(b * Nq + q) * off_ld + h * LP * 3;
     const float* gp = dout + (long)(b * Nq + q) * E + h * Dh + ch0 + sub * 3;
     const float g0 = gp[0], g1 = gp[1], g2 = gp[2];
-    float* dvb = dvalue + ((long)b * Nv + lv.start[ls]) * E + h * Dh + ch0 + sub * 3;
-    for (int k = 0; k < P; ++k) {
-      const int i = ls * P + k;
-      const float lz = rz + of[i * 3 + 0] / (float)Zs;
-      const float ly = ry + of[i * 3 + 1] / (float)Ys;
-      const float lx = rx + of[i * 3 + 2] / (float)Xs;
-      const float pz = ((2.f * lz - 1.f + 1.f) * (float)Zs - 1.f) * 0.5f;
-      const float py = ((2.f * ly - 1.f + 1.f) * (float)Ys - 1.f) * 0.5f;
-      const float px = ((2.f * lx - 1.f + 1.f) * (float)Xs - 1.f) * 0.5f;
-      const float fz = floorf(pz), fy = floorf(py), fx = floorf(px);
-      const float tz = pz - fz, ty = py - fy, tx = px - fx;
-      const int iz = (int)fz, iy = (int)fy, ix = (int)fx;
-      const float a = expf(lg[i] - mx) * inv;
+    const int i = ls * P + k;
+    const float lz = rz + of[i * 3 + 0] / (float)Zs;
+    const float ly = ry + of[i * 3 + 1] / (float)Ys;
+    const float lx = rx + of[i * 3 + 2] / (float)Xs;
+    const float pz = ((2.f * lz - 1.f + 1.f) * (float)Zs - 1.f) * 0.5f;
+    const float py = ((2.f * ly - 1.f + 1.f) * (float)Ys - 1.f) * 0.5f;
+    const float px = ((2.f * lx - 1.f + 1.f) * (float)Xs - 1.f) * 0.5f;
+    const float fz = floorf(pz), fy = floorf(py), fx = floorf(px);
+    const float tz = pz - fz, ty = py - fy, tx = px - fx;
+    const int iz = (int)fz, iy = (int)fy, ix = (int)fx;
+    const float a = expf(lg[i] - mx) * inv;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const int cbx = c >> 2, cby = (c >> 1) & 1, cbz = c & 1;
-        const int xx = ix + cbx, yy = iy + cby, zz = iz + cbz;
-        if ((unsigned)xx >= (unsigned)Xs || (unsigned)yy >= (unsigned)Ys || (unsigned)zz >= (unsigned)Zs) continue;
-        const float cw = a * (cbx ? tx : 1.f - tx) * (cby ? ty : 1.f - ty) * (cbz ? tz : 1.f - tz);
-        const int lx_ = xx - rx0, ly_ = yy - ry0;
-        if ((unsigned)lx_ < (unsigned)RX && (unsigned)ly_ < (unsigned)RY) {
-          unsigned long long* t = tile + (((long)lx_ * RY + ly_) * Zs + zz) * CH + sub * 3;
-          const float cs = cw * fx_scale;
-          atomicAdd(t + 0, (unsigned long long)(long long)llrintf(cs * g0));
-          atomicAdd(t + 1, (unsigned long long)(long long)llrintf(cs * g1));
-          atomicAdd(t + 2, (unsigned long long)(long long)llrintf(cs * g2));
-        } else {
-          float* d = dvb + (((long)xx * Ys + yy) * Zs + zz) * E;
-          atomicAdd(d + 0, cw * g0);
-          atomicAdd(d + 1, cw * g1);
-          atomicAdd(d + 2, cw * g2);
-        }
+    for (int c = 0; c < 8; ++c) {
+      const int cbx = c >> 2, cby = (c >> 1) & 1, cbz = c & 1;
+      const int xx = ix + cbx, yy = iy + cby, zz = iz + cbz;
+      if ((unsigned)xx >= (unsigned)Xs || (unsigned)yy >= (unsigned)Ys || (unsigned)zz >= (unsigned)Zs) continue;
+      const float cw = a * (cbx ? tx : 1.f - tx) * (cby ? ty : 1.f - ty) * (cbz ? tz : 1.f - tz);
+      const int lx_ = xx - rx0, ly_ = yy - ry0;
+      if ((unsigned)lx_ < (unsigned)RX && (unsigned)ly_ < (unsigned)RY) {
+        unsigned long long* t = tile + ((lx_ * RY + ly_) * Zs + zz) * CH + sub * 3;
+        const float cs = cw * fx_scale;
+        atomicAdd(t + 0, msda_fx(cs * g0));
+        atomicAdd(t + 1, msda_fx(cs * g1));
+        atomicAdd(t + 2, msda_fx(cs * g2));
+      } else {
+        float* d = dvb + (((long)xx * Ys + yy) * Zs + zz) * E;
+        atomicAdd(d + 0, cw * g0);
+        atomicAdd(d + 1, cw * g1);
+        atomicAdd(d + 2, cw * g2);
       }
     }
   }
@@ -526,7 +545,7 @@ __global__ void __launch_bounds__(256) msda3d_bwd_value_tile_kernel(
   // hand the region over: plain coalesced stores into this workgroup's slab of the scratch buffer; the gather
   // kernel below sums, for every cell, the (at most 9) regions that cover it -- no atomics, fixed order
   float* slab = scratch + (((long)b * H + h) * gridDim.x + blockIdx.x) * (ncell * CH);
-  for (long i = threadIdx.x; i < ncell * CH; i += 256) slab[i] = (float)((double)(long long)tile[i] * (double)fx_inv);
+  for (long i = threadIdx.x; i < ncell * CH; i += NT) slab[i] = (float)((double)(long long)tile[i] * (double)fx_inv);
 }
 
 // dvalue[cell, h*Dh + ch] += sum over the regions that contain the cell (tiles: <= 3 per axis; whole-level mode: the
@@ -677,8 +696,18 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
       unsigned* absmax = (unsigned*)(workspace + workspace_floats - 4);
       hipLaunchKernelGGL(msda_zero_word_kernel, dim3(1), dim3(1), 0, st, absmax);
       hipLaunchKernelGGL(msda_absmax_kernel, dim3(512), dim3(256), 0, st, dout, (long)B * Nq * heads * head_dim, absmax);
+      static const int tile_threads = [] {
+        const char* e = getenv("OCCF_MSDA_TILE_THREADS");
+        const int v = e ? atoi(e) : MSDA_TILE_THREADS;
+        return v >= 64 && v <= MSDA_TILE_THREADS && v % 64 == 0 ? v : MSDA_TILE_THREADS;
+      }();
+      static const int strided = [] {
+        const char* e = getenv("OCCF_MSDA_STRIDED");
+        return e ? atoi(e) : 1;
+      }();
       for (int l = 0; l < num_levels; ++l) {
-        const MsdaTileCfg& tc = cfgs[l];
+        MsdaTileCfg tc = cfgs[l];
+        tc.stride = strided;
         const size_t lds = (size_t)(tc.T + 2 * tc.M) * (tc.T + 2 * tc.M) * lv.Z[l] * tc.CH * 8;
 #ifndef OCCF_EMU
         static size_t lds_max = 0;
@@ -689,7 +718,7 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
         }
 #endif
         const dim3 grid((unsigned)(tc.tiles_x * tc.tiles_y * tc.groups * tc.passes), heads, B);
-        hipLaunchKernelGGL(msda3d_bwd_value_tile_kernel, grid, dim3(256), lds, st, sampling_offsets, attn_logits, dout,
+        hipLaunchKernelGGL(msda3d_bwd_value_tile_kernel, grid, dim3(tile_threads), lds, st, sampling_offsets, attn_logits, dout,
                            dvalue, workspace, absmax, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
         const long total = (long)B * heads * lv.X[l] * lv.Y[l] * lv.Z[l] * head_dim;
         hipLaunchKernelGGL(msda3d_bwd_value_gather_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, workspace,

@@ -184,33 +184,56 @@ __global__ void __launch_bounds__(64) tk_scan_kernel(unsigned* __restrict__ hist
   }
 }
 
+// One returning atomic per WORKGROUP and counter: a workgroup owns a contiguous chunk, counts its hits first (second
+// read of the keys comes from the L2) and places them behind one reservation.  One atomic per wave iteration
+// (~10 000 same-address returning atomics per row at V = 640 000) serialised at the L2: 420 us per call.
 __global__ void __launch_bounds__(256) tk_compact_kernel(const float* __restrict__ keys,
                                                          unsigned* __restrict__ state, int* __restrict__ counters,
                                                          int64_t* __restrict__ out, long V, unsigned k) {
+  __shared__ int wcnt[2][4], wbase[2][4];
   const int r = blockIdx.y;
   const unsigned thr = state[r * 4 + 0];                   // exact bit pattern of the k-th largest key
   const unsigned ties = state[r * 4 + 2];                  // how many keys == thr to take
-  const int lane = threadIdx.x & 63;
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long i0 = (long)blockIdx.x * blockDim.x + (threadIdx.x & ~63); i0 < V; i0 += stride) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long per = (V + gridDim.x - 1) / gridDim.x;
+  per = (per + 255) / 256 * 256;
+  const long c0 = (long)blockIdx.x * per;
+  const long c1 = c0 + per < V ? c0 + per : V;
+  const float* row = keys + (long)r * V;
+  int ng = 0, ne = 0;
+  for (long i0 = c0 + wave * 64; i0 < c1; i0 += 256) {
     const long i = i0 + lane;
-    const unsigned b = i < V ? tk_bits(keys[(long)r * V + i]) : 0u;
-    const bool gt = i < V && b > thr;
-    const bool eq = i < V && b == thr;
+    const unsigned b = i < c1 ? tk_bits(row[i]) : 0u;
+    ng += __popcll(__ballot(i < c1 && b > thr));
+    ne += __popcll(__ballot(i < c1 && b == thr));
+  }
+  if (lane == 0) {
+    wcnt[0][wave] = ng;
+    wcnt[1][wave] = ne;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const int c = threadIdx.x;
+    const int tot = wcnt[c][0] + wcnt[c][1] + wcnt[c][2] + wcnt[c][3];
+    int base = tot ? atomicAdd(&counters[r * 2 + c], tot) : 0;
+    for (int w = 0; w < 4; ++w) {
+      wbase[c][w] = base;
+      base += wcnt[c][w];
+    }
+  }
+  __syncthreads();
+  int og = wbase[0][wave], oe = wbase[1][wave];
+  for (long i0 = c0 + wave * 64; i0 < c1; i0 += 256) {
+    const long i = i0 + lane;
+    const unsigned b = i < c1 ? tk_bits(row[i]) : 0u;
+    const bool gt = i < c1 && b > thr;
+    const bool eq = i < c1 && b == thr;
     const unsigned long long mg = __ballot(gt), me = __ballot(eq);
-    if (mg) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&counters[r * 2 + 0], __popcll(mg));
-      base = __shfl(base, 0);
-      if (gt) out[(long)r * k + base + __popcll(mg & ((1ull << lane) - 1))] = i;
-    }
-    if (me) {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&counters[r * 2 + 1], __popcll(me));
-      base = __shfl(base, 0);
-      const int slot = base + __popcll(me & ((1ull << lane) - 1));
-      if (eq && slot < (int)ties) out[(long)r * k + (k - ties) + slot] = i;
-    }
+    if (gt) out[(long)r * k + og + __popcll(mg & ((1ull << lane) - 1))] = i;
+    og += __popcll(mg);
+    const int slot = oe + __popcll(me & ((1ull << lane) - 1));
+    if (eq && slot < (int)ties) out[(long)r * k + (k - ties) + slot] = i;
+    oe += __popcll(me);
   }
 }
 

@@ -1,12 +1,13 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/train_wl
+O=$R/gpurun_out/probe11
 mkdir -p $O
 cd $R
-for wl in kitti_effb7_128 nusc_r50_ref128; do
-echo "== train bench $wl"; timeout 600 python bench.py --mode train --workload $wl --steps 3 --warmup 2 --no-cpu-baseline > $O/bench_train_$wl.json 2> $O/err_$wl.txt; echo rc=$?; tail -3 $O/err_$wl.txt
+echo "== window"; python scripts/bwd_probe.py window
+echo "== tests"; timeout 900 python -m pytest tests/test_bwd_ops.py tests/test_training.py -m gpu -q -p no:cacheprovider -k "window or topk or sampl or wor" 2>&1 | tail -3
+echo "== train bench"; timeout 600 python bench.py --mode train --steps 3 --warmup 2 --no-cpu-baseline > $O/bench_train.json 2> $O/err.txt; echo rc=$?; tail -2 $O/err.txt
 python -c "
 import json
-d=json.load(open('$O/bench_train_$wl.json')); print({k:d[k] for k in ('value','ms_per_step','peak_memory_GiB','forward_samples_per_s_same_run')}); print(d['losses'])"
-done
+d=json.load(open('$O/bench_train.json')); print({k:d[k] for k in ('value','ms_per_step','peak_memory_GiB','forward_samples_per_s_same_run')})
+for k,v in list(d['kernels'].items())[:16]: print(k, v['calls'], round(v['total_ms'],2))"
