@@ -776,11 +776,14 @@ extern "C" int occf_upsample_add_bwd(const float* dout, float* dcoarse, int B, i
 __global__ void __launch_bounds__(256) point_sample_3d_bwd_kernel(const float* __restrict__ dout,
                                                                   const float* __restrict__ pts, float* __restrict__ dvol,
                                                                   int N, int C, int X, int Y, int Z, long P, int shared_pts,
-                                                                  int align_corners, int border, long voxel_major_ld) {
+                                                                  int align_corners, int border, long voxel_major_ld,
+                                                                  int cgroups) {
+  // thread = (n, channel group, point), like the forward
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long)N * P) return;
-  const int n = (int)(gid / P);
+  if (gid >= (long)N * cgroups * P) return;
   const long pi = gid % P;
+  const int cg = (int)((gid / P) % cgroups);
+  const int n = (int)(gid / (P * cgroups));
   const float* pt = pts + ((shared_pts ? 0 : (long)n * P) + pi) * 3;
   const int dims[3] = {Z, Y, X};
   int i0[3], i1[3];
@@ -802,7 +805,7 @@ __global__ void __launch_bounds__(256) point_sample_3d_bwd_kernel(const float* _
   // voxel_major_ld > 0: dvol is [V, ld] with column n*C + c (the layout the mask-logit contraction's backward
   // consumes as a row-major [voxels, rows] operand); otherwise [N, C, V]
   const long vstride = voxel_major_ld > 0 ? voxel_major_ld : 1;
-  for (int c = 0; c < C; ++c) {
+  for (int c = cg; c < C; c += cgroups) {
     float* v = voxel_major_ld > 0 ? dvol + ((long)n * C + c) : dvol + ((long)n * C + c) * V;
     const float g = dout[((long)n * C + c) * P + pi];
 #pragma unroll
@@ -822,8 +825,10 @@ extern "C" int occf_point_sample_3d_bwd(const float* dout, const float* pts, flo
   if (N <= 0 || C <= 0 || X <= 0 || Y <= 0 || Z <= 0 || P < 0) return OCCF_EINVAL;
   if (voxel_major_ld != 0 && voxel_major_ld < (long)N * C) return OCCF_EINVAL;
   if (P == 0) return 0;
-  hipLaunchKernelGGL(point_sample_3d_bwd_kernel, dim3(occf_cdiv((long)N * P, 256)), dim3(256), 0, (hipStream_t)stream,
-                     dout, pts, dvol, N, C, X, Y, Z, P, shared_pts, align_corners, border_padding, voxel_major_ld);
+  const int cgroups = occf_sample_cgroups(N, C, P);
+  hipLaunchKernelGGL(point_sample_3d_bwd_kernel, dim3(occf_cdiv((long)N * cgroups * P, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dout, pts, dvol, N, C, X, Y, Z, P, shared_pts, align_corners, border_padding,
+                     voxel_major_ld, cgroups);
   OCCF_LAUNCH_CHECK();
 }
 

@@ -36,6 +36,12 @@ struct ConvGeomB {
   // with dims Xi/Yi/Zi = the forward's output dims): tap (dx,dy,dz) of row x reads dY[(x + pad - dx*dil) / stride]
   // when that division is exact and in range
   int transposed;
+  // cls = 1 (transposed, stride > 1, output dims divisible by the stride; kernel variant CONV == 2): rows are
+  // enumerated CLASS-major -- [b][class (x%s, y%s, z%s)][x/s][y/s][z/s] -- so that a 128-row tile lies inside one
+  // parity class and walks only the taps that class can reach ((x + pad - tap*dil) % stride == 0): 27/8 of the
+  // 27 taps on average for a 3^3 / stride-2 convolution instead of all of them with 7/8 zero-filled
+  int cls;
+  int per_pad;         // rows reserved per class: its (Xo/s)(Yo/s)(Zo/s) voxels rounded up to whole 128-row tiles
 };
 struct GemmArgsB {
   const float* A;
@@ -92,7 +98,31 @@ typedef uint32_t occf_u4 __attribute__((ext_vector_type(4)));
 // and are masked afterwards): a load under a divergent branch makes the compiler wait for it right
 // there (s_waitcnt vmcnt(0) before the join), which serialised the four A loads of a k-tile into
 // four full memory round trips.
-template <int BN, int TERMS, bool CONV, bool SPLIT, int PF>
+// class-major row -> (b, xo, yo, zo) of a transposed / strided problem; false for the padding rows of a class.
+// Class slots are ordered heavy-first (slot 0 = class (s-1, s-1, s-1), which reaches the most taps) so that the
+// long tiles are dispatched first.
+__device__ __forceinline__ bool occf_cls_row(const ConvGeomB& g, long m, long& b, int& xo, int& yo, int& zo, int& cls) {
+  const int s = g.stride;
+  const int Xq = g.Xo / s, Yq = g.Yo / s, Zq = g.Zo / s;
+  const int per = Xq * Yq * Zq;
+  const long per_b = (long)g.per_pad * s * s * s;
+  b = m / per_b;
+  const int r = (int)(m - b * per_b);
+  const int slot = r / g.per_pad;
+  cls = s * s * s - 1 - slot;
+  int q = r - slot * g.per_pad;
+  const bool ok = q < per;
+  q = ok ? q : 0;
+  const int zq = q % Zq;
+  q /= Zq;
+  const int yq = q % Yq, xq = q / Yq;
+  xo = xq * s + cls / (s * s);
+  yo = yq * s + (cls / s) % s;
+  zo = zq * s + cls % s;
+  return ok;
+}
+
+template <int BN, int TERMS, int CONV, bool SPLIT, int PF>
 __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
   constexpr int TN = BN / 64;                      // 32-wide MFMA tiles per wave along N
   constexpr int NB = BN * 4 / 256;                 // 16-B weight pieces per thread per array
@@ -126,10 +156,14 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
     a_ok[i] = m < p.M;
     if (CONV) {
       const long mm = a_ok[i] ? m : 0;
-      const int zo = (int)(mm % p.g.Zo);
-      const int yo = (int)((mm / p.g.Zo) % p.g.Yo);
-      const int xo = (int)((mm / ((long)p.g.Zo * p.g.Yo)) % p.g.Xo);
-      const long b = mm / ((long)p.g.Zo * p.g.Yo * p.g.Xo);
+      int zo = (int)(mm % p.g.Zo);
+      int yo = (int)((mm / p.g.Zo) % p.g.Yo);
+      int xo = (int)((mm / ((long)p.g.Zo * p.g.Yo)) % p.g.Xo);
+      long b = mm / ((long)p.g.Zo * p.g.Yo * p.g.Xo);
+      if (CONV == 2) {
+        int cls_unused;
+        a_ok[i] = occf_cls_row(p.g, mm, b, xo, yo, zo, cls_unused) && a_ok[i];
+      }
       a_base[i] = b * p.g.sb;
       a_x[i] = p.g.transposed ? xo + p.g.pad_x : xo * p.g.stride - p.g.pad_x;
       a_y[i] = p.g.transposed ? yo + p.g.pad_y : yo * p.g.stride - p.g.pad_y;
@@ -154,15 +188,42 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
 
   float4 ra[PF][4];
   occf_u4 rbh[PF][NB], rbl[PF][NB];
+  // CONV == 2: the taps this tile's parity class can reach (all taps if the tile straddles two classes)
+  __shared__ int tapmap[CONV == 2 ? 64 : 1];
+  __shared__ int tapcount;
+  if (CONV == 2) {
+    long b0;
+    int x0, y0, z0, c0;
+    occf_cls_row(p.g, m0, b0, x0, y0, z0, c0);            // per_pad % 128 == 0: one class per tile
+    const int ntaps = p.g.kX * p.g.kY * p.g.kZ;
+    if (tid < 64) {
+      bool ok = tid < ntaps;
+      if (ok) {
+        const int s = p.g.stride;
+        const int dz = tid % p.g.kZ, dy = (tid / p.g.kZ) % p.g.kY, dx = tid / (p.g.kZ * p.g.kY);
+        const int vx = c0 / (s * s) + p.g.pad_x - dx * p.g.dil, vy = (c0 / s) % s + p.g.pad_y - dy * p.g.dil,
+                  vz = c0 % s + p.g.pad_z - dz * p.g.dil;
+        ok = ((vx % s) + s) % s == 0 && ((vy % s) + s) % s == 0 && ((vz % s) + s) % s == 0;
+      }
+      const unsigned long long mk = __ballot(ok);
+      if (ok) tapmap[__popcll(mk & ((1ull << tid) - 1))] = tid;
+      if (tid == 0) tapcount = __popcll(mk);
+    }
+    __syncthreads();
+  }
   // K range of this workgroup (split-K: blockIdx.y selects a contiguous slice of k-tiles)
-  const int nk_all = p.K / GB_BK;
+  const int nk_all = CONV == 2 ? tapcount * (p.g.Cin / GB_BK) : p.K / GB_BK;
   const int kt_begin = SPLIT ? (int)((long)blockIdx.y * nk_all / p.ksplit) : 0;
   const int kt_end = SPLIT ? (int)((long)(blockIdx.y + 1) * nk_all / p.ksplit) : nk_all;
   auto load_tile = [&](int kt, int d) __attribute__((always_inline)) {
-    const int k0 = (kt_begin + kt) * GB_BK;
+    int k0 = (kt_begin + kt) * GB_BK;
     if (CONV) {
-      const int tap = k0 / p.g.Cin;                 // Cin % 32 == 0: block-uniform tap
+      int tap = k0 / p.g.Cin;                       // Cin % 32 == 0: block-uniform tap
       const int c0 = k0 - tap * p.g.Cin;
+      if (CONV == 2) {
+        tap = tapmap[tap];
+        k0 = tap * p.g.Cin + c0;
+      }
       const int dz = tap % p.g.kZ, dy = (tap / p.g.kZ) % p.g.kY, dx = tap / (p.g.kZ * p.g.kY);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -261,8 +322,10 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
   // UNCONDITIONALLY so that the compiler can count how many newer loads may stay in flight when it
   // waits for the oldest slot (s_waitcnt vmcnt(8*(PF-1))); a load under `if` on any path would force
   // a full drain.  The remainder (< 2*PF tiles) keeps conditional loads.
+  if (nk > 0) {                                             // (a parity class may reach no tap at all)
 #pragma unroll
   for (int d = 0; d < PF; ++d) load_tile(d < nk ? d : nk - 1, d);
+  }
   int kt0 = 0;
   for (; kt0 + 2 * PF <= nk; kt0 += PF) {
 #pragma unroll
@@ -358,6 +421,11 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
               const long bb = m / p.hm_rows, q = m - bb * p.hm_rows;
               const int hh = n / p.hm_dh;
               *(float4*)(e_out + ((bb * (p.N / p.hm_dh) + hh) * p.hm_rows + q) * p.hm_dh + (n - hh * p.hm_dh)) = v;
+            } else if (CONV == 2 && !part) {
+              long bb;
+              int xo, yo, zo, cc;
+              if (occf_cls_row(p.g, m, bb, xo, yo, zo, cc))
+                *(float4*)(e_out + (((bb * p.g.Xo + xo) * p.g.Yo + yo) * p.g.Zo + zo) * e_ldc + n) = v;
             } else {
               *(float4*)(e_out + m * e_ldc + n) = v;
             }
@@ -377,7 +445,14 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
           if (e_act == 1) v = fmaxf(v, 0.f);
           else if (e_act == 2) v = occf_gelu_b(v);
           if (e_res) v += e_res[m * p.ldr + nn + e];
-          e_out[m * e_ldc + nn + e] = v;
+          long mo = m;
+          if (CONV == 2 && !part) {
+            long bb;
+            int xo, yo, zo, cc;
+            if (!occf_cls_row(p.g, m, bb, xo, yo, zo, cc)) continue;
+            mo = ((bb * p.g.Xo + xo) * p.g.Yo + yo) * p.g.Zo + zo;
+          }
+          e_out[mo * e_ldc + nn + e] = v;
         }
       }
     }
@@ -423,6 +498,21 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
   out[m * ldc + n] = v;
 }
 
+// the same for the class-major data gradient: slab rows are class-major (with padding rows), out rows are voxels
+__global__ void __launch_bounds__(256) splitk_reduce_cls_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                                long M, int N, int S, long ldc, ConvGeomB g) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= M * N) return;
+  const long m = gid / N;
+  const int n = (int)(gid % N);
+  long bb;
+  int xo, yo, zo, cc;
+  if (!occf_cls_row(g, m, bb, xo, yo, zo, cc)) return;
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += slab[(long)s * M * N + gid];
+  out[(((bb * g.Xo + xo) * g.Yo + yo) * g.Zo + zo) * ldc + n] = v;
+}
+
 static int occf_pick_ksplit(long M, int N, int K, bool wide, long workspace_floats) {
   const long tiles = (long)occf_cdiv(M, GB_BM) * occf_cdiv(N, wide ? 128 : 64);
   const int nk = K / GB_BK;
@@ -456,7 +546,7 @@ static int occf_pick_ksplit(long M, int N, int K, bool wide, long workspace_floa
   return S < 2 ? 1 : S;
 }
 
-template <bool CONV>
+template <int CONV>
 static int launch_gemm_b(GemmArgsB a, int terms, float* workspace, long workspace_floats, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % GB_BK != 0) return OCCF_ESHAPE;
   if (terms != 1 && terms != 3) return OCCF_EINVAL;
@@ -467,7 +557,9 @@ static int launch_gemm_b(GemmArgsB a, int terms, float* workspace, long workspac
     return e ? atoi(e) : 0;
   }();
   const bool wide = bn_env == 64 ? false : bn_env == 128 ? true : ((a.N % 128 == 0) || a.N > 512);
-  a.ksplit = (workspace && a.hm_dh == 0 && !a.gn_partial) ? occf_pick_ksplit(a.M, a.N, a.K, wide, workspace_floats) : 1;
+  // (class-major data gradient: the longest tiles walk k_max of the K taps-times-channels)
+  const int k_pick = CONV == 2 ? a.g.Cin * a.g.cls : a.K;
+  a.ksplit = (workspace && a.hm_dh == 0 && !a.gn_partial) ? occf_pick_ksplit(a.M, a.N, k_pick, wide, workspace_floats) : 1;
   if (a.gn_partial && (a.N % 4 || a.ldc % 4)) return OCCF_ESHAPE;
   a.slab = workspace;
   const dim3 grid((unsigned)((long)mt * occf_cdiv(a.N, wide ? 128 : 64)), a.ksplit);
@@ -499,7 +591,11 @@ static int launch_gemm_b(GemmArgsB a, int terms, float* workspace, long workspac
     else OCCF_GB_LAUNCH(64, 1);
   }
 #undef OCCF_GB_LAUNCH
-  if (a.ksplit > 1) {
+  if (a.ksplit > 1 && CONV == 2) {
+    const long total = (long)a.M * a.N;
+    hipLaunchKernelGGL(splitk_reduce_cls_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, a.slab, a.C, (long)a.M,
+                       a.N, a.ksplit, a.ldc, a.g);
+  } else if (a.ksplit > 1) {
     const long total = (long)a.M * a.N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, a.slab, a.bias,
                        a.residual, a.C, (long)a.M, a.N, a.ksplit, a.ldc, a.ldr, a.act);
@@ -528,7 +624,7 @@ extern "C" int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const 
   a.M = (int)M; a.N = N; a.K = K; a.lda = ldx; a.ldc = out_head_dim > 0 ? 4 : ldo; a.ldr = ldr; a.act = act;
   a.hm_dh = out_head_dim > 0 ? out_head_dim : 0; a.hm_rows = out_head_rows;
   a.gn_partial = gn_partial;
-  return launch_gemm_b<false>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
+  return launch_gemm_b<0>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
 }
 
 extern "C" int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
@@ -552,7 +648,7 @@ extern "C" int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const 
   a.A = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.C = out;
   a.M = (int)M; a.N = Cout; a.K = kX * kY * kZ * Cin; a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.act = act;
   a.gn_partial = gn_partial;
-  return launch_gemm_b<true>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
+  return launch_gemm_b<1>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
 }
 
 // Data gradient of occf_conv3d_bf16_fwd: dx[B, Xi, Yi, Zi, Cin] = sum over taps / output channels of
@@ -579,7 +675,25 @@ extern "C" int occf_conv3d_bf16_dgrad(const float* dy, const uint16_t* wt_hi, co
   if (M >= 2147483647L) return OCCF_ESHAPE;
   a.A = dy; a.Wh = wt_hi; a.Wl = wt_lo; a.C = dx;
   a.M = (int)M; a.N = Cin; a.K = kX * kY * kZ * Cout; a.lda = 0; a.ldc = Cin; a.ldr = Cin; a.act = 0;
-  return launch_gemm_b<true>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
+  static const int cls_env = [] {
+    const char* e = getenv("OCCF_DGRAD_CLASSES");
+    return e ? atoi(e) : 1;
+  }();
+  if (cls_env && stride > 1 && Xi % stride == 0 && Yi % stride == 0 && Zi % stride == 0 && kX * kY * kZ <= 64) {
+    // g.cls = the largest number of taps a class reaches (per axis: ceil(k / (stride / gcd(stride, dil))))
+    auto gcd = [](int x, int y) { while (y) { const int t = x % y; x = y; y = t; } return x; };
+    const int step = stride / gcd(stride, dil);
+    g.cls = ((kX + step - 1) / step) * ((kY + step - 1) / step) * ((kZ + step - 1) / step);
+    const long per = (long)(Xi / stride) * (Yi / stride) * (Zi / stride);
+    g.per_pad = (int)((per + GB_BM - 1) / GB_BM * GB_BM);
+    const long Mp = (long)B * stride * stride * stride * g.per_pad;
+    if (Mp < 2147483647L) {
+      a.M = (int)Mp;
+      return launch_gemm_b<2>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
+    }
+    g.cls = 0;
+  }
+  return launch_gemm_b<1>(a, terms, workspace, workspace_floats, (hipStream_t)stream);
 }
 
 // fp32 -> (hi, lo) bf16 split of a whole array (weights once per version; the mask features once

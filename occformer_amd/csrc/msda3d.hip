@@ -398,7 +398,11 @@ __global__ void __launch_bounds__(256) msda_absmax_kernel(const float* __restric
     m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax((int*)out, (int)occf_f2u(m));       // non-negative floats order like ints
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  // one atomic per workgroup (non-negative floats order like ints): 2 048 same-address atomics cost 40 us
+  if (threadIdx.x == 0) atomicMax((int*)out, (int)occf_f2u(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
 
 __global__ void msda_zero_word_kernel(unsigned* p) { p[0] = 0u; }
@@ -419,10 +423,10 @@ __device__ __forceinline__ unsigned long long msda_fx(float x) {
   return (unsigned long long)(((long long)(int)hi << 20) + (long long)(int)lo);
 }
 
-// workgroup = 1024 threads (16 waves: the tile takes most of the CU's LDS, so the waves that hide the VALU work
-// behind the LDS atomics have to come from ONE workgroup); work item = (query, sampling point), `lpg` lanes each
-// (3 channels per lane).  Items are walked with a large odd stride so that the lanes of one wave instruction
-// belong to queries far apart (neighbouring queries hit the same cells: same-address atomics serialise).
+// workgroup = up to 1024 threads (16 waves: the tile takes most of the CU's LDS, so the waves that hide the VALU
+// work behind the LDS atomics have to come from ONE workgroup; 256 threads: 8.0 ms per call, 512: 5.5, 1024: 4.5);
+// work item = query, `lpg` lanes each (3 channels per lane).  Items are walked with a large odd stride so that the
+// lanes of one wave instruction belong to queries far apart (no measurable effect at these sizes; kept).
 #define MSDA_TILE_THREADS 1024
 __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kernel(
     const float* __restrict__ offs, const float* __restrict__ logits, const float* __restrict__ dout,
@@ -484,11 +488,9 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
   const int n_q = it_end > it_begin ? it_end - it_begin : 0;
   unsigned stride = 1u;                                     // coprime with n_q; j * stride stays below 2^32
   if (tc.stride > 0 && n_q > 1 && n_q < 1000000) stride = (unsigned)(((n_q % 4099) ? 4099 : 4111) % n_q);
-  const int n_units = n_q * P;
   float* dvb = dvalue + ((long)b * Nv + lv.start[ls]) * E + h * Dh + ch0 + sub * 3;
-  for (int u = slot; u < n_units; u += slots) {
-    const int k = u / n_q;
-    const int it = it_begin + (int)(((unsigned)(u - k * n_q) * stride) % (unsigned)n_q);
+  for (int u = slot; u < n_q; u += slots) {
+    const int it = it_begin + (int)(((unsigned)u * stride) % (unsigned)n_q);
     int lq = 0;
     while (lq + 1 < L && it >= cum[lq + 1]) ++lq;
     int r = it - cum[lq];
@@ -509,35 +511,37 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
     const float* of = offs + (long)(b * Nq + q) * off_ld + h * LP * 3;
     const float* gp = dout + (long)(b * Nq + q) * E + h * Dh + ch0 + sub * 3;
     const float g0 = gp[0], g1 = gp[1], g2 = gp[2];
-    const int i = ls * P + k;
-    const float lz = rz + of[i * 3 + 0] / (float)Zs;
-    const float ly = ry + of[i * 3 + 1] / (float)Ys;
-    const float lx = rx + of[i * 3 + 2] / (float)Xs;
-    const float pz = ((2.f * lz - 1.f + 1.f) * (float)Zs - 1.f) * 0.5f;
-    const float py = ((2.f * ly - 1.f + 1.f) * (float)Ys - 1.f) * 0.5f;
-    const float px = ((2.f * lx - 1.f + 1.f) * (float)Xs - 1.f) * 0.5f;
-    const float fz = floorf(pz), fy = floorf(py), fx = floorf(px);
-    const float tz = pz - fz, ty = py - fy, tx = px - fx;
-    const int iz = (int)fz, iy = (int)fy, ix = (int)fx;
-    const float a = expf(lg[i] - mx) * inv;
+    for (int k = 0; k < P; ++k) {
+      const int i = ls * P + k;
+      const float lz = rz + of[i * 3 + 0] / (float)Zs;
+      const float ly = ry + of[i * 3 + 1] / (float)Ys;
+      const float lx = rx + of[i * 3 + 2] / (float)Xs;
+      const float pz = ((2.f * lz - 1.f + 1.f) * (float)Zs - 1.f) * 0.5f;
+      const float py = ((2.f * ly - 1.f + 1.f) * (float)Ys - 1.f) * 0.5f;
+      const float px = ((2.f * lx - 1.f + 1.f) * (float)Xs - 1.f) * 0.5f;
+      const float fz = floorf(pz), fy = floorf(py), fx = floorf(px);
+      const float tz = pz - fz, ty = py - fy, tx = px - fx;
+      const int iz = (int)fz, iy = (int)fy, ix = (int)fx;
+      const float a = expf(lg[i] - mx) * inv;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int cbx = c >> 2, cby = (c >> 1) & 1, cbz = c & 1;
-      const int xx = ix + cbx, yy = iy + cby, zz = iz + cbz;
-      if ((unsigned)xx >= (unsigned)Xs || (unsigned)yy >= (unsigned)Ys || (unsigned)zz >= (unsigned)Zs) continue;
-      const float cw = a * (cbx ? tx : 1.f - tx) * (cby ? ty : 1.f - ty) * (cbz ? tz : 1.f - tz);
-      const int lx_ = xx - rx0, ly_ = yy - ry0;
-      if ((unsigned)lx_ < (unsigned)RX && (unsigned)ly_ < (unsigned)RY) {
-        unsigned long long* t = tile + ((lx_ * RY + ly_) * Zs + zz) * CH + sub * 3;
-        const float cs = cw * fx_scale;
-        atomicAdd(t + 0, msda_fx(cs * g0));
-        atomicAdd(t + 1, msda_fx(cs * g1));
-        atomicAdd(t + 2, msda_fx(cs * g2));
-      } else {
-        float* d = dvb + (((long)xx * Ys + yy) * Zs + zz) * E;
-        atomicAdd(d + 0, cw * g0);
-        atomicAdd(d + 1, cw * g1);
-        atomicAdd(d + 2, cw * g2);
+      for (int c = 0; c < 8; ++c) {
+        const int cbx = c >> 2, cby = (c >> 1) & 1, cbz = c & 1;
+        const int xx = ix + cbx, yy = iy + cby, zz = iz + cbz;
+        if ((unsigned)xx >= (unsigned)Xs || (unsigned)yy >= (unsigned)Ys || (unsigned)zz >= (unsigned)Zs) continue;
+        const float cw = a * (cbx ? tx : 1.f - tx) * (cby ? ty : 1.f - ty) * (cbz ? tz : 1.f - tz);
+        const int lx_ = xx - rx0, ly_ = yy - ry0;
+        if ((unsigned)lx_ < (unsigned)RX && (unsigned)ly_ < (unsigned)RY) {
+          unsigned long long* t = tile + ((lx_ * RY + ly_) * Zs + zz) * CH + sub * 3;
+          const float cs = cw * fx_scale;
+          atomicAdd(t + 0, msda_fx(cs * g0));
+          atomicAdd(t + 1, msda_fx(cs * g1));
+          atomicAdd(t + 2, msda_fx(cs * g2));
+        } else {
+          float* d = dvb + (((long)xx * Ys + yy) * Zs + zz) * E;
+          atomicAdd(d + 0, cw * g0);
+          atomicAdd(d + 1, cw * g1);
+          atomicAdd(d + 2, cw * g2);
+        }
       }
     }
   }
@@ -718,7 +722,20 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
         }
 #endif
         const dim3 grid((unsigned)(tc.tiles_x * tc.tiles_y * tc.groups * tc.passes), heads, B);
-        hipLaunchKernelGGL(msda3d_bwd_value_tile_kernel, grid, dim3(tile_threads), lds, st, sampling_offsets, attn_logits, dout,
+        // threads: as many as the tile's queries fill evenly (level-0 tiles hold ~600 queries x lpg lanes)
+        int threads = tile_threads;
+        if (tc.groups == 1) {
+          long items = 0;
+          for (int lq = 0; lq < num_levels; ++lq) {
+            const long nx = occf_cdiv((long)tc.T * lv.X[lq], lv.X[l]) + 1, ny = occf_cdiv((long)tc.T * lv.Y[lq], lv.Y[l]) + 1;
+            items += (nx < lv.X[lq] ? nx : lv.X[lq]) * (ny < lv.Y[lq] ? ny : lv.Y[lq]) * lv.Z[lq];
+          }
+          const long lanes = items * tc.lpg;
+          const long rounds = occf_cdiv(lanes, tile_threads);
+          const long t = occf_cdiv(occf_cdiv(lanes, rounds), 64) * 64;
+          threads = (int)(t < 64 ? 64 : (t > tile_threads ? tile_threads : t));
+        }
+        hipLaunchKernelGGL(msda3d_bwd_value_tile_kernel, grid, dim3(threads), lds, st, sampling_offsets, attn_logits, dout,
                            dvalue, workspace, absmax, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
         const long total = (long)B * heads * lv.X[l] * lv.Y[l] * lv.Z[l] * head_dim;
         hipLaunchKernelGGL(msda3d_bwd_value_gather_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, workspace,

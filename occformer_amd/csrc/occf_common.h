@@ -142,4 +142,11 @@ __device__ __forceinline__ unsigned occf_xcd_remap(unsigned bid, unsigned nwg) {
 // clamp an index into [0, hi]: the unconditional-load idiom (read a valid address, mask afterwards)
 __device__ __forceinline__ int occf_clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
+// channel groups of the point-sampling kernels: enough threads (>= ~256 K) to hide the dependent gathers
+static inline int occf_sample_cgroups(int N, int C, long P) {
+  const long np = (long)N * P;
+  long g = np > 0 ? (262144 + np - 1) / np : 1;
+  return (int)(g < 1 ? 1 : (g > C ? C : g));
+}
+
 #define OCCF_LAUNCH_CHECK() return (int)hipGetLastError()

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from occformer_amd.ops import get_ops
 ops = get_ops()
 g = torch.Generator().manual_seed(0)
-what = sys.argv[1:] or ["wgrad", "window", "msda"]
+what = sys.argv[1:] or ["wgrad", "window", "msda", "dgrad"]
 
 def timeit(name, fn, n=5):
     for _ in range(2):
@@ -46,3 +46,13 @@ if "msda" in what:
     dout = torch.randn(1, Nq, 192, generator=g).cuda()
     timeit("msda3d_backward 91250 queries, 8 heads x 24",
            lambda: ops.msda3d_backward(value, offs, lg, dout, shapes, 8, 4))
+
+if "dgrad" in what:
+    import torch.nn.functional as F
+    for (dims, Cin, Cout) in (((200, 200, 16), 128, 256), ((100, 100, 8), 256, 512), ((50, 50, 4), 512, 1024)):
+        w = torch.randn(Cout, Cin, 3, 3, 3, generator=g) * 0.02
+        wt = w.permute(1, 2, 3, 4, 0).reshape(Cin, -1).contiguous().cuda()
+        sp = ops.split_bf16(wt)
+        dy = torch.randn(1, dims[0] // 2, dims[1] // 2, dims[2] // 2, Cout, generator=g).cuda()
+        timeit(f"conv3d_dgrad 3^3 stride 2 {Cin}->{Cout} input {dims}",
+               lambda: ops.conv3d_dgrad(dy, sp, (1, *dims, Cin), (3, 3, 3), 2, 1))

@@ -174,6 +174,8 @@ CONV_CASES = [
     (1, (12, 11, 1), 32, 32, (3, 3, 1), 1, 3),
     (1, (8, 6, 4), 64, 128, (1, 1, 1), 2, 1),
     (1, (7, 9, 8), 192, 64, (3, 3, 3), 1, 1),
+    # 256 rows per parity class: the 128-row tiles of the strided data gradient skip the taps their class cannot reach
+    (1, (16, 16, 8), 32, 32, (3, 3, 3), 2, 1),
 ]
 
 
