@@ -412,7 +412,7 @@ def main():
         "stages_ms": stages, "peak_memory_GiB": round(mem_gb, 2),
     }
     if train:
-        out["losses"] = {k: round(float(v), 5) for k, v in res_gpu.items()}
+        out["losses"] = {k: round(float(v.detach()), 5) for k, v in res_gpu.items()}
         out["forward_samples_per_s_same_run"] = other
     if world == 1 and not args.no_cpu_baseline:
         if train:

@@ -40,9 +40,11 @@ class Linear(torch.autograd.Function):
     bf16 split and transpose."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, residual, rows=None):
+    def forward(ctx, x, weight, bias, act, residual, rows=None, head_major=None):
         """``rows = (lo, hi)``: use weight[lo:hi] / bias[lo:hi] (the q / k / v blocks of nn.MultiheadAttention's
-        in_proj_weight); the gradients come back full-size, zero outside the block"""
+        in_proj_weight); the gradients come back full-size, zero outside the block.
+        ``head_major = (rows per batch, head_dim)``: x [B, rows, K] -> y [B, N / head_dim, rows, head_dim] written by
+        the GEMM epilogue (the layout the deformable-attention sampler gathers from)"""
         assert not (act and residual is not None) and act in (0, 1)
         ops = get_ops()
         w2 = _w2d(weight.detach())
@@ -52,9 +54,14 @@ class Linear(torch.autograd.Function):
             lo, hi = rows
             w2, b = w2[lo:hi], (None if b is None else b[lo:hi])
             sp = None if sp is None else (sp[0][lo:hi], sp[1][lo:hi])
-        y = ops.linear(x, w2, b, act, None if residual is None else residual.detach(), w_split=sp, allow_small=True)
+        if head_major is not None:
+            assert not act and residual is None and rows is None
+            y = ops.linear(x, w2, b, 0, None, w_split=sp, head_major=head_major)
+        else:
+            y = ops.linear(x, w2, b, act, None if residual is None else residual.detach(), w_split=sp, allow_small=True)
         ctx.save_for_backward(x, weight, y if act else None)
         ctx.has_bias, ctx.has_res, ctx.act, ctx.rows = bias is not None, residual is not None, act, rows
+        ctx.hm = head_major is not None
         return y
 
     @staticmethod
@@ -64,7 +71,8 @@ class Linear(torch.autograd.Function):
         Nfull, K = weight.shape[0], weight.numel() // weight.shape[0]
         lo, hi = ctx.rows if ctx.rows is not None else (0, Nfull)
         N = hi - lo
-        g = dy.contiguous()
+        # head-major output: the gradient [B, heads, rows, dh] is normally the permuted view of a token-major tensor
+        g = dy.permute(0, 2, 1, 3).contiguous() if ctx.hm else dy.contiguous()
         if ctx.act:
             g = ops.act_backward(y, g, 1)
         g2, x2 = g.reshape(-1, N), x.reshape(-1, K)
@@ -86,7 +94,7 @@ class Linear(torch.autograd.Function):
                     fb[lo:hi] = db
                     db = fb
             dw = dw.view(weight.shape)
-        return dx, dw, db, None, (dy if ctx.has_res else None), None
+        return dx, dw, db, None, (dy if ctx.has_res else None), None, None
 
 
 def linear(x, lin, act=0, residual=None):
@@ -279,21 +287,25 @@ class MSDA(torch.autograd.Function):
     """sampling core; ``ol`` = the fused offset / logit projection output [B, Nq, n_off + n_logits]"""
 
     @staticmethod
-    def forward(ctx, value, ol, n_off, shapes, heads, points):
+    def forward(ctx, value, ol, n_off, shapes, heads, points, head_major=False):
+        """value [B, Nq, E], or head-major [B, heads, Nq, E / heads] (gathers of one head are contiguous rows)"""
         ops = get_ops()
         value, ol = value.contiguous(), ol.contiguous()
         ctx.save_for_backward(value, ol)
-        ctx.cfg = (n_off, tuple(shapes), heads, points)
-        return ops.msda3d(value, ol[..., :n_off], ol[..., n_off:], shapes, heads, points, head_major=False)
+        ctx.cfg = (n_off, tuple(shapes), heads, points, bool(head_major))
+        return ops.msda3d(value, ol[..., :n_off], ol[..., n_off:], shapes, heads, points, head_major=bool(head_major))
 
     @staticmethod
     def backward(ctx, dout):
         value, ol = ctx.saved_tensors
-        n_off, shapes, heads, points = ctx.cfg
+        n_off, shapes, heads, points, hm = ctx.cfg
         d_ol = torch.empty_like(ol)
         dvalue, _, _ = get_ops().msda3d_backward(value, ol[..., :n_off], ol[..., n_off:], dout.contiguous(), shapes,
-                                                 heads, points, head_major=False, d_ol=d_ol, n_off=n_off)
-        return dvalue, d_ol, None, None, None, None
+                                                 heads, points, head_major=hm, d_ol=d_ol, n_off=n_off)
+        if hm:                                        # token-major [B, Nq, E] seen in the input's layout
+            B, Nq, E = dvalue.shape
+            dvalue = dvalue.view(B, Nq, heads, E // heads).permute(0, 2, 1, 3)
+        return dvalue, d_ol, None, None, None, None, None
 
 
 class UpsampleAdd(torch.autograd.Function):
@@ -393,6 +405,55 @@ class DeformConv(torch.autograd.Function):
             dws.append(dw2.view(og, K, K, cpg).permute(0, 3, 1, 2))
         dx, doff = ops.deform_col2im(x_cl, offset, dcol, K, 1, pad, 1, groups, dgroups)
         return dx, doff, torch.cat(dws, 0).contiguous(), None, None, None, None
+
+
+class SampledMaskLogitsJoint(torch.autograd.Function):
+    """``SampledMaskLogits`` for ALL prediction sets of one image at once (the ten sets share the mask features).
+    One prediction set at a time, the backward wrote a dense [V, E] mask-feature gradient per set (491 MB at the
+    200-grid), autograd summed the ten of them (nine more read-modify-write passes) and every set re-read the mask
+    features for its mask_embed gradient: ~10 ms per training step.  Joined, the matched rows of all sets are columns
+    of ONE voxel-major [V, cols] scatter buffer and the two contractions run once.
+
+    apply(feat_tok [V, E], align_corners, padding_mode, k, vol_rows_0..k-1 [n_i, X, Y, Z] (detached logits),
+          embed_rows_0..k-1 [n_i, E], pts_0..k-1 [n_i, P, 3]) -> k tensors [n_i, P]"""
+
+    @staticmethod
+    def forward(ctx, feat_tok, align_corners, padding_mode, k, *args):
+        vols, embeds = args[:k], args[k:2 * k]
+        pts = [p.contiguous() for p in args[2 * k:3 * k]]
+        ctx.save_for_backward(feat_tok, *embeds, *pts)
+        ctx.cfg = ([tuple(v.shape) for v in vols], align_corners, padding_mode, k)
+        ops = get_ops()
+        return tuple(ops.point_sample_3d(v.unsqueeze(1).contiguous(), p, align_corners, padding_mode)[:, 0]
+                     for v, p in zip(vols, pts))
+
+    @staticmethod
+    def backward(ctx, *douts):
+        shapes, align, mode, k = ctx.cfg
+        saved = ctx.saved_tensors
+        feat_tok, embeds, pts = saved[0], saved[1:1 + k], saved[1 + k:1 + 2 * k]
+        ops = get_ops()
+        cols, c = [], 0
+        for shp in shapes:
+            cols.append(c)
+            c += (shp[0] + 3) // 4 * 4
+        total = max(32, (c + 31) // 32 * 32)
+        X, Y, Z = shapes[0][1:]
+        dmt = torch.zeros((X * Y * Z, total), dtype=feat_tok.dtype, device=feat_tok.device)
+        for i in range(k):
+            if douts[i] is not None:
+                ops.point_sample_3d_backward(douts[i].contiguous().unsqueeze(1), pts[i], (shapes[i][0], 1, X, Y, Z), align,
+                                             mode, voxel_major_cols=total, out=dmt, col0=cols[i])
+        d_feat, d_embeds = None, [None] * k
+        if any(ctx.needs_input_grad[4 + k:4 + 2 * k]):
+            d_all = ops.linear_wgrad(dmt, feat_tok.contiguous(), want_bias=False)[0]                 # [total, E]
+            d_embeds = [d_all[cols[i]:cols[i] + shapes[i][0]].contiguous() for i in range(k)]
+        if ctx.needs_input_grad[0]:
+            et = torch.zeros((feat_tok.shape[1], total), dtype=feat_tok.dtype, device=feat_tok.device)
+            for i in range(k):
+                et[:, cols[i]:cols[i] + shapes[i][0]] = embeds[i].detach().t()
+            d_feat = ops.linear(dmt, et, None, allow_small=False)                                    # [V, E]
+        return (d_feat, None, None, None) + (None,) * k + tuple(d_embeds) + (None,) * k
 
 
 class SampledMaskLogits(torch.autograd.Function):

@@ -618,13 +618,23 @@ class HipOps:
         return dc
 
     def point_sample_3d_backward(self, dout, pts, vol_shape, align_corners=False, padding_mode="zeros",
-                                 voxel_major_cols=0):
+                                 voxel_major_cols=0, out=None, col0=0):
         """-> dvol [N, C, X, Y, Z], or with ``voxel_major_cols`` = ld > 0 the voxel-major [X*Y*Z, ld] (column n*C+c,
-        the columns beyond N*C stay zero)"""
+        the columns beyond N*C stay zero).  ``out`` (voxel-major only): accumulate into columns col0 + n*C + c of an
+        existing zero-initialised [X*Y*Z, ld] buffer (several calls share one buffer)."""
         N, C, X, Y, Z = vol_shape
         P = pts.shape[1]
         shared = pts.shape[0] == 1 and N > 1
         shape = (X * Y * Z, int(voxel_major_cols)) if voxel_major_cols else tuple(vol_shape)
+        if out is not None:
+            if not voxel_major_cols or tuple(out.shape) != shape or col0 < 0 or col0 + N * C > voxel_major_cols:
+                raise OccfError("point_sample_3d_backward: out must be the voxel-major [X*Y*Z, ld] buffer")
+            self._ptr(out, self.f32)
+            dvol = out
+            self._call("occf_point_sample_3d_bwd", self._ptr(dout, self.f32), self._ptr(pts, self.f32),
+                       ctypes.c_void_p(out.data_ptr() + 4 * int(col0)), N, C, X, Y, Z, P, int(shared),
+                       int(align_corners), int(padding_mode == "border"), int(voxel_major_cols), self._stream())
+            return dvol
         dvol = torch.zeros(shape, dtype=self.f32, device=dout.device)
         self._call("occf_point_sample_3d_bwd", self._ptr(dout, self.f32), self._ptr(pts, self.f32), self._ptr(dvol),
                    N, C, X, Y, Z, P, int(shared), int(align_corners), int(padding_mode == "border"),

@@ -140,9 +140,15 @@ class MultiScaleDeformableAttention3D(nn.Module):
             raise NotImplementedError("MultiScaleDeformableAttention3D dropout > 0 (every OccFormer config uses 0.0)")
         qp = query + query_pos
         ol = torch.cat((A.linear(qp, self.sampling_offsets), A.linear(qp, self.attention_weights)), -1)
-        value = A.linear(query, self.value_proj)
+        B, Nq, E = query.shape
+        dh = E // self.num_heads
+        hm = get_ops().head_major_supported(B * Nq, E, E, dh)
+        if hm:      # the value projection writes the head-major layout the sampler (forward and backward) gathers from
+            value = A.Linear.apply(query, self.value_proj.weight, self.value_proj.bias, 0, None, None, (Nq, dh))
+        else:
+            value = A.linear(query, self.value_proj)
         out = A.MSDA.apply(value, ol, self.sampling_offsets.out_features, tuple(level_shapes), self.num_heads,
-                           self.num_points)
+                           self.num_points, hm)
         return A.linear(out, self.output_proj, residual=query)
 
 

@@ -71,13 +71,19 @@ class LazyMask:
         return self.dense.shape
 
     def __getitem__(self, b):
-        return LazyMask(self.dense[b], self.embed[b], self.feat_tok[b])
+        return LazyMask(self.dense[b], self.embed[b], _image(self.feat_tok, b))
 
     def rows(self, idx_per_image):
         """matched rows: idx_per_image[b] = query indices of image b (ascending) -> LazyRows"""
         return LazyRows([self.dense[b][i] for b, i in enumerate(idx_per_image)],
                         [self.embed[b][i] for b, i in enumerate(idx_per_image)],
-                        [self.feat_tok[b] for b in range(len(idx_per_image))])
+                        [_image(self.feat_tok, b) for b in range(len(idx_per_image))])
+
+
+def _image(t, b):
+    """t[b]; for a batch of one as a free view (the backward of an index select writes a zero-filled copy of the whole
+    [B, V, E] mask-feature gradient: 491 MB per prediction set at the 200-grid)"""
+    return t.squeeze(0) if t.shape[0] == 1 else t[b]
 
 
 class LazyRows:
@@ -114,6 +120,48 @@ def sample_logits(mp, coords, align_corners=False, padding_mode="zeros"):
     if mp.requires_grad and torch.is_grad_enabled():
         return A.PointSample3d.apply(mp.unsqueeze(1), coords, align_corners, padding_mode).squeeze(1)
     return point_sample_3d(mp.unsqueeze(1), coords, align_corners, padding_mode).squeeze(1)
+
+
+def sample_logits_sets(sets, align_corners=False, padding_mode="zeros"):
+    """``sample_logits`` for several prediction sets at once: sets = [(mp_i, coords_i)].  Lazy rows of sets that share
+    their mask features (the ten prediction sets of a training step) go through ONE
+    ``autograd.SampledMaskLogitsJoint`` per image, so the mask-feature gradient is contracted once instead of once
+    per set."""
+    lazy = [i for i, (mp, _) in enumerate(sets) if isinstance(mp, LazyRows)]
+    out = [None] * len(sets)
+    for i, (mp, coords) in enumerate(sets):
+        if i not in lazy:
+            out[i] = sample_logits(mp, coords, align_corners, padding_mode)
+    if not lazy or not torch.is_grad_enabled():
+        for i in lazy:
+            out[i] = sets[i][0].sample(sets[i][1], align_corners, padding_mode)
+        return out
+    n_img = len(sets[lazy[0]][0].feat_list)
+    parts = {i: [] for i in lazy}
+    offs = {i: 0 for i in lazy}
+    for b in range(n_img):
+        feat = sets[lazy[0]][0].feat_list[b]
+        members, vols, embeds, pts = [], [], [], []
+        for i in lazy:
+            mp, coords = sets[i]
+            n = mp.dense_list[b].shape[0]
+            if n == 0:
+                continue
+            f = mp.feat_list[b]
+            if f.data_ptr() != feat.data_ptr() or f.shape != feat.shape:
+                raise ValueError("sample_logits_sets: the prediction sets must share their mask features")
+            members.append(i)
+            vols.append(mp.dense_list[b])
+            embeds.append(mp.embed_list[b])
+            pts.append(coords[offs[i]:offs[i] + n])
+            offs[i] += n
+        if members:
+            res = A.SampledMaskLogitsJoint.apply(feat, align_corners, padding_mode, len(members), *vols, *embeds, *pts)
+            for i, r in zip(members, res):
+                parts[i].append(r)
+    for i in lazy:
+        out[i] = torch.cat(parts[i], 0) if len(parts[i]) != 1 else parts[i][0]
+    return out
 
 
 # ------------------------------------------------------------------------------------------ helpers
@@ -412,7 +460,18 @@ class OccHeadTrainingMixin:
         gt = list(gt)
         gt[1] = [m.float() for m in gt[1]]
         self._raise_if_infeasible()
-        per = [self.loss_single(c, m, *gt) for c, m in zip(all_cls_scores, all_mask_preds)]
+        # per set: targets, point coordinates and point targets (no gradient; the noise draws keep the order of the
+        # reference's sequential loss_single calls); then the point logits of ALL sets in one joint sampling call;
+        # then the loss arithmetic per set
+        preps = [self._loss_prepare(c, m, *gt) for c, m in zip(all_cls_scores, all_mask_preds)]
+        live = [i for i, p in enumerate(preps) if p["coords"] is not None]
+        pps = sample_logits_sets([(preps[i]["mp"], preps[i]["coords"]) for i in live], *self._sample_mode())
+        per = [None] * len(preps)
+        for i, pp in zip(live, pps):
+            per[i] = self._loss_finish(preps[i], pp)
+        for i, p in enumerate(preps):
+            if per[i] is None:
+                per[i] = self._loss_finish(p, None)
         self._post_infeasible_flag()
         out = {"loss_cls": per[-1][0], "loss_mask": per[-1][1], "loss_dice": per[-1][2]}
         for i, (a, b, c) in enumerate(per[:-1]):
@@ -486,15 +545,17 @@ class NuscTrainingMixin(OccHeadTrainingMixin):
         gt_inds, cost = self.assigner.assign(cls_score, pred_pts, gt_labels, gt_pts, img_metas)
         return self._targets_from_assignment(gt_inds, cls_score, mask_pred, gt_labels, gt_masks) + (cost,)
 
-    def loss_single(self, cls_scores, mask_preds, gt_labels_list, gt_masks_list, gt_lidarseg_list, img_metas=None):
-        """mask2former_nusc_occ.py:317-424"""
+    def _sample_mode(self):
+        return False, self.padding_mode
+
+    def _loss_prepare(self, cls_scores, mask_preds, gt_labels_list, gt_masks_list, gt_lidarseg_list, img_metas=None):
+        """mask2former_nusc_occ.py:317-400: targets, classification loss, point coordinates, point targets"""
         with torch.no_grad():
             targets = [self._get_target_single(cls_scores[i], mask_preds[i], gt_labels_list[i], gt_masks_list[i],
                                                gt_lidarseg_list[i]) for i in range(cls_scores.shape[0])]
         loss_cls, mp, mw, mask_targets = self._cls_and_select(cls_scores, mask_preds, targets)
         if mask_targets.shape[0] == 0:
-            z = cls_scores.sum() * 0
-            return loss_cls, z, z
+            return dict(loss_cls=loss_cls, coords=None, zero=cls_scores.sum() * 0)
         with torch.no_grad():
             mpd = _dense(mp)
             coords = get_nusc_lidarseg_point_coords(mpd.unsqueeze(1), gt_lidarseg_list, gt_labels_list, self.num_points,
@@ -502,10 +563,21 @@ class NuscTrainingMixin(OccHeadTrainingMixin):
                                                     self.point_cloud_range, self._rng(mpd.device),
                                                     padding_mode=self.padding_mode)[..., [2, 1, 0]].contiguous()
             pt = point_sample_3d(mask_targets.unsqueeze(1).float(), coords, padding_mode=self.padding_mode).squeeze(1)
-        pp = sample_logits(mp, coords, False, self.padding_mode)
-        loss_mask, loss_dice = point_mask_losses(pp, pt, mw, self.num_points, self.dice_eps, self.w_mask,
+        return dict(loss_cls=loss_cls, mp=mp, mw=mw, coords=coords, pt=pt)
+
+    def _loss_finish(self, prep, pp):
+        """mask2former_nusc_occ.py:400-424"""
+        if prep["coords"] is None:
+            return prep["loss_cls"], prep["zero"], prep["zero"]
+        loss_mask, loss_dice = point_mask_losses(pp, prep["pt"], prep["mw"], self.num_points, self.dice_eps, self.w_mask,
                                                  self.w_dice, weight_bce_rows=False)
-        return loss_cls, loss_mask, loss_dice
+        return prep["loss_cls"], loss_mask, loss_dice
+
+    def loss_single(self, cls_scores, mask_preds, gt_labels_list, gt_masks_list, gt_lidarseg_list, img_metas=None):
+        """mask2former_nusc_occ.py:317-424"""
+        prep = self._loss_prepare(cls_scores, mask_preds, gt_labels_list, gt_masks_list, gt_lidarseg_list, img_metas)
+        pp = None if prep["coords"] is None else sample_logits(prep["mp"], prep["coords"], *self._sample_mode())
+        return self._loss_finish(prep, pp)
 
     def lidarseg_metric(self, cls_preds, mask_preds, points, img_metas):
         """training branch of forward_lidarseg (mask2former_nusc_occ.py:526-540): point mIoU, no gradient"""
@@ -547,25 +619,38 @@ class KittiTrainingMixin(OccHeadTrainingMixin):
         gt_inds, cost = self.assigner.assign(cls_score, pred_pts, gt_labels, gt_pts, img_metas)
         return self._targets_from_assignment(gt_inds, cls_score, mask_pred, gt_labels, gt_masks) + (cost,)
 
-    def loss_single(self, cls_scores, mask_preds, gt_labels_list, gt_masks_list, img_metas=None):
-        """mask2former_occ.py:343-444"""
+    def _sample_mode(self):
+        return self.align_corners, "zeros"
+
+    def _loss_prepare(self, cls_scores, mask_preds, gt_labels_list, gt_masks_list, img_metas=None):
+        """mask2former_occ.py:343-420: targets, classification loss, point coordinates, point targets"""
         with torch.no_grad():
             targets = [self._get_target_single(cls_scores[i], mask_preds[i], gt_labels_list[i], gt_masks_list[i])
                        for i in range(cls_scores.shape[0])]
         loss_cls, mp, mw, mask_targets = self._cls_and_select(cls_scores, mask_preds, targets)
         if mask_targets.shape[0] == 0:
-            z = cls_scores.sum() * 0
-            return loss_cls, z, z
+            return dict(loss_cls=loss_cls, coords=None, zero=cls_scores.sum() * 0)
         with torch.no_grad():
             mpd = _dense(mp)
             idx, coords = get_uncertain_point_coords_3d_with_frequency(
                 mpd.unsqueeze(1), None, gt_labels_list, gt_masks_list, self.sample_weights, self.num_points,
                 self.oversample_ratio, self.importance_sample_ratio, self._rng(mpd.device))
             pt = torch.gather(mask_targets.reshape(mask_targets.shape[0], -1), 1, idx).float()
-        pp = sample_logits(mp, coords[..., [2, 1, 0]].contiguous(), self.align_corners, "zeros")
-        loss_mask, loss_dice = point_mask_losses(pp, pt, mw, self.num_points, self.dice_eps, self.w_mask,
+        return dict(loss_cls=loss_cls, mp=mp, mw=mw, coords=coords[..., [2, 1, 0]].contiguous(), pt=pt)
+
+    def _loss_finish(self, prep, pp):
+        """mask2former_occ.py:420-444"""
+        if prep["coords"] is None:
+            return prep["loss_cls"], prep["zero"], prep["zero"]
+        loss_mask, loss_dice = point_mask_losses(pp, prep["pt"], prep["mw"], self.num_points, self.dice_eps, self.w_mask,
                                                  self.w_dice, weight_bce_rows=True)
-        return loss_cls, loss_mask, loss_dice
+        return prep["loss_cls"], loss_mask, loss_dice
+
+    def loss_single(self, cls_scores, mask_preds, gt_labels_list, gt_masks_list, img_metas=None):
+        """mask2former_occ.py:343-444"""
+        prep = self._loss_prepare(cls_scores, mask_preds, gt_labels_list, gt_masks_list, img_metas)
+        pp = None if prep["coords"] is None else sample_logits(prep["mp"], prep["coords"], *self._sample_mode())
+        return self._loss_finish(prep, pp)
 
     def forward_train(self, voxel_feats, img_metas, gt_occ, **kwargs):
         """mask2former_occ.py:525-567"""

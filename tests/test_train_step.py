@@ -78,7 +78,7 @@ def test_training_step_gradients_vs_oracle(bound):
                                  points_occ=[p.to(d) for p in pts])
     assert replay.i == len(rec.tape), "the product consumed a different number of noise draws than the oracle"
     for k, v in ref_losses.items():
-        assert abs(float(losses[k]) - float(v)) <= TOL * max(1.0, abs(float(v))), (k, float(losses[k]), float(v))
+        assert abs(float(losses[k].detach()) - float(v)) <= TOL * max(1.0, abs(float(v))), (k, float(losses[k].detach()), float(v))
     total = sum(v for k, v in losses.items() if k.startswith(("loss", "d")) and "iou" not in k)
     total.backward()
     worst = []
