@@ -299,6 +299,15 @@ int occf_modulated_deform_im2col(const float* x, const float* offset, const floa
 int occf_point_sample_3d_fwd(const float* vol, const float* pts, float* out, int N, int C, int X, int Y, int Z,
                              long P, int shared_pts, int align_corners, int border_padding, void* stream);
 
+/* The same sampling on a CHANNELS-LAST volume: tok[X*Y*Z, C] (row stride ld >= C, C % 4 == 0), pts[P, 3] ->
+ * out[P, C].  Used for the matching cost of the training step (mask2former_nusc_occ.py:232-238,
+ * mask2former_occ.py:258-262 sample all Q query logits at the matching points): the query logits are a linear map of
+ * the mask features, einsum('qc,cxyz->qxyz') (mask2former_nusc_occ.py:455), and trilinear sampling is linear, so
+ * sampling the features (8 contiguous C-float rows per point) and contracting with mask_embed afterwards gives the
+ * same [Q, P] matrix without 8 x Q scattered 4-byte gathers per point from the [Q, X, Y, Z] logits. */
+int occf_point_sample_tokens_fwd(const float* tok, const float* pts, float* out, int X, int Y, int Z, int C, long ld,
+                                 long P, int align_corners, int border_padding, void* stream);
+
 /* Weighted sampling without replacement = torch.multinomial(weights, k, replacement=False) of the
  * class-guided sampler (mmdet_utils.py:91-136): the k largest exponential-race keys
  * weights[i] / -log(uniforms[r, i]) per row, found by radix select + wavefront compaction.

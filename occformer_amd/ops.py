@@ -489,6 +489,21 @@ class HipOps:
                    self._stream())
         return out
 
+    def point_sample_tokens(self, tok, dims, pts, align_corners=False, padding_mode="zeros"):
+        """tok [V = X*Y*Z, C] channels-last volume (unit column stride); pts [P, 3] in [0, 1] (grid_sample order)
+        -> [P, C]"""
+        X, Y, Z = dims
+        V, C = tok.shape
+        if V != X * Y * Z or tok.stride(1) != 1:
+            raise OccfError("point_sample_tokens: tok must be [X*Y*Z, C] with unit column stride")
+        P = pts.shape[0]
+        out = torch.empty((P, C), dtype=tok.dtype, device=tok.device)
+        self._ptr(pts, self.f32)
+        self._call("occf_point_sample_tokens_fwd", ctypes.c_void_p(tok.data_ptr()), self._ptr(pts, self.f32),
+                   self._ptr(out), X, Y, Z, C, tok.stride(0), P, int(align_corners), int(padding_mode == "border"),
+                   self._stream())
+        return out
+
     def sample_without_replacement(self, weights, uniforms, k, exponential=False):
         """weights [R, V] or [1, V]; uniforms [R, V] in (0, 1] (or Exp(1) draws with exponential=True)
         -> int64 indices [R, k] (unordered)."""

@@ -22,6 +22,40 @@ def test_point_sample_3d(be, align, pad):
     assert torch.allclose(out2, ref2, atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("align,pad", [(False, "border"), (True, "zeros"), (False, "zeros")])
+def test_point_sample_tokens_and_lazy_matching_logits(be, align, pad):
+    """channels-last sampling == grid_sample of the channel-major volume; and sampling the mask FEATURES then
+    contracting with mask_embed == sampling the query logits einsum('qc,cxyz->qxyz') (the matching cost of the
+    training step, mask2former_nusc_occ.py:232-238)"""
+    from occformer_amd.training import LazyMask
+    import occformer_amd.ops as ops_mod
+    X, Y, Z, E, Q, P = 6, 5, 4, 16, 7, 257
+    feat = paramgen.tensor("pst_feat", (X * Y * Z, E), 1)
+    embed = paramgen.tensor("pst_embed", (Q, E), 2)
+    pts = paramgen.uniform("pst_pts", (P, 3), 1) * 1.3 - 0.15
+    vol = feat.t().reshape(1, E, X, Y, Z)
+    ref = F.grid_sample(vol, (pts * 2 - 1).view(1, P, 1, 1, 3), mode="bilinear", padding_mode=pad,
+                        align_corners=align).view(E, P)
+    out = be.ops.point_sample_tokens(be.to(feat), (X, Y, Z), be.to(pts), align, pad).cpu()
+    assert torch.allclose(out.t(), ref, atol=2e-5, rtol=1e-4)
+    # a column slice of a wider token buffer (row stride > C)
+    wide = torch.cat((feat, feat * 2), 1).contiguous()
+    out2 = be.ops.point_sample_tokens(be.to(wide)[:, E:], (X, Y, Z), be.to(pts), align, pad).cpu()
+    assert torch.allclose(out2.t(), 2 * ref, atol=4e-5, rtol=1e-4)
+    logits = (embed @ feat.t()).view(1, Q, X, Y, Z)
+    ref_q = F.grid_sample(logits, (pts * 2 - 1).view(1, P, 1, 1, 3), mode="bilinear", padding_mode=pad,
+                          align_corners=align).view(Q, P)
+    saved = ops_mod._ops
+    ops_mod._ops = be.ops
+    try:
+        lazy = LazyMask(be.to(logits)[0], be.to(embed), be.to(feat))
+        got = lazy.sample_all(be.to(pts), align, pad).cpu()
+    finally:
+        ops_mod._ops = saved
+    assert got.shape == (Q, P)
+    assert float((got - ref_q).abs().max()) <= 1e-4 * float(ref_q.abs().max())
+
+
 @pytest.mark.parametrize("R,V,k,shared", [(3, 5000, 700, True), (2, 4096, 4096, False), (1, 300, 1, True),
                                           (4, 20000, 15000, True)])
 def test_sample_without_replacement_matches_exponential_race_topk(be, R, V, k, shared):
