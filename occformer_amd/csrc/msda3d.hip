@@ -390,8 +390,9 @@ __global__ void __launch_bounds__(256) msda3d_bwd_kernel(
 // falls back to the global atomic, so the result does not depend on the offsets being small.
 // LDS float atomics (ds_add_f32) serialise the 64 lanes on gfx950: 768 cycles per wave instruction against 30 for
 // ds_add_u32 / ds_add_u64 (scripts/lds_atomic_probe.hip).  The tiles therefore accumulate in 64-bit FIXED POINT:
-// contribution * 2^40 / max|dout| as a signed integer -- |contribution| <= max|dout|, so 2^23 of them fit, the
-// resolution is 2^-40 of the largest gradient entry, and the sum is order-independent (deterministic).
+// contribution * 2^30 / max|dout| rounded to an int32 (|contribution| <= max|dout|) and sign-extended -- 2^33 of them
+// fit, the resolution is 2^-30 of the largest gradient entry (an fp32 sum of the same terms carries 2^-24 of its own
+// magnitude), and the sum is order-independent (deterministic).
 __global__ void __launch_bounds__(256) msda_absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
   float m = 0.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -415,12 +416,10 @@ struct MsdaTileCfg {
 
 __device__ __forceinline__ int msda_cdiv_pos(long num, long den) { return num <= 0 ? 0 : (int)((num + den - 1) / den); }
 
-// signed 64-bit fixed point of x (|x| <= 2^41): rint(x) = rint(x / 2^20) * 2^20 + rint(remainder), both pieces exact
-// in fp32 and inside int32 -- a handful of VALU instructions instead of the generic float -> int64 conversion
+// signed fixed point of x (|x| <= 2^30): one rounding + one int32 conversion, sign-extended into the 64-bit
+// accumulator (the generic float -> int64 conversion is ~25 VALU instructions, three per corner)
 __device__ __forceinline__ unsigned long long msda_fx(float x) {
-  const float hi = rintf(x * 9.5367431640625e-07f);                 // 2^-20
-  const float lo = rintf(fmaf(-hi, 1048576.0f, x));
-  return (unsigned long long)(((long long)(int)hi << 20) + (long long)(int)lo);
+  return (unsigned long long)(long long)(int)rintf(x);
 }
 
 // workgroup = up to 1024 threads (16 waves: the tile takes most of the CU's LDS, so the waves that hide the VALU
@@ -436,7 +435,7 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
   unsigned long long* tile = (unsigned long long*)smem_raw;
   const int NT = blockDim.x;
   const float gmax = occf_u2f(absmax_bits[0]);
-  const float fx_scale = gmax > 0.f ? 1099511627776.0f / gmax : 1.0f;       // 2^40 / max|dout|
+  const float fx_scale = gmax > 0.f ? 1073741824.0f / gmax : 1.0f;          // 2^30 / max|dout|
   const float fx_inv = 1.0f / fx_scale;
   const int L = lv.n, LP = L * P;
   const int ls = tc.ls;

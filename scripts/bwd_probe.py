@@ -18,14 +18,15 @@ def timeit(name, fn, n=5):
     torch.cuda.synchronize()
     print(f"{name:60s} {e0.elapsed_time(e1) / n:8.3f} ms", flush=True)
 
-if "wgrad" in what:
-    for C in (128, 192):
+if "wgrad" in what or "wgrad192" in what or "wgrad128" in what:
+    for C in ((128, 192) if "wgrad" in what else (192,) if "wgrad192" in what else (128,)):
         dy = torch.randn(1, 200, 200, 16, C, generator=g).cuda()
         x = torch.randn(1, 200, 200, 16, C, generator=g).cuda()
         timeit(f"conv3d_wgrad 3^3 {C}->{C} 200x200x16", lambda: ops.conv3d_wgrad(dy, x, (3, 3, 3), 1, 1))
-    dy = torch.randn(680000, 384, generator=g).cuda()
-    x = torch.randn(680000, 128, generator=g).cuda()
-    timeit("linear_wgrad 680000 x (384, 128)", lambda: ops.linear_wgrad(dy, x))
+    if "wgrad" in what:
+        dy = torch.randn(680000, 384, generator=g).cuda()
+        x = torch.randn(680000, 128, generator=g).cuda()
+        timeit("linear_wgrad 680000 x (384, 128)", lambda: ops.linear_wgrad(dy, x))
 if "window" in what:
     B, X, Y, S, heads = 1, 200, 200, 17, 4
     C = heads * 32
@@ -56,3 +57,10 @@ if "dgrad" in what:
         dy = torch.randn(1, dims[0] // 2, dims[1] // 2, dims[2] // 2, Cout, generator=g).cuda()
         timeit(f"conv3d_dgrad 3^3 stride 2 {Cin}->{Cout} input {dims}",
                lambda: ops.conv3d_dgrad(dy, sp, (1, *dims, Cin), (3, 3, 3), 2, 1))
+
+if "conv" in what:
+    for C in (128, 192):
+        x = torch.randn(1, 200, 200, 16, C, generator=g).cuda()
+        w = (torch.randn(C, 27 * C, generator=g) * 0.02).cuda()
+        sp = ops.split_bf16(w)
+        timeit(f"conv3d 3^3 {C}->{C} 200x200x16 (halo kernel)", lambda: ops.conv3d(x, w, (3, 3, 3), 1, 1, (1, 1, 1), None, w_split=sp))

@@ -176,6 +176,10 @@ CONV_CASES = [
     (1, (7, 9, 8), 192, 64, (3, 3, 3), 1, 1),
     # 256 rows per parity class: the 128-row tiles of the strided data gradient skip the taps their class cannot reach
     (1, (16, 16, 8), 32, 32, (3, 3, 3), 2, 1),
+    # Zo = 16 / 8: the per-column staging path of the pre-split weight gradient (two batches, stride 2, dilation)
+    (2, (5, 6, 16), 32, 64, (3, 3, 3), 1, 1),
+    (1, (6, 6, 16), 64, 32, (3, 3, 3), 2, 1),
+    (1, (6, 5, 8), 32, 32, (3, 3, 3), 1, 2),
 ]
 
 
