@@ -147,7 +147,8 @@ def roofline(timed_census, kernels, prec, steps):
         B, X, Y, Z, Cin = shp[0]
         Cout = shp[1][0]
         halo = shp[1][1] == 27 * Cin and Cin % 32 == 0 and prec != "f32"
-        kname = (f"conv3x3x3_halo_kernel<{2 if Cout % 128 == 0 else 3 if Cout % 192 == 0 else 1}, {terms}>"
+        frag = "true" if get_halo_frag() else "false"
+        kname = (f"conv3x3x3_halo_kernel<{2 if Cout % 128 == 0 else 3 if Cout % 192 == 0 else 1}, {terms}, {frag}>"
                  if halo else "gemm_bf16_kernel<CONV>")
         nbytes = 4 * (B * X * Y * Z * (Cin + Cout)) + 4 * Cout * shp[1][1]
         if halo:
@@ -159,7 +160,8 @@ def roofline(timed_census, kernels, prec, steps):
     elif name == "conv3d_wgrad":
         B, X, Y, Z, Cout = shp[0]
         Cin = shp[1][-1]
-        kname = f"wgrad_kernel<{128 if Cin % 128 == 0 else 64}, {terms}>"
+        presplit = taps_hint(shp, flops) >= 9 and Cin % 8 == 0 and Cout % 8 == 0
+        kname = f"wgrad_kernel<{128 if (Cin % 128 == 0 or Cin > 128) else 64}, {terms}, {'true' if presplit else 'false'}>"
         taps = flops // max(2 * B * X * Y * Z * Cout * Cin, 1)
         nbytes = 4 * (B * X * Y * Z * Cout) + 4 * int(torch.tensor(shp[1]).prod()) + 4 * Cout * taps * Cin
     else:
@@ -169,6 +171,17 @@ def roofline(timed_census, kernels, prec, steps):
             "mfma_products_per_algorithmic_product": {"f32": 1, "bf16x3": 3, "bf16": 1}[prec],
             "avg_kernel_ms": avg_ms, "algorithmic_flops_per_launch": flops, "launches_timed": len(ms),
             "launches_per_step": len(ms) // max(steps, 1), "algorithmic_bytes_per_launch": nbytes}
+
+
+def get_halo_frag():
+    from occformer_amd.ops import get_ops
+    return bool(getattr(get_ops(), "halo_frag", False))
+
+
+def taps_hint(shp, flops):
+    B, X, Y, Z, Cout = shp[0]
+    Cin = shp[1][-1]
+    return flops // max(2 * B * X * Y * Z * Cout * Cin, 1)
 
 
 def cpu_baseline(model, meta, img_inputs, points):

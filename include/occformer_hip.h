@@ -267,7 +267,13 @@ int occf_split_bf16(const float* x, uint16_t* hi, uint16_t* lo, long n, void* st
 int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
                             const float* residual, float* out, int B, int X, int Y, int Z, int Cin, int Cout,
                             long in_sb, long in_sx, long in_sy, long in_sz, int act, int terms, float* gn_partial,
-                            void* stream);
+                            const uint16_t* wfrag_hi, const uint16_t* wfrag_lo, void* stream);
+/* Optional: the same weights in MFMA-fragment order (wfrag_hi / wfrag_lo above; NULL = weight slabs staged through
+ * LDS with a barrier per tap).  occf_conv3x3x3_halo_pack_elems = uint16 elements per array (0: shape not packed);
+ * occf_conv3x3x3_halo_pack permutes w_hi / w_lo [Cout, 27*Cin] into [Cin/32][27][2][Cout/32][64 lanes][8]. */
+long occf_conv3x3x3_halo_pack_elems(int Cin, int Cout);
+int occf_conv3x3x3_halo_pack(const uint16_t* w_hi, const uint16_t* w_lo, uint16_t* f_hi, uint16_t* f_lo, int Cin,
+                             int Cout, void* stream);
 /* gn_partial (both convolutions): like occf_linear_bf16_fwd -- [B][tiles per batch element][Cout][2];
  * tiles per batch element = ceil(Xo*Yo*Zo / 128) for occf_conv3d_bf16_fwd (must divide unless B = 1) and
  * occf_conv3x3x3_halo_gn_blocks(X, Y, Z) for the halo kernel (-1: shape not taken). */

@@ -29,6 +29,7 @@ class HipOps:
         # split (fp32-class accuracy, matrix-core rate); "bf16" = plain bf16 products
         self.precision = os.environ.get("OCCF_PRECISION", "bf16x3")
         self.use_halo_conv = os.environ.get("OCCF_HALO_CONV", "1") == "1"
+        self.halo_frag = os.environ.get("OCCF_HALO_FRAG", "1") == "1"
         # fused mask contraction + preserve-pooling (the intermediate mask logits are never written)
         self.use_fused_mask_pool = os.environ.get("OCCF_FUSED_MASK_POOL", "1") == "1"
         self._mgp_reverse = 0
@@ -328,6 +329,24 @@ class HipOps:
                        out.stride(0), r2.stride(0) if r2 is not None else 0, int(act), self._stream())
         return out.view(*x.shape[:-1], N)
 
+    def _halo_fragments(self, w_split, Cin, Cout):
+        """the pre-split weight in MFMA-fragment order for the halo kernel (cached ON the split tensor, which is
+        itself cached per weight version); None when switched off (OCCF_HALO_FRAG=0) or not packable"""
+        if not self.halo_frag or w_split is None:
+            return None
+        hi, lo = w_split
+        pk = getattr(hi, "_occf_halo_pack", None)
+        if pk is None:
+            n = self.lib.occf_conv3x3x3_halo_pack_elems(Cin, Cout)
+            if n <= 0 or hi.numel() != n:
+                return None
+            fh, fl = torch.empty_like(hi), torch.empty_like(lo)
+            self._call("occf_conv3x3x3_halo_pack", self._ptr(hi), self._ptr(lo), self._ptr(fh), self._ptr(fl), Cin, Cout,
+                       self._stream())
+            pk = (fh, fl)
+            hi._occf_halo_pack = pk
+        return pk
+
     def conv3d(self, x_cl, weight_tap, ksize, stride=1, dil=1, pad=None, bias=None, act=0, residual=None,
                w_split=None, gn=None):
         """x_cl [B, Xi, Yi, Zi, Cin] (any strides with unit channel stride) -> [B, Xo, Yo, Zo, Cout].
@@ -355,18 +374,20 @@ class HipOps:
             halo_args = (ctypes.c_void_p(x_cl.data_ptr()), self._ptr(w_split[0]), self._ptr(w_split[1]),
                          self._ptr(bias), self._ptr(residual), self._ptr(out), B, Xi, Yi, Zi, Cin, Cout,
                          x_cl.stride(0), x_cl.stride(1), x_cl.stride(2), x_cl.stride(3), int(act), terms)
+            frag = self._halo_fragments(w_split, Cin, Cout)
+            frag_args = (self._ptr(frag[0]), self._ptr(frag[1])) if frag else (ctypes.c_void_p(0), ctypes.c_void_p(0))
             rc = -2
             if want_gn:
                 nblk = self.lib.occf_conv3x3x3_halo_gn_blocks(Xi, Yi, Zi)
                 if nblk > 0 and Cout % gn[0] == 0:
                     part = torch.empty((B * nblk * Cout * 2,), dtype=self.f32, device=x_cl.device)
-                    rc = self.lib.occf_conv3x3x3_halo_fwd(*halo_args, self._ptr(part), self._stream())
+                    rc = self.lib.occf_conv3x3x3_halo_fwd(*halo_args, self._ptr(part), *frag_args, self._stream())
                     if rc == 0:
                         self.last_gn_stats = self._gn_finalize(part, B, nblk, Cout, gn[0],
                                                                Xo * Yo * Zo * (Cout // gn[0]), gn[1])
                         return out
             if rc == -2:
-                rc = self.lib.occf_conv3x3x3_halo_fwd(*halo_args, ctypes.c_void_p(0), self._stream())
+                rc = self.lib.occf_conv3x3x3_halo_fwd(*halo_args, ctypes.c_void_p(0), *frag_args, self._stream())
             if rc == 0:
                 return out
             if rc != -2:                     # -2 = shape outside the halo kernel's envelope

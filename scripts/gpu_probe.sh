@@ -1,14 +1,6 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/probe18
-mkdir -p $O
 cd $R
-python scripts/bwd_probe.py wgrad msda
-echo "== zfast off"; OCCF_WG_ZFAST=0 python scripts/bwd_probe.py wgrad192
-echo "== tests"; timeout 900 python -m pytest tests/test_bwd_ops.py tests/test_train_ops.py -m gpu -q -p no:cacheprovider 2>&1 | tail -3
-echo "== train bench"; timeout 600 python bench.py --mode train --steps 3 --warmup 2 --no-cpu-baseline > $O/bench_train.json 2> $O/err.txt; echo rc=$?; tail -2 $O/err.txt
-python -c "
-import json
-d=json.load(open('$O/bench_train.json')); print({k:d[k] for k in ('value','ms_per_step','peak_memory_GiB','forward_samples_per_s_same_run')})
-for k,v in list(d['kernels'].items())[:16]: print(k, v['calls'], round(v['total_ms'],2))"
+echo "== frag + A prefetch + 80B rows + lane permutation"; python scripts/bwd_probe.py conv
+echo "== tests"; timeout 900 python -m pytest tests/test_gemm_norm_ops.py tests/test_full_size_gpu.py -m gpu -q -p no:cacheprovider -k "halo or conv" 2>&1 | tail -2

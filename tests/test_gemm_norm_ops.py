@@ -207,10 +207,12 @@ def test_splitk_small_m_long_k(be, monkeypatch):
 @pytest.mark.parametrize("shape,cin,cout", [((1, 5, 9, 16), 32, 64), ((2, 4, 20, 8), 64, 128), ((1, 3, 34, 4), 32, 192),
                                             ((1, 2, 8, 32), 32, 64)])
 @pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
-def test_conv3x3x3_halo(be, monkeypatch, shape, cin, cout, prec, tol):
+@pytest.mark.parametrize("frag", [True, False])      # weights in fragment order from global memory / slabs through LDS
+def test_conv3x3x3_halo(be, monkeypatch, shape, cin, cout, prec, tol, frag):
     """LDS-halo conv kernel (odd X, ragged Y tiles, Z = 4/8/16/32) vs fp64 conv3d; with bias/ReLU/residual"""
     monkeypatch.setattr(be.ops, "precision", prec)
     monkeypatch.setattr(be.ops, "use_halo_conv", True)
+    monkeypatch.setattr(be.ops, "halo_frag", frag)
     B, X, Y, Z = shape
     x = paramgen.tensor("hx", (B, cin, X, Y, Z), 1)
     w = paramgen.tensor("hw", (cout, cin, 3, 3, 3), 2, (cin * 27) ** -0.5)
@@ -231,7 +233,7 @@ def test_conv3x3x3_halo(be, monkeypatch, shape, cin, cout, prec, tol):
     import ctypes
     rc = orig(ctypes.c_void_p(xs.data_ptr()), ctypes.c_void_p(sp[0].data_ptr()), ctypes.c_void_p(sp[1].data_ptr()),
               None, None, ctypes.c_void_p(o2.data_ptr()), B, X, Y, Z, cin, cout, xs.stride(0), xs.stride(1),
-              xs.stride(2), xs.stride(3), 0, 3 if prec == "bf16x3" else 1, None, None)
+              xs.stride(2), xs.stride(3), 0, 3 if prec == "bf16x3" else 1, None, None, None, None)
     assert rc == 0
 
 
