@@ -100,7 +100,7 @@ def shape_report(census, path):
             f.write(f"{ms:8.3f} ms  {n:3d}x  {tf:7.1f} TF  {name} x{shp[0]} w{shp[1]}\n")
 
 
-def pmc_traffic(kernel_substr, grid_size):
+def pmc_traffic(kernel_substr, grid_size, pick="calls"):
     """HBM bytes per launch of a kernel from the newest committed rocprofv3 --pmc summary
     (profiles/*_pmc_traffic.json, written by scripts/summarize_pmc.py; FETCH_SIZE already x2-corrected for
     gfx950 per MI355X_MICROARCH.md).  None when no summary is present."""
@@ -121,7 +121,8 @@ def pmc_traffic(kernel_substr, grid_size):
     best = [r for r in rows if kernel_substr in r["kernel"] and (grid_size is None or r["grid"] == grid_size)]
     if not best:
         return None, None
-    r = max(best, key=lambda r: r["calls"])
+    # pick = "bytes": the launch shape that moves the most (the dominant launch of a kernel used at many shapes)
+    r = max(best, key=(lambda r: r["fetch_bytes"] + r["write_bytes"]) if pick == "bytes" else (lambda r: r["calls"]))
     return r["fetch_bytes"] + r["write_bytes"], os.path.basename(files[-1])
 
 
@@ -164,6 +165,7 @@ def roofline(timed_census, kernels, prec, steps):
         kname = f"wgrad_kernel<{128 if (Cin % 128 == 0 or Cin > 128) else 64}, {terms}, {'true' if presplit else 'false'}>"
         taps = flops // max(2 * B * X * Y * Z * Cout * Cin, 1)
         nbytes = 4 * (B * X * Y * Z * Cout) + 4 * int(torch.tensor(shp[1]).prod()) + 4 * Cout * taps * Cin
+        traffic, src = pmc_traffic(kname, None, pick="bytes")
     else:
         kname = "gemm_bf16_kernel<CONV, transposed loader>"
     return {"bound": "mfma", "kernel": f"{kname}  [{name} {list(shp[0])} {list(shp[1])}]", "achieved": achieved,

@@ -85,7 +85,11 @@ int occf_swin_attn_fused_fwd(const float* x, const float* ln_gamma, const float*
                              const uint16_t* wqkv_hi, const uint16_t* wqkv_lo, const float* bqkv,
                              const float* bias_table, const uint16_t* wproj_hi, const uint16_t* wproj_lo,
                              const float* bproj, float* out, int B, int X, int Y, int S, int C, int heads,
-                             int shift, void* stream);
+                             int shift, int weights_packed, void* stream);
+/* weights_packed != 0: wqkv / wproj (hi and lo) are given in MFMA-fragment order, as written by occf_swin_attn_pack
+ * (w[rows, 128] -> [rows / 32][8 k-steps][64 lanes][8]): a wave's weight load then reads 1 KB contiguous. */
+int occf_swin_attn_pack(const uint16_t* w_hi, const uint16_t* w_lo, uint16_t* f_hi, uint16_t* f_lo, int rows, int C,
+                        void* stream);
 
 /* ------------------------------------------------------------------ pixel decoder ------ */
 

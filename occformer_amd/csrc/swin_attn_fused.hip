@@ -36,6 +36,7 @@ struct SwinAttnArgs {
   float* out;
   int B, X, Y, S, shift;
   float eps, scale;
+  int packed;                 // weights in fragment order (occf_swin_attn_pack): [row / 32][k-step][lane][8]
 };
 
 typedef uint32_t sf_u2 __attribute__((ext_vector_type(2)));
@@ -212,6 +213,19 @@ __global__ void __launch_bounds__(256) SF_WAVES2 swin_attn_fused_kernel(SwinAttn
   bf16x8 qfh[2][2], qfl[2][2], kfh[2][2], kfl[2][2], vfh[2][2], vfl[2][2];
   bf16x8 wfh[1][8], wfl[1][8];
   auto fetch_w = [&](int mat, int buf) __attribute__((always_inline)) {
+    if (p.packed) {
+      // fragment order: the 64 lanes of a (32-row group, k-step) read 1 KB contiguous -- 8 cache lines per load
+      // instruction instead of the 32 a row-major weight costs (each lane's 16 bytes in a different row)
+      const int grp = mat < 3 ? mat * 4 + head : wave;
+      const uint16_t* bh = (mat < 3 ? p.Wqkv_h : p.Wp_h) + (long)grp * 8 * 512 + lane * 8;
+      const uint16_t* bl = (mat < 3 ? p.Wqkv_l : p.Wp_l) + (long)grp * 8 * 512 + lane * 8;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        wfh[buf][ks] = *(const bf16x8*)(bh + ks * 512);
+        wfl[buf][ks] = *(const bf16x8*)(bl + ks * 512);
+      }
+      return;
+    }
     const uint16_t* bh = mat < 3 ? p.Wqkv_h + ((long)(mat * C + head * SF_HD + li)) * C : p.Wp_h + ((long)(wave * 32 + li)) * C;
     const uint16_t* bl = mat < 3 ? p.Wqkv_l + ((long)(mat * C + head * SF_HD + li)) * C : p.Wp_l + ((long)(wave * 32 + li)) * C;
 #pragma unroll
@@ -370,11 +384,32 @@ __global__ void __launch_bounds__(256) SF_WAVES2 swin_attn_fused_kernel(SwinAttn
   }
 }
 
+// w[R][128] (bf16) -> [R / 32][8 k-steps][64 lanes][8]: element e of lane (lk, li) = w[g * 32 + li][ks * 16 + lk * 8 + e]
+__global__ void __launch_bounds__(256) swin_pack_kernel(const uint16_t* __restrict__ w, uint16_t* __restrict__ f, int R) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)R * 16) return;                     // 16-byte groups: R * 128 / 8
+  const int lane = (int)(gid & 63);
+  const int ks = (int)((gid >> 6) & 7);
+  const int g = (int)(gid >> 9);
+  const int li = lane & 31, lk = lane >> 5;
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  *(u4*)(f + gid * 8) = *(const u4*)(w + (long)(g * 32 + li) * SF_C + ks * 16 + lk * 8);
+}
+
+extern "C" int occf_swin_attn_pack(const uint16_t* w_hi, const uint16_t* w_lo, uint16_t* f_hi, uint16_t* f_lo, int rows,
+                                   int C, void* stream) {
+  if (C != SF_C || rows <= 0 || rows % 32 || !w_hi || !w_lo || !f_hi || !f_lo) return OCCF_ESHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(swin_pack_kernel, dim3(occf_cdiv((long)rows * 16, 256)), dim3(256), 0, st, w_hi, f_hi, rows);
+  hipLaunchKernelGGL(swin_pack_kernel, dim3(occf_cdiv((long)rows * 16, 256)), dim3(256), 0, st, w_lo, f_lo, rows);
+  OCCF_LAUNCH_CHECK();
+}
+
 extern "C" int occf_swin_attn_fused_fwd(const float* x, const float* ln_gamma, const float* ln_beta, float eps,
                                         const uint16_t* wqkv_hi, const uint16_t* wqkv_lo, const float* bqkv,
                                         const float* bias_table, const uint16_t* wproj_hi, const uint16_t* wproj_lo,
                                         const float* bproj, float* out, int B, int X, int Y, int S, int C, int heads,
-                                        int shift, void* stream) {
+                                        int shift, int weights_packed, void* stream) {
   if (C != SF_C || heads != 4) return OCCF_ESHAPE;
   if (B <= 0 || X <= 0 || Y <= 0 || S <= 0 || shift < 0 || shift >= SF_WS) return OCCF_EINVAL;
   if (!wqkv_lo || !wproj_lo || !bqkv || !bproj) return OCCF_EINVAL;
@@ -383,7 +418,7 @@ extern "C" int occf_swin_attn_fused_fwd(const float* x, const float* ln_gamma, c
   const long blocks = (long)B * S * nwx * nwy;
   if (blocks >= 2147483647L) return OCCF_ESHAPE;
   SwinAttnArgs a = {x, ln_gamma, ln_beta, wqkv_hi, wqkv_lo, bqkv, bias_table, wproj_hi, wproj_lo, bproj, out,
-                    B, X, Y, S, shift, eps, (float)(1.0 / sqrt((double)SF_HD))};
+                    B, X, Y, S, shift, eps, (float)(1.0 / sqrt((double)SF_HD)), weights_packed != 0};
   hipLaunchKernelGGL(swin_attn_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   OCCF_LAUNCH_CHECK();
 }

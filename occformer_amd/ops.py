@@ -30,6 +30,7 @@ class HipOps:
         self.precision = os.environ.get("OCCF_PRECISION", "bf16x3")
         self.use_halo_conv = os.environ.get("OCCF_HALO_CONV", "1") == "1"
         self.halo_frag = os.environ.get("OCCF_HALO_FRAG", "1") == "1"
+        self.swin_frag = os.environ.get("OCCF_SWIN_FRAG", "1") == "1"
         # fused mask contraction + preserve-pooling (the intermediate mask logits are never written)
         self.use_fused_mask_pool = os.environ.get("OCCF_FUSED_MASK_POOL", "1") == "1"
         self._mgp_reverse = 0
@@ -126,6 +127,19 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ pixel decoder
+    def _swin_pack(self, split, rows, C):
+        """(hi, lo) of a [rows, 128] weight in MFMA-fragment order for the fused Swin kernel (cached on the split
+        tensor, which is cached per weight version)"""
+        hi, lo = split
+        pk = getattr(hi, "_occf_swin_pack", None)
+        if pk is None:
+            fh, fl = torch.empty_like(hi), torch.empty_like(lo)
+            self._call("occf_swin_attn_pack", self._ptr(hi), self._ptr(lo), self._ptr(fh), self._ptr(fl), rows, C,
+                       self._stream())
+            pk = (fh, fl)
+            hi._occf_swin_pack = pk
+        return pk
+
     def swin_attention_fused(self, x, ln_w, ln_b, eps, wqkv_split, bqkv, bias_table, wproj_split, bproj, B, X, Y, S,
                              heads, shift):
         """x [B*X*Y*S, C] -> x + proj(window_msa(layernorm(x))) in one kernel, or None when the shape / precision
@@ -135,11 +149,14 @@ class HipOps:
             return None
         out = torch.empty_like(x)
         self.last_flops = 2 * x.shape[0] * C * 4 * C + 4 * x.shape[0] * 49 * C
+        packed = 0
+        if self.swin_frag:
+            wqkv_split, wproj_split, packed = self._swin_pack(wqkv_split, 3 * C, C), self._swin_pack(wproj_split, C, C), 1
         rc = self.lib.occf_swin_attn_fused_fwd(
             self._ptr(x, self.f32), self._ptr(ln_w, self.f32), self._ptr(ln_b, self.f32), float(eps),
             self._ptr(wqkv_split[0]), self._ptr(wqkv_split[1]), self._ptr(bqkv, self.f32),
             self._ptr(bias_table, self.f32), self._ptr(wproj_split[0]), self._ptr(wproj_split[1]),
-            self._ptr(bproj, self.f32), self._ptr(out), B, X, Y, S, C, heads, int(shift), self._stream())
+            self._ptr(bproj, self.f32), self._ptr(out), B, X, Y, S, C, heads, int(shift), packed, self._stream())
         if rc == -2:
             return None
         if rc != 0:

@@ -73,6 +73,20 @@ _DCN_CACHE = {}
 
 
 # ------------------------------------------------------------------ DepthNet (dense 2-D part)
+def _conv_train(conv, x):
+    """Training mode: an nn.Conv2d of DepthNet on the library's kernel pair (channels-last implicit GEMM forward,
+    wgrad / dgrad kernels backward) instead of ATen / MIOpen -- 7 ms of fp32 MIOpen kernels per training step at the
+    nuScenes sizes, and MIOpen's per-box algorithm search out of the benchmark.  x NCHW (any strides) -> the NCHW
+    view of the channels-last result; the BatchNorm that follows stays on ATen (train-mode batch statistics)."""
+    from . import autograd as A
+    y = A.conv(x.permute(0, 2, 3, 1).unsqueeze(3).contiguous(), conv)          # [BN, H, W, 1, Cout]
+    return y.squeeze(3).permute(0, 3, 1, 2)
+
+
+def _conv(mod, conv, x):
+    return _conv_train(conv, x) if mod.training and torch.is_grad_enabled() else conv(x)
+
+
 class _BasicBlock(nn.Module):
     """mmdet ResNet BasicBlock as used by DepthNet (ViewTransformerLSSBEVDepth.py:475-477)."""
 
@@ -84,8 +98,8 @@ class _BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(c)
 
     def forward(self, x):
-        y = F.relu(self.bn1(self.conv1(x)))
-        return F.relu(self.bn2(self.conv2(y)) + x)
+        y = F.relu(self.bn1(_conv(self, self.conv1, x)))
+        return F.relu(self.bn2(_conv(self, self.conv2, y)) + x)
 
     def forward_cl(self, x_cl):
         """channels-last [BN, H, W, 1, C]; BatchNorms folded into the convolutions"""
@@ -101,7 +115,7 @@ class _AtrousBranch(nn.Module):
         self.bn = nn.BatchNorm2d(cout)
 
     def forward(self, x):
-        return F.relu(self.bn(self.atrous_conv(x)))
+        return F.relu(self.bn(_conv(self, self.atrous_conv, x)))
 
     def forward_cl(self, x_cl):
         from . import fused
@@ -135,7 +149,7 @@ class _ImageASPP(nn.Module):
             g = gp[2](g)
         g = gp[3](g).expand(-1, -1, *x.shape[2:])
         y = torch.cat((self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), g), 1)
-        y = F.relu(self.bn1(self.conv1(y)))
+        y = F.relu(self.bn1(_conv(self, self.conv1, y)))
         if self.training:
             # nn.Dropout(0.5) as an explicit mask from the injectable noise source (occformer_amd/noise.py)
             from . import noise
@@ -280,9 +294,11 @@ class DepthNet(nn.Module):
                 # running statistics
                 m = F.batch_norm(m, self.bn.running_mean, self.bn.running_var, self.bn.weight, self.bn.bias, False,
                                  0.0, self.bn.eps)
-            x = self.reduce_conv(x)
-            ctx = self.context_conv(self.context_se(x, self.context_mlp(m)[..., None, None]))
-            depth = self.depth_conv(self.depth_se(x, self.depth_mlp(m)[..., None, None]))
+            x = self.reduce_conv[2](self.reduce_conv[1](_conv(self, self.reduce_conv[0], x)))
+            ctx = _conv(self, self.context_conv, self.context_se(x, self.context_mlp(m)[..., None, None]))
+            depth = self.depth_se(x, self.depth_mlp(m)[..., None, None])
+            for layer in self.depth_conv:
+                depth = _conv(self, layer, depth) if isinstance(layer, nn.Conv2d) else layer(depth)
             return torch.cat((depth, ctx), 1)
         from . import fused
         m = self.bn(mlp_input.reshape(-1, mlp_input.shape[-1]))

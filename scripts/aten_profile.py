@@ -31,7 +31,15 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step()
     torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=60,
-                                                         max_name_column_width=40, max_shapes_column_width=70))
-print(prof.key_averages(group_by_stack_n=6).table(sort_by="self_cuda_time_total", row_limit=40,
-                                                  max_name_column_width=40, max_src_column_width=110))
+rows = []
+for e in prof.key_averages(group_by_input_shape=True):
+    if e.key.startswith("aten::") or e.key.startswith("Memcpy") or e.key.startswith("Memset"):
+        t = getattr(e, "self_device_time_total", None)
+        if t is None:
+            t = e.self_cuda_time_total
+        rows.append((t, e.count, e.key, str(e.input_shapes)[:110]))
+rows.sort(reverse=True)
+tot = sum(r[0] for r in rows)
+print(f"ATen / memcpy device time in one step: {tot / 1e3:.2f} ms")
+for t, n, k, shp in rows[:70]:
+    print(f"{t / 1e3:8.3f} ms {n:5d}x  {k:32s} {shp}")

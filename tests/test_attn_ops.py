@@ -177,10 +177,12 @@ def test_mask_gemm_pool_declines_non_uniform_windows(be, monkeypatch, shape, tar
 
 
 @pytest.mark.parametrize("X,Y,S,shift,B", [(14, 14, 3, 0, 1), (10, 9, 2, 3, 2), (7, 16, 1, 3, 1), (5, 5, 2, 0, 1)])
-def test_swin_attention_fused(be, monkeypatch, X, Y, S, shift, B):
+@pytest.mark.parametrize("packed", [True, False])      # weights in MFMA-fragment order / row-major
+def test_swin_attention_fused(be, monkeypatch, X, Y, S, shift, B, packed):
     """x + proj(window_msa(layernorm(x))) in one kernel == the oracle's LayerNorm -> ShiftWindowMSA -> residual
     (C = 128 / 4 heads; padded, shifted and partial windows)"""
     monkeypatch.setattr(be.ops, "precision", "bf16x3")
+    monkeypatch.setattr(be.ops, "swin_frag", packed)
     C, heads = 128, 4
     sd = {"a.w_msa.qkv.weight": paramgen.tensor("fqkvw", (3 * C, C), 1, C ** -0.5),
           "a.w_msa.qkv.bias": paramgen.tensor("fqkvb", (3 * C,), 1, 0.3),

@@ -16,6 +16,8 @@ SWITCHES = [
     {"use_fused_mlp": False},                  # OCCF_FUSED_MLP=0
     {"use_fused_mask_pool": False},            # OCCF_FUSED_MASK_POOL=0
     {"precision": "f32"},                      # OCCF_PRECISION=f32
+    {"halo_frag": False},                      # OCCF_HALO_FRAG=0: weight slabs through LDS instead of global fragments
+    {"swin_frag": False},                      # OCCF_SWIN_FRAG=0: row-major weights in the fused Swin kernel
 ]
 
 
@@ -45,8 +47,8 @@ def test_every_switch_gives_the_same_forward(be, monkeypatch):
     monkeypatch.setattr(ops_mod, "_ops", be.ops)
     saved = {k: getattr(be.ops, k) for s in SWITCHES for k in s}
     # (the host emulation is ~100x slower than the chip: the CPU run covers the three paths with their own kernels,
-    # the GPU run all six)
-    todo = SWITCHES if be.kind == "hip" else [SWITCHES[0], SWITCHES[1], SWITCHES[2], SWITCHES[5]]
+    # the GPU run all of them)
+    todo = SWITCHES if be.kind == "hip" else [SWITCHES[0], SWITCHES[1], SWITCHES[2], SWITCHES[5], SWITCHES[6]]
     try:
         ref = None
         for sw in todo:
