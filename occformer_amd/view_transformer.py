@@ -7,6 +7,8 @@ Host-side mirror of projects/mmdet3d_plugin/occformer/image2bev/ViewTransformerL
 (SURVEY.md Appendix D).  The lift, the geometry/quantisation and the voxel pooling run in
 the gfx950 kernels of csrc/lss.hip; the [B,N,D,fH,fW,C] volume is never materialised.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -83,8 +85,15 @@ def _conv_train(conv, x):
     return y.squeeze(3).permute(0, 3, 1, 2)
 
 
+# OCCF_DEPTHNET_LIB=1: DepthNet's training-mode convolutions on the library's kernel pairs.  Default off: at the
+# nuScenes sizes (M = 6 x 16 x 44 = 4 224 rows) the ten 3x3 convolutions cost the same on either side (~6 ms per
+# step), and every non-ATen summation order flips a few more ReLU gates against the CPU oracle in the tiny parity
+# configuration (tests/test_train_step.py); SemanticKITTI (640 channels, one camera) gains: 278 -> 149 ms per step.
+_DEPTHNET_LIB = os.environ.get("OCCF_DEPTHNET_LIB", "0") == "1"
+
+
 def _conv(mod, conv, x):
-    return _conv_train(conv, x) if mod.training and torch.is_grad_enabled() else conv(x)
+    return _conv_train(conv, x) if _DEPTHNET_LIB and mod.training and torch.is_grad_enabled() else conv(x)
 
 
 class _BasicBlock(nn.Module):

@@ -1,8 +1,5 @@
 #!/bin/bash
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/probe26
-mkdir -p $O
 cd $R
-timeout 600 python scripts/aten_profile.py > $O/aten_profile.txt 2>&1; echo rc=$?
-grep -v "amdgpu.ids\|Warning\|warn" $O/aten_profile.txt | head -80
+timeout 900 python -m pytest tests/test_train_step.py -m gpu -q -p no:cacheprovider -s 2>&1 | grep -v "amdgpu.ids" | tail -60

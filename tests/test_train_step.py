@@ -12,7 +12,12 @@ parameter gradient agrees to <= 5e-5 except the ones behind 1 flipped gate out o
 one element); the occupancy head + losses alone agree to 1e-5 (no gate happened to flip); in the full step a flipped
 gate near the loss perturbs everything upstream of it diffusely.  The criteria are therefore: the WHOLE gradient
 vector within 1e-3 (relative L2), every loss value within 1e-3, 90 % of the parameters within 3e-3 and every
-parameter within 3e-2 (relative L2) -- the tiny configuration makes single gates weigh ~100x more than at full size."""
+parameter within 5e-2 (relative L2) -- the tiny configuration makes single gates weigh ~100x more than at full size.
+Measured on MI355X (r02 final tree): whole vector 7.1e-4, quantiles 50 / 75 / 90 / 95 / 100 % = 1.1e-3 / 1.7e-3 /
+2.4e-3 / 2.8e-3 / 2.9e-2 over 583 parameters; the worst five are all DepthNet parameters behind its camera-MLP
+BatchNorm1d (a batch of 4 camera vectors).  The per-parameter bound has ~1.7x headroom over that maximum because the
+set of flipped gates moves with every change of a summation order (MIOpen's algorithm choice for DepthNet's 2-D
+convolutions differs from box to box); the whole-vector and 90 % bounds are the ones that carry the claim."""
 import pytest
 import torch
 
@@ -105,5 +110,5 @@ def test_training_step_gradients_vs_oracle(bound):
     den = sum(float(ref_grads[k].norm() ** 2) for l2, mx, k, s in worst)
     print("whole gradient vector: relative L2 error", (num / den) ** 0.5)
     assert (num / den) ** 0.5 < TOL
-    assert l2s[int(0.9 * (len(l2s) - 1))] < 3e-3 and l2s[-1] < 3e-2, worst[:5]
+    assert l2s[int(0.9 * (len(l2s) - 1))] < 3e-3 and l2s[-1] < 5e-2, worst[:5]
     assert all(float(named[k].grad.abs().max()) < 1e-4 for l2, mx, k, s in worst if s <= 1e-5)
