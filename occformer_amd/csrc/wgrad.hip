@@ -46,6 +46,13 @@ struct WgArgs {
   // all SIMD cycles (MFMA 27 %) -- the address arithmetic and the 4-dword selects of 16 loads per thread and chunk
   int zfast;
   int zshift;          // log2(Zo)
+  // xcd_tiles > 0: 1-D grid; workgroup w runs on XCD w % 8 (round-robin dispatch), so ALL (tap, tile) workgroups of one
+  // M-slab are placed on ONE XCD (slab = xcd + 8 * (k / xcd_tiles), tile = k % xcd_tiles with k = w / 8): the slab's
+  // dY / X rows are then fetched from HBM once into that XCD's L2 and shared by its 27 x tiles workgroups.  With the
+  // slabs spread round-robin over all XCDs every XCD streamed every slab: 21 GB of HBM fetch for 0.99 GB of operands on
+  // the 192 -> 192 convolution (PMC FETCH_SIZE), i.e. the kernel ran at the HBM roof, not the MFMA roof.
+  int xcd_tiles;
+  int n_slabs;
   WgGeom g;
 };
 
@@ -88,12 +95,19 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int c_tiles = (p.Cin + BC - 1) / BC;
   int bx = blockIdx.x;
+  int slab = blockIdx.y;
+  if (p.xcd_tiles > 0) {
+    const int xcd = (int)(blockIdx.x & 7u), k = (int)(blockIdx.x >> 3);
+    slab = xcd + 8 * (k / p.xcd_tiles);
+    bx = k % p.xcd_tiles;
+    if (slab >= p.n_slabs) return;                 // (uniform over the workgroup; only when n_slabs % 8 != 0)
+  }
   const int ct = bx % c_tiles;
   bx /= c_tiles;
   const int tap = bx % p.taps;
   const int nt = bx / p.taps;
   const int n0 = nt * 128, c0 = ct * BC;
-  const long m_begin = (long)blockIdx.y * p.rows_per_split;
+  const long m_begin = (long)slab * p.rows_per_split;
   long m_end = m_begin + p.rows_per_split;
   if (m_end > p.M) m_end = p.M;
   const int nchunks = m_end > m_begin ? (int)((m_end - m_begin + 63) / 64) : 0;
@@ -411,7 +425,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
 
   // ---- epilogue: raw partial sums of this M-slice
   const int Kt = p.taps * p.Cin;
-  float* o = p.out + (long)blockIdx.y * p.N * Kt;
+  float* o = p.out + (long)slab * p.N * Kt;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -434,7 +448,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
       float s = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) s += red[r * 128 + tid];
-      p.bias_out[(long)blockIdx.y * p.N + n0 + tid] = s;
+      p.bias_out[(long)slab * p.N + n0 + tid] = s;
     }
   }
 }
@@ -499,6 +513,7 @@ static int wg_pick_splits(long M, int N, int Cin, int taps, int BC) {
   if (S > chunks / 4) S = chunks / 4;
   if (S < 1) S = 1;
   if (S > 256) S = 256;
+  if (S >= 8) S = (S + 4) / 8 * 8;                    // whole slabs per XCD (xcd_tiles placement)
   return (int)S;
 }
 static int wg_bc(int Cin) {
@@ -534,7 +549,17 @@ static int wg_launch(WgArgs a, float* dW, float* db, float* workspace, long work
   a.rows_per_split = rows;
   a.out = S > 1 ? workspace : dW;
   a.bias_out = db ? (S > 1 ? workspace + (long)S * a.N * Kt : db) : nullptr;
-  const dim3 grid((unsigned)((long)occf_cdiv(a.N, 128) * occf_cdiv(a.Cin, BC) * a.taps), S);
+  const long tiles = (long)occf_cdiv(a.N, 128) * occf_cdiv(a.Cin, BC) * a.taps;
+  dim3 grid((unsigned)tiles, S);
+  static const int xcd_env = [] {
+    const char* e = getenv("OCCF_WG_XCD");
+    return e ? atoi(e) : 1;
+  }();
+  a.n_slabs = S;
+  if (xcd_env && S >= 8 && tiles * ((S + 7) / 8) * 8 < 2147483647L) {
+    a.xcd_tiles = (int)tiles;
+    grid = dim3((unsigned)(tiles * ((S + 7) / 8) * 8), 1);
+  }
   const bool pre = a.dYh != nullptr;
 #define OCCF_WG_LAUNCH(BC_, T_)                                                                        \
   do {                                                                                                 \

@@ -2,4 +2,6 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-timeout 900 python -m pytest tests/test_train_step.py -m gpu -q -p no:cacheprovider -s 2>&1 | grep -v "amdgpu.ids" | tail -60
+echo "== xcd placement"; python scripts/bwd_probe.py wgrad
+echo "== round robin"; OCCF_WG_XCD=0 python scripts/bwd_probe.py wgrad
+echo "== tests"; timeout 900 python -m pytest tests/test_bwd_ops.py -m gpu -q -p no:cacheprovider -k "wgrad" 2>&1 | tail -2
