@@ -110,15 +110,15 @@ __global__ void __launch_bounds__(256) SF_WAVES2 swin_attn_fused_kernel(SwinAttn
   const int X = p.X, Y = p.Y, S = p.S, shift = p.shift;
   const int nwx = (X + SF_WS - 1) / SF_WS, nwy = (Y + SF_WS - 1) / SF_WS;
   const int Xp = nwx * SF_WS, Yp = nwy * SF_WS;
-  // slice index fastest: concurrently resident workgroups work on the S slices of one spatial window, whose token rows
-  // are adjacent in memory (same pages / neighbouring lines)
+  // window y fastest, then x, then slice.  (Slice-fastest -- neighbouring workgroups on the S adjacent token rows of
+  // one window position -- measured the same: 2.09 vs 2.08 ms per forward, probes 25 / 31.)
   long bid = blockIdx.x;
-  const int s = (int)(bid % S);
-  bid /= S;
   const int wy = (int)(bid % nwy);
   bid /= nwy;
   const int wx = (int)(bid % nwx);
-  const int b = (int)(bid / nwx);
+  bid /= nwx;
+  const int s = (int)(bid % S);
+  const int b = (int)(bid / S);
   const int head = wave;
   constexpr int C = SF_C;
 
