@@ -506,6 +506,101 @@ __global__ void __launch_bounds__(256) upsample_classify_lds_kernel(
     if (i < K) out[((long)b * K + i) * V2 + vid] = acc[i];
 }
 
+// Matrix-core variant of the LDS-staged kernel: the class volume is a contraction over the queries,
+//   out[class, voxel] = sum_q prob[q, class] * sigmoid(mask_q(voxel)),
+// i.e. [classes x Q] . [Q x voxels].  The VALU version spends 18 of its ~45 instructions per (voxel, query) on the
+// class FMAs; here they are one v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate) per 32 voxels and TWO
+// queries: A = prob^T (row = class, k = query parity), B = sigmoid values (k = query parity, column = voxel), so lane
+// l computes the sigmoid of voxel l & 31 for query 2t + (l >> 5) -- exactly its B element -- and the matrix pipe does
+// the class sums while the other waves interpolate.  A wave owns two 32-voxel z-lines (two accumulators).
+// (Measured 0.73 ms against 0.62 ms for the VALU variant; kept behind OCCF_CLASSIFY_MFMA=1.)
+template <int QMAX>
+__global__ void __launch_bounds__(256) upsample_classify_mfma_kernel(
+    const float* __restrict__ mask_pred, const float* __restrict__ prob, float* __restrict__ out, int B,
+    int Q, int K, int X, int Y, int X2, int Y2) {
+  constexpr int Z = 16, Z2 = 32;
+  __shared__ __attribute__((aligned(16))) float tile[2][UCL_QG][UCL_CELLS];
+  __shared__ float ptab[QMAX * 32];                       // [query][class], zero beyond K / Q
+  const int b = blockIdx.y;
+  const long V2 = (long)X2 * Y2 * Z2;
+  const long wg = occf_xcd_remap(blockIdx.x, gridDim.x);
+  const int yb = Y2 >> 2;
+  const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  const int vj = ln & 31, par = ln >> 5;
+  const float* pb = prob + (long)b * Q * UC_MAXK;
+  for (int i = threadIdx.x; i < QMAX * 32; i += 256) {
+    const int q = i >> 5, c = i & 31;
+    ptab[i] = (q < Q && c < K) ? pb[q * UC_MAXK + c] : 0.f;
+  }
+  const float sx = X2 > 1 ? (float)(X - 1) / (float)(X2 - 1) : 0.f;
+  const float sy = Y2 > 1 ? (float)(Y - 1) / (float)(Y2 - 1) : 0.f;
+  const float sz = (float)(Z - 1) / (float)(Z2 - 1);
+  const int x2 = (int)(wg / yb) * 2 + (wv >> 1);
+  const int xa = (int)(sx * (float)((int)(wg / yb) * 2)), ya = (int)(sy * (float)((int)(wg % yb) * 4));
+  float w[2][8];
+  int off[2][8];
+  long vid[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int y2 = (int)(wg % yb) * 4 + ((2 * wv) & 3) + g;
+    vid[g] = ((long)x2 * Y2 + y2) * Z2 + vj;
+    const float fx = sx * x2, fy = sy * y2, fz = sz * vj;
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const int x1 = x0 + (x0 < X - 1), y1 = y0 + (y0 < Y - 1), z1 = z0 + (z0 < Z - 1);
+    const float tx = fx - x0, ty = fy - y0, tz = fz - z0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      w[g][c] = ((c & 4) ? tx : 1.f - tx) * ((c & 2) ? ty : 1.f - ty) * ((c & 1) ? tz : 1.f - tz);
+      off[g][c] = ((((c & 4) ? x1 : x0) - xa) * 4 + (((c & 2) ? y1 : y0) - ya)) * Z + ((c & 1) ? z1 : z0);
+    }
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+  // loader role (as in the VALU variant): wave wv fetches query (round * 4 + wv); lane l < 48 -> (rx, ry, z quad)
+  const int lrx = ln >> 4, lry = (ln >> 2) & 3, lzq = ln & 3;
+  const int lx = occf_clampi(xa + lrx, X - 1), ly = occf_clampi(ya + lry, Y - 1);
+  const float* src0 = mask_pred + (long)b * Q * ((long)X * Y * Z) + ((long)lx * Y + ly) * Z + lzq * 4;
+  const long qstride = (long)X * Y * Z;
+  float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](int q) __attribute__((always_inline)) {
+    const int qq = q < Q ? q : Q - 1;
+    if (ln < 48) r4 = *(const float4*)(src0 + (long)qq * qstride);
+  };
+  fetch(wv);
+  const int rounds = (Q + UCL_QG - 1) / UCL_QG;
+  for (int rd = 0; rd < rounds; ++rd) {
+    float* dst = &tile[rd & 1][wv][0];
+    if (ln < 48) *(float4*)(dst + (lrx * 4 + lry) * Z + lzq * 4) = r4;
+    __syncthreads();                                     // round rd (and, the first time, ptab) is staged
+    fetch((rd + 1) * UCL_QG + wv);
+#pragma unroll
+    for (int pr = 0; pr < UCL_QG / 2; ++pr) {
+      const int q = rd * UCL_QG + 2 * pr + par;          // this lane half's query of the pair
+      const float* m = &tile[rd & 1][2 * pr + par][0];
+      const float a = q < Q ? ptab[q * 32 + vj] : 0.f;    // A element: class vj of query q
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float val = w[g][0] * m[off[g][0]];
+#pragma unroll
+        for (int c = 1; c < 8; ++c) val = fmaf(w[g][c], m[off[g][c]], val);
+        const float sg = q < Q ? occf_rcp_fast(1.0f + __expf(-val)) : 0.f;
+        acc[g] = occf_mfma_f32_32x32x2(a, sg, acc[g]);
+      }
+    }
+  }
+  // D[class][voxel]: lane (voxel vj, half par) holds classes (r & 3) + 8 (r >> 2) + 4 par
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int cls = (r & 3) + 8 * (r >> 2) + 4 * par;
+      if (cls < K) out[((long)b * K + cls) * V2 + vid[g]] = acc[g][r];
+    }
+}
+
 // Same-resolution case (X2 == X ...: the nuScenes head predicts masks at the output grid): the
 // align_corners resample is the identity, so every output voxel needs ONE mask value per query instead
 // of 8 taps.  A thread owns 2 consecutive voxels (float2 loads, fully coalesced), keeps UQ queries'
@@ -588,6 +683,17 @@ extern "C" int occf_upsample_classify_fwd(const float* mask_pred, const float* c
     if (lds_env && Z == 16 && Z2 == 32 && (X2 & 1) == 0 && (Y2 & 3) == 0 && X2 >= 2 * X - 1 && Y2 >= 2 * Y - 1 &&
         K <= UC_MAXK) {
       const dim3 grid((unsigned)((long)(X2 / 2) * (Y2 / 4)), B);
+      static const bool mfma_env = [] {
+        // measured SLOWER than the VALU class sums (0.73 vs 0.62 ms at the 200-grid, probe 32: the fp32 MFMA issues
+        // every 64 cycles and the two sigmoids that feed it sit in the same wave's instruction stream): opt-in only
+        const char* e = getenv("OCCF_CLASSIFY_MFMA");
+        return e != nullptr && atoi(e) != 0;
+      }();
+      if (mfma_env && Q <= 128) {
+        hipLaunchKernelGGL((upsample_classify_mfma_kernel<128>), grid, dim3(256), 0, st, mask_pred,
+                           (const float*)workspace, out, B, Q, K, X, Y, X2, Y2);
+        OCCF_LAUNCH_CHECK();
+      }
       if (K <= 18)
         hipLaunchKernelGGL((upsample_classify_lds_kernel<18>), grid, dim3(256), 0, st, mask_pred,
                            (const float*)workspace, out, B, Q, K, X, Y, X2, Y2);
