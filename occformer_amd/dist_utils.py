@@ -1,8 +1,10 @@
 """Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over
-xGMI on ROCm; "gloo" in the CPU tests).  The forward hot path shards by independent samples
-(the reference runs batch 1 per GPU under DDP, occformer_nusc_r50_256x704.py:266;
-mmdet_train.py:72-80), so there is NO data-path collective: only the timing barrier/max and,
-in evaluation, the 16x16 confusion-matrix sum (apis/test.py:206-210)."""
+xGMI on ROCm; "gloo" in the CPU tests).  The path shards by independent samples (the reference
+runs batch 1 per GPU under DDP, occformer_nusc_r50_256x704.py:266; mmdet_train.py:72-80): the
+forward has NO data-path collective; the training step keeps exactly the reference's two --
+DDP's bucketed gradient all-reduce (wired in bench.py / tests/test_ddp_train.py) and the
+scalar ``reduce_mean`` of the loss normalisers (mask2former_nusc_occ.py:408) -- plus the timing
+barrier / max and, in evaluation, the 16x16 confusion-matrix sum (apis/test.py:206-210)."""
 import os
 
 import torch
