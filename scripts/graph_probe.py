@@ -1,50 +1,62 @@
-"""Does the whole forward capture into a HIP graph, and what does replay save?  (GPU box; diagnostics)"""
-import os, sys, time
-import torch
+"""Can the static-shape part of the forward (dual-path encoder -> pixel decoder -> occupancy decoder -> output volume)
+be captured in a HIP graph, and what does replay save over eager launches?"""
+import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
+import occformer_amd  # noqa
 from occformer_amd import configs
 from occformer_amd.registry import build_model
 
-dev = torch.device("cuda:0")
+device = torch.device("cuda", 0)
 torch.manual_seed(0)
-cfg, meta = configs.nusc_r50("200")
-model = build_model(cfg).eval().to(dev)
-img_inputs, metas, points = bench.synthetic_sample(meta, dev, seed=0)
+cfg, meta = configs.workload("nusc_r50_200")
+model = build_model(cfg).to(device).eval()
+img_inputs, metas, points = configs.synthetic_sample(meta, device, seed=0)
 
-def step():
-    with torch.no_grad():
-        vox, _, _ = model.extract_feat(None, img_inputs, metas)
-        return model.pts_bbox_head.simple_test(vox, metas, points=points)
+with torch.no_grad():
+    x = model.image_encoder(img_inputs[0])
+    rots, trans, intrins, post_rots, post_trans, bda = img_inputs[1:7]
+    mlp_input = model.img_view_transformer.get_mlp_input(rots, trans, intrins, post_rots, post_trans, bda)
+    vox, depth = model.img_view_transformer([x, rots, trans, intrins, post_rots, post_trans, bda, mlp_input])
 
-for _ in range(3):
-    ref = step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(8):
-    step()
-torch.cuda.synchronize()
-print("eager   %.2f ms/step" % ((time.perf_counter() - t0) / 8 * 1e3), flush=True)
-g = torch.cuda.CUDAGraph()
-s = torch.cuda.Stream()
-s.wait_stream(torch.cuda.current_stream())
-try:
-    with torch.cuda.stream(s):
-        for _ in range(2):
-            step()
-    torch.cuda.current_stream().wait_stream(s)
-    with torch.cuda.graph(g):
-        out = step()
-    torch.cuda.synchronize()
-    for _ in range(2):
-        g.replay()
+def tail(v):
+    feats = model.bev_encoder(v)
+    if not isinstance(feats, list):
+        feats = [feats]
+    res = model.pts_bbox_head.simple_test(feats, metas, points=points)
+    return res["output_voxels"][0], res["output_points"]
+
+def timeit(fn, n=10):
+    for _ in range(3):
+        fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(8):
-        g.replay()
+    for _ in range(n):
+        fn()
     torch.cuda.synchronize()
-    print("graph   %.2f ms/step" % ((time.perf_counter() - t0) / 8 * 1e3))
-    a, b = out["output_voxels"][0], ref["output_voxels"][0]
-    print("max abs diff graph vs eager", float((a - b).abs().max()))
-except Exception as e:
-    print("capture failed:", type(e).__name__, str(e)[:300])
+    return (time.perf_counter() - t0) / n * 1e3
+
+with torch.no_grad():
+    ref = tail(vox)
+    print("eager tail ms:", round(timeit(lambda: tail(vox)), 3), flush=True)
+    static_in = vox.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            tail(static_in)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.graph(g):
+            out = tail(static_in)
+    except Exception as e:
+        print("capture failed:", type(e).__name__, str(e)[:400], flush=True)
+        sys.exit(0)
+    def replay():
+        static_in.copy_(vox)
+        g.replay()
+    replay()
+    torch.cuda.synchronize()
+    print("graph output max abs diff vs eager:", float((out[0] - ref[0]).abs().max()), float((out[1] - ref[1]).abs().max()))
+    print("graph tail ms:", round(timeit(replay), 3), flush=True)
