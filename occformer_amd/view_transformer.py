@@ -88,7 +88,9 @@ def _conv_train(conv, x):
 # OCCF_DEPTHNET_LIB=1: DepthNet's training-mode convolutions on the library's kernel pairs.  Default off: at the
 # nuScenes sizes (M = 6 x 16 x 44 = 4 224 rows) the ten 3x3 convolutions cost the same on either side (~6 ms per
 # step), and every non-ATen summation order flips a few more ReLU gates against the CPU oracle in the tiny parity
-# configuration (tests/test_train_step.py); SemanticKITTI (640 channels, one camera) gains: 278 -> 149 ms per step.
+# configuration (tests/test_train_step.py).  (SemanticKITTI, 640 channels / one camera: 149 ms per step with the
+# library kernels, 139 ms with MIOpen on a box where its search settles on the igemm kernels, 278 ms on one where it
+# did not -- r02 probes 8 / 27, r02k.)
 _DEPTHNET_LIB = os.environ.get("OCCF_DEPTHNET_LIB", "0") == "1"
 
 
