@@ -44,7 +44,9 @@ def _digest():
         if f.endswith((".hip", ".h")):
             h.update(open(os.path.join(HERE, f), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "occformer_hip.h"), "rb").read())
-    h.update(" ".join(FLAGS).encode())
+    # (flags without the checkout's absolute path: the digest identifies the SOURCES -- profiles/*_pmc_traffic.json is
+    # stamped with it on one GPU box and checked on another, where the repository lives under a different path)
+    h.update(" ".join(f.replace(ROOT, "<root>") for f in FLAGS).encode())
     return h.hexdigest()
 
 
