@@ -97,6 +97,47 @@ class Linear(torch.autograd.Function):
         return dx, dw, db, None, (dy if ctx.has_res else None), None, None
 
 
+class InProj(torch.autograd.Function):
+    """nn.MultiheadAttention's input projections: q = xq Wq^T + bq, k = xk Wk^T + bk, v = xv Wv^T + bv with
+    W = in_proj_weight [3E, E] = (Wq | Wk | Wv).  One node instead of three row-sliced ``Linear``s, so the weight / bias
+    gradients are assembled once (one concatenation) instead of three zero-filled full-size gradients summed by
+    autograd -- the decoder calls this 18 times per training step."""
+
+    @staticmethod
+    def forward(ctx, xq, xk, xv, weight, bias):
+        ops = get_ops()
+        E = weight.shape[1]
+        w, b = weight.detach(), bias.detach()
+        sp = fused.split_weight(weight, _w2d)
+        outs = []
+        for i, x in enumerate((xq, xk, xv)):
+            lo, hi = i * E, (i + 1) * E
+            outs.append(ops.linear(x, w[lo:hi], b[lo:hi], 0, None, w_split=None if sp is None else (sp[0][lo:hi], sp[1][lo:hi]),
+                                   allow_small=True))
+        ctx.save_for_backward(xq, xk, xv, weight)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        xq, xk, xv, weight = ctx.saved_tensors
+        ops = get_ops()
+        E = weight.shape[1]
+        wt, _ = _wt(weight)                                # [E, 3E]
+        dxs, dws, dbs = [], [], []
+        for i, (x, g) in enumerate(((xq, dq), (xk, dk), (xv, dv))):
+            lo, hi = i * E, (i + 1) * E
+            g2, x2 = g.contiguous().reshape(-1, E), x.reshape(-1, E)
+            dx = None
+            if ctx.needs_input_grad[i]:
+                wti = wt[:, lo:hi].contiguous()
+                dx = ops.linear(g2, wti, None, w_split=_split(wti)).view(x.shape)
+            dxs.append(dx)
+            dw, db = ops.linear_wgrad(g2, x2 if x2.stride(1) == 1 else x2.contiguous(), want_bias=True)
+            dws.append(dw)
+            dbs.append(db)
+        return dxs[0], dxs[1], dxs[2], torch.cat(dws, 0), torch.cat(dbs, 0)
+
+
 def linear(x, lin, act=0, residual=None):
     return Linear.apply(x, lin.weight, lin.bias, act, residual, None)
 

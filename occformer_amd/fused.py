@@ -13,6 +13,8 @@ _SPLIT_CACHE = {}
 def _versioned(cache, param, make):
     """value derived from a Parameter, recomputed when the parameter changes (its ``_version``
     bumps on optimizer steps / load_state_dict) or when ``id(param)`` gets reused."""
+    if not param.is_leaf:
+        return make()                   # a graph intermediate (e.g. two weights concatenated per step): never cached
     key = id(param)
     hit = cache.get(key)
     ver = (param._version, param.data_ptr())

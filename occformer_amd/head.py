@@ -56,9 +56,7 @@ class _MHA(nn.Module):
             W, bv = self.attn.in_proj_weight, self.attn.in_proj_bias
             if key_with_pos is None:
                 key_with_pos = key + key_pos if key_pos is not None else key
-            q = A.Linear.apply(query + query_pos, W, bv, 0, None, (0, E))
-            k = A.Linear.apply(key_with_pos, W, bv, 0, None, (E, 2 * E))
-            v = A.Linear.apply(value, W, bv, 0, None, (2 * E, 3 * E))
+            q, k, v = A.InProj.apply(query + query_pos, key_with_pos, value, W, bv)
             o = A.MaskedAttention.apply(q, k, v, self.heads, blocked, row_open)
             return A.linear(o, self.attn.out_proj, residual=query)
         w, b = self.attn.in_proj_weight.detach(), self.attn.in_proj_bias.detach()

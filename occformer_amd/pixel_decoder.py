@@ -139,7 +139,11 @@ class MultiScaleDeformableAttention3D(nn.Module):
         if self.dropout.p > 0:
             raise NotImplementedError("MultiScaleDeformableAttention3D dropout > 0 (every OccFormer config uses 0.0)")
         qp = query + query_pos
-        ol = torch.cat((A.linear(qp, self.sampling_offsets), A.linear(qp, self.attention_weights)), -1)
+        # one projection for offsets | logits (the two weights concatenated per step: 288 x 192, its gradient splits back
+        # through the cat) instead of two GEMM pairs, a [B, Nq, 288] concatenation and two data gradients summed
+        w = torch.cat((self.sampling_offsets.weight, self.attention_weights.weight), 0)
+        b = torch.cat((self.sampling_offsets.bias, self.attention_weights.bias), 0)
+        ol = A.Linear.apply(qp, w, b, 0, None, None)
         B, Nq, E = query.shape
         dh = E // self.num_heads
         hm = get_ops().head_major_supported(B * Nq, E, E, dh)
