@@ -43,3 +43,21 @@ tot = sum(r[0] for r in rows)
 print(f"ATen / memcpy device time in one step: {tot / 1e3:.2f} ms")
 for t, n, k, shp in rows[:70]:
     print(f"{t / 1e3:8.3f} ms {n:5d}x  {k:32s} {shp}")
+
+print()
+print("call sites of the copy / cat / add / fill ops (device time, count, innermost repo frames):")
+sites = {}
+for e in prof.events():
+    if e.name not in ("aten::copy_", "aten::cat", "aten::add_", "aten::add", "aten::fill_", "aten::zeros", "aten::contiguous",
+                      "aten::clone", "aten::index", "aten::mul", "aten::zero_"):
+        continue
+    t = getattr(e, "device_time_total", None)
+    if t is None:
+        t = e.cuda_time_total
+    frames = [f for f in (e.stack or []) if "/occformer_amd/" in f or "/bench.py" in f or "aten_profile" in f]
+    key = (e.name, tuple(f.split("/occformer_amd/")[-1][:70] for f in frames[:3]))
+    a = sites.setdefault(key, [0.0, 0])
+    a[0] += t
+    a[1] += 1
+for (name, fr), (t, n) in sorted(sites.items(), key=lambda kv: -kv[1][0])[:45]:
+    print(f"{t / 1e3:8.3f} ms {n:5d}x {name:18s} {' <- '.join(fr)}")
