@@ -317,3 +317,72 @@ def test_deform_col2im(be, groups, dg):
     dx, doff = be.ops.deform_col2im(be.to(x_cl), be.to(off.detach()), be.to(dcol), K, 1, 1, 1, groups, dg)
     assert _rel(dx.cpu().permute(0, 3, 1, 2), x.grad) < 2e-4
     assert _rel(doff.cpu(), off.grad) < 2e-4
+
+
+# ------------------------------------------------------------------------------------------ composite autograd nodes
+@pytest.fixture
+def bound_ops(be, monkeypatch):
+    import occformer_amd.ops as ops_mod
+    monkeypatch.setattr(ops_mod, "_ops", be.ops)
+    return be
+
+
+def test_inproj_node_matches_three_linears(bound_ops):
+    """autograd.InProj (one node for nn.MultiheadAttention's q / k / v projections) == F.linear on the three blocks of
+    in_proj_weight, forward and every gradient; xq is also used as xk (self-attention passes the same tensor twice)"""
+    from occformer_amd import autograd as A
+    be = bound_ops
+    E, Q, L = 64, 9, 37
+    W = _t("ip_w", (3 * E, E), 1, E ** -0.5)
+    b = _t("ip_b", (3 * E,), 2, 0.3)
+    xq, xv = _t("ip_xq", (2, Q, E), 3), _t("ip_xv", (2, L, E), 4)
+    gq, gk, gv = _t("ip_gq", (2, Q, E), 5), _t("ip_gk", (2, Q, E), 6), _t("ip_gv", (2, L, E), 7)
+    Wr, br, xqr, xvr = (t.clone().requires_grad_() for t in (W, b, xq, xv))
+    (F.linear(xqr, Wr[:E], br[:E]) * gq).sum().add((F.linear(xqr, Wr[E:2 * E], br[E:2 * E]) * gk).sum()).add(
+        (F.linear(xvr, Wr[2 * E:], br[2 * E:]) * gv).sum()).backward()
+    Wd = torch.nn.Parameter(be.to(W))
+    bd = torch.nn.Parameter(be.to(b))
+    xqd, xvd = be.to(xq).requires_grad_(), be.to(xv).requires_grad_()
+    q, k, v = A.InProj.apply(xqd, xqd, xvd, Wd, bd)
+    assert _rel(q.detach().cpu(), F.linear(xq, W[:E], b[:E])) < 1e-5
+    assert _rel(v.detach().cpu(), F.linear(xv, W[2 * E:], b[2 * E:])) < 1e-5
+    ((q * be.to(gq)).sum() + (k * be.to(gk)).sum() + (v * be.to(gv)).sum()).backward()
+    assert _rel(Wd.grad.cpu(), Wr.grad) < 1e-4 and _rel(bd.grad.cpu(), br.grad) < 1e-5
+    assert _rel(xqd.grad.cpu(), xqr.grad) < 1e-4 and _rel(xvd.grad.cpu(), xvr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("align,pad", [(False, "border"), (True, "zeros")])
+def test_sampled_mask_logits_joint_matches_dense_autograd(bound_ops, align, pad):
+    """autograd.SampledMaskLogitsJoint over three prediction sets == torch.autograd through the DENSE formulation the
+    reference uses (einsum('qc,cxyz->qxyz') -> grid_sample at the points): sampled values, d(mask_embed rows) of
+    every set and the ONE summed d(mask features)"""
+    from occformer_amd import autograd as A
+    be = bound_ops
+    X, Y, Z, E, P = 5, 4, 3, 16, 40
+    V = X * Y * Z
+    feat = _t("smj_feat", (V, E), 1)
+    sets = [(3, 11), (1, 12), (5, 13)]                      # (matched rows, seed)
+    embeds = [_t("smj_e", (n, E), s) for n, s in sets]
+    pts = [paramgen.uniform("smj_p", (n, P, 3), s) * 1.2 - 0.1 for n, s in sets]
+    douts = [_t("smj_d", (n, P), s + 50) for n, s in sets]
+    fr = feat.clone().requires_grad_()
+    ers = [e.clone().requires_grad_() for e in embeds]
+    total = 0
+    refs = []
+    for e, p, d in zip(ers, pts, douts):
+        dense = (e @ fr.t()).view(e.shape[0], 1, X, Y, Z)
+        smp = F.grid_sample(dense, (p * 2 - 1).view(e.shape[0], P, 1, 1, 3), mode="bilinear", padding_mode=pad,
+                            align_corners=align).view(e.shape[0], P)
+        refs.append(smp.detach())
+        total = total + (smp * d).sum()
+    total.backward()
+    fd = be.to(feat).requires_grad_()
+    eds = [be.to(e).requires_grad_() for e in embeds]
+    vols = [(e.detach() @ fd.detach().t()).view(e.shape[0], X, Y, Z) for e in eds]      # detached logits of the rows
+    outs = A.SampledMaskLogitsJoint.apply(fd, align, pad, len(sets), *vols, *eds, *[be.to(p) for p in pts])
+    for o, r in zip(outs, refs):
+        assert _rel(o.detach().cpu(), r) < 1e-5
+    sum((o * be.to(d)).sum() for o, d in zip(outs, douts)).backward()
+    assert _rel(fd.grad.cpu(), fr.grad) < 2e-4
+    for ed, er in zip(eds, ers):
+        assert _rel(ed.grad.cpu(), er.grad) < 2e-4
