@@ -56,22 +56,44 @@ class DeviceRNG:
 
 # ------------------------------------------------------------------------------------------ lazy mask logits
 class LazyMask:
-    """The mask logits of one prediction set in the training step: ``dense`` [B, Q, X, Y, Z] are the materialised,
-    DETACHED logits (what target assignment, importance sampling and the attention masks read -- none of them
-    carries a gradient in the reference either); the differentiable route to the parameters goes through
-    ``embed`` [B, Q, E] (mask_embed output) and ``feat_tok`` [B, V, E] (channels-last mask features) by
-    ``autograd.SampledMaskLogits``: einsum('bqc,bcxyz->bqxyz') followed by point sampling is linear in both, so the
-    dense [B, Q, X, Y, Z] gradient of the reference never has to exist.  Indexing by image gives the per-image view."""
+    """The mask logits of one prediction set in the training step.  ``dense`` [B, Q, X, Y, Z] are the DETACHED logits
+    (what target assignment, importance sampling and the attention masks read -- none of them carries a gradient in
+    the reference either); the differentiable route to the parameters goes through ``embed`` [B, Q, E] (mask_embed
+    output) and ``feat_tok`` [B, V, E] (channels-last mask features) by ``autograd.SampledMaskLogits(Joint)``:
+    einsum('bqc,bcxyz->bqxyz') followed by point sampling is linear in both, so the dense [B, Q, X, Y, Z] gradient of
+    the reference never has to exist.  The dense logits themselves are LAZY as well: the attention mask comes from the
+    fused contraction + pooling kernel, the matching cost from sampled mask features, and only the ~20 matched rows
+    of a set (``rows``) -- or, for the last set's lidarseg metric, the whole volume (``dense``) -- are contracted on
+    demand (256 MB per set at the 200-grid otherwise).  Indexing by image gives the per-image view."""
 
-    def __init__(self, dense, embed, feat_tok):
-        self.dense, self.embed, self.feat_tok = dense, embed, feat_tok
+    def __init__(self, dense, embed, feat_tok, vol_shape=None, feat_split=None):
+        self._dense, self.embed, self.feat_tok = dense, embed, feat_tok
+        self.vol_shape = tuple(int(v) for v in (vol_shape if vol_shape is not None else dense.shape[-3:]))
+        self.feat_split = feat_split
 
     @property
     def shape(self):
-        return self.dense.shape
+        return tuple(self.embed.shape[:-1]) + self.vol_shape
+
+    def _contract(self, embed_rows, feat, split):
+        """[n, E] x [V, E]^T -> [n, X, Y, Z] detached"""
+        out = get_ops().linear(embed_rows.detach().contiguous(), feat.detach(), None, w_split=split, allow_small=False)
+        return out.view(embed_rows.shape[0], *self.vol_shape)
+
+    @property
+    def dense(self):
+        if self._dense is None:
+            with torch.no_grad():
+                if self.embed.dim() == 2:
+                    self._dense = self._contract(self.embed, self.feat_tok, self.feat_split)
+                else:
+                    self._dense = torch.stack([self[b].dense for b in range(self.embed.shape[0])])
+        return self._dense
 
     def __getitem__(self, b):
-        return LazyMask(self.dense[b], self.embed[b], _image(self.feat_tok, b))
+        sp = None if self.feat_split is None else (self.feat_split[0][b], self.feat_split[1][b])
+        return LazyMask(None if self._dense is None else self._dense[b], self.embed[b], _image(self.feat_tok, b),
+                        self.vol_shape, sp)
 
     def sample_all(self, coords, align_corners=False, padding_mode="zeros"):
         """(one image) logits of all Q queries at ``coords`` [P, 3] -> [Q, P], no gradient: the logits are
@@ -80,15 +102,21 @@ class LazyMask:
         [Q, X, Y, Z] logits would be gathered 8 x Q times per point, 4 scattered bytes each (HBM-bound, 290 us per
         prediction set at the 200-grid)."""
         ops = get_ops()
-        X, Y, Z = self.dense.shape[-3:]
-        f = ops.point_sample_tokens(self.feat_tok.detach(), (X, Y, Z), coords.contiguous(), align_corners, padding_mode)
+        f = ops.point_sample_tokens(self.feat_tok.detach(), self.vol_shape, coords.contiguous(), align_corners,
+                                    padding_mode)
         return ops.linear(self.embed.detach().contiguous(), f, None, allow_small=False)      # [Q, P]
 
     def rows(self, idx_per_image):
         """matched rows: idx_per_image[b] = query indices of image b (ascending) -> LazyRows"""
-        return LazyRows([self.dense[b][i] for b, i in enumerate(idx_per_image)],
-                        [self.embed[b][i] for b, i in enumerate(idx_per_image)],
-                        [_image(self.feat_tok, b) for b in range(len(idx_per_image))])
+        dense, embed, feat = [], [], []
+        for b, i in enumerate(idx_per_image):
+            img = self[b]
+            e = img.embed[i]
+            with torch.no_grad():
+                dense.append(img._dense[i] if img._dense is not None else img._contract(e, img.feat_tok, img.feat_split))
+            embed.append(e)
+            feat.append(img.feat_tok)
+        return LazyRows(dense, embed, feat)
 
 
 def _image(t, b):
@@ -548,7 +576,8 @@ class NuscTrainingMixin(OccHeadTrainingMixin):
             coords = coords[rng.randperm(coords.shape[0]).to(coords.device)[:n_lidar]]
         coords = torch.cat((coords, rng.rand(self.num_points - n_lidar, 3).to(coords)), 0)[:, [2, 1, 0]]
         lazy = mask_pred if isinstance(mask_pred, LazyMask) else None
-        cls_score, mask_pred = cls_score.detach(), _dense(mask_pred)        # targets carry no gradient
+        cls_score = cls_score.detach()                                       # targets carry no gradient
+        mask_pred = None if lazy is not None else _dense(mask_pred)
         if lazy is not None:
             pred_pts = lazy.sample_all(coords, False, self.padding_mode)
         else:
@@ -629,7 +658,8 @@ class KittiTrainingMixin(OccHeadTrainingMixin):
         idx, coords = sample_valid_coords_with_frequencies(self.num_points, gt_labels, gt_masks, self.sample_weights,
                                                            self._rng(cls_score.device))
         lazy = mask_pred if isinstance(mask_pred, LazyMask) else None
-        cls_score, mask_pred = cls_score.detach(), _dense(mask_pred)        # targets carry no gradient
+        cls_score = cls_score.detach()                                       # targets carry no gradient
+        mask_pred = None if lazy is not None else _dense(mask_pred)
         if lazy is not None:
             pred_pts = lazy.sample_all(coords[0][:, [2, 1, 0]], self.align_corners, "zeros")
         else:
