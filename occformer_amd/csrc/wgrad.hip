@@ -508,6 +508,24 @@ static int wg_pick_splits(long M, int N, int Cin, int taps, int BC) {
   }();
   // measured (scripts/bwd_probe.py, r02 probes): the 27-tap convolutions want ~2048 workgroups (3.95 vs 4.92 ms at
   // 128 -> 128), a plain linear with 3 tiles pays for every extra slab in the reduction (0.63 ms at 512 vs 0.83)
+  if (target <= 0 && taps > 1) {
+    // convolutions: 2 workgroups per CU are resident (512 slots); choose the slab count (whole slabs per XCD: a
+    // multiple of 8) whose workgroup count fills whole rounds of 512 best, between ~1 000 and ~4 600 workgroups.
+    // Measured on the 192 -> 192 convolution (108 tiles): S = 16 (3.4 rounds) 7.85 ms, S = 40 (8.4 rounds) 7.15 ms.
+    long best_s = 0;
+    double best_e = 0.0;
+    for (long S = 8; S <= 128 && S <= chunks / 4; S += 8) {
+      const long total = tiles * S;
+      if (total < 1024 && S + 8 <= 128 && S + 8 <= chunks / 4) continue;
+      if (total > 4608 && best_s) break;
+      const double e = (double)total / (double)(((total + 511) / 512) * 512);
+      if (e > best_e + 0.01) {
+        best_e = e;
+        best_s = S;
+      }
+    }
+    if (best_s) return (int)best_s;
+  }
   const int tgt = target > 0 ? target : (taps > 1 ? 2048 : 512);
   long S = (tgt + tiles - 1) / tiles;
   if (S > chunks / 4) S = chunks / 4;
