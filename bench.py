@@ -1,18 +1,21 @@
 #!/usr/bin/env python
-"""bench.py -- OccFormer forward hot path on MI355X.
+"""bench.py -- the OccFormer hot path on MI355X.
 
-One "step" = one pass of the hot path over one synthetic nuScenes sample (6 cameras):
-image-neck features [1,6,512,16,44] + camera calibration + 34 720 LiDAR points ->
-LSS voxel pooling -> dual-path 3-D encoder -> 3-D deformable pixel decoder -> Mask2Former
-occupancy decoder (`simple_test`: occupancy volume [1,17,400,400,32] + lidarseg points), on
-BASELINE.json's 200x200x16 grid.  Weights are random (seeded), data synthetic.
+One "step" (default, ``--mode train`` = BASELINE.json's fwd+bwd metric) = one TRAINING step of the hot path over one
+synthetic nuScenes sample (6 cameras): image-neck features [1,6,512,16,44] + camera calibration + sparse LiDAR depth
++ occupancy ground truth [200,200,16] + 34 720 labelled LiDAR points -> ``OccupancyFormer.forward_train`` (LSS voxel
+pooling -> dual-path 3-D encoder -> 3-D deformable pixel decoder -> Mask2Former occupancy decoder -> Hungarian targets,
+point-sampled losses, depth loss) -> ``sum(losses).backward()`` on the library's backward kernels -> (DDP gradient
+all-reduce over RCCL for N > 1) -> grad-clip -> fused AdamW, on BASELINE.json's 200x200x16 grid.  ``--mode forward``
+times the inference hot path (`simple_test`: occupancy volume [1,17,400,400,32] + lidarseg points).  Weights are
+random (seeded), data synthetic.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant
-hand-written kernel, HIP-event timed on the launching stream) and `cpu_baseline` (the CPU
-oracle = restated reference path, timed on the host cores, N=1 only).
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant hand-written kernel, HIP-event
+timed on the launching stream; `traffic` from the committed rocprofv3 --pmc summary of the same kernel sources) and
+`cpu_baseline` (the CPU oracle = restated reference path, timed on the host cores, N=1 only).
 """
 import argparse
 import json
