@@ -147,3 +147,36 @@ def test_hungarian_structured_costs(be):
         assert float(cost[p][q, torch.arange(cost.shape[2])].sum()) == float(cost[p].numpy()[r, c].sum())
         assert torch.equal(assigned[p][q], torch.arange(cost.shape[2], dtype=torch.int32) + 1)
         assert int((assigned[p] > 0).sum()) == cost.shape[2]
+
+
+def test_lazy_mask_contracts_on_demand(be):
+    """training.LazyMask without materialised logits: ``dense``, the matched ``rows`` and the per-image view are the
+    einsum('bqc,bcxyz->bqxyz') contraction (mask2former_nusc_occ.py:455), computed only when asked for"""
+    from occformer_amd.training import LazyMask
+    import occformer_amd.ops as ops_mod
+    B, Q, E, X, Y, Z = 2, 6, 32, 4, 3, 2
+    embed = paramgen.tensor("lm_e", (B, Q, E), 1)
+    feat = paramgen.tensor("lm_f", (B, X * Y * Z, E), 2)
+    ref = torch.einsum("bqc,bvc->bqv", embed, feat).view(B, Q, X, Y, Z)
+    saved = ops_mod._ops
+    ops_mod._ops = be.ops
+    try:
+        fd = be.to(feat)
+        split = None if be.ops.precision == "f32" else be.ops.split_bf16(fd)
+        lazy = LazyMask(None, be.to(embed), fd, (X, Y, Z), split)
+        assert lazy._dense is None and tuple(lazy.shape) == (B, Q, X, Y, Z)
+        rows = lazy.rows([torch.tensor([1, 4], device=be.device), torch.tensor([0], device=be.device)])
+        assert lazy._dense is None, "matched rows must not materialise the whole volume"
+        assert rows.dense.shape == (3, X, Y, Z)
+        got = rows.dense.cpu()
+        want = torch.cat((ref[0][[1, 4]], ref[1][[0]]), 0)
+        assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+        img1 = lazy[1]
+        assert float((img1.dense.cpu() - ref[1]).abs().max()) <= 1e-4 * float(ref.abs().max())
+        assert float((lazy.dense.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+        # an eagerly materialised LazyMask behaves the same
+        eager = LazyMask(be.to(ref), be.to(embed), fd)
+        assert torch.equal(eager.rows([torch.tensor([2], device=be.device), torch.tensor([5], device=be.device)]).dense.cpu(),
+                           torch.cat((ref[0][[2]], ref[1][[5]]), 0))
+    finally:
+        ops_mod._ops = saved
