@@ -113,7 +113,12 @@ class LazyMask:
             img = self[b]
             e = img.embed[i]
             with torch.no_grad():
-                dense.append(img._dense[i] if img._dense is not None else img._contract(e, img.feat_tok, img.feat_split))
+                if img._dense is not None:
+                    dense.append(img._dense[i])
+                elif e.shape[0] == 0:                       # an image without a matched query
+                    dense.append(e.new_zeros((0,) + self.vol_shape))
+                else:
+                    dense.append(img._contract(e, img.feat_tok, img.feat_split))
             embed.append(e)
             feat.append(img.feat_tok)
         return LazyRows(dense, embed, feat)
