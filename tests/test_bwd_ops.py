@@ -386,3 +386,37 @@ def test_sampled_mask_logits_joint_matches_dense_autograd(bound_ops, align, pad)
     assert _rel(fd.grad.cpu(), fr.grad) < 2e-4
     for ed, er in zip(eds, ers):
         assert _rel(ed.grad.cpu(), er.grad) < 2e-4
+
+
+def test_depthnet_training_convs_on_the_library_kernels(bound_ops, monkeypatch):
+    """OCCF_DEPTHNET_LIB=1: DepthNet's training-mode 2-D convolutions on the library's kernel pairs give the same
+    output and the same parameter gradients as the ATen / MIOpen graph (ViewTransformerLSSBEVDepth.py:450-504)"""
+    import occformer_amd.view_transformer as vt
+    be = bound_ops
+    torch.manual_seed(0)
+    net = vt.DepthNet(32, 32, 16, 12, cam_channels=27)
+    sd = paramgen.fill_state_dict(net.state_dict(), 5)
+    net.load_state_dict(sd)
+    x = paramgen.tensor("dn_x", (3, 32, 6, 10), 1)
+    m = paramgen.tensor("dn_m", (3, 27), 2)
+    g = paramgen.tensor("dn_g", (3, 28, 6, 10), 3)
+
+    def run(lib):
+        monkeypatch.setattr(vt, "_DEPTHNET_LIB", lib)
+        n = vt.DepthNet(32, 32, 16, 12, cam_channels=27)
+        n.load_state_dict(sd)
+        n = n.to(be.device).train()
+        for mod in n.modules():                            # (dropout off: this test is about the convolutions)
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        xd = be.to(x).requires_grad_()
+        y = n(xd, be.to(m))
+        (y * be.to(g)).sum().backward()
+        return y.detach().cpu(), xd.grad.cpu(), {k: p.grad.cpu() for k, p in n.named_parameters() if p.grad is not None}
+
+    y0, dx0, g0 = run(False)
+    y1, dx1, g1 = run(True)
+    assert _rel(y1, y0) < 2e-4 and _rel(dx1, dx0) < 2e-3
+    num = sum(float((g1[k] - g0[k]).norm() ** 2) for k in g0)
+    den = sum(float(g0[k].norm() ** 2) for k in g0)
+    assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
