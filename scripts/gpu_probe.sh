@@ -2,4 +2,4 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-timeout 600 python -m pytest tests/test_train_ops.py -m gpu -q -p no:cacheprovider 2>&1 | tail -1
+timeout 600 python -m pytest tests/test_bwd_ops.py -m gpu -q -p no:cacheprovider -k "depthnet or inproj or joint" 2>&1 | tail -3
