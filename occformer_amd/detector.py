@@ -302,6 +302,8 @@ class OccupancyFormer(nn.Module):
         the path runs as a graph of forward / backward kernel pairs (occformer_amd/autograd.py), so the returned
         losses carry ``grad_fn`` and ``sum(losses).backward()`` produces every parameter gradient -- the reference's
         training step.  In ``eval()`` mode the fused inference kernels run and the losses are plain values."""
+        from . import fused
+        fused.invalidate_caches()       # a new step: weight layouts / bf16 splits are rebuilt once (fused.py, _EPOCH)
         voxel_feats, img_feats, depth = self.extract_feat(points=None, img=img_inputs, img_metas=img_metas)
         losses = {"loss_depth": self.img_view_transformer.get_depth_loss(img_inputs[7], depth)}
         losses.update(self.pts_bbox_head.forward_train(voxel_feats=voxel_feats, img_metas=img_metas, gt_occ=gt_occ,

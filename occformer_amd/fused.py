@@ -1,28 +1,81 @@
 """Host-side helpers that bind nn.Module parameters (kept in the reference's layout and
 names for checkpoint compatibility) to the channels-last HIP kernels."""
+import os
+import weakref
+
 import torch
 
 from .ops import get_ops
 
-import weakref
-
 _TAP_CACHE = {}
 _SPLIT_CACHE = {}
 
+# ---- validity of everything derived from parameter VALUES (bf16 hi/lo splits, tap-major / transposed / flipped
+# layouts, folded BatchNorms, stacked projections, positional projections) ---------------------------------------
+# ``param._version`` alone is NOT a valid key: in-place updates that go through ``.data`` or through the fused
+# optimizer kernels (torch.optim.AdamW(fused=True): _fused_adamw_ mutates the storage without a version bump on this
+# torch build) leave it unchanged.  Every derived value is therefore also keyed on a process-wide EPOCH that is bumped
+#   * after every ``torch.optim.Optimizer.step`` (a global post-step hook, registered below at import),
+#   * at the start of every ``OccupancyFormer.forward_train`` call (one "prepare weights" pass per training step:
+#     each weight is re-laid / re-split once, on first use, by the kernels in gemm_bf16.hip -- covers hand-written
+#     update loops that touch ``p.data``),
+#   * by ``invalidate_caches()`` (public; call it after any other out-of-band write to a parameter).
+# ``OCCF_CACHE_CHECK=1`` additionally stores a content checksum with every entry and asserts it on every hit
+# (device-side ``torch._assert_async``: no host sync), to catch writers that bypass all of the above.
+_EPOCH = [0]
+_CHECK = os.environ.get("OCCF_CACHE_CHECK", "0") == "1"
+
+
+def invalidate_caches():
+    """declare every parameter-derived cache entry stale (cheap: a counter bump; entries are rebuilt on next use)"""
+    _EPOCH[0] += 1
+
+
+def epoch():
+    return _EPOCH[0]
+
+
+def param_version(*params):
+    """cache key component for values derived from ``params`` -- use this, never ``_version`` alone"""
+    return tuple((p._version, p.data_ptr()) for p in params) + (_EPOCH[0],)
+
+
+def _post_step_hook(optimizer, args, kwargs):
+    invalidate_caches()
+
+
+try:        # every torch optimizer instance, present and future, in this process
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg
+    _hook_handle = _reg(_post_step_hook)
+except ImportError:      # pragma: no cover  (torch < 2.0)
+    _hook_handle = None
+
+
+def _checksum(param):
+    p = param.detach()
+    return torch.stack((p.double().sum(), p.double().abs().sum()))
+
 
 def _versioned(cache, param, make):
-    """value derived from a Parameter, recomputed when the parameter changes (its ``_version``
-    bumps on optimizer steps / load_state_dict) or when ``id(param)`` gets reused."""
+    """value derived from a Parameter, recomputed when the parameter may have changed: its ``_version`` bumped
+    (load_state_dict, foreach optimizers), the process-wide epoch moved (see above), or ``id(param)`` got reused."""
     if not param.is_leaf:
         return make()                   # a graph intermediate (e.g. two weights concatenated per step): never cached
     key = id(param)
     hit = cache.get(key)
-    ver = (param._version, param.data_ptr())
+    ver = (param._version, param.data_ptr(), _EPOCH[0])
     if hit is not None and hit[0] == ver and hit[2]() is param:
+        if _CHECK:
+            torch._assert_async(bool_all(hit[3] == _checksum(param)),
+                                "occformer_amd: a cached weight layout is stale (parameter written behind the cache)")
         return hit[1]
     val = make()
-    cache[key] = (ver, val, weakref.ref(param))
+    cache[key] = (ver, val, weakref.ref(param), _checksum(param) if _CHECK else None)
     return val
+
+
+def bool_all(t):
+    return t.all()
 
 
 def split_weight(param, as_2d=None):
@@ -98,7 +151,7 @@ def conv_bn(x_cl, conv_mod, bn=None, act=0, residual=None):
     w = conv_mod.weight
     deps = [w] + ([] if conv_mod.bias is None else [conv_mod.bias]) + \
         ([] if bn is None else [bn.weight, bn.bias, bn.running_mean, bn.running_var])
-    ver = tuple((t._version, t.data_ptr()) for t in deps) + (ops.precision, id(ops))
+    ver = param_version(*deps) + (ops.precision, id(ops))
     hit = _FOLD_CACHE.get(id(w))
     if hit is None or hit[0] != ver or hit[2]() is not w:
         with torch.no_grad():

@@ -245,7 +245,7 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
             return None
         params = [l.attentions[0].attn.in_proj_weight for l in layers] + \
                  [l.attentions[0].attn.in_proj_bias for l in layers]
-        ver = tuple((p._version, p.data_ptr()) for p in params) + (ops.precision, id(ops))
+        ver = fused.param_version(*params) + (ops.precision, id(ops))
         cache = getattr(self, "_kv_stack", None)
         if cache is None or cache[0] != ver:
             per_level = []

@@ -97,8 +97,7 @@ class MultiScaleDeformableAttention3D(nn.Module):
     def _offset_logit_weights(self):
         """sampling_offsets and attention_weights share their input: one fused GEMM, N = H*L*P*4."""
         a, b = self.sampling_offsets, self.attention_weights
-        key = (a.weight._version, b.weight._version, a.bias._version, b.bias._version, a.weight.data_ptr(),
-               get_ops().precision, id(get_ops()))
+        key = fused.param_version(a.weight, b.weight, a.bias, b.bias) + (get_ops().precision, id(get_ops()))
         if getattr(self, "_fused_key", None) != key:
             self._fused_w = torch.cat((a.weight.detach(), b.weight.detach()), 0).contiguous()
             self._fused_b = torch.cat((a.bias.detach(), b.bias.detach()), 0).contiguous()
@@ -267,7 +266,7 @@ class MSDeformAttnPixelDecoder3D(nn.Module):
             shapes.append(shp)
         x = torch.cat(toks, 1).contiguous()
         lw = self.level_encoding.weight
-        pkey = (tuple(shapes), B, lw._version, lw.data_ptr(), str(x.device))
+        pkey = (tuple(shapes), B, fused.param_version(lw), str(x.device))
         if self.training:
             pos = torch.cat(poss, 1).contiguous()        # carries the level-encoding gradient
         else:

@@ -393,7 +393,8 @@ def train_step(sd, img_feats, cams, gt_depths, gt_occ, points, cfg, rng=None, dr
     g = cfg.get("groups", 32)
     with O.training_mode(rng, drop_path, aspp_drop, depth_aspp_drop):
         vox, depth = O.view_transformer(params, "img_view_transformer.", img_feats, cams, cfg["D"], cfg["C"])
-        enc = O.occupancy_encoder(params, "img_bev_encoder_backbone.", vox, groups=g)
+        enc = O.occupancy_encoder(params, "img_bev_encoder_backbone.", vox, groups=g,
+                                  block_numbers=cfg.get("block_numbers", (2, 2, 2, 2)))
         dec = O.pixel_decoder(params, "img_bev_encoder_neck.", enc, groups=g, num_layers=cfg.get("pd_layers", 6))
         cls_list, mask_list = O.mask2former_head(params, "pts_bbox_head.", dec, heads=cfg.get("heads", 6),
                                                  num_layers=cfg.get("dec_layers", 9))

@@ -1,0 +1,160 @@
+"""The training LOOP of the path, not just its first step: ``torch.optim.AdamW(fused=True)`` updates
+the parameters through ``_fused_adamw_`` WITHOUT bumping ``param._version`` on this torch build, so every value derived
+from a weight (bf16 hi/lo split, tap-major / transposed / flipped layouts: occformer_amd/fused.py, autograd.py) must be
+invalidated by something else -- the process-wide epoch of ``fused.invalidate_caches`` (optimizer post-step hook +
+``forward_train`` entry).  Reference loop: projects/mmdet3d_plugin/occformer/apis/mmdet_train.py:72-80,
+projects/configs/occformer_nusc/occformer_nusc_r50_256x704.py:284-301 (AdamW + grad-clip).
+
+  * ``test_fused_adamw_invalidates_weight_caches``: the cache primitive itself, every optimizer flavour, and a
+    ``p.data`` write + ``invalidate_caches()``;
+  * ``test_linear_after_fused_adamw_steps``: one kernel pair (``A.linear``) stepped 3 times, forward vs ``F.linear``
+    on the CURRENT weights after every step (was 1.5e-5 / 3.68 / 7.3 before the fix);
+  * ``test_three_fused_adamw_steps_then_oracle``: 3 steps of AdamW(fused) + clip on the (shrunk) detector, then one
+    more ``forward_train`` + backward on the UPDATED weights vs the CPU oracle on replayed noise: every loss <= 1e-3,
+    whole gradient vector <= 1e-3 relative L2 (measured before the fix: 0.63 relative on ``loss_mask``)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import occformer_amd  # noqa: F401
+import occformer_amd.ops as ops_mod
+from occformer_amd import autograd as A
+from occformer_amd import fused, noise
+from occformer_amd.registry import build_model
+from occformer_amd.training import DeviceRNG
+from oracle import occformer_train_ref as T
+from tests import paramgen, tinycfg
+from tests.golden.make_golden_train import inputs, oracle_cfg, train_cfg
+from tests.test_training import ReplayRNG
+
+TOL = 1e-3
+
+
+@pytest.fixture
+def bound(be, monkeypatch):
+    monkeypatch.setattr(ops_mod, "_ops", be.ops)
+    yield be
+    noise.set_rng(None)
+
+
+def _optimizers(params):
+    yield "adamw_fused", torch.optim.AdamW(params, lr=0.05, fused=True)
+    yield "adamw_foreach", torch.optim.AdamW(params, lr=0.05, foreach=True)
+    yield "sgd", torch.optim.SGD(params, lr=0.05)
+
+
+def test_fused_adamw_invalidates_weight_caches():
+    for name, _ in _optimizers([torch.nn.Parameter(torch.zeros(1))]):
+        p = torch.nn.Parameter(torch.arange(12.0).view(3, 4))
+        opt = dict(_optimizers([p]))[name]
+        cache = {}
+        v0 = fused._versioned(cache, p, lambda: p.detach().clone())
+        assert fused._versioned(cache, p, lambda: None) is v0               # a hit while nothing changed
+        p.grad = torch.ones_like(p)
+        opt.step()
+        v1 = fused._versioned(cache, p, lambda: p.detach().clone())
+        assert v1 is not v0 and torch.equal(v1, p.detach()), name
+    # out-of-band write: .data bypasses the version counter and no optimizer is involved
+    p = torch.nn.Parameter(torch.ones(4))
+    cache = {}
+    fused._versioned(cache, p, lambda: p.detach().clone())
+    p.data.mul_(2.0)
+    fused.invalidate_caches()
+    assert torch.equal(fused._versioned(cache, p, lambda: p.detach().clone()), p.detach())
+
+
+def test_linear_after_fused_adamw_steps(bound):
+    d = bound.device
+    lin = torch.nn.Linear(64, 96).to(d)
+    x = paramgen.tensor("ms_lin_x", (256, 64), 3).to(d).requires_grad_(True)
+    opt = torch.optim.AdamW(lin.parameters(), lr=0.05, fused=True)
+    for step in range(4):
+        y = A.linear(x, lin)
+        ref = F.linear(x.detach(), lin.weight.detach(), lin.bias.detach())
+        err = float((y.detach() - ref).abs().max())
+        assert err < 2e-4, (step, err)
+        opt.zero_grad(set_to_none=True)
+        (y * y).mean().backward()
+        gx = x.grad.clone()
+        x.grad = None
+        # the data gradient reads W^T (another cached layout): check it against autograd of the plain formulation
+        xr = x.detach().clone().requires_grad_(True)
+        (F.linear(xr, lin.weight.detach(), lin.bias.detach()) ** 2).mean().backward()
+        assert float((gx - xr.grad).abs().max()) < 2e-4 * max(1.0, float(xr.grad.abs().max())), step
+        opt.step()
+
+
+def _small():
+    cfg, meta = tinycfg.tiny_nusc(ncams=2)
+    cfg["pts_bbox_head"]["transformer_decoder"]["num_layers"] = 3
+    cfg["img_bev_encoder_backbone"]["block_numbers"] = [1, 1, 1, 1]
+    cfg["img_bev_encoder_neck"]["encoder"]["num_layers"] = 1
+    tc = train_cfg(num_points=64)
+    cfg["train_cfg"] = dict(pts=tc)
+    cfg["test_cfg"] = None
+    meta = dict(meta, pd_layers=1, dec_layers=3, block_numbers=(1, 1, 1, 1))
+    return cfg, meta, tc
+
+
+def small_sample(meta, r=0):
+    B, N = 1, 2
+    cams = paramgen.camera_rig(B, N, *meta["input_size"], meta["focal"], seed=30 + r)
+    x = paramgen.tensor(f"ms_x{r}", (B, N, 32, meta["fH"], meta["fW"]), 5)
+    _, _, gt_occ, pts = inputs("nusc")
+    H, W = meta["input_size"]
+    gd = paramgen.uniform(f"ms_d{r}", (B, N, H, W), 5) * 12.0
+    gd = torch.where(paramgen.uniform(f"ms_k{r}", (B, N, H, W), 6) < 0.05, gd, torch.zeros_like(gd))
+    return cams, x, gt_occ[r:r + 1], [pts[r]], gd
+
+
+def oracle_step(cfg, meta, tc, sd, cams, x, gt_occ, pts, gd, rng):
+    ocfg = dict(D=meta["D"], C=meta["C"], groups=meta["groups"], heads=meta["heads"], pd_layers=meta["pd_layers"],
+                dec_layers=meta["dec_layers"], downsample=16, block_numbers=meta["block_numbers"],
+                dbound=cfg["img_view_transformer"]["grid_config"]["dbound"], head=oracle_cfg(cfg["pts_bbox_head"], tc))
+    return T.train_step(sd, x, cams, gd, gt_occ, pts, ocfg, rng=rng)
+
+
+def test_three_fused_adamw_steps_then_oracle(bound):
+    be = bound
+    d = be.device
+    cfg, meta, tc = _small()
+    model = build_model(cfg)
+    model.load_state_dict(paramgen.fill_state_dict(model.state_dict(), 77))
+    model = model.to(d).train()
+    cams, x, gt_occ, pts, gd = small_sample(meta)
+    metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])]
+    img_inputs = [t.to(d) for t in (x, *cams)] + [gd.to(d)]
+    kw = dict(img_metas=metas, img_inputs=img_inputs, gt_occ=gt_occ.to(d), points_occ=[p.to(d) for p in pts])
+    params = [p for p in model.parameters() if p.requires_grad]
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    opt = torch.optim.AdamW(params, lr=2e-3, weight_decay=0.01, fused=True)      # the bench's optimizer, a large lr
+    noise.set_rng(DeviceRNG(d, seed=5))
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        losses = model(return_loss=True, **kw)
+        sum(v for k, v in losses.items() if "loss" in k).backward()
+        torch.nn.utils.clip_grad_norm_(params, 5.0)
+        opt.step()
+    moved = sorted(float((p.detach() - before[k]).norm() / before[k].norm().clamp_min(1e-9))
+                   for k, p in model.named_parameters() if p.requires_grad and p.dim() > 1)
+    assert moved[len(moved) // 2] > 5e-3, "the optimizer steps are too small to expose stale weight layouts"
+
+    # the 4th forward / backward on the UPDATED weights against the oracle on identical noise
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    rec = T.RecordingRNG()
+    torch.manual_seed(3)
+    ref_losses, ref_grads = oracle_step(cfg, meta, tc, sd, cams, x, gt_occ, pts, gd, rec)
+    replay = ReplayRNG(rec.tape, d)
+    noise.set_rng(replay)
+    opt.zero_grad(set_to_none=True)
+    losses = model(return_loss=True, **kw)
+    assert replay.i == len(rec.tape)
+    worst = max(abs(float(losses[k].detach()) - float(v)) / max(1.0, abs(float(v))) for k, v in ref_losses.items())
+    print("after 3 fused AdamW steps: worst relative loss difference vs the oracle", worst)
+    assert worst <= TOL, {k: (float(losses[k].detach()), float(v)) for k, v in ref_losses.items()}
+    sum(v for k, v in losses.items() if "loss" in k).backward()
+    named = dict(model.named_parameters())
+    num = sum(float((named[k].grad.cpu() - g).norm() ** 2) for k, g in ref_grads.items() if g is not None)
+    den = sum(float(g.norm() ** 2) for g in ref_grads.values() if g is not None)
+    print("whole gradient vector: relative L2 error", (num / den) ** 0.5)
+    assert (num / den) ** 0.5 < 2e-3
