@@ -213,27 +213,85 @@ def cpu_baseline_train(model, cfg, meta, img_inputs, targets):
     """The oracle's training step (train-mode forward + torch.autograd backward of the summed losses,
     oracle/occformer_train_ref.train_step) on the host cores: one sample of the same workload."""
     from oracle import occformer_train_ref as T
+    from occformer_amd import configs
     gt_occ, points, gt_depths = targets
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    head = cfg["pts_bbox_head"]
-    tc = cfg["train_cfg"]["pts"]
-    ocfg = dict(D=meta["D"], C=meta["C"], groups=32, heads=6, pd_layers=6, dec_layers=9, downsample=16,
-                dbound=cfg["img_view_transformer"]["grid_config"]["dbound"],
-                head=dict(point_cloud_range=head.get("point_cloud_range"), num_points=tc["num_points"],
-                          oversample_ratio=tc["oversample_ratio"], importance_sample_ratio=tc["importance_sample_ratio"],
-                          padding_mode="border", num_classes=head["num_occupancy_classes"],
-                          class_weight=head["loss_cls"]["class_weight"]))
+    ocfg = configs.oracle_train_cfg(cfg, meta, class_weight=model.pts_bbox_head.class_weight)
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
+    rec = T.RecordingRNG()          # every noise draw of the step is taped so that the GPU can replay it (`check`)
     t0 = time.perf_counter()
     losses, grads = T.train_step(sd, img_inputs[0].cpu(), tuple(t.cpu() for t in img_inputs[1:7]), gt_depths.cpu(),
-                                 gt_occ.cpu(), [p.cpu() for p in points], ocfg)
+                                 gt_occ.cpu(), None if points is None else [p.cpu() for p in points], ocfg, rng=rec)
     dt = time.perf_counter() - t0
     return dict(value=1.0 / dt, unit="samples/s", cores=cores, kind="port",
-                sample="1 training step (fwd + bwd) of the same workload on the CPU oracle "
+                sample="1 training step (fwd + bwd) of the same workload on the CPU oracle, on the weights the timed "
+                       "GPU steps left behind "
                        f"(oracle/occformer_train_ref.train_step, fp32, torch CPU autograd, {cores} threads): {dt:.1f} s"), \
-        {k: float(v) for k, v in losses.items()}
+        {k: float(v) for k, v in losses.items()}, grads, rec.tape
+
+
+class _Replay:
+    """feeds the GPU step the very noise draws the CPU oracle consumed (same protocol as tests/test_training.ReplayRNG)"""
+
+    def __init__(self, tape, device):
+        self.tape, self.i, self.device = tape, 0, device
+
+    def _next(self, kind, numel):
+        k, t = self.tape[self.i]
+        self.i += 1
+        if k != kind or t.numel() != numel:
+            raise RuntimeError(f"noise draw {self.i}: the GPU step asks {kind}/{numel}, the oracle drew {k}/{t.numel()}")
+        return t.to(self.device)
+
+    def rand(self, *shape):
+        import math
+        return self._next("rand", math.prod(shape)).reshape(shape)
+
+    def randperm(self, n):
+        return self._next("randperm", n)
+
+    def exponential(self, shape, dtype=torch.float32):
+        import math
+        return self._next("exponential", math.prod(shape)).reshape(tuple(shape)).float()
+
+
+def train_check(model, net_kwargs, cpu_losses, cpu_grads, tape, device):
+    """ONE more forward_train + backward on the GPU at the SAME (post-training) weights and on the oracle's taped
+    noise: the record's `losses` (GPU) and `cpu_losses` are then the same quantity, and `check` says how far apart."""
+    from occformer_amd import noise
+    replay = _Replay(tape, device)
+    noise.set_rng(replay)
+    try:
+        for p in model.parameters():
+            p.grad = None
+        losses = model(return_loss=True, **net_kwargs)
+        total = sum(v for k, v in losses.items() if "loss" in k)
+        total.backward()
+    finally:
+        noise.set_rng(None)
+    gl = {k: float(v.detach()) for k, v in losses.items()}
+    worst = max(abs(gl[k] - v) / max(1.0, abs(v)) for k, v in cpu_losses.items())
+    named = dict(model.named_parameters())
+    num = den = 0.0
+    per = []
+    for k, g in cpu_grads.items():
+        if g is None or named[k].grad is None:
+            continue
+        d = float((named[k].grad.detach().cpu() - g).norm()) ** 2
+        n = float(g.norm()) ** 2
+        num, den = num + d, den + n
+        if float(g.abs().max()) > 1e-5:
+            per.append((d / max(n, 1e-30)) ** 0.5)
+    per.sort()
+    q = lambda f: per[int(f * (len(per) - 1))] if per else None
+    return gl, dict(max_rel_loss_diff=worst, grad_rel_l2=(num / max(den, 1e-30)) ** 0.5,
+                    per_parameter_rel_l2_quantiles={"50%": q(0.5), "90%": q(0.9), "99%": q(0.99), "100%": q(1.0)},
+                    parameters_compared=len(per), noise_draws_replayed=replay.i,
+                    what="GPU forward_train + backward vs the CPU oracle's train_step: same weights (after the timed "
+                         "optimizer steps), same inputs, the oracle's noise tape replayed; losses relative to "
+                         "max(1, |loss|), gradients as relative L2 of the whole vector / per parameter")
 
 
 WORKLOAD_DESC = {
@@ -338,9 +396,11 @@ def main():
         train_inputs = list(img_inputs) + [gt_depths]
         census_ops = ("conv3d", "conv3d_wgrad", "conv3d_dgrad")
 
+        net_kwargs = dict(img_metas=metas, img_inputs=train_inputs, gt_occ=gt_occ, points_occ=gt_points)
+
         def step_train():
             opt.zero_grad(set_to_none=True)
-            losses = net(return_loss=True, img_metas=metas, img_inputs=train_inputs, gt_occ=gt_occ, points_occ=gt_points)
+            losses = net(return_loss=True, **net_kwargs)
             total = sum(v for k, v in losses.items() if "loss" in k)
             total.backward()
             torch.nn.utils.clip_grad_norm_(params, max_norm)
@@ -384,18 +444,24 @@ def main():
         shape_report(census, args.shape_report)
     stages = {k: round(1e3 * sum(v) / len(v), 3) for k, v in model.time_stats.items() if k}
 
-    # the other mode's number from the same process (informational)
-    other = None
+    # the north-star FORWARD figure from the same process (N = 1): >= 20 timed steps of the inference hot path with its
+    # own roofline (the halo convolution) -- and, below, its own check against the oracle's forward
+    forward_rec = None
     if train and rank == 0 and world == 1:
         model.eval()
-        for _ in range(2):
+        for _ in range(3):
             step_forward()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            step_forward()
-        torch.cuda.synchronize()
-        other = 5.0 / (time.perf_counter() - t1)
+        fsteps = max(20, args.steps)
+        with KernelCensus(get_ops(), only=("conv3d",)) as fcensus:
+            t1 = time.perf_counter()
+            for _ in range(fsteps):
+                res_fwd = step_forward()
+            torch.cuda.synchronize()
+            fdt = time.perf_counter() - t1
+        forward_rec = {"metric": "samples/sec forward (inference hot path, simple_test) -- north_star target >= 30",
+                       "value": fsteps / fdt, "unit": "samples/s", "steps": fsteps, "warmup": 3,
+                       "ms_per_step": 1e3 * fdt / fsteps, "roofline": roofline(fcensus, None, prec, fsteps)}
         model.train()
 
     if rank != 0:
@@ -431,15 +497,33 @@ def main():
     }
     if train:
         out["losses"] = {k: round(float(v.detach()), 5) for k, v in res_gpu.items()}
-        out["forward_samples_per_s_same_run"] = other
+        out["forward"] = forward_rec
     if world == 1 and not args.no_cpu_baseline:
         if train:
+            if forward_rec is not None:
+                model.eval()
+                fbase, res_cpu = cpu_baseline(model, meta, img_inputs, points)
+                forward_rec["cpu_baseline"] = fbase
+                res_fwd = step_forward()                   # on the same (post-training) weights the oracle just used
+                forward_rec["check"] = {
+                    "output_voxels_max_abs_err": float((res_fwd["output_voxels"][0].cpu() - res_cpu["output_voxels"]).abs().max()),
+                    "output_points_max_abs_err": None if res_cpu["output_points"] is None else float(
+                        (res_fwd["output_points"].cpu() - res_cpu["output_points"]).abs().max())}
+                del res_cpu
+                model.train()
+            cpu_leg = None
             try:
-                out["cpu_baseline"], out["cpu_losses"] = cpu_baseline_train(model, cfg, meta, img_inputs, targets)
-            except (MemoryError, RuntimeError) as e:       # host RAM: fall back to the forward leg
+                cpu_leg = cpu_baseline_train(model, cfg, meta, img_inputs, targets)
+            except MemoryError as e:       # host RAM: fall back to the forward leg
                 base, _ = cpu_baseline(model, meta, img_inputs, points)
                 base["sample"] = "FORWARD ONLY (the CPU training step did not fit: %s); " % type(e).__name__ + base["sample"]
                 out["cpu_baseline"] = base
+            if cpu_leg is not None:
+                out["cpu_baseline"], out["cpu_losses"], cpu_grads, tape = cpu_leg
+                # `losses` is re-taken on the oracle's noise so that it is comparable with `cpu_losses`
+                out["losses_last_timed_step"] = out["losses"]
+                gl, out["check"] = train_check(model, net_kwargs, out["cpu_losses"], cpu_grads, tape, device)
+                out["losses"] = {k: round(v, 5) for k, v in gl.items()}
         else:
             base, res_cpu = cpu_baseline(model, meta, img_inputs, points)
             out["cpu_baseline"] = base

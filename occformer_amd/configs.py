@@ -144,6 +144,29 @@ def oracle_cfg(meta):
     return dict(D=meta["D"], C=meta["C"], occ_size=meta["occ_size"], pc_range=meta["pc_range"], groups=32)
 
 
+def oracle_train_cfg(cfg, meta, class_weight=None):
+    """keyword dict of oracle.occformer_train_ref.train_step for a workload (``cfg`` = the model config with
+    ``train_cfg.pts``).  SemanticKITTI (``Mask2FormerOccHead``): class-guided sampling weights from the class
+    frequencies (mask2former_occ.py:96-100) and the head's class weights (``class_weight``: the built head's)."""
+    head = cfg["pts_bbox_head"]
+    tc = cfg["train_cfg"]["pts"]
+    hd = dict(point_cloud_range=head.get("point_cloud_range"), num_points=tc["num_points"],
+              oversample_ratio=tc["oversample_ratio"], importance_sample_ratio=tc["importance_sample_ratio"],
+              padding_mode="border", num_classes=head["num_occupancy_classes"],
+              class_weight=head["loss_cls"]["class_weight"] if class_weight is None else class_weight)
+    if head["type"] == "Mask2FormerOccHead":
+        import numpy as np
+        from .training import semantic_kitti_class_frequencies
+        w = 1.0 / np.asarray(semantic_kitti_class_frequencies, dtype=np.float64)
+        hd.update(align_corners=True, sample_weights=(w / w.min()) ** head.get("sample_weight_gamma", 0.25))
+    enc = cfg["img_bev_encoder_backbone"]
+    return dict(D=meta["D"], C=meta["C"], groups=meta.get("groups", 32), heads=meta.get("heads", 6),
+                pd_layers=cfg["img_bev_encoder_neck"]["encoder"]["num_layers"],
+                dec_layers=head["transformer_decoder"]["num_layers"], downsample=16,
+                block_numbers=tuple(enc.get("block_numbers", (2, 2, 2, 2))),
+                dbound=cfg["img_view_transformer"]["grid_config"]["dbound"], head=hd)
+
+
 def synthetic_sample(meta, device, seed=0):
     """seeded neck features, the 6-camera surround rig (or the one forward camera with 4x4
     intrinsics / BEV augmentation of SemanticKITTI), uniform LiDAR points.

@@ -198,8 +198,11 @@ def _dropout(x, p):
 
 # ---------------------------------------------------------------------------- DepthNet (row 2)
 def _bn(sd, p, x, eps=1e-5):
-    if _TRAIN is not None:
+    if _TRAIN is not None and x.numel() // x.shape[1] > 1:
         return F.batch_norm(x, None, None, sd[p + "weight"], sd[p + "bias"], True, 0.0, eps)
+    # (train mode with ONE value per channel -- SemanticKITTI: batch 1, one camera vector into BatchNorm1d, one pooled
+    # pixel into the image-ASPP BatchNorm2d -- has no batch variance: torch raises, the reference only runs because
+    # tools/train.py:221-223 converts to SyncBN over 8 ranks.  Per-rank semantics: the running statistics.)
     return F.batch_norm(x, sd[p + "running_mean"], sd[p + "running_var"], sd[p + "weight"],
                         sd[p + "bias"], False, 0.0, eps)
 

@@ -383,7 +383,9 @@ def train_step(sd, img_feats, cams, gt_depths, gt_occ, points, cfg, rng=None, dr
     then torch.autograd of their sum w.r.t. every trainable parameter.
     cfg: D, C, groups, heads, pd_layers, dec_layers, downsample, dbound, head (= oracle_cfg dict of the head's
     training rows: point_cloud_range, num_points, oversample_ratio, importance_sample_ratio, padding_mode,
-    num_classes, class_weight).  -> (losses dict, {name: grad})"""
+    num_classes, class_weight).  A head dict with ``sample_weights`` selects the SemanticKITTI head
+    (mask2former_occ.py:343-444: class-guided sampling, class-weighted mask losses, ``align_corners``; no LiDAR
+    points).  -> (losses dict, {name: grad})"""
     from . import occformer_ref as O
     rng = rng or GlobalTorchRNG()
     frozen = ("running_mean", "running_var", "num_batches_tracked", ".frustum", ".dx", ".bx", ".nx",
@@ -400,8 +402,11 @@ def train_step(sd, img_feats, cams, gt_depths, gt_occ, points, cfg, rng=None, dr
                                                  num_layers=cfg.get("dec_layers", 9))
     losses = {"loss_depth": depth_bce_loss(gt_depths, depth, cfg.get("downsample", 16), cfg["dbound"], cfg["D"])}
     gl, gm = zip(*[preprocess_occupancy_gt(o, cfg["head"]["num_classes"]) for o in gt_occ])
-    losses.update(head_loss(cls_list, mask_list, nusc_loss_single, list(gl), list(gm), points, cfg=cfg["head"],
-                            rng=rng))
+    if "sample_weights" in cfg["head"]:
+        losses.update(head_loss(cls_list, mask_list, kitti_loss_single, list(gl), list(gm), cfg=cfg["head"], rng=rng))
+    else:
+        losses.update(head_loss(cls_list, mask_list, nusc_loss_single, list(gl), list(gm), points, cfg=cfg["head"],
+                                rng=rng))
     names = [k for k, v in params.items() if torch.is_tensor(v) and v.requires_grad]
     grads = torch.autograd.grad(sum(losses.values()), [params[k] for k in names], allow_unused=True)
     return losses, dict(zip(names, grads))

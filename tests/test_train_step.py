@@ -112,3 +112,79 @@ def test_training_step_gradients_vs_oracle(bound):
     assert (num / den) ** 0.5 < TOL
     assert l2s[int(0.9 * (len(l2s) - 1))] < 3e-3 and l2s[-1] < 5e-2, worst[:5]
     assert all(float(named[k].grad.abs().max()) < 1e-4 for l2, mx, k, s in worst if s <= 1e-5)
+
+
+def test_kitti_training_step_gradients_vs_oracle(bound):
+    """The SemanticKITTI training graph: one camera with 4x4 intrinsics, BatchNorm layers that see ONE value
+    per channel (running statistics, see oracle.occformer_ref._bn), ``Mask2FormerOccHead`` -- class-guided multinomial
+    sampling, class-weighted BCE / Dice rows, ``align_corners=True`` point sampling -- forward_train -> backward vs
+    ``torch.autograd`` through the oracle on identical parameters, inputs and noise.  Reference:
+    mask2former_occ.py:224-292, 343-444; occupancyformer.py:132-199.
+
+    Precision.  On the host emulation the step runs in the exact-fp32 mode and must agree to 2e-4 (measured 1.4e-5 on
+    every module): that pins the GRAPH.  In the default bf16x3 mode (what the GPU leg runs) the same step measures
+    1.5e-3 on the whole vector while the head agrees to 3e-5 and every loss to 1e-5: one ReLU gate of the single
+    pixel-decoder FFN flips on a 1e-6 difference and, with one sample and one layer, weighs that much (see the
+    module docstring); the bound there is 5e-3."""
+    from occformer_amd import configs
+    be = bound
+    exact = be.kind == "emu"
+    prev = be.ops.precision
+    if exact:
+        be.ops.precision = "f32"
+    try:
+        _kitti_step(be, configs, 2e-4 if exact else 5e-3)
+    finally:
+        be.ops.precision = prev
+
+
+def _kitti_step(be, configs, whole_tol):
+    cfg, meta = tinycfg.tiny_kitti()
+    cfg["pts_bbox_head"]["transformer_decoder"]["num_layers"] = 3
+    cfg["img_bev_encoder_backbone"]["block_numbers"] = [1, 1, 1, 1]
+    cfg["img_bev_encoder_neck"]["encoder"]["num_layers"] = 1
+    tc = train_cfg(num_points=64)
+    cfg["train_cfg"] = dict(pts=tc)
+    cfg["test_cfg"] = None
+    model = build_model(cfg)
+    sd = paramgen.fill_state_dict(model.state_dict(), 78)
+    model.load_state_dict(sd)
+    B, N = 1, 1
+    cams = paramgen.camera_rig(B, N, *meta["input_size"], meta["focal"], seed=6, kitti=True)
+    x = paramgen.tensor("tk_x", (B, N, 32, meta["fH"], meta["fW"]), 5)
+    _, _, gt_occ, _ = inputs("kitti")
+    gt_occ = gt_occ[:B]
+    H, W = meta["input_size"]
+    gd = paramgen.uniform("tk_depth", (B, N, H, W), 5) * 12.0
+    gd = torch.where(paramgen.uniform("tk_depth_mask", (B, N, H, W), 6) < 0.05, gd, torch.zeros_like(gd))
+    ocfg = configs.oracle_train_cfg(cfg, meta, class_weight=model.pts_bbox_head.class_weight)
+    rec = T.RecordingRNG()
+    torch.manual_seed(4)
+    ref_losses, ref_grads = T.train_step(sd, x, cams, gd, gt_occ, None, ocfg, rng=rec)
+
+    d = be.device
+    model = model.to(d).train()
+    replay = ReplayRNG(rec.tape, d)
+    noise.set_rng(replay)
+    metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])] * B
+    losses = model.forward_train(img_metas=metas, img_inputs=[t.to(d) for t in (x, *cams)] + [gd.to(d)],
+                                 gt_occ=gt_occ.to(d), points_occ=None)
+    assert replay.i == len(rec.tape), "the product consumed a different number of noise draws than the oracle"
+    for k, v in ref_losses.items():
+        assert abs(float(losses[k].detach()) - float(v)) <= TOL * max(1.0, abs(float(v))), (k, float(losses[k].detach()), float(v))
+    sum(v for k, v in losses.items() if "loss" in k).backward()
+    named = dict(model.named_parameters())
+    per = []
+    num = den = 0.0
+    for k, g in ref_grads.items():
+        if g is None:
+            continue
+        assert named[k].grad is not None, f"no gradient reached {k}"
+        dd, nn_ = float((named[k].grad.cpu() - g).norm() ** 2), float(g.norm() ** 2)
+        num, den = num + dd, den + nn_
+        if float(g.abs().max()) > 1e-5:
+            per.append(((dd / nn_) ** 0.5, k))
+    per.sort(reverse=True)
+    print("whole gradient vector: relative L2 error", (num / den) ** 0.5, " worst parameters:", per[:5])
+    assert (num / den) ** 0.5 < whole_tol
+    assert per[0][0] < 5e-2 and per[len(per) // 10][0] < 10 * whole_tol

@@ -72,3 +72,16 @@ def tiny_nusc(ncams=3):
                 dec_layers=6, heads=E // 32, E=E, chans=chans, fH=4, fW=11, focal=140.0,
                 input_size=(64, 176), grid=(16, 16, 8))
     return copy.deepcopy(model), meta
+
+
+def tiny_kitti():
+    """SemanticKITTI form of the tiny detector (occformer_kitti.py:22-205): ONE camera with 4x4 intrinsics / BEV
+    augmentation (33 camera scalars), ``Mask2FormerOccHead`` with 20 classes and class-guided sampling."""
+    model, meta = tiny_nusc(ncams=1)
+    model["img_view_transformer"]["cam_channels"] = 33
+    head = model["pts_bbox_head"]
+    head.update(type="Mask2FormerOccHead", num_occupancy_classes=20)
+    head.pop("point_cloud_range", None)
+    head["loss_cls"] = dict(head["loss_cls"], class_weight=[1.0] * 20 + [0.1])
+    meta = dict(meta, kitti=True)
+    return copy.deepcopy(model), meta
