@@ -12,6 +12,7 @@ import occformer_amd
 from occformer_amd import _lib, configs, dist_utils
 from occformer_amd.registry import MODELS, Config, build_model
 from tests import refshim
+from tests.conftest import golden
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -223,3 +224,78 @@ def test_kitti_detector_with_image_branch_wiring(be, monkeypatch):
     assert out["output_points"] is None and torch.isfinite(out["output_voxels"]).all()
     assert {"loss_depth", "loss_cls", "loss_mask", "loss_dice"} <= set(losses)
     assert all(torch.isfinite(torch.as_tensor(v)).all() for v in losses.values())
+
+
+# ---------------------------------------------------------------- the op boundary, through the reference's own wrapper
+def _bind_stub(be):
+    """occformer_amd/integration/bev_pool_ext.py bound to the backend's library"""
+    from occformer_amd.integration import bev_pool_ext as stub
+    stub.use_library(be.ops.lib, host_tensors=(be.kind == "emu"))
+    return stub
+
+
+def test_reference_bev_pool_wrapper_runs_unmodified_over_the_stub(be):
+    """The reference's ``mmdet3d/ops/bev_pool/bev_pool.py:37-97`` imported UNMODIFIED from /root/reference, with its
+    ``from . import bev_pool_ext`` resolving to the ctypes stub of INTEGRATION.md §B bound to the library:
+    ``bev_pool()`` -> ``QuickCumsumCuda.apply`` -> ``.backward()``, bit-exact against the oracle's restatement of
+    bev_pool_cuda.cu:20-84.  Skipped where the reference tree is absent (the GPU box): there
+    ``test_bev_pool_ext_stub_replays_reference_calls`` replays the calls this wrapper made here."""
+    import os
+    from oracle import occformer_ref as O
+    from tests.golden import make_golden_bev_pool_ext as G
+    if not os.path.isdir(G.REF_DIR):
+        pytest.skip("reference tree not present on this box")
+    stub = _bind_stub(be)
+    mod = G.load_reference_wrapper(stub, name="occf_ref_bev_pool_stub")
+    feats, coords, gout, (B, D, H, W) = G.case(seed=9, n=1500, c=20)
+    f = feats.to(be.device).requires_grad_(True)
+    y = mod.bev_pool(f, coords.to(be.device), B, D, H, W)                      # the reference's entry point
+    (y * gout.to(be.device)).sum().backward()
+    # oracle: same ranks / stable order as the wrapper computes them
+    ranks = coords[:, 0] * (W * D * B) + coords[:, 1] * (D * B) + coords[:, 2] * B + coords[:, 3]
+    order = ranks.argsort()
+    xs, cs, rs = feats[order], coords[order].int(), ranks[order]
+    kept = torch.ones(xs.shape[0], dtype=torch.bool)
+    kept[1:] = rs[1:] != rs[:-1]
+    starts = torch.where(kept)[0].int()
+    lengths = torch.cat((starts[1:] - starts[:-1], torch.tensor([xs.shape[0]], dtype=torch.int32) - starts[-1:]))
+    ref = torch.zeros(B, D, H, W, xs.shape[1])
+    for s, l in zip(starts.tolist(), lengths.tolist()):
+        acc = torch.zeros(xs.shape[1])
+        for r in range(s, s + l):
+            acc = acc + xs[r]
+        gx, gy, gz, gb = cs[s].tolist()
+        ref[gb, gz, gx, gy] = acc
+    assert torch.equal(y.detach().cpu(), ref.permute(0, 4, 1, 2, 3)), "forward differs from the reference kernel's sums"
+    assert torch.allclose(y.detach().cpu().permute(0, 2, 3, 4, 1), O.bev_pool_forward(xs, cs, starts, lengths, B, D, H, W),
+                          atol=1e-5, rtol=1e-6)
+    og = gout.permute(0, 2, 3, 4, 1).contiguous()
+    ref_g = torch.empty_like(feats)
+    ref_g[order] = O.bev_pool_backward(og, cs, starts, lengths)
+    assert torch.equal(f.grad.cpu(), ref_g)
+
+
+def test_bev_pool_ext_stub_replays_reference_calls(be):
+    """tests/golden/bev_pool_ext_calls.npz = the arguments the reference's ``QuickCumsumCuda`` handed to
+    ``bev_pool_ext.bev_pool_forward/backward`` and the reference kernel's results (recorded by
+    tests/golden/make_golden_bev_pool_ext.py from the unmodified reference wrapper): the stub must reproduce both,
+    bit-exact, on this backend."""
+    g = golden("bev_pool_ext_calls")
+    stub = _bind_stub(be)
+    b, d, h, w = (int(v) for v in g["bdhw"])
+    x, geom, lengths, starts, og = be.to(g["x"].contiguous(), g["geom"].int().contiguous(), g["lengths"].int(),
+                                         g["starts"].int(), g["out_grad"].contiguous())
+    out = stub.bev_pool_forward(x, geom, lengths, starts, b, d, h, w)
+    assert torch.equal(out.cpu(), g["out"])
+    xg = stub.bev_pool_backward(og, geom, lengths, starts, b, d, h, w)
+    assert torch.equal(xg.cpu(), g["x_grad"])
+
+
+def test_bev_pool_ext_stub_has_no_cpu_path():
+    import ctypes
+    from occformer_amd import _lib
+    from occformer_amd.integration import bev_pool_ext as stub
+    stub.use_library(ctypes.CDLL(_lib.LIB_PATH), host_tensors=False)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        stub.bev_pool_forward(torch.zeros(4, 8), torch.zeros(4, 4, dtype=torch.int32), torch.ones(1, dtype=torch.int32),
+                              torch.zeros(1, dtype=torch.int32), 1, 1, 2, 2)
