@@ -106,6 +106,21 @@ static inline float occf_buf_load_f32(occf_buf b, uint32_t voff, uint32_t soff) 
   return f;
 }
 static inline float occf_rcp_fast(float x) { return 1.0f / x; }
+// bounded buffer: a 16-byte load whose byte offset does not fit inside [0, nbytes) returns zeros (the hardware's
+// out-of-range rule for raw buffers) -- "load or zero" with ONE 32-bit select on the offset
+struct occf_bbuf {
+  const char* base;
+  uint32_t nbytes;
+};
+struct occf_u32x4 {
+  uint32_t x, y, z, w;
+};
+static inline occf_bbuf occf_make_bbuf(const void* p, uint32_t nbytes) { return occf_bbuf{(const char*)p, nbytes}; }
+static inline occf_u32x4 occf_bbuf_load_b128(occf_bbuf b, uint32_t voff) {
+  occf_u32x4 v = {0u, 0u, 0u, 0u};
+  if ((uint64_t)voff + 16u <= (uint64_t)b.nbytes) memcpy(&v, b.base + voff, 16);
+  return v;
+}
 #else
 typedef __amdgpu_buffer_rsrc_t occf_buf;
 __device__ __forceinline__ occf_buf occf_make_buf(const void* p) {
@@ -115,7 +130,16 @@ __device__ __forceinline__ float occf_buf_load_f32(occf_buf b, uint32_t voff, ui
   return occf_u2f(__builtin_amdgcn_raw_buffer_load_b32(b, voff, soff, 0));
 }
 __device__ __forceinline__ float occf_rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }   // 1 ulp
+typedef __amdgpu_buffer_rsrc_t occf_bbuf;
+typedef uint32_t occf_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ occf_bbuf occf_make_bbuf(const void* p, uint32_t nbytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, nbytes, 0x00020000);
+}
+__device__ __forceinline__ occf_u32x4 occf_bbuf_load_b128(occf_bbuf b, uint32_t voff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(b, voff, 0, 0);
+}
 #endif
+#define OCCF_BUF_OOB 0x80000000u        // a byte offset no bounded buffer (< 2 GiB) contains
 
 // 24-bit unsigned multiply (v_mul_u32_u24: full rate, v_mul_lo_u32 is quarter rate); operands must be < 2^24
 #ifdef OCCF_EMU

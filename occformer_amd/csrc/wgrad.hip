@@ -44,8 +44,9 @@ struct WgArgs {
   // thread and chunk, not per row, and an out-of-range row reads a 16-byte zero constant instead of being masked
   // after the load.  PMC on the 192 -> 192 convolution before: 14.9 VALU instructions per MFMA, VALU issue = 50 % of
   // all SIMD cycles (MFMA 27 %) -- the address arithmetic and the 4-dword selects of 16 loads per thread and chunk
-  int zfast;
+  int zfast;           // per-column staging with bounded buffer loads and incremental decode (kernel template ZF)
   int zshift;          // log2(Zo)
+  uint32_t ybytes, xbytes;   // sizes of ONE pre-split array (hi or lo) of dY / X in bytes (zfast == 2: < 2 GiB each)
   // xcd_tiles > 0: 1-D grid; workgroup w runs on XCD w % 8 (round-robin dispatch), so ALL (tap, tile) workgroups of one
   // M-slab are placed on ONE XCD (slab = xcd + 8 * (k / xcd_tiles), tile = k % xcd_tiles with k = w / 8): the slab's
   // dY / X rows are then fetched from HBM once into that XCD's L2 and shared by its 27 x tiles workgroups.  With the
@@ -53,6 +54,8 @@ struct WgArgs {
   // the 192 -> 192 convolution (PMC FETCH_SIZE), i.e. the kernel ran at the HBM roof, not the MFMA roof.
   int xcd_tiles;
   int n_slabs;
+  int bc;              // channel tile width (128 = 128-wide tiles + remainder tile, 64 = uniform 64-wide tiles)
+  int mix;             // remainder tiles of <= 64 columns run as 64-wide tiles (both dimensions)
   WgGeom g;
 };
 
@@ -83,37 +86,29 @@ __device__ __forceinline__ uint32_t wg_pack_hi(uint32_t a, uint32_t b) {
 #endif
 }
 
-template <int BC, int TERMS, bool PRE>
-__global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
+// One workgroup tile: TN (n, 128 or 64) x BC (c, 128 or 64) of one tap over one M-slab.  N and Cin are covered by
+// 128-wide tiles plus ONE remainder tile that is 64 wide when the remainder fits (192 = 128 + 64: no padded MFMAs;
+// with uniform 128 x 128 tiles the 192 -> 192 convolution issued 207 M MFMAs for 117 M needed -- PMC).
+template <int TN, int BC, int TERMS, bool PRE, bool ZF>
+__device__ __forceinline__ void wgrad_body(const WgArgs& p, wg_u4* __restrict__ Ah, wg_u4* __restrict__ Al,
+                                           wg_u4* __restrict__ Bh, wg_u4* __restrict__ Bl, const int n0, const int c0,
+                                           const int tap, const int slab, const bool first_c) {
+  constexpr int TI = TN / 64;                 // 32-wide tiles per wave along n
   constexpr int TC = BC / 64;                 // 32-wide tiles per wave along c
+  constexpr int QA = TN / 4;                  // column quads of the dY tile
+  constexpr int RPA = 64 * QA / 256;          // rows per thread of the dY tile (8 or 4)
   constexpr int QB = BC / 4;                  // channel quads of the X tile
   constexpr int RPT = 64 * QB / 256;          // rows per thread of the X tile (8 or 4)
-  // [8 row groups][columns] of 16-byte groups (8 bf16 = 8 consecutive rows of one column)
-  __shared__ __attribute__((aligned(16))) wg_u4 Ah[8 * 128], Al[8 * 128], Bh[8 * BC], Bl[8 * BC];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int c_tiles = (p.Cin + BC - 1) / BC;
-  int bx = blockIdx.x;
-  int slab = blockIdx.y;
-  if (p.xcd_tiles > 0) {
-    const int xcd = (int)(blockIdx.x & 7u), k = (int)(blockIdx.x >> 3);
-    slab = xcd + 8 * (k / p.xcd_tiles);
-    bx = k % p.xcd_tiles;
-    if (slab >= p.n_slabs) return;                 // (uniform over the workgroup; only when n_slabs % 8 != 0)
-  }
-  const int ct = bx % c_tiles;
-  bx /= c_tiles;
-  const int tap = bx % p.taps;
-  const int nt = bx / p.taps;
-  const int n0 = nt * 128, c0 = ct * BC;
   const long m_begin = (long)slab * p.rows_per_split;
   long m_end = m_begin + p.rows_per_split;
   if (m_end > p.M) m_end = p.M;
   const int nchunks = m_end > m_begin ? (int)((m_end - m_begin + 63) / 64) : 0;
 
   // ---- loader roles
-  const int a_c4 = tid & 31, a_rg = tid >> 5;                 // dY: 8 rows x 4 columns per thread
+  const int a_c4 = tid % QA, a_rg = tid / QA;                 // dY: RPA rows x 4 columns per thread
   const int a_col = n0 + a_c4 * 4;
   const bool a_col_ok = a_col < p.N;
   const int b_c4 = tid % QB, b_rg = tid / QB;                 // X: RPT rows x 4 channels per thread
@@ -129,57 +124,74 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
   // ---- pre-split loader roles: threads 0..127 stage the hi halves, 128..255 the lo halves; a thread owns 8 rows x
   // 8 columns (one 16-byte load per row)
   const int p_half = tid >> 7, p_t = tid & 127;
-  const int pa_c8 = p_t & 15, pa_rg = p_t >> 4;
+  constexpr int PAQ = TN / 8;                                  // 8-column groups of the dY tile
+  const int pa_c8 = p_t % PAQ, pa_rg = p_t / PAQ;
+  const bool pa_act = pa_rg < 8;
   const int pa_col = n0 + pa_c8 * 8;
-  const bool pa_ok = pa_col < p.N;
+  const bool pa_ok = pa_act && pa_col < p.N;
   constexpr int PBQ = BC / 8;                                  // 8-column groups of the X tile
   const int pb_c8 = p_t % PBQ, pb_rg = p_t / PBQ;
   const bool pb_act = pb_rg < 8;
   const int pb_ch = c0 + pb_c8 * 8;
   const bool pb_ok = pb_act && pb_ch < p.Cin;
   wg_u4 pa[8], pb[8];
+  int zc_next = -1, zc_b = 0, zc_x = 0, zc_y = 0;                      // incremental column decode (zfast == 2)
+  const int zb_z0 = ((pb_act ? pb_rg : 0) * 8) & (p.g.Zo - 1);         // (chunk bases are multiples of 64 >= Zo)
   auto load_chunk_pre = [&](int ck) __attribute__((always_inline)) {
     const long mb = m_begin + (long)ck * 64;
     const uint16_t* ya = p_half ? p.dYl : p.dYh;
     const uint16_t* xa = p_half ? p.Xl : p.Xh;
     const wg_u4 z4 = {0u, 0u, 0u, 0u};
-    if (p.zfast) {
-      const wg_u4* zp = (const wg_u4*)wg_zero16;
+    if constexpr (ZF) {
+      // bounded buffer loads ("load or zero" = one 32-bit select on the byte offset; the row stride folds into the
+      // instruction's immediate) and an INCREMENTAL column decode: PMC on the 192 -> 192 convolution counted 6.6 VALU
+      // per MFMA in this loop, ~100 of the ~320 per chunk in the two runtime divisions of the decode and ~130 in
+      // 64-bit address selects / adds of the 16 loads
+      const occf_bbuf ybuf = occf_make_bbuf(ya, p.ybytes), xbuf = occf_make_bbuf(xa, p.xbytes);
       {
-        const long m0 = mb + pa_rg * 8;
-        const uint16_t* base = ya + (m0 < p.M ? m0 : 0) * p.ldy + (pa_ok ? pa_col : 0);
+        const long m0 = mb + (pa_act ? pa_rg : 0) * 8;
+        const uint32_t off0 = pa_ok && m0 < p.M ? (uint32_t)((m0 * p.ldy + pa_col) * 2) : OCCF_BUF_OOB;
+        const uint32_t rs = (uint32_t)p.ldy * 2u;
+        const int left = (int)(m_end - m0 < 8 ? m_end - m0 : 8);       // rows of this group inside the slab
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const bool ok = pa_ok && m0 + j < m_end;
-          pa[j] = *(ok ? (const wg_u4*)(base + j * p.ldy) : zp);
-        }
+        for (int j = 0; j < 8; ++j)
+          pa[j] = __builtin_bit_cast(wg_u4, occf_bbuf_load_b128(ybuf, j < left ? off0 + (uint32_t)j * rs : OCCF_BUF_OOB));
       }
       {
+        // (zc_b, zc_x, zc_y) = the (batch, x, y) column of this thread's row group in chunk `zc_next`
+        if (zc_next != ck) {                                            // first chunk (or a re-read): decode by division
+          const long ml = mb + (pb_act ? pb_rg : 0) * 8;
+          unsigned t = (unsigned)((ml < p.M ? ml : 0) >> p.zshift);
+          zc_y = (int)(t % (unsigned)p.g.Yo);
+          t /= (unsigned)p.g.Yo;
+          zc_x = (int)(t % (unsigned)p.g.Xo);
+          zc_b = (int)(t / (unsigned)p.g.Xo);
+        }
         const long ml = mb + (pb_act ? pb_rg : 0) * 8;
-        const unsigned m = (unsigned)(ml < p.M ? ml : 0);
-        const int z0 = (int)(m & (unsigned)(p.g.Zo - 1));
-        unsigned t = m >> p.zshift;
-        const int yo = (int)(t % (unsigned)p.g.Yo);
-        t /= (unsigned)p.g.Yo;
-        const int xo = (int)(t % (unsigned)p.g.Xo);
-        const long b = t / (unsigned)p.g.Xo;
-        const int xi = xo * p.g.stride - p.g.pad_x + tdx * p.g.dil, yi = yo * p.g.stride - p.g.pad_y + tdy * p.g.dil;
-        const int zi0 = z0 * p.g.stride - p.g.pad_z + tdz * p.g.dil;
+        const int xi = zc_x * p.g.stride - p.g.pad_x + tdx * p.g.dil, yi = zc_y * p.g.stride - p.g.pad_y + tdy * p.g.dil;
         const bool okxy = pb_ok && ml < p.M && xi >= 0 && xi < p.g.Xi && yi >= 0 && yi < p.g.Yi;
-        const uint16_t* base = xa + (okxy ? b * p.g.sb + xi * p.g.sx + yi * p.g.sy + pb_ch : 0);
-        const int zstep = p.g.stride * (int)p.g.sz;
+        const int zi0 = zb_z0 * p.g.stride - p.g.pad_z + tdz * p.g.dil;
+        const uint32_t off0 = okxy ? (uint32_t)((zc_b * p.g.sb + xi * p.g.sx + yi * p.g.sy + zi0 * p.g.sz + pb_ch) * 2)
+                                   : OCCF_BUF_OOB;
+        const uint32_t zs = (uint32_t)(p.g.stride * (int)p.g.sz) * 2u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int zi = zi0 + j * p.g.stride;
-          const bool ok = okxy && (unsigned)zi < (unsigned)p.g.Zi;
-          pb[j] = *(ok ? (const wg_u4*)(base + (zi0 * (int)p.g.sz + j * zstep)) : zp);
+          const bool ok = okxy && (unsigned)(zi0 + j * p.g.stride) < (unsigned)p.g.Zi;
+          pb[j] = __builtin_bit_cast(wg_u4, occf_bbuf_load_b128(xbuf, ok ? off0 + (uint32_t)j * zs : OCCF_BUF_OOB));
+        }
+        // advance the column to the next chunk: 64 rows = 64 >> zshift columns further along y
+        zc_next = ck + 1;
+        zc_y += 64 >> p.zshift;
+        while (zc_y >= p.g.Yo) {
+          zc_y -= p.g.Yo;
+          if (++zc_x == p.g.Xo) { zc_x = 0; ++zc_b; }
         }
       }
       return;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      long m = mb + pa_rg * 8 + j;
+      long m = mb + (pa_act ? pa_rg : 0) * 8 + j;
       const bool ok = m < m_end && pa_ok;
       if (m >= p.M) m = p.M - 1;
       const wg_u4 v = *(const wg_u4*)(ya + m * p.ldy + (pa_ok ? pa_col : 0));
@@ -246,23 +258,23 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
         w.z = wg_pack_lo(br[4 * 4 + d], br[5 * 4 + d]); w.w = wg_pack_lo(br[6 * 4 + d], br[7 * 4 + d]);
       }
       if (TERMS == 3 || p_half == 0) {
-        Ad[pa_rg * 128 + wg_swz(pa_c8 * 8 + e, p.swz)] = v;
+        if (pa_act) Ad[pa_rg * TN + wg_swz(pa_c8 * 8 + e, p.swz)] = v;
         if (pb_act) Bd[pb_rg * BC + wg_swz(pb_c8 * 8 + e, p.swz)] = w;
       }
     }
   };
 
-  float4 ra[8], rb[RPT];
+  float4 ra[RPA], rb[RPT];
   auto load_chunk = [&](int ck) __attribute__((always_inline)) {
     const long mb = m_begin + (long)ck * 64;
     {
       // one base address per thread and chunk; a row outside the slice reads the 16-byte zero constant (a select on
       // the ADDRESS, two instructions, instead of four on the loaded dwords)
       const float4* zp = (const float4*)wg_zero16;
-      const long m0 = mb + a_rg * 8;
+      const long m0 = mb + a_rg * RPA;
       const float* base = p.dY + (m0 < p.M ? m0 : 0) * p.ldy + (a_col_ok ? a_col : 0);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < RPA; ++j) {
         const bool ok = a_col_ok && m0 + j < m_end;
         ra[j] = *(ok ? (const float4*)(base + j * p.ldy) : zp);
       }
@@ -311,30 +323,39 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
     }
   };
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = !PRE && p.bias_out != nullptr && tap == 0 && ct == 0;
+  const bool do_bias = !PRE && p.bias_out != nullptr && tap == 0 && first_c;
   auto store_chunk = [&]() __attribute__((always_inline)) {
-    // dY: rows a_rg*8 .. +7 of columns a_c4*4 .. +3 -> four 16-byte groups (one per column) in row group a_rg
+    // dY: rows a_rg*RPA .. of columns a_c4*4 .. +3: RPA = 8 -> four whole 16-byte groups (one per column) in row group
+    // a_rg; RPA = 4 (TN = 64) -> the thread owns half a group (rows 4*(a_rg&1) .. +3), as the X side does for BC = 64
     {
-      const float cx[4][8] = {{ra[0].x, ra[1].x, ra[2].x, ra[3].x, ra[4].x, ra[5].x, ra[6].x, ra[7].x},
-                              {ra[0].y, ra[1].y, ra[2].y, ra[3].y, ra[4].y, ra[5].y, ra[6].y, ra[7].y},
-                              {ra[0].z, ra[1].z, ra[2].z, ra[3].z, ra[4].z, ra[5].z, ra[6].z, ra[7].z},
-                              {ra[0].w, ra[1].w, ra[2].w, ra[3].w, ra[4].w, ra[5].w, ra[6].w, ra[7].w}};
+      float cx[4][RPA];
+#pragma unroll
+      for (int j = 0; j < RPA; ++j) { cx[0][j] = ra[j].x; cx[1][j] = ra[j].y; cx[2][j] = ra[j].z; cx[3][j] = ra[j].w; }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        wg_u4 h, l;
-        uint32_t hh, ll;
-        occf_bf16_split2(cx[e][0], cx[e][1], hh, ll); h.x = hh; l.x = ll;
-        occf_bf16_split2(cx[e][2], cx[e][3], hh, ll); h.y = hh; l.y = ll;
-        occf_bf16_split2(cx[e][4], cx[e][5], hh, ll); h.z = hh; l.z = ll;
-        occf_bf16_split2(cx[e][6], cx[e][7], hh, ll); h.w = hh; l.w = ll;
-        const int off = a_rg * 128 + wg_swz(a_c4 * 4 + e, p.swz);
-        Ah[off] = h;
-        if (TERMS == 3) Al[off] = l;
+        uint32_t hh[RPA / 2], ll[RPA / 2];
+#pragma unroll
+        for (int j = 0; j < RPA; j += 2) occf_bf16_split2(cx[e][j], cx[e][j + 1], hh[j / 2], ll[j / 2]);
+        if (RPA == 8) {
+          const int off = a_rg * TN + wg_swz(a_c4 * 4 + e, p.swz);
+          wg_u4 h, l;
+          h.x = hh[0]; h.y = hh[1]; h.z = hh[RPA / 2 - 2]; h.w = hh[RPA / 2 - 1];
+          l.x = ll[0]; l.y = ll[1]; l.z = ll[RPA / 2 - 2]; l.w = ll[RPA / 2 - 1];
+          Ah[off] = h;
+          if (TERMS == 3) Al[off] = l;
+        } else {
+          const int off = (a_rg >> 1) * TN + wg_swz(a_c4 * 4 + e, p.swz);
+          uint32_t* dh = (uint32_t*)(Ah + off) + (a_rg & 1) * 2;
+          uint32_t* dl = (uint32_t*)(Al + off) + (a_rg & 1) * 2;
+          dh[0] = hh[0];
+          dh[1] = hh[1];
+          if (TERMS == 3) { dl[0] = ll[0]; dl[1] = ll[1]; }
+        }
       }
     }
     if (do_bias) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { bsum[0] += ra[j].x; bsum[1] += ra[j].y; bsum[2] += ra[j].z; bsum[3] += ra[j].w; }
+      for (int j = 0; j < RPA; ++j) { bsum[0] += ra[j].x; bsum[1] += ra[j].y; bsum[2] += ra[j].z; bsum[3] += ra[j].w; }
     }
     // X: RPT = 8 -> whole 16-byte groups; RPT = 4 -> the thread owns half a group (rows 4*(b_rg&1) .. +3)
     {
@@ -365,9 +386,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
     }
   };
 
-  f32x16 acc[2][TC];
+  f32x16 acc[TI][TC];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < TC; ++j)
 #pragma unroll
@@ -379,11 +400,11 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
   auto compute = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 ah[2], al[2], bh[TC], bl[TC];
+      bf16x8 ah[TI], al[TI], bh[TC], bl[TC];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ah[i] = frag(Ah, 128, wm * 64 + i * 32 + li, ks);
-        if (TERMS == 3) al[i] = frag(Al, 128, wm * 64 + i * 32 + li, ks);
+      for (int i = 0; i < TI; ++i) {
+        ah[i] = frag(Ah, TN, wm * (TN / 2) + i * 32 + li, ks);
+        if (TERMS == 3) al[i] = frag(Al, TN, wm * (TN / 2) + i * 32 + li, ks);
       }
 #pragma unroll
       for (int j = 0; j < TC; ++j) {
@@ -391,7 +412,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
         if (TERMS == 3) bl[j] = frag(Bl, BC, wn * (BC / 2) + j * 32 + li, ks);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TC; ++j) {
           if (TERMS == 3) {
@@ -427,29 +448,72 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgArgs p) {
   const int Kt = p.taps * p.Cin;
   float* o = p.out + (long)slab * p.N * Kt;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < TC; ++j) {
       const int c = c0 + wn * (BC / 2) + j * 32 + li;
       if (c >= p.Cin) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int n = n0 + wm * (TN / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
         if (n < p.N) o[(long)n * Kt + (long)tap * p.Cin + c] = acc[i][j][r];
       }
     }
   if (do_bias) {
     __syncthreads();
-    float* red = (float*)Ah;                   // [8 row groups][128 columns]
+    constexpr int RG = 256 / QA;               // row groups of the dY loader (8 or 16)
+    float* red = (float*)Ah;                   // [RG row groups][TN columns]  (RG * TN = 1024 floats)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[a_rg * 128 + a_c4 * 4 + e] = bsum[e];
+    for (int e = 0; e < 4; ++e) red[a_rg * TN + a_c4 * 4 + e] = bsum[e];
     __syncthreads();
-    if (tid < 128 && n0 + tid < p.N) {
+    if (tid < TN && n0 + tid < p.N) {
       float s = 0.f;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) s += red[r * 128 + tid];
+      for (int r = 0; r < RG; ++r) s += red[r * TN + tid];
       p.bias_out[(long)slab * p.N + n0 + tid] = s;
     }
+  }
+}
+
+// tile table of one dimension: full 128-wide tiles, then one remainder tile (64 wide if the remainder is <= 64 and
+// mixed tiles are enabled, else 128 wide and partly masked); uniform 64-wide tiles when `w` = 64
+struct WgTiles { int count, w, rem_w; };
+__host__ __device__ __forceinline__ WgTiles wg_tiles(int n, int w, int mix) {
+  WgTiles t;
+  t.w = w;
+  if (w == 64) { t.count = (n + 63) / 64; t.rem_w = 64; return t; }
+  const int full = n / 128, rem = n % 128;
+  t.count = full + (rem ? 1 : 0);
+  t.rem_w = (rem && rem <= 64 && mix) ? 64 : 128;
+  return t;
+}
+
+template <int TERMS, bool PRE, bool ZF>
+__global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs p) {
+  // [8 row groups][columns] of 16-byte groups (8 bf16 = 8 consecutive rows of one column); sized for the 128 x 128 tile
+  __shared__ __attribute__((aligned(16))) wg_u4 Ah[8 * 128], Al[8 * 128], Bh[8 * 128], Bl[8 * 128];
+  const WgTiles tn = wg_tiles(p.N, 128, p.mix), tc = wg_tiles(p.Cin, p.bc, p.mix);
+  int bx = blockIdx.x;
+  int slab = blockIdx.y;
+  if (p.xcd_tiles > 0) {
+    const int xcd = (int)(blockIdx.x & 7u), k = (int)(blockIdx.x >> 3);
+    slab = xcd + 8 * (k / p.xcd_tiles);
+    bx = k % p.xcd_tiles;
+    if (slab >= p.n_slabs) return;                 // (uniform over the workgroup; only when n_slabs % 8 != 0)
+  }
+  const int ct = bx % tc.count;
+  bx /= tc.count;
+  const int tap = bx % p.taps;
+  const int nt = bx / p.taps;
+  const int n0 = nt * 128, c0 = ct * tc.w;
+  const int wn_ = nt == tn.count - 1 && p.N % 128 ? tn.rem_w : 128;
+  const int wc_ = tc.w == 64 ? 64 : (ct == tc.count - 1 && p.Cin % 128 ? tc.rem_w : 128);
+  if (wn_ == 128) {
+    if (wc_ == 128) wgrad_body<128, 128, TERMS, PRE, ZF>(p, Ah, Al, Bh, Bl, n0, c0, tap, slab, ct == 0);
+    else wgrad_body<128, 64, TERMS, PRE, ZF>(p, Ah, Al, Bh, Bl, n0, c0, tap, slab, ct == 0);
+  } else {
+    if (wc_ == 128) wgrad_body<64, 128, TERMS, PRE, ZF>(p, Ah, Al, Bh, Bl, n0, c0, tap, slab, ct == 0);
+    else wgrad_body<64, 64, TERMS, PRE, ZF>(p, Ah, Al, Bh, Bl, n0, c0, tap, slab, ct == 0);
   }
 }
 
@@ -499,8 +563,18 @@ __global__ void __launch_bounds__(256) wgrad_small_kernel(const float* __restric
   }
 }
 
+static int wg_mix() {
+  static const int env = [] {
+    const char* e = getenv("OCCF_WG_MIX");               // diagnostics: 0 = uniform (padded) tiles as in round 2
+    return e ? atoi(e) : 1;
+  }();
+  return env;
+}
+static long wg_tile_count(int N, int Cin, int taps, int BC) {
+  return (long)wg_tiles(N, 128, wg_mix()).count * wg_tiles(Cin, BC, wg_mix()).count * taps;
+}
 static int wg_pick_splits(long M, int N, int Cin, int taps, int BC) {
-  const long tiles = (long)occf_cdiv(N, 128) * occf_cdiv(Cin, BC) * taps;
+  const long tiles = wg_tile_count(N, Cin, taps, BC);
   const long chunks = (M + 63) / 64;
   static const int target = [] {
     const char* e = getenv("OCCF_WG_TARGET");          // diagnostics: workgroups aimed at per launch
@@ -567,7 +641,9 @@ static int wg_launch(WgArgs a, float* dW, float* db, float* workspace, long work
   a.rows_per_split = rows;
   a.out = S > 1 ? workspace : dW;
   a.bias_out = db ? (S > 1 ? workspace + (long)S * a.N * Kt : db) : nullptr;
-  const long tiles = (long)occf_cdiv(a.N, 128) * occf_cdiv(a.Cin, BC) * a.taps;
+  const long tiles = wg_tile_count(a.N, a.Cin, a.taps, BC);
+  a.bc = BC;
+  a.mix = wg_mix();
   dim3 grid((unsigned)tiles, S);
   static const int xcd_env = [] {
     const char* e = getenv("OCCF_WG_XCD");
@@ -579,19 +655,16 @@ static int wg_launch(WgArgs a, float* dW, float* db, float* workspace, long work
     grid = dim3((unsigned)(tiles * ((S + 7) / 8) * 8), 1);
   }
   const bool pre = a.dYh != nullptr;
-#define OCCF_WG_LAUNCH(BC_, T_)                                                                        \
-  do {                                                                                                 \
-    if (pre) hipLaunchKernelGGL((wgrad_kernel<BC_, T_, true>), grid, dim3(256), 0, st, a);             \
-    else hipLaunchKernelGGL((wgrad_kernel<BC_, T_, false>), grid, dim3(256), 0, st, a);                \
-  } while (0)
-  if (BC == 128) {
-    if (terms == 3) OCCF_WG_LAUNCH(128, 3);
-    else OCCF_WG_LAUNCH(128, 1);
+  if (pre && a.zfast) {
+    if (terms == 3) hipLaunchKernelGGL((wgrad_kernel<3, true, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<1, true, true>), grid, dim3(256), 0, st, a);
+  } else if (pre) {
+    if (terms == 3) hipLaunchKernelGGL((wgrad_kernel<3, true, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<1, true, false>), grid, dim3(256), 0, st, a);
   } else {
-    if (terms == 3) OCCF_WG_LAUNCH(64, 3);
-    else OCCF_WG_LAUNCH(64, 1);
+    if (terms == 3) hipLaunchKernelGGL((wgrad_kernel<3, false, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_kernel<1, false, false>), grid, dim3(256), 0, st, a);
   }
-#undef OCCF_WG_LAUNCH
   if (S > 1) {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(occf_cdiv((long)a.N * Kt, 64)), dim3(256), 0, st, workspace, dW,
                        (long)a.N * Kt, S);
@@ -691,7 +764,13 @@ extern "C" int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapm
       return e ? atoi(e) : 1;
     }();
     if (zfast_env && (g.Zo == 8 || g.Zo == 16 || g.Zo == 32 || g.Zo == 64) && a.M < 2147483647L) {
-      a.zfast = 1;
+      static const int buf_env = [] {
+        const char* e = getenv("OCCF_WG_BUFLOAD");
+        return e ? atoi(e) : 1;
+      }();
+      a.zfast = (buf_env && ny * 2 < 2147483647L && nx * 2 < 2147483647L) ? 1 : 0;
+      a.ybytes = (uint32_t)(ny * 2);
+      a.xbytes = (uint32_t)(nx * 2);
       a.zshift = g.Zo == 8 ? 3 : g.Zo == 16 ? 4 : g.Zo == 32 ? 5 : 6;
     }
   }

@@ -149,7 +149,8 @@ def test_point_loss_rows_backward(be):
     assert _rel(dx.cpu(), x.grad) < 1e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(1500, 192, 128), (2100, 128, 384), (4000, 96, 192), (100, 18, 192), (1300, 288, 64)])
+@pytest.mark.parametrize("M,N,K", [(1500, 192, 128), (2100, 128, 384), (4000, 96, 192), (100, 18, 192), (1300, 288, 64),
+                                   (1100, 192, 192), (1200, 40, 160)])
 def test_linear_wgrad(be, M, N, K):
     dy = _t("wg_dy", (M, N), M)
     x = _t("wg_x", (M, K), M + 1)
@@ -180,6 +181,10 @@ CONV_CASES = [
     (2, (5, 6, 16), 32, 64, (3, 3, 3), 1, 1),
     (1, (6, 6, 16), 64, 32, (3, 3, 3), 2, 1),
     (1, (6, 5, 8), 32, 32, (3, 3, 3), 1, 2),
+    # 192 = 128 + 64 in BOTH tile dimensions (the roofline kernel's shape: tiles 128x128, 128x64, 64x128, 64x64 of one
+    # launch, pre-split per-column staging) and 160 = 128 + 32 (a 64-wide remainder tile, half masked)
+    (1, (4, 5, 16), 192, 192, (3, 3, 3), 1, 1),
+    (1, (5, 4, 8), 160, 96, (3, 3, 3), 1, 1),
 ]
 
 
