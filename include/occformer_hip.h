@@ -463,6 +463,22 @@ int occf_deform_col2im(const float* x, const float* offset, const float* dcol, f
                        int H, int W, int C, int K, int stride, int pad, int dil, int groups, int deform_groups,
                        void* stream);
 
+/* ------------------------------------------------------------------ input pipeline / evaluation ---- */
+
+/* Replaces CreateDepthFromLiDAR.__call__ (P/datasets/pipelines/lidar2depth.py:15-87; no FFI in the reference: torch
+ * ops on the host inside the data loader).  points[P, >=3] (row stride points_ld floats), cam[N, 36] =
+ * inv(rots)[9] | trans[3] | intrins (3x3 in the first 9 of 16, or 4x4 when kitti) [16] | post_rots[:2,:2][4] |
+ * post_trans[:2][2] | pad[2]; gt_depths[N, H, W] <- nearest valid LiDAR depth per pixel, 0 where none.
+ * workspace: N*H*W uint32. */
+int occf_lidar_depth_fwd(const float* points, long points_ld, const float* cam, float* gt_depths, uint32_t* workspace,
+                         long P, int N, int H, int W, int kitti, void* stream);
+
+/* Replaces SSCMetrics.update (P/utils/ssc_metric.py:62-175).  pred[B*V] int64 labels, or scores[B, C, V] (arg-max
+ * over C taken here; apis/test.py:64); target[B*V] uint8 (255 = ignore); nonempty / nonsurface[B*V] uint8 or NULL.
+ * counts[C*C + 3] int64 are ACCUMULATED: conf[t*C + p] over the semantic mask, then completion tp, fp, fn. */
+int occf_ssc_confusion_fwd(const int64_t* pred, const float* scores, const uint8_t* target, const uint8_t* nonempty,
+                           const uint8_t* nonsurface, int64_t* counts, long B, long V, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -495,16 +495,39 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs p) {
   const WgTiles tn = wg_tiles(p.N, 128, p.mix), tc = wg_tiles(p.Cin, p.bc, p.mix);
   int bx = blockIdx.x;
   int slab = blockIdx.y;
+  int nt, ct, tap;
   if (p.xcd_tiles > 0) {
-    const int xcd = (int)(blockIdx.x & 7u), k = (int)(blockIdx.x >> 3);
-    slab = xcd + 8 * (k / p.xcd_tiles);
-    bx = k % p.xcd_tiles;
-    if (slab >= p.n_slabs) return;                 // (uniform over the workgroup; only when n_slabs % 8 != 0)
+    // All workgroups of one M-slab run on ONE XCD (workgroup w is dispatched to XCD w % 8) and share the slab's rows in
+    // that L2 -- as long as they walk the slab in step.  Tiles of different widths do not (a 64 x 64 tile stages half
+    // the bytes of a 128 x 128 tile per chunk and runs ahead): with the mixed tiles of the 192 -> 192 convolution in
+    // plain tile order the launch fetched 15 GB for 0.99 GB of operands (PMC r03b).  So the order on an XCD is
+    // CLASS-major: every (slab of this XCD, tap, tile) of the 128 x 128 class first, then 128 x 64, 64 x 128, 64 x 64 --
+    // the ~64 workgroups resident on the XCD at any time are of ONE class and a couple of slabs.
+    const int xcd = (int)(blockIdx.x & 7u);
+    int k = (int)(blockIdx.x >> 3);
+    const int sx = (p.n_slabs - xcd + 7) >> 3;                         // slabs of this XCD: xcd, xcd + 8, ...
+    const int n_small = (p.N % 128 && tn.rem_w == 64) ? 1 : 0, n_big = tn.count - n_small;
+    const int c_small = tc.w == 64 ? tc.count : ((p.Cin % 128 && tc.rem_w == 64) ? 1 : 0), c_big = tc.count - c_small;
+    const int cn[4] = {n_big, n_big, n_small, n_small}, cc[4] = {c_big, c_small, c_big, c_small};
+    int cl = 0, T = 0;
+    for (; cl < 4; ++cl) {
+      T = p.taps * cn[cl] * cc[cl];
+      if (k < sx * T) break;
+      k -= sx * T;
+    }
+    if (cl == 4) return;                           // (uniform over the workgroup: XCDs with one slab fewer)
+    slab = xcd + 8 * (k / T);
+    k %= T;
+    ct = k % cc[cl] + ((cl & 1) ? c_big : 0);
+    k /= cc[cl];
+    tap = k % p.taps;
+    nt = k / p.taps + ((cl & 2) ? n_big : 0);
+  } else {
+    ct = bx % tc.count;
+    bx /= tc.count;
+    tap = bx % p.taps;
+    nt = bx / p.taps;
   }
-  const int ct = bx % tc.count;
-  bx /= tc.count;
-  const int tap = bx % p.taps;
-  const int nt = bx / p.taps;
   const int n0 = nt * 128, c0 = ct * tc.w;
   const int wn_ = nt == tn.count - 1 && p.N % 128 ? tn.rem_w : 128;
   const int wc_ = tc.w == 64 ? 64 : (ct == tc.count - 1 && p.Cin % 128 ? tc.rem_w : 128);

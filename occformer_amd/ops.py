@@ -586,6 +586,41 @@ class HipOps:
                    self._stream())
         return match, assigned
 
+    # ------------------------------------------------------------------ input pipeline / evaluation (csrc/pipeline.hip)
+    def lidar_depth(self, points, cam, N, H, W, kitti):
+        """points [P, >=3] fp32 (rows may be wider: x, y, z, ...), cam [N, 36] packed camera constants
+        (occformer_amd.pipeline.pack_depth_cameras) -> gt_depths [N, H, W]: nearest valid LiDAR depth per pixel"""
+        pts = points if points.stride(-1) == 1 and points.dtype == self.f32 else points.to(self.f32).contiguous()
+        if pts.dim() != 2 or pts.shape[1] < 3 or pts.stride(1) != 1:
+            raise OccfError("lidar_depth: points [P, >=3] with unit column stride")
+        P = pts.shape[0]
+        out = torch.empty((N, H, W), dtype=self.f32, device=pts.device)
+        ws = torch.empty((N * H * W,), dtype=torch.int32, device=pts.device)
+        if not pts.is_contiguous():                      # a column block of a wider matrix: pass its row stride
+            base, ld = pts, pts.stride(0)
+            ptr = ctypes.c_void_p(base.data_ptr())
+            if self.strict and not base.is_cuda:
+                raise OccfError("occformer_amd ops need GPU tensors (no CPU path exists)")
+        else:
+            ptr, ld = self._ptr(pts, self.f32), pts.shape[1]
+        self._call("occf_lidar_depth_fwd", ptr, int(ld), self._ptr(cam.contiguous(), self.f32), self._ptr(out),
+                   self._ptr(ws), P, int(N), int(H), int(W), int(bool(kitti)), self._stream())
+        return out
+
+    def ssc_confusion(self, counts, target, pred=None, scores=None, nonempty=None, nonsurface=None, num_classes=None):
+        """accumulate into ``counts`` [C*C + 3] int64 (conf[t, p] then completion tp, fp, fn); target uint8 [B, ...],
+        pred int64 labels of the same shape OR scores [B, C, ...] fp32 (arg-max over C inside the kernel)"""
+        C = int(num_classes if num_classes is not None else scores.shape[1])
+        B = target.shape[0]
+        V = target.numel() // B
+        as_u8 = lambda t: None if t is None else (t if t.dtype == torch.uint8 else t.to(torch.uint8)).contiguous()
+        # (the converted copies must outlive the launch: keep them in locals, not as temporaries of the call expression)
+        tg, ne, ns = as_u8(target), as_u8(nonempty), as_u8(nonsurface)
+        pr = None if pred is None else pred.to(torch.int64).contiguous()
+        sc = None if scores is None else scores.contiguous()
+        self._call("occf_ssc_confusion_fwd", self._ptr(pr, torch.int64), self._ptr(sc, self.f32), self._ptr(tg),
+                   self._ptr(ne), self._ptr(ns), self._ptr(counts, torch.int64), int(B), int(V), C, self._stream())
+        return counts
 
     # ------------------------------------------------------------------ backward kernels (training step)
     def _ws(self, n, device):

@@ -174,6 +174,11 @@ static inline int atomicMax(int* p, int v) {
   if (v > o) *p = v;
   return o;
 }
+static inline unsigned atomicMin(unsigned* p, unsigned v) {
+  unsigned o = *p;
+  if (v < o) *p = v;
+  return o;
+}
 static inline unsigned atomicOr(unsigned* p, unsigned v) {
   unsigned o = *p;
   *p = o | v;

@@ -901,6 +901,20 @@ def install():
     real = importlib.import_module("mmdet3d.ops.bev_pool.bev_pool")
     bp.bev_pool = real.bev_pool
     _mod("mmdet3d.ops.voxel_pooling", voxel_pooling=_not_available)
+    # data-pipeline / metric modules (lidar2depth.py, ssc_metric.py): a transform registry and the part of
+    # torchmetrics.Metric that SSCMetrics uses (add_state -> attribute; single process, no sync)
+    _mod("mmdet.datasets")
+    _mod("mmdet.datasets.builder", PIPELINES=Registry("pipeline"))
+
+    class _Metric(torch.nn.Module):
+        def __init__(self, compute_on_step=False, **kw):
+            super().__init__()
+
+        def add_state(self, name, default, dist_reduce_fx=None):
+            self.register_buffer(name, default.clone())
+
+    _mod("torchmetrics")
+    _mod("torchmetrics.metric", Metric=_Metric)
 
     # package tree of the reference, pre-seeded (no __init__ execution)
     P = os.path.join(REFERENCE_ROOT, "projects", "mmdet3d_plugin")
@@ -922,6 +936,8 @@ def install():
          os.path.join(P, "occformer/mask2former/samplers")),
         ("projects.mmdet3d_plugin.occformer.mask2former.losses", os.path.join(P, "occformer/mask2former/losses")),
         ("projects.mmdet3d_plugin.utils", os.path.join(P, "utils")),
+        ("projects.mmdet3d_plugin.datasets", os.path.join(P, "datasets")),
+        ("projects.mmdet3d_plugin.datasets.pipelines", os.path.join(P, "datasets/pipelines")),
     ]:
         m = _mod(name)
         m.__path__ = [path]

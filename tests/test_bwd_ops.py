@@ -150,7 +150,9 @@ def test_point_loss_rows_backward(be):
 
 
 @pytest.mark.parametrize("M,N,K", [(1500, 192, 128), (2100, 128, 384), (4000, 96, 192), (100, 18, 192), (1300, 288, 64),
-                                   (1100, 192, 192), (1200, 40, 160)])
+                                   (1100, 192, 192), (1200, 40, 160),
+                                   # >= 8 M-slabs: the per-XCD, tile-class-major workgroup order
+                                   (9000, 192, 192), (9100, 160, 64), (8200, 320, 192)])
 def test_linear_wgrad(be, M, N, K):
     dy = _t("wg_dy", (M, N), M)
     x = _t("wg_x", (M, K), M + 1)
