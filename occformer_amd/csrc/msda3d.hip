@@ -338,8 +338,19 @@ __global__ void __launch_bounds__(256) msda3d_bwd_kernel(
         const float wx = bx ? tx : 1.f - tx, wy = by ? ty : 1.f - ty, wz = bz ? tz : 1.f - tz;
         const long key = ((long)xx * Yl + yy) * Zl + zz;
         float dot = 0.f;                                  // <dout, v[corner]> over this lane's channels
+        if (VEC % 4 == 0) {                               // (cv, Dh and E multiples of 4: 16-byte aligned rows)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) dot = fmaf(go[v], vbase[key * kstride + v], dot);
+          for (int v = 0; v < VEC; v += 4) {
+            const float4 t4 = *(const float4*)(vbase + key * kstride + v);
+            dot = fmaf(go[v], t4.x, dot);
+            dot = fmaf(go[(v + 1) % VEC], t4.y, dot);
+            dot = fmaf(go[(v + 2) % VEC], t4.z, dot);
+            dot = fmaf(go[(v + 3) % VEC], t4.w, dot);
+          }
+        } else {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) dot = fmaf(go[v], vbase[key * kstride + v], dot);
+        }
         s_acc = fmaf(wx * wy * wz, dot, s_acc);
         gx = fmaf((bx ? 1.f : -1.f) * wy * wz, dot, gx);
         gy = fmaf((by ? 1.f : -1.f) * wx * wz, dot, gy);
@@ -746,6 +757,15 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
   int vec = head_dim / lpg;
   while (vec > 6 && lpg < 8) { lpg *= 2; vec = head_dim / lpg; }
   if (head_dim % lpg != 0 || vec > 6) { lpg = 1; vec = head_dim; }
+  // Without the scatter (value gradient taken by the LDS tiles above) this pass is a pure gather + dot product like the
+  // forward, and the forward's split serves it best: 12 channels per lane, i.e. the softmax / position / corner-weight
+  // arithmetic of a (query, head) is repeated by 2 lanes instead of 8 (measured r03c; OCCF_MSDA_BWD_VEC12=0 restores
+  // the narrow split, which the atomics of the scatter want: one contiguous head row per corner)
+  static const int vec12_env = [] {
+    const char* e = getenv("OCCF_MSDA_BWD_VEC12");
+    return e ? atoi(e) : 1;
+  }();
+  if (!do_value && vec12_env && head_dim % 12 == 0 && (heads * head_dim) % 4 == 0) { vec = 12; lpg = head_dim / 12; }
   const long total = (long)B * Nq * heads * lpg;
 #define OCCF_MSDB_LAUNCH(V_, HM_)                                                                                   \
   hipLaunchKernelGGL((msda3d_bwd_kernel<V_, 16, HM_>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,        \
@@ -759,6 +779,7 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
     case 4: OCCF_MSDB_LAUNCH(4, HM_); break;   \
     case 5: OCCF_MSDB_LAUNCH(5, HM_); break;   \
     case 6: OCCF_MSDB_LAUNCH(6, HM_); break;   \
+    case 12: OCCF_MSDB_LAUNCH(12, HM_); break; \
     default: return OCCF_ESHAPE;               \
   }
   if (value_head_major) { OCCF_MSDB_VEC(true) } else { OCCF_MSDB_VEC(false) }
