@@ -978,6 +978,15 @@ __global__ void __launch_bounds__(256) xattn_dq_reduce_kernel(const float* __res
   dq[((long)b * Q + qi) * E + h * XB_HD + d] = s;
 }
 
+// matrix-core kernels (xattn_mfma.hip: forward partials = the softmax statistics; xattn_bwd_mfma.hip: dQ / dK / dV)
+void occf_xattn_mfma_launch(const float* q, const float* k, const float* v, const uint8_t* blocked, const int* row_open,
+                            float* part_o, float* part_ml, int B, int Q, int L, int E, int heads, int chunk, int n_chunks,
+                            float scale, hipStream_t st);
+void occf_xattn_bwd_mfma_launch(const float* q, const float* k, const float* v, const uint8_t* blocked,
+                                const int* row_open, const float* dout, const float* lse, const float* Dv,
+                                float* dq_part, float* dk, float* dv, int B, int Q, int L, int E, int heads, int chunk,
+                                int n_chunks, float scale, hipStream_t st);
+
 static void xb_chunks(int B, int L, int heads, int& chunk, int& n_chunks) {
   // enough workgroups to fill the chip, at least 4 tiles per chunk
   long want = 1024 / ((long)B * heads > 0 ? (long)B * heads : 1);
@@ -1009,12 +1018,27 @@ extern "C" int occf_masked_xattn_bwd(const float* q, const float* k, const float
   float* Dv = lse + rows;
   float* dq_part = Dv + rows;
   const float scale = 1.0f / sqrtf((float)XB_HD);
-  hipLaunchKernelGGL(xattn_stats_partial_kernel, dim3(nc, heads, B), dim3(XB_QMAX), 0, st, q, k, blocked,
-                     (const int*)row_open, part_ml, B, Q, L, E, heads, chunk, nc, scale);
-  hipLaunchKernelGGL(xattn_stats_merge_kernel, dim3(occf_cdiv(rows, 256)), dim3(256), 0, st, part_ml, out, dout, lse,
-                     Dv, B, Q, E, heads, nc);
-  hipLaunchKernelGGL(xattn_bwd_kernel, dim3(nc, heads, B), dim3(XB_QMAX), 0, st, q, k, v, blocked,
-                     (const int*)row_open, dout, lse, Dv, dq_part, dk, dv, B, Q, L, E, heads, chunk, nc, scale);
+  static const int mfma_env = [] {
+    const char* e = getenv("OCCF_XATTN_BWD_MFMA");          // diagnostics: 0 = the scalar kernels of round 2
+    return e ? atoi(e) : 1;
+  }();
+  if (mfma_env) {
+    // statistics from the forward's own matrix-core partial kernel ((max, sum) per key chunk; its weighted value sums
+    // land in the dQ partial buffer, which is rewritten below)
+    occf_xattn_mfma_launch(q, k, v, blocked, (const int*)row_open, dq_part, part_ml, B, Q, L, E, heads, chunk, nc, scale,
+                           st);
+    hipLaunchKernelGGL(xattn_stats_merge_kernel, dim3(occf_cdiv(rows, 256)), dim3(256), 0, st, part_ml, out, dout, lse,
+                       Dv, B, Q, E, heads, nc);
+    occf_xattn_bwd_mfma_launch(q, k, v, blocked, (const int*)row_open, dout, lse, Dv, dq_part, dk, dv, B, Q, L, E, heads,
+                               chunk, nc, scale, st);
+  } else {
+    hipLaunchKernelGGL(xattn_stats_partial_kernel, dim3(nc, heads, B), dim3(XB_QMAX), 0, st, q, k, blocked,
+                       (const int*)row_open, part_ml, B, Q, L, E, heads, chunk, nc, scale);
+    hipLaunchKernelGGL(xattn_stats_merge_kernel, dim3(occf_cdiv(rows, 256)), dim3(256), 0, st, part_ml, out, dout, lse,
+                       Dv, B, Q, E, heads, nc);
+    hipLaunchKernelGGL(xattn_bwd_kernel, dim3(nc, heads, B), dim3(XB_QMAX), 0, st, q, k, v, blocked,
+                       (const int*)row_open, dout, lse, Dv, dq_part, dk, dv, B, Q, L, E, heads, chunk, nc, scale);
+  }
   hipLaunchKernelGGL(xattn_dq_reduce_kernel, dim3(occf_cdiv(rows * XB_HD, 256)), dim3(256), 0, st, dq_part, dq, B, Q,
                      E, heads, nc);
   OCCF_LAUNCH_CHECK();

@@ -48,6 +48,19 @@ if "msda" in what:
     timeit("msda3d_backward 91250 queries, 8 heads x 24",
            lambda: ops.msda3d_backward(value, offs, lg, dout, shapes, 8, 4))
 
+if "xattn" in what:
+    heads, Q = 6, 100
+    for L in (80000, 10000, 1250, 100):
+        qq = torch.randn(1, Q, 192, generator=g).cuda()
+        kk = torch.randn(1, L, 192, generator=g).cuda()
+        vv = torch.randn(1, L, 192, generator=g).cuda()
+        bl = (torch.rand(1, Q, L, generator=g) < 0.5).to(torch.uint8).cuda() if L > 100 else None
+        ro = torch.ones(Q, dtype=torch.int32).cuda() if L > 100 else None
+        out = ops.masked_attention(qq, kk, vv, heads, bl, ro)
+        do = torch.randn(1, Q, 192, generator=g).cuda()
+        timeit(f"masked_attention forward Q=100 L={L}", lambda: ops.masked_attention(qq, kk, vv, heads, bl, ro))
+        timeit(f"masked_attention_backward Q=100 L={L}", lambda: ops.masked_attention_backward(qq, kk, vv, heads, out, do, bl, ro))
+
 if "dgrad" in what:
     import torch.nn.functional as F
     for (dims, Cin, Cout) in (((200, 200, 16), 128, 256), ((100, 100, 8), 256, 512), ((50, 50, 4), 512, 1024)):

@@ -245,7 +245,9 @@ def test_window_attention_backward(be, X, Y, S, heads, shift, B):
 
 
 @pytest.mark.parametrize("Q,L,heads,masked", [(20, 100, 3, True), (100, 37, 2, True), (100, 100, 6, False),
-                                              (7, 300, 1, True)])
+                                              (7, 300, 1, True),
+                                              # several key chunks x tiles, a partial last tile, all 128 query slots
+                                              (100, 1234, 2, True), (128, 260, 1, True), (33, 129, 1, False)])
 def test_masked_attention_backward(be, Q, L, heads, masked):
     B, E = 2, heads * 32
     q = _t("xb_q", (B, Q, E), 1).requires_grad_()
