@@ -304,6 +304,10 @@ class OccupancyFormer(nn.Module):
         training step.  In ``eval()`` mode the fused inference kernels run and the losses are plain values."""
         from . import fused
         fused.invalidate_caches()       # a new step: weight layouts / bf16 splits are rebuilt once (fused.py, _EPOCH)
+        # ground-truth conversion first: its torch.unique synchronises the host, which is free while the device queue
+        # is still empty and would cost the whole forward's duration after extract_feat has been queued
+        if "gt_prepared" not in kwargs and hasattr(self.pts_bbox_head, "preprocess_gt"):
+            kwargs["gt_prepared"] = self.pts_bbox_head.preprocess_gt(gt_occ, img_metas)
         voxel_feats, img_feats, depth = self.extract_feat(points=None, img=img_inputs, img_metas=img_metas)
         losses = {"loss_depth": self.img_view_transformer.get_depth_loss(img_inputs[7], depth)}
         losses.update(self.pts_bbox_head.forward_train(voxel_feats=voxel_feats, img_metas=img_metas, gt_occ=gt_occ,

@@ -12,6 +12,13 @@ import torch
 from . import _lib
 
 
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream          # (device index) -> hipStream_t as int
+except AttributeError:      # pragma: no cover
+    def _raw_stream(dev):
+        return torch.cuda.current_stream(dev).cuda_stream
+
+
 class OccfError(RuntimeError):
     pass
 
@@ -39,8 +46,10 @@ class HipOps:
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
+        """the raw HIP stream torch currently launches on (torch.cuda.current_stream() builds a Stream object through
+        four Python layers: 9 us per call x 2 700 library launches = 8 ms of host time per training step, r03d)"""
         if self.strict:
-            return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
         return ctypes.c_void_p(0)
 
     def _ptr(self, t, dtype=None):

@@ -36,6 +36,20 @@ semantic_kitti_class_frequencies = np.array([
     1.57196520e07, 1.58442623e08, 2.06162300e06, 3.69705220e07, 1.15198800e06, 3.34146000e05])
 
 
+_DEV_CONST = {}
+
+
+def dev_const(values, device, dtype):
+    """a small constant (point-cloud range, grid dimensions, class weights) as a device tensor, uploaded ONCE per
+    (values, device, dtype): ``torch.tensor(list, device=...)`` in the loss loop is a pageable host-to-device copy per
+    call -- the host blocks on each (90 per training step, r03d)"""
+    key = (tuple(float(v) for v in values), str(device), dtype)
+    t = _DEV_CONST.get(key)
+    if t is None:
+        t = _DEV_CONST[key] = torch.tensor([float(v) for v in values], dtype=dtype, device=device)
+    return t
+
+
 class DeviceRNG:
     """noise source on the compute device (a seeded torch.Generator)"""
 
@@ -237,7 +251,7 @@ def _voxel_weights(gt_labels, gt_masks, sample_weights):
 
 
 def _norm_coords(idx, dims, like):
-    return unravel_indices(idx, dims).float() / (torch.tensor(dims, device=idx.device).float().view(1, 1, -1) - 1)
+    return unravel_indices(idx, dims).float() / (dev_const(dims, idx.device, torch.float32).view(1, 1, -1) - 1)
 
 
 def sample_valid_coords_with_frequencies(num_points, gt_labels, gt_masks, sample_weights, rng):
@@ -301,7 +315,7 @@ def get_nusc_lidarseg_point_coords(mask_pred, gt_lidarseg_list, labels, num_poin
     assert oversample_ratio >= 1 and 0 <= importance_sample_ratio <= 1
     n_pos = mask_pred.shape[0]
     num_sampled = int(num_points * oversample_ratio)
-    pcr = torch.tensor(point_cloud_range, dtype=mask_pred.dtype, device=mask_pred.device)
+    pcr = dev_const(point_cloud_range, mask_pred.device, mask_pred.dtype)
     n_unc = int(importance_sample_ratio * num_points)
     out, r0 = [], 0
     for lidar, lab in zip(gt_lidarseg_list, labels):
@@ -476,6 +490,11 @@ class OccHeadTrainingMixin:
         from . import noise
         return noise.get_rng(device)
 
+    def _const(self, name, values, device, dtype):
+        """small per-head constants (class weights, point-cloud range) as device tensors, uploaded once: a
+        ``torch.tensor(list, device=...)`` per prediction set is a pageable host-to-device copy each time (30 per step)"""
+        return dev_const(values, device, dtype)
+
     def preprocess_gt(self, gt_occ, img_metas):
         pairs = [preprocess_occupancy_gt(g, self.num_occupancy_classes) for g in gt_occ]
         return [p[0] for p in pairs], [p[1] for p in pairs]
@@ -492,7 +511,7 @@ class OccHeadTrainingMixin:
             pos_gt = gt_inds[pos] - 1
         labels = gt_labels.new_full((self.num_queries,), self.num_classes, dtype=torch.long)
         labels[pos] = gt_labels[pos_gt]
-        cw = torch.tensor(self.class_weight, dtype=cls_score.dtype, device=cls_score.device)
+        cw = self._const("class_weight", self.class_weight, cls_score.device, cls_score.dtype)
         mask_weights = cls_score.new_zeros((self.num_queries,))
         mask_weights[pos] = cw[labels[pos]]
         return labels, torch.ones_like(mask_weights), gt_masks[pos_gt], mask_weights, pos, pos_gt
@@ -552,7 +571,7 @@ class OccHeadTrainingMixin:
         label_weights = torch.stack([t[1] for t in targets]).flatten()
         mask_targets = torch.cat([t[2] for t in targets], 0)
         mask_weights = torch.stack([t[3] for t in targets])
-        cw = cls_scores.new_tensor(self.class_weight)
+        cw = self._const("class_weight", self.class_weight, cls_scores.device, cls_scores.dtype)
         loss_cls = cross_entropy_loss(cls_scores.flatten(0, 1), labels, label_weights, cw, cw[labels].sum(),
                                       self.w_cls)
         if min(self.class_weight[:self.num_classes]) > 0:
@@ -574,7 +593,7 @@ class NuscTrainingMixin(OccHeadTrainingMixin):
         """mask2former_nusc_occ.py:196-273"""
         rng = self._rng(cls_score.device)
         gt_labels = gt_labels.long()
-        pcr = torch.tensor(self.point_cloud_range, dtype=torch.float32, device=cls_score.device)
+        pcr = self._const("pcr", self.point_cloud_range, cls_score.device, torch.float32)
         coords = (gt_lidarseg[:, :3].float() - pcr[:3]) / (pcr[3:] - pcr[:3])
         n_lidar = min(self.num_points // 2, coords.shape[0])
         if n_lidar < coords.shape[0]:
@@ -640,7 +659,10 @@ class NuscTrainingMixin(OccHeadTrainingMixin):
         """mask2former_nusc_occ.py:547-587.  In train() mode the head's forward builds the differentiable graph
         (occformer_amd/autograd.py) and the returned losses carry grad_fn; in eval() mode these are loss VALUES."""
         all_cls, all_masks = self(voxel_feats, img_metas)
-        gt_labels, gt_masks = self.preprocess_gt(gt_occ, img_metas)
+        # (``gt_prepared``: the detector converts the ground truth BEFORE it queues the view transformer / encoder --
+        # torch.unique has a data-dependent output shape, i.e. a host synchronisation that would otherwise wait here
+        # for the whole forward)
+        gt_labels, gt_masks = kwargs.get("gt_prepared") or self.preprocess_gt(gt_occ, img_metas)
         losses = self.loss(all_cls, all_masks, gt_labels, gt_masks, points, img_metas)
         with torch.no_grad():
             losses.update(self.lidarseg_metric(all_cls[-1].detach(), _dense(all_masks[-1]), points, img_metas))
@@ -710,5 +732,5 @@ class KittiTrainingMixin(OccHeadTrainingMixin):
         """mask2former_occ.py:525-567"""
         self.get_sampling_weights()
         all_cls, all_masks = self(voxel_feats, img_metas)
-        gt_labels, gt_masks = self.preprocess_gt(gt_occ, img_metas)
+        gt_labels, gt_masks = kwargs.get("gt_prepared") or self.preprocess_gt(gt_occ, img_metas)
         return self.loss(all_cls, all_masks, gt_labels, gt_masks, img_metas)
