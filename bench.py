@@ -400,6 +400,9 @@ def main():
 
         def step_train():
             opt.zero_grad(set_to_none=True)
+            # the label scan of this sample's ground truth runs on a side stream (inputs are resident: ready=True), so
+            # that forward_train does not synchronise with the previous step's still queued backward / optimizer
+            model.prefetch_gt(gt_occ, ready=True)
             losses = net(return_loss=True, **net_kwargs)
             total = sum(v for k, v in losses.items() if "loss" in k)
             total.backward()

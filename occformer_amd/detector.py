@@ -304,15 +304,66 @@ class OccupancyFormer(nn.Module):
         training step.  In ``eval()`` mode the fused inference kernels run and the losses are plain values."""
         from . import fused
         fused.invalidate_caches()       # a new step: weight layouts / bf16 splits are rebuilt once (fused.py, _EPOCH)
-        # ground-truth conversion first: its torch.unique synchronises the host, which is free while the device queue
-        # is still empty and would cost the whole forward's duration after extract_feat has been queued
+        # ground-truth conversion first: the number of labels present is read back to the host (a synchronisation) --
+        # free when ``prefetch_gt`` ran the scan ahead of time on the side stream, cheap while the device queue is still
+        # short, and as expensive as the whole forward once extract_feat has been queued
         if "gt_prepared" not in kwargs and hasattr(self.pts_bbox_head, "preprocess_gt"):
-            kwargs["gt_prepared"] = self.pts_bbox_head.preprocess_gt(gt_occ, img_metas)
+            kwargs["gt_prepared"] = self.pts_bbox_head.preprocess_gt(gt_occ, img_metas, scans=self._take_gt_scans(gt_occ))
         voxel_feats, img_feats, depth = self.extract_feat(points=None, img=img_inputs, img_metas=img_metas)
         losses = {"loss_depth": self.img_view_transformer.get_depth_loss(img_inputs[7], depth)}
         losses.update(self.pts_bbox_head.forward_train(voxel_feats=voxel_feats, img_metas=img_metas, gt_occ=gt_occ,
                                                        points=points_occ, img_feats=img_feats, **kwargs))
         return losses
+
+    # ---- ground-truth label scan one step ahead, on a side stream -------------------------------------------------
+    def prefetch_gt(self, gt_occ, ready=None):
+        """Start the label scan of a FUTURE training sample (``gt_occ`` [B, X, Y, Z] on the device) on a side HIP
+        stream and return immediately.  ``forward_train`` of that sample then finds the per-sample label counts in
+        pinned host memory instead of synchronising with everything the main stream still has queued (the previous
+        step's backward and optimizer) -- with the scan in flight one step ahead the host issues step n + 1 while the
+        device executes step n (r03e: the host needs ~100 ms to issue a step the device runs in ~140 ms; with a
+        synchronisation at the start of every step the two serialise wherever the host is the slower one).
+        What a prefetching data loader calls right after it has the next batch on the device.
+        ``ready``: None = the scan waits (on the device) for the main stream's current position; a ``torch.cuda.Event``
+        = it waits for that event; True = ``gt_occ`` is already complete (resident inputs)."""
+        if not gt_occ.is_cuda:
+            return
+        from .training import gt_label_scan
+        dev = gt_occ.device
+        side = self.__dict__.get("_gt_stream")
+        if side is None or side.device != dev:
+            side = self.__dict__["_gt_stream"] = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        if ready is None:
+            ready = torch.cuda.Event()
+            ready.record(main)
+        if ready is not True:
+            side.wait_event(ready)
+        nc = self.pts_bbox_head.num_occupancy_classes
+        with torch.cuda.stream(side):
+            scans = [gt_label_scan(g, nc) for g in gt_occ]
+            counts = torch.stack([s[1] for s in scans]).to(torch.int64)
+            host = torch.empty(counts.shape, dtype=torch.int64, pin_memory=True)
+            host.copy_(counts, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(side)
+        for s in scans:
+            s[0].record_stream(main)            # allocated on the side stream, consumed on the main stream
+        q = self.__dict__.setdefault("_gt_prefetched", {})
+        q[(gt_occ.data_ptr(), gt_occ._version, tuple(gt_occ.shape))] = ([s[0] for s in scans], host, done)
+        while len(q) > 4:
+            q.pop(next(iter(q)))
+
+    def _take_gt_scans(self, gt_occ):
+        q = self.__dict__.get("_gt_prefetched")
+        hit = None if not q or not torch.is_tensor(gt_occ) else q.pop((gt_occ.data_ptr(), gt_occ._version,
+                                                                     tuple(gt_occ.shape)), None)
+        if hit is None:
+            return None
+        labels, host, done = hit
+        done.synchronize()                                   # long complete when the scan ran a step ahead
+        torch.cuda.current_stream(gt_occ.device).wait_event(done)
+        return [(labels[i], int(host[i])) for i in range(len(labels))]
 
     def forward_test(self, img_metas=None, img_inputs=None, **kwargs):
         return self.simple_test(img_metas, img_inputs, **kwargs)

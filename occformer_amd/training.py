@@ -36,6 +36,9 @@ semantic_kitti_class_frequencies = np.array([
     1.57196520e07, 1.58442623e08, 2.06162300e06, 3.69705220e07, 1.15198800e06, 3.34146000e05])
 
 
+# NOTE on ``x.flip(-1)`` for the (x, y, z) <-> (z, y, x) swaps below: the reference writes ``coords[..., [2, 1, 0]]``;
+# indexing with a Python list uploads an index tensor from pageable host memory on every call -- a host
+# synchronisation in the middle of the loss loop (found by tests/test_boundary.py under sync-debug mode).
 _DEV_CONST = {}
 
 
@@ -237,12 +240,33 @@ def unravel_indices(indices, shape):
     return torch.stack(coord[::-1], dim=-1)
 
 
-def preprocess_occupancy_gt(gt_occ, num_classes, img_metas=None):
-    """mmdet_utils.py:426-475: labels present (< num_classes) and their 0/1 int64 masks"""
-    gt_occ = gt_occ.squeeze(0)
-    labels = [l for l in torch.unique(gt_occ) if l < num_classes]
-    assert len(labels) > 0
-    return torch.stack(labels).long(), torch.stack([gt_occ == l for l in labels]).long()
+def gt_label_scan(gt_occ, num_classes):
+    """Device-only half of the ground-truth conversion: which labels < num_classes occur in ``gt_occ`` [1, X, Y, Z].
+    -> (labels_sorted [num_classes] int64: the present labels in ascending order first, n_present [] int64).
+    No data-dependent shape, hence no host synchronisation: it can run on a side stream one step ahead
+    (``OccupancyFormer.prefetch_gt``)."""
+    flat = gt_occ.reshape(-1).long()
+    valid = (flat >= 0) & (flat < num_classes)
+    cnt = torch.zeros(num_classes, dtype=torch.int32, device=gt_occ.device)
+    cnt.scatter_add_(0, torch.where(valid, flat, torch.zeros_like(flat)), valid.int())
+    present = cnt > 0
+    ar = torch.arange(num_classes, device=gt_occ.device)
+    labels_sorted = torch.sort(torch.where(present, ar, torch.full_like(ar, num_classes)))[0]
+    return labels_sorted, present.sum()
+
+
+def preprocess_occupancy_gt(gt_occ, num_classes, img_metas=None, scan=None, n_present=None):
+    """mmdet_utils.py:426-475: labels present (< num_classes) and their 0/1 int64 masks.  The reference takes
+    ``torch.unique(gt_occ)`` -- sorted values of a data-dependent count, i.e. a host synchronisation; here the count is
+    the ONLY thing read back (``n_present``: already on the host when the scan was prefetched)."""
+    if scan is None:
+        scan = gt_label_scan(gt_occ, num_classes)
+    if n_present is None:
+        n_present = int(scan[1])                      # host synchronisation (one integer)
+    assert n_present > 0
+    labels = scan[0][:n_present]
+    g = gt_occ.squeeze(0) if gt_occ.dim() == 4 and gt_occ.shape[0] == 1 else gt_occ
+    return labels.long(), (g.unsqueeze(0) == labels.view(-1, *([1] * g.dim()))).long()
 
 
 def _voxel_weights(gt_labels, gt_masks, sample_weights):
@@ -295,7 +319,7 @@ def get_uncertain_point_coords_3d_with_frequency(mask_pred, labels, gt_labels_li
     if tuple(mask_pred.shape[-3:]) == tuple(gt_masks_list[0].shape[1:]):
         logits = torch.gather(mask_pred.reshape(n, -1), 1, idx)
     else:
-        logits = point_sample_3d(mask_pred, coords[..., [2, 1, 0]], align_corners=True).squeeze(1)
+        logits = point_sample_3d(mask_pred, coords.flip(-1), align_corners=True).squeeze(1)
     n_unc = int(importance_sample_ratio * num_points)
     top = ops.topk_smallest_abs(logits.contiguous(), n_unc)
     idx = torch.gather(idx, 1, top)
@@ -324,7 +348,7 @@ def get_nusc_lidarseg_point_coords(mask_pred, gt_lidarseg_list, labels, num_poin
         c = torch.cat((c, rng.rand(num_sampled - c.shape[0], 3).to(c)), 0)
         if n:
             vol = mask_pred[r0:r0 + n, 0][None]                                     # [1, n, X, Y, Z]
-            logits = ops.point_sample_3d(vol.contiguous(), c[None, :, [2, 1, 0]].contiguous(), False, padding_mode)[0]
+            logits = ops.point_sample_3d(vol.contiguous(), c[None].flip(-1).contiguous(), False, padding_mode)[0]
             top = ops.topk_smallest_abs(logits.contiguous(), n_unc)                  # [n, n_unc]
             out.append(c[top])
         r0 += n
@@ -495,8 +519,11 @@ class OccHeadTrainingMixin:
         ``torch.tensor(list, device=...)`` per prediction set is a pageable host-to-device copy each time (30 per step)"""
         return dev_const(values, device, dtype)
 
-    def preprocess_gt(self, gt_occ, img_metas):
-        pairs = [preprocess_occupancy_gt(g, self.num_occupancy_classes) for g in gt_occ]
+    def preprocess_gt(self, gt_occ, img_metas, scans=None):
+        """``scans``: per sample (labels_sorted, n_present on the HOST) from ``gt_label_scan`` run ahead of time"""
+        pairs = [preprocess_occupancy_gt(g, self.num_occupancy_classes, scan=None if scans is None else scans[i][0],
+                                         n_present=None if scans is None else scans[i][1])
+                 for i, g in enumerate(gt_occ)]
         return [p[0] for p in pairs], [p[1] for p in pairs]
 
     def _targets_from_assignment(self, gt_inds, cls_score, mask_pred, gt_labels, gt_masks):
@@ -598,7 +625,7 @@ class NuscTrainingMixin(OccHeadTrainingMixin):
         n_lidar = min(self.num_points // 2, coords.shape[0])
         if n_lidar < coords.shape[0]:
             coords = coords[rng.randperm(coords.shape[0]).to(coords.device)[:n_lidar]]
-        coords = torch.cat((coords, rng.rand(self.num_points - n_lidar, 3).to(coords)), 0)[:, [2, 1, 0]]
+        coords = torch.cat((coords, rng.rand(self.num_points - n_lidar, 3).to(coords)), 0).flip(-1)
         lazy = mask_pred if isinstance(mask_pred, LazyMask) else None
         cls_score = cls_score.detach()                                       # targets carry no gradient
         mask_pred = None if lazy is not None else _dense(mask_pred)
@@ -629,7 +656,7 @@ class NuscTrainingMixin(OccHeadTrainingMixin):
             coords = get_nusc_lidarseg_point_coords(mpd.unsqueeze(1), gt_lidarseg_list, gt_labels_list, self.num_points,
                                                     self.oversample_ratio, self.importance_sample_ratio,
                                                     self.point_cloud_range, self._rng(mpd.device),
-                                                    padding_mode=self.padding_mode)[..., [2, 1, 0]].contiguous()
+                                                    padding_mode=self.padding_mode).flip(-1).contiguous()
             pt = point_sample_3d(mask_targets.unsqueeze(1).float(), coords, padding_mode=self.padding_mode).squeeze(1)
         return dict(loss_cls=loss_cls, mp=mp, mw=mw, coords=coords, pt=pt)
 
@@ -688,9 +715,9 @@ class KittiTrainingMixin(OccHeadTrainingMixin):
         cls_score = cls_score.detach()                                       # targets carry no gradient
         mask_pred = None if lazy is not None else _dense(mask_pred)
         if lazy is not None:
-            pred_pts = lazy.sample_all(coords[0][:, [2, 1, 0]], self.align_corners, "zeros")
+            pred_pts = lazy.sample_all(coords[0].flip(-1), self.align_corners, "zeros")
         else:
-            pred_pts = point_sample_3d(mask_pred[None], coords[..., [2, 1, 0]], align_corners=self.align_corners)[0]
+            pred_pts = point_sample_3d(mask_pred[None], coords.flip(-1), align_corners=self.align_corners)[0]
         gt_pts = gt_masks.reshape(gt_masks.shape[0], -1)[:, idx].float()
         gt_inds, cost = self.assigner.assign(cls_score, pred_pts, gt_labels, gt_pts, img_metas)
         return self._targets_from_assignment(gt_inds, cls_score, mask_pred, gt_labels, gt_masks) + (cost,)
@@ -712,7 +739,7 @@ class KittiTrainingMixin(OccHeadTrainingMixin):
                 mpd.unsqueeze(1), None, gt_labels_list, gt_masks_list, self.sample_weights, self.num_points,
                 self.oversample_ratio, self.importance_sample_ratio, self._rng(mpd.device))
             pt = torch.gather(mask_targets.reshape(mask_targets.shape[0], -1), 1, idx).float()
-        return dict(loss_cls=loss_cls, mp=mp, mw=mw, coords=coords[..., [2, 1, 0]].contiguous(), pt=pt)
+        return dict(loss_cls=loss_cls, mp=mp, mw=mw, coords=coords.flip(-1).contiguous(), pt=pt)
 
     def _loss_finish(self, prep, pp):
         """mask2former_occ.py:420-444"""

@@ -28,6 +28,8 @@ kw = dict(img_metas=metas, img_inputs=list(img_inputs) + [gt_depths], gt_occ=gt_
 
 def step():
     opt.zero_grad(set_to_none=True)
+    if os.environ.get("PROBE_PREFETCH", "1") == "1":
+        model.prefetch_gt(gt_occ, ready=True)
     losses = model(return_loss=True, **kw)
     sum(v for k, v in losses.items() if "loss" in k).backward()
     torch.nn.utils.clip_grad_norm_(params, 5.0)

@@ -176,9 +176,9 @@ def test_inference_forward_has_no_host_sync(hip, monkeypatch):
 
 @pytest.mark.gpu
 def test_training_step_has_no_host_sync_after_gt_preparation(hip, monkeypatch):
-    """The training step (forward_train -> backward -> clip -> fused AdamW) with the ground truth already converted
-    (``gt_prepared``: torch.unique has a data-dependent shape, the detector runs it BEFORE anything is queued) must not
-    synchronise the host: r03d measured the reference-style depth loss (``pred[fg_mask]``, ``max(1.0, fg.sum())``)
+    """The training step (forward_train -> backward -> clip -> fused AdamW) with the ground-truth label scan prefetched
+    on the side stream (``OccupancyFormer.prefetch_gt``: the label COUNT is the one data-dependent shape of the step;
+    its event synchronisation waits for the side stream only) must not synchronise the host with the main stream: r03d measured the reference-style depth loss (``pred[fg_mask]``, ``max(1.0, fg.sum())``)
     blocking the host for 46 ms per step at full size -- the whole view transformer + encoder -- with the GPU idling
     behind it, and 30 ``torch.tensor(list, device=...)`` uploads per step in the loss loop."""
     import occformer_amd.ops as ops_mod
@@ -220,17 +220,56 @@ def test_training_step_has_no_host_sync_after_gt_preparation(hip, monkeypatch):
     try:
         step()
         step()                                  # caches, kernel attributes, optimizer state (may synchronise)
-        gt_prepared = model.pts_bbox_head.preprocess_gt(kw["gt_occ"], metas)
         torch.cuda.synchronize()
-        torch.cuda.set_sync_debug_mode("error")
+        # "warn" mode + recorded warnings: ALL synchronising calls of the step are listed in one run
+        import traceback
+        import warnings
+        found = []
+
+        def hook(message, category, filename, lineno, file=None, line=None):
+            if "synchroniz" in str(message).lower():
+                frames = [f for f in traceback.extract_stack() if "occformer_amd" in f.filename or "tests/" in f.filename]
+                found.append(" <- ".join(f"{f.filename.split('/')[-1]}:{f.lineno}" for f in frames[-4:][::-1]))
+
+        prev_hook = warnings.showwarning
+        torch.cuda.set_sync_debug_mode("warn")
         try:
-            losses = step(gt_prepared=gt_prepared)
+            with warnings.catch_warnings():
+                warnings.simplefilter("always")
+                warnings.showwarning = hook
+                model.prefetch_gt(kw["gt_occ"], ready=True)      # label scan on the side stream (own, tiny sync)
+                losses = step()
         finally:
+            warnings.showwarning = prev_hook
             torch.cuda.set_sync_debug_mode("default")
         torch.cuda.synchronize()
     finally:
         noise.set_rng(None)
+    assert not found, "host synchronisations inside the training step:\n  " + "\n  ".join(sorted(set(found)))
     assert all(bool(torch.isfinite(v.detach()).all()) for v in losses.values())
+
+
+@pytest.mark.gpu
+def test_prefetch_gt_matches_inline_preprocessing(hip):
+    """``prefetch_gt`` (label scan on the side stream, count through pinned memory) hands ``preprocess_gt`` the same
+    labels / masks as the inline path (mmdet_utils.py:426-475: sorted labels < num_classes, one 0/1 mask each)"""
+    from occformer_amd.registry import build_model
+    from tests import tinycfg
+    from tests.golden.make_golden_train import inputs
+    cfg, meta = tinycfg.tiny_nusc(ncams=2)
+    model = build_model(cfg).to(hip.device)
+    _, _, gt_occ, _ = inputs("nusc")
+    gt = gt_occ.to(hip.device)
+    metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])] * gt.shape[0]
+    ref_l, ref_m = model.pts_bbox_head.preprocess_gt(gt, metas)
+    model.prefetch_gt(gt)                                    # default: waits (on the device) for the main stream
+    scans = model._take_gt_scans(gt)
+    assert scans is not None and model._take_gt_scans(gt) is None          # consumed once
+    got_l, got_m = model.pts_bbox_head.preprocess_gt(gt, metas, scans=scans)
+    for a, b, c, d in zip(ref_l, got_l, ref_m, got_m):
+        assert torch.equal(a, b) and torch.equal(c, d)
+        uniq = torch.unique(gt[0])
+    assert torch.equal(ref_l[0].cpu(), torch.unique(gt[0]).cpu()[torch.unique(gt[0]).cpu() < 17])
 
 
 def test_kitti_detector_with_image_branch_wiring(be, monkeypatch):
