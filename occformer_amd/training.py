@@ -521,7 +521,7 @@ class OccHeadTrainingMixin:
 
     def preprocess_gt(self, gt_occ, img_metas, scans=None):
         """``scans``: per sample (labels_sorted, n_present on the HOST) from ``gt_label_scan`` run ahead of time"""
-        pairs = [preprocess_occupancy_gt(g, self.num_occupancy_classes, scan=None if scans is None else scans[i][0],
+        pairs = [preprocess_occupancy_gt(g, self.num_occupancy_classes, scan=None if scans is None else (scans[i][0], None),
                                          n_present=None if scans is None else scans[i][1])
                  for i, g in enumerate(gt_occ)]
         return [p[0] for p in pairs], [p[1] for p in pairs]
