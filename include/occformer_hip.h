@@ -463,6 +463,12 @@ int occf_deform_col2im(const float* x, const float* offset, const float* dcol, f
                        int H, int W, int C, int K, int stride, int pad, int dil, int groups, int deform_groups,
                        void* stream);
 
+/* One launch for a TABLE of strided-gather + bf16-split jobs (the per-step "prepare weights" pass: tap-major,
+ * transposed, tap-flipped layouts and (hi, lo) splits of every parameter).  table[(n + 1) * 15] int64 on the device, row
+ * r = {in, f32_out or 0, hi_out, lo_out, first pair index, dims[5], input strides[5] (elements, base offset folded
+ * into `in`)}; row n carries the total pair count.  A pair = two consecutive outputs of the last dimension (even). */
+int occf_prep_weights(const int64_t* table, int n, long total_pairs, void* stream);
+
 /* ------------------------------------------------------------------ input pipeline / evaluation ---- */
 
 /* Replaces CreateDepthFromLiDAR.__call__ (P/datasets/pipelines/lidar2depth.py:15-87; no FFI in the reference: torch

@@ -22,12 +22,15 @@ def _split(t):
     return None if ops.precision == "f32" else ops.split_bf16(t)
 
 
-def _w2d(w):
-    return w.reshape(w.shape[0], -1)
+_w2d = fused._w2d
 
 
 def _wt(weight):
     """W^T [K, N] (+ bf16 split) of a linear weight [N, K(, 1, 1, 1)], cached per parameter version"""
+    hit = fused.prepared(weight, "wt")
+    if hit is not None:
+        return hit
+
     def make():
         wt = _w2d(weight.detach()).t().contiguous()
         return wt, _split(wt)
@@ -156,7 +159,7 @@ class Conv3d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_cl, weight, bias, ks, stride, dil, pad):
         ops = get_ops()
-        w2 = fused._versioned(fused._TAP_CACHE, weight, lambda: fused._tap_layout(weight.detach()))
+        w2 = fused.tap_major_of(weight)
         y = ops.conv3d(x_cl, w2, ks, stride, dil, pad, None if bias is None else bias.detach(),
                        w_split=fused.split_weight(weight, fused._tap_layout))
         ctx.save_for_backward(x_cl, weight)
@@ -180,7 +183,7 @@ class Conv3d(torch.autograd.Function):
                     w5 = weight.detach() if weight.dim() == 5 else weight.detach().unsqueeze(-1)
                     wf = w5.flip(2, 3, 4).permute(1, 2, 3, 4, 0).reshape(Cin, -1).contiguous()   # [Cin, taps*Cout]
                     return wf, _split(wf)
-                wf, sp = fused._versioned(_FLIP_CACHE, weight, make)
+                wf, sp = fused.prepared(weight, "flip") or fused._versioned(_FLIP_CACHE, weight, make)
                 dpad = tuple(dil * (k - 1) - p for k, p in zip(ks, pad))
                 dx = ops.conv3d(g, wf, ks, 1, dil, dpad, None, w_split=sp)
             else:
@@ -188,7 +191,7 @@ class Conv3d(torch.autograd.Function):
                     w5 = weight.detach() if weight.dim() == 5 else weight.detach().unsqueeze(-1)
                     wt = w5.permute(1, 2, 3, 4, 0).reshape(Cin, -1).contiguous()                   # [Cin, taps*Cout]
                     return wt, ops.split_bf16(wt)
-                wt, sp = fused._versioned(_DG_CACHE, weight, make)
+                wt, sp = fused.prepared(weight, "dg") or fused._versioned(_DG_CACHE, weight, make)
                 dx = ops.conv3d_dgrad(g, sp, tuple(x_cl.shape), ks, stride, dil, pad)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw2, db = ops.conv3d_wgrad(g, x_cl, ks, stride, dil, pad, want_bias=ctx.has_bias)

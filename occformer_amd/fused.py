@@ -78,11 +78,143 @@ def bool_all(t):
     return t.all()
 
 
+# ---- all weight-derived layouts of a step in ONE launch ------------------------------------------------------------
+class _WeightPrep:
+    """The layouts the kernels consume -- 'split' (hi, lo of the weight read as [N, K]), 'tap' ([Cout, taps*Cin] + split),
+    'wt' (W^T [K, N] + split: data gradient of a linear), 'flip' / 'dg' ([Cin, taps*Cout] with / without flipped taps
+    + split: stride-1 / strided data gradient of a convolution) -- as persistent buffers refreshed together by
+    csrc/prep.hip (one table of strided-gather descriptors, one launch) whenever any parameter may have changed
+    (``param_version``).  Rebuilding them one by one after every optimizer step cost ~1 200 small launches per step."""
+
+    KINDS = ("split", "tap", "wt", "flip", "dg")
+
+    def __init__(self):
+        self.entries = {}
+        self.table = None
+        self.table_for = None
+
+    @staticmethod
+    def _spec(param, kind):
+        """-> (dims[5], strides[5] of the INPUT in elements, base offset, output shape) or None if not expressible"""
+        if not param.is_contiguous() or param.dim() not in (2, 4, 5):
+            return None
+        shp = list(param.shape)
+        N = shp[0]
+        C = shp[1]
+        k = shp[2:] + [1] * (5 - len(shp)) if len(shp) > 2 else [1, 1, 1]
+        kx, ky, kz = k
+        taps = kx * ky * kz
+        sN, sC, sx, sy, sz = C * taps, taps, ky * kz, kz, 1
+        if kind == "split":
+            spec = ((1, 1, 1, N, C * taps), (0, 0, 0, C * taps, 1), 0, (N, C * taps))
+        elif kind == "tap":
+            spec = ((N, kx, ky, kz, C), (sN, sx, sy, sz, sC), 0, (N, taps * C))
+        elif kind == "wt":
+            if taps != 1:
+                return None
+            spec = ((1, 1, 1, C, N), (0, 0, 0, 1, C), 0, (C, N))
+        elif kind == "dg":
+            spec = ((C, kx, ky, kz, N), (sC, sx, sy, sz, sN), 0, (C, taps * N))
+        elif kind == "flip":
+            spec = ((C, kx, ky, kz, N), (sC, -sx, -sy, -sz, sN), (kx - 1) * sx + (ky - 1) * sy + (kz - 1) * sz,
+                    (C, taps * N))
+        else:
+            raise KeyError(kind)
+        return None if spec[0][4] % 2 else spec
+
+    def get(self, param, kind):
+        """-> (fp32 layout or None for 'split', (hi, lo)); None when this (parameter, kind) cannot go through the
+        table (non-leaf, odd inner dimension, CPU tensor under the GPU library ...) -- the caller then derives it the
+        slow way"""
+        if not param.is_leaf or param.dtype != torch.float32:
+            return None
+        ops = get_ops()
+        key = (id(param), kind)
+        e = self.entries.get(key)
+        if e is not None and (e["ref"]() is not param or e["ptr"] != param.data_ptr() or e["shape"] != tuple(param.shape)
+                              or e["ops"] is not ops):
+            e = None
+        if e is None:
+            spec = self._spec(param, kind)
+            if spec is None:
+                return None
+            dims, strides, base, oshape = spec
+            dev = param.device
+            e = dict(ref=weakref.ref(param), ptr=param.data_ptr(), shape=tuple(param.shape), ops=ops, kind=kind,
+                     dims=dims, strides=strides, base=base, stamp=None,
+                     f32=None if kind == "split" else torch.empty(oshape, dtype=torch.float32, device=dev),
+                     hi=torch.empty(oshape, dtype=torch.int16, device=dev),
+                     lo=torch.empty(oshape, dtype=torch.int16, device=dev))
+            self.entries[key] = e
+            self.table = None
+        if e["stamp"] != (param._version, _EPOCH[0]):
+            self._refresh(ops, param.device)
+        elif _CHECK:
+            torch._assert_async(bool_all(e["sum"] == _checksum(param)),
+                                "occformer_amd: a prepared weight layout is stale (parameter written behind the cache)")
+        return e["f32"], (e["hi"], e["lo"])
+
+    def _refresh(self, ops, device):
+        live = []
+        for key, e in list(self.entries.items()):
+            p = e["ref"]()
+            if p is None or p.data_ptr() != e["ptr"] or tuple(p.shape) != e["shape"]:
+                del self.entries[key]
+                self.table = None
+            elif e["ops"] is ops and p.device == device:
+                live.append((e, p))
+        if not live:
+            return
+        ids = tuple(id(e) for e, _ in live)
+        if self.table is None or self.table_for != (ids, str(device)):
+            rows, pair0 = [], 0
+            for e, p in live:
+                rows.append([e["ptr"] + 4 * e["base"], 0 if e["f32"] is None else e["f32"].data_ptr(),
+                             e["hi"].data_ptr(), e["lo"].data_ptr(), pair0, *e["dims"], *e["strides"]])
+                n = 1
+                for d in e["dims"]:
+                    n *= d
+                pair0 += n // 2
+            rows.append([0, 0, 0, 0, pair0] + [1] * 5 + [0] * 5)
+            # (a pageable upload: only when the set of prepared layouts changes, i.e. during the first one or two steps)
+            self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+            self.table_for = (ids, str(device))
+            self.total = pair0
+        ops.prep_weights(self.table, len(live), self.total)
+        for e, p in live:
+            e["stamp"] = (p._version, _EPOCH[0])
+            if _CHECK:
+                e["sum"] = _checksum(p)
+            if hasattr(e["hi"], "_occf_halo_pack"):          # MFMA-fragment order of the halo kernel: derived from hi / lo
+                del e["hi"]._occf_halo_pack
+
+
+_PREP = _WeightPrep()
+
+
+def prepared(param, kind):
+    """(fp32 layout | None, (hi, lo)) of ``param`` in layout ``kind`` from the one-launch table, or None (see
+    ``_WeightPrep.get``); exact-fp32 mode has no splits and stays on the per-parameter caches"""
+    if get_ops().precision == "f32":
+        return None
+    return _PREP.get(param, kind)
+
+
+def _w2d(w):
+    return w.reshape(w.shape[0], -1)
+
+
 def split_weight(param, as_2d=None):
-    """(hi, lo) bf16 split of a weight for the bf16 matrix-core path, or None in exact-fp32 mode."""
+    """(hi, lo) bf16 split of a weight for the bf16 matrix-core path, or None in exact-fp32 mode.  ``as_2d``: None /
+    ``_w2d`` (the weight read as [N, K]) or ``_tap_layout`` (tap-major) go through the one-launch table."""
     ops = get_ops()
     if ops.precision == "f32":
         return None
+    kind = "split" if as_2d is None or as_2d is _w2d else "tap" if as_2d is _tap_layout else None
+    if kind is not None:
+        hit = _PREP.get(param, kind)
+        if hit is not None:
+            return hit[1]
     return _versioned(_SPLIT_CACHE, param,
                       lambda: ops.split_bf16(param.detach() if as_2d is None else as_2d(param.detach())))
 
@@ -96,7 +228,14 @@ def _tap_layout(w):
 def tap_major(conv):
     """Conv weight [Cout, Cin, kX, kY(, kZ)] -> [Cout, taps*Cin] (k = tap*Cin + cin), cached
     until the parameter is modified."""
-    return _versioned(_TAP_CACHE, conv.weight, lambda: _tap_layout(conv.weight.detach()))
+    return tap_major_of(conv.weight)
+
+
+def tap_major_of(weight):
+    hit = prepared(weight, "tap")
+    if hit is not None:
+        return hit[0]
+    return _versioned(_TAP_CACHE, weight, lambda: _tap_layout(weight.detach()))
 
 
 def channels_last_view(x):
@@ -127,7 +266,7 @@ def conv(x_cl, conv, act=0, gn=None):
     if ks == (1, 1, 1) and stride == 1 and x_cl.is_contiguous():
         rows = x_cl.numel() // (x_cl.shape[0] * x_cl.shape[-1])
         return get_ops().linear(x_cl, conv.weight.detach().reshape(conv.out_channels, -1), bias, act,
-                                w_split=split_weight(conv.weight, lambda w: w.reshape(w.shape[0], -1)),
+                                w_split=split_weight(conv.weight, _w2d),
                                 gn=None if gn is None else (gn.num_groups, gn.eps, rows))
     return get_ops().conv3d(x_cl, tap_major(conv), ks, stride, dil, pad, bias, act,
                             w_split=split_weight(conv.weight, _tap_layout),

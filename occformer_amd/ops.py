@@ -272,6 +272,10 @@ class HipOps:
                    self._stream())
         return hi, lo
 
+    def prep_weights(self, table, n, total_pairs):
+        """run a device-resident descriptor table of strided-gather + split jobs (csrc/prep.hip) in one launch"""
+        self._call("occf_prep_weights", self._ptr(table, torch.int64), int(n), int(total_pairs), self._stream())
+
     def _splitk_workspace(self, M, N, K, device):
         need = self.lib.occf_gemm_bf16_workspace(M, N, K)
         if need <= 0:

@@ -23,6 +23,9 @@ def main():
     be = Backend("emu")
     ops_mod._ops = be.ops
     cfg, meta = tinycfg.tiny_nusc(ncams=2)
+    # the full model's layer counts (launch counts per step then match the bench workload)
+    cfg["pts_bbox_head"]["transformer_decoder"]["num_layers"] = 9
+    cfg["img_bev_encoder_neck"]["encoder"]["num_layers"] = 6
     cfg["train_cfg"] = dict(pts=train_cfg(num_points=64))
     cfg["test_cfg"] = None
     model = build_model(cfg)
@@ -50,14 +53,30 @@ def main():
     with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
         step()
     agg = collections.defaultdict(int)
+    LAUNCH = ("add", "mul", "div", "sub", "cat", "stack", "copy_", "contiguous", "clone", "zeros", "fill_", "zero_",
+              "index", "gather", "sum", "mean", "where", "sort", "neg", "sigmoid", "softmax", "exp", "log", "clamp",
+              "rsub", "full", "ones", "arange", "eq", "ne", "lt", "gt", "ge", "le", "max", "min", "scatter", "select_backward",
+              "slice_backward", "index_put", "masked_fill", "relu", "threshold", "bitwise", "logical", "floor", "rand",
+              "randperm", "exponential", "topk", "cumsum", "flip", "repeat", "expand_copy", "to", "_to_copy", "float", "long",
+              "int", "abs", "sqrt", "pow", "reciprocal", "nan_to_num", "any", "all", "nonzero", "unique", "bincount",
+              "argmax", "one_hot", "binary_cross_entropy", "cross_entropy", "nll_loss", "log_softmax", "linalg")
     for e in prof.events():
         if not e.name.startswith("aten::"):
             continue
         par = e.cpu_parent
         if par is not None and par.name.startswith("aten::"):
             continue
+        base = e.name[6:].split(".")[0]
+        if not any(base == k or base == k + "_" or base.startswith(k + "_") or base.startswith(k) and k in ("zeros", "ones", "full", "linalg") for k in LAUNCH):
+            continue
         st = [s for s in (e.stack or []) if "occformer_amd" in s]
-        loc = st[0].split("/repo/")[-1][:80] if st else (par.name[:80] if par is not None else "?")
+        if st:
+            loc = st[0].split("/repo/")[-1][:90]
+        else:
+            q = par
+            while q is not None and not q.name.startswith("autograd::engine") and q.cpu_parent is not None:
+                q = q.cpu_parent
+            loc = q.name[:90] if q is not None else "?"
         agg[(e.name, loc)] += 1
     rows = sorted(agg.items(), key=lambda kv: -kv[1])
     want = sys.argv[1:] or None

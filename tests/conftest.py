@@ -16,6 +16,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (-m "not gpu") runs every kernel through the host emulation: ~30 min of single-core work, 9 min on
+    four pytest-xdist workers.  So a plain ``pytest tests -m "not gpu"`` distributes itself over 4 workers when xdist is
+    installed (OCCF_TEST_SERIAL=1 or an explicit -n / -p no:xdist keeps it serial).  GPU runs are never distributed: one
+    process owns the device and the loaded in-tree library stays visible in that process."""
+    opt = config.option
+    if hasattr(config, "workerinput") or os.environ.get("PYTEST_XDIST_WORKER"):
+        return None                     # inside an xdist worker: never nest
+    if os.environ.get("OCCF_TEST_SERIAL", "0") == "1" or "not gpu" not in (getattr(opt, "markexpr", "") or ""):
+        return None
+    if getattr(opt, "numprocesses", None) or not config.pluginmanager.hasplugin("xdist"):
+        return None
+    if getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False):
+        return None
+    opt.numprocesses = max(1, min(4, (os.cpu_count() or 1) // 2))
+    return None
+
+
 def golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     return {k: torch.from_numpy(z[k]) if z[k].ndim else z[k].item() for k in z.files}

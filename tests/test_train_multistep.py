@@ -161,3 +161,50 @@ def test_three_fused_adamw_steps_then_oracle(bound):
     # ATen / MIOpen ops flip ReLU gates, which this one-sample, one-layer configuration weighs heavily: measured 7.4e-3
     # with every loss within 1.8e-5 -- stale weights showed as 0.63 on the LOSSES)
     assert (num / den) ** 0.5 < (2e-3 if be.kind == "emu" else 3e-2)
+
+
+def test_prepared_layouts_match_the_slow_derivations(bound):
+    """csrc/prep.hip (one launch over a descriptor table) against the per-parameter derivations it replaces, for every
+    layout kind and weight rank, before and after a fused AdamW step (the table must be re-run, not re-built)."""
+    d = bound.device
+    ops = bound.ops
+    ws = [torch.nn.Parameter(paramgen.tensor("prep_w%d" % i, s, 3).to(d))
+          for i, s in enumerate([(24, 16), (16, 8, 3, 3, 3), (8, 12, 3, 3, 1), (10, 6, 1, 1, 1), (6, 4, 3, 3)])]
+    opt = torch.optim.AdamW(ws, lr=0.1, fused=True)
+
+    def slow(w, kind):
+        w = w.detach()
+        w5 = w.reshape(*w.shape, *([1] * (5 - w.dim()))) if w.dim() > 2 else w.reshape(*w.shape, 1, 1, 1)
+        cout, cin = w5.shape[:2]
+        if kind == "split":
+            return w.reshape(cout, -1)
+        if kind == "tap":
+            return w5.permute(0, 2, 3, 4, 1).reshape(cout, -1)
+        if kind == "wt":
+            return w.reshape(cout, -1).t()
+        if kind == "dg":
+            return w5.permute(1, 2, 3, 4, 0).reshape(cin, -1)
+        return w5.flip(2, 3, 4).permute(1, 2, 3, 4, 0).reshape(cin, -1)
+
+    for step in range(3):
+        seen = 0
+        for w in ws:
+            for kind in fused._WeightPrep.KINDS:
+                hit = fused.prepared(w, kind)
+                taps = w[0, 0].numel() if w.dim() > 2 else 1
+                if kind == "wt" and taps != 1:
+                    assert hit is None
+                    continue
+                if hit is None:          # odd inner dimension: stays on the per-parameter caches
+                    continue
+                seen += 1
+                want = slow(w, kind).contiguous()
+                f32, (hi, lo) = hit
+                if kind != "split":
+                    assert torch.equal(f32, want), (step, tuple(w.shape), kind)
+                rhi, rlo = ops.split_bf16(want)
+                assert torch.equal(hi, rhi) and torch.equal(lo, rlo), (step, tuple(w.shape), kind)
+        assert seen >= 18
+        for w in ws:
+            w.grad = torch.ones_like(w) * (step + 1)
+        opt.step()
