@@ -141,6 +141,23 @@ __device__ __forceinline__ occf_u32x4 occf_bbuf_load_b128(occf_bbuf b, uint32_t 
 #endif
 #define OCCF_BUF_OOB 0x80000000u        // a byte offset no bounded buffer (< 2 GiB) contains
 
+// LDS-DMA: a bounded 16-byte buffer load that lands in LDS without passing through VGPRs (buffer_load_dwordx4 ... lds).
+// The destination is WAVE-UNIFORM base + lane * 16 (the hardware's rule), the source offset is per lane; an offset
+// outside the buffer writes zeros.  Completion is tracked by vmcnt: the data may be read after s_waitcnt vmcnt(0) by
+// the issuing wave + a workgroup barrier (__syncthreads emits both).  `wave_uniform` = readfirstlane.
+#ifdef OCCF_EMU
+static inline void occf_bbuf_load_lds_b128(occf_bbuf b, uint32_t voff, void* lds_wave_base) {
+  const occf_u32x4 v = occf_bbuf_load_b128(b, voff);
+  memcpy((char*)lds_wave_base + (threadIdx.x & 63u) * 16u, &v, 16);
+}
+static inline int occf_wave_uniform(int v) { return v; }
+#else
+__device__ __forceinline__ void occf_bbuf_load_lds_b128(occf_bbuf b, uint32_t voff, void* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ int occf_wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
+
 // 24-bit unsigned multiply (v_mul_u32_u24: full rate, v_mul_lo_u32 is quarter rate); operands must be < 2^24
 #ifdef OCCF_EMU
 static inline uint32_t occf_umul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }

@@ -586,6 +586,8 @@ __global__ void __launch_bounds__(256) wgrad_small_kernel(const float* __restric
   }
 }
 
+#include "wgrad_g8.h"
+
 static int wg_mix() {
   static const int env = [] {
     const char* e = getenv("OCCF_WG_MIX");               // diagnostics: 0 = uniform (padded) tiles as in round 2
@@ -745,8 +747,13 @@ extern "C" long occf_conv3d_wgrad_workspace(int B, int Xi, int Yi, int Zi, int C
   const int Yo = (Yi + 2 * pad_y - dil * (kY - 1) - 1) / stride + 1;
   const int Zo = (Zi + 2 * pad_z - dil * (kZ - 1) - 1) / stride + 1;
   long need = wg_workspace((long)B * Xo * Yo * Zo, Cout, Cin, kX * kY * kZ);
+  const long M = (long)B * Xo * Yo * Zo, nx = (long)B * Xi * Yi * Zi * Cin, ny = M * Cout;
   if (wg_presplit_ok(Cin, Cout, kX * kY * kZ))        // bf16 (hi, lo) copies of dy and x: 4 bytes per element
-    need += (long)B * Xo * Yo * Zo * Cout + (long)B * Xi * Yi * Zi * Cin;
+    need += ny + nx;
+  if (Xo > 0 && Yo > 0 && Zo == Zi && wg8_eligible(Zi, Cin, Cout, kX, kY, kZ, stride, dil, pad_z, M, nx, ny)) {
+    const long g8 = wg8_workspace(B * Xo, Yo, Zi / 8, Cout, Cin, kX * kY * kZ, nx, ny);  // x in three z-shifted copies
+    if (g8 > need) need = g8;
+  }
   return need;
 }
 
@@ -773,6 +780,45 @@ extern "C" int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapm
   const long nx = (long)B * Xi * Yi * Zi * Cin, ny = a.M * Cout;
   const bool dense = in_sz == Cin && in_sy == (long)Zi * Cin && in_sx == (long)Yi * Zi * Cin &&
                      in_sb == (long)Xi * Yi * Zi * Cin;
+  if (dense && !dbias && workspace && g.Zo == Zi &&
+      wg8_eligible(Zi, Cin, Cout, kX, kY, kZ, stride, dil, pad_z, a.M, nx, ny) &&
+      workspace_floats >= wg8_workspace(B * g.Xo, g.Yo, Zi / 8, Cout, Cin, a.taps, nx, ny)) {
+    Wg8Args q = {};
+    const Wg8Geom gm = wg8_geometry(B * g.Xo, g.Yo, Zi / 8, Cout, Cin, a.taps);
+    const int S = gm.n_slabs;
+    const long Kt = (long)a.taps * Cin;
+    float* part = S > 1 ? workspace : dw_tapmajor;
+    uint16_t* yh = (uint16_t*)(workspace + (long)S * Cout * Kt);
+    uint16_t* yl = yh + ny;
+    uint16_t* xh = yl + ny;
+    uint16_t* xl = xh + 3 * nx;
+    const int ZG = Zi / 8;
+    const long cols = (long)B * Xi * Yi;
+    hipLaunchKernelGGL(wg8_split_y_kernel, dim3(occf_cdiv((a.M / 8) * Cout, 256)), dim3(256), 0, st, dy,
+                       (long)Cout, a.M / 8, Cout, (wg_u4*)yh, (wg_u4*)yl);
+    hipLaunchKernelGGL(wg8_split_x_kernel, dim3(occf_cdiv(cols * ZG * Cin, 256)), dim3(256), 0, st, x, cols, ZG,
+                       Cin, (wg_u4*)xh, (wg_u4*)xl, cols * ZG * Cin);
+    q.Yh = yh; q.Yl = yl; q.Xh = xh; q.Xl = xl; q.out = part; q.xcopy_elems = nx;
+    q.n_strips = gm.n_strips; q.strip_w = gm.strip_w; q.seg_planes = gm.seg_planes; q.planes = B * g.Xo;
+    q.slabs_per_xcd = (S + 7) / 8;
+    q.N = Cout; q.Cin = Cin; q.taps = a.taps; q.ybytes = (uint32_t)(ny * 2); q.xbytes = (uint32_t)(nx * 2);
+    q.B = B; q.Xo = g.Xo; q.Yo = g.Yo; q.Xi = Xi; q.Yi = Yi; q.ZG = ZG;
+    q.zg_shift = ZG == 1 ? 0 : ZG == 2 ? 1 : ZG == 4 ? 2 : 3;
+    q.kX = kX; q.kY = kY; q.kZ = kZ; q.pad_x = pad_x; q.pad_y = pad_y; q.n_slabs = S;
+    Wg8Seg sn[2], sc[2];
+    const int nn = wg8_segments(Cout, sn), nc = wg8_segments(Cin, sc);
+    for (int i = 0; i < nn; ++i)
+      for (int j = 0; j < nc; ++j) {
+        if (!sn[i].count || !sc[j].count) continue;
+        q.n_base = sn[i].base; q.tn_count = sn[i].count; q.c_base = sc[j].base; q.tc_count = sc[j].count;
+        q.tiles = a.taps * sn[i].count * sc[j].count;
+        wg8_launch_class(q, sn[i].w / 64, sc[j].w / 64, st);
+      }
+    if (S > 1)
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(occf_cdiv((long)Cout * Kt, 64)), dim3(256), 0, st, part, dw_tapmajor,
+                         (long)Cout * Kt, S);
+    return (int)hipGetLastError();
+  }
   if (wg_presplit_ok(Cin, Cout, a.taps) && dense && !dbias && workspace && workspace_floats >= nx + ny) {
     uint16_t* yh = (uint16_t*)(workspace + workspace_floats - (nx + ny));
     uint16_t* yl = yh + ny;

@@ -187,6 +187,15 @@ CONV_CASES = [
     # launch, pre-split per-column staging) and 160 = 128 + 32 (a 64-wide remainder tile, half masked)
     (1, (4, 5, 16), 192, 192, (3, 3, 3), 1, 1),
     (1, (5, 4, 8), 160, 96, (3, 3, 3), 1, 1),
+    # the G8 path (csrc/wgrad_g8.h: stride 1, 3^3, Z % 8 == 0, channels % 64 == 0; >= 1024 rows): LDS-DMA staging from
+    # z-shifted pre-split copies.  Tiles 128x64 / 64x128 (two batches, Z = 16: two z-groups per column), 192x192 with
+    # several slabs per XCD and a ragged last stage, Z = 32 (four z-groups per column, a stage spans half a column),
+    # 320 = 128 + 192 output channels (two tile classes in one call), a 3x3x3 window that leaves the grid in x and y
+    (2, (6, 6, 16), 64, 128, (3, 3, 3), 1, 1),
+    (1, (9, 15, 8), 192, 192, (3, 3, 3), 1, 1),
+    (1, (4, 9, 32), 128, 64, (3, 3, 3), 1, 1),
+    (1, (8, 8, 16), 64, 320, (3, 3, 3), 1, 1),
+    (1, (2, 64, 8), 64, 64, (3, 3, 3), 1, 1),
 ]
 
 
