@@ -309,6 +309,13 @@ int occf_modulated_deform_im2col(const float* x, const float* offset, const floa
 int occf_point_sample_3d_fwd(const float* vol, const float* pts, float* out, int N, int C, int X, int Y, int Z,
                              long P, int shared_pts, int align_corners, int border_padding, void* stream);
 
+/* The same with a ROW INDIRECTION and one channel: sample n reads the volume vol[rows[n]] of a stack vol[R, X, Y, Z]
+ * (rows int64 [N], values in [0, R)), out[N, P].  Replaces gt_masks[pos_assigned_gt_inds] followed by point_sample_3d
+ * (mask2former_nusc_occ.py:253-262, 383-390): the matched ground-truth rows are never copied. */
+int occf_point_sample_3d_rows_fwd(const float* vol, const int64_t* rows, const float* pts, float* out, int N, int X,
+                                  int Y, int Z, long P, int shared_pts, int align_corners, int border_padding,
+                                  void* stream);
+
 /* The same sampling on a CHANNELS-LAST volume: tok[X*Y*Z, C] (row stride ld >= C, C % 4 == 0), pts[P, 3] ->
  * out[P, C].  Used for the matching cost of the training step (mask2former_nusc_occ.py:232-238,
  * mask2former_occ.py:258-262 sample all Q query logits at the matching points): the query logits are a linear map of
@@ -356,10 +363,11 @@ long occf_colsum_workspace(long M, int N);
 int occf_colsum(const float* x, float* out, float* workspace, long M, int N, long ldx, void* stream);
 
 /* nn.LayerNorm backward: x/dy/dx[M, C]; dgamma/dbeta[C] (deterministic two-stage sums).
- * workspace: occf_layernorm_bwd_workspace floats. */
+ * workspace: occf_layernorm_bwd_workspace floats.  addend (may be NULL) [M, C]: dx = addend + (the LayerNorm gradient) --
+ * the gradient that reaches x through the residual connection around the normalised branch, added in the same pass. */
 long occf_layernorm_bwd_workspace(long M, int C);
-int occf_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,
-                       float* workspace, long M, int C, float eps, void* stream);
+int occf_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* addend, float* dx,
+                       float* dgamma, float* dbeta, float* workspace, long M, int C, float eps, void* stream);
 
 /* Backward of occf_groupnorm_apply (same x / stats / flags): dy[B, P, Zs, C] (Zs = Z + 1 in token mode: the
  * gradient of the z-mean slot is spread over the Z slices), dx[B, P, Z, C], dgamma/dbeta[C]; dresidual (may be

@@ -157,7 +157,10 @@ class Conv3d(torch.autograd.Function):
     """channels-last convolution y = conv(x) + b on the implicit-GEMM / halo kernels; weight in nn.Conv layout"""
 
     @staticmethod
-    def forward(ctx, x_cl, weight, bias, ks, stride, dil, pad):
+    def forward(ctx, x_cl, weight, bias, ks, stride, dil, pad, fork=False):
+        """``fork``: also return x_cl itself (-> (x_cl, y)) for the residual connection around the convolution: the node
+        then receives the residual gradient too and the data-gradient convolution adds it in its epilogue (a separate
+        ATen add of two [1, 200, 200, 16, 128] gradients per Dualpath / ASPP block otherwise)"""
         ops = get_ops()
         w2 = fused.tap_major_of(weight)
         y = ops.conv3d(x_cl, w2, ks, stride, dil, pad, None if bias is None else bias.detach(),
@@ -165,10 +168,17 @@ class Conv3d(torch.autograd.Function):
         ctx.save_for_backward(x_cl, weight)
         ctx.geom = (ks, stride, dil, pad)
         ctx.has_bias = bias is not None
+        ctx.fork = fork
+        if fork:
+            ctx.set_materialize_grads(False)
+            return x_cl, y
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, *grads):
+        dres, dy = grads if ctx.fork else (None, grads[0])
+        if dy is None:
+            return dres, None, None, None, None, None, None, None
         x_cl, weight = ctx.saved_tensors
         ks, stride, dil, pad = ctx.geom
         ops = get_ops()
@@ -185,7 +195,9 @@ class Conv3d(torch.autograd.Function):
                     return wf, _split(wf)
                 wf, sp = fused.prepared(weight, "flip") or fused._versioned(_FLIP_CACHE, weight, make)
                 dpad = tuple(dil * (k - 1) - p for k, p in zip(ks, pad))
-                dx = ops.conv3d(g, wf, ks, 1, dil, dpad, None, w_split=sp)
+                dx = ops.conv3d(g, wf, ks, 1, dil, dpad, None, w_split=sp,
+                                residual=None if dres is None else dres.contiguous())
+                dres = None
             else:
                 def make():
                     w5 = weight.detach() if weight.dim() == 5 else weight.detach().unsqueeze(-1)
@@ -193,13 +205,21 @@ class Conv3d(torch.autograd.Function):
                     return wt, ops.split_bf16(wt)
                 wt, sp = fused.prepared(weight, "dg") or fused._versioned(_DG_CACHE, weight, make)
                 dx = ops.conv3d_dgrad(g, sp, tuple(x_cl.shape), ks, stride, dil, pad)
+        if dres is not None:
+            dx = dres if dx is None else dx + dres
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw2, db = ops.conv3d_wgrad(g, x_cl, ks, stride, dil, pad, want_bias=ctx.has_bias)
             dw = dw2.view(Cout, *ks, Cin).permute(0, 4, 1, 2, 3)
             if weight.dim() == 4:
                 dw = dw.squeeze(-1)
             dw = dw.contiguous()
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv_fork(x_cl, conv_mod):
+    """-> (x_cl as the residual operand, conv(x_cl)); see Conv3d.forward"""
+    ks, stride, dil, pad = _conv_geometry(conv_mod)
+    return Conv3d.apply(x_cl, conv_mod.weight, conv_mod.bias, ks, stride, dil, pad, True)
 
 
 def conv(x_cl, conv_mod):
@@ -258,6 +278,35 @@ class LayerNorm(torch.autograd.Function):
 
 def layernorm(x, ln):
     return LayerNorm.apply(x, ln.weight, ln.bias, ln.eps)
+
+
+class LayerNormFork(torch.autograd.Function):
+    """(x, LN(x)) for a pre-norm residual block  x -> x + f(LN(x)):  the first output is x itself, to be used as the
+    residual operand.  One node then receives BOTH gradients of x and the LayerNorm backward kernel adds the residual
+    one in its own pass -- as two consumers of x, autograd summed them with a separate ATen add (three passes over
+    [680 000, 128] per norm at the 200-grid, 2 ms per training step)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        assert x.is_contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.eps = eps
+        ctx.set_materialize_grads(False)
+        return x, get_ops().layernorm(x, weight.detach(), bias.detach(), eps)
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x, weight = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None
+        dx, dg, db = get_ops().layernorm_backward(x, weight.detach(), dy.contiguous(), ctx.eps,
+                                                  addend=None if dres is None else dres.contiguous())
+        return dx, dg, db, None
+
+
+def layernorm_fork(x, ln):
+    """-> (x as the residual operand, LN(x)); see LayerNormFork"""
+    return LayerNormFork.apply(x.contiguous(), ln.weight, ln.bias, ln.eps)
 
 
 class Act(torch.autograd.Function):

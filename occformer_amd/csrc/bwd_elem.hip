@@ -114,7 +114,8 @@ extern "C" int occf_colsum(const float* x, float* out, float* workspace, long M,
 // One wave per row (statistics recomputed from x), a wave walks `rows_per_wave` rows and keeps the parameter
 // gradients of its channels in registers; workgroup partials -> partial[block][C][2].
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                            const float* __restrict__ dy, float* __restrict__ dx,
+                                                            const float* __restrict__ dy,
+                                                            const float* __restrict__ addend, float* __restrict__ dx,
                                                             float* __restrict__ partial, long M, int C, float eps,
                                                             int rows_per_wave) {
   __shared__ float red[4][1024][2];
@@ -187,10 +188,15 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < BE_MAXV; ++i) {
       const int q = lane + i * 64;
-      if (q < Q)
-        *(float4*)(dx + row * C + q * 4) =
-            make_float4(rstd * (gg[i][0] - s1 - xh[i][0] * s2), rstd * (gg[i][1] - s1 - xh[i][1] * s2),
-                        rstd * (gg[i][2] - s1 - xh[i][2] * s2), rstd * (gg[i][3] - s1 - xh[i][3] * s2));
+      if (q < Q) {
+        float4 o = make_float4(rstd * (gg[i][0] - s1 - xh[i][0] * s2), rstd * (gg[i][1] - s1 - xh[i][1] * s2),
+                               rstd * (gg[i][2] - s1 - xh[i][2] * s2), rstd * (gg[i][3] - s1 - xh[i][3] * s2));
+        if (addend) {
+          const float4 a = *(const float4*)(addend + row * C + q * 4);
+          o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+        *(float4*)(dx + row * C + q * 4) = o;
+      }
     }
   }
 #pragma unroll
@@ -217,7 +223,8 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
 // kernel above walks its rows serially with half of the lanes idle at C = 128: 0.4 TB/s on 680 000 x 128)
 template <int NV>
 __global__ void __launch_bounds__(256) layernorm16_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                              const float* __restrict__ dy, float* __restrict__ dx,
+                                                              const float* __restrict__ dy,
+                                                              const float* __restrict__ addend, float* __restrict__ dx,
                                                               float* __restrict__ partial, long M, float eps, int iters) {
   constexpr int C = 64 * NV;
   __shared__ float red[16][C][2];
@@ -283,10 +290,15 @@ __global__ void __launch_bounds__(256) layernorm16_bwd_kernel(const float* __res
     s2 /= (float)C;
     if (ok) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j)
-        *(float4*)(dx + row * C + (sub + 16 * j) * 4) =
-            make_float4(rstd * (gg[j][0] - s1 - xh[j][0] * s2), rstd * (gg[j][1] - s1 - xh[j][1] * s2),
-                        rstd * (gg[j][2] - s1 - xh[j][2] * s2), rstd * (gg[j][3] - s1 - xh[j][3] * s2));
+      for (int j = 0; j < NV; ++j) {
+        float4 o = make_float4(rstd * (gg[j][0] - s1 - xh[j][0] * s2), rstd * (gg[j][1] - s1 - xh[j][1] * s2),
+                               rstd * (gg[j][2] - s1 - xh[j][2] * s2), rstd * (gg[j][3] - s1 - xh[j][3] * s2));
+        if (addend) {
+          const float4 a = *(const float4*)(addend + row * C + (sub + 16 * j) * 4);
+          o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+        *(float4*)(dx + row * C + (sub + 16 * j) * 4) = o;
+      }
     }
   }
 #pragma unroll
@@ -325,21 +337,22 @@ extern "C" long occf_layernorm_bwd_workspace(long M, int C) {
   return (long)occf_cdiv(M, 4L * rpw) * C * 2;
 }
 
-extern "C" int occf_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma,
-                                  float* dbeta, float* workspace, long M, int C, float eps, void* stream) {
+extern "C" int occf_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* addend, float* dx,
+                                  float* dgamma, float* dbeta, float* workspace, long M, int C, float eps,
+                                  void* stream) {
   if (M <= 0 || C % 4 != 0 || C > 1024) return OCCF_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
   int nblk;
   if (C == 128 || C == 192 || C == 256) {
     const int iters = occf_ln16_iters(M);
     nblk = occf_cdiv(M, 16L * iters);
-    if (C == 128) hipLaunchKernelGGL(layernorm16_bwd_kernel<2>, dim3(nblk), dim3(256), 0, st, x, gamma, dy, dx, workspace, M, eps, iters);
-    else if (C == 192) hipLaunchKernelGGL(layernorm16_bwd_kernel<3>, dim3(nblk), dim3(256), 0, st, x, gamma, dy, dx, workspace, M, eps, iters);
-    else hipLaunchKernelGGL(layernorm16_bwd_kernel<4>, dim3(nblk), dim3(256), 0, st, x, gamma, dy, dx, workspace, M, eps, iters);
+    if (C == 128) hipLaunchKernelGGL(layernorm16_bwd_kernel<2>, dim3(nblk), dim3(256), 0, st, x, gamma, dy, addend, dx, workspace, M, eps, iters);
+    else if (C == 192) hipLaunchKernelGGL(layernorm16_bwd_kernel<3>, dim3(nblk), dim3(256), 0, st, x, gamma, dy, addend, dx, workspace, M, eps, iters);
+    else hipLaunchKernelGGL(layernorm16_bwd_kernel<4>, dim3(nblk), dim3(256), 0, st, x, gamma, dy, addend, dx, workspace, M, eps, iters);
   } else {
     const int rpw = occf_ln_rows_per_wave(M);
     nblk = occf_cdiv(M, 4L * rpw);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, st, x, gamma, dy, dx, workspace, M, C, eps, rpw);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, st, x, gamma, dy, addend, dx, workspace, M, C, eps, rpw);
   }
   occf_reduce_partials(workspace, dgamma, (long)nblk, C, (long)C * 2, 2, 0, st);
   occf_reduce_partials(workspace, dbeta, (long)nblk, C, (long)C * 2, 2, 1, st);

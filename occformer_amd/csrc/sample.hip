@@ -19,7 +19,8 @@ __global__ void __launch_bounds__(256) point_sample_3d_kernel(const float* __res
                                                               const float* __restrict__ pts,
                                                               float* __restrict__ out, int N, int C, int X, int Y,
                                                               int Z, long P, int shared_pts, int align_corners,
-                                                              int border, int cgroups) {
+                                                              int border, int cgroups,
+                                                              const long* __restrict__ rows) {
   // thread = (n, channel group, point): a thread per point alone left 12 544-point calls with 49 workgroups
   // walking 100 channels x 8 dependent gathers each (127 us per call)
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -46,7 +47,7 @@ __global__ void __launch_bounds__(256) point_sample_3d_kernel(const float* __res
   }
   const long V = (long)X * Y * Z;
   for (int c = cg; c < C; c += cgroups) {
-    const float* v = vol + ((long)n * C + c) * V;
+    const float* v = vol + ((rows ? rows[n] : (long)n) * C + c) * V;
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -72,7 +73,17 @@ extern "C" int occf_point_sample_3d_fwd(const float* vol, const float* pts, floa
   const int cgroups = 1;
   hipLaunchKernelGGL(point_sample_3d_kernel, dim3(occf_cdiv((long)N * cgroups * P, 256)), dim3(256), 0,
                      (hipStream_t)stream, vol, pts, out, N, C, X, Y, Z, P, shared_pts, align_corners, border_padding,
-                     cgroups);
+                     cgroups, (const long*)nullptr);
+  OCCF_LAUNCH_CHECK();
+}
+
+extern "C" int occf_point_sample_3d_rows_fwd(const float* vol, const int64_t* rows, const float* pts, float* out, int N,
+                                             int X, int Y, int Z, long P, int shared_pts, int align_corners,
+                                             int border_padding, void* stream) {
+  if (N <= 0 || X <= 0 || Y <= 0 || Z <= 0 || P < 0 || !rows) return OCCF_EINVAL;
+  if (P == 0) return 0;
+  hipLaunchKernelGGL(point_sample_3d_kernel, dim3(occf_cdiv((long)N * P, 256)), dim3(256), 0, (hipStream_t)stream, vol,
+                     pts, out, N, 1, X, Y, Z, P, shared_pts, align_corners, border_padding, 1, (const long*)rows);
   OCCF_LAUNCH_CHECK();
 }
 

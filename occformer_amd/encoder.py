@@ -132,7 +132,8 @@ class SwinBlock(nn.Module):
         B, X, Y, S, C = tok.shape
         t = tok.reshape(-1, C)
         m = self.attn.w_msa
-        qkv = A.linear(A.layernorm(t, self.norm1), m.qkv)
+        t, n1 = A.layernorm_fork(t, self.norm1)           # (t continues as the residual operand)
+        qkv = A.linear(n1, m.qkv)
         a = A.WindowAttention.apply(qkv, m.qkv.bias, m.relative_position_bias_table, B, X, Y, S, self.heads,
                                     self.attn.shift_size)
         sc = self._drop_path(B, S, tok.device)
@@ -140,7 +141,8 @@ class SwinBlock(nn.Module):
             t = A.linear(a, m.proj, residual=t)
         else:
             t = A.DropPathAdd.apply(t, A.linear(a, m.proj), sc, X * Y, S)
-        f = A.Act.apply(A.linear(A.layernorm(t, self.norm2), self.ffn.layers[0][0]), 2)
+        t, n2 = A.layernorm_fork(t, self.norm2)
+        f = A.Act.apply(A.linear(n2, self.ffn.layers[0][0]), 2)
         sc = self._drop_path(B, S, tok.device)
         if sc is None:
             t = A.linear(f, self.ffn.layers[1], residual=t)
@@ -251,11 +253,15 @@ class DualpathTransformerBlock(nn.Module):
         ops = get_ops()
         x_cl = fused.channels_last_view(x.float())
         if self.training:
-            tok = A.conv_gn(x_cl, self.input_conv[0], self.input_conv[1], relu=True, tokens=True)
+            if self.stride > 1:
+                tok = A.conv_gn(x_cl, self.input_conv[0], self.input_conv[1], relu=True, tokens=True)
+                ident = A.conv_gn(x_cl, self.downsample[0], self.downsample[1])
+            else:       # x_cl is also the identity operand: its two gradients meet inside the convolution's backward
+                ident, y = A.conv_fork(x_cl, self.input_conv[0])
+                tok = A.group_norm(y, self.input_conv[1], relu=True, tokens=True)
             Z = tok.shape[3] - 1
             tok = self.bev_encoder(tok)
             bev = self.aspp(tok[:, :, :, Z:Z + 1])
-            ident = A.conv_gn(x_cl, self.downsample[0], self.downsample[1]) if self.stride > 1 else x_cl
             out = A.DualpathCombine.apply(tok, bev.reshape(*bev.shape[:3], -1), self.combine_coeff.weight,
                                           self.combine_coeff.bias, ident)
             return out.permute(0, 4, 1, 2, 3)

@@ -540,6 +540,22 @@ class HipOps:
                    self._stream())
         return out
 
+    def point_sample_3d_rows(self, vol, rows, pts, align_corners=False, padding_mode="zeros"):
+        """vol [R, X, Y, Z] (contiguous); rows int64 [N] in [0, R); pts [N, P, 3] (or [1, P, 3] shared) -> [N, P]:
+        point_sample_3d(vol[rows].unsqueeze(1), pts)[:, 0] without materialising vol[rows]"""
+        R, X, Y, Z = vol.shape
+        N, P = rows.shape[0], pts.shape[1]
+        shared = pts.shape[0] == 1 and N > 1
+        if not vol.is_contiguous() or rows.dtype != torch.int64 or not (shared or pts.shape[0] == N):
+            raise OccfError("point_sample_3d_rows: contiguous [R, X, Y, Z] volume, int64 rows, [N | 1, P, 3] points")
+        out = torch.empty((N, P), dtype=vol.dtype, device=vol.device)
+        if N == 0:
+            return out
+        self._call("occf_point_sample_3d_rows_fwd", self._ptr(vol, self.f32), self._ptr(rows.contiguous(), torch.int64),
+                   self._ptr(pts.contiguous(), self.f32), self._ptr(out), N, X, Y, Z, P, int(shared),
+                   int(align_corners), int(padding_mode == "border"), self._stream())
+        return out
+
     def point_sample_tokens(self, tok, dims, pts, align_corners=False, padding_mode="zeros"):
         """tok [V = X*Y*Z, C] channels-last volume (unit column stride); pts [P, 3] in [0, 1] (grid_sample order)
         -> [P, C]"""
@@ -650,15 +666,19 @@ class HipOps:
                    self._stream())
         return out
 
-    def layernorm_backward(self, x, gamma, dy, eps=1e-5):
+    def layernorm_backward(self, x, gamma, dy, eps=1e-5, addend=None):
+        """-> (dx [+ addend: the residual connection's gradient, same pass], dgamma, dbeta)"""
         C = x.shape[-1]
         M = x.numel() // C
         dx = torch.empty_like(x)
         dg = torch.empty((C,), dtype=self.f32, device=x.device)
         db = torch.empty((C,), dtype=self.f32, device=x.device)
         ws = self._ws(self.lib.occf_layernorm_bwd_workspace(M, C), x.device)
+        if addend is not None and (tuple(addend.shape) != tuple(x.shape) or not addend.is_contiguous()):
+            raise OccfError("layernorm_backward: addend must be a contiguous tensor of x's shape")
         self._call("occf_layernorm_bwd", self._ptr(x, self.f32), self._ptr(gamma, self.f32), self._ptr(dy, self.f32),
-                   self._ptr(dx), self._ptr(dg), self._ptr(db), self._ptr(ws), M, C, float(eps), self._stream())
+                   self._ptr(addend, self.f32), self._ptr(dx), self._ptr(dg), self._ptr(db), self._ptr(ws), M, C,
+                   float(eps), self._stream())
         return dx, dg, db
 
     def groupnorm_backward(self, x_cl, stats, gamma, beta, dy, groups, relu=False, tokens=False, want_residual=False):

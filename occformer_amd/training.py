@@ -231,6 +231,46 @@ def point_sample_3d(input, points, align_corners=False, padding_mode="zeros"):
     return get_ops().point_sample_3d(input.contiguous(), points.contiguous(), align_corners, padding_mode)
 
 
+class MaskRows:
+    """``cat([masks_b[rows_b] for b in images])`` -- the matched ground-truth masks of a prediction set
+    (mask2former_nusc_occ.py:253-262) -- without the copy: parts = [(masks_b [R_b, X, Y, Z] float, rows_b int64 [n_b])].
+    Materialised, this was a 33 MB row gather plus a 33 MB concatenation per prediction set at the 200-grid (0.24 ms,
+    ten times per training step), only to be read once by a point sampler."""
+
+    def __init__(self, parts):
+        self.parts = list(parts)
+
+    @property
+    def shape(self):
+        return (sum(int(r.shape[0]) for _, r in self.parts),) + tuple(self.parts[0][0].shape[1:])
+
+    @staticmethod
+    def cat(items):
+        return MaskRows([p for it in items for p in it.parts])
+
+    def dense(self):
+        return torch.cat([m[r] for m, r in self.parts], 0)
+
+    def sample(self, coords, align_corners=False, padding_mode="zeros"):
+        """point_sample_3d(dense().unsqueeze(1).float(), coords).squeeze(1); coords [n, P, 3] in grid_sample order"""
+        out, r0 = [], 0
+        for m, r in self.parts:
+            n = int(r.shape[0])
+            out.append(get_ops().point_sample_3d_rows(m.float().contiguous(), r, coords[r0:r0 + n], align_corners,
+                                                      padding_mode))
+            r0 += n
+        return out[0] if len(out) == 1 else torch.cat(out, 0)
+
+    def gather(self, idx):
+        """torch.gather(dense().reshape(n, -1), 1, idx); idx [n, K] voxel indices"""
+        out, r0 = [], 0
+        for m, r in self.parts:
+            n = int(r.shape[0])
+            out.append(m.reshape(m.shape[0], -1)[r.unsqueeze(1), idx[r0:r0 + n]])
+            r0 += n
+        return out[0] if len(out) == 1 else torch.cat(out, 0)
+
+
 def unravel_indices(indices, shape):
     """mmdet_utils.py:71-89"""
     coord = []
@@ -245,12 +285,9 @@ def gt_label_scan(gt_occ, num_classes):
     -> (labels_sorted [num_classes] int64: the present labels in ascending order first, n_present [] int64).
     No data-dependent shape, hence no host synchronisation: it can run on a side stream one step ahead
     (``OccupancyFormer.prefetch_gt``)."""
-    flat = gt_occ.reshape(-1).long()
-    valid = (flat >= 0) & (flat < num_classes)
-    cnt = torch.zeros(num_classes, dtype=torch.int32, device=gt_occ.device)
-    cnt.scatter_add_(0, torch.where(valid, flat, torch.zeros_like(flat)), valid.int())
-    present = cnt > 0
+    # (one comparison per class, not a scatter-add histogram: 640 000 atomics onto 17 counters took 0.93 ms)
     ar = torch.arange(num_classes, device=gt_occ.device)
+    present = (gt_occ.reshape(1, -1) == ar.to(gt_occ.dtype).view(-1, 1)).any(1)
     labels_sorted = torch.sort(torch.where(present, ar, torch.full_like(ar, num_classes)))[0]
     return labels_sorted, present.sum()
 
@@ -541,7 +578,7 @@ class OccHeadTrainingMixin:
         cw = self._const("class_weight", self.class_weight, cls_score.device, cls_score.dtype)
         mask_weights = cls_score.new_zeros((self.num_queries,))
         mask_weights[pos] = cw[labels[pos]]
-        return labels, torch.ones_like(mask_weights), gt_masks[pos_gt], mask_weights, pos, pos_gt
+        return labels, torch.ones_like(mask_weights), MaskRows([(gt_masks, pos_gt)]), mask_weights, pos, pos_gt
 
     def loss(self, all_cls_scores, all_mask_preds, *gt):
         """mask2former_nusc_occ.py:275-315 / mask2former_occ.py:294-341"""
@@ -596,7 +633,7 @@ class OccHeadTrainingMixin:
     def _cls_and_select(self, cls_scores, mask_preds, targets):
         labels = torch.stack([t[0] for t in targets]).flatten()
         label_weights = torch.stack([t[1] for t in targets]).flatten()
-        mask_targets = torch.cat([t[2] for t in targets], 0)
+        mask_targets = MaskRows.cat([t[2] for t in targets])
         mask_weights = torch.stack([t[3] for t in targets])
         cw = self._const("class_weight", self.class_weight, cls_scores.device, cls_scores.dtype)
         loss_cls = cross_entropy_loss(cls_scores.flatten(0, 1), labels, label_weights, cw, cw[labels].sum(),
@@ -657,7 +694,7 @@ class NuscTrainingMixin(OccHeadTrainingMixin):
                                                     self.oversample_ratio, self.importance_sample_ratio,
                                                     self.point_cloud_range, self._rng(mpd.device),
                                                     padding_mode=self.padding_mode).flip(-1).contiguous()
-            pt = point_sample_3d(mask_targets.unsqueeze(1).float(), coords, padding_mode=self.padding_mode).squeeze(1)
+            pt = mask_targets.sample(coords, False, self.padding_mode)
         return dict(loss_cls=loss_cls, mp=mp, mw=mw, coords=coords, pt=pt)
 
     def _loss_finish(self, prep, pp):
@@ -738,7 +775,7 @@ class KittiTrainingMixin(OccHeadTrainingMixin):
             idx, coords = get_uncertain_point_coords_3d_with_frequency(
                 mpd.unsqueeze(1), None, gt_labels_list, gt_masks_list, self.sample_weights, self.num_points,
                 self.oversample_ratio, self.importance_sample_ratio, self._rng(mpd.device))
-            pt = torch.gather(mask_targets.reshape(mask_targets.shape[0], -1), 1, idx).float()
+            pt = mask_targets.gather(idx).float()
         return dict(loss_cls=loss_cls, mp=mp, mw=mw, coords=coords.flip(-1).contiguous(), pt=pt)
 
     def _loss_finish(self, prep, pp):

@@ -33,6 +33,64 @@ def test_layernorm_backward(be, C):
     F.layer_norm(x, (C,), g, b, 1e-5).backward(dy)
     dx, dg, db = be.ops.layernorm_backward(*be.to(x.detach(), g.detach(), dy), 1e-5)
     assert _rel(dx.cpu(), x.grad) < 1e-4 and _rel(dg.cpu(), g.grad) < 1e-4 and _rel(db.cpu(), b.grad) < 1e-4
+    # the residual connection's gradient added in the same pass
+    add = _t("ln_add", (M, C), C + 3)
+    dx2, dg2, db2 = be.ops.layernorm_backward(*be.to(x.detach(), g.detach(), dy), 1e-5, addend=be.to(add))
+    assert torch.equal(dx2.cpu(), dx.cpu() + add) and torch.equal(dg2.cpu(), dg.cpu()) and torch.equal(db2.cpu(), db.cpu())
+
+
+def test_fork_nodes_fuse_the_residual_gradient(be, monkeypatch):
+    """LayerNormFork / conv_fork (autograd.py): x -> x + f(LN(x)) and x -> conv(x) (+) x with ONE autograd node seeing
+    both gradients of x -- same values as the two-consumer graph, whose sum autograd computes with a separate add"""
+    import occformer_amd.ops as ops_mod
+    from occformer_amd import autograd as A
+    monkeypatch.setattr(ops_mod, "_ops", be.ops)
+    d = be.device
+    ln = torch.nn.LayerNorm(128).to(d)
+    lin = torch.nn.Linear(128, 128).to(d)
+    x = _t("fk_x", (300, 128), 1).to(d).requires_grad_()
+    w = _t("fk_w", (300, 128), 2).to(d)
+
+    def run(fork):
+        for p in (*ln.parameters(), *lin.parameters()):
+            p.grad = None
+        x.grad = None
+        h = x * 1.0
+        if fork:
+            r, n = A.layernorm_fork(h, ln)
+        else:
+            r, n = h, A.layernorm(h, ln)
+        y = A.linear(n, lin, residual=r)
+        (y * w).sum().backward()
+        return [x.grad.clone()] + [p.grad.clone() for p in (*ln.parameters(), *lin.parameters())]
+    for a, b in zip(run(True), run(False)):
+        assert _rel(a.cpu(), b.cpu()) < 1e-5
+    # only the normalised branch used / only the residual used
+    h = x * 1.0
+    r, n = A.layernorm_fork(h, ln)
+    x.grad = None
+    (n * w).sum().backward()
+    ga = x.grad.clone()
+    x.grad = None
+    (A.layernorm(x * 1.0, ln) * w).sum().backward()
+    assert _rel(ga.cpu(), x.grad.cpu()) < 1e-5
+
+    conv = torch.nn.Conv3d(64, 64, 3, padding=1, bias=False).to(d)
+    xc = _t("fk_xc", (1, 5, 6, 8, 64), 3).to(d).requires_grad_()
+    wc = _t("fk_wc", (1, 5, 6, 8, 64), 4).to(d)
+
+    def runc(fork):
+        conv.weight.grad = None
+        xc.grad = None
+        h = xc * 1.0
+        if fork:
+            r, y = A.conv_fork(h, conv)
+        else:
+            r, y = h, A.conv(h, conv)
+        ((y + r * 0.5) * wc).sum().backward()
+        return xc.grad.clone(), conv.weight.grad.clone()
+    for a, b in zip(runc(True), runc(False)):
+        assert _rel(a.cpu(), b.cpu()) < 1e-5
 
 
 @pytest.mark.parametrize("relu,tokens,res", [(True, True, False), (False, False, False), (True, False, True),

@@ -22,6 +22,37 @@ def test_point_sample_3d(be, align, pad):
     assert torch.allclose(out2, ref2, atol=2e-5, rtol=1e-4)
 
 
+
+def test_point_sample_3d_rows_is_gather_then_sample(be):
+    """occf_point_sample_3d_rows_fwd == point_sample_3d(vol[rows][:, None], pts)[:, 0] bit for bit (per-row and shared
+    points, both padding modes, repeated and unordered rows); MaskRows.sample / .gather / .dense over two images"""
+    from occformer_amd.training import MaskRows
+    import occformer_amd.ops as ops_mod
+    vol = paramgen.tensor("psr_v", (5, 6, 7, 4), 1)
+    rows = torch.tensor([3, 0, 3, 4, 1, 1], dtype=torch.int64)
+    pts = paramgen.uniform("psr_p", (6, 50, 3), 2) * 1.2 - 0.1
+    for align in (False, True):
+        for pad in ("zeros", "border"):
+            for p in (pts, pts[:1]):
+                ref = be.ops.point_sample_3d(be.to(vol[rows].unsqueeze(1).contiguous()), be.to(p), align, pad)[:, 0]
+                out = be.ops.point_sample_3d_rows(be.to(vol), be.to(rows), be.to(p), align, pad)
+                assert torch.equal(out.cpu(), ref.cpu())
+    old = ops_mod._ops
+    ops_mod._ops = be.ops
+    try:
+        vol2 = paramgen.tensor("psr_v2", (3, 6, 7, 4), 3)
+        r2 = torch.tensor([2, 0], dtype=torch.int64)
+        mr = MaskRows.cat([MaskRows([(be.to(vol), be.to(rows))]), MaskRows([(be.to(vol2), be.to(r2))])])
+        dense = torch.cat((vol[rows], vol2[r2]), 0)
+        assert mr.shape == (8, 6, 7, 4) and torch.equal(mr.dense().cpu(), dense)
+        pts8 = paramgen.uniform("psr_p8", (8, 20, 3), 4)
+        ref = be.ops.point_sample_3d(be.to(dense.unsqueeze(1).contiguous()), be.to(pts8), False, "border")[:, 0]
+        assert torch.equal(mr.sample(be.to(pts8), False, "border").cpu(), ref.cpu())
+        idx = torch.randint(0, 6 * 7 * 4, (8, 9), generator=torch.Generator().manual_seed(0))
+        assert torch.equal(mr.gather(be.to(idx)).cpu(), torch.gather(dense.reshape(8, -1), 1, idx))
+    finally:
+        ops_mod._ops = old
+
 @pytest.mark.parametrize("align,pad", [(False, "border"), (True, "zeros"), (False, "zeros")])
 def test_point_sample_tokens_and_lazy_matching_logits(be, align, pad):
     """channels-last sampling == grid_sample of the channel-major volume; and sampling the mask FEATURES then
