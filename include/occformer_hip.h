@@ -471,6 +471,13 @@ int occf_deform_col2im(const float* x, const float* offset, const float* dcol, f
                        int H, int W, int C, int K, int stride, int pad, int dil, int groups, int deform_groups,
                        void* stream);
 
+/* DCNv2 backward (mmcv-full 1.4.0 `modulated_deformable_col2im` + `modulated_deformable_col2im_coord`, behind the
+ * R101-DCN image backbone, occformer_nusc_r101_896x1600.py:78-79): as occf_deform_col2im with the forward's modulation
+ * mask[BN, dg*K*K, Ho, Wo]; dmask of the same shape receives the gradient of the (already sigmoid-ed) modulation. */
+int occf_modulated_deform_col2im(const float* x, const float* offset, const float* mask, const float* dcol, float* dx,
+                                 float* doffset, float* dmask, int BN, int H, int W, int C, int K, int stride, int pad,
+                                 int dil, int groups, int deform_groups, void* stream);
+
 /* One launch for a TABLE of strided-gather + bf16-split jobs (the per-step "prepare weights" pass: tap-major,
  * transposed, tap-flipped layouts and (hi, lo) splits of every parameter).  table[(n + 1) * 15] int64 on the device, row
  * r = {in, f32_out or 0, hi_out, lo_out, first pair index, dims[5], input strides[5] (elements, base offset folded

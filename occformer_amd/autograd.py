@@ -461,28 +461,30 @@ class PointLossRows(torch.autograd.Function):
 
 
 class DeformConv(torch.autograd.Function):
-    """DCNv1: bilinear im2col (csrc/dcn.hip) + grouped contraction; x_cl [BN, H, W, C], offset [BN, dg*2*K*K, H, W],
-    weight [Cout, Cin/groups, K, K] -> [BN*H*W, Cout]"""
+    """DCNv1 / DCNv2: bilinear im2col (csrc/dcn.hip) + grouped contraction; x_cl [BN, H, W, C], offset
+    [BN, dg*2*K*K, Ho, Wo], weight [Cout, Cin/groups, K, K] (, mask [BN, dg*K*K, Ho, Wo]: the sigmoid-ed modulation of
+    DCNv2) -> [BN*Ho*Wo, Cout]"""
 
     @staticmethod
-    def forward(ctx, x_cl, offset, weight, K, pad, groups, dgroups):
+    def forward(ctx, x_cl, offset, weight, K, pad, groups, dgroups, mask=None, stride=1):
         ops = get_ops()
         x_cl, offset = x_cl.contiguous(), offset.contiguous()
-        col = ops.deform_im2col(x_cl, offset, K, 1, pad, 1, groups, dgroups)
+        mask = None if mask is None else mask.contiguous()
+        col = ops.deform_im2col(x_cl, offset, K, stride, pad, 1, groups, dgroups, mask=mask)
         Cout = weight.shape[0]
         out = torch.empty((col.shape[0], Cout), dtype=x_cl.dtype, device=x_cl.device)
         og = Cout // groups
         for g, wg in enumerate(weight.detach().chunk(groups, 0)):
             w2 = wg.permute(0, 2, 3, 1).reshape(og, -1).contiguous()
             ops.linear(col[:, g].flatten(1), w2, out=out[:, g * og:(g + 1) * og], w_split=_split(w2))
-        ctx.save_for_backward(x_cl, offset, weight, col)
-        ctx.cfg = (K, pad, groups, dgroups)
+        ctx.save_for_backward(x_cl, offset, weight, col, mask)
+        ctx.cfg = (K, pad, groups, dgroups, stride)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x_cl, offset, weight, col = ctx.saved_tensors
-        K, pad, groups, dgroups = ctx.cfg
+        x_cl, offset, weight, col, mask = ctx.saved_tensors
+        K, pad, groups, dgroups, stride = ctx.cfg
         ops = get_ops()
         dout = dout.contiguous()
         Cout = weight.shape[0]
@@ -496,8 +498,12 @@ class DeformConv(torch.autograd.Function):
             ops.linear(dy_g, wt, None, out=dcol[:, g].flatten(1), w_split=_split(wt))
             dw2, _ = ops.linear_wgrad(dy_g, col[:, g].flatten(1), want_bias=False)
             dws.append(dw2.view(og, K, K, cpg).permute(0, 3, 1, 2))
-        dx, doff = ops.deform_col2im(x_cl, offset, dcol, K, 1, pad, 1, groups, dgroups)
-        return dx, doff, torch.cat(dws, 0).contiguous(), None, None, None, None
+        dw = torch.cat(dws, 0).contiguous()
+        if mask is not None:
+            dx, doff, dmask = ops.deform_col2im(x_cl, offset, dcol, K, stride, pad, 1, groups, dgroups, mask=mask)
+            return dx, doff, dw, None, None, None, None, dmask, None
+        dx, doff = ops.deform_col2im(x_cl, offset, dcol, K, stride, pad, 1, groups, dgroups)
+        return dx, doff, dw, None, None, None, None, None, None
 
 
 class SampledMaskLogitsJoint(torch.autograd.Function):

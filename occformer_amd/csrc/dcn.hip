@@ -96,10 +96,13 @@ extern "C" int occf_modulated_deform_im2col(const float* x, const float* offset,
 // column layout -> dx (bilinear scatter, float atomics; ZERO-FILLED by the caller) and doffset[BN, dg*2*K*K, Ho, Wo]
 // (every element written).  One wave per (output pixel, tap, deform group): lanes stride over the channel quads of
 // the group, the two coordinate gradients are wave reductions.
+// `mask` != NULL (DCNv2, mmcv `modulated_deformable_col2im` + `_coord`): the forward sample was scaled by the modulation
+// mk = mask[bn, dg*K*K + t, ho, wo], so dx and doffset carry the factor mk and dmask[bn, dg*K*K + t, ho, wo] =
+// <dcol, unscaled sample> (every element written).
 __global__ void __launch_bounds__(256) deform_col2im_kernel(
-    const float* __restrict__ x, const float* __restrict__ offset, const float* __restrict__ dcol,
-    float* __restrict__ dx, float* __restrict__ doffset, int BN, int H, int W, int C, int Ho, int Wo, int K, int stride,
-    int pad, int dil, int groups, int dgroups) {
+    const float* __restrict__ x, const float* __restrict__ offset, const float* __restrict__ mask,
+    const float* __restrict__ dcol, float* __restrict__ dx, float* __restrict__ doffset, float* __restrict__ dmask,
+    int BN, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad, int dil, int groups, int dgroups) {
   const int KK = K * K;
   const int lane = threadIdx.x & 63;
   const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -118,7 +121,9 @@ __global__ void __launch_bounds__(256) deform_col2im_kernel(
   const long obase = (((long)bn * dgroups + dg) * 2 * KK + 2 * t) * Ho * Wo + (long)ho * Wo + wo;
   const float py = (float)(ho * stride - pad + ky * dil) + offset[obase];
   const float px = (float)(wo * stride - pad + kx * dil) + offset[obase + (long)Ho * Wo];
-  float gy = 0.f, gx = 0.f;
+  float gy = 0.f, gx = 0.f, gm = 0.f;
+  const long mbase = (((long)bn * dgroups + dg) * KK + t) * Ho * Wo + (long)ho * Wo + wo;
+  const float mk = mask ? mask[mbase] : 1.f;
   if (py > -1.f && px > -1.f && py < (float)H && px < (float)W) {
     const float fy = floorf(py), fx = floorf(px);
     const int y0 = (int)fy, x0 = (int)fx;
@@ -140,8 +145,9 @@ __global__ void __launch_bounds__(256) deform_col2im_kernel(
         const float dot = (gc.x * v.x + gc.y * v.y) + (gc.z * v.z + gc.w * v.w);
         gy = fmaf(((k >> 1) ? 1.f : -1.f) * wx, dot, gy);
         gx = fmaf(((k & 1) ? 1.f : -1.f) * wy, dot, gx);
+        gm = fmaf(wy * wx, dot, gm);
         float* d = db + ((long)yy * W + xx) * C;
-        const float wgt = wy * wx;
+        const float wgt = wy * wx * mk;
         atomicAdd(d + 0, wgt * gc.x);
         atomicAdd(d + 1, wgt * gc.y);
         atomicAdd(d + 2, wgt * gc.z);
@@ -153,10 +159,12 @@ __global__ void __launch_bounds__(256) deform_col2im_kernel(
   for (int o = 32; o > 0; o >>= 1) {
     gy += __shfl_xor(gy, o);
     gx += __shfl_xor(gx, o);
+    gm += __shfl_xor(gm, o);
   }
   if (lane == 0) {
-    doffset[obase] = gy;
-    doffset[obase + (long)Ho * Wo] = gx;
+    doffset[obase] = gy * mk;
+    doffset[obase + (long)Ho * Wo] = gx * mk;
+    if (dmask) dmask[mbase] = gm;
   }
 }
 
@@ -169,6 +177,22 @@ extern "C" int occf_deform_col2im(const float* x, const float* offset, const flo
   const int Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
   const long waves = (long)BN * Ho * Wo * K * K * deform_groups;
   hipLaunchKernelGGL(deform_col2im_kernel, dim3(occf_cdiv(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                     offset, dcol, dx, doffset, BN, H, W, C, Ho, Wo, K, stride, pad, dil, groups, deform_groups);
+                     offset, (const float*)nullptr, dcol, dx, doffset, (float*)nullptr, BN, H, W, C, Ho, Wo, K, stride,
+                     pad, dil, groups, deform_groups);
+  OCCF_LAUNCH_CHECK();
+}
+
+extern "C" int occf_modulated_deform_col2im(const float* x, const float* offset, const float* mask, const float* dcol,
+                                            float* dx, float* doffset, float* dmask, int BN, int H, int W, int C, int K,
+                                            int stride, int pad, int dil, int groups, int deform_groups, void* stream) {
+  if (BN <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || groups <= 0 || deform_groups <= 0 || !mask || !dmask)
+    return OCCF_EINVAL;
+  if (C % groups || C % deform_groups || (C / groups) % 4 || (C / deform_groups) % 4) return OCCF_ESHAPE;
+  const int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  const int Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  const long waves = (long)BN * Ho * Wo * K * K * deform_groups;
+  hipLaunchKernelGGL(deform_col2im_kernel, dim3(occf_cdiv(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     offset, mask, dcol, dx, doffset, dmask, BN, H, W, C, Ho, Wo, K, stride, pad, dil, groups,
+                     deform_groups);
   OCCF_LAUNCH_CHECK();
 }

@@ -586,6 +586,46 @@ __global__ void __launch_bounds__(256) wgrad_small_kernel(const float* __restric
   }
 }
 
+// the same for M <= 2048 as a 32 x 32 register-tiled contraction staged through LDS: the kernel above re-reads dY and X
+// once per OUTPUT (8 lanes walking M with strided loads: 28 us per call for the decoder's 100-row linears, ~120 calls
+// per training step); here a workgroup reads its 32 columns of each operand once
+__global__ void __launch_bounds__(256) wgrad_small_tile_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                               float* __restrict__ dW, float* __restrict__ db, long M,
+                                                               int N, int K, long ldy, long ldx) {
+  __shared__ float ys[32][33], xs[32][33];
+  const int ktiles = (K + 31) / 32;
+  const int n0 = (int)(blockIdx.x / ktiles) * 32, k0 = (int)(blockIdx.x % ktiles) * 32;
+  const int tid = threadIdx.x, n = tid >> 3, kq = (tid & 7) * 4;
+  const int lr = tid >> 5, lc = tid & 31;                       // loader: rows lr, lr + 8, .. of column lc
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}, bsum = 0.f;
+  const bool do_b = db != nullptr && k0 == 0 && (tid & 7) == 0;
+  for (long m0 = 0; m0 < M; m0 += 32) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long m = m0 + lr + 8 * j;
+      ys[lr + 8 * j][lc] = (m < M && n0 + lc < N) ? dY[m * ldy + n0 + lc] : 0.f;
+      xs[lr + 8 * j][lc] = (m < M && k0 + lc < K) ? X[m * ldx + k0 + lc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      const float a = ys[r][n];
+      acc[0] = fmaf(a, xs[r][kq + 0], acc[0]);
+      acc[1] = fmaf(a, xs[r][kq + 1], acc[1]);
+      acc[2] = fmaf(a, xs[r][kq + 2], acc[2]);
+      acc[3] = fmaf(a, xs[r][kq + 3], acc[3]);
+      if (do_b) bsum += a;
+    }
+    __syncthreads();
+  }
+  if (n0 + n < N) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k0 + kq + j < K) dW[(long)(n0 + n) * K + k0 + kq + j] = acc[j];
+    if (do_b) db[n0 + n] = bsum;
+  }
+}
+
 #include "wgrad_g8.h"
 
 static int wg_mix() {
@@ -712,6 +752,11 @@ extern "C" int occf_linear_wgrad(const float* dy, const float* x, float* dw, flo
   hipStream_t st = (hipStream_t)stream;
   if (M <= 1024 || N % 4 || K % 4 || ldy % 4 || ldx % 4) {
     if (M > 65536) return OCCF_ESHAPE;
+    if (M <= 2048) {
+      hipLaunchKernelGGL(wgrad_small_tile_kernel, dim3((unsigned)(((N + 31) / 32) * ((K + 31) / 32))), dim3(256), 0, st,
+                         dy, x, dw, dbias, M, N, K, ldy, ldx);
+      return (int)hipGetLastError();
+    }
     const long total = ((long)N * K > N ? (long)N * K : N) * 8;
     hipLaunchKernelGGL(wgrad_small_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, dy, x, dw, dbias, M, N, K,
                        ldy, ldx);

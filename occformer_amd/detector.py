@@ -38,6 +38,7 @@ class ModulatedDeformConv2dPack(nn.Module):
         if groups != 1:
             raise NotImplementedError("grouped DCNv2 is not used by the OccFormer configs")
         self.k, self.stride, self.padding, self.dilation, self.dg = kernel_size, stride, padding, dilation, deform_groups
+        self.force_hip = False          # tests: route CPU tensors through the bound library (the host emulation)
         self.weight = nn.Parameter(torch.empty(cout, cin, kernel_size, kernel_size))
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
         nn.init.kaiming_uniform_(self.weight, nonlinearity="relu")
@@ -67,8 +68,17 @@ class ModulatedDeformConv2dPack(nn.Module):
         o1, o2, logit = torch.chunk(self.conv_offset(x), 3, dim=1)
         offset = torch.cat((o1, o2), 1)                                  # [B, dg * 2 * k*k, Ho, Wo]
         mask = torch.sigmoid(logit)                                       # [B, dg * k*k, Ho, Wo]
-        if x.is_cuda and x.dtype == torch.float32 and (C // dg) % 4 == 0 and \
-                not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
+        hip_ok = x.dtype == torch.float32 and (C // dg) % 4 == 0 and self.dilation == 1
+        if hip_ok and (x.is_cuda or self.force_hip) and torch.is_grad_enabled() and \
+                (x.requires_grad or self.weight.requires_grad):
+            # training: im2col / col2im(+coord, +mask) kernels and the split-bf16 contractions as one autograd node
+            # (occf_modulated_deform_col2im); conv_offset and the sigmoid stay on ATen autograd
+            from . import autograd as A
+            out = A.DeformConv.apply(x.permute(0, 2, 3, 1), offset, self.weight, k, self.padding, 1, dg, mask,
+                                     self.stride)
+            out = out.view(B, offset.shape[-2], offset.shape[-1], -1).permute(0, 3, 1, 2)
+            return out if self.bias is None else out + self.bias.view(1, -1, 1, 1)
+        if hip_ok and x.is_cuda and not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
             return self._forward_hip(x, offset, mask)
         Ho, Wo = offset.shape[-2:]
         ys = (torch.arange(Ho, device=x.device, dtype=x.dtype) * self.stride - self.padding).view(1, Ho, 1)

@@ -874,11 +874,17 @@ class HipOps:
                    doff.stride(1), dlg.stride(1), self._ptr(ws), need, self._stream())
         return dvalue, doff, dlg
 
-    def deform_col2im(self, x_cl, offset, dcol, K, stride, pad, dil, groups, deform_groups):
-        """backward of deform_im2col -> (dx [BN, H, W, C], doffset like offset)"""
+    def deform_col2im(self, x_cl, offset, dcol, K, stride, pad, dil, groups, deform_groups, mask=None):
+        """backward of deform_im2col -> (dx [BN, H, W, C], doffset like offset[, dmask like mask: DCNv2])"""
         BN, H, W, C = x_cl.shape
         dx = torch.zeros_like(x_cl)
         doff = torch.empty_like(offset)
+        if mask is not None:
+            dmask = torch.empty_like(mask)
+            self._call("occf_modulated_deform_col2im", self._ptr(x_cl, self.f32), self._ptr(offset, self.f32),
+                       self._ptr(mask, self.f32), self._ptr(dcol, self.f32), self._ptr(dx), self._ptr(doff),
+                       self._ptr(dmask), BN, H, W, C, K, stride, pad, dil, groups, deform_groups, self._stream())
+            return dx, doff, dmask
         self._call("occf_deform_col2im", self._ptr(x_cl, self.f32), self._ptr(offset, self.f32),
                    self._ptr(dcol, self.f32), self._ptr(dx), self._ptr(doff), BN, H, W, C, K, stride, pad, dil, groups,
                    deform_groups, self._stream())

@@ -210,7 +210,10 @@ def test_point_loss_rows_backward(be):
 @pytest.mark.parametrize("M,N,K", [(1500, 192, 128), (2100, 128, 384), (4000, 96, 192), (100, 18, 192), (1300, 288, 64),
                                    (1100, 192, 192), (1200, 40, 160),
                                    # >= 8 M-slabs: the per-XCD, tile-class-major workgroup order
-                                   (9000, 192, 192), (9100, 160, 64), (8200, 320, 192)])
+                                   (9000, 192, 192), (9100, 160, 64), (8200, 320, 192),
+                                   # M <= 2048 with shapes off the 32 x 32 tiles of the small-M kernel; M in (2048, 65536]
+                                   # with widths the tile kernel does not take (the 8-lanes-per-output kernel)
+                                   (100, 1536, 192), (7, 33, 50), (1024, 18, 18), (2500, 18, 30), (300, 192, 6)])
 def test_linear_wgrad(be, M, N, K):
     dy = _t("wg_dy", (M, N), M)
     x = _t("wg_x", (M, K), M + 1)

@@ -152,6 +152,36 @@ def test_dcnv2_hip_im2col_vs_grid_sample_formulation(be, stride, dg):
     assert torch.allclose(out.view(2, Ho, Wo, 8).permute(0, 3, 1, 2), ref, atol=1e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("stride,dg", [(1, 1), (2, 2)])
+def test_dcnv2_training_step_on_the_kernels(be, stride, dg, monkeypatch):
+    """DCNv2 forward + backward as ONE autograd node on csrc/dcn.hip (modulated im2col, occf_modulated_deform_col2im:
+    dx, doffset, dmask) and the split-bf16 contractions, against torch autograd through the module's grid_sample
+    statement: output and the gradients of the input, the weight and conv_offset (through offsets AND modulation)"""
+    import occformer_amd.ops as ops_mod
+    monkeypatch.setattr(ops_mod, "_ops", be.ops)
+    m = _dcn(cin=16, cout=8, stride=stride, dg=dg)
+    with torch.no_grad():
+        m.conv_offset.weight.copy_(paramgen.tensor("dcn4.ow", m.conv_offset.weight.shape, 3, 0.1))
+        m.conv_offset.bias.copy_(paramgen.tensor("dcn4.ob", m.conv_offset.bias.shape, 3, 0.8))
+    x0 = paramgen.tensor("dcn4.x", (2, 16, 9, 11), 4)
+    dy = None
+    res = []
+    for hipmode in (False, True):
+        mm = m if not hipmode else m.to(be.device)
+        mm.force_hip = hipmode
+        for p in mm.parameters():
+            p.grad = None
+        x = x0.clone().to(be.device if hipmode else "cpu").requires_grad_()
+        y = mm(x)
+        if dy is None:
+            dy = paramgen.tensor("dcn4.dy", tuple(y.shape), 5)
+        y.backward(dy.to(y.device))
+        res.append([y.detach().cpu(), x.grad.cpu(), mm.weight.grad.cpu(), mm.conv_offset.weight.grad.cpu(),
+                    mm.conv_offset.bias.grad.cpu()])
+    for a, b, name in zip(res[1], res[0], ("y", "dx", "dweight", "dconv_offset.weight", "dconv_offset.bias")):
+        assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < 2e-4, name
+
+
 @pytest.mark.gpu
 def test_dcnv2_module_on_gpu_uses_the_kernel(hip):
     """ModulatedDeformConv2dPack on a GPU tensor (R101 stage-3 width) == its CPU grid_sample statement"""

@@ -88,7 +88,9 @@ def test_point_sample_tokens_and_lazy_matching_logits(be, align, pad):
 
 
 @pytest.mark.parametrize("R,V,k,shared", [(3, 5000, 700, True), (2, 4096, 4096, False), (1, 300, 1, True),
-                                          (4, 20000, 15000, True)])
+                                          (4, 20000, 15000, True),
+                                          # V > 65 536: the multi-kernel pipeline (smaller rows: one workgroup per row)
+                                          (2, 70000, 900, True)])
 def test_sample_without_replacement_matches_exponential_race_topk(be, R, V, k, shared):
     """same selected SET as torch's own algorithm for multinomial(replacement=False):
     topk(w / q), q ~ Exp(1), with the exponential noise injected"""
@@ -122,8 +124,9 @@ def test_sample_without_replacement_distribution(be):
     assert 0.50 < frac_heavy < 0.60
 
 
-def test_topk_smallest_abs(be):
-    R, V, k = 3, 9000, 2500
+@pytest.mark.parametrize("V", [9000, 70000])
+def test_topk_smallest_abs(be, V):
+    R, k = 3, 2500
     v = paramgen.tensor("tka", (R, V), 3)
     ref = torch.topk(-v.abs(), k, dim=1)[1]
     out = be.ops.topk_smallest_abs(be.to(v), k).cpu()

@@ -164,7 +164,7 @@ def test_nusc_targets_and_lidarseg_metric(bound):
         labels, lw, mt, mw, pos, pos_gt, cost = head._get_target_single(cls[0][i].to(d), masks[0][i].to(d),
                                                                         gl[i].to(d), gm[i].to(d), pts[i].to(d))
         assert torch.equal(labels.cpu(), to["labels"]) and torch.equal(pos.cpu(), to["pos_inds"])
-        assert torch.allclose(mw.cpu(), to["mask_weights"]) and torch.equal(mt.cpu(), to["mask_targets"])
+        assert torch.allclose(mw.cpu(), to["mask_weights"]) and torch.equal(mt.dense().cpu(), to["mask_targets"])
         assert torch.allclose(cost.cpu(), to["cost"], atol=2e-4, rtol=1e-4)
     metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])] * 2
     m = head.lidarseg_metric(cls[-1].to(d), masks[-1].to(d), [p.to(d) for p in pts], metas)
