@@ -176,8 +176,9 @@ def test_dcnv2_training_step_on_the_kernels(be, stride, dg, monkeypatch):
         if dy is None:
             dy = paramgen.tensor("dcn4.dy", tuple(y.shape), 5)
         y.backward(dy.to(y.device))
-        res.append([y.detach().cpu(), x.grad.cpu(), mm.weight.grad.cpu(), mm.conv_offset.weight.grad.cpu(),
-                    mm.conv_offset.bias.grad.cpu()])
+        # (clones: Module.to() moves .grad tensors in place)
+        res.append([t.detach().cpu().clone() for t in (y, x.grad, mm.weight.grad, mm.conv_offset.weight.grad,
+                                                       mm.conv_offset.bias.grad)])
     for a, b, name in zip(res[1], res[0], ("y", "dx", "dweight", "dconv_offset.weight", "dconv_offset.bias")):
         assert float((a - b).norm() / b.norm().clamp_min(1e-12)) < 2e-4, name
 
