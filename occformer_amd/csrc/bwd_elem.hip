@@ -67,7 +67,9 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __rest
 // blockIdx.y = batch element (strides in_bs / out_bs).
 __global__ void __launch_bounds__(1024) reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                                long nblk, int C, long ld, int stride, int offset,
-                                                               long in_bs, long out_bs) {
+                                                               long in_bs, long out_bs, float* __restrict__ out2) {
+  // out2 != NULL: the C columns are (a, b) pairs -- even columns go to out[c / 2], odd ones to out2[c / 2] (dgamma and
+  // dbeta of a LayerNorm from one launch instead of two)
   __shared__ double red[16][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
@@ -88,13 +90,14 @@ __global__ void __launch_bounds__(1024) reduce_partials_kernel(const float* __re
     double t = 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) t += red[r][tx];
-    out[(long)blockIdx.y * out_bs + c] = (float)t;
+    if (out2) ((c & 1) ? out2 : out)[(long)blockIdx.y * out_bs + (c >> 1)] = (float)t;
+    else out[(long)blockIdx.y * out_bs + c] = (float)t;
   }
 }
 static void occf_reduce_partials(const float* partial, float* out, long nblk, int C, long ld, int stride, int offset,
-                                 hipStream_t st, int batch = 1, long in_bs = 0, long out_bs = 0) {
+                                 hipStream_t st, int batch = 1, long in_bs = 0, long out_bs = 0, float* out2 = nullptr) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(occf_cdiv(C, 64), batch), dim3(1024), 0, st, partial, out, nblk, C, ld,
-                     stride, offset, in_bs, out_bs);
+                     stride, offset, in_bs, out_bs, out2);
 }
 
 extern "C" long occf_colsum_workspace(long M, int N) { return (long)occf_cdiv(M, 512) * N; }
@@ -354,8 +357,7 @@ extern "C" int occf_layernorm_bwd(const float* x, const float* gamma, const floa
     nblk = occf_cdiv(M, 4L * rpw);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 0, st, x, gamma, dy, addend, dx, workspace, M, C, eps, rpw);
   }
-  occf_reduce_partials(workspace, dgamma, (long)nblk, C, (long)C * 2, 2, 0, st);
-  occf_reduce_partials(workspace, dbeta, (long)nblk, C, (long)C * 2, 2, 1, st);
+  occf_reduce_partials(workspace, dgamma, (long)nblk, 2 * C, (long)C * 2, 1, 0, st, 1, 0, 0, dbeta);
   OCCF_LAUNCH_CHECK();
 }
 

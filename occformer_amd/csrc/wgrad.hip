@@ -544,10 +544,20 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs p) {
 // accumulators, combined 0..3 -- deterministic).  64 elements x 4 slab groups per workgroup: one thread per element
 // walking all S slabs serially was latency-bound (23 us per call at S ~ 170, 257 calls = 5.9 ms per training step).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
-                                                           long n, int S) {
+                                                           long n, int S, const float* __restrict__ slab2,
+                                                           float* __restrict__ out2, long n2) {
+  // workgroups [0, ceil(n / 64)) reduce the weight partials, the rest (slab2 != NULL) the bias partials: one launch for
+  // both (the bias reduction was a launch of its own: ~120 eight-microsecond launches per training step)
   __shared__ float part[4][64];
   const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + e;
+  const long nb1 = (n + 63) / 64;
+  long i = (long)blockIdx.x * 64 + e;
+  if ((long)blockIdx.x >= nb1) {
+    i = ((long)blockIdx.x - nb1) * 64 + e;
+    slab = slab2;
+    out = out2;
+    n = n2;
+  }
   float v0 = 0.f, v1 = 0.f;
   if (i < n) {
     int s = g;
@@ -731,10 +741,9 @@ static int wg_launch(WgArgs a, float* dW, float* db, float* workspace, long work
     else hipLaunchKernelGGL((wgrad_kernel<1, false, false>), grid, dim3(256), 0, st, a);
   }
   if (S > 1) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(occf_cdiv((long)a.N * Kt, 64)), dim3(256), 0, st, workspace, dW,
-                       (long)a.N * Kt, S);
-    if (db)
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(occf_cdiv(a.N, 64)), dim3(256), 0, st, a.bias_out, db, (long)a.N, S);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(occf_cdiv((long)a.N * Kt, 64) + (db ? occf_cdiv(a.N, 64) : 0)),
+                       dim3(256), 0, st, workspace, dW, (long)a.N * Kt, S, db ? a.bias_out : (const float*)nullptr, db,
+                       (long)a.N);
   }
   return (int)hipGetLastError();
 }
@@ -861,7 +870,7 @@ extern "C" int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapm
       }
     if (S > 1)
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(occf_cdiv((long)Cout * Kt, 64)), dim3(256), 0, st, part, dw_tapmajor,
-                         (long)Cout * Kt, S);
+                         (long)Cout * Kt, S, (const float*)nullptr, (float*)nullptr, 0L);
     return (int)hipGetLastError();
   }
   if (wg_presplit_ok(Cin, Cout, a.taps) && dense && !dbias && workspace && workspace_floats >= nx + ny) {
