@@ -77,3 +77,29 @@ if "conv" in what:
         w = (torch.randn(C, 27 * C, generator=g) * 0.02).cuda()
         sp = ops.split_bf16(w)
         timeit(f"conv3d 3^3 {C}->{C} 200x200x16 (halo kernel)", lambda: ops.conv3d(x, w, (3, 3, 3), 1, 1, (1, 1, 1), None, w_split=sp))
+if "psb" in what:
+    # the matched rows' point-logit gradient scattered voxel-major: one [V, 160] buffer shared by the ten prediction
+    # sets (13 columns each) vs a [V, 16] buffer per set, vs the row-major [13, V] volumes
+    X, Y, Z, n, P = 200, 200, 16, 13, 12544
+    V = X * Y * Z
+    pts = torch.rand(n, P, 3, generator=g).cuda()
+    dout = torch.randn(n, 1, P, generator=g).cuda()
+    big = torch.zeros(V, 160, device="cuda")
+    small = [torch.zeros(V, 16, device="cuda") for _ in range(10)]
+    k = [0]
+
+    def f_big():
+        ops.point_sample_3d_backward(dout, pts, (n, 1, X, Y, Z), False, "border", voxel_major_cols=160, out=big,
+                                     col0=16 * (k[0] % 10))
+        k[0] += 1
+
+    def f_small():
+        ops.point_sample_3d_backward(dout, pts, (n, 1, X, Y, Z), False, "border", voxel_major_cols=16,
+                                     out=small[k[0] % 10], col0=0)
+        k[0] += 1
+    timeit("point_sample_3d_backward 13 x 12544 -> [V, 160] cols", f_big, n=10)
+    timeit("point_sample_3d_backward 13 x 12544 -> [V, 16] per set", f_small, n=10)
+    timeit("point_sample_3d_backward 13 x 12544 -> [13, V] (+ zero fill)",
+           lambda: ops.point_sample_3d_backward(dout, pts, (n, 1, X, Y, Z), False, "border"), n=10)
+    timeit("torch.cat of ten [V, 16] -> [V, 160]", lambda: torch.cat(small, 1), n=5)
+    timeit("zero fill [V, 160]", lambda: big.zero_(), n=5)
