@@ -21,6 +21,8 @@ with non-finite entries (a diverged step; scipy raises there) leaves GT rows unm
 device flag and raised as ``FloatingPointError`` by ``OccHeadTrainingMixin.loss`` one step later (no host sync in
 the step itself).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -152,7 +154,7 @@ class LazyRows:
 
     def __init__(self, dense, embed, feat_tok):
         self.dense_list, self.embed_list, self.feat_list = dense, embed, feat_tok
-        self.dense = torch.cat(dense, 0)                       # [n_pos, X, Y, Z] detached
+        self.dense = dense[0] if len(dense) == 1 else torch.cat(dense, 0)          # [n_pos, X, Y, Z] detached
 
     @property
     def shape(self):
@@ -679,6 +681,139 @@ class NuscTrainingMixin(OccHeadTrainingMixin):
 
     def _sample_mode(self):
         return False, self.padding_mode
+
+    # ------------------------------------------------------------------ all prediction sets at once
+    batched_loss = os.environ.get("OCCF_BATCHED_LOSS", "1") == "1"
+
+    def loss(self, all_cls_scores, all_mask_preds, gt_labels_list, gt_masks_list, gt_lidarseg_list, img_metas=None):
+        """mask2former_nusc_occ.py:275-315.  One image per rank (the reference's samples_per_gpu = 1) with every ground-
+        truth row matchable: the S prediction sets go through ``_loss_sets`` together; anything else takes the
+        set-by-set path of the base class (same values: tests/test_training.py)."""
+        if self.batched_loss and len(gt_labels_list) == 1 and all_cls_scores[0].shape[0] == 1 and \
+                all(isinstance(m, LazyMask) for m in all_mask_preds) and \
+                0 < int(gt_labels_list[0].shape[0]) <= self.num_queries and \
+                min(self.class_weight[:self.num_classes]) > 0:
+            gt_masks = [m.float() for m in gt_masks_list]
+            self._raise_if_infeasible()
+            out = self._loss_sets(all_cls_scores, all_mask_preds, gt_labels_list[0].long(), gt_masks[0],
+                                  gt_lidarseg_list[0])
+            self._post_infeasible_flag()
+            return out
+        return super().loss(all_cls_scores, all_mask_preds, gt_labels_list, gt_masks_list, gt_lidarseg_list, img_metas)
+
+    def _loss_sets(self, all_cls_scores, all_mask_preds, gt_labels, gt_masks, lidar):
+        """The set-by-set loss (``_get_target_single`` -> ``_cls_and_select`` -> ``get_nusc_lidarseg_point_coords`` ->
+        point targets -> point losses, ten times) with the SET as a batch dimension of every kernel and formula: the
+        matching / target / sampling arithmetic of one set is ~130 launches of 5-microsecond kernels on 100 x 17
+        operands (1 340 launches, 21 ms of a profiled step for the ten sets).  The noise is drawn FIRST, in the
+        reference's order (per set: assignment points, oversampled candidates, random points), so the draws are those of
+        the sequential formulation; no shape depends on a matching result (every GT row is matched: G <= Q)."""
+        ops = get_ops()
+        S = len(all_mask_preds)
+        dev = all_cls_scores[0].device
+        rng = self._rng(dev)
+        Q, P, G = self.num_queries, self.num_points, int(gt_labels.shape[0])
+        P3 = int(P * self.oversample_ratio)
+        n_unc = int(self.importance_sample_ratio * P)
+        pad = self.padding_mode
+        f32 = torch.float32
+        lazies = [m[0] for m in all_mask_preds]
+        feat = lazies[0].feat_tok
+        vol_shape = lazies[0].vol_shape
+        with torch.no_grad():
+            pcr = self._const("pcr", self.point_cloud_range, dev, f32)
+            lc = (lidar[:, :3].float() - pcr[:3]) / (pcr[3:] - pcr[:3])                      # [L, 3] in [0, 1]
+            L = int(lc.shape[0])
+            n_lidar = min(P // 2, L)
+            # ---- noise, in the order of the sequential formulation
+            draws = []
+            for _ in range(S):
+                perm = rng.randperm(L).to(dev)[:n_lidar] if n_lidar < L else None
+                r1 = rng.rand(P - n_lidar, 3).to(lc)
+                r2 = rng.rand(P3 - L, 3).to(lc)
+                r3 = rng.rand(G, P - n_unc, 3).to(lc) if P - n_unc > 0 else None
+                draws.append((perm, r1, r2, r3))
+            # ---- matching points: [S, P, 3] in grid_sample order
+            mpts = torch.stack([torch.cat((lc if d[0] is None else lc[d[0]], d[1]), 0) for d in draws]).flip(-1)
+            mpts = mpts.contiguous()
+            fs = ops.point_sample_tokens(feat.detach(), vol_shape, mpts.view(S * P, 3), False, pad)       # [S*P, E]
+            x = torch.empty((S, Q, P), dtype=f32, device=dev)
+            for s in range(S):
+                ops.linear(lazies[s].embed.detach().contiguous(), fs[s * P:(s + 1) * P], None, allow_small=False,
+                           out=x[s])
+            gt_pts = ops.point_sample_3d(gt_masks[None].contiguous(), mpts.view(1, S * P, 3), False, pad)[0]  # [G, S*P]
+            g = gt_pts.view(G, S, P).permute(1, 0, 2).contiguous()                                # [S, G, P]
+            # ---- matching cost of all sets (MaskHungarianAssigner.cost, batched)
+            asg = self.assigner
+            rows = ops.point_loss_rows(x.view(S * Q, P), torch.zeros_like(x).view(S * Q, P)).view(S, Q, -1)
+            a = torch.cat((x, x.sigmoid()), 1)                                                    # [S, 2Q, P]
+            if P % 4:
+                a, g2 = F.pad(a, (0, 4 - P % 4)), F.pad(g, (0, 4 - P % 4))
+            else:
+                g2 = g
+            a, g2 = a.contiguous(), g2.contiguous()
+            sp = None
+            if ops.precision != "f32" and g2.shape[-1] % 32 == 0:
+                hi, lo = ops.split_bf16(g2.view(S * G, -1))
+                sp = (hi.view(S, G, -1), lo.view(S, G, -1))
+            prod = torch.empty((S, 2 * Q, G), dtype=f32, device=dev)
+            for s in range(S):
+                ops.linear(a[s], g2[s], allow_small=False, w_split=None if sp is None else (sp[0][s], sp[1][s]),
+                           out=prod[s])
+            xg, sg = prod[:, :Q], prod[:, Q:]
+            bce = (rows[:, :, 0:1] - xg) / P
+            dice = 1 - (2 * sg + asg.dice_eps) / (rows[:, :, 2:3] + g.sum(2)[:, None] + asg.dice_eps)
+            cls_all = torch.cat([c.detach() for c in all_cls_scores], 0)                          # [S, Q, C + 1]
+            ccost = -cls_all.softmax(-1)[:, :, gt_labels]
+            cost = ccost * asg.w_cls + bce * asg.w_mask + dice * asg.w_dice
+            match, _ = ops.hungarian(cost)                                                       # [S, G] query of GT g
+            bad = (match < 0).any()
+            asg.infeasible = bad if asg.infeasible is None else (asg.infeasible | bad)
+            pos, pos_gt = torch.sort(match.clamp_min(0).long(), dim=1)                           # ascending queries
+            # ---- targets
+            cw = self._const("class_weight", self.class_weight, dev, f32)
+            lab_pos = gt_labels[pos_gt]                                                           # [S, G]
+            labels = torch.full((S, Q), self.num_classes, dtype=torch.long, device=dev).scatter_(1, pos, lab_pos)
+            mw = cw[lab_pos]                                                                      # [S, G]
+        cls_flat = torch.cat(list(all_cls_scores), 0).flatten(0, 1)                              # [S*Q, C + 1], grad
+        ce = F.cross_entropy(cls_flat, labels.flatten(), weight=cw, reduction="none").view(S, Q)
+        loss_cls = self.w_cls * ce.sum(1) / cw[labels].sum(1)                                     # (label_weights = 1)
+        with torch.no_grad():
+            # ---- matched rows of every set: dense logits [S, G, X, Y, Z]
+            dense = torch.empty((S, G) + tuple(vol_shape), dtype=f32, device=dev)
+            for s in range(S):
+                lz = lazies[s]
+                if lz._dense is not None:
+                    torch.index_select(lz._dense, 0, pos[s], out=dense[s])
+                else:
+                    dense[s] = lz._contract(lz.embed[pos[s]], lz.feat_tok, lz.feat_split)
+            # ---- importance sampling of the point coordinates (get_nusc_lidarseg_point_coords, batched)
+            cand = torch.stack([torch.cat((lc, d[2]), 0) for d in draws])                        # [S, P3, 3]
+            logits = ops.point_sample_3d(dense, cand.flip(-1).contiguous(), False, pad)           # [S, G, P3]
+            top = ops.topk_smallest_abs(logits.view(S * G, P3), n_unc).view(S, G, n_unc)
+            coords = torch.gather(cand[:, None].expand(S, G, P3, 3), 2, top[..., None].expand(S, G, n_unc, 3))
+            if P - n_unc > 0:
+                coords = torch.cat((coords, torch.stack([d[3] for d in draws])), 2)               # [S, G, P, 3]
+            coords = coords.flip(-1).contiguous()
+            pt = ops.point_sample_3d_rows(gt_masks.contiguous(), pos_gt.reshape(-1).contiguous(),
+                                          coords.view(S * G, P, 3), False, pad)                   # [S*G, P]
+        # ---- point logits with the gradient route (one joint node), point losses
+        mps = [LazyRows([dense[s]], [lazies[s].embed[pos[s]]], [lazies[s].feat_tok]) for s in range(S)]
+        pps = sample_logits_sets([(mps[s], coords[s]) for s in range(S)], False, pad)
+        pp = torch.cat(pps, 0)                                                                    # [S*G, P]
+        if pp.requires_grad and torch.is_grad_enabled():
+            prow = A.PointLossRows.apply(pp, pt)
+        else:
+            prow = ops.point_loss_rows(pp.contiguous(), pt)
+        prow = prow.view(S, G, -1)
+        total = dist_utils.reduce_mean(mw.sum(1).detach()).clamp_min(1e-12)                       # [S]
+        d = (2 * prow[..., 1] + self.dice_eps) / (prow[..., 2] + prow[..., 3] + self.dice_eps)
+        loss_dice = self.w_dice * ((1 - d) * mw).sum(1) / total
+        loss_mask = self.w_mask * prow[..., 0].sum(1) / (total * P)
+        out = {"loss_cls": loss_cls[-1], "loss_mask": loss_mask[-1], "loss_dice": loss_dice[-1]}
+        for i in range(S - 1):
+            out[f"d{i}.loss_cls"], out[f"d{i}.loss_mask"], out[f"d{i}.loss_dice"] = loss_cls[i], loss_mask[i], loss_dice[i]
+        return out
 
     def _loss_prepare(self, cls_scores, mask_preds, gt_labels_list, gt_masks_list, gt_lidarseg_list, img_metas=None):
         """mask2former_nusc_occ.py:317-400: targets, classification loss, point coordinates, point targets"""

@@ -130,6 +130,41 @@ def test_head_loss_matches_oracle_on_injected_noise(bound, kind):
         assert abs(float(out[k]) - float(g[f"{kind}.{k}"])) < 1e-3 * max(1.0, abs(float(v))), k
 
 
+def test_nusc_loss_of_all_sets_at_once_equals_set_by_set(bound):
+    """NuscTrainingMixin._loss_sets (the prediction set as a batch dimension of every kernel and formula, noise drawn
+    up front in the sequential order) against the set-by-set path on the same noise stream: every loss, and the
+    gradients w.r.t. the mask features, every set's mask embeddings and class scores"""
+    be = bound
+    d = be.device
+    head, ocfg, meta = _heads("nusc")
+    cls, masks, gt_occ, pts = inputs("nusc")
+    S = len(cls)
+    _, Q, X, Y, Z = masks[0].shape
+    E = 32
+    feat = paramgen.tensor("bl_feat", (1, X * Y * Z, E), 1).to(d).requires_grad_()
+    embeds = [paramgen.tensor(f"bl_e{s}", (1, Q, E), 2 + s, 0.4).to(d).requires_grad_() for s in range(S)]
+    cls_d = [c[:1].to(d).clone().requires_grad_() for c in cls]
+    metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])]
+
+    def run(batched):
+        head.batched_loss = batched
+        head.rng = TR.DeviceRNG(d, seed=5)
+        lm = [TR.LazyMask((e.detach()[0] @ feat.detach()[0].t()).view(1, Q, X, Y, Z).contiguous(), e, feat, (X, Y, Z))
+              for e in embeds]
+        gl_p, gm_p = head.preprocess_gt(gt_occ[:1].to(d), metas)
+        out = head.loss(cls_d, lm, gl_p, gm_p, [pts[0].to(d)], metas)
+        grads = torch.autograd.grad(sum(out.values()), [feat] + embeds + cls_d)
+        return out, grads, int(head.rng.gen.initial_seed())
+
+    out_b, g_b, _ = run(True)
+    out_s, g_s, _ = run(False)
+    assert set(out_b) == set(out_s) and len(out_b) == 3 * S
+    for k in out_s:
+        assert abs(float(out_b[k]) - float(out_s[k])) < 2e-6 * max(1.0, abs(float(out_s[k]))), k
+    for a, b in zip(g_b, g_s):
+        assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-9
+
+
 def test_kitti_same_resolution_branch(bound):
     """mask logits at the GT resolution: the gather branch of get_uncertain_point_coords_3d_with_frequency"""
     be = bound
