@@ -341,6 +341,33 @@ class DropPathAdd(torch.autograd.Function):
         return dy, get_ops().droppath(None, dy, scale, *ctx.geom), None, None, None
 
 
+class TokenBevSlot(torch.autograd.Function):
+    """(tok, tok[:, :, :, Z:Z+1]) of the token buffer [B, X, Y, Z + 1, C]: the z-mean slot feeds the BEV ASPP while the
+    whole buffer goes on to the soft-gated fusion.  As a plain slice, the slot's gradient came back as a zero-filled
+    copy of the WHOLE buffer (fill + strided copy + add: three passes over [680 000, 128] per Dualpath block); here
+    it is added into the slot rows of the buffer's gradient, which this node alone receives."""
+
+    @staticmethod
+    def forward(ctx, tok, Z):
+        ctx.Z = Z
+        ctx.set_materialize_grads(False)
+        return tok, tok[:, :, :, Z:Z + 1].contiguous()
+
+    @staticmethod
+    def backward(ctx, dtok, dslot):
+        if dslot is None:
+            return dtok, None
+        Z = ctx.Z
+        if dtok is None:
+            shape = list(dslot.shape)
+            shape[3] = Z + 1
+            dtok = dslot.new_zeros(shape)
+        elif not dtok.is_contiguous():
+            dtok = dtok.contiguous()
+        dtok[:, :, :, Z:Z + 1] += dslot
+        return dtok, None
+
+
 class WindowAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, qkv_bias, table, B, X, Y, S, heads, shift):

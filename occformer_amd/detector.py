@@ -318,7 +318,8 @@ class OccupancyFormer(nn.Module):
         # free when ``prefetch_gt`` ran the scan ahead of time on the side stream, cheap while the device queue is still
         # short, and as expensive as the whole forward once extract_feat has been queued
         if "gt_prepared" not in kwargs and hasattr(self.pts_bbox_head, "preprocess_gt"):
-            kwargs["gt_prepared"] = self.pts_bbox_head.preprocess_gt(gt_occ, img_metas, scans=self._take_gt_scans(gt_occ))
+            kwargs["gt_prepared"] = self.pts_bbox_head.preprocess_gt(gt_occ, img_metas, scans=self._take_gt_scans(gt_occ),
+                                                                     mask_dtype=torch.float32)
         voxel_feats, img_feats, depth = self.extract_feat(points=None, img=img_inputs, img_metas=img_metas)
         losses = {"loss_depth": self.img_view_transformer.get_depth_loss(img_inputs[7], depth)}
         losses.update(self.pts_bbox_head.forward_train(voxel_feats=voxel_feats, img_metas=img_metas, gt_occ=gt_occ,

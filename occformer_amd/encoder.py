@@ -260,8 +260,8 @@ class DualpathTransformerBlock(nn.Module):
                 ident, y = A.conv_fork(x_cl, self.input_conv[0])
                 tok = A.group_norm(y, self.input_conv[1], relu=True, tokens=True)
             Z = tok.shape[3] - 1
-            tok = self.bev_encoder(tok)
-            bev = self.aspp(tok[:, :, :, Z:Z + 1])
+            tok, slot = A.TokenBevSlot.apply(self.bev_encoder(tok), Z)
+            bev = self.aspp(slot)
             out = A.DualpathCombine.apply(tok, bev.reshape(*bev.shape[:3], -1), self.combine_coeff.weight,
                                           self.combine_coeff.bias, ident)
             return out.permute(0, 4, 1, 2, 3)

@@ -165,6 +165,37 @@ def test_nusc_loss_of_all_sets_at_once_equals_set_by_set(bound):
         assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-9
 
 
+def test_token_bev_slot_and_label_scan_and_mask_dtype():
+    """autograd.TokenBevSlot == (tok, tok[..., Z:Z+1, :]) with the slice gradient added in place; the label scan's
+    two-stage reduction and the fp32 mask option of preprocess_occupancy_gt against the plain formulations"""
+    from occformer_amd import autograd as A
+    tok = paramgen.tensor("tbs", (2, 3, 4, 5, 8), 1).requires_grad_()
+    w1, w2 = paramgen.tensor("tbs1", (2, 3, 4, 5, 8), 2), paramgen.tensor("tbs2", (2, 3, 4, 1, 8), 3)
+    t, slot = A.TokenBevSlot.apply(tok * 1.0, 4)
+    ((t * w1).sum() + (slot * w2).sum()).backward()
+    g = tok.grad.clone()
+    tok.grad = None
+    t2 = tok * 1.0
+    ((t2 * w1).sum() + (t2[:, :, :, 4:5] * w2).sum()).backward()
+    assert torch.equal(g, tok.grad)
+    tok.grad = None
+    _, slot = A.TokenBevSlot.apply(tok * 1.0, 4)              # only the slot is used
+    (slot * w2).sum().backward()
+    assert float(tok.grad[:, :, :, :4].abs().max()) == 0.0 and torch.equal(tok.grad[:, :, :, 4:5], w2)
+    gen = torch.Generator().manual_seed(3)
+    gt = torch.randint(0, 19, (1, 16, 16, 8), generator=gen)          # 2048 voxels: the chunked reduction
+    gt[gt == 18] = 255
+    gt[gt == 5] = 6                                                    # an absent label
+    labels_sorted, n = TR.gt_label_scan(gt, 17)
+    want = torch.unique(gt)
+    want = want[want < 17]
+    assert int(n) == want.numel() and torch.equal(labels_sorted[:int(n)], want)
+    lab_l, m_l = TR.preprocess_occupancy_gt(gt, 17)
+    lab_f, m_f = TR.preprocess_occupancy_gt(gt, 17, mask_dtype=torch.float32)
+    assert m_l.dtype == torch.long and m_f.dtype == torch.float32
+    assert torch.equal(lab_l, lab_f) and torch.equal(m_l.float(), m_f)
+
+
 def test_kitti_same_resolution_branch(bound):
     """mask logits at the GT resolution: the gather branch of get_uncertain_point_coords_3d_with_frequency"""
     be = bound
