@@ -167,6 +167,13 @@ def roofline(timed_census, kernels, prec, steps):
         presplit = taps_hint(shp, flops) >= 9 and Cin % 8 == 0 and Cout % 8 == 0
         kname = f"wgrad_kernel<{128 if (Cin % 128 == 0 or Cin > 128) else 64}, {terms}, {'true' if presplit else 'false'}>"
         taps = flops // max(2 * B * X * Y * Z * Cout * Cin, 1)
+        same_grid = list(shp[1][:4]) == [B, X, Y, Z]
+        if taps == 27 and same_grid and Z in (8, 16, 32, 64) and Cin % 64 == 0 and Cout % 64 == 0 and terms == 3 \
+                and os.environ.get("OCCF_WG_G8", "1") != "0":
+            # csrc/wgrad_g8.h: tiles of 192 / 128 / 64 channels, LDS-DMA staging (the largest tile class of the launch)
+            tile = lambda c: 3 if c % 192 == 0 or (c % 128 == 64 and c >= 192) else 2 if c % 128 == 0 else 1
+            ti, tc = tile(Cout), tile(Cin)
+            kname = f"wgrad_g8_kernel<{ti}, {tc}, {1 if ti + tc >= 5 else 2}, 2>"
         nbytes = 4 * (B * X * Y * Z * Cout) + 4 * int(torch.tensor(shp[1]).prod()) + 4 * Cout * taps * Cin
         traffic, src = pmc_traffic(kname, None, pick="bytes")
     else:

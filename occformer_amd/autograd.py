@@ -157,14 +157,16 @@ class Conv3d(torch.autograd.Function):
     """channels-last convolution y = conv(x) + b on the implicit-GEMM / halo kernels; weight in nn.Conv layout"""
 
     @staticmethod
-    def forward(ctx, x_cl, weight, bias, ks, stride, dil, pad, fork=False):
+    def forward(ctx, x_cl, weight, bias, ks, stride, dil, pad, fork=False, gn=None):
         """``fork``: also return x_cl itself (-> (x_cl, y)) for the residual connection around the convolution: the node
         then receives the residual gradient too and the data-gradient convolution adds it in its epilogue (a separate
         ATen add of two [1, 200, 200, 16, 128] gradients per Dualpath / ASPP block otherwise)"""
         ops = get_ops()
         w2 = fused.tap_major_of(weight)
+        # ``gn = (groups, eps)``: the GroupNorm that follows takes its statistics from this convolution's epilogue
+        # (``ops.last_gn_stats`` right after the call; None when the launch shape has no such epilogue)
         y = ops.conv3d(x_cl, w2, ks, stride, dil, pad, None if bias is None else bias.detach(),
-                       w_split=fused.split_weight(weight, fused._tap_layout))
+                       w_split=fused.split_weight(weight, fused._tap_layout), gn=gn)
         ctx.save_for_backward(x_cl, weight)
         ctx.geom = (ks, stride, dil, pad)
         ctx.has_bias = bias is not None
@@ -178,7 +180,7 @@ class Conv3d(torch.autograd.Function):
     def backward(ctx, *grads):
         dres, dy = grads if ctx.fork else (None, grads[0])
         if dy is None:
-            return dres, None, None, None, None, None, None, None
+            return dres, None, None, None, None, None, None, None, None
         x_cl, weight = ctx.saved_tensors
         ks, stride, dil, pad = ctx.geom
         ops = get_ops()
@@ -213,13 +215,18 @@ class Conv3d(torch.autograd.Function):
             if weight.dim() == 4:
                 dw = dw.squeeze(-1)
             dw = dw.contiguous()
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv_fork(x_cl, conv_mod):
-    """-> (x_cl as the residual operand, conv(x_cl)); see Conv3d.forward"""
+def conv_fork(x_cl, conv_mod, gn=None):
+    """-> (x_cl as the residual operand, conv(x_cl), GroupNorm statistics of the output for ``gn`` or None); see
+    Conv3d.forward"""
     ks, stride, dil, pad = _conv_geometry(conv_mod)
-    return Conv3d.apply(x_cl, conv_mod.weight, conv_mod.bias, ks, stride, dil, pad, True)
+    ops = get_ops()
+    ident, y = Conv3d.apply(x_cl, conv_mod.weight, conv_mod.bias, ks, stride, dil, pad, True,
+                            None if gn is None else (gn.num_groups, gn.eps))
+    stats, ops.last_gn_stats = ops.last_gn_stats, None
+    return ident, y, (stats if gn is not None else None)
 
 
 def conv(x_cl, conv_mod):
@@ -234,10 +241,11 @@ class GroupNorm(torch.autograd.Function):
     """occf_groupnorm_apply: y = relu?(GN(x)) [+ residual], token mode appends the z-mean slot"""
 
     @staticmethod
-    def forward(ctx, x_cl, weight, bias, groups, eps, relu, tokens, residual):
+    def forward(ctx, x_cl, weight, bias, groups, eps, relu, tokens, residual, stats=None):
         ops = get_ops()
         x_cl = x_cl.contiguous()
-        stats = ops.groupnorm_stats(x_cl, groups, eps)
+        if stats is None:
+            stats = ops.groupnorm_stats(x_cl, groups, eps)
         y = ops.groupnorm_apply(x_cl, stats, weight.detach(), bias.detach(), groups, relu, tokens,
                                 None if residual is None else residual.detach().contiguous())
         ctx.save_for_backward(x_cl, stats, weight, bias)
@@ -250,15 +258,23 @@ class GroupNorm(torch.autograd.Function):
         groups, relu, tokens, has_res = ctx.cfg
         dx, dg, db, dres = get_ops().groupnorm_backward(x_cl, stats, weight.detach(), bias.detach(), dy.contiguous(),
                                                         groups, relu, tokens, want_residual=has_res)
-        return dx, dg, db, None, None, None, None, dres
+        return dx, dg, db, None, None, None, None, dres, None
 
 
-def group_norm(x_cl, gn, relu=False, tokens=False, residual=None):
-    return GroupNorm.apply(x_cl, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, tokens, residual)
+def group_norm(x_cl, gn, relu=False, tokens=False, residual=None, stats=None):
+    return GroupNorm.apply(x_cl, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, tokens, residual, stats)
 
 
 def conv_gn(x_cl, conv_mod, gn, relu=False, tokens=False, residual=None):
-    return group_norm(conv(x_cl, conv_mod), gn, relu, tokens, residual)
+    """conv -> GroupNorm (-> ReLU / token buffer / + residual); the statistics come from the convolution's epilogue
+    where the launch has one (as in the inference path, fused.conv_gn) instead of a separate pass over its output"""
+    ks, stride, dil, pad = _conv_geometry(conv_mod)
+    if ks == (1, 1, 1) and stride == 1 and x_cl.is_contiguous():
+        return group_norm(conv(x_cl, conv_mod), gn, relu, tokens, residual)
+    ops = get_ops()
+    y = Conv3d.apply(x_cl, conv_mod.weight, conv_mod.bias, ks, stride, dil, pad, False, (gn.num_groups, gn.eps))
+    stats, ops.last_gn_stats = ops.last_gn_stats, None
+    return group_norm(y, gn, relu, tokens, residual, stats)
 
 
 class LayerNorm(torch.autograd.Function):

@@ -257,8 +257,8 @@ class DualpathTransformerBlock(nn.Module):
                 tok = A.conv_gn(x_cl, self.input_conv[0], self.input_conv[1], relu=True, tokens=True)
                 ident = A.conv_gn(x_cl, self.downsample[0], self.downsample[1])
             else:       # x_cl is also the identity operand: its two gradients meet inside the convolution's backward
-                ident, y = A.conv_fork(x_cl, self.input_conv[0])
-                tok = A.group_norm(y, self.input_conv[1], relu=True, tokens=True)
+                ident, y, st = A.conv_fork(x_cl, self.input_conv[0], self.input_conv[1])
+                tok = A.group_norm(y, self.input_conv[1], relu=True, tokens=True, stats=st)
             Z = tok.shape[3] - 1
             tok, slot = A.TokenBevSlot.apply(self.bev_encoder(tok), Z)
             bev = self.aspp(slot)

@@ -84,7 +84,7 @@ def test_fork_nodes_fuse_the_residual_gradient(be, monkeypatch):
         xc.grad = None
         h = xc * 1.0
         if fork:
-            r, y = A.conv_fork(h, conv)
+            r, y, _ = A.conv_fork(h, conv)
         else:
             r, y = h, A.conv(h, conv)
         ((y + r * 0.5) * wc).sum().backward()
