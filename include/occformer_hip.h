@@ -500,6 +500,22 @@ int occf_lidar_depth_fwd(const float* points, long points_ld, const float* cam, 
 int occf_ssc_confusion_fwd(const int64_t* pred, const float* scores, const uint8_t* target, const uint8_t* nonempty,
                            const uint8_t* nonsurface, int64_t* counts, long B, long V, int C, void* stream);
 
+/* img_inputs producer, image half (P/datasets/pipelines/loading_nusc_imgs.py:57-64 img_transform_core = PIL
+ * Image.resize / crop / FLIP_LEFT_RIGHT / rotate, :179-193 mmlabNormalize; no FFI in the reference: PIL in the data-loader
+ * workers).  occf_image_resample_fwd: ONE pass of Pillow's separable antialiased resampling on uint8 [H][W][C] (host
+ * pointers are not accepted: every pointer is device memory); bounds [out_size][2] = (first tap, taps), kk
+ * [out_size][ksize] = 22-bit fixed-point coefficients (Resample.c precompute_coeffs + normalize_coeffs_8bpc, computed by
+ * the caller in double); vertical = 0: out [H][out_size][C], 1: out [out_size][W][C]. */
+int occf_image_resample_fwd(const uint8_t* in, uint8_t* out, const int32_t* bounds, const int32_t* kk, int ksize, int H,
+                            int W, int C, int out_size, int vertical, void* stream);
+/* crop (cx0, cy0, fW x fH, zero outside) -> horizontal flip -> rotate (rot_mode 0 none | 1 = 180 degrees | 2 = Pillow's
+ * 16.16 fixed-point affine map, affine[6] on the HOST) -> out [3][fH][fW] = (pixel - mean) * stdinv per channel (mean /
+ * stdinv [3] on the HOST; to_rgb swaps channels 0 and 2 first, mmcv imnormalize), canvas (may be NULL) uint8 [fH][fW][3]
+ * = the un-normalised frame (results['canvas']). */
+int occf_image_crop_rotate_normalize_fwd(const uint8_t* in, float* out, uint8_t* canvas, int Hn, int Wn, int cx0, int cy0,
+                                         int fW, int fH, int flip, int rot_mode, const int64_t* affine, const float* mean,
+                                         const float* stdinv, int to_rgb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,8 @@ The reference's counterpart is ATen autograd through the PyTorch modules plus ``
 torch is used for the graph bookkeeping, device memory and streams only; every gradient is computed by a kernel of
 the library.  Parameters enter as Function inputs so autograd accumulates into their ``.grad`` (what DDP hooks).
 """
+import os
+
 import torch
 
 from . import fused
@@ -218,13 +220,16 @@ class Conv3d(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None
 
 
+_GN_EPILOGUE = os.environ.get("OCCF_TRAIN_GN_EPILOGUE", "1") == "1"
+
+
 def conv_fork(x_cl, conv_mod, gn=None):
     """-> (x_cl as the residual operand, conv(x_cl), GroupNorm statistics of the output for ``gn`` or None); see
     Conv3d.forward"""
     ks, stride, dil, pad = _conv_geometry(conv_mod)
     ops = get_ops()
     ident, y = Conv3d.apply(x_cl, conv_mod.weight, conv_mod.bias, ks, stride, dil, pad, True,
-                            None if gn is None else (gn.num_groups, gn.eps))
+                            None if gn is None or not _GN_EPILOGUE else (gn.num_groups, gn.eps))
     stats, ops.last_gn_stats = ops.last_gn_stats, None
     return ident, y, (stats if gn is not None else None)
 
@@ -269,7 +274,7 @@ def conv_gn(x_cl, conv_mod, gn, relu=False, tokens=False, residual=None):
     """conv -> GroupNorm (-> ReLU / token buffer / + residual); the statistics come from the convolution's epilogue
     where the launch has one (as in the inference path, fused.conv_gn) instead of a separate pass over its output"""
     ks, stride, dil, pad = _conv_geometry(conv_mod)
-    if ks == (1, 1, 1) and stride == 1 and x_cl.is_contiguous():
+    if (ks == (1, 1, 1) and stride == 1 and x_cl.is_contiguous()) or not _GN_EPILOGUE:
         return group_norm(conv(x_cl, conv_mod), gn, relu, tokens, residual)
     ops = get_ops()
     y = Conv3d.apply(x_cl, conv_mod.weight, conv_mod.bias, ks, stride, dil, pad, False, (gn.num_groups, gn.eps))

@@ -149,3 +149,101 @@ extern "C" int occf_ssc_confusion_fwd(const int64_t* pred, const float* scores, 
                      scores, target, nonempty, nonsurface, (unsigned long long*)counts, BV, V, C);
   OCCF_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// img_inputs producer: the image half of LoadMultiViewImageFromFiles_OccFormer.img_transform_core + mmlabNormalize
+// (datasets/pipelines/loading_nusc_imgs.py:57-64, 179-193) on decoded uint8 frames.  The reference runs PIL inside the
+// data-loader workers: Image.resize (bicubic with antialiasing: separable, coefficients normalised and quantised to
+// 22-bit fixed point, a uint8-rounded intermediate between the horizontal and the vertical pass -- Pillow
+// src/libImaging/Resample.c), crop (zero outside), horizontal flip, Image.rotate (nearest neighbour about the centre in
+// 16.16 fixed point, zero fill -- Geometry.c affine_fixed), then (x - mean) / std with the BGR -> RGB swap.  Restated
+// bit for bit (tests compare with Pillow itself); the coefficient tables come from the host (doubles, as in Pillow).
+#define OCCF_PIL_PRECISION_BITS 22
+
+// one pass of the separable resampling: in [H][W][C] uint8 -> horizontal: [H][out_size][C], vertical: [out_size][W][C];
+// bounds [out_size][2] = (first tap, tap count), kk [out_size][ksize] int32 coefficients
+__global__ void __launch_bounds__(256) image_resample_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                             const int32_t* __restrict__ bounds,
+                                                             const int32_t* __restrict__ kk, int ksize, int H, int W,
+                                                             int C, int out_size, int vertical) {
+  const long total = vertical ? (long)out_size * W * C : (long)H * out_size * C;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const int c = (int)(gid % C);
+  long r = gid / C;
+  int o, fixed;                                           // output index along the resampled axis, index along the other
+  if (vertical) { fixed = (int)(r % W); o = (int)(r / W); } else { o = (int)(r % out_size); fixed = (int)(r / out_size); }
+  const int first = bounds[o * 2 + 0], n = bounds[o * 2 + 1];
+  const int32_t* k = kk + (long)o * ksize;
+  int acc = 1 << (OCCF_PIL_PRECISION_BITS - 1);
+  for (int t = 0; t < n; ++t) {
+    const long src = vertical ? ((long)(first + t) * W + fixed) * C + c : ((long)fixed * W + first + t) * C + c;
+    acc += (int)in[src] * k[t];
+  }
+  int v = acc >> OCCF_PIL_PRECISION_BITS;                 // clip8
+  v = v < 0 ? 0 : (v > 255 ? 255 : v);
+  out[gid] = (uint8_t)v;
+}
+
+extern "C" int occf_image_resample_fwd(const uint8_t* in, uint8_t* out, const int32_t* bounds, const int32_t* kk,
+                                       int ksize, int H, int W, int C, int out_size, int vertical, void* stream) {
+  if (H <= 0 || W <= 0 || C <= 0 || out_size <= 0 || ksize <= 0) return OCCF_EINVAL;
+  const long total = vertical ? (long)out_size * W * C : (long)H * out_size * C;
+  hipLaunchKernelGGL(image_resample_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, in, out, bounds,
+                     kk, ksize, H, W, C, out_size, vertical);
+  OCCF_LAUNCH_CHECK();
+}
+
+// crop (cx0, cy0, fW x fH; zero outside the resized frame) -> flip -> rotate (mode 0 none, 1 = 180 degrees, 2 = the
+// 16.16 fixed-point affine map a[0..5]: x_in = (a2 + a1 y + a0 x) >> 16, y_in = (a5 + a4 y + a3 x) >> 16, zero outside)
+// -> canvas uint8 [fH][fW][3] (optional) and out[c][y][x] = (float(v) - mean[c]) * stdinv[c], v = channel 2 - c if to_rgb
+struct ImgXform { long a[6]; float mean[3], stdinv[3]; };
+__global__ void __launch_bounds__(256) image_crop_rotate_normalize_kernel(const uint8_t* __restrict__ in,
+                                                                          float* __restrict__ out,
+                                                                          uint8_t* __restrict__ canvas, int Hn, int Wn,
+                                                                          int cx0, int cy0, int fW, int fH, int flip,
+                                                                          int rot_mode, int to_rgb, ImgXform t) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)fW * fH) return;
+  const int x = (int)(gid % fW), y = (int)(gid / fW);
+  long xin = x, yin = y;
+  if (rot_mode == 1) {
+    xin = fW - 1 - x;
+    yin = fH - 1 - y;
+  } else if (rot_mode == 2) {
+    xin = (t.a[2] + t.a[1] * y + t.a[0] * x) >> 16;
+    yin = (t.a[5] + t.a[4] * y + t.a[3] * x) >> 16;
+  }
+  int px[3] = {0, 0, 0};
+  if (xin >= 0 && xin < fW && yin >= 0 && yin < fH) {
+    const long sx = cx0 + (flip ? fW - 1 - xin : xin), sy = cy0 + yin;
+    if (sx >= 0 && sx < Wn && sy >= 0 && sy < Hn) {
+      const uint8_t* p = in + (sy * Wn + sx) * 3;
+      px[0] = p[0]; px[1] = p[1]; px[2] = p[2];
+    }
+  }
+  if (canvas) {
+    uint8_t* q = canvas + gid * 3;
+    q[0] = (uint8_t)px[0]; q[1] = (uint8_t)px[1]; q[2] = (uint8_t)px[2];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = (float)px[to_rgb ? 2 - c : c];
+    out[(long)c * fW * fH + gid] = occf_fmul(occf_fadd(v, -t.mean[c]), t.stdinv[c]);
+  }
+}
+
+extern "C" int occf_image_crop_rotate_normalize_fwd(const uint8_t* in, float* out, uint8_t* canvas, int Hn, int Wn,
+                                                    int cx0, int cy0, int fW, int fH, int flip, int rot_mode,
+                                                    const int64_t* affine, const float* mean, const float* stdinv,
+                                                    int to_rgb, void* stream) {
+  if (Hn <= 0 || Wn <= 0 || fW <= 0 || fH <= 0 || rot_mode < 0 || rot_mode > 2 || !mean || !stdinv ||
+      (rot_mode == 2 && !affine))
+    return OCCF_EINVAL;
+  ImgXform t;
+  for (int i = 0; i < 6; ++i) t.a[i] = rot_mode == 2 ? (long)affine[i] : 0;
+  for (int i = 0; i < 3; ++i) { t.mean[i] = mean[i]; t.stdinv[i] = stdinv[i]; }
+  hipLaunchKernelGGL(image_crop_rotate_normalize_kernel, dim3(occf_cdiv((long)fW * fH, 256)), dim3(256), 0,
+                     (hipStream_t)stream, in, out, canvas, Hn, Wn, cx0, cy0, fW, fH, flip, rot_mode, to_rgb, t);
+  OCCF_LAUNCH_CHECK();
+}

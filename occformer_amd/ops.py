@@ -891,6 +891,37 @@ class HipOps:
         return dx, doff
 
 
+    # ------------------------------------------------------------------ img_inputs producer (csrc/pipeline.hip)
+    def image_resample(self, img, bounds, kk, out_size, vertical):
+        """one pass of Pillow's separable resampling: img uint8 [H, W, C]; bounds int32 [out_size, 2], kk int32
+        [out_size, ksize] on the device -> uint8 [H, out_size, C] (horizontal) or [out_size, W, C] (vertical)"""
+        H, W, C = img.shape
+        if img.dtype != torch.uint8 or bounds.dtype != torch.int32 or kk.dtype != torch.int32:
+            raise OccfError("image_resample: uint8 image, int32 tables")
+        out = torch.empty((out_size, W, C) if vertical else (H, out_size, C), dtype=torch.uint8, device=img.device)
+        self._call("occf_image_resample_fwd", self._ptr(img, torch.uint8), self._ptr(out), self._ptr(bounds), self._ptr(kk),
+                   int(kk.shape[1]), H, W, C, int(out_size), int(bool(vertical)), self._stream())
+        return out
+
+    def image_crop_rotate_normalize(self, img, crop_xy, out_wh, flip, rot_mode, affine, mean, stdinv, to_rgb,
+                                    want_canvas=False):
+        """img uint8 [Hn, Wn, 3] -> (float32 [3, fH, fW], uint8 canvas [fH, fW, 3] or None); see the header"""
+        Hn, Wn, C = img.shape
+        if C != 3 or img.dtype != torch.uint8:
+            raise OccfError("image_crop_rotate_normalize: uint8 [H, W, 3] image")
+        fW, fH = int(out_wh[0]), int(out_wh[1])
+        out = torch.empty((3, fH, fW), dtype=self.f32, device=img.device)
+        canvas = torch.empty((fH, fW, 3), dtype=torch.uint8, device=img.device) if want_canvas else None
+        aff = (ctypes.c_int64 * 6)(*[int(v) for v in (affine if affine is not None else [0] * 6)])
+        mean_h = (ctypes.c_float * 3)(*[float(v) for v in mean])
+        std_h = (ctypes.c_float * 3)(*[float(v) for v in stdinv])
+        self._call("occf_image_crop_rotate_normalize_fwd", self._ptr(img, torch.uint8), self._ptr(out), self._ptr(canvas),
+                   Hn, Wn, int(crop_xy[0]), int(crop_xy[1]), fW, fH, int(bool(flip)), int(rot_mode),
+                   ctypes.cast(aff, ctypes.c_void_p), ctypes.cast(mean_h, ctypes.c_void_p),
+                   ctypes.cast(std_h, ctypes.c_void_p), int(bool(to_rgb)), self._stream())
+        return out, canvas
+
+
 _ops = None
 
 

@@ -9,9 +9,12 @@
     same ``update`` / ``compute`` / ``compute_single`` contract, state = one int64 confusion matrix on the device that the
     kernel accumulates into (no host synchronisation per sample; ``reduce`` all-reduces it over RCCL like
     ``dist_reduce_fx='sum'``).
-  * ``image_post_homography`` -- the calibration half of ``LoadMultiViewImageFromFiles_OccFormer.img_transform``
-    (loading_nusc_imgs.py:35-55): the post-rotation / post-translation the view transformer consumes, for a batch of
-    augmentation draws.  (JPEG decoding and PIL resampling are I/O: out of scope.)
+  * ``LoadMultiViewImageFromFiles_OccFormer`` -- loading_nusc_imgs.py:9-193, the ``img_inputs`` producer (registered
+    under the reference's pipeline name): augmentation draws in the reference's numpy order, ``img_transform_core``
+    (PIL resize -> crop -> flip -> rotate) and ``mmlabNormalize`` on the device from decoded uint8 frames
+    (``image_transform``: Pillow's antialiased bicubic resampling and its fixed-point nearest-neighbour rotation restated
+    bit for bit), the post-homography (``image_post_homography``, :35-55) and the calibration tensors.  JPEG decoding is
+    file I/O and stays with the caller (``cam['img']``) or PIL (``cam['data_path']``).
 
 There is no CPU implementation: host tensors raise in ``occformer_amd.ops``."""
 import math
@@ -84,6 +87,177 @@ def image_post_homography(resize, crop, flip, rotate_deg):
     b = torch.tensor([float(crop[2] - crop[0]), float(crop[3] - crop[1])]) / 2
     b = A.matmul(-b) + b
     return A.matmul(post_rot), A.matmul(post_tran) + b
+
+
+# ------------------------------------------------------------------------------------------ img_inputs producer
+_PIL_BITS = 22
+_COEFF_CACHE = {}
+
+
+def _pil_bicubic_tables(in_size, out_size, device):
+    """Pillow's antialiased bicubic taps for one axis (Resample.c precompute_coeffs + normalize_coeffs_8bpc), vectorised:
+    -> (bounds int32 [out, 2], kk int32 [out, ksize]) on ``device``, cached per (sizes, device)"""
+    key = (int(in_size), int(out_size), str(device))
+    hit = _COEFF_CACHE.get(key)
+    if hit is not None:
+        return hit
+    import numpy as np
+    scale = in_size / out_size
+    fscale = max(scale, 1.0)
+    support = 2.0 * fscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    centers = (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    first = np.maximum((centers - support + 0.5).astype(np.int64), 0)          # C's (int) truncation: operands >= 0
+    first = np.where(centers - support + 0.5 < 0, 0, first)
+    last = np.minimum((centers + support + 0.5).astype(np.int64), in_size)
+    count = last - first
+    taps = np.arange(ksize, dtype=np.float64)[None, :]
+    x = np.abs((taps + first[:, None] - centers[:, None] + 0.5) / fscale)
+    a = -0.5
+    w = np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1.0,
+                 np.where(x < 2.0, (((x - 5.0) * x + 8.0) * x - 4.0) * a, 0.0))
+    w = np.where(taps < count[:, None], w, 0.0)
+    # Pillow accumulates the weights left to right in double; numpy's cumulative sum along the row does the same
+    tot = np.cumsum(w, axis=1)[:, -1:]
+    w = np.where(tot != 0.0, w / np.where(tot != 0.0, tot, 1.0), w)
+    q = np.where(w < 0, -0.5 + w * (1 << _PIL_BITS), 0.5 + w * (1 << _PIL_BITS)).astype(np.int64)    # (int) truncates
+    bounds = torch.from_numpy(np.stack((first, count), 1).astype(np.int32)).to(device)
+    kk = torch.from_numpy(q.astype(np.int32)).to(device)
+    _COEFF_CACHE[key] = (bounds, kk)
+    return bounds, kk
+
+
+def image_resize(img, out_w, out_h):
+    """``PIL.Image.resize((out_w, out_h))`` (default BICUBIC, antialiased) of a uint8 [H, W, C] frame on the device:
+    horizontal pass, uint8 intermediate, vertical pass -- bit for bit (tests compare with Pillow)"""
+    ops = get_ops()
+    H, W, _ = img.shape
+    if out_w != W:
+        img = ops.image_resample(img.contiguous(), *_pil_bicubic_tables(W, out_w, img.device), out_w, False)
+    if out_h != H:
+        img = ops.image_resample(img.contiguous(), *_pil_bicubic_tables(H, out_h, img.device), out_h, True)
+    return img
+
+
+def _pil_rotate_fixed(w, h, angle):
+    """``Image.rotate(angle)``'s affine matrix (centre of the frame, cos / sin rounded to 15 digits) in the 16.16 fixed
+    point of Geometry.c's affine_fixed -> (mode, a[6]); mode 0 = identity, 1 = 180 degrees (transpose fast paths)"""
+    angle = angle % 360.0
+    if angle == 0:
+        return 0, None
+    if angle == 180:
+        return 1, None
+    cx, cy = w / 2.0, h / 2.0
+    t = -math.radians(angle)
+    c, s_ = round(math.cos(t), 15), round(math.sin(t), 15)
+    m = [c, s_, 0.0, -s_ if s_ != 0 else round(-math.sin(t), 15), c, 0.0]
+    m[3] = round(-math.sin(t), 15)
+    m[2] = m[0] * -cx + m[1] * -cy + cx
+    m[5] = m[3] * -cx + m[4] * -cy + cy
+    fx = lambda v: int(math.floor(v * 65536.0 + 0.5))            # noqa: E731
+    return 2, [fx(m[0]), fx(m[1]), fx(m[2] + 0.5 * m[0] + 0.5 * m[1]), fx(m[3]), fx(m[4]), fx(m[5] + 0.5 * m[3] + 0.5 * m[4])]
+
+
+IMG_NORM_DEFAULT = dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True)
+
+
+def image_transform(img, resize_dims, crop, flip, rotate, img_norm_cfg=None, want_canvas=False):
+    """loading_nusc_imgs.py:57-64 + :179-193 on the device: decoded uint8 [H, W, 3] frame (channel order as mmcv.imread
+    delivers it: BGR) -> (float32 [3, fH, fW] normalised image, uint8 [fH, fW, 3] canvas or None)"""
+    import numpy as np
+    cfg = img_norm_cfg or IMG_NORM_DEFAULT
+    x0, y0, x1, y1 = (int(v) for v in crop)
+    fW, fH = x1 - x0, y1 - y0
+    r = image_resize(img, int(resize_dims[0]), int(resize_dims[1]))
+    mode, aff = _pil_rotate_fixed(fW, fH, float(rotate))
+    mean = np.asarray(cfg["mean"], np.float64).astype(np.float32)
+    stdinv = (1.0 / np.asarray(cfg["std"], np.float64)).astype(np.float32)
+    return get_ops().image_crop_rotate_normalize(r.contiguous(), (x0, y0), (fW, fH), bool(flip), mode, aff, mean, stdinv,
+                                                 bool(cfg.get("to_rgb", True)), want_canvas)
+
+
+@PIPELINES.register_module()
+class LoadMultiViewImageFromFiles_OccFormer:
+    """loading_nusc_imgs.py:9-177 with the image work on the device.  ``results['curr']['cams'][name]`` carries
+    ``cam_intrinsic`` and either ``img`` (a decoded uint8 [H, W, 3] BGR array / tensor, what mmcv.imread returns) or
+    ``data_path`` (decoded here with PIL: file I/O stays on the host); ``results['lidar2cam_dic'][name]`` the 4x4
+    lidar -> camera matrix.  The augmentation draws come from numpy's global RNG in the reference's order (resize, crop_h,
+    crop_w, flip, rotate per camera), so a seeded run samples the same augmentations."""
+
+    def __init__(self, data_config, is_train=False, img_norm_cfg=None, device=None):
+        self.is_train, self.data_config, self.img_norm_cfg, self.device = is_train, data_config, img_norm_cfg, device
+
+    def choose_cams(self):
+        import numpy as np
+        if self.is_train and self.data_config["Ncams"] < len(self.data_config["cams"]):
+            return np.random.choice(self.data_config["cams"], self.data_config["Ncams"], replace=False)
+        return self.data_config["cams"]
+
+    def sample_augmentation(self, H, W, flip=None, scale=None):
+        import numpy as np
+        fH, fW = self.data_config["input_size"]
+        rs = float(fW) / float(W)
+        if self.is_train:
+            rs += np.random.uniform(*self.data_config["resize"])
+            dims = (int(W * rs), int(H * rs))
+            crop_h = int((1 - np.random.uniform(*self.data_config["crop_h"])) * dims[1]) - fH
+            crop_w = int(np.random.uniform(0, max(0, dims[0] - fW)))
+            flip = self.data_config["flip"] and np.random.choice([0, 1])
+            rotate = np.random.uniform(*self.data_config["rot"])
+        else:
+            rs += self.data_config.get("resize_test", 0.0)
+            if scale is not None:
+                rs = scale
+            dims = (int(W * rs), int(H * rs))
+            crop_h = int((1 - np.mean(self.data_config["crop_h"])) * dims[1]) - fH
+            crop_w = int(max(0, dims[0] - fW) / 2)
+            flip = False if flip is None else flip
+            rotate = 0
+        return rs, dims, (crop_w, crop_h, crop_w + fW, crop_h + fH), flip, rotate
+
+    def _frame(self, cam_data, device):
+        import numpy as np
+        img = cam_data.get("img")
+        if img is None:
+            from PIL import Image
+            img = np.asarray(Image.open(cam_data["data_path"]))
+            if img.ndim == 3 and img.shape[2] >= 3:
+                img = img[:, :, 2::-1]                               # RGB(A) file order -> the BGR of mmcv.imread
+        if not torch.is_tensor(img):
+            img = torch.from_numpy(np.ascontiguousarray(img))
+        return img.to(device=device, dtype=torch.uint8).contiguous()
+
+    def get_inputs(self, results, flip=None, scale=None):
+        dev = self.device or results.get("device") or "cuda"
+        names = self.choose_cams()
+        results["cam_names"] = names
+        imgs, rots, trans, intrins, post_rots, post_trans, s2s, canvas = [], [], [], [], [], [], [], []
+        for name in names:
+            cam = results["curr"]["cams"][name]
+            frame = self._frame(cam, dev)
+            sensor2lidar = torch.tensor(results["lidar2cam_dic"][name]).inverse().float()
+            rs, dims, crop, flip_, rot = self.sample_augmentation(frame.shape[0], frame.shape[1], flip=flip, scale=scale)
+            flip = flip_                          # (the reference rebinds its argument: later cameras inherit the draw)
+            x, cv = image_transform(frame, dims, crop, flip_, rot, self.img_norm_cfg, want_canvas=True)
+            pr2, pt2 = image_post_homography(rs, crop, flip_, rot)
+            pr, pt = torch.eye(3), torch.zeros(3)
+            pr[:2, :2], pt[:2] = pr2, pt2
+            imgs.append(x)
+            canvas.append(cv)
+            intrins.append(torch.Tensor(cam["cam_intrinsic"]))
+            rots.append(sensor2lidar[:3, :3])
+            trans.append(sensor2lidar[:3, 3])
+            post_rots.append(pr)
+            post_trans.append(pt)
+            s2s.append(sensor2lidar)
+        results["canvas"] = torch.stack(canvas)
+        host = lambda ts: torch.stack(ts).to(dev)                   # noqa: E731
+        return (torch.stack(imgs), host(rots), host(trans), host(intrins), host(post_rots), host(post_trans),
+                torch.zeros((len(names), 1), device=dev), host(s2s))
+
+    def __call__(self, results):
+        results["img_inputs"] = self.get_inputs(results)
+        return results
 
 
 SEMANTIC_KITTI_CLASS_NAMES = ["unlabeled", "car", "bicycle", "motorcycle", "truck", "other-vehicle", "person", "bicyclist",

@@ -123,3 +123,74 @@ def test_image_post_homography_matches_reference_formula():
         b = torch.Tensor([crop[2] - crop[0], crop[3] - crop[1]]) / 2
         b = A.matmul(-b) + b
         assert torch.equal(pr, A.matmul(post_rot)) and torch.equal(pt, A.matmul(post_tran) + b)
+
+
+# ------------------------------------------------------------------ img_inputs producer (loading_nusc_imgs.py:9-193)
+def test_image_oracle_is_pillow():
+    """the oracle's restatement of Pillow's Image.resize (antialiased bicubic, 22-bit fixed point, uint8 intermediate)
+    and Image.rotate (nearest neighbour, 16.16 fixed point) against Pillow itself, bit for bit"""
+    Image = pytest.importorskip("PIL.Image")
+    from oracle import image_pipeline_ref as IR
+    rng = np.random.RandomState(0)
+    for (H, W, ow, oh) in [(90, 160, 70, 39), (90, 160, 77, 43), (45, 80, 100, 56), (64, 64, 64, 30), (50, 50, 50, 50)]:
+        img = rng.randint(0, 256, (H, W, 3)).astype(np.uint8)
+        assert np.array_equal(np.array(Image.fromarray(img).resize((ow, oh))), IR.resize(img, ow, oh)), (H, W, ow, oh)
+    for ang in (0.0, 3.3, -5.4, 180.0, 90.0, 45.0, -0.7, 5.399999):
+        img = rng.randint(0, 256, (32, 88, 3)).astype(np.uint8)
+        assert np.array_equal(np.array(Image.fromarray(img).rotate(ang)), IR.rotate(img, ang)), ang
+    img = rng.randint(0, 256, (20, 30, 3)).astype(np.uint8)
+    for box in ((3, -4, 25, 12), (-2, 5, 40, 26), (0, 0, 30, 20)):
+        assert np.array_equal(np.array(Image.fromarray(img).crop(box)), IR.crop(img, box)), box
+
+
+def test_image_oracle_reproduces_reference_fixture():
+    from oracle import image_pipeline_ref as IR
+    from tests.golden.make_golden_image_pipeline import CAMS, DATA_CONFIG, frames
+    g = golden("image_pipeline")
+    imgs, _, _ = frames()
+    for mode in ("train", "train2", "test"):
+        np.random.seed(int(g[f"{mode}.seed"]))
+        for k, c in enumerate(CAMS):
+            rs, dims, crop, flip, rot = IR.sample_augmentation(90, 160, DATA_CONFIG, mode != "test")
+            cv = IR.img_transform_core(imgs[c], dims, crop, flip, rot)
+            assert np.array_equal(cv, g[f"{mode}.canvas"][k].numpy())
+            assert np.array_equal(IR.normalize(cv), g[f"{mode}.imgs"][k].numpy())
+
+
+@pytest.mark.parametrize("case", [((70, 39), (5, 3, 55, 33), False, 3.3), ((77, 43), (-4, 6, 60, 40), True, -5.4),
+                                  ((200, 112), (30, 40, 118, 72), True, 180.0), ((160, 90), (0, 20, 88, 52), False, 0.0),
+                                  ((64, 90), (0, 0, 64, 90), False, 45.0)])
+def test_image_transform_kernels_vs_oracle(bound, case):
+    """resize -> crop -> flip -> rotate -> normalize on the kernels against the oracle: the uint8 frame bit for bit
+    (up- and down-scaling, crops that leave the frame, the 0 / 180 degree fast paths), the float image to 1e-6"""
+    from oracle import image_pipeline_ref as IR
+    dims, crop, flip, rot = case
+    rng = np.random.RandomState(3)
+    img = rng.randint(0, 256, (90, 160, 3)).astype(np.uint8)
+    cfg = dict(mean=[103.53, 116.28, 123.675], std=[57.375, 57.12, 58.395], to_rgb=False)
+    for norm in (None, cfg):
+        x, cv = PL.image_transform(bound.to(torch.from_numpy(img)), dims, crop, flip, rot, norm, want_canvas=True)
+        ref_cv = IR.img_transform_core(img, dims, crop, flip, rot)
+        assert np.array_equal(cv.cpu().numpy(), ref_cv)
+        ref = IR.normalize(ref_cv) if norm is None else IR.normalize(ref_cv, **cfg)
+        assert np.allclose(x.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(PL.image_resize(bound.to(torch.from_numpy(img)), *dims).cpu().numpy(), IR.resize(img, *dims))
+
+
+def test_load_multi_view_images_vs_reference_fixture(bound):
+    """the registered pipeline stage (same name and results contract as the reference's) on seeded draws against the
+    fixture the reference's class produced: canvas bit-exact, images 1e-6, calibration tensors exact"""
+    from tests.golden.make_golden_image_pipeline import CAMS, DATA_CONFIG, frames
+    g = golden("image_pipeline")
+    imgs, l2c, intr = frames()
+    assert PL.PIPELINES.get("LoadMultiViewImageFromFiles_OccFormer") is PL.LoadMultiViewImageFromFiles_OccFormer
+    for mode in ("train", "train2", "test"):
+        t = PL.LoadMultiViewImageFromFiles_OccFormer(DATA_CONFIG, is_train=mode != "test", device=bound.device)
+        res = dict(curr=dict(cams={c: dict(img=imgs[c], cam_intrinsic=intr[c]) for c in CAMS}), lidar2cam_dic=l2c)
+        np.random.seed(int(g[f"{mode}.seed"]))
+        out = t(res)["img_inputs"]
+        assert len(out) == 8 and tuple(out[0].shape) == (3, 3, 32, 88) and tuple(out[6].shape) == (3, 1)
+        assert np.array_equal(res["canvas"].cpu().numpy(), g[f"{mode}.canvas"].numpy())
+        assert torch.allclose(out[0].cpu(), g[f"{mode}.imgs"], rtol=1e-6, atol=1e-6)
+        for i, name in ((1, "rots"), (2, "trans"), (3, "intrins"), (4, "post_rots"), (5, "post_trans")):
+            assert torch.equal(out[i].cpu(), g[f"{mode}.{name}"]), (mode, name)
