@@ -708,6 +708,12 @@ class NuscTrainingMixin(OccHeadTrainingMixin):
                                   gt_lidarseg_list[0])
             self._post_infeasible_flag()
             return out
+        if self.batched_loss and len(gt_labels_list) == 1 and int(gt_labels_list[0].shape[0]) == 0 and \
+                dist_utils.world() > 1:
+            # a sample without ground-truth rows takes the zero-match exit of the set-by-set path, which (as in the
+            # reference, mask2former_nusc_occ.py:381-385) never reaches the normaliser's all-reduce; the other ranks
+            # issue ONE all-reduce over the S sets in ``_loss_sets`` -- join it, so that the collectives of the ranks match
+            dist_utils.reduce_mean(all_cls_scores[0].new_zeros((len(all_mask_preds),)))
         return super().loss(all_cls_scores, all_mask_preds, gt_labels_list, gt_masks_list, gt_lidarseg_list, img_metas)
 
     def _loss_sets(self, all_cls_scores, all_mask_preds, gt_labels, gt_masks, lidar):
