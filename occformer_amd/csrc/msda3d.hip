@@ -562,195 +562,6 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
   for (long i = threadIdx.x; i < ncell * CH; i += NT) slab[i] = (float)((double)(long long)tile[i] * (double)fx_inv);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// d(value) of a level that fits ONE region (the coarsest level: 25 x 25 x 2 = 1 250 cells at the 200-grid) on the
-// matrix cores.  Every query of every level samples this level, so all samples of a head meet ~1 250 x Dh addresses:
-// as LDS atomics that is 18.7 K contributions per address and the slowest of the three levels (0.66 + 0.20 ms of the
-// call's 2.1 ms).  Dense instead: for a chunk of 16 queries the trilinear weights x attention weights of their P
-// points are a [cells x 16] matrix W with <= 8 P non-zeros per column, and
-//     dvalue[cells, Dh] += W[cells, 16 queries] . dout[16 queries, Dh]
-// is one k-step of v_mfma_f32_32x32x16_bf16 per 32 cells (3-term bf16 split of both factors, fp32 accumulate in
-// registers over the whole query range of the workgroup).  W is built in LDS as 2^30 fixed point with ds_add_u32 (the
-// points of a query may share a corner cell; integer adds are exact and order-free, ds_add_f32 is 25x slower), read
-// back as fragments (8 consecutive queries of one cell = 32 bytes), and un-written by the lanes that wrote it.
-// Workgroup = 4 waves, wave w owns the cell tiles w, w + 4, ...; grid = (groups of queries, heads, batch); the
-// per-group partial sums go to the scratch slabs the gather kernel below reduces in fixed order (deterministic).
-#define MSDA_DENSE_LD 20                 // dwords per cell row of W (16 queries + 4 pad: with 16 a fragment read puts 32
-                                         // lanes on 4 bank groups, an 8-way conflict per ds_read_b128)
-#define MSDA_DENSE_MAX_TILES 10          // 32-cell tiles per wave: 4 x 10 x 32 = 1 280 cells (all of them always
-                                         // computed: a conditional tile makes the compiler shuttle the accumulators
-                                         // between AGPRs and VGPRs, 946 moves per chunk in the first version)
-__global__ void __launch_bounds__(256) msda3d_bwd_value_dense_kernel(
-    const float* __restrict__ offs, const float* __restrict__ logits, const float* __restrict__ dout,
-    float* __restrict__ scratch, MsdaLevels lv, int ls, int groups, int B, int Nq, int H, int Dh, int P, long off_ld,
-    long lg_ld, int RY) {
-  OCCF_DYN_SMEM(smem_raw);
-  unsigned* Wf = (unsigned*)smem_raw;                       // [cells_pad][16] fixed-point weights of the chunk
-  const int L = lv.n, LP = L * P;
-  const int Xs = lv.X[ls], Ys = lv.Y[ls], Zs = lv.Z[ls];
-  const int ncell = Xs * RY * Zs;                           // slab layout of the gather kernel: (x * RY + y) * Zs + z
-  const int ntiles = (ncell + 31) / 32;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, lk = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z, grp = blockIdx.x;
-  const int per = ((Nq + groups - 1) / groups + 15) / 16 * 16;
-  const int q_begin = grp * per, q_end = q_begin + per < Nq ? q_begin + per : Nq;
-  const int E = H * Dh;
-  for (int i = tid; i < 4 * MSDA_DENSE_MAX_TILES * 32 * MSDA_DENSE_LD; i += 256) Wf[i] = 0u;
-  f32x16 acc[MSDA_DENSE_MAX_TILES];
-#pragma unroll
-  for (int t = 0; t < MSDA_DENSE_MAX_TILES; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  __syncthreads();
-  // builder role (wave 0): lane = (query j of the chunk, point k)
-  const int bj = lane >> 2, bk = lane & 3;
-  const bool builder = wave == 0 && bk < P;
-  int cells[8];
-  // one chunk of global loads ahead: the dout column pieces of this lane's B fragment and, for the builder lanes, the
-  // logits / offsets of their sample (everything a chunk needs from memory: per chunk the loads, the build and the
-  // contraction otherwise run back to back, ~5 us each time -- the first version was 1.17 ms per launch)
-  float bv_n[8], lg_n[16], of_n[3];
-  auto load_chunk = [&](int q0) __attribute__((always_inline)) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int q = q0 + lk * 8 + e;
-      const int qc = q < Nq ? q : Nq - 1;
-      bv_n[e] = dout[((long)b * Nq + qc) * E + h * Dh + (li < Dh ? li : 0)];
-    }
-    if (builder) {
-      const int q = q0 + bj < Nq ? q0 + bj : Nq - 1;
-      const float* lg = logits + ((long)b * Nq + q) * lg_ld + h * LP;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) lg_n[i] = lg[i < LP ? i : LP - 1];
-      const float* of = offs + ((long)b * Nq + q) * off_ld + h * LP * 3 + (ls * P + bk) * 3;
-      of_n[0] = of[0]; of_n[1] = of[1]; of_n[2] = of[2];
-    }
-  };
-  if (q_begin < q_end) load_chunk(q_begin);
-  for (int q0 = q_begin; q0 < q_end; q0 += 16) {
-    float bv[8], lgv[16], ofv[3];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = bv_n[e];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) lgv[i] = lg_n[i];
-    ofv[0] = of_n[0]; ofv[1] = of_n[1]; ofv[2] = of_n[2];
-    if (q0 + 16 < q_end) load_chunk(q0 + 16);
-    // ---- build W of the chunk
-#pragma unroll
-    for (int c = 0; c < 8; ++c) cells[c] = -1;
-    if (builder) {
-      const int q = q0 + bj;
-      if (q < q_end) {
-        int lq = 0;
-        while (lq + 1 < L && q >= lv.start[lq + 1]) ++lq;
-        const int local = q - lv.start[lq];
-        const int qz = local % lv.Z[lq], qy = (local / lv.Z[lq]) % lv.Y[lq], qx = local / (lv.Z[lq] * lv.Y[lq]);
-        const float rz = ((float)qz + 0.5f) / (float)lv.Z[lq];
-        const float ry = ((float)qy + 0.5f) / (float)lv.Y[lq];
-        const float rx = ((float)qx + 0.5f) / (float)lv.X[lq];
-        float mx = -3.0e38f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, i < LP ? lgv[i] : -3.0e38f);
-        float sum = 0.f, mine = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float ex = i < LP ? expf(lgv[i] - mx) : 0.f;
-          sum += ex;
-          if (i == ls * P + bk) mine = ex;
-        }
-        const float a = mine / sum;
-        const float lz = rz + ofv[0] / (float)Zs;
-        const float ly = ry + ofv[1] / (float)Ys;
-        const float lx = rx + ofv[2] / (float)Xs;
-        const float pz = ((2.f * lz - 1.f + 1.f) * (float)Zs - 1.f) * 0.5f;
-        const float py = ((2.f * ly - 1.f + 1.f) * (float)Ys - 1.f) * 0.5f;
-        const float px = ((2.f * lx - 1.f + 1.f) * (float)Xs - 1.f) * 0.5f;
-        const float fz = floorf(pz), fy = floorf(py), fx = floorf(px);
-        const float tz = pz - fz, ty = py - fy, tx = px - fx;
-        const int iz = (int)fz, iy = (int)fy, ix = (int)fx;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const int cbx = c >> 2, cby = (c >> 1) & 1, cbz = c & 1;
-          const int xx = ix + cbx, yy = iy + cby, zz = iz + cbz;
-          if ((unsigned)xx >= (unsigned)Xs || (unsigned)yy >= (unsigned)Ys || (unsigned)zz >= (unsigned)Zs) continue;
-          const float cw = a * (cbx ? tx : 1.f - tx) * (cby ? ty : 1.f - ty) * (cbz ? tz : 1.f - tz);
-          const int cell = (xx * RY + yy) * Zs + zz;
-          atomicAdd(&Wf[cell * MSDA_DENSE_LD + bj], (unsigned)rintf(cw * 1073741824.0f));
-          cells[c] = cell;
-        }
-      }
-    }
-    // ---- B fragments of the chunk: dout[q0 + 8 lk + e][h, channel li] (zero beyond Dh / the query range)
-    bf16x8 bh, bl;
-    {
-      uint32_t hh[4], ll[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool ok0 = li < Dh && q0 + lk * 8 + 2 * e < q_end, ok1 = li < Dh && q0 + lk * 8 + 2 * e + 1 < q_end;
-        occf_bf16_split2(ok0 ? bv[2 * e] : 0.f, ok1 ? bv[2 * e + 1] : 0.f, hh[e], ll[e]);
-      }
-#ifdef OCCF_EMU
-      memcpy(&bh, hh, 16);
-      memcpy(&bl, ll, 16);
-#else
-      typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-      u4 h4 = {hh[0], hh[1], hh[2], hh[3]}, l4 = {ll[0], ll[1], ll[2], ll[3]};
-      bh = __builtin_bit_cast(bf16x8, h4);
-      bl = __builtin_bit_cast(bf16x8, l4);
-#endif
-    }
-    __syncthreads();
-    // ---- contraction: tile t of this wave = cells [32 (wave + 4 t), +32)
-#pragma unroll
-    for (int t = 0; t < MSDA_DENSE_MAX_TILES; ++t) {
-      const int tile = wave + 4 * t;
-      {
-        const unsigned* wrow = Wf + ((tile * 32 + li) * MSDA_DENSE_LD + lk * 8);
-        float wv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) wv[e] = (float)wrow[e] * (1.0f / 1073741824.0f);
-        uint32_t hh[4], ll[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) occf_bf16_split2(wv[2 * e], wv[2 * e + 1], hh[e], ll[e]);
-        bf16x8 ah, al;
-#ifdef OCCF_EMU
-        memcpy(&ah, hh, 16);
-        memcpy(&al, ll, 16);
-#else
-        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        u4 h4 = {hh[0], hh[1], hh[2], hh[3]}, l4 = {ll[0], ll[1], ll[2], ll[3]};
-        ah = __builtin_bit_cast(bf16x8, h4);
-        al = __builtin_bit_cast(bf16x8, l4);
-#endif
-        acc[t] = occf_mfma_bf16_32x32x16(al, bh, acc[t]);
-        acc[t] = occf_mfma_bf16_32x32x16(ah, bl, acc[t]);
-        acc[t] = occf_mfma_bf16_32x32x16(ah, bh, acc[t]);
-      }
-    }
-    __syncthreads();
-    // ---- un-write: the builder lanes zero what they added.  (The points of a query share a column, so a lane's zero
-    // store must not overtake another lane's add of the NEXT chunk: one more barrier instead of relying on the
-    // lock-step order of wave 0.)
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-      if (cells[c] >= 0) Wf[cells[c] * MSDA_DENSE_LD + bj] = 0u;
-    __syncthreads();
-  }
-  // ---- this group's slab: [cell][Dh]
-  float* slab = scratch + (((long)b * H + h) * gridDim.x + blockIdx.x) * ((long)ncell * Dh);
-#pragma unroll
-  for (int t = 0; t < MSDA_DENSE_MAX_TILES; ++t) {
-    const int tile = wave + 4 * t;
-    if (tile >= ntiles) continue;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int cell = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      if (cell < ncell && li < Dh) slab[(long)cell * Dh + li] = acc[t][r];
-    }
-  }
-}
-
 // dvalue[cell, h*Dh + ch] += sum over the regions that contain the cell (tiles: <= 3 per axis; whole-level mode: the
 // `groups` copies).  thread = (b, h, cell of level ls, channel)
 __global__ void __launch_bounds__(256) msda3d_bwd_value_gather_kernel(const float* __restrict__ scratch,
@@ -920,35 +731,6 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
           lds_max = lds;
         }
 #endif
-        static const int dense_env = [] {
-          const char* e = getenv("OCCF_MSDA_DENSE");       // 1: the dense matrix-core kernel for whole-level regions
-          return e ? atoi(e) : 0;
-        }();
-        const long cells_pad = ((long)lv.X[l] * tc.T * lv.Z[l] + 31) / 32 * 32;
-        if (dense_env && tc.groups > 1 && tc.M == 0 && cells_pad <= 4L * MSDA_DENSE_MAX_TILES * 32 && head_dim <= 32 &&
-            num_points <= 4) {
-          // whole level in one region: the dense matrix-core formulation (scratch layout = the tile kernel's with all
-          // head channels in one pass)
-          MsdaTileCfg dc = tc;
-          dc.CH = head_dim;
-          dc.passes = 1;
-          const size_t dl = (size_t)4 * MSDA_DENSE_MAX_TILES * 32 * MSDA_DENSE_LD * 4;
-#ifndef OCCF_EMU
-          static size_t dl_max = 0;
-          if (dl > dl_max) {
-            (void)hipFuncSetAttribute((const void*)msda3d_bwd_value_dense_kernel,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)dl);
-            dl_max = dl;
-          }
-#endif
-          hipLaunchKernelGGL(msda3d_bwd_value_dense_kernel, dim3((unsigned)dc.groups, heads, B), dim3(256), dl, st,
-                             sampling_offsets, attn_logits, dout, workspace, lv, l, dc.groups, B, Nq, heads, head_dim,
-                             num_points, off_ld, lg_ld, dc.T);
-          const long totald = (long)B * heads * lv.X[l] * lv.Y[l] * lv.Z[l] * head_dim;
-          hipLaunchKernelGGL(msda3d_bwd_value_gather_kernel, dim3(occf_cdiv(totald, 256)), dim3(256), 0, st, workspace,
-                             dvalue, lv, dc, B, heads, head_dim);
-          continue;
-        }
         const dim3 grid((unsigned)(tc.tiles_x * tc.tiles_y * tc.groups * tc.passes), heads, B);
         // threads: as many as the tile's queries fill evenly (level-0 tiles hold ~600 queries x lpg lanes)
         int threads = tile_threads;
