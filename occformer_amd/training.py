@@ -314,6 +314,16 @@ def preprocess_occupancy_gt(gt_occ, num_classes, img_metas=None, scan=None, n_pr
     g = gt_occ.squeeze(0) if gt_occ.dim() == 4 and gt_occ.shape[0] == 1 else gt_occ
     # (``mask_dtype``: the reference's masks are int64; the training step only ever reads them as fp32 -- built directly,
     # the int64 copy and its conversion (0.6 ms at the 200-grid) never exist)
+    if mask_dtype.is_floating_point and labels.numel() > 0:
+        # one scatter of V ones into a zero-filled [G + 1, V] (row = rank of the voxel's label among the present labels,
+        # G = "not a present label"): the broadcast comparison + bool -> float conversion took 0.3 ms at the 200-grid
+        flat = g.reshape(-1).to(labels.dtype)
+        G = labels.shape[0]
+        rank = torch.searchsorted(labels, flat).clamp_(max=G - 1)
+        row = torch.where(labels[rank] == flat, rank, torch.full_like(rank, G))
+        m = torch.zeros((G + 1, flat.shape[0]), dtype=mask_dtype, device=g.device)
+        m.scatter_(0, row.unsqueeze(0), 1.0)
+        return labels.long(), m[:G].view(G, *g.shape)
     return labels.long(), (g.unsqueeze(0) == labels.view(-1, *([1] * g.dim()))).to(mask_dtype)
 
 

@@ -18,8 +18,8 @@ def pytest_configure(config):
 
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
-    """The CPU suite (-m "not gpu") runs every kernel through the host emulation: ~30 min of single-core work, 9 min on
-    four pytest-xdist workers.  So a plain ``pytest tests -m "not gpu"`` distributes itself over 4 workers when xdist is
+    """The CPU suite (-m "not gpu") runs every kernel through the host emulation: ~35 min of single-core work, 8-10 min on
+    four to six pytest-xdist workers (the two-rank DDP test alone takes 7.7 min).  So a plain ``pytest tests -m "not gpu"`` distributes itself over 4 workers when xdist is
     installed (OCCF_TEST_SERIAL=1 or an explicit -n / -p no:xdist keeps it serial).  GPU runs are never distributed: one
     process owns the device and the loaded in-tree library stays visible in that process."""
     opt = config.option
@@ -31,7 +31,7 @@ def pytest_cmdline_main(config):
         return None
     if getattr(opt, "collectonly", False) or getattr(opt, "usepdb", False):
         return None
-    opt.numprocesses = max(1, min(4, (os.cpu_count() or 1) // 2))
+    opt.numprocesses = max(1, min(6, (os.cpu_count() or 1) - 2))
     return None
 
 
