@@ -108,18 +108,25 @@ def pmc_traffic(kernel_substr, grid_size, pick="calls"):
     (profiles/*_pmc_traffic.json, written by scripts/summarize_pmc.py; FETCH_SIZE already x2-corrected for
     gfx950 per MI355X_MICROARCH.md).  None when no summary is present."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=os.path.getmtime)
+    # (by name, newest run last: a fresh checkout gives every file the same mtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
         return None, None
-    doc = json.load(open(files[-1]))
     # a counter summary is only valid for the kernels it was collected on: scripts/summarize_pmc.py stamps the
-    # digest of the kernel sources; a summary from other sources is refused (traffic = null) rather than quoted
+    # digest of the kernel sources; the summary of THESE sources is quoted, any other is refused (traffic = null)
+    doc = None
     try:
         from occformer_amd.csrc.build import _digest
-        if doc.get("source_digest") not in (None, _digest()):
+        dig = _digest()
+        for f in reversed(files):
+            cand = json.load(open(f))
+            if cand.get("source_digest") == dig:
+                doc, files = cand, [f]
+                break
+        if doc is None:
             return None, os.path.basename(files[-1]) + " (stale: kernel sources changed since)"
     except Exception:
-        pass
+        doc = json.load(open(files[-1]))
     rows = doc["kernels"]
     best = [r for r in rows if kernel_substr in r["kernel"] and (grid_size is None or r["grid"] == grid_size)]
     if not best:
