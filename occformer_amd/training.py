@@ -809,13 +809,18 @@ class NuscTrainingMixin(OccHeadTrainingMixin):
         loss_cls = self.w_cls * ce.sum(1) / cw[labels].sum(1)                                     # (label_weights = 1)
         with torch.no_grad():
             # ---- matched rows of every set: dense logits [S, G, X, Y, Z]
-            dense = torch.empty((S, G) + tuple(vol_shape), dtype=f32, device=dev)
-            for s in range(S):
-                lz = lazies[s]
-                if lz._dense is not None:
-                    torch.index_select(lz._dense, 0, pos[s], out=dense[s])
-                else:
-                    dense[s] = lz._contract(lz.embed[pos[s]], lz.feat_tok, lz.feat_split)
+            if all(lz._dense is None for lz in lazies):
+                # lazy logits: the matched rows of ALL sets from one contraction (the mask features are read once)
+                rows_e = torch.cat([lazies[s].embed.detach()[pos[s]] for s in range(S)], 0)            # [S*G, E]
+                dense = lazies[0]._contract(rows_e, feat, lazies[0].feat_split).view((S, G) + tuple(vol_shape))
+            else:
+                dense = torch.empty((S, G) + tuple(vol_shape), dtype=f32, device=dev)
+                for s in range(S):
+                    lz = lazies[s]
+                    if lz._dense is not None:
+                        torch.index_select(lz._dense, 0, pos[s], out=dense[s])
+                    else:
+                        dense[s] = lz._contract(lz.embed[pos[s]], lz.feat_tok, lz.feat_split)
             # ---- importance sampling of the point coordinates (get_nusc_lidarseg_point_coords, batched)
             cand = torch.stack([torch.cat((lc, d[2]), 0) for d in draws])                        # [S, P3, 3]
             logits = ops.point_sample_3d(dense, cand.flip(-1).contiguous(), False, pad)           # [S, G, P3]

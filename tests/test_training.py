@@ -130,7 +130,8 @@ def test_head_loss_matches_oracle_on_injected_noise(bound, kind):
         assert abs(float(out[k]) - float(g[f"{kind}.{k}"])) < 1e-3 * max(1.0, abs(float(v))), k
 
 
-def test_nusc_loss_of_all_sets_at_once_equals_set_by_set(bound):
+@pytest.mark.parametrize("lazy", [False, True])
+def test_nusc_loss_of_all_sets_at_once_equals_set_by_set(bound, lazy):
     """NuscTrainingMixin._loss_sets (the prediction set as a batch dimension of every kernel and formula, noise drawn
     up front in the sequential order) against the set-by-set path on the same noise stream: every loss, and the
     gradients w.r.t. the mask features, every set's mask embeddings and class scores"""
@@ -149,8 +150,9 @@ def test_nusc_loss_of_all_sets_at_once_equals_set_by_set(bound):
     def run(batched):
         head.batched_loss = batched
         head.rng = TR.DeviceRNG(d, seed=5)
-        lm = [TR.LazyMask((e.detach()[0] @ feat.detach()[0].t()).view(1, Q, X, Y, Z).contiguous(), e, feat, (X, Y, Z))
-              for e in embeds]
+        # lazy: no dense logits (OCCF_LAZY_LOGITS=1 in the head): the matched rows are contracted on demand
+        lm = [TR.LazyMask(None if lazy else (e.detach()[0] @ feat.detach()[0].t()).view(1, Q, X, Y, Z).contiguous(), e,
+                          feat, (X, Y, Z)) for e in embeds]
         gl_p, gm_p = head.preprocess_gt(gt_occ[:1].to(d), metas)
         out = head.loss(cls_d, lm, gl_p, gm_p, [pts[0].to(d)], metas)
         grads = torch.autograd.grad(sum(out.values()), [feat] + embeds + cls_d)
