@@ -406,8 +406,13 @@ __global__ void __launch_bounds__(256) msda3d_bwd_kernel(
 // magnitude), and the sum is order-independent (deterministic).
 __global__ void __launch_bounds__(256) msda_absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
   float m = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    m = fmaxf(m, fabsf(x[i]));
+  // a NaN counts as +inf (fmaxf would drop it): with max|dout| = inf the fixed-point scale is 0 and its inverse inf, so
+  // every value the tiles hand over is 0 * inf = NaN -- a diverged step stays visible in d(value) instead of going
+  // through an undefined float -> int conversion
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    m = v != v ? occf_u2f(0x7F800000u) : fmaxf(m, fabsf(v));
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   __shared__ float wm[4];

@@ -374,6 +374,21 @@ def test_msda3d_backward(be, E, heads, shapes):
         assert _rel(doff.cpu(), offs.grad) < 2e-4 and _rel(dlg.cpu(), logits.grad) < 2e-4
 
 
+def test_msda3d_backward_keeps_a_diverged_step_visible(be):
+    """a NaN / inf in dout must reach d(value) (the tiled path accumulates in fixed point scaled by max|dout|; fmaxf
+    alone would drop the NaN and the float -> int conversion of the contributions is undefined for it)"""
+    E, heads, shapes, B, P = 24, 2, [(4, 4, 2), (8, 8, 4)], 1, 4
+    L, Nq = len(shapes), sum(x * y * z for x, y, z in shapes)
+    value = paramgen.tensor("mn_value", (B, Nq, E), 1)
+    offs = paramgen.tensor("mn_offs", (B, Nq, heads * L * P * 3), 1, 1.0)
+    logits = paramgen.tensor("mn_logits", (B, Nq, heads * L * P), 1)
+    for bad in (float("nan"), float("inf")):
+        dout = paramgen.tensor("mn_do", (B, Nq, E), 2).clone()
+        dout[0, 7, 3] = bad
+        dv, _, _ = be.ops.msda3d_backward(*be.to(value, offs, logits, dout), shapes, heads, P, head_major=False)
+        assert not bool(torch.isfinite(dv).all()), bad
+
+
 @pytest.mark.parametrize("groups,dg", [(4, 1), (2, 2)])
 def test_deform_col2im(be, groups, dg):
     from oracle import occformer_ref as O
