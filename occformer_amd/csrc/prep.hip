@@ -27,16 +27,18 @@ __global__ void __launch_bounds__(256) prep_weights_kernel(const long* __restric
   uint32_t* hi = (uint32_t*)d[2];
   uint32_t* lo = (uint32_t*)d[3];
   const long j = i - d[4];
-  long e = 2 * j;
-  const long i4 = e % d[9];
-  e /= d[9];
-  const long i3 = e % d[8];
-  e /= d[8];
-  const long i2 = e % d[7];
-  e /= d[7];
-  const long i1 = e % d[6];
-  const long i0 = e / d[6];
-  const long off = i0 * d[10] + i1 * d[11] + i2 * d[12] + i3 * d[13] + i4 * d[14];
+  // index decomposition in 32 bits (a layout has < 2^31 elements; 64-bit divisions were ~500 instructions per thread)
+  unsigned e = (unsigned)(2 * j);
+  const unsigned d4 = (unsigned)d[9], d3 = (unsigned)d[8], d2 = (unsigned)d[7], d1 = (unsigned)d[6];
+  const unsigned i4 = e % d4;
+  e /= d4;
+  const unsigned i3 = e % d3;
+  e /= d3;
+  const unsigned i2 = e % d2;
+  e /= d2;
+  const unsigned i1 = e % d1;
+  const unsigned i0 = e / d1;
+  const long off = (long)i0 * d[10] + (long)i1 * d[11] + (long)i2 * d[12] + (long)i3 * d[13] + (long)i4 * d[14];
   const float a = in[off], b = in[off + d[14]];
   uint32_t h, l;
   occf_bf16_split2(a, b, h, l);

@@ -96,7 +96,7 @@ class _WeightPrep:
     @staticmethod
     def _spec(param, kind):
         """-> (dims[5], strides[5] of the INPUT in elements, base offset, output shape) or None if not expressible"""
-        if not param.is_contiguous() or param.dim() not in (2, 4, 5):
+        if not param.is_contiguous() or param.dim() not in (2, 4, 5) or param.numel() >= 2 ** 31:
             return None
         shp = list(param.shape)
         N = shp[0]
