@@ -223,8 +223,9 @@ __global__ void __launch_bounds__(256) wg8_split_y_kernel(const float* __restric
                                                           wg_u4* __restrict__ yh, wg_u4* __restrict__ yl) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= groups * N) return;
-  const int c = (int)(i % N);
-  const long g = i / N;
+  const unsigned i32 = (unsigned)i;                         // (< 2^31 elements per array: 32-bit divisions)
+  const int c = (int)(i32 % (unsigned)N);
+  const long g = (long)(i32 / (unsigned)N);
   const float* src = dy + g * 8 * ldy + c;
   float v[8];
 #pragma unroll
@@ -245,10 +246,12 @@ __global__ void __launch_bounds__(256) wg8_split_x_kernel(const float* __restric
                                                           long copy_slots) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= cols * ZG * C) return;
-  const int c = (int)(i % C);
-  const long gi = i / C;
-  const int zg = (int)(gi % ZG);
-  const long col = gi / ZG;
+  const unsigned i32 = (unsigned)i;
+  const int c = (int)(i32 % (unsigned)C);
+  const unsigned gi32 = i32 / (unsigned)C;
+  const long gi = (long)gi32;
+  const int zg = (int)(gi32 % (unsigned)ZG);
+  const long col = (long)(gi32 / (unsigned)ZG);
   const int Z = ZG * 8;
   const float* src = x + col * Z * C + c;
   float rows[10];
