@@ -16,7 +16,16 @@
     bit for bit), the post-homography (``image_post_homography``, :35-55) and the calibration tensors.  JPEG decoding is
     file I/O and stays with the caller (``cam['img']``) or PIL (``cam['data_path']``).
 
-There is no CPU implementation: host tensors raise in ``occformer_amd.ops``."""
+  * ``LoadMultiViewImageFromFiles_SemanticKitti`` -- loading_kitti_imgs.py:11-145, the monocular producer of the
+    SemanticKITTI configs on the same image path.
+  * ``LoadNuscOccupancyAnnotations`` / ``LoadSemKittiAnnotation`` -- loading_nusc_occ.py:13-224 /
+    loading_kitti_occ.py:7-116: ``gt_occ``, ``points_occ`` and the BEV-augmentation matrix ``bda_rot`` (``img_inputs[6]``).
+    The lidarseg voxelisation (majority label per voxel), the flips and the PIL-style rotation of the label volume are
+    device tensor programs (integer scatter-add / gather: index work, bit-exact), no kernel of their own yet.
+  * ``OccDefaultFormatBundle3D`` / ``Collect3D`` / ``Compose`` / ``collate`` -- the remaining stages of the configs'
+    ``train_pipeline`` / ``test_pipeline`` lists, so that the lists build by name and feed ``forward_train`` directly.
+
+The image / depth / metric kernels have no CPU implementation: host tensors raise in ``occformer_amd.ops``."""
 import math
 
 import torch
@@ -258,6 +267,314 @@ class LoadMultiViewImageFromFiles_OccFormer:
     def __call__(self, results):
         results["img_inputs"] = self.get_inputs(results)
         return results
+
+
+@PIPELINES.register_module()
+class LoadMultiViewImageFromFiles_SemanticKitti(LoadMultiViewImageFromFiles_OccFormer):
+    """loading_kitti_imgs.py:11-145, the monocular ``img_inputs`` producer of the SemanticKITTI configs: the same
+    augmentation draws and device image path as the nuScenes loader, one frame.  ``results['img']`` (a list with the one
+    decoded uint8 [H, W, 3] frame, as mmcv.imread(..., 'unchanged') returns it) or ``results['img_filename']`` (decoded
+    with PIL here); ``results['cam_intrinsic'][0]`` and ``results['lidar2cam'][0]`` as in the reference."""
+
+    def get_inputs(self, results, flip=None, scale=None):
+        dev = self.device or results.get("device") or "cuda"
+        names = results["img_filename"]
+        assert len(names) == 1
+        frames = results.get("img")
+        frame = self._frame(dict(img=None if frames is None else frames[0], data_path=names[0]), dev)
+        results["raw_img"] = frame
+        rs, dims, crop, flip, rot = self.sample_augmentation(frame.shape[0], frame.shape[1], flip=flip, scale=scale)
+        x, cv = image_transform(frame, dims, crop, flip, rot, self.img_norm_cfg, want_canvas=True)
+        pr2, pt2 = image_post_homography(rs, crop, flip, rot)
+        pr, pt = torch.eye(3), torch.zeros(3)
+        pr[:2, :2], pt[:2] = pr2, pt2
+        cam2lidar = torch.Tensor(results["lidar2cam"][0]).inverse()
+        results["canvas"] = cv[None]
+        host = [cam2lidar[:3, :3], cam2lidar[:3, 3], torch.Tensor(results["cam_intrinsic"][0]), pr, pt, torch.zeros(1)]
+        rots, trans, intrin, pr, pt, depth = (t[None].to(dev) for t in host)
+        return x[None], rots, trans, intrin, pr, pt, depth, cam2lidar[None].to(dev)
+
+
+# --------------------------------------------------------------------------- occupancy ground truth (gt_occ, bda_rot)
+def sample_bda_augmentation(conf):
+    """loading_nusc_occ.py:47-57 / loading_kitti_occ.py:17-26: rot, scale, flip_dx, flip_dy, flip_dz from numpy's
+    global RNG in the reference's order (the nuScenes configs carry no flip_dz_ratio: 0)"""
+    import numpy as np
+    rot = np.random.uniform(*conf["rot_lim"])
+    scale = np.random.uniform(*conf["scale_lim"])
+    fx = np.random.uniform() < conf["flip_dx_ratio"]
+    fy = np.random.uniform() < conf["flip_dy_ratio"]
+    fz = np.random.uniform() < conf.get("flip_dz_ratio", 0.0)
+    return rot, scale, fx, fy, fz
+
+
+def bda_matrix(rotate_deg, flip_dx, flip_dy, flip_dz, center=None):
+    """The BEV-augmentation matrix ``bda_rot`` (``img_inputs[6]``), host float32 as the reference builds it:
+    flip @ rot [3, 3] (loading_nusc_occ.py:147-180) or, about ``center``, denorm @ flip @ rot @ norm [4, 4]
+    (loading_kitti_occ.py:59-101).  The scale draw is unused there as well."""
+    a = torch.tensor(rotate_deg / 180 * math.pi)
+    s, c = torch.sin(a), torch.cos(a)
+    rot = torch.Tensor([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    flip = torch.eye(4)
+    for on, axis in ((flip_dx, 0), (flip_dy, 1), (flip_dz, 2)):
+        if on:
+            f = torch.eye(4)
+            f[axis, axis] = -1
+            flip = flip @ f
+    if center is None:
+        return (flip @ rot)[:3, :3]
+    norm, denorm = torch.eye(4), torch.eye(4)
+    norm[:3, -1] = -torch.as_tensor(center, dtype=torch.float32)
+    denorm[:3, -1] = torch.as_tensor(center, dtype=torch.float32)
+    return denorm @ flip @ rot @ norm
+
+
+def rotate_label_volume(vox, angle, fill=255):
+    """custom_rotate_3d (loading_nusc_occ.py:205-224): every [X, Y] height slice of the uint8 label volume rotated as
+    ``Image.rotate(angle, NEAREST, fillcolor=255)`` does (16.16 fixed-point source index; the transpose fast paths for
+    0 / 180 and, on square slices, 90 / 270 degrees), all slices at once on the device"""
+    H, W, Z = vox.shape
+    ang = angle % 360.0
+    if ang in (90, 270) and H == W:
+        return torch.rot90(vox, 1 if ang == 90 else 3, dims=(0, 1)).contiguous()
+    mode, a = _pil_rotate_fixed(W, H, angle)
+    if mode == 0:
+        return vox.clone()
+    if mode == 1:
+        return vox.flip(0, 1)
+    ys = torch.arange(H, device=vox.device, dtype=torch.int64)[:, None]
+    xs = torch.arange(W, device=vox.device, dtype=torch.int64)[None, :]
+    xin = (a[2] + a[1] * ys + a[0] * xs) >> 16
+    yin = (a[5] + a[4] * ys + a[3] * xs) >> 16
+    ok = (xin >= 0) & (xin < W) & (yin >= 0) & (yin < H)
+    src = (yin.clamp(0, H - 1) * W + xin.clamp(0, W - 1)).reshape(-1)
+    out = vox.reshape(H * W, Z).index_select(0, src).reshape(H, W, Z)
+    return torch.where(ok[..., None], out, torch.full_like(out, fill))
+
+
+def voxel_transform(vox, rotate_deg, flip_dx, flip_dy, flip_dz, center=None):
+    """voxel_transform of both loaders: (int64 label volume rotated unless the angle is ~0, then flipped along z, y, x;
+    the bda matrix).  ``vox`` None -> only the matrix (the nuScenes loader augments the points instead)."""
+    mat = bda_matrix(rotate_deg, flip_dx, flip_dy, flip_dz, center)
+    if vox is None:
+        return None, mat
+    vox = vox.to(torch.uint8)
+    if abs(rotate_deg) > 1e-8:                                       # np.isclose(rotate_degree, 0)
+        vox = rotate_label_volume(vox, rotate_deg)
+    dims = [d for d, on in ((2, flip_dz), (1, flip_dy), (0, flip_dx)) if on]
+    if dims:
+        vox = vox.flip(*dims)
+    return vox.long(), mat
+
+
+def voxelize_point_labels(points, labels, grid_size, pc_range, num_labels, empty_id=17):
+    """loading_nusc_occ.py:99-121 on the device: points float32 [P, 3] (augmented), labels int64 [P] in [0, num_labels)
+    -> int64 [X, Y, Z]: the label most points of a voxel carry (the smallest on a tie, as np.argmax of
+    nb_process_label's counter; the counter is uint16 there and wraps here too), ``empty_id`` where no point falls;
+    then 0 (noise) -> 255, ``empty_id`` -> 0.  The grid index is computed in float64 like the reference's numpy
+    (points promoted, clip to [lo, hi - 1e-5], floor of the quotient).  No host synchronisation."""
+    import numpy as np
+    dev = points.device
+    gs = [int(v) for v in grid_size]
+    rng = np.array(pc_range, np.float64)
+    vs = (rng[3:] - rng[:3]) / np.array(gs)
+    lo = torch.tensor(rng[:3], dtype=torch.float64, device=dev)
+    hi = torch.tensor(rng[3:] - 1e-5, dtype=torch.float64, device=dev)
+    ind = torch.floor((torch.minimum(torch.maximum(points.double(), lo), hi) - lo)
+                      / torch.tensor(vs, dtype=torch.float64, device=dev)).long()
+    V, L = gs[0] * gs[1] * gs[2], int(num_labels)
+    lin = (ind[:, 0] * gs[1] + ind[:, 1]) * gs[2] + ind[:, 2]
+    counts = torch.zeros(V * L, dtype=torch.int64, device=dev)       # (bincount would read the largest key back)
+    counts = counts.scatter_add_(0, lin * L + labels, torch.ones_like(lin)).view(V, L)
+    hit = counts.sum(1) > 0
+    order = torch.arange(L - 1, -1, -1, device=dev)
+    best = ((counts & 0xFFFF) * L + order).max(1).values
+    lab = (L - 1) - best % L
+    lab = torch.where(lab == 0, torch.full_like(lab, 255), lab)
+    lab = torch.where(hit & (lab != empty_id), lab, torch.zeros_like(lab))
+    return lab.view(gs)
+
+
+@PIPELINES.register_module()
+class LoadNuscOccupancyAnnotations:
+    """loading_nusc_occ.py:13-125 (registered under the reference's pipeline name): lidarseg points -> ``gt_occ``
+    (int64 [X, Y, Z]), ``points_occ`` (float32 [P, 4]) and ``bda_rot`` inserted as ``img_inputs[6]``.  The decoded arrays
+    come in ``results['points']`` (float32 [P, >=3]) and ``results['points_label']`` (raw uint8 lidarseg labels [P]), or
+    are read from ``results['pts_filename']`` / ``data_root + results['lidarseg']`` as the reference does (file I/O on the
+    host); learning map, BEV augmentation of the points and the voxelisation run on the device."""
+
+    def __init__(self, data_root="data/nuscenes", is_train=False, is_test_submit=False, grid_size=None,
+                 point_cloud_range=None, bda_aug_conf=None, unoccupied_id=17, cls_metas="nuscenes.yaml", device=None):
+        import numpy as np
+        import yaml
+        self.is_train, self.is_test_submit, self.data_root = is_train, is_test_submit, data_root
+        if isinstance(cls_metas, dict):
+            self.learning_map = cls_metas.get("learning_map", cls_metas)
+        else:
+            with open(cls_metas, "r") as stream:
+                self.learning_map = yaml.safe_load(stream)["learning_map"]
+        lut = np.zeros(256, np.int64)
+        for k, v in self.learning_map.items():
+            lut[int(k)] = int(v)
+        self._lut_host, self._lut = lut, {}
+        self.num_labels = max(int(lut.max()), int(unoccupied_id)) + 1
+        self.bda_aug_conf, self.unoccupied_id, self.device = bda_aug_conf, unoccupied_id, device
+        self.grid_size = [int(v) for v in grid_size]
+        self.point_cloud_range = [float(v) for v in point_cloud_range]
+
+    def sample_3d_augmentation(self):
+        return sample_bda_augmentation(self.bda_aug_conf)
+
+    def _points(self, results, dev):
+        import numpy as np
+        pts = results.get("points")
+        if pts is None:
+            pts = np.fromfile(results["pts_filename"], dtype=np.float32, count=-1).reshape(-1, 5)
+        if not torch.is_tensor(pts):
+            pts = torch.from_numpy(np.ascontiguousarray(pts))
+        return pts.to(device=dev, dtype=torch.float32)[:, :3]
+
+    def __call__(self, results):
+        import os
+
+        import numpy as np
+        dev = self.device or results.get("device") or results["img_inputs"][0].device
+        head, tail = tuple(results["img_inputs"][:6]), tuple(results["img_inputs"][6:])
+        points = self._points(results, dev)
+        if self.is_test_submit:
+            results["img_inputs"] = head + (torch.eye(3, device=dev),) + tail
+            results["points_occ"] = torch.cat([points, points.new_zeros(points.shape[0], 1)], 1)
+            return results
+        raw = results.get("points_label")
+        if raw is None:
+            raw = np.fromfile(os.path.join(self.data_root, results["lidarseg"]), dtype=np.uint8)
+        if not torch.is_tensor(raw):
+            raw = torch.from_numpy(np.ascontiguousarray(raw))
+        if dev not in self._lut:
+            self._lut[dev] = torch.from_numpy(self._lut_host).to(dev)
+        labels = self._lut[dev][raw.to(dev).reshape(-1).long()]
+        if self.is_train:
+            rot, _, fx, fy, fz = self.sample_3d_augmentation()
+            bda = bda_matrix(rot, fx, fy, fz)
+        else:
+            bda = torch.eye(3)
+        bda = bda.to(dev)
+        points = points @ bda.t()
+        results["gt_occ"] = voxelize_point_labels(points, labels, self.grid_size, self.point_cloud_range, self.num_labels,
+                                                  self.unoccupied_id)
+        results["points_occ"] = torch.cat([points, labels[:, None].float()], 1)
+        results["img_inputs"] = head + (bda,) + tail
+        return results
+
+
+@PIPELINES.register_module()
+class LoadSemKittiAnnotation:
+    """loading_kitti_occ.py:7-55 (registered under the reference's pipeline name): the voxel labels the dataset loaded
+    (``results['gt_occ']``, [X, Y, Z]) through the BEV augmentation on the device, ``bda_rot`` [4, 4] (about the centre
+    of the point-cloud range) inserted as ``img_inputs[6]``; ``gt_occ`` None = the test split."""
+
+    def __init__(self, bda_aug_conf, is_train=True, point_cloud_range=(0, -25.6, -2, 51.2, 25.6, 4.4), device=None):
+        self.bda_aug_conf, self.is_train, self.device = bda_aug_conf, is_train, device
+        rng = torch.tensor(point_cloud_range)
+        self.point_cloud_range = rng
+        self.transform_center = (rng[:3] + rng[3:]) / 2
+
+    def sample_bda_augmentation(self):
+        return sample_bda_augmentation(self.bda_aug_conf)
+
+    def __call__(self, results):
+        dev = self.device or results.get("device") or results["img_inputs"][0].device
+        head, tail = tuple(results["img_inputs"][:6]), tuple(results["img_inputs"][6:])
+        gt = results["gt_occ"]
+        if gt is None:
+            results["img_inputs"] = head + (torch.eye(4, device=dev),) + tail
+            return results
+        gt = torch.as_tensor(gt).to(dev)
+        if self.is_train:
+            rot, _, fx, fy, fz = self.sample_bda_augmentation()
+            gt, bda = voxel_transform(gt, rot, fx, fy, fz, self.transform_center)
+        else:
+            bda = torch.eye(4)
+        results["img_inputs"] = head + (bda.to(dev),) + tail
+        results["gt_occ"] = gt.long()
+        return results
+
+
+@PIPELINES.register_module()
+class OccDefaultFormatBundle3D:
+    """formating.py:7-45: ``gt_occ`` / ``points_occ`` / ``points_uv`` become tensors.  The reference wraps them in mmcv
+    DataContainers for its multi-worker collate; here one process per GPU feeds its own model and ``collate`` below
+    applies the same stacking rules (gt_occ stacked, points lists kept per sample) without the wrapper."""
+
+    def __init__(self, class_names=None, with_gt=True, with_label=True):
+        self.class_names, self.with_gt, self.with_label = class_names, with_gt, with_label
+
+    def __call__(self, results):
+        gt = results.get("gt_occ")
+        if gt is not None:
+            results["gt_occ"] = tuple(torch.as_tensor(x) for x in gt) if isinstance(gt, list) else torch.as_tensor(gt)
+        for key in ("points_occ", "points_uv"):
+            if key in results:
+                results[key] = torch.as_tensor(results[key])
+        return results
+
+
+@PIPELINES.register_module()
+class Collect3D:
+    """mmdet3d's Collect3D as the configs use it: ``img_metas`` = the ``meta_keys`` present in ``results``, plus ``keys``"""
+
+    def __init__(self, keys, meta_keys=("pc_range", "occ_size")):
+        self.keys, self.meta_keys = keys, meta_keys
+
+    def __call__(self, results):
+        data = dict(img_metas={k: results[k] for k in self.meta_keys if k in results})
+        for key in self.keys:
+            data[key] = results[key]
+        return data
+
+
+class Compose:
+    """the configs' ``train_pipeline`` / ``test_pipeline`` lists: every stage built from PIPELINES by its ``type``;
+    ``defaults`` (e.g. ``device``) is handed to the stages whose constructor takes it"""
+
+    def __init__(self, stages, **defaults):
+        import inspect
+        self.stages = []
+        for cfg in stages:
+            if isinstance(cfg, dict):
+                cfg = dict(cfg)
+                name = cfg.pop("type")
+                cls = PIPELINES.get(name)
+                if cls is None:
+                    raise KeyError(f"pipeline stage {name!r} is not registered")
+                accepted = inspect.signature(cls.__init__).parameters
+                cfg.update({k: v for k, v in defaults.items() if k in accepted and k not in cfg})
+                self.stages.append(cls(**cfg))
+            else:
+                self.stages.append(cfg)
+
+    def __call__(self, results):
+        for stage in self.stages:
+            results = stage(results)
+            if results is None:
+                return None
+        return results
+
+
+def collate(samples):
+    """The batch a model call takes from per-sample pipeline outputs, with mmcv collate's rules for these keys: tensors
+    and the ``img_inputs`` tuple stacked along a new batch axis, ``points_occ`` / ``points_uv`` kept as per-sample lists,
+    ``img_metas`` a list of dicts"""
+    out = {}
+    for key, first in samples[0].items():
+        vals = [s[key] for s in samples]
+        if key == "img_metas" or key in ("points_occ", "points_uv") or first is None:
+            out[key] = vals if first is not None else None
+        elif isinstance(first, (tuple, list)):
+            out[key] = [torch.stack([v[i] for v in vals]) for i in range(len(first))]
+        else:
+            out[key] = torch.stack(vals)
+    return out
 
 
 SEMANTIC_KITTI_CLASS_NAMES = ["unlabeled", "car", "bicycle", "motorcycle", "truck", "other-vehicle", "person", "bicyclist",
