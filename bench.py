@@ -338,6 +338,10 @@ def main():
                          "region and is reported as stage img_encoder")
     ap.add_argument("--image-dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="train mode, N > 1: the reference's sync_bn = True (tools/train.py:221-223) -- DepthNet's BatchNorms "
+                         "normalise with all ranks' statistics (one small all-gather per layer); default: per-rank "
+                         "statistics, the gradient all-reduce stays the only collective (north_star)")
     ap.add_argument("--shape-report", default=None, help="write a per-shape GEMM/conv timing table here")
     ap.add_argument("--check", action="store_true", help="also report max abs err vs the oracle output")
     args = ap.parse_args()
@@ -373,6 +377,8 @@ def main():
     if train and meta.get("kitti"):
         cfg["train_cfg"] = dict(pts=configs.train_cfg_pts())
     model = build_model(cfg).to(device)
+    if args.sync_bn and train and world > 1:
+        dist_utils.convert_sync_batchnorm(model)
     img_inputs, metas, points = synthetic_sample(meta, device, seed=rank)
     if args.from_images:
         g = torch.Generator().manual_seed(7 + rank)
@@ -502,9 +508,10 @@ def main():
         "config": {"workload": f"{args.workload}_{'train_step' if train else 'forward'}_from_" +
                                (f"images_{args.image_dtype}_image_branch" if args.from_images else "neck_features"),
                    "grid": list(meta["grid"]), "input_size": list(meta["input_size"]), "global_batch": world,
-                   "parallelism": f"dp{world} " + ("(DDP: one RCCL gradient all-reduce per step, bucketed, overlapped "
-                                                   "with backward; BatchNorm on per-rank batch statistics)" if train else
-                                                   "(independent samples, no data-path collective)")},
+                   "parallelism": f"dp{world} " + (
+                       "(DDP: one RCCL gradient all-reduce per step, bucketed, overlapped with backward; BatchNorm on %s)"
+                       % ("all ranks' statistics (sync_bn)" if args.sync_bn and world > 1 else "per-rank batch statistics")
+                       if train else "(independent samples, no data-path collective)")},
         "roofline": roof,
         "kernels": {k: {"calls": v["calls"], "total_ms": round(v["total_ms"], 3), "avg_ms": round(v["avg_ms"], 4),
                         "GBps": round(v["bytes_per_call"] / (v["avg_ms"] * 1e-3) / 1e9, 1),

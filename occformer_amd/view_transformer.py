@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .dist_utils import is_synced
 from .ops import get_ops
 from .registry import NECKS
 
@@ -151,10 +152,11 @@ class _ImageASPP(nn.Module):
     def forward(self, x):
         gp = self.global_avg_pool
         g = gp[1](gp[0](x))
-        if self.training and g.numel() == g.shape[1]:
+        if self.training and g.numel() == g.shape[1] and not is_synced(gp[2]):
             # one pooled value per channel on this rank (SemanticKITTI: batch 1, one camera): batch statistics do
-            # not exist -- the reference gets them from SyncBatchNorm over its 8 ranks; per-rank policy:
-            # this layer normalises with its running statistics
+            # not exist -- the reference gets them from SyncBatchNorm over its 8 ranks (here:
+            # dist_utils.convert_sync_batchnorm, opt-in); under the default per-rank policy this layer
+            # normalises with its running statistics
             g = F.batch_norm(g, gp[2].running_mean, gp[2].running_var, gp[2].weight, gp[2].bias, False, 0.0, gp[2].eps)
         else:
             g = gp[2](g)
@@ -296,13 +298,13 @@ class DepthNet(nn.Module):
         implicit-GEMM kernels with its BatchNorm folded in; training mode keeps the nn.Module graph."""
         if self.training:
             m = mlp_input.reshape(-1, mlp_input.shape[-1])
-            if m.shape[0] > 1:
+            if m.shape[0] > 1 or is_synced(self.bn):
                 m = self.bn(m)
             else:
                 # one camera vector per rank (SemanticKITTI: batch 1, one camera): batch statistics do not exist;
-                # the reference gets them from SyncBatchNorm over the 8 ranks (tools/train.py:221-223) -- with
-                # per-rank statistics (the only collective kept is the gradient all-reduce) this layer uses its
-                # running statistics
+                # the reference gets them from SyncBatchNorm over the 8 ranks (tools/train.py:221-223; here opt-in:
+                # dist_utils.convert_sync_batchnorm) -- with per-rank statistics (the default: the only collective kept
+                # is the gradient all-reduce) this layer uses its running statistics
                 m = F.batch_norm(m, self.bn.running_mean, self.bn.running_var, self.bn.weight, self.bn.bias, False,
                                  0.0, self.bn.eps)
             x = self.reduce_conv[2](self.reduce_conv[1](_conv(self, self.reduce_conv[0], x)))
