@@ -327,7 +327,8 @@ def test_occupancy_loaders_vs_reference_fixture(bound, tmp_path):
         assert len(res["img_inputs"]) == 9 and float(res["img_inputs"][7]) == 6.0 and float(res["img_inputs"][5]) == 5.0
         occ, pocc, bda = res["gt_occ"].cpu(), res["points_occ"].cpu(), res["img_inputs"][6].cpu()
         assert occ.dtype == torch.int64 and tuple(occ.shape) == tuple(GRID) and pocc.dtype == torch.float32
-        assert torch.equal(bda, g[f"nusc.{tag}.bda_rot"]), tag               # host float32, the reference's own ops
+        # host float32, the reference's own ops (sin / cos of a rotation: the host's vector math library, 1e-6)
+        assert torch.equal(bda, g[f"nusc.{tag}.bda_rot"]) if tag != "rot" else torch.allclose(bda, g[f"nusc.{tag}.bda_rot"], atol=1e-6), tag
         if tag == "rot":
             assert torch.allclose(pocc, g[f"nusc.{tag}.points_occ"], rtol=1e-5, atol=1e-5)
             assert float((occ != g[f"nusc.{tag}.gt_occ"].long()).float().mean()) <= 0.01
@@ -345,7 +346,8 @@ def test_occupancy_loaders_vs_reference_fixture(bound, tmp_path):
         np.random.seed(int(g[f"kitti.{tag}.seed"]))
         res = t(dict(gt_occ=vol.copy(), img_inputs=inputs()))
         assert res["gt_occ"].dtype == torch.int64 and torch.equal(res["gt_occ"].cpu(), g[f"kitti.{tag}.gt_occ"].long()), tag
-        assert torch.equal(res["img_inputs"][6].cpu(), g[f"kitti.{tag}.bda_rot"]), tag
+        bda = res["img_inputs"][6].cpu()
+        assert torch.equal(bda, g[f"kitti.{tag}.bda_rot"]) if "rot" not in tag else torch.allclose(bda, g[f"kitti.{tag}.bda_rot"], atol=1e-5), tag
     t = PL.LoadSemKittiAnnotation(BDA_FLIP, is_train=False, device=bound.device)
     res = t(dict(gt_occ=vol.copy(), img_inputs=inputs()))
     assert torch.equal(res["gt_occ"].cpu(), torch.from_numpy(vol).long()) and torch.equal(res["img_inputs"][6].cpu(), torch.eye(4))
