@@ -12,8 +12,37 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _poison_uninitialised_memory():
+    """OCCF_TEST_POISON=1: every ``torch.empty`` / ``empty_like`` / ``new_empty`` / ``empty_strided`` buffer is filled with NaN
+    (floating point) or 0x5A bytes (integers) before it is handed out, so that a kernel or a host routine that READS a
+    buffer it was supposed to overwrite first shows up as a wrong / NaN result instead of depending on what the
+    allocator happened to return (on the GPU: on which tests ran before).  Debug mode of the CPU (emulation) suite."""
+    def poison(t):
+        if t.numel() == 0 or t.is_meta:
+            return t
+        with torch.no_grad():
+            if t.is_floating_point() or t.is_complex():
+                t.fill_(float("nan"))
+            elif t.dtype == torch.bool:
+                t.fill_(True)
+            else:
+                t.fill_(0x5A5A5A5A if t.dtype in (torch.int32, torch.int64) else 0x5A)
+        return t
+
+    def wrap(fn):
+        def inner(*a, **k):
+            return poison(fn(*a, **k))
+        inner.__name__ = getattr(fn, "__name__", "empty")
+        return inner
+    for name in ("empty", "empty_like", "empty_strided"):
+        setattr(torch, name, wrap(getattr(torch, name)))
+    torch.Tensor.new_empty = wrap(torch.Tensor.new_empty)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    if os.environ.get("OCCF_TEST_POISON", "0") == "1":
+        _poison_uninitialised_memory()
 
 
 @pytest.hookimpl(tryfirst=True)
