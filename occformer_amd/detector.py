@@ -407,3 +407,43 @@ class OccupancyFormer(nn.Module):
         k = (gt >= 0) & (gt < n + 1)      # labels 0..16, row/col 0 cropped below
         hist = np.bincount((n + 1) * gt[k] + pred[k], minlength=(n + 1) ** 2).reshape(n + 1, n + 1)
         return hist[1:, 1:]
+
+
+@DETECTORS.register_module()
+class OccupancyFormer4D(OccupancyFormer):
+    """occupancyformer.py:256-313: the two-frame detector.  ``img_inputs[0]`` holds 2 frames per camera
+    ([B, 2N, C, H, W], viewed [B, N, 2, ...]: frame index innermost), the calibration tensors 2N entries viewed
+    [B, 2, N, ...] (frame index outermost) -- the reference's layouts, kept.  Each frame is lifted on its own with the KEY
+    frame's extrinsics in the DepthNet camera vector; the previous frame runs without a graph; the two voxel volumes are
+    concatenated along the channels (``img_bev_encoder_backbone.in_channels = 2 * numC_Trans``); depth and image
+    features of the key frame are returned."""
+
+    def prepare_voxel_feat(self, img, rot, tran, intrin, post_rot, post_tran, bda, mlp_input):
+        x = self.image_encoder(img)
+        voxel_feat, depth = self.img_view_transformer([x, rot, tran, intrin, post_rot, post_tran, bda, mlp_input])
+        return voxel_feat, depth, x
+
+    def extract_img_feat(self, img, img_metas=None):
+        B, N2, C, H, W = img[0].shape
+        N = N2 // 2
+        frames = img[0].view(B, N, 2, C, H, W).unbind(2)
+        rots, trans, intrins, post_rots, post_trans, bda = img[1:7]
+        per_frame = [t.view(B, 2, N, *t.shape[2:]).unbind(1) for t in (rots, trans, intrins, post_rots, post_trans)]
+        rots, trans, intrins, post_rots, post_trans = per_frame
+        voxels, depths, feats = [], [], []
+        for f in range(2):
+            mlp_input = self.img_view_transformer.get_mlp_input(rots[0], trans[0], intrins[f], post_rots[f],
+                                                                post_trans[f], bda)
+            args = (frames[f], rots[f], trans[f], intrins[f], post_rots[f], post_trans[f], bda, mlp_input)
+            if f == 0:                                      # back-propagation through the key frame only
+                v, d, x = self.prepare_voxel_feat(*args)
+            else:
+                with torch.no_grad():
+                    v, d, x = self.prepare_voxel_feat(*args)
+            voxels.append(v)
+            depths.append(d)
+            feats.append(x)
+        x = self.bev_encoder(torch.cat(voxels, dim=1))
+        if not isinstance(x, list):
+            x = [x]
+        return x, depths[0], feats[0]

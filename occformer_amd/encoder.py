@@ -250,6 +250,11 @@ class DualpathTransformerBlock(nn.Module):
         """x logical [B, Cin, X, Y, Z] -> logical [B, C, X', Y', Z'] over channels-last memory."""
         if not isinstance(self.input_conv[1], nn.GroupNorm):
             raise NotImplementedError("the HIP path implements the GroupNorm blocks of the OccFormer configs")
+        if self.stride == 1 and x.shape[1] != self.channels:
+            # dualpath_block.py:36-42,82: the skip is nn.Identity() unless stride > 1 -- the reference's final addition
+            # fails on these shapes as well
+            raise RuntimeError(f"DualpathTransformerBlock: identity skip needs in_channels == channels at stride 1, got "
+                               f"{x.shape[1]} -> {self.channels}")
         ops = get_ops()
         x_cl = fused.channels_last_view(x.float())
         if self.training:

@@ -36,7 +36,7 @@ def test_product_has_no_cpu_path():
 
 
 def test_registry_names():
-    for name in ("OccupancyFormer", "OccupancyEncoder", "ViewTransformerLiftSplatShootVoxel",
+    for name in ("OccupancyFormer", "OccupancyFormer4D", "OccupancyEncoder", "ViewTransformerLiftSplatShootVoxel",
                  "MSDeformAttnPixelDecoder3D", "Mask2FormerNuscOccHead", "Mask2FormerOccHead", "ResNet",
                  "SECONDFPN"):
         assert name in MODELS, name
@@ -135,6 +135,55 @@ def test_detector_forward_train_and_test_wiring(be, monkeypatch):
     assert set(losses) == expect
     assert all(torch.isfinite(torch.as_tensor(v)).all() for v in losses.values())
     assert out["output_voxels"].shape[-3:] == occ and out["output_points"] is not None
+
+
+def test_two_frame_detector(be, monkeypatch):
+    """``OccupancyFormer4D`` (occupancyformer.py:256-313): 2 frames per camera in the reference's layouts (images
+    [B, N, 2, ...] frame-innermost, calibration [B, 2, N, ...] frame-outermost), each lifted on its own with the KEY
+    frame's extrinsics in the camera vector, voxel volumes concatenated along the channels; equal to that composition
+    written out with the single-frame modules, and in train mode the gradient reaches the key frame's features only"""
+    import occformer_amd.ops as ops_mod
+    from occformer_amd.registry import build_model
+    from tests import paramgen, tinycfg
+    monkeypatch.setattr(ops_mod, "_ops", be.ops)
+    cfg, meta = tinycfg.tiny_nusc(ncams=2)
+    cfg = dict(cfg, type="OccupancyFormer4D")
+    # two volumes of C / 2 channels each: the first encoder block keeps in_channels == channels (its stride-1 skip is
+    # the identity, dualpath_block.py:36-42)
+    cfg["img_view_transformer"] = dict(cfg["img_view_transformer"], numC_Trans=meta["C"] // 2)
+    cfg["img_bev_encoder_backbone"] = dict(cfg["img_bev_encoder_backbone"], block_numbers=[1, 1, 1, 1])
+    cfg["pts_bbox_head"] = None
+    model = build_model(cfg).eval().to(be.device)
+    B, N = 1, 2
+    H, W = meta["input_size"]
+    rots, trans, intr, post_rots, post_trans, bda = (t.to(be.device) for t in paramgen.camera_rig(B, 2 * N, H, W, meta["focal"], seed=9))
+    x = paramgen.tensor("f4d_x", (B, 2 * N, 32, meta["fH"], meta["fW"]), 9).to(be.device)
+    with torch.no_grad():
+        vox, depth, feats = model.extract_img_feat([x, rots, trans, intr, post_rots, post_trans, bda])
+        vt = model.img_view_transformer
+        parts = []
+        for f in range(2):
+            fr = lambda t: t.view(B, 2, N, *t.shape[2:])[:, f]                          # noqa: E731
+            mlp = vt.get_mlp_input(rots.view(B, 2, N, 3, 3)[:, 0], trans.view(B, 2, N, 3)[:, 0], fr(intr), fr(post_rots),
+                                   fr(post_trans), bda)
+            v, d = vt([x.view(B, N, 2, *x.shape[2:])[:, :, f], fr(rots), fr(trans), fr(intr), fr(post_rots), fr(post_trans),
+                       bda, mlp])
+            parts.append(v)
+            if f == 0:
+                assert torch.equal(d, depth) and torch.equal(feats, x.view(B, N, 2, *x.shape[2:])[:, :, 0])
+        assert float((parts[0] - parts[1]).abs().max()) > 1e-3                           # the frames differ
+        ref = model.bev_encoder(torch.cat(parts, 1))
+    assert len(vox) == len(ref) and all(torch.equal(a, b) for a, b in zip(vox, ref))
+    bad = dict(cfg, img_view_transformer=dict(cfg["img_view_transformer"], numC_Trans=meta["C"]),
+               img_bev_encoder_backbone=dict(cfg["img_bev_encoder_backbone"], in_channels=2 * meta["C"]))
+    with pytest.raises(RuntimeError, match="identity skip"), torch.no_grad():
+        build_model(bad).eval().to(be.device).extract_img_feat([x, rots, trans, intr, post_rots, post_trans, bda])
+    model.train()
+    xg = x.clone().requires_grad_(True)
+    vox, depth, _ = model.extract_img_feat([xg, rots, trans, intr, post_rots, post_trans, bda])
+    (sum(v.float().square().sum() for v in vox) + depth.square().sum()).backward()
+    g = xg.grad.view(B, N, 2, *x.shape[2:])
+    assert float(g[:, :, 0].abs().max()) > 0 and float(g[:, :, 1].abs().max()) == 0.0
 
 
 @pytest.mark.gpu
