@@ -52,9 +52,13 @@ class HipOps:
             return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
         return ctypes.c_void_p(0)
 
-    def _ptr(self, t, dtype=None):
+    def _ptr(self, t, dtype=None, n=None):
+        """device pointer of a contiguous tensor (None -> NULL); ``n`` = the element count the kernel will address
+        through it: the kernels do no bounds checks, an operand of another size is refused here"""
         if t is None:
             return ctypes.c_void_p(0)
+        if n is not None and t.numel() != n:
+            raise OccfError(f"operand of {t.numel()} elements (shape {tuple(t.shape)}) where the kernel addresses {n}")
         if self.strict and not t.is_cuda:
             raise OccfError("occformer_amd ops need GPU tensors (no CPU path exists)")
         if not t.is_contiguous():
@@ -77,8 +81,8 @@ class HipOps:
         (mmdet3d/ops/bev_pool/src/bev_pool.cpp:22-28)."""
         n, c = x.shape
         out = torch.empty((b, d, h, w, c), dtype=x.dtype, device=x.device)
-        self._call("occf_bev_pool_fwd", self._ptr(x, self.f32), self._ptr(geom, self.i32),
-                   self._ptr(interval_starts, self.i32), self._ptr(interval_lengths, self.i32),
+        self._call("occf_bev_pool_fwd", self._ptr(x, self.f32), self._ptr(geom, self.i32, 4 * n),
+                   self._ptr(interval_starts, self.i32), self._ptr(interval_lengths, self.i32, interval_starts.numel()),
                    self._ptr(out), int(b), int(d), int(h), int(w), n, c,
                    interval_starts.numel(), self._stream())
         return out
@@ -87,8 +91,9 @@ class HipOps:
         n = geom.shape[0]
         c = out_grad.shape[4]
         x_grad = torch.empty((n, c), dtype=out_grad.dtype, device=out_grad.device)
-        self._call("occf_bev_pool_bwd", self._ptr(out_grad, self.f32), self._ptr(geom, self.i32),
-                   self._ptr(interval_starts, self.i32), self._ptr(interval_lengths, self.i32),
+        self._call("occf_bev_pool_bwd", self._ptr(out_grad, self.f32, int(b) * int(d) * int(h) * int(w) * c),
+                   self._ptr(geom, self.i32, 4 * n),
+                   self._ptr(interval_starts, self.i32), self._ptr(interval_lengths, self.i32, interval_starts.numel()),
                    self._ptr(x_grad), int(b), int(d), int(h), int(w), n, c,
                    interval_starts.numel(), self._stream())
         return x_grad
@@ -130,7 +135,7 @@ class HipOps:
         """qkv [B*X*Y*S, 3C] -> attention output [B*X*Y*S, C] (before proj)."""
         C = qkv.shape[1] // 3
         out = torch.empty((qkv.shape[0], C), dtype=qkv.dtype, device=qkv.device)
-        self._call("occf_window_attn_fwd", self._ptr(qkv, self.f32), self._ptr(qkv_bias, self.f32),
+        self._call("occf_window_attn_fwd", self._ptr(qkv, self.f32, B * X * Y * S * 3 * C), self._ptr(qkv_bias, self.f32, 3 * C),
                    self._ptr(bias_table, self.f32), self._ptr(out), B, X, Y, S, C, heads, int(shift),
                    self._stream())
         return out
@@ -237,8 +242,9 @@ class HipOps:
         need = self.lib.occf_masked_xattn_workspace(B, Q, L, heads)
         ws = torch.empty((need,), dtype=self.f32, device=q.device)
         out = torch.empty_like(q)
-        self._call("occf_masked_xattn_fwd", self._ptr(q, self.f32), self._ptr(k, self.f32),
-                   self._ptr(v, self.f32), self._ptr(blocked, torch.uint8), self._ptr(row_open, self.i32),
+        self._call("occf_masked_xattn_fwd", self._ptr(q, self.f32), self._ptr(k, self.f32, B * L * E),
+                   self._ptr(v, self.f32, B * L * E), self._ptr(blocked, torch.uint8, B * Q * L),
+                   self._ptr(row_open, self.i32, B * Q),
                    self._ptr(out), self._ptr(ws), need, B, Q, L, E, heads, self._stream())
         return out
 
@@ -248,7 +254,7 @@ class HipOps:
         X2, Y2, Z2 = (int(t) for t in occ_size)
         out = torch.empty((B, K, X2, Y2, Z2), dtype=mask_pred.dtype, device=mask_pred.device)
         ws = torch.empty((B * Q * 24,), dtype=self.f32, device=mask_pred.device)
-        self._call("occf_upsample_classify_fwd", self._ptr(mask_pred, self.f32), self._ptr(cls, self.f32),
+        self._call("occf_upsample_classify_fwd", self._ptr(mask_pred, self.f32), self._ptr(cls, self.f32, B * Q * (K + 1)),
                    self._ptr(out), self._ptr(ws), B, Q, K, X, Y, Z, X2, Y2, Z2, self._stream())
         return out
 
@@ -258,8 +264,8 @@ class HipOps:
         K = cls.shape[-1] - 1
         P = pts.shape[0]
         out = torch.empty((P, K), dtype=mask_pred.dtype, device=mask_pred.device)
-        self._call("occf_lidarseg_sample_fwd", self._ptr(mask_pred, self.f32), self._ptr(cls, self.f32),
-                   self._ptr(pts, self.f32), self._ptr(out), P, B, Q, K, X, Y, Z, self._stream())
+        self._call("occf_lidarseg_sample_fwd", self._ptr(mask_pred, self.f32), self._ptr(cls, self.f32, B * Q * (K + 1)),
+                   self._ptr(pts, self.f32, 4 * P), self._ptr(out), P, B, Q, K, X, Y, Z, self._stream())
         return out
 
     # ------------------------------------------------------------------ dense contractions
@@ -312,6 +318,9 @@ class HipOps:
         if out is None:
             out = torch.empty((M, N), dtype=x.dtype, device=x.device)
         r2 = residual.reshape(-1, N) if residual is not None else None
+        if weight.numel() != N * K or (bias is not None and bias.numel() != N) or out.numel() != M * N or \
+                (r2 is not None and r2.shape[0] != M):
+            raise OccfError(f"linear: x [{M}, {K}], weight {tuple(weight.shape)}, bias / residual / out sizes disagree")
         self.last_flops = 2 * M * N * K
         for t in (x2, out, r2):
             if t is not None and (t.stride(1) != 1 or (self.strict and not t.is_cuda)):
@@ -392,6 +401,10 @@ class HipOps:
         Yo = (Yi + 2 * pad[1] - dil * (kY - 1) - 1) // stride + 1
         Zo = (Zi + 2 * pad[2] - dil * (kZ - 1) - 1) // stride + 1
         out = torch.empty((B, Xo, Yo, Zo, Cout), dtype=x_cl.dtype, device=x_cl.device)
+        if weight_tap.numel() != Cout * kX * kY * kZ * Cin or (bias is not None and bias.numel() != Cout) or \
+                (residual is not None and residual.numel() != out.numel()):
+            raise OccfError(f"conv3d: x {tuple(x_cl.shape)}, weight {tuple(weight_tap.shape)} for taps {tuple(ksize)}, "
+                            "bias / residual sizes disagree")
         self.last_flops = 2 * B * Xo * Yo * Zo * Cout * kX * kY * kZ * Cin
         if self.strict and not x_cl.is_cuda:
             raise OccfError("occformer_amd ops need GPU tensors (no CPU path exists)")
@@ -482,31 +495,34 @@ class HipOps:
         if tokens:
             shape[-2] = Z + 1
         out = torch.empty(shape, dtype=x_cl.dtype, device=x_cl.device)
-        self._call("occf_groupnorm_apply", self._ptr(x_cl, self.f32), self._ptr(stats, self.f32),
-                   self._ptr(gamma, self.f32), self._ptr(beta, self.f32), self._ptr(residual), self._ptr(out),
+        self._call("occf_groupnorm_apply", self._ptr(x_cl, self.f32), self._ptr(stats, self.f32, B * groups * 2),
+                   self._ptr(gamma, self.f32, C), self._ptr(beta, self.f32, C),
+                   self._ptr(residual, None, None if residual is None else x_cl.numel()), self._ptr(out),
                    B, P, Z, C, groups, int(relu), int(tokens), self._stream())
         return out
 
     def layernorm(self, x, gamma, beta, eps=1e-5):
         C = x.shape[-1]
         out = torch.empty_like(x)
-        self._call("occf_layernorm_fwd", self._ptr(x, self.f32), self._ptr(gamma, self.f32),
-                   self._ptr(beta, self.f32), self._ptr(out), x.numel() // C, C, float(eps), self._stream())
+        self._call("occf_layernorm_fwd", self._ptr(x, self.f32), self._ptr(gamma, self.f32, C),
+                   self._ptr(beta, self.f32, C), self._ptr(out), x.numel() // C, C, float(eps), self._stream())
         return out
 
     def dualpath_combine(self, tokens, bev, w, b, identity):
         """tokens [B, X, Y, Z+1, C], bev [B, X, Y, C], identity [B, X, Y, Z, C] -> [B, X, Y, Z, C]."""
         B, X, Y, Zs, C = tokens.shape
         out = torch.empty((B, X, Y, Zs - 1, C), dtype=tokens.dtype, device=tokens.device)
-        self._call("occf_dualpath_combine", self._ptr(tokens, self.f32), self._ptr(bev, self.f32),
-                   self._ptr(w, self.f32), self._ptr(b), self._ptr(identity, self.f32), self._ptr(out),
+        self._call("occf_dualpath_combine", self._ptr(tokens, self.f32), self._ptr(bev, self.f32, B * X * Y * C),
+                   self._ptr(w, self.f32, C), self._ptr(b), self._ptr(identity, self.f32, out.numel()), self._ptr(out),
                    B * X * Y, Zs - 1, C, self._stream())
         return out
 
     def upsample_add(self, coarse, lateral):
         """coarse [B, X, Y, Z, C] trilinearly resized (align_corners=False) onto lateral [B, X2, Y2, Z2, C]."""
         B, X, Y, Z, C = coarse.shape
-        _, X2, Y2, Z2, _ = lateral.shape
+        _, X2, Y2, Z2, C2 = lateral.shape
+        if C2 != C or lateral.shape[0] != B:
+            raise OccfError(f"upsample_add: coarse {tuple(coarse.shape)} vs lateral {tuple(lateral.shape)}")
         out = torch.empty_like(lateral)
         self._call("occf_upsample_add", self._ptr(coarse, self.f32), self._ptr(lateral, self.f32), self._ptr(out),
                    B, X, Y, Z, X2, Y2, Z2, C, self._stream())
@@ -725,14 +741,17 @@ class HipOps:
         dw = torch.empty((C,), dtype=self.f32, device=tokens.device)
         dbias = torch.empty((1,), dtype=self.f32, device=tokens.device)
         ws = self._ws(self.lib.occf_dualpath_combine_bwd_workspace(BP, C), tokens.device)
-        self._call("occf_dualpath_combine_bwd", self._ptr(tokens, self.f32), self._ptr(bev, self.f32),
-                   self._ptr(w, self.f32), self._ptr(b), self._ptr(dout, self.f32), self._ptr(dtok), self._ptr(dbev),
+        self._call("occf_dualpath_combine_bwd", self._ptr(tokens, self.f32), self._ptr(bev, self.f32, BP * C),
+                   self._ptr(w, self.f32, C), self._ptr(b), self._ptr(dout, self.f32, BP * (Zs - 1) * C),
+                   self._ptr(dtok), self._ptr(dbev),
                    self._ptr(dw), self._ptr(dbias), self._ptr(ws), BP, Zs - 1, C, self._stream())
         return dtok, dbev, dw, dbias
 
     def upsample_add_backward(self, dout, coarse_shape):
         B, X, Y, Z, C = coarse_shape
-        _, X2, Y2, Z2, _ = dout.shape
+        _, X2, Y2, Z2, C2 = dout.shape
+        if C2 != C or dout.shape[0] != B:
+            raise OccfError(f"upsample_add_backward: dout {tuple(dout.shape)} vs coarse {tuple(coarse_shape)}")
         dc = torch.empty(tuple(coarse_shape), dtype=self.f32, device=dout.device)
         self._call("occf_upsample_add_bwd", self._ptr(dout, self.f32), self._ptr(dc), B, X, Y, Z, X2, Y2, Z2, C,
                    self._stream())
