@@ -25,7 +25,8 @@
   * ``OccDefaultFormatBundle3D`` / ``Collect3D`` / ``Compose`` / ``collate`` -- the remaining stages of the configs'
     ``train_pipeline`` / ``test_pipeline`` lists, so that the lists build by name and feed ``forward_train`` directly.
 
-The image / depth / metric kernels have no CPU implementation: host tensors raise in ``occformer_amd.ops``."""
+The image / depth / metric kernels have no CPU implementation: host tensors raise in ``occformer_amd.ops``; the tensor
+programs of the ground-truth loaders refuse them the same way under the product binding (``_device_only``)."""
 import math
 
 import torch
@@ -329,10 +330,19 @@ def bda_matrix(rotate_deg, flip_dx, flip_dy, flip_dz, center=None):
     return denorm @ flip @ rot @ norm
 
 
+def _device_only(t, what):
+    """the tensor programs below are part of the device pipeline: like the kernels (``ops._ptr``) they refuse host tensors
+    under the product binding (the test-only host emulation binding runs them on the CPU)"""
+    if get_ops().strict and not t.is_cuda:
+        from .ops import OccfError
+        raise OccfError(f"{what}: GPU tensors expected (no CPU path exists)")
+
+
 def rotate_label_volume(vox, angle, fill=255):
     """custom_rotate_3d (loading_nusc_occ.py:205-224): every [X, Y] height slice of the uint8 label volume rotated as
     ``Image.rotate(angle, NEAREST, fillcolor=255)`` does (16.16 fixed-point source index; the transpose fast paths for
     0 / 180 and, on square slices, 90 / 270 degrees), all slices at once on the device"""
+    _device_only(vox, "rotate_label_volume")
     H, W, Z = vox.shape
     ang = angle % 360.0
     if ang in (90, 270) and H == W:
@@ -358,6 +368,7 @@ def voxel_transform(vox, rotate_deg, flip_dx, flip_dy, flip_dz, center=None):
     mat = bda_matrix(rotate_deg, flip_dx, flip_dy, flip_dz, center)
     if vox is None:
         return None, mat
+    _device_only(vox, "voxel_transform")
     vox = vox.to(torch.uint8)
     if abs(rotate_deg) > 1e-8:                                       # np.isclose(rotate_degree, 0)
         vox = rotate_label_volume(vox, rotate_deg)
@@ -374,6 +385,7 @@ def voxelize_point_labels(points, labels, grid_size, pc_range, num_labels, empty
     then 0 (noise) -> 255, ``empty_id`` -> 0.  The grid index is computed in float64 like the reference's numpy
     (points promoted, clip to [lo, hi - 1e-5], floor of the quotient).  No host synchronisation."""
     import numpy as np
+    _device_only(points, "voxelize_point_labels")
     dev = points.device
     gs = [int(v) for v in grid_size]
     rng = np.array(pc_range, np.float64)

@@ -33,6 +33,19 @@ def test_product_has_no_cpu_path():
     ops = HipOps(_lib.get(), strict=True)
     with pytest.raises(OccfError):
         ops.mask_pool(torch.zeros(1, 1, 2, 2, 2), (1, 1, 1))
+    # the tensor-program stages of the data pipeline follow the same rule under the product binding
+    import occformer_amd.ops as ops_mod
+    from occformer_amd import pipeline as PL
+    saved, ops_mod._ops = ops_mod._ops, ops
+    try:
+        with pytest.raises(OccfError):
+            PL.voxelize_point_labels(torch.zeros(4, 3), torch.zeros(4, dtype=torch.long), [2, 2, 2], [0, 0, 0, 1, 1, 1], 18)
+        with pytest.raises(OccfError):
+            PL.voxel_transform(torch.zeros(4, 4, 2, dtype=torch.uint8), 0.0, True, False, False)
+        with pytest.raises(OccfError):
+            PL.rotate_label_volume(torch.zeros(4, 4, 2, dtype=torch.uint8), 10.0)
+    finally:
+        ops_mod._ops = saved
 
 
 def test_registry_names():
