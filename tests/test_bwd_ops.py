@@ -9,6 +9,7 @@ from tests import paramgen
 
 
 def _rel(a, b):
+    a, b = a.detach(), b.detach()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
 
 

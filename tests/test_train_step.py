@@ -83,7 +83,8 @@ def test_training_step_gradients_vs_oracle(bound):
                                  points_occ=[p.to(d) for p in pts])
     assert replay.i == len(rec.tape), "the product consumed a different number of noise draws than the oracle"
     for k, v in ref_losses.items():
-        assert abs(float(losses[k].detach()) - float(v)) <= TOL * max(1.0, abs(float(v))), (k, float(losses[k].detach()), float(v))
+        v = float(v.detach())
+        assert abs(float(losses[k].detach()) - v) <= TOL * max(1.0, abs(v)), (k, float(losses[k].detach()), v)
     total = sum(v for k, v in losses.items() if k.startswith(("loss", "d")) and "iou" not in k)
     total.backward()
     worst = []
@@ -171,7 +172,8 @@ def _kitti_step(be, configs, whole_tol):
                                  gt_occ=gt_occ.to(d), points_occ=None)
     assert replay.i == len(rec.tape), "the product consumed a different number of noise draws than the oracle"
     for k, v in ref_losses.items():
-        assert abs(float(losses[k].detach()) - float(v)) <= TOL * max(1.0, abs(float(v))), (k, float(losses[k].detach()), float(v))
+        v = float(v.detach())
+        assert abs(float(losses[k].detach()) - v) <= TOL * max(1.0, abs(v)), (k, float(losses[k].detach()), v)
     sum(v for k, v in losses.items() if "loss" in k).backward()
     named = dict(model.named_parameters())
     per = []

@@ -162,7 +162,8 @@ def test_nusc_loss_of_all_sets_at_once_equals_set_by_set(bound, lazy):
     out_s, g_s, _ = run(False)
     assert set(out_b) == set(out_s) and len(out_b) == 3 * S
     for k in out_s:
-        assert abs(float(out_b[k]) - float(out_s[k])) < 2e-6 * max(1.0, abs(float(out_s[k]))), k
+        vb, vs = float(out_b[k].detach()), float(out_s[k].detach())
+        assert abs(vb - vs) < 2e-6 * max(1.0, abs(vs)), k
     for a, b in zip(g_b, g_s):
         assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-9
 
