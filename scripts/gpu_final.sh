@@ -18,7 +18,7 @@ python - <<PY
 import json
 try:
     d=json.load(open("$O/bench_train.json"))
-    print({k:d[k] for k in ("metric","value","ms_per_step","peak_memory_GiB","forward_samples_per_s_same_run")})
+    print({k:d[k] for k in ("metric","value","ms_per_step","peak_memory_GiB")}, "forward", (d.get("forward") or {}).get("value"))
     print(d["roofline"]); print(d.get("cpu_baseline"))
     for k,v in list(d["kernels"].items())[:14]: print(k, v["calls"], round(v["total_ms"],2))
 except Exception as e: print("no json", e)

@@ -15,7 +15,7 @@ python - <<PY
 import json
 try:
     d=json.load(open("$O/bench_train.json"))
-    print({k:d[k] for k in ("value","ms_per_step","peak_memory_GiB","forward_samples_per_s_same_run") if k in d})
+    print({k:d[k] for k in ("value","ms_per_step","peak_memory_GiB") if k in d}, "forward", (d.get("forward") or {}).get("value"))
     print(d["roofline"])
     for k,v in list(d["kernels"].items())[:40]: print(k, v)
     print(d.get("losses"))
