@@ -21,7 +21,7 @@
   * ``LoadNuscOccupancyAnnotations`` / ``LoadSemKittiAnnotation`` -- loading_nusc_occ.py:13-224 /
     loading_kitti_occ.py:7-116: ``gt_occ``, ``points_occ`` and the BEV-augmentation matrix ``bda_rot`` (``img_inputs[6]``).
     The lidarseg voxelisation (majority label per voxel), the flips and the PIL-style rotation of the label volume are
-    device tensor programs (integer sorts / searches / gathers: index work, bit-exact), no kernel of their own yet.
+    device tensor programs (integer sorts / scans / gathers: index work, bit-exact), no kernel of their own yet.
   * ``OccDefaultFormatBundle3D`` / ``Collect3D`` / ``Compose`` / ``collate`` -- the remaining stages of the configs'
     ``train_pipeline`` / ``test_pipeline`` lists, so that the lists build by name and feed ``forward_train`` directly.
 
@@ -396,11 +396,19 @@ def voxelize_point_labels(points, labels, grid_size, pc_range, num_labels, empty
                       / torch.tensor(vs, dtype=torch.float64, device=dev)).long()
     V, L = gs[0] * gs[1] * gs[2], int(num_labels)
     lin = (ind[:, 0] * gs[1] + ind[:, 1]) * gs[2] + ind[:, 2]
-    # per (voxel, label) run of the sorted keys its length (two binary searches: static shapes, no histogram of
-    # [voxels x labels] -- 1.5 GB at 512 x 512 x 40 x 18), then per voxel the entry with the largest (count, -label):
-    # a second sort puts it first in the voxel's run; everything else is written to a dump slot
+    P = int(points.shape[0])
+    if P == 0:
+        return torch.zeros(gs, dtype=torch.int64, device=dev)
+    # per (voxel, label) run of the sorted keys its length (running maxima of the run-start / run-end positions: static
+    # shapes, no histogram of [voxels x labels] -- 1.5 GB at 512 x 512 x 40 x 18), then per voxel the entry with the
+    # largest (count, -label): a second sort puts it first in the voxel's run; everything else goes to a dump slot
     key = torch.sort(lin * L + labels).values
-    cnt = (torch.searchsorted(key, key, right=True) - torch.searchsorted(key, key, right=False)) & 0xFFFF
+    pos = torch.arange(P, device=dev)
+    edge = torch.ones(P + 1, dtype=torch.bool, device=dev)
+    edge[1:P] = key[1:] != key[:-1]                                   # edge[i]: a run starts at i; edge[i + 1]: one ends at i
+    run_first = torch.cummax(torch.where(edge[:P], pos, torch.zeros_like(pos)), 0).values
+    run_last = (P - 1) - torch.cummax(torch.where(edge[1:].flip(0), pos, torch.zeros_like(pos)), 0).values.flip(0)
+    cnt = (run_last - run_first + 1) & 0xFFFF
     big = 65536 * L + L
     key2 = torch.sort((key // L) * big + (big - 1 - (cnt * L + (L - 1 - key % L)))).values
     lin2 = key2 // big
