@@ -1,4 +1,5 @@
 // TEST-ONLY: fiber scheduler behind tests/hipemu/hipemu.h (see the header).
+#include <cstdlib>
 #include "hipemu.h"
 
 asm(R"(
@@ -59,7 +60,11 @@ void run_block(void (*entry)(void*), void* arg, dim3 grid, dim3 block, emu_uint3
   static std::vector<char*> stacks;
   const int nt = (int)(block.x * block.y * block.z);
   while ((int)stacks.size() < nt) stacks.push_back((char*)malloc(STACK));
-  std::vector<char> dyn(shmem + 64);
+  // OCCF_EMU_LDS_POISON=1: the dynamic LDS of every workgroup starts as 0xFF bytes (NaN as f32 / bf16, -1 as an integer)
+  // instead of zeros -- on the GPU it holds whatever the previous workgroup left, so a kernel that reads a word it has
+  // not written must not pass the CPU suite because the emulation happened to hand it zeros
+  static const char fill = (getenv("OCCF_EMU_LDS_POISON") && getenv("OCCF_EMU_LDS_POISON")[0] == '1') ? (char)0xFF : (char)0;
+  std::vector<char> dyn(shmem + 64, fill);
   Block b;
   b.fibers.resize(nt);
   b.waves.resize((nt + WAVE - 1) / WAVE);
