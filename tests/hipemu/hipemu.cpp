@@ -1,6 +1,9 @@
 // TEST-ONLY: fiber scheduler behind tests/hipemu/hipemu.h (see the header).
 #include <cstdlib>
 #include "hipemu.h"
+#include <cstring>
+extern "C" char __start_emu_lds[] __attribute__((weak));
+extern "C" char __stop_emu_lds[] __attribute__((weak));
 
 asm(R"(
 .text
@@ -60,11 +63,13 @@ void run_block(void (*entry)(void*), void* arg, dim3 grid, dim3 block, emu_uint3
   static std::vector<char*> stacks;
   const int nt = (int)(block.x * block.y * block.z);
   while ((int)stacks.size() < nt) stacks.push_back((char*)malloc(STACK));
-  // OCCF_EMU_LDS_POISON=1: the dynamic LDS of every workgroup starts as 0xFF bytes (NaN as f32 / bf16, -1 as an integer)
-  // instead of zeros -- on the GPU it holds whatever the previous workgroup left, so a kernel that reads a word it has
-  // not written must not pass the CPU suite because the emulation happened to hand it zeros
+  // OCCF_EMU_LDS_POISON=1: the LDS of every workgroup -- the dynamic block and every static __shared__ array (section
+  // emu_lds, hipemu.h) -- starts as 0xFF bytes (NaN as f32 / bf16, -1 as an integer) instead of zeros / the previous
+  // workgroup's values: on the GPU it holds whatever ran before, so a kernel that reads a word it has not written must
+  // not pass the CPU suite because the emulation happened to hand it something benign
   static const char fill = (getenv("OCCF_EMU_LDS_POISON") && getenv("OCCF_EMU_LDS_POISON")[0] == '1') ? (char)0xFF : (char)0;
   std::vector<char> dyn(shmem + 64, fill);
+  if (fill) memset(__start_emu_lds, 0xFF, (size_t)(__stop_emu_lds - __start_emu_lds));   // the static __shared__ arrays
   Block b;
   b.fibers.resize(nt);
   b.waves.resize((nt + WAVE - 1) / WAVE);

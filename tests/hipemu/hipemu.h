@@ -124,7 +124,8 @@ void launch(F&& body, dim3 grid, dim3 block, size_t shmem) {
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#define __shared__ static
+// static LDS lives in one named section so that the emulator can poison it per workgroup (OCCF_EMU_LDS_POISON)
+#define __shared__ static __attribute__((section("emu_lds")))
 #define __launch_bounds__(...)
 #define __restrict__
 #define OCCF_DYN_SMEM(name) char* name = hipemu::g_dyn_smem
