@@ -14,6 +14,7 @@
 // next tap's slab is fetched into registers while the current tap multiplies.
 // LDS rows are 64 B with the 16-B k-slots XOR-swizzled by (row>>2)&3 (see gemm_bf16.hip).
 // Optionally emits per-workgroup GroupNorm partial sums of the raw outputs.
+#include <stdlib.h>
 #include "occf_common.h"
 #include "../../include/occformer_hip.h"
 
@@ -82,7 +83,12 @@ typedef uint32_t ch_u2 __attribute__((ext_vector_type(2)));
 // k-step ahead of the MFMAs that use them -- no weight slabs in LDS and NO BARRIER PER TAP (the slab double buffer
 // needed one; PMC r02: MFMA pipe 50 % busy, 48 % of the wave cycles waiting): the 8 waves only meet when the halo
 // tile changes, every 27 taps.
-template <int TN, int TERMS, bool FRAG>
+// SCH (FRAG only): the k-step as an explicit software pipeline -- MFMAs issued term-major (six accumulators between two
+// products into the same one), the NEXT k-step's four A reads and 2 * TN B loads placed one per MFMA at the head of
+// the current k-step (sched_group_barrier), no conditional load in the loop.  The compiler's own order sank the
+// loads to 1-5 MFMAs in front of their first use to save registers (ISA: s_waitcnt lgkmcnt one MFMA after four
+// ds_read_b128, vmcnt four MFMAs after the loads).
+template <int TN, int TERMS, bool FRAG, int SCH = 0>
 __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
   constexpr int BN = 64 * TN;
   constexpr int NBP = (BN * 4 + 511) / 512;          // 16-B weight pieces per thread per array
@@ -273,6 +279,64 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
     if (HPF) load_halo(0, 0);
     load_f(0, 0, f0h, f0l);
     int cc = 0, tap = 0;
+    if (SCH) {
+      auto mma_tm = [&](const bf16x8 (&ah)[2], const bf16x8 (&al)[2], const bf16x8 (&fh)[TN],
+                        const bf16x8 (&fl)[TN]) __attribute__((always_inline)) {
+        if (TERMS == 3) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = occf_mfma_bf16_32x32x16(al[i], fh[j], acc[i][j]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], fl[j], acc[i][j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], fh[j], acc[i][j]);
+      };
+      constexpr int NA = TERMS == 3 ? 4 : 2;             // ds_read_b128 per k-step
+      constexpr int NF = TERMS == 3 ? 2 * TN : TN;       // global 16-byte loads per k-step
+      constexpr int NM = 2 * TN * TERMS;                 // MFMAs per k-step
+      for (int g = 0; g < G; ++g) {
+        if (tap == 0) {
+          __syncthreads();
+          if (HPF) {
+            store_halo(0);
+            load_halo((cc + 1 < n_chunks ? cc + 1 : cc) * 32, 0);
+          } else {
+#pragma unroll
+            for (int i0 = 0; i0 < NHI; i0 += HB) {
+              load_halo(cc * 32, i0);
+              store_halo(i0);
+            }
+          }
+          __syncthreads();
+          load_a(0, 0, a0h, a0l);
+        }
+        const int toff = tap_off(tap);
+        const int tnx = tap_off(tap < 26 ? tap + 1 : 0);   // (tap 26: a harmless read, replaced after the staging)
+        OCCF_SCHED_FENCE();
+        load_a(toff, 1, a1h, a1l);
+        load_f(g, 1, f1h, f1l);
+        mma_tm(a0h, a0l, f0h, f0l);
+        load_a(tnx, 0, a0h, a0l);
+        load_f(g + 1, 0, f0h, f0l);
+        mma_tm(a1h, a1l, f1h, f1l);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int i = 0; i < NA; ++i) { OCCF_SCHED_GROUP(0x008, 1); OCCF_SCHED_GROUP(0x100, 1); }
+#pragma unroll
+          for (int i = 0; i < NF; ++i) { OCCF_SCHED_GROUP(0x008, 1); OCCF_SCHED_GROUP(0x020, 1); }
+          OCCF_SCHED_GROUP(0x008, NM - NA - NF);
+        }
+        OCCF_SCHED_FENCE();
+        if (++tap == 27) { tap = 0; ++cc; }
+      }
+    } else
     for (int g = 0; g < G; ++g) {
       if (tap == 0) {
         __syncthreads();                                 // previous chunk's taps are done with the halo
@@ -436,16 +500,22 @@ static size_t conv_halo_lds(int TY, int TZ, int TN, int terms, bool frag) {
   return NH * 64 * (terms == 3 ? 2 : 1) + (size_t)2 * 64 * TN * 64 * (terms == 3 ? 2 : 1);
 }
 
+typedef void (*conv_halo_fn_t)(ConvHaloArgs);
 template <int TN>
-static int launch_conv_halo(const ConvHaloArgs& a, int terms, unsigned grid, size_t lds, hipStream_t st) {
-  if (a.Fh) {
-    if (terms == 3) hipLaunchKernelGGL((conv3x3x3_halo_kernel<TN, 3, true>), dim3(grid), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((conv3x3x3_halo_kernel<TN, 1, true>), dim3(grid), dim3(512), lds, st, a);
-  } else {
-    if (terms == 3) hipLaunchKernelGGL((conv3x3x3_halo_kernel<TN, 3, false>), dim3(grid), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((conv3x3x3_halo_kernel<TN, 1, false>), dim3(grid), dim3(512), lds, st, a);
+static conv_halo_fn_t conv_halo_fn(bool t3, bool frag, int sch) {
+  if (frag && sch) return t3 ? conv3x3x3_halo_kernel<TN, 3, true, 1> : conv3x3x3_halo_kernel<TN, 1, true, 1>;
+  if (frag) return t3 ? conv3x3x3_halo_kernel<TN, 3, true> : conv3x3x3_halo_kernel<TN, 1, true>;
+  return t3 ? conv3x3x3_halo_kernel<TN, 3, false> : conv3x3x3_halo_kernel<TN, 1, false>;
+}
+
+// OCCF_HALO_SCHED: 1 (default) = the explicitly pipelined k-step of the FRAG variant, 0 = the compiler's order
+static int conv_halo_sched() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("OCCF_HALO_SCHED");
+    v = e ? atoi(e) : 1;
   }
-  return (int)hipGetLastError();
+  return v;
 }
 
 // w[Cout][27 * Cin] (tap-major rows, bf16) -> fragment order [chunk][tap][k-step][Cout / 32][lane = lk * 32 + li][8]:
@@ -519,27 +589,20 @@ extern "C" int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, con
   if (wfrag_hi && (terms == 1 || wfrag_lo)) { a.Fh = wfrag_hi; a.Fl = wfrag_lo; }
   const long blocks = (long)B * ((X + 1) / 2) * ((Y + TY - 1) / TY) * (Z / TZ) * ((Cout + 64 * TN - 1) / (64 * TN));
   if (blocks >= 2147483647L) return OCCF_ESHAPE;
-#ifndef OCCF_EMU
-  static bool attr_set[4][2][2] = {};
-  const void* fn = nullptr;
   const bool t3 = terms == 3, fr = a.Fh != nullptr;
-#define OCCF_CH_FN(TN_)                                                                                       \
-  (fr ? (t3 ? (const void*)conv3x3x3_halo_kernel<TN_, 3, true> : (const void*)conv3x3x3_halo_kernel<TN_, 1, true>) \
-      : (t3 ? (const void*)conv3x3x3_halo_kernel<TN_, 3, false> : (const void*)conv3x3x3_halo_kernel<TN_, 1, false>))
-  if (TN == 1) fn = OCCF_CH_FN(1);
-  if (TN == 2) fn = OCCF_CH_FN(2);
-  if (TN == 3) fn = OCCF_CH_FN(3);
-#undef OCCF_CH_FN
-  if (!attr_set[TN][t3][fr]) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const int sch = fr ? (conv_halo_sched() ? 1 : 0) : 0;
+  const conv_halo_fn_t fn = TN == 1 ? conv_halo_fn<1>(t3, fr, sch) : TN == 2 ? conv_halo_fn<2>(t3, fr, sch) : conv_halo_fn<3>(t3, fr, sch);
+#ifndef OCCF_EMU
+  static bool attr_set[4][2][2][2] = {};
+  if (!attr_set[TN][t3][fr][sch]) {
+    hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set[TN][t3][fr] = true;
+    attr_set[TN][t3][fr][sch] = true;
   }
 #endif
   hipStream_t st = (hipStream_t)stream;
-  if (TN == 1) return launch_conv_halo<1>(a, terms, (unsigned)blocks, lds, st);
-  if (TN == 2) return launch_conv_halo<2>(a, terms, (unsigned)blocks, lds, st);
-  return launch_conv_halo<3>(a, terms, (unsigned)blocks, lds, st);
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(512), lds, st, a);
+  return (int)hipGetLastError();
 }
 
 // number of spatial workgroup tiles per batch element (= rows of the GroupNorm partial buffer) the halo

@@ -88,8 +88,12 @@ void occf_bf16_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
 // compiler's register-minimising order would serialise LDS latency and dependent MFMAs)
 #ifdef OCCF_EMU
 #define OCCF_SCHED_FENCE() do { } while (0)
+#define OCCF_SCHED_GROUP(mask, n) do { } while (0)
 #else
 #define OCCF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// one link of an explicit issue pipeline: the next `n` instructions of class `mask` (0x008 MFMA, 0x020 VMEM read,
+// 0x100 DS read, 0x200 DS write, 0x002 VALU, 0x004 SALU) of this scheduling region, in the order the links appear
+#define OCCF_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #endif
 
 // buffer-addressed loads: SGPR resource + 32-bit VGPR byte offset + SGPR byte offset, i.e. no 64-bit

@@ -38,3 +38,22 @@ def dropout_mask(shape, p, device):
         return None
     u = get_rng(device).rand(*shape).to(device=device, dtype=torch.float32)
     return (u >= p).float() / (1.0 - p)
+
+
+# ---- debug tap for gradient comparisons (tests, bench.py's check): the gates of the decoder head's ReLUs -------------
+_gates = None
+
+
+def record_gates(on=True):
+    """start (-> the list that fills up, in call order) or stop recording ``relu_gate`` calls"""
+    global _gates
+    _gates = [] if on else None
+    return _gates
+
+
+def relu_gate(h):
+    """called by the decoder head on every ReLU OUTPUT of its small MLPs; a no-op unless a comparison asked for the
+    gates (oracle.occformer_ref.forced_gates explains why)"""
+    if _gates is not None:
+        _gates.append(h.detach() > 0)
+    return h

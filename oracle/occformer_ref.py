@@ -165,6 +165,57 @@ def lift_splat(depth_prob, img_feat, geom, dx, bx, nx):
 # All noise comes from ``rng.rand`` in call order (oracle/occformer_train_ref.GlobalTorchRNG or a recording
 # subclass), so that the product can replay the identical draws.
 _TRAIN = None
+_GATES = None
+
+
+class forced_gates:
+    """Test infrastructure for gradient comparisons.  The ReLUs of the decoder head (decoder-layer FFNs, the
+    mask-embedding MLP: ~1.8 M units, each of which moves EVERY upstream gradient when its gate differs) sit on fp32
+    pre-activations; two correct implementations whose pre-activations differ by 1e-6 open a unit at |z| ~ 1e-6
+    differently, and the gradient through it is then 'all' in one and 'nothing' in the other.  Inside this context the
+    head's ReLUs take their gates from ``masks`` (bool tensors in call order: the gates the OTHER implementation
+    used), so that both sides differentiate the same piecewise-linear function; the context counts where the forced
+    gate differs from this implementation's own and how far from zero those pre-activations are (they must be
+    rounding-close for the forcing to be legitimate -- the caller asserts it)."""
+
+    def __init__(self, masks):
+        self.masks = [m.detach().cpu().bool() for m in masks]
+        self.i = 0
+        self.units = 0
+        self.flipped = 0
+        self.max_abs_z = 0.0          # largest |pre-activation| among the units gated differently
+        self.max_rel_z = 0.0          # the same relative to the RMS of its tensor
+
+    def __enter__(self):
+        global _GATES
+        self._prev, _GATES = _GATES, self
+        self.i = 0
+        return self
+
+    def __exit__(self, *exc):
+        global _GATES
+        _GATES = self._prev
+        return False
+
+
+def _relu_head(z):
+    """ReLU of the decoder head: F.relu, or the forced gate inside ``forced_gates``"""
+    g = _GATES
+    if g is None:
+        return F.relu(z)
+    assert g.i < len(g.masks), "forced_gates: the head evaluates more ReLUs than gate masks were recorded"
+    m = g.masks[g.i].reshape(z.shape)
+    g.i += 1
+    zd = z.detach()
+    diff = (zd > 0) != m
+    n = int(diff.sum())
+    g.units += z.numel()
+    if n:
+        a = float(zd[diff].abs().max())
+        g.flipped += n
+        g.max_abs_z = max(g.max_abs_z, a)
+        g.max_rel_z = max(g.max_rel_z, a / max(float(zd.pow(2).mean().sqrt()), 1e-30))
+    return z * m.to(z.dtype)
 
 
 class training_mode:
@@ -590,7 +641,7 @@ def head_predict(sd, p, dec, mask_feat, target_shape, heads, pooling=True):
     d = F.layer_norm(dec, (E,), sd[p + "transformer_decoder.post_norm.weight"],
                      sd[p + "transformer_decoder.post_norm.bias"], 1e-5)
     cls = _linear(sd, p + "cls_embed.", d)
-    m = _linear(sd, p + "mask_embed.4.", F.relu(_linear(sd, p + "mask_embed.2.", F.relu(
+    m = _linear(sd, p + "mask_embed.4.", _relu_head(_linear(sd, p + "mask_embed.2.", _relu_head(
         _linear(sd, p + "mask_embed.0.", d)))))
     mask_pred = torch.einsum("bqc,bcxyz->bqxyz", m, mask_feat)
     if pooling:
@@ -629,7 +680,7 @@ def mask2former_head(sd, p, feats, heads=6, num_layers=9, num_levels=3, pooling=
         q = F.layer_norm(q + a, (E,), sd[lp + "norms.0.weight"], sd[lp + "norms.0.bias"], 1e-5)
         a = _mha(sd, lp + "attentions.1.attn.", q + qpos, q + qpos, q, heads)
         q = F.layer_norm(q + a, (E,), sd[lp + "norms.1.weight"], sd[lp + "norms.1.bias"], 1e-5)
-        y = _linear(sd, lp + "ffns.0.layers.1.", F.relu(_linear(sd, lp + "ffns.0.layers.0.0.", q)))
+        y = _linear(sd, lp + "ffns.0.layers.1.", _relu_head(_linear(sd, lp + "ffns.0.layers.0.0.", q)))
         q = F.layer_norm(q + y, (E,), sd[lp + "norms.2.weight"], sd[lp + "norms.2.bias"], 1e-5)
         inter.append((pooled, blocked))
         cls, mp, pooled, blocked = head_predict(

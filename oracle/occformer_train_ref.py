@@ -377,7 +377,7 @@ def depth_bce_loss(gt_depths, depth_preds, downsample, dbound, D, loss_depth_wei
 
 # ----------------------------------------------------------------------------------------- one training step
 def train_step(sd, img_feats, cams, gt_depths, gt_occ, points, cfg, rng=None, drop_path=0.2, aspp_drop=0.1,
-               depth_aspp_drop=0.5):
+               depth_aspp_drop=0.5, gates=None, forward_only=False):
     """occupancyformer.py:132-199 (forward_train) + loss.backward() on the restated reference path in TRAIN mode
     (oracle.occformer_ref.training_mode): depth BCE + the ten Hungarian prediction-set losses of the nuScenes head,
     then torch.autograd of their sum w.r.t. every trainable parameter.
@@ -385,7 +385,11 @@ def train_step(sd, img_feats, cams, gt_depths, gt_occ, points, cfg, rng=None, dr
     training rows: point_cloud_range, num_points, oversample_ratio, importance_sample_ratio, padding_mode,
     num_classes, class_weight).  A head dict with ``sample_weights`` selects the SemanticKITTI head
     (mask2former_occ.py:343-444: class-guided sampling, class-weighted mask losses, ``align_corners``; no LiDAR
-    points).  -> (losses dict, {name: grad})"""
+    points).  -> (losses dict, {name: grad})
+    ``gates``: an ``occformer_ref.forced_gates`` context -- the head's ReLUs then use the recorded gates of the
+    implementation under test (see there).  ``forward_only``: losses only (call it under ``torch.no_grad()`` to tape
+    the noise draws at a third of the cost); the gradients are then None."""
+    import contextlib
     from . import occformer_ref as O
     rng = rng or GlobalTorchRNG()
     frozen = ("running_mean", "running_var", "num_batches_tracked", ".frustum", ".dx", ".bx", ".nx",
@@ -393,7 +397,7 @@ def train_step(sd, img_feats, cams, gt_depths, gt_occ, points, cfg, rng=None, dr
     params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(frozen) else v)
               for k, v in sd.items()}
     g = cfg.get("groups", 32)
-    with O.training_mode(rng, drop_path, aspp_drop, depth_aspp_drop):
+    with O.training_mode(rng, drop_path, aspp_drop, depth_aspp_drop), (gates or contextlib.nullcontext()):
         vox, depth = O.view_transformer(params, "img_view_transformer.", img_feats, cams, cfg["D"], cfg["C"])
         enc = O.occupancy_encoder(params, "img_bev_encoder_backbone.", vox, groups=g,
                                   block_numbers=cfg.get("block_numbers", (2, 2, 2, 2)))
@@ -407,6 +411,8 @@ def train_step(sd, img_feats, cams, gt_depths, gt_occ, points, cfg, rng=None, dr
     else:
         losses.update(head_loss(cls_list, mask_list, nusc_loss_single, list(gl), list(gm), points, cfg=cfg["head"],
                                 rng=rng))
+    if forward_only:
+        return losses, None
     names = [k for k, v in params.items() if torch.is_tensor(v) and v.requires_grad]
     grads = torch.autograd.grad(sum(losses.values()), [params[k] for k in names], allow_unused=True)
     return losses, dict(zip(names, grads))
