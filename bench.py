@@ -317,6 +317,52 @@ WORKLOAD_DESC = {
 }
 
 
+def launch_ranks(n, argv=None):
+    """``python bench.py --gpus N`` without a launcher around it: re-run this very command line as N ranks of ONE node
+    under ``torch.distributed.run`` (one process per GPU, LOCAL_RANK -> device, rendezvous on 127.0.0.1; the
+    reference's counterpart is tools/dist_train.sh:9-19) and hand its exit code back.  Rank 0 of that job prints the one
+    JSON line with ``n_gpus`` = N."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + \
+          list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run_rank(args, rank, world):
+    """``--dry-run``: the launcher / rendezvous / timing / reporting skeleton of the bench on CPU ranks over gloo with a
+    mock step (tests/test_boundary.py runs it at N = 2: no GPU, no library) -- everything around the step is the code
+    the real run goes through: barrier, K timed steps, barrier, max over ranks, rank 0 prints the one line."""
+    from occformer_amd import dist_utils
+    dist = dist_utils.init("gloo") if world > 1 else None
+    w = torch.eye(64)
+    step = lambda: (w @ w).sum().item()
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if dist is not None:
+        dist.barrier()
+    dt = dist_utils.max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (mock step on CPU ranks, gloo)", "value": world * args.steps / dt,
+                          "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+                          "dry_run": True}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -344,11 +390,22 @@ def main():
                          "statistics, the gradient all-reduce stays the only collective (north_star)")
     ap.add_argument("--shape-report", default=None, help="write a per-shape GEMM/conv timing table here")
     ap.add_argument("--check", action="store_true", help="also report max abs err vs the oracle output")
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: become one (N ranks of this node, one per GPU)
+        if not args.dry_run and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {torch.cuda.device_count()} GPU(s)")
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}",
+              file=sys.stderr)
+    if args.dry_run:
+        return dry_run_rank(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
     torch.cuda.set_device(local_rank)
@@ -538,7 +595,11 @@ def main():
             cpu_leg = None
             try:
                 cpu_leg = cpu_baseline_train(model, cfg, meta, img_inputs, targets)
-            except MemoryError as e:       # host RAM: fall back to the forward leg
+            except (MemoryError, RuntimeError) as e:       # host RAM: fall back to the forward leg
+                # (torch reports a failed host allocation as a RuntimeError from DefaultCPUAllocator; anything else
+                # is a real error and propagates)
+                if isinstance(e, RuntimeError) and not any(m in str(e) for m in ("not enough memory", "DefaultCPUAllocator")):
+                    raise
                 base, _ = cpu_baseline(model, meta, img_inputs, points)
                 base["sample"] = "FORWARD ONLY (the CPU training step did not fit: %s); " % type(e).__name__ + base["sample"]
                 out["cpu_baseline"] = base

@@ -383,8 +383,12 @@ class TokenBevSlot(torch.autograd.Function):
             shape = list(dslot.shape)
             shape[3] = Z + 1
             dtok = dslot.new_zeros(shape)
-        elif not dtok.is_contiguous():
-            dtok = dtok.contiguous()
+        elif not (getattr(dtok, "_occf_owned", False) and dtok.is_contiguous()):
+            # never write to an incoming gradient that may be shared (another consumer of ``tok``, a tensor hook, a
+            # retained graph: the autograd contract).  Only the buffer DualpathCombine.backward has just allocated and
+            # tagged -- handed over by the engine untouched, one consumer -- is completed in place (one slot of Z + 1
+            # instead of a pass over the whole token buffer)
+            dtok = dtok.clone(memory_format=torch.contiguous_format)
         dtok[:, :, :, Z:Z + 1] += dslot
         return dtok, None
 
@@ -421,6 +425,7 @@ class DualpathCombine(torch.autograd.Function):
         dtok, dbev, dw, db = get_ops().dualpath_combine_backward(tok, bev, weight.detach().reshape(-1),
                                                                  None if bias is None else bias.detach(),
                                                                  dout.contiguous())
+        dtok._occf_owned = True                  # fresh, exclusively this graph's (see TokenBevSlot.backward)
         return dtok, dbev, dw.view(weight.shape), (db if bias is not None else None), dout
 
 

@@ -360,18 +360,29 @@ class OccupancyFormer(nn.Module):
             done.record(side)
         for s in scans:
             s[0].record_stream(main)            # allocated on the side stream, consumed on the main stream
-        q = self.__dict__.setdefault("_gt_prefetched", {})
-        q[(gt_occ.data_ptr(), gt_occ._version, tuple(gt_occ.shape))] = ([s[0] for s in scans], host, done)
-        while len(q) > 4:
-            q.pop(next(iter(q)))
+        gt_occ.record_stream(side)              # read on the side stream: its block must not be recycled under the scan
+        # an entry belongs to the TENSOR OBJECT it was computed from (weak reference), never to its address: the caching
+        # allocator hands the next same-shaped ground truth the address (and version 0) of a freed one, and an entry
+        # whose sample never reached forward_train would then label another sample
+        import weakref
+        q = self.__dict__.setdefault("_gt_prefetched", [])
+        q[:] = [e for e in q if e[0]() is not None and e[0]() is not gt_occ]
+        q.append((weakref.ref(gt_occ), gt_occ._version, [s[0] for s in scans], host, done))
+        del q[:-4]
 
     def _take_gt_scans(self, gt_occ):
         q = self.__dict__.get("_gt_prefetched")
-        hit = None if not q or not torch.is_tensor(gt_occ) else q.pop((gt_occ.data_ptr(), gt_occ._version,
-                                                                     tuple(gt_occ.shape)), None)
-        if hit is None:
+        if not q or not torch.is_tensor(gt_occ):
             return None
-        labels, host, done = hit
+        hit = None
+        for i, e in enumerate(q):
+            if e[0]() is gt_occ:
+                hit = q.pop(i)
+                break
+        q[:] = [e for e in q if e[0]() is not None]          # samples that were dropped before their step
+        if hit is None or hit[1] != gt_occ._version:         # (written to since the scan: scan again)
+            return None
+        _, _, labels, host, done = hit
         done.synchronize()                                   # long complete when the scan ran a step ahead
         torch.cuda.current_stream(gt_occ.device).wait_event(done)
         return [(labels[i], int(host[i])) for i in range(len(labels))]

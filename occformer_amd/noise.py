@@ -57,3 +57,25 @@ def relu_gate(h):
     if _gates is not None:
         _gates.append(h.detach() > 0)
     return h
+
+
+class RecordedRNG:
+    """wraps a noise source and tapes every draw as (kind, CPU tensor) in call order -- the tape a comparison feeds to
+    the CPU oracle so that it repeats THIS step's noise (the converse of replaying the oracle's tape on the device; one
+    oracle pass instead of two).  A host copy per draw: comparison runs only."""
+
+    def __init__(self, inner):
+        self.inner, self.tape = inner, []
+
+    def _keep(self, kind, t):
+        self.tape.append((kind, t.detach().cpu()))
+        return t
+
+    def rand(self, *shape):
+        return self._keep("rand", self.inner.rand(*shape))
+
+    def randperm(self, n):
+        return self._keep("randperm", self.inner.randperm(n))
+
+    def exponential(self, shape, dtype=torch.float32):
+        return self._keep("exponential", self.inner.exponential(shape, dtype))

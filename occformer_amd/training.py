@@ -48,6 +48,9 @@ def dev_const(values, device, dtype):
     """a small constant (point-cloud range, grid dimensions, class weights) as a device tensor, uploaded ONCE per
     (values, device, dtype): ``torch.tensor(list, device=...)`` in the loss loop is a pageable host-to-device copy per
     call -- the host blocks on each (90 per training step, r03d)"""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:      # 'cuda' and 'cuda:N' are one device: key on the resolved index
+        device = torch.device("cuda", torch.cuda.current_device())
     key = (tuple(float(v) for v in values), str(device), dtype)
     t = _DEV_CONST.get(key)
     if t is None:

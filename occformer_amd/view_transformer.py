@@ -443,7 +443,9 @@ class ViewTransformerLiftSplatShootVoxel(nn.Module):
         # transformer + encoder; measured r03d: 46 of the 145 ms the host needs to issue a training step) and the GPU
         # idles while the host catches up.  Same value without a data-dependent shape: the rows outside the mask
         # contribute exactly 0 (BCE is finite: torch clamps the logs at -100).
-        fg = (labels.max(1).values > 0.0).to(preds.dtype)
+        fg = labels.max(1).values > 0.0
         bce = F.binary_cross_entropy(preds, labels, reduction="none")
-        loss = (bce.sum(1) * fg).sum() / fg.sum().clamp_min(1.0)
+        # (a select, not a product: a NaN / Inf prediction in a row the reference never looks at must stay out of the
+        # loss and out of every gradient -- 0 * NaN = NaN)
+        loss = torch.where(fg, bce.sum(1), bce.new_zeros(())).sum() / fg.sum().to(preds.dtype).clamp_min(1.0)
         return self.loss_depth_weight * loss

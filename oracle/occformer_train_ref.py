@@ -377,7 +377,7 @@ def depth_bce_loss(gt_depths, depth_preds, downsample, dbound, D, loss_depth_wei
 
 # ----------------------------------------------------------------------------------------- one training step
 def train_step(sd, img_feats, cams, gt_depths, gt_occ, points, cfg, rng=None, drop_path=0.2, aspp_drop=0.1,
-               depth_aspp_drop=0.5, gates=None, forward_only=False):
+               depth_aspp_drop=0.5, gates=None):
     """occupancyformer.py:132-199 (forward_train) + loss.backward() on the restated reference path in TRAIN mode
     (oracle.occformer_ref.training_mode): depth BCE + the ten Hungarian prediction-set losses of the nuScenes head,
     then torch.autograd of their sum w.r.t. every trainable parameter.
@@ -387,8 +387,7 @@ def train_step(sd, img_feats, cams, gt_depths, gt_occ, points, cfg, rng=None, dr
     (mask2former_occ.py:343-444: class-guided sampling, class-weighted mask losses, ``align_corners``; no LiDAR
     points).  -> (losses dict, {name: grad})
     ``gates``: an ``occformer_ref.forced_gates`` context -- the head's ReLUs then use the recorded gates of the
-    implementation under test (see there).  ``forward_only``: losses only (call it under ``torch.no_grad()`` to tape
-    the noise draws at a third of the cost); the gradients are then None."""
+    implementation under test (see there)."""
     import contextlib
     from . import occformer_ref as O
     rng = rng or GlobalTorchRNG()
@@ -411,8 +410,6 @@ def train_step(sd, img_feats, cams, gt_depths, gt_occ, points, cfg, rng=None, dr
     else:
         losses.update(head_loss(cls_list, mask_list, nusc_loss_single, list(gl), list(gm), points, cfg=cfg["head"],
                                 rng=rng))
-    if forward_only:
-        return losses, None
     names = [k for k, v in params.items() if torch.is_tensor(v) and v.requires_grad]
     grads = torch.autograd.grad(sum(losses.values()), [params[k] for k in names], allow_unused=True)
     return losses, dict(zip(names, grads))

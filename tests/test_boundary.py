@@ -108,6 +108,30 @@ def test_two_rank_gloo(tmp_path):
     assert outs[0][0].strip().splitlines()[-1] == "OK 7 2.0 2"
 
 
+def test_bench_launches_its_own_ranks():
+    """``python bench.py --gpus 2`` with no launcher around it must start TWO ranks itself and rank 0 must print ONE
+    JSON line with ``n_gpus: 2`` (``--gpus`` was parsed and ignored, the driver's command measured one
+    GPU).  ``--dry-run`` swaps the step for a mock on CPU ranks over gloo; launcher, rendezvous, barriers, max over
+    ranks and the rank-0 report are the code of the real run.  Reference: tools/dist_train.sh:9-19."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["value"] > 0
+    # under an external launcher (the driver's torch.distributed.run command line) bench.py must NOT spawn again
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2, r.stdout
+
+
 def test_detector_forward_train_and_test_wiring(be, monkeypatch):
     """OccupancyFormer built from the (tiny) reference-style config: forward(return_loss=True) returns the
     reference's loss dictionary (depth + 3 x (n_layers + 1) head losses + lidarseg metric), forward(return_loss=
@@ -343,11 +367,6 @@ def test_kitti_detector_with_image_branch_wiring(be, monkeypatch):
     from occformer_amd.registry import build_model
     from tests import paramgen, tinycfg
     from tests.golden.make_golden_train import kitti_head_cfg
-    if be.kind == "hip":
-        # the image branch is plain PyTorch: on a fresh GPU box MIOpen would first compile ~80 distinct
-        # (depthwise / same-padded) convolution configurations; the hot-path pieces of this wiring have their own
-        # GPU tests (test_view_transformer_kitti, test_head_kitti, the training rows)
-        pytest.skip("image-branch wiring is exercised on the CPU run")
     monkeypatch.setattr(ops_mod, "_ops", be.ops)
     cfg, meta = tinycfg.tiny_nusc(ncams=1)
     cfg = dict(cfg)

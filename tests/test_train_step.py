@@ -67,20 +67,15 @@ def _oracle_step(cfg, meta, tc, sd, cams, x, gt_occ, pts, gd, rng, **kw):
 
 
 def test_training_step_gradients_vs_oracle(bound):
-    """(the flow of tests/test_workloads_gpu.py: the oracle's forward tapes the noise, the product runs on the replayed
-    tape and its decoder-head ReLU gates are recorded, the oracle differentiates with those gates)"""
+    """(the flow of tests/test_workloads_gpu.py: the product runs on its own taped noise, its decoder-head ReLU gates
+    are recorded; the oracle replays the noise and differentiates with those gates)"""
+    from occformer_amd.training import DeviceRNG
     be = bound
     cfg, meta, tc, model, sd, cams, x, gt_occ, pts, gd = _setup()
-    rec = T.RecordingRNG()
-    torch.manual_seed(3)
-    with torch.no_grad():
-        tape_losses, none = _oracle_step(cfg, meta, tc, sd, cams, x, gt_occ, pts, gd, rec, forward_only=True)
-    assert none is None
-
     d = be.device
     model = model.to(d).train()
-    replay = ReplayRNG(rec.tape, d)
-    noise.set_rng(replay)
+    rec = noise.RecordedRNG(DeviceRNG(d, 3))
+    noise.set_rng(rec)
     gates = noise.record_gates(True)
     metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])] * x.shape[0]
     img_inputs = [t.to(d) for t in (x, *cams)] + [gd.to(d)]
@@ -89,18 +84,16 @@ def test_training_step_gradients_vs_oracle(bound):
                                      points_occ=[p.to(d) for p in pts])
     finally:
         noise.record_gates(False)
-    assert replay.i == len(rec.tape), "the product consumed a different number of noise draws than the oracle"
     # 10 prediction sets x 2 mask-embedding ReLUs + one FFN ReLU per decoder layer
     assert len(gates) == 2 * (meta["dec_layers"] + 1) + meta["dec_layers"]
     forced = O.forced_gates(gates)
     cpu_replay = ReplayRNG(rec.tape, torch.device("cpu"))
     ref_losses, ref_grads = _oracle_step(cfg, meta, tc, sd, cams, x, gt_occ, pts, gd, cpu_replay, gates=forced)
-    assert cpu_replay.i == len(rec.tape) and forced.i == len(gates)
+    assert cpu_replay.i == len(rec.tape), "the oracle consumed a different number of noise draws than the product"
+    assert forced.i == len(gates)
     print(f"head ReLU gates: {forced.flipped} of {forced.units} gated differently, largest |z| among them "
           f"{forced.max_abs_z:.1e} ({forced.max_rel_z:.1e} of the tensor's RMS)")
     assert forced.max_rel_z <= 1e-3
-    for k, v in tape_losses.items():          # the forced gates move no loss (a flipped unit's output is ~0 either way)
-        assert abs(float(ref_losses[k]) - float(v)) <= 1e-5 * max(1.0, abs(float(v))), k
     for k, v in ref_losses.items():
         v = float(v.detach())
         assert abs(float(losses[k].detach()) - v) <= TOL * max(1.0, abs(v)), (k, float(losses[k].detach()), v)

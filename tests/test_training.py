@@ -34,6 +34,12 @@ class ReplayRNG:
     def exponential(self, shape, dtype=torch.float32):
         return self._next("exponential", int(np.prod(shape))).reshape(tuple(shape)).float()
 
+    def multinomial(self, weights, k):
+        """the oracle's formulation (oracle.occformer_train_ref.GlobalTorchRNG.multinomial) on the replayed draw -- used
+        when the ORACLE replays a tape the product recorded"""
+        q = self.exponential(weights.shape, weights.dtype)
+        return torch.topk(weights / q, k, dim=-1)[1]
+
 
 @pytest.fixture
 def bound(be, monkeypatch):

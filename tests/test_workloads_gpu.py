@@ -149,44 +149,41 @@ def test_workload_training_step_vs_oracle(hip, name):
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     named = dict(model.named_parameters())
 
-    def product_step(tape):
-        """forward_train + backward of the product on the replayed noise; -> (losses, head ReLU gates)"""
+    def product_step(seed):
+        """forward_train + backward of the product on its own (seeded, taped) noise; -> (losses, tape, head ReLU gates)"""
+        from occformer_amd.training import DeviceRNG
         opt.zero_grad(set_to_none=True)
-        replay = ReplayRNG(tape, d)
-        noise.set_rng(replay)
+        rec = noise.RecordedRNG(DeviceRNG(d, seed))
+        noise.set_rng(rec)
         gates = noise.record_gates(True)
         try:
             losses = model(return_loss=True, **kw)
-            assert replay.i == len(tape), "the product consumed a different number of noise draws than the oracle"
             sum(v for k, v in losses.items() if "loss" in k).backward()
         finally:
             noise.set_rng(None)
             noise.record_gates(False)
         torch.cuda.synchronize()
-        return losses, gates
+        return losses, rec.tape, gates
 
     def compare(tape_seed):
-        """ONE draw, no retry.  (1) the oracle's forward (no autograd) tapes the noise; (2) the product runs forward +
-        backward on the replayed tape, its decoder-head ReLU gates are recorded; (3) the oracle runs forward + backward on
-        the same tape WITH those gates (oracle.occformer_ref.forced_gates): both sides then differentiate the same
-        piecewise-linear function, so a head unit whose pre-activation is rounding-close to zero can no longer show up
-        as a 1e-3 shift of every upstream gradient.  The forcing is only legitimate where the two pre-activations
-        straddle zero within rounding: the flipped units' |z| is asserted below."""
+        """ONE draw, no retry.  (1) the product runs forward + backward; its noise draws and its decoder-head ReLU gates
+        are taped; (2) the oracle runs forward + backward on the host cores on the SAME draws (replayed in call order;
+        a different count or size of any draw fails) and WITH those gates (oracle.occformer_ref.forced_gates): both
+        sides then differentiate the same piecewise-linear function, so a head unit whose pre-activation is
+        rounding-close to zero can no longer show up as a 1e-3 shift of every upstream gradient.  The forcing is only
+        legitimate where the two pre-activations straddle zero within rounding: the flipped units' |z| is asserted."""
         from oracle import occformer_ref as O
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         oargs = (sd, img_inputs[0].cpu(), tuple(t.cpu() for t in img_inputs[1:7]), gt_depths.cpu(), gt_occ.cpu(),
                  None if gt_points is None else [p.cpu() for p in gt_points], ocfg)
-        rec = T.RecordingRNG()
-        torch.manual_seed(tape_seed)
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            T.train_step(*oargs, rng=rec, forward_only=True)
-        losses, gates = product_step(rec.tape)
+        losses, tape, gates = product_step(tape_seed)
         forced = O.forced_gates(gates)
-        cpu_replay = ReplayRNG(rec.tape, torch.device("cpu"))
+        cpu_replay = ReplayRNG(tape, torch.device("cpu"))
+        t0 = time.perf_counter()
         ref_losses, ref_grads = T.train_step(*oargs, rng=cpu_replay, gates=forced)
-        assert cpu_replay.i == len(rec.tape) and forced.i == len(gates), "gate / noise tapes not consumed in full"
         t_cpu = time.perf_counter() - t0
+        assert cpu_replay.i == len(tape), "the oracle consumed a different number of noise draws than the product"
+        assert forced.i == len(gates), "the oracle evaluated a different number of head ReLUs than the product"
         pairs = {k: (float(losses[k].detach()), float(v.detach())) for k, v in ref_losses.items()}
         worst_loss = max(abs(a - b) / max(1.0, abs(b)) for a, b in pairs.values())
         per, num, den = [], 0.0, 0.0
