@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(256) SF_WAVES2 swin_attn_fused_kernel(SwinAttn
   // fetched as ONE batch, one matrix ahead of the MFMAs that use them (one wave per SIMD: nothing else would
   // hide 24 dependent L2 round trips).  Matrix 3 = proj, consumed after the attention.
   bf16x8 qfh[2][2], qfl[2][2], kfh[2][2], kfl[2][2], vfh[2][2], vfl[2][2];
-  bf16x8 wfh[1][8], wfl[1][8];
+  bf16x8 wfh[2][8], wfl[2][8];
   auto fetch_w = [&](int mat, int buf) __attribute__((always_inline)) {
     if (p.packed) {
       // fragment order: the 64 lanes of a (32-row group, k-step) read 1 KB contiguous -- 8 cache lines per load
@@ -234,9 +234,14 @@ __global__ void __launch_bounds__(256) SF_WAVES2 swin_attn_fused_kernel(SwinAttn
       wfl[buf][ks] = *(const bf16x8*)(bl + lk * 8 + ks * 16);
     }
   };
+  // (the fences pin the fetch order: left alone, the compiler hoists all three matrices' loads to the top -- 192
+  // registers of fragments in flight, 65 spilled: the 0.9 GB of scratch writes per launch PMC showed as "output")
+  fetch_w(0, 0);
 #pragma unroll
   for (int mat = 0; mat < 3; ++mat) {
-    fetch_w(mat, 0);
+    OCCF_SCHED_FENCE();
+    if (mat < 2) fetch_w(mat + 1, (mat + 1) & 1);      // next matrix' fragments travel under this matrix' MFMAs
+    OCCF_SCHED_FENCE();
     f32x16 acc[2];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt)
@@ -244,7 +249,7 @@ __global__ void __launch_bounds__(256) SF_WAVES2 swin_attn_fused_kernel(SwinAttn
       for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const bf16x8 wh = wfh[0][ks], wl = wfl[0][ks];
+      const bf16x8 wh = wfh[mat & 1][ks], wl = wfl[mat & 1][ks];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int off = ks * 2048 + (tt * 32 + li) * 32 + lk * 16;
@@ -287,6 +292,9 @@ __global__ void __launch_bounds__(256) SF_WAVES2 swin_attn_fused_kernel(SwinAttn
       }
   }
   __syncthreads();                                   // every wave is done reading the Xn image
+  OCCF_SCHED_FENCE();
+  fetch_w(3, 1);                                     // proj fragments: in flight during the attention
+  OCCF_SCHED_FENCE();
 
   // ---- attention of this head; the result goes to the (reused) image as the B operand of proj
 #pragma unroll
@@ -354,10 +362,9 @@ __global__ void __launch_bounds__(256) SF_WAVES2 swin_attn_fused_kernel(SwinAttn
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ao[tt][r] = 0.f;
-  fetch_w(3, 0);
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
-    const bf16x8 wh = wfh[0][ks], wl = wfl[0][ks];      // proj fragments
+    const bf16x8 wh = wfh[1][ks], wl = wfl[1][ks];      // proj fragments
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       const int off = ks * 2048 + (tt * 32 + li) * 32 + lk * 16;
