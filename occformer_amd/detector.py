@@ -62,46 +62,42 @@ class ModulatedDeformConv2dPack(nn.Module):
                          w_split=fused.split_weight(self.weight, tap))
         return out.view(B, Ho, Wo, -1).permute(0, 3, 1, 2)
 
+    # tests only: a callable (module, x, offset, mask) -> out that stands in for CPU tensors (oracle/dcn_ref.py: the
+    # grid_sample statement of the op, installed by tests/conftest.py).  The product itself has no CPU path.
+    cpu_reference = None
+
     def forward(self, x):
         B, C, H, W = x.shape
         k, dg = self.k, self.dg
         o1, o2, logit = torch.chunk(self.conv_offset(x), 3, dim=1)
         offset = torch.cat((o1, o2), 1)                                  # [B, dg * 2 * k*k, Ho, Wo]
         mask = torch.sigmoid(logit)                                       # [B, dg * k*k, Ho, Wo]
-        hip_ok = x.dtype == torch.float32 and (C // dg) % 4 == 0 and self.dilation == 1
-        if hip_ok and (x.is_cuda or self.force_hip) and torch.is_grad_enabled() and \
-                (x.requires_grad or self.weight.requires_grad):
+        if not (x.is_cuda or self.force_hip):
+            if ModulatedDeformConv2dPack.cpu_reference is None:
+                raise RuntimeError("ModulatedDeformConv2dPack: the deformable sampling runs on the library's kernels "
+                                   "(csrc/dcn.hip); there is no CPU path")
+            return ModulatedDeformConv2dPack.cpu_reference(self, x, offset, mask)
+        if (C // dg) % 4 != 0 or self.dilation != 1:
+            raise NotImplementedError(f"ModulatedDeformConv2dPack: {C // dg} channels per deform group / dilation "
+                                      f"{self.dilation} (the kernels take multiples of 4 channels, dilation 1)")
+        # a reduced-precision image branch (bench.py --image-dtype bf16) crosses this layer as an fp32 ISLAND: the
+        # sampling positions are fp32 quantities (a bf16 offset has 3 fractional bits at 8 pixels), the gather /
+        # modulation / contraction run on the fp32 kernels, the result returns in the caller's dtype -- two casts of
+        # [B, C, H, W] per layer instead of a second implementation
+        dt = x.dtype
+        if dt != torch.float32:
+            x, offset, mask = x.float(), offset.float(), mask.float()
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
             # training: im2col / col2im(+coord, +mask) kernels and the split-bf16 contractions as one autograd node
             # (occf_modulated_deform_col2im); conv_offset and the sigmoid stay on ATen autograd
             from . import autograd as A
             out = A.DeformConv.apply(x.permute(0, 2, 3, 1), offset, self.weight, k, self.padding, 1, dg, mask,
                                      self.stride)
             out = out.view(B, offset.shape[-2], offset.shape[-1], -1).permute(0, 3, 1, 2)
-            return out if self.bias is None else out + self.bias.view(1, -1, 1, 1)
-        if hip_ok and x.is_cuda and not (torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad)):
-            return self._forward_hip(x, offset, mask)
-        Ho, Wo = offset.shape[-2:]
-        ys = (torch.arange(Ho, device=x.device, dtype=x.dtype) * self.stride - self.padding).view(1, Ho, 1)
-        xs = (torch.arange(Wo, device=x.device, dtype=x.dtype) * self.stride - self.padding).view(1, 1, Wo)
-        offset = offset.view(B, dg, k * k, 2, Ho, Wo)
-        mask = mask.view(B, dg, k * k, Ho, Wo)
-        cpg = C // dg
-        cols = []
-        for t in range(k * k):
-            ky, kx = divmod(t, k)
-            per_group = []
-            for g in range(dg):
-                py = ys + ky * self.dilation + offset[:, g, t, 0]
-                px = xs + kx * self.dilation + offset[:, g, t, 1]
-                # pixel coordinates -> grid_sample's align_corners=True convention (zeros outside)
-                grid = torch.stack((2 * px / max(W - 1, 1) - 1, 2 * py / max(H - 1, 1) - 1), -1)
-                smp = F.grid_sample(x[:, g * cpg:(g + 1) * cpg], grid, mode="bilinear", padding_mode="zeros",
-                                    align_corners=True)
-                per_group.append(smp * mask[:, g, t].unsqueeze(1))
-            cols.append(torch.cat(per_group, 1))
-        col = torch.stack(cols, 2)                                        # [B, C, k*k, Ho, Wo]
-        out = torch.einsum("bcthw,oct->bohw", col, self.weight.flatten(2))
-        return out if self.bias is None else out + self.bias.view(1, -1, 1, 1)
+            out = out if self.bias is None else out + self.bias.view(1, -1, 1, 1)
+        else:
+            out = self._forward_hip(x, offset, mask)
+        return out if dt == torch.float32 else out.to(dt)
 
 
 class _Bottleneck(nn.Module):

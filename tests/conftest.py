@@ -64,6 +64,18 @@ def pytest_cmdline_main(config):
     return None
 
 
+@pytest.fixture(autouse=True)
+def _dcnv2_cpu_statement():
+    """CPU tensors through ``ModulatedDeformConv2dPack`` (the R101-DCN image backbone built on the host in the wiring
+    and GPU-vs-CPU tests) take the oracle's grid_sample statement; the product raises without it"""
+    from occformer_amd.detector import ModulatedDeformConv2dPack
+    from oracle import dcn_ref
+    prev = ModulatedDeformConv2dPack.cpu_reference
+    ModulatedDeformConv2dPack.cpu_reference = staticmethod(dcn_ref.module_reference)
+    yield
+    ModulatedDeformConv2dPack.cpu_reference = prev
+
+
 def golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     return {k: torch.from_numpy(z[k]) if z[k].ndim else z[k].item() for k in z.files}

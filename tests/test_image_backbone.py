@@ -72,6 +72,20 @@ def _dcn(cin=6, cout=5, stride=1, dg=1):
 
 
 @torch.no_grad()
+def test_dcnv2_product_has_no_cpu_path():
+    """without the oracle's stand-in (tests/conftest.py installs it) a CPU tensor raises: the grid_sample formulation
+    that used to sit in the module as a silent second backend lives in oracle/dcn_ref.py"""
+    from occformer_amd.detector import ModulatedDeformConv2dPack
+    m = _dcn()
+    prev, ModulatedDeformConv2dPack.cpu_reference = ModulatedDeformConv2dPack.cpu_reference, None
+    try:
+        with pytest.raises(RuntimeError, match="no CPU path"):
+            m(paramgen.tensor("dcn.x", (1, 6, 5, 5), 2))
+    finally:
+        ModulatedDeformConv2dPack.cpu_reference = prev
+
+
+@torch.no_grad()
 def test_dcnv2_zero_init_is_half_a_convolution():
     """freshly built (conv_offset = 0): no displacement, modulation sigmoid(0) = 0.5"""
     for stride in (1, 2):
@@ -192,8 +206,20 @@ def test_dcnv2_module_on_gpu_uses_the_kernel(hip):
         m.conv_offset.bias.copy_(paramgen.tensor("dcn3.ob", m.conv_offset.bias.shape, 3, 0.8))
         x = paramgen.tensor("dcn3.x", (2, 256, 14, 25), 4)
         ref = m(x)
-        out = m.to(hip.device)(x.to(hip.device)).cpu()
+        calls = []
+        orig = hip.ops.deform_im2col
+        hip.ops.deform_im2col = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            out = m.to(hip.device)(x.to(hip.device)).cpu()
+            # the bf16 image branch (bench.py --image-dtype bf16: autocast) crosses the layer as an fp32 island on the
+            # SAME kernels (it used to fall to a grid_sample composition)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out16 = m(x.to(hip.device).bfloat16())
+        finally:
+            hip.ops.deform_im2col = orig
+    assert len(calls) == 2 and out16.dtype == torch.bfloat16
     assert float((out - ref).abs().max() / ref.abs().max()) < 1e-4
+    assert float((out16.float().cpu() - ref).abs().max() / ref.abs().max()) < 3e-2
 
 
 @pytest.mark.gpu
