@@ -123,9 +123,15 @@ def test_workload_training_step_vs_oracle(hip, name):
     from oracle import occformer_train_ref as T
     from tests.test_training import ReplayRNG
 
-    if name == "kitti_effb7_256lit" and os.environ.get("OCCF_TEST_HUGE", "0") != "1":
-        pytest.skip("encoder grid 256x256x32: ~82 GiB on the GPU and a multiple of that for host autograd; "
-                    "set OCCF_TEST_HUGE=1 on a host with >= 512 GiB")
+    if name == "kitti_effb7_256lit":
+        # encoder grid 256x256x32: ~82 GiB on the GPU, and host autograd of the oracle keeps a few hundred GiB of
+        # activations -- runs wherever the host has the memory (the MI355X boxes of this pool: 3 TiB), OCCF_TEST_HUGE=0/1
+        # overrides the detection
+        host_gib = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2 ** 30
+        want = os.environ.get("OCCF_TEST_HUGE")
+        if want == "0" or (want != "1" and host_gib < 600):
+            pytest.skip(f"encoder grid 256x256x32: the oracle's autograd needs a host with >= 600 GiB (this one: "
+                        f"{host_gib:.0f} GiB); OCCF_TEST_HUGE=1 forces it")
     torch.manual_seed(0)
     cfg, meta = configs.workload(name)
     if meta.get("kitti"):
