@@ -109,7 +109,7 @@ def pmc_traffic(kernel_substr, grid_size, pick="calls"):
     gfx950 per MI355X_MICROARCH.md).  None when no summary is present."""
     import glob
     # (by name, newest run last: a fresh checkout gives every file the same mtime)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "**", "*_pmc_traffic.json"), recursive=True), key=os.path.basename)
     if not files:
         return None, None
     # a counter summary is only valid for the kernels it was collected on: scripts/summarize_pmc.py stamps the
