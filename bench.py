@@ -159,7 +159,8 @@ def roofline(timed_census, kernels, prec, steps):
         Cout = shp[1][0]
         halo = shp[1][1] == 27 * Cin and Cin % 32 == 0 and prec != "f32"
         frag = "true" if get_halo_frag() else "false"
-        kname = (f"conv3x3x3_halo_kernel<{2 if Cout % 128 == 0 else 3 if Cout % 192 == 0 else 1}, {terms}, {frag}>"
+        sch = (1 if os.environ.get("OCCF_HALO_SCHED", "1") != "0" else 0) if get_halo_frag() else 0
+        kname = (f"conv3x3x3_halo_kernel<{2 if Cout % 128 == 0 else 3 if Cout % 192 == 0 else 1}, {terms}, {frag}, {sch}>"
                  if halo else "gemm_bf16_kernel<CONV>")
         nbytes = 4 * (B * X * Y * Z * (Cin + Cout)) + 4 * Cout * shp[1][1]
         if halo:
@@ -223,9 +224,12 @@ def cpu_baseline(model, meta, img_inputs, points):
                        f"torch CPU, {cores} threads): {dt:.1f} s"), res
 
 
-def cpu_baseline_train(model, cfg, meta, img_inputs, targets):
+def cpu_baseline_train(model, cfg, meta, img_inputs, targets, tape, gates):
     """The oracle's training step (train-mode forward + torch.autograd backward of the summed losses,
-    oracle/occformer_train_ref.train_step) on the host cores: one sample of the same workload."""
+    oracle/occformer_train_ref.train_step) on the host cores: one sample of the same workload, on the noise draws the
+    GPU step just consumed (``tape``, replayed in call order) and with the decoder head's ReLU gates the GPU step used
+    (``gates``: oracle.occformer_ref.forced_gates -- both sides differentiate the same piecewise-linear function)."""
+    from oracle import occformer_ref as O
     from oracle import occformer_train_ref as T
     from occformer_amd import configs
     gt_occ, points, gt_depths = targets
@@ -233,17 +237,20 @@ def cpu_baseline_train(model, cfg, meta, img_inputs, targets):
     ocfg = configs.oracle_train_cfg(cfg, meta, class_weight=model.pts_bbox_head.class_weight)
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    rec = T.RecordingRNG()          # every noise draw of the step is taped so that the GPU can replay it (`check`)
+    replay = _Replay(tape, torch.device("cpu"))
+    forced = O.forced_gates(gates)
     t0 = time.perf_counter()
     losses, grads = T.train_step(sd, img_inputs[0].cpu(), tuple(t.cpu() for t in img_inputs[1:7]), gt_depths.cpu(),
-                                 gt_occ.cpu(), None if points is None else [p.cpu() for p in points], ocfg, rng=rec)
+                                 gt_occ.cpu(), None if points is None else [p.cpu() for p in points], ocfg, rng=replay,
+                                 gates=forced)
     dt = time.perf_counter() - t0
+    if replay.i != len(tape) or forced.i != len(gates):
+        raise RuntimeError("the oracle consumed a different number of noise draws / head ReLUs than the GPU step")
     return dict(value=1.0 / dt, unit="samples/s", cores=cores, kind="port",
                 sample="1 training step (fwd + bwd) of the same workload on the CPU oracle, on the weights the timed "
                        "GPU steps left behind "
                        f"(oracle/occformer_train_ref.train_step, fp32, torch CPU autograd, {cores} threads): {dt:.1f} s"), \
-        {k: float(v) for k, v in losses.items()}, grads, rec.tape
+        {k: float(v) for k, v in losses.items()}, grads, forced
 
 
 class _Replay:
@@ -270,13 +277,20 @@ class _Replay:
         import math
         return self._next("exponential", math.prod(shape)).reshape(tuple(shape)).float()
 
+    def multinomial(self, weights, k):
+        """the oracle's statement of torch.multinomial(.., replacement=False) on the replayed exponential draw"""
+        q = self.exponential(weights.shape, weights.dtype)
+        return torch.topk(weights / q, k, dim=-1)[1]
 
-def train_check(model, net_kwargs, cpu_losses, cpu_grads, tape, device):
-    """ONE more forward_train + backward on the GPU at the SAME (post-training) weights and on the oracle's taped
-    noise: the record's `losses` (GPU) and `cpu_losses` are then the same quantity, and `check` says how far apart."""
+
+def train_check_gpu_step(model, net_kwargs, device):
+    """ONE more forward_train + backward on the GPU at the (post-training) weights, with its noise draws and its
+    decoder-head ReLU gates taped for the oracle -> (losses, tape, gates); the gradients stay in ``param.grad``"""
     from occformer_amd import noise
-    replay = _Replay(tape, device)
-    noise.set_rng(replay)
+    from occformer_amd.training import DeviceRNG
+    rec = noise.RecordedRNG(DeviceRNG(device, 1234))
+    noise.set_rng(rec)
+    gates = noise.record_gates(True)
     try:
         for p in model.parameters():
             p.grad = None
@@ -285,7 +299,14 @@ def train_check(model, net_kwargs, cpu_losses, cpu_grads, tape, device):
         total.backward()
     finally:
         noise.set_rng(None)
-    gl = {k: float(v.detach()) for k, v in losses.items()}
+        noise.record_gates(False)
+    torch.cuda.synchronize()
+    return {k: float(v.detach()) for k, v in losses.items()}, rec.tape, gates
+
+
+def train_check(model, gl, cpu_losses, cpu_grads, forced, n_draws):
+    """`losses` (GPU) and `cpu_losses` are the same quantity (same weights, inputs, noise); `check` says how far apart
+    they and the gradients are"""
     worst = max(abs(gl[k] - v) / max(1.0, abs(v)) for k, v in cpu_losses.items())
     named = dict(model.named_parameters())
     num = den = 0.0
@@ -300,12 +321,16 @@ def train_check(model, net_kwargs, cpu_losses, cpu_grads, tape, device):
             per.append((d / max(n, 1e-30)) ** 0.5)
     per.sort()
     q = lambda f: per[int(f * (len(per) - 1))] if per else None
-    return gl, dict(max_rel_loss_diff=worst, grad_rel_l2=(num / max(den, 1e-30)) ** 0.5,
-                    per_parameter_rel_l2_quantiles={"50%": q(0.5), "90%": q(0.9), "99%": q(0.99), "100%": q(1.0)},
-                    parameters_compared=len(per), noise_draws_replayed=replay.i,
-                    what="GPU forward_train + backward vs the CPU oracle's train_step: same weights (after the timed "
-                         "optimizer steps), same inputs, the oracle's noise tape replayed; losses relative to "
-                         "max(1, |loss|), gradients as relative L2 of the whole vector / per parameter")
+    return dict(max_rel_loss_diff=worst, grad_rel_l2=(num / max(den, 1e-30)) ** 0.5,
+                per_parameter_rel_l2_quantiles={"50%": q(0.5), "90%": q(0.9), "99%": q(0.99), "100%": q(1.0)},
+                parameters_compared=len(per), noise_draws_replayed=n_draws,
+                head_relu_gates={"units": forced.units, "gated_differently": forced.flipped,
+                                 "largest_abs_preactivation_among_them": forced.max_abs_z},
+                what="GPU forward_train + backward vs the CPU oracle's train_step: same weights (after the timed "
+                     "optimizer steps), same inputs, the GPU step's noise tape replayed by the oracle, the decoder "
+                     "head's ReLU gates taken from the GPU step (units whose pre-activations straddle zero within "
+                     "rounding: counted above); losses relative to max(1, |loss|), gradients as relative L2 of the "
+                     "whole vector / per parameter")
 
 
 WORKLOAD_DESC = {
@@ -593,8 +618,13 @@ def main():
                 del res_cpu
                 model.train()
             cpu_leg = None
+            # `losses` is re-taken on a taped step (its noise is what the oracle replays) so that it is comparable
+            # with `cpu_losses`
+            out["losses_last_timed_step"] = out["losses"]
+            gl, tape, gates = train_check_gpu_step(model, net_kwargs, device)
+            out["losses"] = {k: round(v, 5) for k, v in gl.items()}
             try:
-                cpu_leg = cpu_baseline_train(model, cfg, meta, img_inputs, targets)
+                cpu_leg = cpu_baseline_train(model, cfg, meta, img_inputs, targets, tape, gates)
             except (MemoryError, RuntimeError) as e:       # host RAM: fall back to the forward leg
                 # (torch reports a failed host allocation as a RuntimeError from DefaultCPUAllocator; anything else
                 # is a real error and propagates)
@@ -604,11 +634,8 @@ def main():
                 base["sample"] = "FORWARD ONLY (the CPU training step did not fit: %s); " % type(e).__name__ + base["sample"]
                 out["cpu_baseline"] = base
             if cpu_leg is not None:
-                out["cpu_baseline"], out["cpu_losses"], cpu_grads, tape = cpu_leg
-                # `losses` is re-taken on the oracle's noise so that it is comparable with `cpu_losses`
-                out["losses_last_timed_step"] = out["losses"]
-                gl, out["check"] = train_check(model, net_kwargs, out["cpu_losses"], cpu_grads, tape, device)
-                out["losses"] = {k: round(v, 5) for k, v in gl.items()}
+                out["cpu_baseline"], out["cpu_losses"], cpu_grads, forced = cpu_leg
+                out["check"] = train_check(model, gl, out["cpu_losses"], cpu_grads, forced, len(tape))
         else:
             base, res_cpu = cpu_baseline(model, meta, img_inputs, points)
             out["cpu_baseline"] = base

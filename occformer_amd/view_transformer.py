@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import noise
 from .dist_utils import is_synced
 from .ops import get_ops
 from .registry import NECKS
@@ -189,7 +190,7 @@ class _CamMlp(nn.Module):
         self.fc2 = nn.Linear(hidden, cout)
 
     def forward(self, x):
-        return self.fc2(F.relu(self.fc1(x)))
+        return self.fc2(noise.relu_gate(F.relu(self.fc1(x))))
 
 
 class _SE(nn.Module):
@@ -199,7 +200,7 @@ class _SE(nn.Module):
         self.conv_expand = nn.Conv2d(c, c, 1)
 
     def forward(self, x, x_se):
-        return x * torch.sigmoid(self.conv_expand(F.relu(self.conv_reduce(x_se))))
+        return x * torch.sigmoid(self.conv_expand(noise.relu_gate(F.relu(self.conv_reduce(x_se)))))
 
     def forward_cl(self, x_cl, x_se):
         """x_cl [BN, H, W, 1, C]; x_se [BN, C, 1, 1] (the gate is a per-camera channel vector)"""

@@ -170,7 +170,8 @@ _GATES = None
 
 class forced_gates:
     """Test infrastructure for gradient comparisons.  The ReLUs of the decoder head (decoder-layer FFNs, the
-    mask-embedding MLP: ~1.8 M units, each of which moves EVERY upstream gradient when its gate differs) sit on fp32
+    mask-embedding MLP: ~1.8 M units, each of which moves EVERY upstream gradient when its gate differs) and of
+    DepthNet's camera MLPs / SE layers ([cameras, 512] vectors that scale whole feature maps) sit on fp32
     pre-activations; two correct implementations whose pre-activations differ by 1e-6 open a unit at |z| ~ 1e-6
     differently, and the gradient through it is then 'all' in one and 'nothing' in the other.  Inside this context the
     head's ReLUs take their gates from ``masks`` (bool tensors in call order: the gates the OTHER implementation
@@ -198,8 +199,9 @@ class forced_gates:
         return False
 
 
-def _relu_head(z):
-    """ReLU of the decoder head: F.relu, or the forced gate inside ``forced_gates``"""
+def _relu_gated(z):
+    """ReLU of a "heavy" unit (decoder head MLPs, DepthNet's camera MLPs / SE layers: few units, each feeding whole
+    feature maps): F.relu, or the forced gate inside ``forced_gates``"""
     g = _GATES
     if g is None:
         return F.relu(z)
@@ -328,12 +330,12 @@ def _aspp2d_bn(sd, p, x):
 
 def _se(sd, p, x, x_se):
     """ViewTransformerLSSBEVDepth.py:432-446 (SELayer)."""
-    g = _conv2d(sd, p + "conv_expand.", F.relu(_conv2d(sd, p + "conv_reduce.", x_se)))
+    g = _conv2d(sd, p + "conv_expand.", _relu_gated(_conv2d(sd, p + "conv_reduce.", x_se)))
     return x * torch.sigmoid(g)
 
 
 def _cam_mlp(sd, p, x):
-    return _linear(sd, p + "fc2.", F.relu(_linear(sd, p + "fc1.", x)))
+    return _linear(sd, p + "fc2.", _relu_gated(_linear(sd, p + "fc1.", x)))
 
 
 def depthnet(sd, p, x, mlp_input, dcn_groups=4):
@@ -641,7 +643,7 @@ def head_predict(sd, p, dec, mask_feat, target_shape, heads, pooling=True):
     d = F.layer_norm(dec, (E,), sd[p + "transformer_decoder.post_norm.weight"],
                      sd[p + "transformer_decoder.post_norm.bias"], 1e-5)
     cls = _linear(sd, p + "cls_embed.", d)
-    m = _linear(sd, p + "mask_embed.4.", _relu_head(_linear(sd, p + "mask_embed.2.", _relu_head(
+    m = _linear(sd, p + "mask_embed.4.", _relu_gated(_linear(sd, p + "mask_embed.2.", _relu_gated(
         _linear(sd, p + "mask_embed.0.", d)))))
     mask_pred = torch.einsum("bqc,bcxyz->bqxyz", m, mask_feat)
     if pooling:
@@ -680,7 +682,7 @@ def mask2former_head(sd, p, feats, heads=6, num_layers=9, num_levels=3, pooling=
         q = F.layer_norm(q + a, (E,), sd[lp + "norms.0.weight"], sd[lp + "norms.0.bias"], 1e-5)
         a = _mha(sd, lp + "attentions.1.attn.", q + qpos, q + qpos, q, heads)
         q = F.layer_norm(q + a, (E,), sd[lp + "norms.1.weight"], sd[lp + "norms.1.bias"], 1e-5)
-        y = _linear(sd, lp + "ffns.0.layers.1.", _relu_head(_linear(sd, lp + "ffns.0.layers.0.0.", q)))
+        y = _linear(sd, lp + "ffns.0.layers.1.", _relu_gated(_linear(sd, lp + "ffns.0.layers.0.0.", q)))
         q = F.layer_norm(q + y, (E,), sd[lp + "norms.2.weight"], sd[lp + "norms.2.bias"], 1e-5)
         inter.append((pooled, blocked))
         cls, mp, pooled, blocked = head_predict(
