@@ -370,12 +370,13 @@ extern "C" int occf_mlp_fused_fwd(const float* x, const float* ln_gamma, const f
   if (terms != 1 && terms != 3) return OCCF_EINVAL;
   if (terms == 3 && (w1_lo == nullptr || w2_lo == nullptr)) return OCCF_EINVAL;
   if (ln_mode != 0 && (ln_gamma == nullptr || ln_beta == nullptr)) return OCCF_EINVAL;
-  // OCCF_MLP_CHAIN: 0 = never, 1 = the register-chained kernel for C = 192, 2 = also for C = 128
+  // OCCF_MLP_CHAIN: 0 = never, 1 = the register-chained kernels: C = 192 (any H), C = H = 128 (weight-resident),
+  // 2 = also C = 128 with H != 128
   static const int chain = [] {
     const char* e = getenv("OCCF_MLP_CHAIN");
     return e ? atoi(e) : 1;
   }();
-  if (chain && (C == 192 || (chain >= 2 && C == 128))) {
+  if (chain && (C == 192 || (C == 128 && (H == 128 || chain >= 2)))) {
     const int rc = occf_mlp_chain_launch(x, ln_gamma, ln_beta, w1_hi, w1_lo, b1, w2_hi, w2_lo, b2, out, M, C, H, act,
                                          ln_mode, eps, terms, (hipStream_t)stream);
     if (rc != OCCF_ESHAPE) return rc;

@@ -238,10 +238,13 @@ def test_conv3x3x3_halo(be, monkeypatch, shape, cin, cout, prec, tol, frag):
 
 
 @pytest.mark.parametrize("C,H,act,ln_mode,M", [(128, 128, 2, 1, 150), (192, 768, 1, 2, 70), (256, 256, 2, 1, 64),
-                                               (128, 256, 1, 0, 33)])
+                                               (128, 256, 1, 0, 33), (128, 128, 1, 2, 900)])
 @pytest.mark.parametrize("prec,tol", [("bf16x3", 3e-5), ("bf16", 3e-2)])
 def test_mlp_fused(be, monkeypatch, C, H, act, ln_mode, M, prec, tol):
     monkeypatch.setattr(be.ops, "precision", prec)
+    # C = H = 128 runs the weight-resident persistent kernel (csrc/mlp_chain.hip): two workgroups walk the 8 token
+    # tiles of the M = 900 case (4 iterations each, the last tile ragged, next-tile prefetch on every iteration)
+    monkeypatch.setenv("OCCF_MLP_RES_WGS", "2")
     x = paramgen.tensor("mx", (M, C), 1, 1.5) + 0.3
     w1 = paramgen.tensor("mw1", (H, C), 2, C ** -0.5)
     b1 = paramgen.tensor("mb1", (H,), 3, 0.2)
