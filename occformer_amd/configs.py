@@ -204,6 +204,27 @@ def synthetic_sample(meta, device, seed=0):
         bda = torch.eye(3).view(1, 3, 3)
     post_rots = torch.eye(3).view(1, 1, 3, 3).repeat(B, N, 1, 1)
     post_trans = torch.zeros(B, N, 3)
+    if N > 1:
+        # Six physical cameras never share their calibration to the last bit, and the image augmentation draws a
+        # resize / crop per camera (loading_nusc_imgs.py:98-174), so intrinsics, post_rots and post_trans differ from
+        # camera to camera.  An IDENTICAL column matters numerically: DepthNet normalises the 27 camera scalars with a
+        # train-mode BatchNorm1d over the cameras (ViewTransformerLSSBEVDepth.py:453,489), and a constant column there is
+        # (x - mean) = rounding noise divided by sqrt(eps) -- with fx = 557 repeated six times that is +-0.02 of pure
+        # noise in the layer's output, different on every backend (measured r04e: camera-MLP pre-activations 6e-4 apart
+        # between GPU and CPU, their parameters' gradients 3e-2 apart).  The rig below keeps the survey's nominal values
+        # and perturbs them per camera the way real calibrations / augmentations do.
+        fs = torch.tensor([0.985, 0.993, 1.0, 1.004, 1.011, 0.996])[:N]
+        dcx = torch.tensor([-3.0, 2.0, 0.0, 4.0, -1.0, 1.5])[:N]
+        dcy = torch.tensor([1.0, -2.0, 0.5, 0.0, 2.0, -1.0])[:N]
+        intr[0, :, 0, 0] *= fs
+        intr[0, :, 1, 1] *= fs
+        intr[0, :, 0, 2] += dcx * (W / 704.0)
+        intr[0, :, 1, 2] += dcy * (H / 256.0)
+        rs = torch.tensor([1.0, 0.97, 1.03, 0.99, 1.02, 0.96])[:N]          # resize of the augmentation, per camera
+        post_rots[0, :, 0, 0] = rs
+        post_rots[0, :, 1, 1] = rs
+        post_trans[0, :, 0] = torch.tensor([0.0, -6.0, 4.0, -2.0, 8.0, -5.0])[:N] * (W / 704.0)
+        post_trans[0, :, 1] = torch.tensor([0.0, 3.0, -4.0, 2.0, -1.0, 5.0])[:N] * (H / 256.0)
     points = None
     if meta.get("lidar_points", 0):
         lo = torch.tensor(meta["pc_range"][:3])
