@@ -217,6 +217,8 @@ def test_workload_training_step_vs_oracle(hip, name):
     worst_loss, whole, qs, pairs, forced = compare(7)
     assert worst_loss <= TOL, pairs
     # a unit may only be gated differently where its pre-activation is rounding-close to zero
-    assert forced.max_rel_z <= 1e-3, (forced.flipped, forced.max_abs_z, forced.max_rel_z)
+    # (measured r04f over the five workloads: 1 ... 3 units of 1.78 M at |z| <= 2.2e-6 of the RMS)
+    assert forced.max_rel_z <= 1e-4, (forced.flipped, forced.max_abs_z, forced.max_rel_z)
     assert whole <= TOL
-    assert qs[0.9] <= 3e-3 and qs[1.0] <= 1e-1
+    # (measured r04f: whole gradient 6.3e-5 ... 1.9e-4, 90 % of the parameters <= 6.0e-4, worst parameter <= 4.6e-3)
+    assert qs[0.9] <= 2e-3 and qs[1.0] <= 2e-2
