@@ -14,7 +14,6 @@
 // so q, k, v, the scores and the probabilities never leave registers.  LDS holds the layer-normed window (the B / A
 // operand of the projections) and, after the attention, the four heads' outputs (the B operand of proj, each wave
 // then producing 32 output channels for all tokens -- no cross-wave reduction).  3-term bf16 split products.
-#include <stdlib.h>
 #include "occf_common.h"
 #include "../../include/occformer_hip.h"
 
@@ -392,353 +391,6 @@ __global__ void __launch_bounds__(256) SF_WAVES2 swin_attn_fused_kernel(SwinAttn
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Weight-RESIDENT persistent variant.  The kernel above spends ~25 us per window where its MFMAs take 3.8: every window
-// re-fetches its head's 64 KB of weight fragments from the L2 in four dependent batches, re-reads the bias table,
-// rebuilds the relative-position table and waits for its 49 token rows from HBM, with two workgroups per CU to hide
-// all of it.  Here a workgroup is persistent (one per CU, one wave per SIMD, the whole 512-register file): each wave
-// keeps the fragments of ITS head's Wq / Wk / Wv rows and of its 32 proj rows in registers for the kernel's lifetime
-// (256 registers), the bias table and the relative-position table stay in LDS (the latter is rebuilt only around
-// the shifted layout's edge windows, whose mask differs), and the next window's token rows are fetched while the
-// current window multiplies.  Requires the fragment-order weights (occf_swin_attn_pack).
-#ifdef OCCF_EMU
-#define SF_WAVES1
-#else
-#define SF_WAVES1 __attribute__((amdgpu_waves_per_eu(1, 1)))
-#endif
-
-// rolled-frame position t of window (wx, wy) of slice (b, s) -> source token (-1 = padding / idle column)
-__device__ __forceinline__ int sf_tok_of(int t, int wx, int wy, int b, int s, int X, int Y, int S, int Xp, int Yp,
-                                         int shift) {
-  if (t >= SF_T) return -1;
-  const int i = (t * 37) >> 8, j = t - i * SF_WS;              // t / 7, t % 7 for t < 64
-  int sx = wx * SF_WS + i + shift, sy = wy * SF_WS + j + shift; // torch.roll(-shift)
-  if (sx >= Xp) sx -= Xp;
-  if (sy >= Yp) sy -= Yp;
-  return (sx < X && sy < Y) ? (int)((((long)b * X + sx) * Y + sy) * S + s) : -1;
-}
-// shift-mask region of rolled-frame position t (0 for every position of a window that is not on the last window
-// row / column)
-__device__ __forceinline__ int sf_region_of(int t, int wx, int wy, int Xp, int Yp, int shift) {
-  const int i = (t * 37) >> 8, j = t - i * SF_WS;
-  const int px = wx * SF_WS + i, py = wy * SF_WS + j;
-  const int rx = px < Xp - SF_WS ? 0 : (px < Xp - shift ? 1 : 2);
-  const int ry = py < Yp - SF_WS ? 0 : (py < Yp - shift ? 1 : 2);
-  return rx * 3 + ry;
-}
-
-__global__ void __launch_bounds__(256) SF_WAVES1 swin_attn_res_kernel(SwinAttnArgs p, long n_win) {
-  __shared__ __attribute__((aligned(16))) unsigned char img_h[SF_IMG], img_l[SF_IMG];   // Xn, later the heads' outputs
-  __shared__ float lds_bias[4][256];
-  __shared__ uint16_t lds_rel[64 * 64];
-
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 31, lk = lane >> 5;
-  const int X = p.X, Y = p.Y, S = p.S, shift = p.shift;
-  const int nwx = (X + SF_WS - 1) / SF_WS, nwy = (Y + SF_WS - 1) / SF_WS;
-  const int Xp = nwx * SF_WS, Yp = nwy * SF_WS;
-  const int head = wave;
-  constexpr int C = SF_C;
-
-  // ---- this wave's weight fragments: resident for the whole kernel
-  bf16x8 wqh[8], wql[8], wkh[8], wkl[8], wvh[8], wvl[8], wph[8], wpl[8];
-  {
-    const uint16_t* qh = p.Wqkv_h + (long)(0 * 4 + head) * 8 * 512 + lane * 8;
-    const uint16_t* ql = p.Wqkv_l + (long)(0 * 4 + head) * 8 * 512 + lane * 8;
-    const uint16_t* kh = p.Wqkv_h + (long)(1 * 4 + head) * 8 * 512 + lane * 8;
-    const uint16_t* kl = p.Wqkv_l + (long)(1 * 4 + head) * 8 * 512 + lane * 8;
-    const uint16_t* vh = p.Wqkv_h + (long)(2 * 4 + head) * 8 * 512 + lane * 8;
-    const uint16_t* vl = p.Wqkv_l + (long)(2 * 4 + head) * 8 * 512 + lane * 8;
-    const uint16_t* ph = p.Wp_h + (long)wave * 8 * 512 + lane * 8;
-    const uint16_t* pl = p.Wp_l + (long)wave * 8 * 512 + lane * 8;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      wqh[ks] = *(const bf16x8*)(qh + ks * 512); wql[ks] = *(const bf16x8*)(ql + ks * 512);
-      wkh[ks] = *(const bf16x8*)(kh + ks * 512); wkl[ks] = *(const bf16x8*)(kl + ks * 512);
-      wvh[ks] = *(const bf16x8*)(vh + ks * 512); wvl[ks] = *(const bf16x8*)(vl + ks * 512);
-      wph[ks] = *(const bf16x8*)(ph + ks * 512); wpl[ks] = *(const bf16x8*)(pl + ks * 512);
-    }
-  }
-  for (int t = lane; t < (2 * SF_WS - 1) * (2 * SF_WS - 1); t += 64)
-    lds_bias[wave][t] = p.bias_table[(long)t * 4 + head];
-
-  // LayerNorm staging: 16 lanes per row, 4 passes of 16 rows; the rows of the NEXT window travel in xv
-  const int sub = tid & 15, rloc = tid >> 4;
-  float4 xv[4][2];
-  int xtok[4];
-  auto decode = [&](long win, int& wx, int& wy, int& s, int& b) __attribute__((always_inline)) {
-    wy = (int)(win % nwy);
-    win /= nwy;
-    wx = (int)(win % nwx);
-    win /= nwx;
-    s = (int)(win % S);
-    b = (int)(win / S);
-  };
-  auto fetch_rows = [&](long win) __attribute__((always_inline)) {
-    int wx, wy, s, b;
-    decode(win, wx, wy, s, b);
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      xtok[pass] = sf_tok_of(pass * 16 + rloc, wx, wy, b, s, X, Y, S, Xp, Yp, shift);
-      const long row = xtok[pass] >= 0 ? xtok[pass] : 0;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) xv[pass][j] = *(const float4*)(p.x + row * C + (sub + 16 * j) * 4);
-    }
-  };
-
-  long win = blockIdx.x;
-  if (win < n_win) fetch_rows(win);
-  bool rel_plain = false;                              // lds_rel currently holds the mask-free table
-  for (; win < n_win; win += gridDim.x) {
-    int wx, wy, s, b;
-    decode(win, wx, wy, s, b);
-    const bool edge = shift > 0 && (wx == nwx - 1 || wy == nwy - 1);      // workgroup-uniform
-    // ---- [key][query] -> relative-position-bias index (bits 0..7), shift-mask flag (bit 8), 0xFFFF = padding key
-    if (edge || !rel_plain) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int idx = tid + i * 256;
-        const int key = idx >> 6, qi = idx & 63;
-        const int krow = (key * 37) >> 8, kcol = key - krow * SF_WS;
-        const int qrow = (qi * 37) >> 8, qcol = qi - qrow * SF_WS;
-        int v = 0xFFFF;
-        if (key < SF_T) {
-          v = qi < SF_T ? (qrow - krow + SF_WS - 1) * (2 * SF_WS - 1) + (qcol - kcol + SF_WS - 1) : 0;
-          if (edge && qi < SF_T && sf_region_of(key, wx, wy, Xp, Yp, shift) != sf_region_of(qi, wx, wy, Xp, Yp, shift))
-            v |= 0x100;
-        }
-        lds_rel[idx] = (uint16_t)v;
-      }
-      rel_plain = !edge;
-    }
-    // ---- LayerNorm of the window's rows (already in registers) -> operand image
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int t = pass * 16 + rloc;
-      float sm = 0.f;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) sm += (xv[pass][j].x + xv[pass][j].y) + (xv[pass][j].z + xv[pass][j].w);
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
-      const float mean = sm / (float)C;
-      float q2 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const float a = xv[pass][j].x - mean, bb = xv[pass][j].y - mean, c = xv[pass][j].z - mean, d = xv[pass][j].w - mean;
-        q2 += (a * a + bb * bb) + (c * c + d * d);
-      }
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) q2 += __shfl_xor(q2, o);
-      const float rstd = 1.0f / sqrtf(q2 / (float)C + p.eps);
-      const bool live = xtok[pass] >= 0;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int c0 = (sub + 16 * j) * 4;
-        const float4 g = *(const float4*)(p.gamma + c0), be = *(const float4*)(p.beta + c0);
-        const float y0 = live ? (xv[pass][j].x - mean) * rstd * g.x + be.x : 0.f;
-        const float y1 = live ? (xv[pass][j].y - mean) * rstd * g.y + be.y : 0.f;
-        const float y2 = live ? (xv[pass][j].z - mean) * rstd * g.z + be.z : 0.f;
-        const float y3 = live ? (xv[pass][j].w - mean) * rstd * g.w + be.w : 0.f;
-        sf_put4(img_h, img_l, t, c0, y0, y1, y2, y3);
-      }
-    }
-    __syncthreads();
-    // the next window's rows travel under this window's MFMAs (the last window re-reads itself: no branch around loads)
-    OCCF_SCHED_FENCE();
-    fetch_rows(win + gridDim.x < n_win ? win + gridDim.x : win);
-    OCCF_SCHED_FENCE();
-
-    // ---- projections of this head (weights from registers)
-    bf16x8 qfh[2][2], qfl[2][2], kfh[2][2], kfl[2][2], vfh[2][2], vfl[2][2];
-#pragma unroll
-    for (int mat = 0; mat < 3; ++mat) {
-      f32x16 acc[2];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
-      // operand fragments one k-step ahead, each k-step fenced: left alone the compiler batches all 32 LDS reads of a
-      // matrix in front of its MFMAs (128 registers next to the 256 resident ones: 205 spills)
-      bf16x8 xh[2][2], xl[2][2];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int off = (tt * 32 + li) * 32 + lk * 16;
-        xh[0][tt] = *(const bf16x8*)(img_h + off);
-        xl[0][tt] = *(const bf16x8*)(img_l + off);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8 wh = mat == 0 ? wqh[ks] : mat == 1 ? wkh[ks] : wvh[ks];
-        const bf16x8 wl = mat == 0 ? wql[ks] : mat == 1 ? wkl[ks] : wvl[ks];
-        if (ks < 7) {
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt) {
-            const int off = (ks + 1) * 2048 + (tt * 32 + li) * 32 + lk * 16;
-            xh[(ks + 1) & 1][tt] = *(const bf16x8*)(img_h + off);
-            xl[(ks + 1) & 1][tt] = *(const bf16x8*)(img_l + off);
-          }
-        }
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const bf16x8 ch = xh[ks & 1][tt], cl = xl[ks & 1][tt];
-          if (mat < 2) {        // W . Xn^T
-            acc[tt] = occf_mfma_bf16_32x32x16(wl, ch, acc[tt]);
-            acc[tt] = occf_mfma_bf16_32x32x16(wh, cl, acc[tt]);
-            acc[tt] = occf_mfma_bf16_32x32x16(wh, ch, acc[tt]);
-          } else {              // Xn . W^T
-            acc[tt] = occf_mfma_bf16_32x32x16(cl, wh, acc[tt]);
-            acc[tt] = occf_mfma_bf16_32x32x16(ch, wl, acc[tt]);
-            acc[tt] = occf_mfma_bf16_32x32x16(ch, wh, acc[tt]);
-          }
-        }
-        OCCF_SCHED_FENCE();
-      }
-      float br[16];
-      if (mat < 2) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 a4 = *(const float4*)(p.bqkv + mat * C + head * SF_HD + 8 * g + 4 * lk);
-          br[g * 4 + 0] = a4.x; br[g * 4 + 1] = a4.y; br[g * 4 + 2] = a4.z; br[g * 4 + 3] = a4.w;
-        }
-      } else {
-        const float bv = p.bqkv[2 * C + head * SF_HD + li];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) br[r] = bv;
-      }
-      const float mul = mat == 0 ? p.scale : 1.0f;
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          float f[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = (acc[tt][s2 * 8 + e] + br[s2 * 8 + e]) * mul;
-          if (mat == 0) sf_split8(f, qfh[tt][s2], qfl[tt][s2]);
-          else if (mat == 1) sf_split8(f, kfh[tt][s2], kfl[tt][s2]);
-          else sf_split8(f, vfh[tt][s2], vfl[tt][s2]);
-        }
-    }
-    __syncthreads();                                   // every wave is done reading the Xn image
-
-    // ---- attention of this head; the result goes to the (reused) image as the B operand of proj
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      const int qi = qt * 32 + li;
-      f32x16 st[2];
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          st[kt] = occf_mfma_bf16_32x32x16(kfl[kt][s2], qfh[qt][s2], st[kt]);
-          st[kt] = occf_mfma_bf16_32x32x16(kfh[kt][s2], qfl[qt][s2], st[kt]);
-          st[kt] = occf_mfma_bf16_32x32x16(kfh[kt][s2], qfh[qt][s2], st[kt]);
-        }
-      }
-      float mx = -3.0e38f;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-          const int tv = lds_rel[key * 64 + qi];
-          float a = st[kt][r] + lds_bias[wave][tv & 0xFF];
-          if (tv & 0x100) a += -100.0f;
-          a = tv == 0xFFFF ? -INFINITY : a;
-          st[kt][r] = a;
-          mx = fmaxf(mx, a);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      float sum = 0.f;
-      f32x16 ot;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ot[r] = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          float pv[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            pv[e] = __expf(st[kt][s2 * 8 + e] - mx);    // padding keys: exp(-inf) = 0
-            sum += pv[e];
-          }
-          bf16x8 ph, pl;
-          sf_split8(pv, ph, pl);
-          ot = occf_mfma_bf16_32x32x16(vfl[kt][s2], ph, ot);
-          ot = occf_mfma_bf16_32x32x16(vfh[kt][s2], pl, ot);
-          ot = occf_mfma_bf16_32x32x16(vfh[kt][s2], ph, ot);
-        }
-      sum += __shfl_xor(sum, 32);
-      const float inv = 1.0f / sum;
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        sf_put4(img_h, img_l, qi, head * SF_HD + 8 * g + 4 * lk, ot[g * 4 + 0] * inv, ot[g * 4 + 1] * inv,
-                ot[g * 4 + 2] * inv, ot[g * 4 + 3] * inv);
-    }
-    __syncthreads();
-
-    // ---- proj + bias + residual: this wave produces output channels 32 wave .. +31 of every token
-    int otok[2];
-    float4 xres[2][4];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {                   // the residual rows travel under the proj MFMAs
-      otok[tt] = sf_tok_of(tt * 32 + li, wx, wy, b, s, X, Y, S, Xp, Yp, shift);
-      const long row = otok[tt] >= 0 ? otok[tt] : 0;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) xres[tt][g] = *(const float4*)(p.x + row * C + wave * 32 + 8 * g + 4 * lk);
-    }
-    f32x16 ao[2];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ao[tt][r] = 0.f;
-    {
-      bf16x8 oh[2][2], ol[2][2];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int off = (tt * 32 + li) * 32 + lk * 16;
-        oh[0][tt] = *(const bf16x8*)(img_h + off);
-        ol[0][tt] = *(const bf16x8*)(img_l + off);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        if (ks < 7) {
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt) {
-            const int off = (ks + 1) * 2048 + (tt * 32 + li) * 32 + lk * 16;
-            oh[(ks + 1) & 1][tt] = *(const bf16x8*)(img_h + off);
-            ol[(ks + 1) & 1][tt] = *(const bf16x8*)(img_l + off);
-          }
-        }
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          ao[tt] = occf_mfma_bf16_32x32x16(wpl[ks], oh[ks & 1][tt], ao[tt]);
-          ao[tt] = occf_mfma_bf16_32x32x16(wph[ks], ol[ks & 1][tt], ao[tt]);
-          ao[tt] = occf_mfma_bf16_32x32x16(wph[ks], oh[ks & 1][tt], ao[tt]);
-        }
-        OCCF_SCHED_FENCE();
-      }
-    }
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      if (otok[tt] < 0) continue;                      // padded / idle token columns are cropped
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int c0 = wave * 32 + 8 * g + 4 * lk;
-        const float4 bb = *(const float4*)(p.bp + c0);
-        const float4 xr = xres[tt][g];
-        *(float4*)(p.out + (long)otok[tt] * C + c0) =
-            make_float4(ao[tt][g * 4 + 0] + bb.x + xr.x, ao[tt][g * 4 + 1] + bb.y + xr.y,
-                        ao[tt][g * 4 + 2] + bb.z + xr.z, ao[tt][g * 4 + 3] + bb.w + xr.w);
-      }
-    }
-    __syncthreads();                                   // the image (proj operand) is free for the next window's rows
-  }
-}
-
 // w[R][128] (bf16) -> [R / 32][8 k-steps][64 lanes][8]: element e of lane (lk, li) = w[g * 32 + li][ks * 16 + lk * 8 + e]
 __global__ void __launch_bounds__(256) swin_pack_kernel(const uint16_t* __restrict__ w, uint16_t* __restrict__ f, int R) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -774,16 +426,6 @@ extern "C" int occf_swin_attn_fused_fwd(const float* x, const float* ln_gamma, c
   if (blocks >= 2147483647L) return OCCF_ESHAPE;
   SwinAttnArgs a = {x, ln_gamma, ln_beta, wqkv_hi, wqkv_lo, bqkv, bias_table, wproj_hi, wproj_lo, bproj, out,
                     B, X, Y, S, shift, eps, (float)(1.0 / sqrt((double)SF_HD)), weights_packed != 0};
-  // OCCF_SWIN_RES (default 1): the weight-resident persistent kernel (fragment-order weights only); OCCF_SWIN_RES_WGS
-  // caps its grid (tests walk several windows per workgroup)
-  const char* er = getenv("OCCF_SWIN_RES");
-  if (weights_packed && (!er || atoi(er) != 0)) {
-    const char* ew = getenv("OCCF_SWIN_RES_WGS");
-    const long cap = ew && atoi(ew) > 0 ? atoi(ew) : 256;
-    hipLaunchKernelGGL(swin_attn_res_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0,
-                       (hipStream_t)stream, a, blocks);
-    OCCF_LAUNCH_CHECK();
-  }
   hipLaunchKernelGGL(swin_attn_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   OCCF_LAUNCH_CHECK();
 }

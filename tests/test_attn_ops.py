@@ -183,9 +183,6 @@ def test_swin_attention_fused(be, monkeypatch, X, Y, S, shift, B, packed):
     (C = 128 / 4 heads; padded, shifted and partial windows)"""
     monkeypatch.setattr(be.ops, "precision", "bf16x3")
     monkeypatch.setattr(be.ops, "swin_frag", packed)
-    # packed weights run the weight-resident persistent kernel: three workgroups walk the 4 ... 16 windows of a case
-    # (edge windows of the shifted layout rebuild the relative-position table, interior ones reuse it)
-    monkeypatch.setenv("OCCF_SWIN_RES_WGS", "3")
     C, heads = 128, 4
     sd = {"a.w_msa.qkv.weight": paramgen.tensor("fqkvw", (3 * C, C), 1, C ** -0.5),
           "a.w_msa.qkv.bias": paramgen.tensor("fqkvb", (3 * C,), 1, 0.3),
