@@ -333,11 +333,15 @@ __global__ void __launch_bounds__(256) mlp_chain_kernel(MlpChainArgs p) {
 // and W2: 128 KB) are staged ONCE per workgroup, workgroups are persistent (one per CU) and walk the token tiles;
 // the four waves never meet again after the staging barrier, and the next tile's rows are fetched under the current
 // tile's MFMAs (one wave per SIMD: nothing else would hide the HBM latency).
-template <int TERMS>
-__global__ void __launch_bounds__(256) mlp_chain_res_kernel(MlpChainArgs p, long n_tiles) {
+// NW = waves per workgroup: 4 (one per SIMD: the next tile's rows are prefetched, three accumulator chains in GEMM1) or
+// 8 (two per SIMD sharing the resident weights: a wave's LayerNorm / GELU / split VALU overlaps its partner's MFMAs, the
+// partner also hides the row latency -- no prefetch, one accumulator chain, <= 256 registers)
+template <int TERMS, int NW>
+__global__ void __launch_bounds__(NW * 64) mlp_chain_res_kernel(MlpChainArgs p, long n_tiles) {
+  constexpr int NT = NW * 64;
   constexpr int C = 128, KC = C / 16, CT = C / 32, NG = 4;
   constexpr int WB = 64 * C;                 // bytes of one weight image (hi or lo) of a 32-unit hidden group
-  constexpr int NPC = (WB / 16) / 256;       // 16-byte pieces per thread per image: 2
+  constexpr int NPC = (WB / 16) / NT;        // 16-byte pieces per thread per image
   OCCF_DYN_SMEM(smem);
   unsigned char* Wall = (unsigned char*)smem;          // group g: W1 [hi | lo] at g * 4 WB, W2 [hi | lo] at g * 4 WB + 2 WB
   float* b1s = (float*)(Wall + NG * 4 * WB);           // [128]
@@ -355,7 +359,7 @@ __global__ void __launch_bounds__(256) mlp_chain_res_kernel(MlpChainArgs p, long
       const uint16_t* W2 = arr ? p.W2l : p.W2h;
 #pragma unroll
       for (int i = 0; i < NPC; ++i) {
-        const int s = tid + i * 256;                    // slot within the image
+        const int s = tid + i * NT;                     // slot within the image
         {
           const int ks = s >> 6, row = (s >> 1) & 31, k2 = s & 1;
           const mc_u4 v = *(const mc_u4*)(W1 + ((long)g * 32 + row) * C + ks * 16 + k2 * 8);
@@ -376,7 +380,7 @@ __global__ void __launch_bounds__(256) mlp_chain_res_kernel(MlpChainArgs p, long
 
   float xf[KC][8];
   auto load_x = [&](long tile) __attribute__((always_inline)) {
-    const long tok = (tile * 4 + wave) * 32 + li;
+    const long tok = (tile * NW + wave) * 32 + li;
     const float* xr = p.x + (tok < p.M ? tok : p.M - 1) * C + lk * 8;
 #pragma unroll
     for (int ks = 0; ks < KC; ++ks) {
@@ -386,9 +390,10 @@ __global__ void __launch_bounds__(256) mlp_chain_res_kernel(MlpChainArgs p, long
     }
   };
   long tile = blockIdx.x;
-  if (tile < n_tiles) load_x(tile);
+  if (NW == 4 && tile < n_tiles) load_x(tile);
   for (; tile < n_tiles; tile += gridDim.x) {
-    const long tok = (tile * 4 + wave) * 32 + li;
+    if (NW != 4) load_x(tile);
+    const long tok = (tile * NW + wave) * 32 + li;
     const long tokc = tok < p.M ? tok : p.M - 1;
     bf16x8 xh[KC], xl[KC];
     if (p.ln_mode == 1) {       // LayerNorm over the C channels of a token = this lane + its partner (lane ^ 32)
@@ -423,9 +428,11 @@ __global__ void __launch_bounds__(256) mlp_chain_res_kernel(MlpChainArgs p, long
 #pragma unroll
     for (int ks = 0; ks < KC; ++ks) mc_split8(xf[ks], xh[ks], xl[ks]);
     // the next tile's rows travel while this one multiplies (the last tile re-reads itself: no branch around loads)
-    OCCF_SCHED_FENCE();
-    load_x(tile + gridDim.x < n_tiles ? tile + gridDim.x : tile);
-    OCCF_SCHED_FENCE();
+    if (NW == 4) {
+      OCCF_SCHED_FENCE();
+      load_x(tile + gridDim.x < n_tiles ? tile + gridDim.x : tile);
+      OCCF_SCHED_FENCE();
+    }
 
     f32x16 acc[CT];
 #pragma unroll
@@ -443,7 +450,12 @@ __global__ void __launch_bounds__(256) mlp_chain_res_kernel(MlpChainArgs p, long
       for (int ks = 0; ks < KC; ++ks) {
         const int off = ks * 1024 + li * 32 + lk * 16;
         const bf16x8 ah = *(const bf16x8*)(W1i + off);
-        if (three) {
+        if (three && NW != 4) {
+          const bf16x8 al = *(const bf16x8*)(W1i + WB + off);
+          ht = occf_mfma_bf16_32x32x16(al, xh[ks], ht);
+          ht = occf_mfma_bf16_32x32x16(ah, xl[ks], ht);
+          ht = occf_mfma_bf16_32x32x16(ah, xh[ks], ht);
+        } else if (three) {
           const bf16x8 al = *(const bf16x8*)(W1i + WB + off);
           hu = occf_mfma_bf16_32x32x16(al, xh[ks], hu);
           hv = occf_mfma_bf16_32x32x16(ah, xl[ks], hv);
@@ -453,6 +465,7 @@ __global__ void __launch_bounds__(256) mlp_chain_res_kernel(MlpChainArgs p, long
         } else {
           ht = occf_mfma_bf16_32x32x16(ah, xh[ks], ht);
         }
+        if (NW != 4 && (ks & 1)) OCCF_SCHED_FENCE();      // (256-register budget: no batch of all 16 fragment reads)
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) ht[r] = (hu[r] + hv[r]) + ht[r];
@@ -485,6 +498,7 @@ __global__ void __launch_bounds__(256) mlp_chain_res_kernel(MlpChainArgs p, long
         }
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[ct] = occf_mfma_bf16_32x32x16(ah[ct], hh[s2], acc[ct]);
+        if (NW != 4) OCCF_SCHED_FENCE();
       }
     }
 
@@ -556,20 +570,23 @@ int occf_mlp_chain_launch(const float* x, const float* ln_gamma, const float* ln
     // tile loop with a handful of workgroups)
     const char* e = getenv("OCCF_MLP_RES_WGS");
     const long cap = e && atoi(e) > 0 ? atoi(e) : 256;
-    const long n_tiles = occf_cdiv(M, 128);
+    const char* ew = getenv("OCCF_MLP_RES_WAVES");               // 4 or 8 (default) waves per workgroup
+    const int nw = ew && atoi(ew) == 4 ? 4 : 8;
+    const long n_tiles = occf_cdiv(M, 32 * nw);
     const unsigned grid = (unsigned)(n_tiles < cap ? n_tiles : cap);
     const size_t lds = (size_t)4 * 4 * 64 * 128 + 512;
+    typedef void (*fn_t)(MlpChainArgs, long);
+    const fn_t fn = nw == 4 ? (terms == 3 ? (fn_t)mlp_chain_res_kernel<3, 4> : (fn_t)mlp_chain_res_kernel<1, 4>)
+                            : (terms == 3 ? (fn_t)mlp_chain_res_kernel<3, 8> : (fn_t)mlp_chain_res_kernel<1, 8>);
 #ifndef OCCF_EMU
-    static bool done[2] = {false, false};
-    if (!done[terms == 3]) {
-      hipError_t err = terms == 3 ? hipFuncSetAttribute((const void*)mlp_chain_res_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                                  : hipFuncSetAttribute((const void*)mlp_chain_res_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static bool done[2][2] = {{false, false}, {false, false}};
+    if (!done[nw == 8][terms == 3]) {
+      hipError_t err = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (err != hipSuccess) return (int)err;
-      done[terms == 3] = true;
+      done[nw == 8][terms == 3] = true;
     }
 #endif
-    if (terms == 3) hipLaunchKernelGGL(mlp_chain_res_kernel<3>, dim3(grid), dim3(256), lds, st, a, n_tiles);
-    else hipLaunchKernelGGL(mlp_chain_res_kernel<1>, dim3(grid), dim3(256), lds, st, a, n_tiles);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(nw * 64), lds, st, a, n_tiles);
     return (int)hipGetLastError();
   }
   const size_t lds = (size_t)4 * 64 * C + 128;

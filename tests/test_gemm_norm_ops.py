@@ -245,6 +245,7 @@ def test_mlp_fused(be, monkeypatch, C, H, act, ln_mode, M, prec, tol):
     # C = H = 128 runs the weight-resident persistent kernel (csrc/mlp_chain.hip): two workgroups walk the 8 token
     # tiles of the M = 900 case (4 iterations each, the last tile ragged, next-tile prefetch on every iteration)
     monkeypatch.setenv("OCCF_MLP_RES_WGS", "2")
+    monkeypatch.setenv("OCCF_MLP_RES_WAVES", "4" if M == 150 else "8")      # both workgroup shapes of that kernel
     x = paramgen.tensor("mx", (M, C), 1, 1.5) + 0.3
     w1 = paramgen.tensor("mw1", (H, C), 2, C ** -0.5)
     b1 = paramgen.tensor("mb1", (H,), 3, 0.2)
