@@ -115,11 +115,11 @@ class _Decoder(nn.Module):
 
 
 class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
-    # OCCF_LAZY_LOGITS=1: the training graph contracts the full-resolution mask logits only where the losses read them
-    # (attention mask from the fused contraction + pooling kernel, ~20 matched rows per set on demand) instead of one
-    # dense [Q, X, Y, Z] volume per prediction set.  Measured (r02 probe 39): same gradients, 2.4 GB less memory, no
-    # faster (173.8 vs 172.6 ms per step) -- off by default.
-    lazy_train_logits = os.environ.get("OCCF_LAZY_LOGITS", "0") == "1"
+    # OCCF_LAZY_LOGITS (default 1): the training graph contracts the full-resolution mask logits only where the losses
+    # read them (attention mask from the fused contraction + pooling kernel, ~20 matched rows per set on demand) instead
+    # of one dense [Q, X, Y, Z] volume per prediction set: same gradients, 2.4 GB less memory, 141.0 vs 141.9 ms per
+    # step (r04i; in round 2 it had measured even and stayed off).  0 = the dense volumes.
+    lazy_train_logits = os.environ.get("OCCF_LAZY_LOGITS", "1") == "1"
 
     def __init__(self, feat_channels, out_channels, num_occupancy_classes=20, num_queries=100,
                  num_transformer_feat_level=3, enforce_decoder_input_project=False,

@@ -87,13 +87,13 @@ def _conv_train(conv, x):
     return y.squeeze(3).permute(0, 3, 1, 2)
 
 
-# OCCF_DEPTHNET_LIB=1: DepthNet's training-mode convolutions on the library's kernel pairs.  Default off: at the
-# nuScenes sizes (M = 6 x 16 x 44 = 4 224 rows) the ten 3x3 convolutions cost the same on either side (~6 ms per
-# step), and every non-ATen summation order flips a few more ReLU gates against the CPU oracle in the tiny parity
-# configuration (tests/test_train_step.py).  (SemanticKITTI, 640 channels / one camera: 149 ms per step with the
-# library kernels, 139 ms with MIOpen on a box where its search settles on the igemm kernels, 278 ms on one where it
-# did not -- r02 probes 8 / 27, r02k.)
-_DEPTHNET_LIB = os.environ.get("OCCF_DEPTHNET_LIB", "0") == "1"
+# OCCF_DEPTHNET_LIB (default 1): DepthNet's training-mode convolutions on the library's kernel pairs instead of ATen /
+# MIOpen.  At the nuScenes sizes (M = 6 x 16 x 44 = 4 224 rows) 139.5 vs 141.0 ms per step (r04i; r03b: 170.4 vs 172.0)
+# and no dependence on MIOpen's per-box algorithm search (SemanticKITTI, 640 channels / one camera: 149 ms with the
+# library kernels, 139 ms with MIOpen on a box where its search settles on the igemm kernels, 278 ms on one where it did
+# not -- r02 probes 8 / 27).  It stayed off while a non-ATen summation order could tip the tiny parity configuration
+# over its bound through a flipped ReLU gate; the comparisons now force the heavy gates.
+_DEPTHNET_LIB = os.environ.get("OCCF_DEPTHNET_LIB", "1") == "1"
 
 
 def _conv(mod, conv, x):
