@@ -87,17 +87,21 @@ def _conv_train(conv, x):
     return y.squeeze(3).permute(0, 3, 1, 2)
 
 
-# OCCF_DEPTHNET_LIB (default 1): DepthNet's training-mode convolutions on the library's kernel pairs instead of ATen /
+# OCCF_DEPTHNET_LIB (default auto): DepthNet's training-mode convolutions on the library's kernel pairs instead of ATen /
 # MIOpen.  At the nuScenes sizes (M = 6 x 16 x 44 = 4 224 rows) 139.5 vs 141.0 ms per step (r04i; r03b: 170.4 vs 172.0)
 # and no dependence on MIOpen's per-box algorithm search (SemanticKITTI, 640 channels / one camera: 149 ms with the
 # library kernels, 139 ms with MIOpen on a box where its search settles on the igemm kernels, 278 ms on one where it did
 # not -- r02 probes 8 / 27).  It stayed off while a non-ATen summation order could tip the tiny parity configuration
 # over its bound through a flipped ReLU gate; the comparisons now force the heavy gates.
-_DEPTHNET_LIB = os.environ.get("OCCF_DEPTHNET_LIB", "1") == "1"
+# Per shape: the SemanticKITTI workloads (one camera: 24 x 80 = 1 920 rows of 640 channels) run 104.1 ms per step with
+# DepthNet on MIOpen and 108.0 ms on the library's kernels (r04j) -- too few rows to fill the chip with 128-row tiles -- so
+# the default ("auto") takes the library's kernels from 4 096 rows up; 0 / 1 force either side.
+_DEPTHNET_LIB = os.environ.get("OCCF_DEPTHNET_LIB", "auto")
 
 
 def _conv(mod, conv, x):
-    return _conv_train(conv, x) if _DEPTHNET_LIB and mod.training and torch.is_grad_enabled() else conv(x)
+    lib = _DEPTHNET_LIB == "1" or (_DEPTHNET_LIB != "0" and x.shape[0] * x.shape[2] * x.shape[3] >= 4096)
+    return _conv_train(conv, x) if lib and mod.training and torch.is_grad_enabled() else conv(x)
 
 
 class _BasicBlock(nn.Module):
