@@ -14,7 +14,6 @@
 // the query index instead of being read from memory.
 //
 // Gather-bound: the value tensor (<= 70 MB at the 200-grid) is L2/Infinity-Cache resident.
-#include <stdlib.h>
 #include "occf_common.h"
 #include "../../include/occformer_hip.h"
 
@@ -611,12 +610,9 @@ __global__ void __launch_bounds__(256) msda3d_bwd_value_gather_kernel(const floa
 }
 
 static bool msda_tile_cfg(const MsdaLevels& lv, int ls, int Dh, MsdaTileCfg& tc) {
-  // bytes of LDS per workgroup (8 bytes per element); OCCF_MSDA_LDS_KB overrides (<= 156: the CU has 160 KiB)
-  static const long budget = [] {
-    const char* e = getenv("OCCF_MSDA_LDS_KB");
-    const long kb = e ? atol(e) : 124;
-    return (kb >= 32 && kb <= 156 ? kb : 124) * 1024;
-  }();
+  // bytes of LDS per workgroup (8 bytes per element).  Larger tiles are slower: 140 KB 2.51 ms, 156 KB 2.72 ms per call
+  // against 2.50 (profiles/r04/r04k_msda_lds_sweep.txt) -- fewer, longer workgroups on the same LDS atomic rate
+  const long budget = 124 * 1024;
   const int X = lv.X[ls], Y = lv.Y[ls], Z = lv.Z[ls];
   tc.ls = ls;
   tc.M = 5;
