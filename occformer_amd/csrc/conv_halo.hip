@@ -88,16 +88,9 @@ typedef uint32_t ch_u2 __attribute__((ext_vector_type(2)));
 // the current k-step (sched_group_barrier), no conditional load in the loop.  The compiler's own order sank the
 // loads to 1-5 MFMAs in front of their first use to save registers (ISA: s_waitcnt lgkmcnt one MFMA after four
 // ds_read_b128, vmcnt four MFMAs after the loads).
-// WN = waves along the channel dimension (8 waves = WM x WN): 2 -> a wave owns 64 voxels x 32 TN channels; 4 (TN = 2
-// only, SCH path) -> 128 voxels x 32 channels: twice the A fragments from LDS (which has the headroom), half the weight
-// fragments through the L1 per MFMA.
-template <int TN, int TERMS, bool FRAG, int SCH = 0, int WN = 2>
+template <int TN, int TERMS, bool FRAG, int SCH = 0>
 __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
   constexpr int BN = 64 * TN;
-  constexpr int WM = 8 / WN;                          // waves along the voxel dimension
-  constexpr int NI = 256 / WM / 32;                   // 32-voxel tiles per wave
-  constexpr int NJ = BN / WN / 32;                    // 32-channel tiles per wave
-  static_assert(WN == 2 || (WN == 4 && TN == 2 && FRAG && SCH), "conv3x3x3_halo: wave layout");
   constexpr int NBP = (BN * 4 + 511) / 512;          // 16-B weight pieces per thread per array
   constexpr int NHI = 13;                             // float4 halo pieces per thread (816 * 8 / 512)
   constexpr bool HPF = TN <= 2;                       // prefetch the next chunk's halo across the taps
@@ -117,7 +110,7 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lk = lane >> 5;
 
   // workgroup -> (b, x-pair, y-tile, z-tile, n-tile); n fastest so the workgroups sharing a halo
@@ -133,10 +126,10 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
   const int n0 = nt * BN;
 
   // halo base index of this lane's two A rows at tap (0,0,0)
-  int hb[NI];
+  int hb[2];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int r = wm * (256 / WM) + i * 32 + (FRAG ? ch_pos(li) : li);
+  for (int i = 0; i < 2; ++i) {
+    const int r = wm * 64 + i * 32 + (FRAG ? ch_pos(li) : li);
     const int tx = r >> 7, pp = r & 127;
     hb[i] = (tx * HY + pp / TZ) * HZ + pp % TZ;
   }
@@ -171,11 +164,11 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
     b_off[i] = (long)(n < p.Cout ? n : p.Cout - 1) * K + b_slot[i] * 8;
   }
 
-  f32x16 acc[NI][NJ];
+  f32x16 acc[2][TN];
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -233,17 +226,17 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
   if (FRAG) {
     const int ngrp = p.Cout >> 5;
 #ifdef OCCF_EMU
-    const int jg0 = (n0 + wn * (BN / WN)) >> 5;
+    const int jg0 = (n0 + wn * (BN / 2)) >> 5;
 #else
-    const int jg0 = __builtin_amdgcn_readfirstlane((n0 + wn * (BN / WN)) >> 5);     // wave-uniform: scalar base address
+    const int jg0 = __builtin_amdgcn_readfirstlane((n0 + wn * (BN / 2)) >> 5);     // wave-uniform: scalar base address
 #endif
     const unsigned lane8 = (unsigned)lane * 8u;
     // B fragments of stream position g (clamped), k-step s
-    auto load_f = [&](int g, int s, bf16x8 (&fh)[NJ], bf16x8 (&fl)[NJ]) __attribute__((always_inline)) {
+    auto load_f = [&](int g, int s, bf16x8 (&fh)[TN], bf16x8 (&fl)[TN]) __attribute__((always_inline)) {
       const int gc = g < G ? g : G - 1;
       const long o = ((long)(gc * 2 + s) * ngrp + jg0) * 512;          // scalar
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
+      for (int j = 0; j < TN; ++j) {
         // (scalar base + UNSIGNED 32-bit lane offset: the saddr + voffset addressing mode, no 64-bit VALU adds)
         fh[j] = *(const bf16x8*)(p.Fh + o + j * 512 + lane8);
         if (TERMS == 3) fl[j] = *(const bf16x8*)(p.Fl + o + j * 512 + lane8);
@@ -255,21 +248,21 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
     const int a_base = hb[0] * HROW + lk * 16;
     const int a_i1 = (hb[1] - hb[0]) * HROW;            // wave-uniform
     const int hl_off = (int)((size_t)NH * HROW);
-    auto load_a = [&](int toff, int s, bf16x8 (&ah)[NI], bf16x8 (&al)[NI]) __attribute__((always_inline)) {
+    auto load_a = [&](int toff, int s, bf16x8 (&ah)[2], bf16x8 (&al)[2]) __attribute__((always_inline)) {
       const unsigned char* ap = Hh + a_base + toff * HROW + s * 32;
-      // (the 32-voxel tiles of a wave are 32 / TZ halo y-rows apart: tile i sits at i * a_i1)
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        ah[i] = *(const bf16x8*)(ap + i * a_i1);
-        if (TERMS == 3) al[i] = *(const bf16x8*)(ap + hl_off + i * a_i1);
+      ah[0] = *(const bf16x8*)(ap);
+      ah[1] = *(const bf16x8*)(ap + a_i1);
+      if (TERMS == 3) {
+        al[0] = *(const bf16x8*)(ap + hl_off);
+        al[1] = *(const bf16x8*)(ap + hl_off + a_i1);
       }
     };
-    auto mma_step = [&](const bf16x8 (&ah)[NI], const bf16x8 (&al)[NI], const bf16x8 (&fh)[NJ],
-                        const bf16x8 (&fl)[NJ]) __attribute__((always_inline)) {
+    auto mma_step = [&](const bf16x8 (&ah)[2], const bf16x8 (&al)[2], const bf16x8 (&fh)[TN],
+                        const bf16x8 (&fl)[TN]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+        for (int j = 0; j < TN; ++j) {
           if (TERMS == 3) {
             acc[i][j] = occf_mfma_bf16_32x32x16(al[i], fh[j], acc[i][j]);
             acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], fl[j], acc[i][j]);
@@ -281,32 +274,32 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
       const int dz = tap % 3, dy = (tap / 3) % 3, dx = tap / 9;
       return (dx * HY + dy) * HZ + dz;
     };
-    bf16x8 f0h[NJ], f0l[NJ], f1h[NJ], f1l[NJ];
-    bf16x8 a0h[NI], a0l[NI], a1h[NI], a1l[NI];
+    bf16x8 f0h[TN], f0l[TN], f1h[TN], f1l[TN];
+    bf16x8 a0h[2], a0l[2], a1h[2], a1l[2];
     if (HPF) load_halo(0, 0);
     load_f(0, 0, f0h, f0l);
     int cc = 0, tap = 0;
     if (SCH) {
-      auto mma_tm = [&](const bf16x8 (&ah)[NI], const bf16x8 (&al)[NI], const bf16x8 (&fh)[NJ],
-                        const bf16x8 (&fl)[NJ]) __attribute__((always_inline)) {
+      auto mma_tm = [&](const bf16x8 (&ah)[2], const bf16x8 (&al)[2], const bf16x8 (&fh)[TN],
+                        const bf16x8 (&fl)[TN]) __attribute__((always_inline)) {
         if (TERMS == 3) {
 #pragma unroll
-          for (int i = 0; i < NI; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = occf_mfma_bf16_32x32x16(al[i], fh[j], acc[i][j]);
+            for (int j = 0; j < TN; ++j) acc[i][j] = occf_mfma_bf16_32x32x16(al[i], fh[j], acc[i][j]);
 #pragma unroll
-          for (int i = 0; i < NI; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], fl[j], acc[i][j]);
+            for (int j = 0; j < TN; ++j) acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], fl[j], acc[i][j]);
         }
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], fh[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], fh[j], acc[i][j]);
       };
-      constexpr int NA = (TERMS == 3 ? 2 : 1) * NI;      // ds_read_b128 per k-step
-      constexpr int NF = (TERMS == 3 ? 2 : 1) * NJ;      // global 16-byte loads per k-step
-      constexpr int NM = NI * NJ * TERMS;                // MFMAs per k-step
+      constexpr int NA = TERMS == 3 ? 4 : 2;             // ds_read_b128 per k-step
+      constexpr int NF = TERMS == 3 ? 2 * TN : TN;       // global 16-byte loads per k-step
+      constexpr int NM = 2 * TN * TERMS;                 // MFMAs per k-step
       for (int g = 0; g < G; ++g) {
         if (tap == 0) {
           __syncthreads();
@@ -401,23 +394,23 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           const int kslot = s * 2 + lk;
-          bf16x8 ah[NI], al[NI], bh[NJ], bl[NJ];
+          bf16x8 ah[2], al[2], bh[TN], bl[TN];
 #pragma unroll
-          for (int i = 0; i < NI; ++i) {
+          for (int i = 0; i < 2; ++i) {
             const int off = ch_slot(hb[i] + toff, kslot);
             ah[i] = *(const bf16x8*)(Hh + off);
             if (TERMS == 3) al[i] = *(const bf16x8*)(Hl + off);
           }
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            const int off = d * BN * 64 + ch_slot(wn * (BN / WN) + j * 32 + li, kslot);
+          for (int j = 0; j < TN; ++j) {
+            const int off = d * BN * 64 + ch_slot(wn * (BN / 2) + j * 32 + li, kslot);
             bh[j] = *(const bf16x8*)(Bh + off);
             if (TERMS == 3) bl[j] = *(const bf16x8*)(Bl + off);
           }
 #pragma unroll
-          for (int i = 0; i < NI; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
+            for (int j = 0; j < TN; ++j) {
               if (TERMS == 3) {
                 acc[i][j] = occf_mfma_bf16_32x32x16(al[i], bh[j], acc[i][j]);
                 acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bl[j], acc[i][j]);
@@ -434,14 +427,14 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
   }
 
   // ---- epilogue: row r of the tile -> voxel (tx0 + r>>7, ty0 + (r&127)/TZ, tz0 + (r&127)%TZ)
-  float gs[NJ], gq[NJ];                                   // GroupNorm partial sums of this lane's columns
+  float gs[TN], gq[TN];                                   // GroupNorm partial sums of this lane's columns
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) gs[j] = gq[j] = 0.f;
+  for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.f;
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
+  for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int n = n0 + wn * (BN / WN) + j * 32 + li;
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + li;
       const bool n_ok = n < p.Cout;
       const int nc = n_ok ? n : p.Cout - 1;
       const float bv = p.bias ? p.bias[nc] : 0.f;
@@ -450,7 +443,7 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int mrow_ = (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const int row = wm * (256 / WM) + i * 32 + (FRAG ? ch_pos(mrow_) : mrow_);
+        const int row = wm * 64 + i * 32 + (FRAG ? ch_pos(mrow_) : mrow_);
         const int pp = row & 127;
         const int x = tx0 + (row >> 7), y = ty0 + pp / TZ, z = tz0 + pp % TZ;
         mok[r] = n_ok && x < p.X && y < p.Y;
@@ -477,13 +470,13 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
   }
   if (p.gn_partial) {
     // deterministic workgroup reduction: lanes (lk) -> LDS [wm][channel] -> channel -> group
-    float* red = (float*)smem;                             // [WM][BN][2]
+    float* red = (float*)smem;                             // [4][BN][2], then [BN][2] at offset 8*BN
     __syncthreads();                                        // every wave is out of the tap loop (halo LDS is free)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+    for (int j = 0; j < TN; ++j) {
       const float a = gs[j] + __shfl_xor(gs[j], 32), q = gq[j] + __shfl_xor(gq[j], 32);
       if (lk == 0) {
-        const int c = wn * (BN / WN) + j * 32 + li;
+        const int c = wn * (BN / 2) + j * 32 + li;
         red[(wm * BN + c) * 2 + 0] = a;
         red[(wm * BN + c) * 2 + 1] = q;
       }
@@ -492,7 +485,7 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
     if (tid < BN && n0 + tid < p.Cout) {
       float a = 0.f, q = 0.f;
 #pragma unroll
-      for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+      for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
       const long sp = ((long)(tx0 >> 1) * yt + ty0 / TY) * zt + tz0 / TZ;
       float* o = p.gn_partial + ((((long)b * xt * yt * zt) + sp) * p.Cout + n0 + tid) * 2;
       o[0] = a;
@@ -510,9 +503,6 @@ static size_t conv_halo_lds(int TY, int TZ, int TN, int terms, bool frag) {
 typedef void (*conv_halo_fn_t)(ConvHaloArgs);
 template <int TN>
 static conv_halo_fn_t conv_halo_fn(bool t3, bool frag, int sch) {
-  if (frag && sch == 2) {          // (TN = 2 only: 2 x 4 wave layout)
-    if constexpr (TN == 2) return t3 ? conv3x3x3_halo_kernel<2, 3, true, 1, 4> : conv3x3x3_halo_kernel<2, 1, true, 1, 4>;
-  }
   if (frag && sch) return t3 ? conv3x3x3_halo_kernel<TN, 3, true, 1> : conv3x3x3_halo_kernel<TN, 1, true, 1>;
   if (frag) return t3 ? conv3x3x3_halo_kernel<TN, 3, true> : conv3x3x3_halo_kernel<TN, 1, true>;
   return t3 ? conv3x3x3_halo_kernel<TN, 3, false> : conv3x3x3_halo_kernel<TN, 1, false>;
@@ -600,13 +590,10 @@ extern "C" int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, con
   const long blocks = (long)B * ((X + 1) / 2) * ((Y + TY - 1) / TY) * (Z / TZ) * ((Cout + 64 * TN - 1) / (64 * TN));
   if (blocks >= 2147483647L) return OCCF_ESHAPE;
   const bool t3 = terms == 3, fr = a.Fh != nullptr;
-  // OCCF_HALO_WN4 (TN = 2): the 2 x 4 wave layout of the pipelined kernel (selected as sch = 2)
-  const char* e4 = getenv("OCCF_HALO_WN4");              // (read per call: tests switch it inside one process)
-  const int wn4 = e4 ? atoi(e4) : 0;
-  const int sch = fr ? (conv_halo_sched() ? (TN == 2 && wn4 ? 2 : 1) : 0) : 0;
+  const int sch = fr ? (conv_halo_sched() ? 1 : 0) : 0;
   const conv_halo_fn_t fn = TN == 1 ? conv_halo_fn<1>(t3, fr, sch) : TN == 2 ? conv_halo_fn<2>(t3, fr, sch) : conv_halo_fn<3>(t3, fr, sch);
 #ifndef OCCF_EMU
-  static bool attr_set[4][2][2][3] = {};
+  static bool attr_set[4][2][2][2] = {};
   if (!attr_set[TN][t3][fr][sch]) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;

@@ -210,7 +210,6 @@ def test_splitk_small_m_long_k(be, monkeypatch):
 @pytest.mark.parametrize("frag", [True, False])      # weights in fragment order from global memory / slabs through LDS
 def test_conv3x3x3_halo(be, monkeypatch, shape, cin, cout, prec, tol, frag):
     """LDS-halo conv kernel (odd X, ragged Y tiles, Z = 4/8/16/32) vs fp64 conv3d; with bias/ReLU/residual"""
-    monkeypatch.setenv("OCCF_HALO_WN4", "1" if shape[0] == 2 else "0")      # (the 128-channel case also in the 2 x 4 wave layout)
     monkeypatch.setattr(be.ops, "precision", prec)
     monkeypatch.setattr(be.ops, "use_halo_conv", True)
     monkeypatch.setattr(be.ops, "halo_frag", frag)
@@ -282,7 +281,7 @@ def test_linear_head_major_output(be):
     assert out.shape == ref.shape and torch.allclose(out, ref, atol=2e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("kind", ["halo", "halo128wn4", "strided", "linear", "linear192"])
+@pytest.mark.parametrize("kind", ["halo", "strided", "linear", "linear192"])
 def test_groupnorm_stats_from_conv_epilogue(be, kind, monkeypatch):
     """the GroupNorm statistics emitted by the conv / GEMM epilogues equal groupnorm_stats of the output"""
     ops = be.ops
@@ -306,9 +305,6 @@ def test_groupnorm_stats_from_conv_epilogue(be, kind, monkeypatch):
         y = ops.linear(xd, wd, None, w_split=ops.split_bf16(wd), gn=(G, 1e-5, V))
     else:
         B, cin, cout = 2, 32, 64
-        if kind == "halo128wn4":         # 128 output channels in the 2 x 4 wave layout of the pipelined halo kernel
-            monkeypatch.setenv("OCCF_HALO_WN4", "1")
-            cout, kind = 128, "halo"
         X, Y, Z = (4, 16, 8) if kind == "halo" else (8, 16, 8)
         x = paramgen.tensor("gx", (B, X, Y, Z, cin), 1)
         w = paramgen.tensor("gw", (cout, cin, 3, 3, 3), 2, (cin * 27) ** -0.5)
