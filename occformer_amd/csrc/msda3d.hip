@@ -426,7 +426,8 @@ __global__ void msda_zero_word_kernel(unsigned* p) { p[0] = 0u; }
 
 struct MsdaTileCfg {
   int ls, T, M, tiles_x, tiles_y, groups;   // groups > 1: the level is ONE tile, its queries are split over `groups`
-  int CH, passes, lpg;                      // channels per pass, passes per head, lanes per query (CH = 3 * lpg)
+  int CH, passes, lpg;                      // channels per pass, passes per head, lanes per query (CH = cpl * lpg)
+  int cpl;                                  // channels per lane: 3 or 6
   int stride;                               // 1: strided walk over the queries (conflict spreading), 0: linear
 };
 
@@ -442,7 +443,11 @@ __device__ __forceinline__ unsigned long long msda_fx(float x) {
 // work behind the LDS atomics have to come from ONE workgroup; 256 threads: 8.0 ms per call, 512: 5.5, 1024: 4.5);
 // work item = query, `lpg` lanes each (3 channels per lane).  Items are walked with a large odd stride so that the
 // lanes of one wave instruction belong to queries far apart (no measurable effect at these sizes; kept).
+// CPL = channels per lane.  Every lane of a query repeats the query's softmax, the four sample positions and the 32
+// corner weights (~1 000 VALU instructions against 32 CPL LDS atomics): 6 channels per lane instead of 3 halve the
+// lanes that repeat them.
 #define MSDA_TILE_THREADS 1024
+template <int CPL>
 __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kernel(
     const float* __restrict__ offs, const float* __restrict__ logits, const float* __restrict__ dout,
     float* __restrict__ dvalue, float* __restrict__ scratch, const unsigned* __restrict__ absmax_bits, MsdaLevels lv,
@@ -503,7 +508,7 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
   const int n_q = it_end > it_begin ? it_end - it_begin : 0;
   unsigned stride = 1u;                                     // coprime with n_q; j * stride stays below 2^32
   if (tc.stride > 0 && n_q > 1 && n_q < 1000000) stride = (unsigned)(((n_q % 4099) ? 4099 : 4111) % n_q);
-  float* dvb = dvalue + ((long)b * Nv + lv.start[ls]) * E + h * Dh + ch0 + sub * 3;
+  float* dvb = dvalue + ((long)b * Nv + lv.start[ls]) * E + h * Dh + ch0 + sub * CPL;
   for (int u = slot; u < n_q; u += slots) {
     const int it = it_begin + (int)(((unsigned)u * stride) % (unsigned)n_q);
     int lq = 0;
@@ -524,8 +529,10 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
     for (int i = 0; i < LP; ++i) sum += expf(lg[i] - mx);
     const float inv = 1.0f / sum;
     const float* of = offs + (long)(b * Nq + q) * off_ld + h * LP * 3;
-    const float* gp = dout + (long)(b * Nq + q) * E + h * Dh + ch0 + sub * 3;
-    const float g0 = gp[0], g1 = gp[1], g2 = gp[2];
+    const float* gp = dout + (long)(b * Nq + q) * E + h * Dh + ch0 + sub * CPL;
+    float gch[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) gch[c] = gp[c];
     for (int k = 0; k < P; ++k) {
       const int i = ls * P + k;
       const float lz = rz + of[i * 3 + 0] / (float)Zs;
@@ -546,16 +553,14 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
         const float cw = a * (cbx ? tx : 1.f - tx) * (cby ? ty : 1.f - ty) * (cbz ? tz : 1.f - tz);
         const int lx_ = xx - rx0, ly_ = yy - ry0;
         if ((unsigned)lx_ < (unsigned)RX && (unsigned)ly_ < (unsigned)RY) {
-          unsigned long long* t = tile + ((lx_ * RY + ly_) * Zs + zz) * CH + sub * 3;
+          unsigned long long* t = tile + ((lx_ * RY + ly_) * Zs + zz) * CH + sub * CPL;
           const float cs = cw * fx_scale;
-          atomicAdd(t + 0, msda_fx(cs * g0));
-          atomicAdd(t + 1, msda_fx(cs * g1));
-          atomicAdd(t + 2, msda_fx(cs * g2));
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) atomicAdd(t + c, msda_fx(cs * gch[c]));
         } else {
           float* d = dvb + (((long)xx * Ys + yy) * Zs + zz) * E;
-          atomicAdd(d + 0, cw * g0);
-          atomicAdd(d + 1, cw * g1);
-          atomicAdd(d + 2, cw * g2);
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) atomicAdd(d + c, cw * gch[c]);
         }
       }
     }
@@ -619,9 +624,15 @@ static bool msda_tile_cfg(const MsdaLevels& lv, int ls, int Dh, MsdaTileCfg& tc)
   // channels per pass: 12 (4 lanes per query) if a tile of at least 4 x 4 columns fits, else 6
   for (int lpg = Dh >= 12 ? 4 : Dh / 3; lpg >= 2; lpg >>= 1) {
     if (Dh % (3 * lpg)) continue;
-    tc.lpg = lpg;
     tc.CH = 3 * lpg;
     tc.passes = Dh / tc.CH;
+    static const int cpl_env = [] {
+      const char* e = getenv("OCCF_MSDA_CPL");            // 3: the narrow split (one lane per 3 channels)
+      return e ? atoi(e) : 6;
+    }();
+    // (12 per lane measured slower again: 2.38 vs 2.28 ms per call, profiles/r04/r04m_msda_cpl.txt)
+    tc.cpl = (cpl_env >= 6 && tc.CH % 6 == 0) ? 6 : 3;
+    tc.lpg = tc.CH / tc.cpl;
     if ((long)X * Y * Z * tc.CH * 8 <= budget) {        // the whole level as one tile, its queries split over groups
       tc.T = X > Y ? X : Y;
       tc.M = 0;
@@ -731,11 +742,12 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
         tc.stride = strided;
         const size_t lds = (size_t)(tc.T + 2 * tc.M) * (tc.T + 2 * tc.M) * lv.Z[l] * tc.CH * 8;
 #ifndef OCCF_EMU
-        static size_t lds_max = 0;
-        if (lds > lds_max) {
-          hipFuncSetAttribute((const void*)msda3d_bwd_value_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-          lds_max = lds;
+        static size_t lds_max[2] = {0, 0};
+        const int ci = tc.cpl == 6 ? 1 : 0;
+        if (lds > lds_max[ci]) {
+          const void* fn = ci == 1 ? (const void*)msda3d_bwd_value_tile_kernel<6> : (const void*)msda3d_bwd_value_tile_kernel<3>;
+          hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          lds_max[ci] = lds;
         }
 #endif
         const dim3 grid((unsigned)(tc.tiles_x * tc.tiles_y * tc.groups * tc.passes), heads, B);
@@ -752,8 +764,12 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
           const long t = occf_cdiv(occf_cdiv(lanes, rounds), 64) * 64;
           threads = (int)(t < 64 ? 64 : (t > tile_threads ? tile_threads : t));
         }
-        hipLaunchKernelGGL(msda3d_bwd_value_tile_kernel, grid, dim3(threads), lds, st, sampling_offsets, attn_logits, dout,
-                           dvalue, workspace, absmax, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
+        if (tc.cpl == 6)
+          hipLaunchKernelGGL(msda3d_bwd_value_tile_kernel<6>, grid, dim3(threads), lds, st, sampling_offsets, attn_logits,
+                             dout, dvalue, workspace, absmax, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
+        else
+          hipLaunchKernelGGL(msda3d_bwd_value_tile_kernel<3>, grid, dim3(threads), lds, st, sampling_offsets, attn_logits,
+                             dout, dvalue, workspace, absmax, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
         const long total = (long)B * heads * lv.X[l] * lv.Y[l] * lv.Z[l] * head_dim;
         hipLaunchKernelGGL(msda3d_bwd_value_gather_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, workspace,
                            dvalue, lv, tc, B, heads, head_dim);

@@ -192,5 +192,9 @@ done
 l)  # round 4, visit l: halo conv 128 -> 128 / 256 -> 256 with the 2 x 4 wave layout (OCCF_HALO_WN4)
 for v in 0 1; do OCCF_HALO_WN4=$v timeout 200 python scripts/conv_probe.py; done 2>/dev/null | tee $O/r04l_conv_probe_wn4.txt
 ;;
-*) echo "usage: $0 <stage a..l>"; exit 2;;
+m)  # round 4, visit m: msda value-gradient tiles with 3 / 6 channels per lane (scripts/bwd_probe.py msda + the full-size test)
+for v in 3 6 12; do echo -n "OCCF_MSDA_CPL=$v: "; OCCF_MSDA_CPL=$v timeout 120 python scripts/bwd_probe.py msda 2>/dev/null | tail -1; done | tee $O/r04m_msda_cpl.txt
+timeout 600 python -m pytest tests/test_full_size_gpu.py tests/test_bwd_ops.py -m gpu -q -p no:cacheprovider -k "msda" 2>&1 | tail -3
+;;
+*) echo "usage: $0 <stage a..m>"; exit 2;;
 esac
