@@ -196,5 +196,9 @@ m)  # round 4, visit m: msda value-gradient tiles with 3 / 6 channels per lane (
 for v in 3 6 12; do echo -n "OCCF_MSDA_CPL=$v: "; OCCF_MSDA_CPL=$v timeout 120 python scripts/bwd_probe.py msda 2>/dev/null | tail -1; done | tee $O/r04m_msda_cpl.txt
 timeout 600 python -m pytest tests/test_full_size_gpu.py tests/test_bwd_ops.py -m gpu -q -p no:cacheprovider -k "msda" 2>&1 | tail -3
 ;;
-*) echo "usage: $0 <stage a..m>"; exit 2;;
+n)  # round 4, visit n: the five training-parity tests with their figures printed, on the final tree (DepthNet's training convolutions on the library's kernels where the shape rule says so)
+( time timeout 1500 python -m pytest tests/test_workloads_gpu.py -m gpu -q -p no:cacheprovider -s -k training_step ) 2>&1 | grep -v "MIOpen(HIP)" > $O/r04n_pytest_workloads_train.log
+grep "training step vs oracle\|passed\|failed\|^real" $O/r04n_pytest_workloads_train.log | cut -c1-900
+;;
+*) echo "usage: $0 <stage a..n>"; exit 2;;
 esac
