@@ -115,8 +115,10 @@ class _BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(c)
 
     def forward(self, x):
-        y = F.relu(self.bn1(_conv(self, self.conv1, x)))
-        return F.relu(self.bn2(_conv(self, self.conv2, y)) + x)
+        # (noise.relu_gate: a no-op tap, see there -- DepthNet's ReLUs sit behind train-mode BatchNorms and weigh on its
+        # own parameters' gradients; comparisons against the oracle force them like the head's)
+        y = noise.relu_gate(F.relu(self.bn1(_conv(self, self.conv1, x))))
+        return noise.relu_gate(F.relu(self.bn2(_conv(self, self.conv2, y)) + x))
 
     def forward_cl(self, x_cl):
         """channels-last [BN, H, W, 1, C]; BatchNorms folded into the convolutions"""
@@ -132,7 +134,7 @@ class _AtrousBranch(nn.Module):
         self.bn = nn.BatchNorm2d(cout)
 
     def forward(self, x):
-        return F.relu(self.bn(_conv(self, self.atrous_conv, x)))
+        return noise.relu_gate(F.relu(self.bn(_conv(self, self.atrous_conv, x))))
 
     def forward_cl(self, x_cl):
         from . import fused
@@ -165,12 +167,12 @@ class _ImageASPP(nn.Module):
             g = F.batch_norm(g, gp[2].running_mean, gp[2].running_var, gp[2].weight, gp[2].bias, False, 0.0, gp[2].eps)
         else:
             g = gp[2](g)
-        g = gp[3](g).expand(-1, -1, *x.shape[2:])
-        y = torch.cat((self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x), g), 1)
-        y = F.relu(self.bn1(_conv(self, self.conv1, y)))
+        branches = (self.aspp1(x), self.aspp2(x), self.aspp3(x), self.aspp4(x))      # (the reference's order: branches, then pool)
+        g = noise.relu_gate(gp[3](g)).expand(-1, -1, *x.shape[2:])
+        y = torch.cat((*branches, g), 1)
+        y = noise.relu_gate(F.relu(self.bn1(_conv(self, self.conv1, y))))
         if self.training:
             # nn.Dropout(0.5) as an explicit mask from the injectable noise source (occformer_amd/noise.py)
-            from . import noise
             mask = noise.dropout_mask(tuple(y.shape), self.dropout.p, y.device)
             return y if mask is None else y * mask
         return y
@@ -312,7 +314,7 @@ class DepthNet(nn.Module):
                 # is the gradient all-reduce) this layer uses its running statistics
                 m = F.batch_norm(m, self.bn.running_mean, self.bn.running_var, self.bn.weight, self.bn.bias, False,
                                  0.0, self.bn.eps)
-            x = self.reduce_conv[2](self.reduce_conv[1](_conv(self, self.reduce_conv[0], x)))
+            x = noise.relu_gate(self.reduce_conv[2](self.reduce_conv[1](_conv(self, self.reduce_conv[0], x))))
             ctx = _conv(self, self.context_conv, self.context_se(x, self.context_mlp(m)[..., None, None]))
             depth = self.depth_se(x, self.depth_mlp(m)[..., None, None])
             for layer in self.depth_conv:

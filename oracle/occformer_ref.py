@@ -171,8 +171,8 @@ _GATES = None
 class forced_gates:
     """Test infrastructure for gradient comparisons.  The ReLUs of the decoder head (decoder-layer FFNs, the
     mask-embedding MLP: ~1.8 M units, each of which moves EVERY upstream gradient when its gate differs) and of
-    DepthNet's camera MLPs / SE layers ([cameras, 512] vectors that scale whole feature maps) sit on fp32
-    pre-activations; two correct implementations whose pre-activations differ by 1e-6 open a unit at |z| ~ 1e-6
+    DepthNet (its camera MLPs / SE layers: [cameras, 512] vectors that scale whole feature maps; its feature-map ReLUs
+    behind train-mode BatchNorms, which weigh on DepthNet's own parameters) sit on fp32 pre-activations; two correct implementations whose pre-activations differ by 1e-6 open a unit at |z| ~ 1e-6
     differently, and the gradient through it is then 'all' in one and 'nothing' in the other.  Inside this context the
     head's ReLUs take their gates from ``masks`` (bool tensors in call order: the gates the OTHER implementation
     used), so that both sides differentiate the same piecewise-linear function; the context counts where the forced
@@ -309,9 +309,9 @@ def deform_conv2d(x, offset, weight, stride=1, padding=1, dilation=1, groups=1, 
 
 def _basic_block(sd, p, x):
     """mmdet 2.14.0 ResNet BasicBlock (third-party): conv-bn-relu-conv-bn, +id, relu."""
-    y = F.relu(_bn(sd, p + "bn1.", _conv2d(sd, p + "conv1.", x, padding=1)))
+    y = _relu_gated(_bn(sd, p + "bn1.", _conv2d(sd, p + "conv1.", x, padding=1)))
     y = _bn(sd, p + "bn2.", _conv2d(sd, p + "conv2.", y, padding=1))
-    return F.relu(y + x)
+    return _relu_gated(y + x)
 
 
 def _aspp2d_bn(sd, p, x):
@@ -320,12 +320,12 @@ def _aspp2d_bn(sd, p, x):
     for i, dil in enumerate((1, 6, 12, 18), 1):
         q = f"{p}aspp{i}."
         y = _conv2d(sd, q + "atrous_conv.", x, padding=0 if i == 1 else dil, dilation=dil)
-        outs.append(F.relu(_bn(sd, q + "bn.", y)))
+        outs.append(_relu_gated(_bn(sd, q + "bn.", y)))
     g = x.mean((2, 3), keepdim=True)
-    g = F.relu(_bn(sd, p + "global_avg_pool.2.", _conv2d(sd, p + "global_avg_pool.1.", g)))
+    g = _relu_gated(_bn(sd, p + "global_avg_pool.2.", _conv2d(sd, p + "global_avg_pool.1.", g)))
     outs.append(g.expand(-1, -1, *x.shape[2:]))
     y = _conv2d(sd, p + "conv1.", torch.cat(outs, 1))
-    return _dropout(F.relu(_bn(sd, p + "bn1.", y)), _TRAIN["depth_aspp_drop"] if _TRAIN else 0.0)
+    return _dropout(_relu_gated(_bn(sd, p + "bn1.", y)), _TRAIN["depth_aspp_drop"] if _TRAIN else 0.0)
 
 
 def _se(sd, p, x, x_se):
@@ -342,7 +342,7 @@ def depthnet(sd, p, x, mlp_input, dcn_groups=4):
     """ViewTransformerLSSBEVDepth.py:450-504 (DepthNet.forward), eval-mode BN.
     x [B*N, Cin, fH, fW] -> [B*N, D + C, fH, fW] (depth logits first, then context)."""
     m = _bn(sd, p + "bn.", mlp_input.reshape(-1, mlp_input.shape[-1]))
-    x = F.relu(_bn(sd, p + "reduce_conv.1.", _conv2d(sd, p + "reduce_conv.0.", x, padding=1)))
+    x = _relu_gated(_bn(sd, p + "reduce_conv.1.", _conv2d(sd, p + "reduce_conv.0.", x, padding=1)))
     ctx = _se(sd, p + "context_se.", x, _cam_mlp(sd, p + "context_mlp.", m)[..., None, None])
     ctx = _conv2d(sd, p + "context_conv.", ctx)
     d = _se(sd, p + "depth_se.", x, _cam_mlp(sd, p + "depth_mlp.", m)[..., None, None])

@@ -84,8 +84,9 @@ def test_training_step_gradients_vs_oracle(bound):
                                      points_occ=[p.to(d) for p in pts])
     finally:
         noise.record_gates(False)
-    # DepthNet: 2 camera MLPs + 2 SE layers; head: 10 prediction sets x 2 mask-embedding ReLUs + one FFN ReLU per layer
-    assert len(gates) == 4 + 2 * (meta["dec_layers"] + 1) + meta["dec_layers"]
+    # DepthNet: reduce_conv, 2 camera MLPs + 2 SE layers, 3 BasicBlocks x 2, ASPP 4 branches + pool + output;
+    # head: 10 prediction sets x 2 mask-embedding ReLUs + one FFN ReLU per layer
+    assert len(gates) == 17 + 2 * (meta["dec_layers"] + 1) + meta["dec_layers"]
     forced = O.forced_gates(gates)
     cpu_replay = ReplayRNG(rec.tape, torch.device("cpu"))
     ref_losses, ref_grads = _oracle_step(cfg, meta, tc, sd, cams, x, gt_occ, pts, gd, cpu_replay, gates=forced)
