@@ -356,6 +356,19 @@ def test_prefetch_gt_matches_inline_preprocessing(hip):
         assert torch.equal(a, b) and torch.equal(c, d)
         uniq = torch.unique(gt[0])
     assert torch.equal(ref_l[0].cpu(), torch.unique(gt[0]).cpu()[torch.unique(gt[0]).cpu() < 17])
+    # a prefetched sample that never reaches forward_train must not label the NEXT same-shaped ground truth
+    # (the caching allocator hands it the freed address, version 0): entries belong to the tensor object
+    stale = gt.clone()
+    stale[stale < 17] = 3                                      # another sample: a single class
+    model.prefetch_gt(stale)
+    ptr = stale.data_ptr()
+    del stale
+    torch.cuda.synchronize()
+    fresh = gt.clone()                                        # same shape; normally the very address just freed
+    assert model._take_gt_scans(fresh) is None, ("stale entry taken", fresh.data_ptr() == ptr)
+    model.prefetch_gt(fresh)
+    fresh.add_(0)                                             # written to after the scan (version bump): scan again
+    assert model._take_gt_scans(fresh) is None
 
 
 def test_kitti_detector_with_image_branch_wiring(be, monkeypatch):
