@@ -285,7 +285,7 @@ class _Replay:
 
 def train_check_gpu_step(model, net_kwargs, device):
     """ONE more forward_train + backward on the GPU at the (post-training) weights, with its noise draws and its
-    decoder-head ReLU gates taped for the oracle -> (losses, tape, gates); the gradients stay in ``param.grad``"""
+    heavy ReLU gates (noise.relu_gate) taped for the oracle -> (losses, tape, gates); the gradients stay in ``param.grad``"""
     from occformer_amd import noise
     from occformer_amd.training import DeviceRNG
     rec = noise.RecordedRNG(DeviceRNG(device, 1234))
@@ -324,12 +324,12 @@ def train_check(model, gl, cpu_losses, cpu_grads, forced, n_draws):
     return dict(max_rel_loss_diff=worst, grad_rel_l2=(num / max(den, 1e-30)) ** 0.5,
                 per_parameter_rel_l2_quantiles={"50%": q(0.5), "90%": q(0.9), "99%": q(0.99), "100%": q(1.0)},
                 parameters_compared=len(per), noise_draws_replayed=n_draws,
-                head_relu_gates={"units": forced.units, "gated_differently": forced.flipped,
+                forced_relu_gates={"units": forced.units, "gated_differently": forced.flipped,
                                  "largest_abs_preactivation_among_them": forced.max_abs_z},
                 what="GPU forward_train + backward vs the CPU oracle's train_step: same weights (after the timed "
-                     "optimizer steps), same inputs, the GPU step's noise tape replayed by the oracle, the decoder "
-                     "head's ReLU gates taken from the GPU step (units whose pre-activations straddle zero within "
-                     "rounding: counted above); losses relative to max(1, |loss|), gradients as relative L2 of the "
+                     "optimizer steps), same inputs, the GPU step's noise tape replayed by the oracle, the ReLU gates "
+                     "of the decoder head's MLPs and of DepthNet taken from the GPU step (units whose pre-activations "
+                     "straddle zero within rounding: counted above); losses relative to max(1, |loss|), gradients as relative L2 of the "
                      "whole vector / per parameter")
 
 

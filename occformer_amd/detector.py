@@ -11,6 +11,7 @@ PyTorch-ROCm/MIOpen (outside the hand-written kernel scope
 """
 import collections
 import time
+import weakref
 
 import numpy as np
 import torch
@@ -360,7 +361,6 @@ class OccupancyFormer(nn.Module):
         # an entry belongs to the TENSOR OBJECT it was computed from (weak reference), never to its address: the caching
         # allocator hands the next same-shaped ground truth the address (and version 0) of a freed one, and an entry
         # whose sample never reached forward_train would then label another sample
-        import weakref
         q = self.__dict__.setdefault("_gt_prefetched", [])
         q[:] = [e for e in q if e[0]() is not None and e[0]() is not gt_occ]
         q.append((weakref.ref(gt_occ), gt_occ._version, [s[0] for s in scans], host, done))

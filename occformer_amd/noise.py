@@ -40,7 +40,7 @@ def dropout_mask(shape, p, device):
     return (u >= p).float() / (1.0 - p)
 
 
-# ---- debug tap for gradient comparisons (tests, bench.py's check): the gates of the decoder head's ReLUs -------------
+# ---- debug tap for gradient comparisons (tests, bench.py's check): the gates of the decoder head's and DepthNet's ReLUs ----
 _gates = None
 
 
@@ -52,8 +52,9 @@ def record_gates(on=True):
 
 
 def relu_gate(h):
-    """called by the decoder head on every ReLU OUTPUT of its small MLPs; a no-op unless a comparison asked for the
-    gates (oracle.occformer_ref.forced_gates explains why)"""
+    """called on the ReLU OUTPUTS of the decoder head's small MLPs and of DepthNet (camera MLPs, SE layers, the
+    feature-map ReLUs behind its BatchNorms) in the training graph; a no-op unless a comparison asked for the gates
+    (oracle.occformer_ref.forced_gates explains why).  The call ORDER is the oracle's evaluation order."""
     if _gates is not None:
         _gates.append(h.detach() > 0)
     return h

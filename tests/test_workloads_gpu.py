@@ -209,7 +209,7 @@ def test_workload_training_step_vs_oracle(hip, name):
               f"gradient rel L2 {whole:.2e}  per-parameter rel L2 quantiles 50/90/99/100 % = "
               + " / ".join(f"{qs[q]:.1e}" for q in (0.5, 0.9, 0.99, 1.0)) + f" over {len(per)} parameters; worst: "
               + ", ".join(f"{k} {e:.1e}" for e, k in per[-3:])
-              + f"; head ReLU gates: {forced.flipped} of {forced.units} units gated differently by the two "
+              + f"; forced ReLU gates: {forced.flipped} of {forced.units} units gated differently by the two "
               f"implementations, largest |pre-activation| among them {forced.max_abs_z:.1e} "
               f"({forced.max_rel_z:.1e} of its tensor's RMS)")
         return worst_loss, whole, qs, pairs, forced
