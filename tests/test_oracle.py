@@ -75,3 +75,30 @@ def test_oracle_live_vs_reference_encoder_block():
         out = O.dualpath_block({"e." + k: v for k, v in sd.items()}, "e.layers.0.0.", x, 1, False, 8)
         out = O.dualpath_block({"e." + k: v for k, v in sd.items()}, "e.layers.0.1.", out, 1, True, 8)
     assert torch.allclose(out, ref, atol=1e-5)
+
+
+def test_forced_gates_mechanism():
+    """oracle.occformer_ref.forced_gates (test infrastructure of the gradient comparisons): with a unit's OWN gates the
+    forced ReLU is F.relu in value and gradient; a gate forced the other way is counted, its pre-activation reported,
+    and the gradient follows the forced gate (what makes two implementations differentiate the same function)"""
+    from oracle import occformer_ref as O
+    z = torch.tensor([[-0.5, 2e-7, 0.25, -3e-7], [1.5, -1.0, 4e-7, 0.75]], requires_grad=True)
+    own = (z.detach() > 0)
+    with O.forced_gates([own]) as g:
+        y = O._relu_gated(z)
+    assert g.i == 1 and g.flipped == 0 and g.units == z.numel()
+    assert torch.equal(y, torch.relu(z))
+    (gy,) = torch.autograd.grad(y.sum(), z)
+    assert torch.equal(gy, own.float())
+    other = own.clone()
+    other[0, 1] = False            # the other implementation saw 2e-7 as <= 0
+    other[0, 3] = True             # ... and -3e-7 as > 0
+    with O.forced_gates([other]) as g:
+        y2 = O._relu_gated(z)
+        with pytest.raises(AssertionError):
+            O._relu_gated(z)       # more ReLUs evaluated than gates recorded
+    assert g.flipped == 2 and abs(g.max_abs_z - 3e-7) < 1e-12 and g.max_rel_z < 1e-6
+    (gy2,) = torch.autograd.grad(y2.sum(), z)
+    assert torch.equal(gy2, other.float())
+    assert float((y2 - torch.relu(z)).abs().max()) <= 3.1e-7      # the forward moves by the flipped pre-activations only
+    assert O._GATES is None and torch.equal(O._relu_gated(z), torch.relu(z))      # outside the context: plain ReLU
