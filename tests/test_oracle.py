@@ -102,3 +102,25 @@ def test_forced_gates_mechanism():
     assert torch.equal(gy2, other.float())
     assert float((y2 - torch.relu(z)).abs().max()) <= 3.1e-7      # the forward moves by the flipped pre-activations only
     assert O._GATES is None and torch.equal(O._relu_gated(z), torch.relu(z))      # outside the context: plain ReLU
+
+
+def test_synthetic_rig_has_no_noise_amplifying_camera_columns():
+    """DepthNet normalises the 27 camera scalars with a train-mode BatchNorm1d over the cameras
+    (ViewTransformerLSSBEVDepth.py:453,489).  A column that is constant but whose mean does not round back to the value
+    ((x1 + .. + x6) / 6 != x in fp32) comes out as rounding noise / sqrt(eps): +-0.02 for fx = 557 repeated six times --
+    backend-dependent, it put the camera-MLP gradients of GPU and CPU 3e-2 apart.  The
+    bench / parity rig must not contain one: every column either varies or is reproduced exactly by its own mean."""
+    from occformer_amd import configs
+    from oracle import occformer_ref as O
+    for name in ("nusc_r50_200", "nusc_r50_ref128", "nusc_r101"):
+        _, meta = configs.workload(name)
+        inp, _, _ = configs.synthetic_sample(meta, "cpu", seed=0)
+        m = O.mlp_input_from_cameras(*inp[1:7])[0]                       # [6, 27]
+        mean = m.sum(0) / m.shape[0]
+        for c in range(m.shape[1]):
+            col = m[:, c]
+            constant = bool((col == col[0]).all())
+            if constant:
+                assert float(mean[c]) == float(col[0]), (name, c, float(col[0]), float(mean[c]))
+            else:
+                assert float(col.std()) > 1e-4 * max(1.0, float(col.abs().max())), (name, c)
