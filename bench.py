@@ -227,8 +227,9 @@ def cpu_baseline(model, meta, img_inputs, points):
 def cpu_baseline_train(model, cfg, meta, img_inputs, targets, tape, gates):
     """The oracle's training step (train-mode forward + torch.autograd backward of the summed losses,
     oracle/occformer_train_ref.train_step) on the host cores: one sample of the same workload, on the noise draws the
-    GPU step just consumed (``tape``, replayed in call order) and with the decoder head's ReLU gates the GPU step used
-    (``gates``: oracle.occformer_ref.forced_gates -- both sides differentiate the same piecewise-linear function)."""
+    GPU step just consumed (``tape``, replayed in call order).  Two passes: (1) the oracle as it is -- the TIMED
+    ``cpu_baseline`` and the UNGATED side of ``check``; (2) with the heavy ReLU gates the GPU step used (``gates``:
+    oracle.occformer_ref.forced_gates -- both sides differentiate the same piecewise-linear function): the gated side."""
     from oracle import occformer_ref as O
     from oracle import occformer_train_ref as T
     from occformer_amd import configs
@@ -237,20 +238,24 @@ def cpu_baseline_train(model, cfg, meta, img_inputs, targets, tape, gates):
     ocfg = configs.oracle_train_cfg(cfg, meta, class_weight=model.pts_bbox_head.class_weight)
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
+    oargs = (sd, img_inputs[0].cpu(), tuple(t.cpu() for t in img_inputs[1:7]), gt_depths.cpu(), gt_occ.cpu(),
+             None if points is None else [p.cpu() for p in points], ocfg)
+    replay = _Replay(tape, torch.device("cpu"))
+    t0 = time.perf_counter()
+    losses_u, grads_u = T.train_step(*oargs, rng=replay)
+    dt = time.perf_counter() - t0
+    if replay.i != len(tape):
+        raise RuntimeError("the oracle consumed a different number of noise draws than the GPU step")
     replay = _Replay(tape, torch.device("cpu"))
     forced = O.forced_gates(gates)
-    t0 = time.perf_counter()
-    losses, grads = T.train_step(sd, img_inputs[0].cpu(), tuple(t.cpu() for t in img_inputs[1:7]), gt_depths.cpu(),
-                                 gt_occ.cpu(), None if points is None else [p.cpu() for p in points], ocfg, rng=replay,
-                                 gates=forced)
-    dt = time.perf_counter() - t0
+    losses, grads = T.train_step(*oargs, rng=replay, gates=forced)
     if replay.i != len(tape) or forced.i != len(gates):
-        raise RuntimeError("the oracle consumed a different number of noise draws / head ReLUs than the GPU step")
+        raise RuntimeError("the oracle consumed a different number of noise draws / heavy ReLUs than the GPU step")
     return dict(value=1.0 / dt, unit="samples/s", cores=cores, kind="port",
                 sample="1 training step (fwd + bwd) of the same workload on the CPU oracle, on the weights the timed "
                        "GPU steps left behind "
                        f"(oracle/occformer_train_ref.train_step, fp32, torch CPU autograd, {cores} threads): {dt:.1f} s"), \
-        {k: float(v) for k, v in losses.items()}, grads, forced
+        {k: float(v) for k, v in losses.items()}, grads, forced, ({k: float(v) for k, v in losses_u.items()}, grads_u)
 
 
 class _Replay:
@@ -304,9 +309,10 @@ def train_check_gpu_step(model, net_kwargs, device):
     return {k: float(v.detach()) for k, v in losses.items()}, rec.tape, gates
 
 
-def train_check(model, gl, cpu_losses, cpu_grads, forced, n_draws):
-    """`losses` (GPU) and `cpu_losses` are the same quantity (same weights, inputs, noise); `check` says how far apart
-    they and the gradients are"""
+MAX_REL_Z = 5e-4        # a forced gate may differ from the oracle's own only where |z| <= this x the tensor's RMS
+
+
+def _grad_figures(model, gl, cpu_losses, cpu_grads):
     worst = max(abs(gl[k] - v) / max(1.0, abs(v)) for k, v in cpu_losses.items())
     named = dict(model.named_parameters())
     num = den = 0.0
@@ -321,16 +327,30 @@ def train_check(model, gl, cpu_losses, cpu_grads, forced, n_draws):
             per.append((d / max(n, 1e-30)) ** 0.5)
     per.sort()
     q = lambda f: per[int(f * (len(per) - 1))] if per else None
-    return dict(max_rel_loss_diff=worst, grad_rel_l2=(num / max(den, 1e-30)) ** 0.5,
-                per_parameter_rel_l2_quantiles={"50%": q(0.5), "90%": q(0.9), "99%": q(0.99), "100%": q(1.0)},
-                parameters_compared=len(per), noise_draws_replayed=n_draws,
+    return worst, (num / max(den, 1e-30)) ** 0.5, {"50%": q(0.5), "90%": q(0.9), "99%": q(0.99), "100%": q(1.0)}, len(per)
+
+
+def train_check(model, gl, cpu_losses, cpu_grads, forced, n_draws, ungated):
+    """`losses` (GPU) and `cpu_losses` are the same quantity (same weights, inputs, noise); `check` says how far apart
+    they and the gradients are -- with the heavy ReLU gates of the GPU step forced into the oracle (the figure the
+    parity gate is held to) AND with the oracle on its own gates (``*_ungated``: what the forcing buys on this box)"""
+    worst, whole, quant, n = _grad_figures(model, gl, cpu_losses, cpu_grads)
+    worst_u, whole_u, quant_u, _ = _grad_figures(model, gl, *ungated)
+    return dict(max_rel_loss_diff=worst, grad_rel_l2=whole, per_parameter_rel_l2_quantiles=quant,
+                max_rel_loss_diff_ungated=worst_u, grad_rel_l2_ungated=whole_u,
+                per_parameter_rel_l2_quantiles_ungated=quant_u,
+                parameters_compared=n, noise_draws_replayed=n_draws,
                 forced_relu_gates={"units": forced.units, "gated_differently": forced.flipped,
-                                 "largest_abs_preactivation_among_them": forced.max_abs_z},
+                                 "largest_abs_preactivation_among_them": forced.max_abs_z,
+                                 "largest_preactivation_over_tensor_rms": forced.max_rel_z,
+                                 "bound_on_that": MAX_REL_Z},
                 what="GPU forward_train + backward vs the CPU oracle's train_step: same weights (after the timed "
-                     "optimizer steps), same inputs, the GPU step's noise tape replayed by the oracle, the ReLU gates "
-                     "of the decoder head's MLPs and of DepthNet taken from the GPU step (units whose pre-activations "
-                     "straddle zero within rounding: counted above); losses relative to max(1, |loss|), gradients as relative L2 of the "
-                     "whole vector / per parameter")
+                     "optimizer steps), same inputs, the GPU step's noise tape replayed by the oracle.  Gated figures: "
+                     "the ReLU gates of the decoder head's MLPs, of DepthNet and of the BEV ASPP's image-level vector "
+                     "taken from the GPU step (units whose pre-activations straddle zero within rounding: counted "
+                     "above; bench.py exits non-zero when one of them is further from zero than the bound).  "
+                     "*_ungated: the oracle on its own gates.  Losses relative to max(1, |loss|), gradients as "
+                     "relative L2 of the whole vector / per parameter")
 
 
 WORKLOAD_DESC = {
@@ -340,6 +360,59 @@ WORKLOAD_DESC = {
     "kitti_effb7_256lit": "SemanticKITTI EfficientNetB7 mono 384x1280, 256x256x32 voxels (lss_downsample 1)",
     "nusc_r101": "nuScenes R101-DCN 896x1600, 200x200x16 voxels",
 }
+
+
+def raw_images(meta, device, seed=0):
+    g = torch.Generator().manual_seed(7 + seed)
+    return torch.randn(1, meta["ncams"], 3, *meta["input_size"], generator=g).to(device)
+
+
+def set_image_dtype(model, image_dtype):
+    if image_dtype == "bf16":
+        model.image_dtype = torch.bfloat16
+        model.img_backbone.to(memory_format=torch.channels_last)
+        model.img_neck.to(memory_format=torch.channels_last)
+
+
+def forward_from_images(workload, device, image_dtype, steps):
+    """the forward as the reference's own fps harness times it (tools/analysis_tools/benchmark.py:69-94:
+    ``model(return_loss=False, **data)`` from the raw images): a second detector WITH the workload's image branch,
+    random weights, ``steps`` timed inference steps + one step with the stage timers"""
+    from occformer_amd import configs
+    from occformer_amd.registry import build_model
+    cfg, meta = configs.workload(workload, with_image_branch=True)
+    torch.manual_seed(1)
+    m = build_model(cfg).to(device).eval()
+    set_image_dtype(m, image_dtype)
+    img_inputs, metas, points = synthetic_sample(meta, device, seed=0)
+    img_inputs[0] = raw_images(meta, device)
+
+    def step():
+        with torch.no_grad():
+            vox, _, _ = m.extract_feat(None, img_inputs, metas)
+            t = m._tick("", 0.0)
+            res = m.pts_bbox_head.simple_test(vox, metas, points=points)
+            m._tick("mask2former_head", t)
+            return res
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    m.record_time = True
+    m.time_stats.clear()
+    step()
+    m.record_time = False
+    stages = {k: round(1e3 * sum(v) / len(v), 3) for k, v in m.time_stats.items() if k}
+    del m
+    torch.cuda.empty_cache()
+    return {"metric": "samples/sec forward FROM THE RAW IMAGES (img_backbone + img_neck on PyTorch-ROCm / MIOpen, "
+                      f"{image_dtype}, inside the timed region -> inference hot path) -- north_star target >= 30",
+            "value": steps / dt, "unit": "samples/s", "steps": steps, "warmup": 3, "ms_per_step": 1e3 * dt / steps,
+            "input": [1, meta["ncams"], 3, *meta["input_size"]], "stages_ms": stages}
 
 
 def launch_ranks(n, argv=None):
@@ -404,9 +477,9 @@ def main():
     ap.add_argument("--precision", default=None, choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the dense contractions (default: the library default, bf16x3)")
     ap.add_argument("--from-images", action="store_true",
-                    help="forward mode, nusc_r50 workloads: start at the raw images [1, 6, 3, 256, 704] -- the R50 + "
-                         "SECONDFPN image branch (PyTorch-ROCm / MIOpen, bf16 channels_last) runs inside the timed "
-                         "region and is reported as stage img_encoder")
+                    help="start at the raw images [1, N, 3, H, W]: the workload's img_backbone + img_neck "
+                         "(PyTorch-ROCm / MIOpen, --image-dtype) run inside the timed region, forward or training step "
+                         "(stage img_encoder in forward mode)")
     ap.add_argument("--image-dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-bn", action="store_true",
@@ -452,9 +525,10 @@ def main():
     cfg, meta = configs.workload(args.workload)
     train = args.mode == "train"
     if args.from_images:
-        if train or not args.workload.startswith("nusc_r50"):
-            raise SystemExit("--from-images: forward mode on the nusc_r50 workloads")
-        cfg, meta2 = configs.nusc_r50("200" if args.workload == "nusc_r50_200" else "reference", with_image_branch=True)
+        # the reference's own entry: model(**data) from the raw images (tools/analysis_tools/benchmark.py:69-94 for the
+        # forward, occupancyformer.py:132-199 for the training step) -- the workload's img_backbone / img_neck
+        # (PyTorch-ROCm / MIOpen; DCNv2 of the R101 on csrc/dcn.hip) run inside the timed region
+        cfg, meta = configs.workload(args.workload, with_image_branch=True)
         args.no_cpu_baseline = True            # the oracle starts at the neck features
     if train and meta.get("kitti"):
         cfg["train_cfg"] = dict(pts=configs.train_cfg_pts())
@@ -463,12 +537,8 @@ def main():
         dist_utils.convert_sync_batchnorm(model)
     img_inputs, metas, points = synthetic_sample(meta, device, seed=rank)
     if args.from_images:
-        g = torch.Generator().manual_seed(7 + rank)
-        img_inputs[0] = torch.randn(1, meta["ncams"], 3, *meta["input_size"], generator=g).to(device)
-        if args.image_dtype == "bf16":
-            model.image_dtype = torch.bfloat16
-            model.img_backbone.to(memory_format=torch.channels_last)
-            model.img_neck.to(memory_format=torch.channels_last)
+        img_inputs[0] = raw_images(meta, device, rank)
+        set_image_dtype(model, args.image_dtype)
     targets = configs.synthetic_targets(meta, device, seed=rank) if train else None
 
     def step_forward():
@@ -574,12 +644,15 @@ def main():
             dist.destroy_process_group()
         return
     roof = roofline(timed_census, kernels, prec, args.steps)
+    gate_failure = None
     what = "fwd+bwd" if train else "forward"
     out = {
         "metric": f"samples/sec ({meta['ncams']}-cam frame) {what}, {WORKLOAD_DESC[args.workload]}, "
-                  + ("training step of the hot path from image-neck features (forward_train + backward + gradient "
-                     "all-reduce + grad-clip + AdamW)" if train else
-                     ("raw images -> R50 + SECONDFPN image branch (MIOpen, %s) -> " % args.image_dtype
+                  + ("training step of the hot path from %s (forward_train + backward + gradient all-reduce + "
+                     "grad-clip + AdamW)" % ("the raw images (img_backbone + img_neck on PyTorch-ROCm / MIOpen, %s)"
+                                             % args.image_dtype if args.from_images else "image-neck features")
+                     if train else
+                     ("raw images -> img_backbone + img_neck (PyTorch-ROCm / MIOpen, %s) -> " % args.image_dtype
                       if args.from_images else "") +
                      "hot path (LSS voxel pooling -> dual-path encoder -> pixel decoder -> occupancy decoder)"),
         "value": world * args.steps / dt, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -604,6 +677,8 @@ def main():
     if train:
         out["losses"] = {k: round(float(v.detach()), 5) for k, v in res_gpu.items()}
         out["forward"] = forward_rec
+        if forward_rec is not None and not args.from_images:
+            out["forward_from_images"] = forward_from_images(args.workload, device, args.image_dtype, max(20, args.steps))
     if world == 1 and not args.no_cpu_baseline:
         if train:
             if forward_rec is not None:
@@ -634,8 +709,12 @@ def main():
                 base["sample"] = "FORWARD ONLY (the CPU training step did not fit: %s); " % type(e).__name__ + base["sample"]
                 out["cpu_baseline"] = base
             if cpu_leg is not None:
-                out["cpu_baseline"], out["cpu_losses"], cpu_grads, forced = cpu_leg
-                out["check"] = train_check(model, gl, out["cpu_losses"], cpu_grads, forced, len(tape))
+                out["cpu_baseline"], out["cpu_losses"], cpu_grads, forced, ungated = cpu_leg
+                out["check"] = train_check(model, gl, out["cpu_losses"], cpu_grads, forced, len(tape), ungated)
+                if forced.max_rel_z > MAX_REL_Z or forced.flipped > 1e-4 * forced.units:
+                    gate_failure = (f"bench.py: {forced.flipped} of {forced.units} forced ReLU gates differ from the "
+                                    f"oracle's own, the furthest at |z| = {forced.max_rel_z:.1e} of its tensor's RMS "
+                                    f"(bound {MAX_REL_Z:.0e}, at most 1e-4 of the units): the forcing is not legitimate")
         else:
             base, res_cpu = cpu_baseline(model, meta, img_inputs, points)
             out["cpu_baseline"] = base
@@ -647,6 +726,8 @@ def main():
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if gate_failure:
+        raise SystemExit(gate_failure)
 
 
 if __name__ == "__main__":

@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from . import fused
+from . import fused, noise
 from .ops import get_ops
 
 _WT_CACHE = {}
@@ -143,8 +143,10 @@ class InProj(torch.autograd.Function):
         return dxs[0], dxs[1], dxs[2], torch.cat(dws, 0), torch.cat(dbs, 0)
 
 
-def linear(x, lin, act=0, residual=None):
-    return Linear.apply(x, lin.weight, lin.bias, act, residual, None)
+def linear(x, lin, act=0, residual=None, heavy_gate=False):
+    """``heavy_gate``: how the comparison tap (noise.relu_gate) classifies this layer's ReLU units"""
+    y = Linear.apply(x, lin.weight, lin.bias, act, residual, None)
+    return noise.relu_gate(y, heavy_gate) if act == 1 else y
 
 
 def _conv_geometry(conv):
@@ -267,7 +269,23 @@ class GroupNorm(torch.autograd.Function):
 
 
 def group_norm(x_cl, gn, relu=False, tokens=False, residual=None, stats=None):
-    return GroupNorm.apply(x_cl, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, tokens, residual, stats)
+    y = GroupNorm.apply(x_cl, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, tokens, residual, stats)
+    if relu and noise.gates_wanted(False):
+        noise.relu_gate(y, False, lambda: _gn_relu_gate(x_cl, gn, y, tokens, residual, stats))
+    return y
+
+
+def _gn_relu_gate(x_cl, gn, y, tokens, residual, stats):
+    """comparison runs only: the ReLU gate of y = relu(GN(x)) [+ residual | + token slot] in the reference's
+    channel-first layout"""
+    if residual is not None:
+        ops = get_ops()
+        x = x_cl.detach().contiguous()
+        st = stats if stats is not None else ops.groupnorm_stats(x, gn.num_groups, gn.eps)
+        y = ops.groupnorm_apply(x, st, gn.weight.detach(), gn.bias.detach(), gn.num_groups, True, False, None)
+    elif tokens:
+        y = y.detach()[:, :, :, :-1]
+    return (y.detach() > 0).movedim(-1, 1)
 
 
 def conv_gn(x_cl, conv_mod, gn, relu=False, tokens=False, residual=None):

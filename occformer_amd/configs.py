@@ -132,10 +132,34 @@ WORKLOADS = {
 }
 
 
-def workload(name):
-    """(model config, meta) of a named bench / parity workload (all start at the image-neck features)"""
+def image_branch(name):
+    """the 2-D image branch of a workload's reference config (img_backbone, img_neck):
+    occformer_nusc_r50_256x704.py:60-74, occformer_nusc_r101_896x1600.py:68-85, occformer_kitti.py:66-80 (without the
+    pretrained-checkpoint ``init_cfg``: there is no network for checkpoints, weights are random)"""
+    if name.startswith("kitti"):
+        return (dict(type="CustomEfficientNet", arch="b7", drop_path_rate=0.2, frozen_stages=0, norm_eval=False,
+                     out_indices=(2, 3, 4, 5, 6), with_cp=True),
+                dict(type="SECONDFPN", in_channels=[48, 80, 224, 640, 2560], upsample_strides=[0.25, 0.5, 1, 2, 2],
+                     out_channels=[128, 128, 128, 128, 128]))
+    neck = dict(type="SECONDFPN", in_channels=[256, 512, 1024, 2048], upsample_strides=[0.25, 0.5, 1, 2],
+                out_channels=[128, 128, 128, 128])
+    if name == "nusc_r101":
+        return (dict(type="ResNet", depth=101, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                     norm_cfg=dict(type="BN2d", requires_grad=False), norm_eval=True, style="caffe", with_cp=True,
+                     dcn=dict(type="DCNv2", deform_groups=1, fallback_on_stride=False),
+                     stage_with_dcn=(False, False, True, True)), neck)
+    return (dict(type="ResNet", depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=0,
+                 norm_cfg=dict(type="BN", requires_grad=True), norm_eval=False, style="pytorch"), neck)
+
+
+def workload(name, with_image_branch=False):
+    """(model config, meta) of a named bench / parity workload.  All start at the image-neck features unless
+    ``with_image_branch``: then the config carries the reference's img_backbone / img_neck and the sample's first input
+    is the raw image batch [B, N, 3, H, W]"""
     cfg, meta = WORKLOADS[name]()
     meta["workload"] = name
+    if with_image_branch:
+        cfg["img_backbone"], cfg["img_neck"] = image_branch(name)
     return cfg, meta
 
 

@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
           for (int i = 0; i < NA; ++i) { OCCF_SCHED_GROUP(0x008, 1); OCCF_SCHED_GROUP(0x100, 1); }
 #pragma unroll
           for (int i = 0; i < NF; ++i) { OCCF_SCHED_GROUP(0x008, 1); OCCF_SCHED_GROUP(0x020, 1); }
-          OCCF_SCHED_GROUP(0x008, NM - NA - NF);
+          OCCF_SCHED_GROUP(0x008, (NM > NA + NF ? NM - NA - NF : 0));   // (TN = 1, one term: 2 MFMAs per k-step, 3 slots asked)
         }
         OCCF_SCHED_FENCE();
         if (++tap == 27) { tap = 0; ++cc; }

@@ -10,6 +10,7 @@ constructor keys, sub-module attribute names, ``forward(return_loss=...)`` dispa
 PyTorch-ROCm/MIOpen (outside the hand-written kernel scope).
 """
 import collections
+import contextlib
 import time
 import weakref
 
@@ -70,9 +71,20 @@ class ModulatedDeformConv2dPack(nn.Module):
     def forward(self, x):
         B, C, H, W = x.shape
         k, dg = self.k, self.dg
-        o1, o2, logit = torch.chunk(self.conv_offset(x), 3, dim=1)
-        offset = torch.cat((o1, o2), 1)                                  # [B, dg * 2 * k*k, Ho, Wo]
-        mask = torch.sigmoid(logit)                                       # [B, dg * k*k, Ho, Wo]
+        # a reduced-precision image branch (bench.py --image-dtype bf16, torch.autocast) crosses this layer as an fp32
+        # ISLAND, and the island starts HERE: the sampling positions are fp32 quantities (a bf16 offset has 3
+        # fractional bits at 8 pixels), so the offset convolution and the sigmoid run outside autocast on the fp32 input
+        # (under autocast they would already return bf16 -- ADVICE r4), the gather / modulation / contraction on the
+        # fp32 kernels, and the result returns in the caller's dtype: casts of [B, C, H, W] instead of a second
+        # implementation
+        dt = x.dtype
+        autocast = x.is_cuda and torch.is_autocast_enabled()
+        if dt != torch.float32:
+            x = x.float()
+        with torch.autocast("cuda", enabled=False) if autocast else contextlib.nullcontext():
+            o1, o2, logit = torch.chunk(self.conv_offset(x), 3, dim=1)
+            offset = torch.cat((o1, o2), 1).float()                      # [B, dg * 2 * k*k, Ho, Wo]
+            mask = torch.sigmoid(logit).float()                          # [B, dg * k*k, Ho, Wo]
         if not (x.is_cuda or self.force_hip):
             if ModulatedDeformConv2dPack.cpu_reference is None:
                 raise RuntimeError("ModulatedDeformConv2dPack: the deformable sampling runs on the library's kernels "
@@ -81,13 +93,6 @@ class ModulatedDeformConv2dPack(nn.Module):
         if (C // dg) % 4 != 0 or self.dilation != 1:
             raise NotImplementedError(f"ModulatedDeformConv2dPack: {C // dg} channels per deform group / dilation "
                                       f"{self.dilation} (the kernels take multiples of 4 channels, dilation 1)")
-        # a reduced-precision image branch (bench.py --image-dtype bf16) crosses this layer as an fp32 ISLAND: the
-        # sampling positions are fp32 quantities (a bf16 offset has 3 fractional bits at 8 pixels), the gather /
-        # modulation / contraction run on the fp32 kernels, the result returns in the caller's dtype -- two casts of
-        # [B, C, H, W] per layer instead of a second implementation
-        dt = x.dtype
-        if dt != torch.float32:
-            x, offset, mask = x.float(), offset.float(), mask.float()
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
             # training: im2col / col2im(+coord, +mask) kernels and the split-bf16 contractions as one autograd node
             # (occf_modulated_deform_col2im); conv_offset and the sigmoid stay on ATen autograd
@@ -98,6 +103,8 @@ class ModulatedDeformConv2dPack(nn.Module):
             out = out if self.bias is None else out + self.bias.view(1, -1, 1, 1)
         else:
             out = self._forward_hip(x, offset, mask)
+        # (under autocast an fp32 input means the caller's ops produce the autocast dtype: hand that back)
+        dt = torch.get_autocast_gpu_dtype() if autocast and dt == torch.float32 else dt
         return out if dt == torch.float32 else out.to(dt)
 
 

@@ -184,10 +184,12 @@ class _ASPP(nn.Module):
         B, X, Y, _, C = x_cl.shape
         # image-level branch: mean over (X, Y) -> 1x1 conv -> GN -> ReLU -> broadcast
         # (bilinear upsampling of a 1x1 map with align_corners=True is a broadcast)
+        branches = (self.aspp1(x_cl), self.aspp2(x_cl), self.aspp3(x_cl), self.aspp4(x_cl))   # (the reference's order)
         g = x_cl.mean((1, 2), keepdim=True)
-        g = F.relu(self.global_avg_pool[2](self.global_avg_pool[1](g.reshape(B, C, 1, 1))))
+        # (noise.relu_gate: the comparison tap -- C units that scale the whole map; a no-op unless a comparison records)
+        g = noise.relu_gate(F.relu(self.global_avg_pool[2](self.global_avg_pool[1](g.reshape(B, C, 1, 1)))))
         g = g.view(B, 1, 1, 1, C).expand(B, X, Y, 1, C)
-        y = torch.cat((self.aspp1(x_cl), self.aspp2(x_cl), self.aspp3(x_cl), self.aspp4(x_cl), g), -1)
+        y = torch.cat((*branches, g), -1)
         if self.training:
             y = A.conv_gn(y, self.conv1, self.bn1, relu=True)
             mask = noise.dropout_mask((B, C, X, Y), self.dropout.p, x_cl.device)     # aspp.py:103,122

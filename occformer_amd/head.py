@@ -91,7 +91,7 @@ class _DecoderLayer(nn.Module):
                             self.norms[0])
             q = A.layernorm(self.attentions[1](q, q, q, qpos, qpos), self.norms[1])
             ffn = self.ffns[0].layers
-            y = A.linear(noise.relu_gate(A.linear(q, ffn[0][0], act=1)), ffn[1], residual=q)
+            y = A.linear(A.linear(q, ffn[0][0], act=1, heavy_gate=True), ffn[1], residual=q)
             return A.layernorm(y, self.norms[2])
         q = fused.layernorm(self.attentions[0](q, key, key, qpos, key_pos, blocked, row_open, key_with_pos, kv),
                             self.norms[0])
@@ -208,7 +208,7 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
         d = A.layernorm(decoder_out, self.transformer_decoder.post_norm)
         cls_pred = A.linear(d, self.cls_embed)
         me = self.mask_embed
-        mask_embed = A.linear(noise.relu_gate(A.linear(noise.relu_gate(A.linear(d, me[0], act=1)), me[2], act=1)), me[4])
+        mask_embed = A.linear(A.linear(A.linear(d, me[0], act=1, heavy_gate=True), me[2], act=1, heavy_gate=True), me[4])
         B, Q = mask_embed.shape[:2]
         with torch.no_grad():
             dense, am = None, None

@@ -40,23 +40,35 @@ def dropout_mask(shape, p, device):
     return (u >= p).float() / (1.0 - p)
 
 
-# ---- debug tap for gradient comparisons (tests, bench.py's check): the gates of the decoder head's and DepthNet's ReLUs ----
+# ---- comparison tap (tests, bench.py's check): the ReLU gates this implementation used in the training graph ----
+# Two levels.  "heavy" = the units whose gate moves every upstream gradient (decoder-head MLPs, DepthNet, the ASPP's
+# image-level vector): what the full-size comparisons force into the oracle.  "all" = every ReLU of the path (encoder /
+# pixel-decoder GroupNorm + ReLU maps, the pixel decoder's FFNs): what the tiny configurations need, where ONE gate of a
+# 10^4-unit map weighs 1e-3 of the whole gradient.  The taps sit in the op layer (autograd.Linear / autograd.GroupNorm:
+# one hook per op) and in one helper per ATen-composed module (view_transformer._relu, encoder._ASPP); call ORDER is
+# the oracle's evaluation order, masks are in the reference's [B, C, ...] layout.
 _gates = None
+_level = None
 
 
 def record_gates(on=True):
-    """start (-> the list that fills up, in call order) or stop recording ``relu_gate`` calls"""
-    global _gates
+    """start (``True`` / "heavy" or "all" -> the list that fills up, in call order) or stop (``False``) recording"""
+    global _gates, _level
     _gates = [] if on else None
+    _level = None if not on else ("all" if on == "all" else "heavy")
     return _gates
 
 
-def relu_gate(h):
-    """called on the ReLU OUTPUTS of the decoder head's small MLPs and of DepthNet (camera MLPs, SE layers, the
-    feature-map ReLUs behind its BatchNorms) in the training graph; a no-op unless a comparison asked for the gates
-    (oracle.occformer_ref.forced_gates explains why).  The call ORDER is the oracle's evaluation order."""
-    if _gates is not None:
-        _gates.append(h.detach() > 0)
+def gates_wanted(heavy):
+    return _gates is not None and (heavy or _level == "all")
+
+
+def relu_gate(h, heavy=True, gate=None):
+    """``h``: a ReLU OUTPUT of the training graph; a no-op unless a comparison asked for the gates
+    (oracle.occformer_ref.forced_gates explains why).  ``gate``: a callable -> bool tensor for the ops whose output is
+    not the bare ReLU (GroupNorm + ReLU + residual, token buffers); evaluated only while recording."""
+    if gates_wanted(heavy):
+        _gates.append((h.detach() > 0) if gate is None else gate())
     return h
 
 

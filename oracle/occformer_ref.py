@@ -170,17 +170,24 @@ _GATES = None
 
 class forced_gates:
     """Test infrastructure for gradient comparisons.  The ReLUs of the decoder head (decoder-layer FFNs, the
-    mask-embedding MLP: ~1.8 M units, each of which moves EVERY upstream gradient when its gate differs) and of
+    mask-embedding MLP: ~1.8 M units, each of which moves EVERY upstream gradient when its gate differs), of
     DepthNet (its camera MLPs / SE layers: [cameras, 512] vectors that scale whole feature maps; its feature-map ReLUs
-    behind train-mode BatchNorms, which weigh on DepthNet's own parameters) sit on fp32 pre-activations; two correct implementations whose pre-activations differ by 1e-6 open a unit at |z| ~ 1e-6
-    differently, and the gradient through it is then 'all' in one and 'nothing' in the other.  Inside this context the
-    head's ReLUs take their gates from ``masks`` (bool tensors in call order: the gates the OTHER implementation
-    used), so that both sides differentiate the same piecewise-linear function; the context counts where the forced
-    gate differs from this implementation's own and how far from zero those pre-activations are (they must be
-    rounding-close for the forcing to be legitimate -- the caller asserts it)."""
+    behind train-mode BatchNorms, which weigh on DepthNet's own parameters) and the image-level vector of the BEV ASPP
+    sit on fp32 pre-activations; two correct implementations whose pre-activations differ by 1e-6 open a unit at
+    |z| ~ 1e-6 differently, and the gradient through it is then 'all' in one and 'nothing' in the other.  Inside this
+    context those ("heavy") ReLUs take their gates from ``masks`` (bool tensors in call order: the gates the OTHER
+    implementation used), so that both sides differentiate the same piecewise-linear function; the context counts where
+    the forced gate differs from this implementation's own and how far from zero those pre-activations are (they must
+    be rounding-close for the forcing to be legitimate -- the caller asserts it).
 
-    def __init__(self, masks):
+    ``level="all"``: EVERY ReLU of the path takes its gate from the tape (the encoder's / pixel decoder's
+    GroupNorm + ReLU maps and the pixel decoder's FFNs as well) -- for the tiny configurations, where one unit of a
+    10^4-unit map weighs 1e-3 of the whole gradient."""
+
+    def __init__(self, masks, level="heavy"):
+        assert level in ("heavy", "all")
         self.masks = [m.detach().cpu().bool() for m in masks]
+        self.level = level
         self.i = 0
         self.units = 0
         self.flipped = 0
@@ -199,14 +206,17 @@ class forced_gates:
         return False
 
 
-def _relu_gated(z):
-    """ReLU of a "heavy" unit (decoder head MLPs, DepthNet's camera MLPs / SE layers: few units, each feeding whole
-    feature maps): F.relu, or the forced gate inside ``forced_gates``"""
+def _relu_gated(z, heavy=True):
+    """ReLU: F.relu, or -- inside ``forced_gates``, for the heavy units (decoder head MLPs, DepthNet, the ASPP's
+    image-level vector: few units, each feeding whole feature maps) or for every unit at level "all" -- the forced gate"""
     g = _GATES
-    if g is None:
+    if g is None or not (heavy or g.level == "all"):
         return F.relu(z)
-    assert g.i < len(g.masks), "forced_gates: the head evaluates more ReLUs than gate masks were recorded"
-    m = g.masks[g.i].reshape(z.shape)
+    assert g.i < len(g.masks), "forced_gates: more ReLUs are evaluated than gate masks were recorded"
+    m = g.masks[g.i]
+    assert m.numel() == z.numel() and (m.dim() != z.dim() or m.shape == z.shape), \
+        f"forced_gates: ReLU {g.i} has shape {tuple(z.shape)}, the recorded gate {tuple(m.shape)}"
+    m = m.reshape(z.shape)
     g.i += 1
     zd = z.detach()
     diff = (zd > 0) != m
@@ -455,19 +465,19 @@ def bottleneck_aspp(sd, p, x, groups=32):
     ch = C // 4
     g_in = groups
     g_aspp = ch // 2 if ch <= groups else groups
-    y = F.relu(_gn(sd, p + "input_conv.1.", _conv2d(sd, p + "input_conv.0.", x), g_in))
+    y = _relu_gated(_gn(sd, p + "input_conv.1.", _conv2d(sd, p + "input_conv.0.", x), g_in), False)
     a = p + "aspp."
     outs = []
     for i, dil in enumerate((1, 6, 12, 18), 1):
         q = f"{a}aspp{i}."
         z = _conv2d(sd, q + "atrous_conv.", y, padding=0 if i == 1 else dil, dilation=dil)
-        outs.append(F.relu(_gn(sd, q + "bn.", z, g_aspp)))
+        outs.append(_relu_gated(_gn(sd, q + "bn.", z, g_aspp), False))
     g = y.mean((2, 3), keepdim=True)
-    g = F.relu(_gn(sd, a + "global_avg_pool.2.", _conv2d(sd, a + "global_avg_pool.1.", g), g_aspp))
+    g = _relu_gated(_gn(sd, a + "global_avg_pool.2.", _conv2d(sd, a + "global_avg_pool.1.", g), g_aspp))
     outs.append(g.expand(-1, -1, *y.shape[2:]))
-    z = F.relu(_gn(sd, a + "bn1.", _conv2d(sd, a + "conv1.", torch.cat(outs, 1)), g_aspp))
+    z = _relu_gated(_gn(sd, a + "bn1.", _conv2d(sd, a + "conv1.", torch.cat(outs, 1)), g_aspp), False)
     y = y + _dropout(z, _TRAIN["aspp_drop"] if _TRAIN else 0.0)
-    y = F.relu(_gn(sd, p + "output_conv.1.", _conv2d(sd, p + "output_conv.0.", y), groups))
+    y = _relu_gated(_gn(sd, p + "output_conv.1.", _conv2d(sd, p + "output_conv.0.", y), groups), False)
     return x + y
 
 
@@ -475,7 +485,7 @@ def dualpath_block(sd, p, x, stride, shift, groups=32):
     """P/occformer/backbones/dualpath_block.py:65-82.  x [B, Cin, X, Y, Z]."""
     ident = x
     y = F.conv3d(x, sd[p + "input_conv.0.weight"], None, stride=stride, padding=1)
-    y = F.relu(_gn(sd, p + "input_conv.1.", y, groups))
+    y = _relu_gated(_gn(sd, p + "input_conv.1.", y, groups), False)
     B, C, X, Y, Z = y.shape
     heads = C // 32
     bev = y.mean(-1)
@@ -598,7 +608,7 @@ def pixel_decoder(sd, p, feats, num_layers=6, heads=8, points=4, groups=32, num_
         q = f"{p}encoder.layers.{l}."
         x = msda3d_layer(sd, q + "attentions.0.", x, pos, ref, shapes, heads, points)
         x = F.layer_norm(x, (E,), sd[q + "norms.0.weight"], sd[q + "norms.0.bias"], 1e-5)
-        y = _linear(sd, q + "ffns.0.layers.1.", F.relu(_linear(sd, q + "ffns.0.layers.0.0.", x)))
+        y = _linear(sd, q + "ffns.0.layers.1.", _relu_gated(_linear(sd, q + "ffns.0.layers.0.0.", x), False))
         x = F.layer_norm(x + y, (E,), sd[q + "norms.1.weight"], sd[q + "norms.1.bias"], 1e-5)
     outs, start = [], 0
     for shp in shapes:
@@ -611,7 +621,7 @@ def pixel_decoder(sd, p, feats, num_layers=6, heads=8, points=4, groups=32, num_
         y = cur + F.interpolate(outs[-1], size=cur.shape[-3:], mode="trilinear", align_corners=False)
         q = f"{p}output_convs.{j}."
         y = F.conv3d(y, sd[q + "conv.weight"], sd.get(q + "conv.bias"), padding=1)
-        outs.append(F.relu(_gn(sd, q + "gn.", y, groups)))
+        outs.append(_relu_gated(_gn(sd, q + "gn.", y, groups), False))
     outs[-1] = F.conv3d(outs[-1], sd[p + "mask_feature.weight"], sd[p + "mask_feature.bias"])
     return outs[::-1]
 

@@ -213,13 +213,19 @@ def test_dcnv2_module_on_gpu_uses_the_kernel(hip):
             out = m.to(hip.device)(x.to(hip.device)).cpu()
             # the bf16 image branch (bench.py --image-dtype bf16: autocast) crosses the layer as an fp32 island on the
             # SAME kernels (it used to fall to a grid_sample composition)
+            x16 = x.to(hip.device).bfloat16()
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                out16 = m(x.to(hip.device).bfloat16())
+                out16 = m(x16)
+            # the island includes the offset convolution and the sigmoid (under autocast they returned
+            # bf16-rounded sampling positions): the layer on the bf16-ROUNDED input in plain fp32 is the same
+            # computation up to the one rounding of the result
+            ref16 = m(x16.float()).cpu()
         finally:
             hip.ops.deform_im2col = orig
-    assert len(calls) == 2 and out16.dtype == torch.bfloat16
+    assert len(calls) == 3 and out16.dtype == torch.bfloat16
     assert float((out - ref).abs().max() / ref.abs().max()) < 1e-4
     assert float((out16.float().cpu() - ref).abs().max() / ref.abs().max()) < 3e-2
+    assert float((out16.float().cpu() - ref16).abs().max() / ref16.abs().max()) < 5e-3     # 2^-8 of the result's rounding
 
 
 @pytest.mark.gpu

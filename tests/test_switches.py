@@ -65,3 +65,51 @@ def test_every_switch_gives_the_same_forward(be, monkeypatch):
     finally:
         for k, v in saved.items():
             setattr(be.ops, k, v)
+
+
+@pytest.mark.parametrize("switch", ["lazy_logits_off", "depthnet_lib_off", "depthnet_lib_on"])
+def test_training_switches_give_the_same_step(be, monkeypatch, switch):
+    """The two switches of the TRAINING graph whose defaults changed in round 4: ``OCCF_LAZY_LOGITS`` (default
+    1: dense mask logits contracted only for the matched rows) and ``OCCF_DEPTHNET_LIB`` (default "auto": DepthNet's
+    training convolutions on the library's kernels from 4 096 rows up, GPU tensors only).  The non-default sides --
+    dense logits, DepthNet forced to ATen / forced to the library -- must give the same losses and gradients on the
+    same noise, so that neither fallback rots behind its default."""
+    from occformer_amd import noise, view_transformer
+    from occformer_amd.training import DeviceRNG
+    from tests.test_train_step import _setup
+    if be.kind == "emu" and switch == "depthnet_lib_off":
+        pytest.skip('on CPU tensors "auto" already is ATen: the pair is the GPU leg\'s')
+    monkeypatch.setattr(ops_mod, "_ops", be.ops)
+    cfg, meta, tc, model, sd, cams, x, gt_occ, pts, gd = _setup(B=1, N=2)
+    d = be.device
+    model = model.to(d).train()
+    kw = dict(img_metas=[dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])],
+              img_inputs=[t[:1].to(d) for t in (x, *cams)] + [gd[:1].to(d)], gt_occ=gt_occ[:1].to(d),
+              points_occ=[pts[0].to(d)])
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        noise.set_rng(DeviceRNG(d, 11))
+        try:
+            losses = model(return_loss=True, **kw)
+            sum(v for k, v in losses.items() if "loss" in k).backward()
+        finally:
+            noise.set_rng(None)
+        return ({k: float(v.detach()) for k, v in losses.items()},
+                {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters() if p.grad is not None})
+
+    ref_l, ref_g = step()
+    if switch == "lazy_logits_off":
+        assert model.pts_bbox_head.lazy_train_logits, "the default is the lazy contraction"
+        monkeypatch.setattr(type(model.pts_bbox_head), "lazy_train_logits", False)
+    else:
+        monkeypatch.setattr(view_transformer, "_DEPTHNET_LIB", "0" if switch == "depthnet_lib_off" else "1")
+    l, g = step()
+    for k, v in ref_l.items():
+        assert abs(l[k] - v) <= 1e-4 * max(1.0, abs(v)), (switch, k, l[k], v)
+    assert g.keys() == ref_g.keys()
+    num = sum(float((g[k] - v).norm() ** 2) for k, v in ref_g.items())
+    den = sum(float(v.norm() ** 2) for v in ref_g.values())
+    # (the library's kernels and ATen sum in different orders; a flipped ReLU gate of this tiny model weighs ~1e-3)
+    assert (num / den) ** 0.5 < 3e-3, (switch, (num / den) ** 0.5)

@@ -76,7 +76,7 @@ def test_training_step_gradients_vs_oracle(bound):
     model = model.to(d).train()
     rec = noise.RecordedRNG(DeviceRNG(d, 3))
     noise.set_rng(rec)
-    gates = noise.record_gates(True)
+    gates = noise.record_gates("all")
     metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])] * x.shape[0]
     img_inputs = [t.to(d) for t in (x, *cams)] + [gd.to(d)]
     try:
@@ -85,14 +85,18 @@ def test_training_step_gradients_vs_oracle(bound):
     finally:
         noise.record_gates(False)
     # DepthNet: reduce_conv, 2 camera MLPs + 2 SE layers, 3 BasicBlocks x 2, ASPP 4 branches + pool + output;
-    # head: 10 prediction sets x 2 mask-embedding ReLUs + one FFN ReLU per layer
-    assert len(gates) == 17 + 2 * (meta["dec_layers"] + 1) + meta["dec_layers"]
-    forced = O.forced_gates(gates)
+    # head: 10 prediction sets x 2 mask-embedding ReLUs + one FFN ReLU per layer;
+    # level "all" adds per dual-path block its input conv + the BEV ASPP's 8 maps, per pixel-decoder layer its FFN,
+    # per output conv one map
+    n_heavy = 17 + 2 * (meta["dec_layers"] + 1) + meta["dec_layers"]
+    n_blocks = sum(meta.get("block_numbers", (1, 1, 1, 1)))
+    assert len(gates) >= n_heavy + 9 * n_blocks + meta["pd_layers"], len(gates)
+    forced = O.forced_gates(gates, level="all")
     cpu_replay = ReplayRNG(rec.tape, torch.device("cpu"))
     ref_losses, ref_grads = _oracle_step(cfg, meta, tc, sd, cams, x, gt_occ, pts, gd, cpu_replay, gates=forced)
     assert cpu_replay.i == len(rec.tape), "the oracle consumed a different number of noise draws than the product"
     assert forced.i == len(gates)
-    print(f"head ReLU gates: {forced.flipped} of {forced.units} gated differently, largest |z| among them "
+    print(f"ReLU gates (every ReLU of the path): {forced.flipped} of {forced.units} gated differently, largest |z| among them "
           f"{forced.max_abs_z:.1e} ({forced.max_rel_z:.1e} of the tensor's RMS)")
     assert forced.max_rel_z <= 1e-3
     for k, v in ref_losses.items():
@@ -123,8 +127,9 @@ def test_training_step_gradients_vs_oracle(bound):
     num = sum(float((named[k].grad.cpu() - ref_grads[k]).norm() ** 2) for l2, mx, k, s in worst)
     den = sum(float(ref_grads[k].norm() ** 2) for l2, mx, k, s in worst)
     print("whole gradient vector: relative L2 error", (num / den) ** 0.5)
+    assert forced.flipped <= max(8, 1e-4 * forced.units), (forced.flipped, forced.units)
     assert (num / den) ** 0.5 < TOL
-    assert l2s[int(0.9 * (len(l2s) - 1))] < 3e-3 and l2s[-1] < 5e-2, worst[:5]
+    assert l2s[int(0.9 * (len(l2s) - 1))] < 1e-3 and l2s[-1] < 6e-3, worst[:5]
     assert all(float(named[k].grad.abs().max()) < 1e-4 for l2, mx, k, s in worst if s <= 1e-5)
 
 
@@ -136,18 +141,20 @@ def test_kitti_training_step_gradients_vs_oracle(bound):
     mask2former_occ.py:224-292, 343-444; occupancyformer.py:132-199.
 
     Precision.  On the host emulation the step runs in the exact-fp32 mode and must agree to 2e-4 (measured 1.4e-5 on
-    every module): that pins the GRAPH.  In the default bf16x3 mode (what the GPU leg runs) the same step measures
-    1.5e-3 on the whole vector while the head agrees to 3e-5 and every loss to 1e-5: one ReLU gate of the single
-    pixel-decoder FFN flips on a 1e-6 difference and, with one sample and one layer, weighs that much (see the
-    module docstring); the bound there is 5e-3."""
+    every module): that pins the GRAPH.  In the default bf16x3 mode (what the GPU leg runs) the bound is north_star's
+    1e-3: the product runs first on its own taped noise with EVERY ReLU gate of the path recorded
+    (noise.record_gates("all")), the oracle replays the noise and differentiates with those gates -- without them one
+    ReLU unit of the single pixel-decoder FFN, flipped on a 1e-6 difference, weighs 1.5e-3 of this one-sample,
+    one-layer configuration's gradient (r02/r03: that was the 5e-3 bound here)."""
     from occformer_amd import configs
     be = bound
-    exact = be.kind == "emu"
+    import os
+    exact = be.kind == "emu" and not os.environ.get("OCCF_TEST_KITTI_X3")   # (=1: the emulation leg in bf16x3 too)
     prev = be.ops.precision
     if exact:
         be.ops.precision = "f32"
     try:
-        _kitti_step(be, configs, 2e-4 if exact else 5e-3)
+        _kitti_step(be, configs, 2e-4 if exact else TOL)
     finally:
         be.ops.precision = prev
 
@@ -172,18 +179,26 @@ def _kitti_step(be, configs, whole_tol):
     gd = paramgen.uniform("tk_depth", (B, N, H, W), 5) * 12.0
     gd = torch.where(paramgen.uniform("tk_depth_mask", (B, N, H, W), 6) < 0.05, gd, torch.zeros_like(gd))
     ocfg = configs.oracle_train_cfg(cfg, meta, class_weight=model.pts_bbox_head.class_weight)
-    rec = T.RecordingRNG()
-    torch.manual_seed(4)
-    ref_losses, ref_grads = T.train_step(sd, x, cams, gd, gt_occ, None, ocfg, rng=rec)
-
+    from occformer_amd.training import DeviceRNG
     d = be.device
     model = model.to(d).train()
-    replay = ReplayRNG(rec.tape, d)
-    noise.set_rng(replay)
+    rec = noise.RecordedRNG(DeviceRNG(d, 4))
+    noise.set_rng(rec)
+    gates = noise.record_gates("all")
     metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])] * B
-    losses = model.forward_train(img_metas=metas, img_inputs=[t.to(d) for t in (x, *cams)] + [gd.to(d)],
-                                 gt_occ=gt_occ.to(d), points_occ=None)
-    assert replay.i == len(rec.tape), "the product consumed a different number of noise draws than the oracle"
+    try:
+        losses = model.forward_train(img_metas=metas, img_inputs=[t.to(d) for t in (x, *cams)] + [gd.to(d)],
+                                     gt_occ=gt_occ.to(d), points_occ=None)
+    finally:
+        noise.record_gates(False)
+    forced = O.forced_gates(gates, level="all")
+    cpu_replay = ReplayRNG(rec.tape, torch.device("cpu"))
+    ref_losses, ref_grads = T.train_step(sd, x, cams, gd, gt_occ, None, ocfg, rng=cpu_replay, gates=forced)
+    assert cpu_replay.i == len(rec.tape), "the oracle consumed a different number of noise draws than the product"
+    assert forced.i == len(gates), "the oracle evaluated a different number of ReLUs than the product"
+    print(f"ReLU gates (every ReLU of the path): {forced.flipped} of {forced.units} gated differently, largest |z| "
+          f"among them {forced.max_abs_z:.1e} ({forced.max_rel_z:.1e} of the tensor's RMS)")
+    assert forced.max_rel_z <= 1e-3 and forced.flipped <= max(8, 1e-4 * forced.units), (forced.flipped, forced.units)
     for k, v in ref_losses.items():
         v = float(v.detach())
         assert abs(float(losses[k].detach()) - v) <= TOL * max(1.0, abs(v)), (k, float(losses[k].detach()), v)
@@ -202,4 +217,4 @@ def _kitti_step(be, configs, whole_tol):
     per.sort(reverse=True)
     print("whole gradient vector: relative L2 error", (num / den) ** 0.5, " worst parameters:", per[:5])
     assert (num / den) ** 0.5 < whole_tol
-    assert per[0][0] < 5e-2 and per[len(per) // 10][0] < 10 * whole_tol
+    assert per[0][0] < 6e-3 and per[len(per) // 10][0] < 1e-3, per[:5]

@@ -190,28 +190,45 @@ def test_workload_training_step_vs_oracle(hip, name):
         t_cpu = time.perf_counter() - t0
         assert cpu_replay.i == len(tape), "the oracle consumed a different number of noise draws than the product"
         assert forced.i == len(gates), "the oracle evaluated a different number of head ReLUs than the product"
-        pairs = {k: (float(losses[k].detach()), float(v.detach())) for k, v in ref_losses.items()}
-        worst_loss = max(abs(a - b) / max(1.0, abs(b)) for a, b in pairs.values())
-        per, num, den = [], 0.0, 0.0
-        for k, g in ref_grads.items():
-            if g is None:
-                continue
-            assert named[k].grad is not None, f"no gradient reached {k}"
-            dd, nn_ = float((named[k].grad.cpu() - g).norm()) ** 2, float(g.norm()) ** 2
-            num, den = num + dd, den + nn_
-            per.append(((dd / max(nn_, 1e-30)) ** 0.5, k, nn_))
-        # per-parameter figures over the parameters that carry gradient (norm >= 1e-4 of the whole vector's)
-        per = [(e, k) for e, k, nn_ in per if nn_ >= 1e-8 * den]
-        per.sort()
-        qs = {q: per[int(q * (len(per) - 1))][0] for q in (0.5, 0.9, 0.99, 1.0)}
-        whole = (num / den) ** 0.5
+
+        def figures(ref_losses, ref_grads):
+            pairs = {k: (float(losses[k].detach()), float(v.detach())) for k, v in ref_losses.items()}
+            worst_loss = max(abs(a - b) / max(1.0, abs(b)) for a, b in pairs.values())
+            per, num, den = [], 0.0, 0.0
+            for k, g in ref_grads.items():
+                if g is None:
+                    continue
+                assert named[k].grad is not None, f"no gradient reached {k}"
+                dd, nn_ = float((named[k].grad.cpu() - g).norm()) ** 2, float(g.norm()) ** 2
+                num, den = num + dd, den + nn_
+                per.append(((dd / max(nn_, 1e-30)) ** 0.5, k, nn_))
+            # per-parameter figures over the parameters that carry gradient (norm >= 1e-4 of the whole vector's)
+            per = [(e, k) for e, k, nn_ in per if nn_ >= 1e-8 * den]
+            per.sort()
+            qs = {q: per[int(q * (len(per) - 1))][0] for q in (0.5, 0.9, 0.99, 1.0)}
+            return worst_loss, (num / den) ** 0.5, qs, pairs, per
+
+        worst_loss, whole, qs, pairs, per = figures(ref_losses, ref_grads)
+        del ref_grads
+        # the UNGATED figure beside it: the same comparison with the oracle on its own gates --
+        # what the forcing buys on this box.  One more oracle pass; skipped for the 256-grid workload (153 s per pass)
+        ungated = "not run"
+        if name != "kitti_effb7_256lit" or os.environ.get("OCCF_TEST_UNGATED") == "1":
+            ul, ug = T.train_step(*oargs, rng=ReplayRNG(tape, torch.device("cpu")))
+            u = figures(ul, ug)
+            ungated = f"worst loss diff {u[0]:.2e}, whole gradient rel L2 {u[1]:.2e}, worst parameter {u[2][1.0]:.1e}"
+            # the canary of the forcing: with NO gate forced the whole gradient still agrees to a few 1e-3
+            # (r03, no forcing at all: 5.5e-4 ... 1.25e-3 over the workloads) -- a systematic error the forcing adopted
+            # would show here
+            assert u[0] <= TOL and u[1] <= 5e-3, ungated
+            del ul, ug
         print(f"[{name}] training step vs oracle ({t_cpu:.0f} s on the host): worst loss diff {worst_loss:.2e}  whole "
               f"gradient rel L2 {whole:.2e}  per-parameter rel L2 quantiles 50/90/99/100 % = "
               + " / ".join(f"{qs[q]:.1e}" for q in (0.5, 0.9, 0.99, 1.0)) + f" over {len(per)} parameters; worst: "
               + ", ".join(f"{k} {e:.1e}" for e, k in per[-3:])
               + f"; forced ReLU gates: {forced.flipped} of {forced.units} units gated differently by the two "
               f"implementations, largest |pre-activation| among them {forced.max_abs_z:.1e} "
-              f"({forced.max_rel_z:.1e} of its tensor's RMS)")
+              f"({forced.max_rel_z:.1e} of its tensor's RMS); UNGATED (oracle on its own gates): {ungated}")
         return worst_loss, whole, qs, pairs, forced
 
     worst_loss, whole, qs, pairs, forced = compare(7)
@@ -220,6 +237,9 @@ def test_workload_training_step_vs_oracle(hip, name):
     # (measured r04n over the five workloads: 17 ... 975 of 16.5 M ... 208 M units -- the decoder head's MLPs and all of
     # DepthNet's ReLUs -- at |z| <= 5.9e-5 of the tensor's RMS: the tail of a 1e-5 implementation difference over 2e8 units)
     assert forced.max_rel_z <= 5e-4, (forced.flipped, forced.max_abs_z, forced.max_rel_z)
+    # ... and only a vanishing fraction of them: a systematic pre-activation error would be ADOPTED by the forcing,
+    # not detected -- measured <= 975 of 2.1e8
+    assert forced.flipped <= 1e-4 * forced.units, (forced.flipped, forced.units)
     assert whole <= TOL
     # (measured r04n: whole gradient 4.1e-5 ... 1.3e-4, 90 % of the parameters <= 3.9e-4, worst parameter <= 2.0e-3)
-    assert qs[0.9] <= 2e-3 and qs[1.0] <= 2e-2
+    assert qs[0.9] <= 1e-3 and qs[1.0] <= 6e-3
