@@ -509,7 +509,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from occformer_amd import dist_utils
-    dist = dist_utils.init("nccl", device) if world > 1 else None
+    # under a launcher the process group is brought up even for ONE rank (and the step then goes through the DDP wrap,
+    # its bucket hooks and -- with OCCF_DIST_AT_WORLD_1=1 -- every collective of the path on RCCL): what a 1-GPU box can
+    # verify of the N > 1 path.  A plain ``python bench.py`` (the N = 1 record) stays free of it.
+    dist = dist_utils.init("nccl", device) if world > 1 or "WORLD_SIZE" in os.environ else None
 
     import occformer_amd
     from occformer_amd import configs
@@ -533,7 +536,7 @@ def main():
     if train and meta.get("kitti"):
         cfg["train_cfg"] = dict(pts=configs.train_cfg_pts())
     model = build_model(cfg).to(device)
-    if args.sync_bn and train and world > 1:
+    if args.sync_bn and train and dist is not None:
         dist_utils.convert_sync_batchnorm(model)
     img_inputs, metas, points = synthetic_sample(meta, device, seed=rank)
     if args.from_images:
@@ -555,7 +558,7 @@ def main():
         # DDP (gradient all-reduce over RCCL, overlapped with backward), grad-clip 5 (nuScenes) / 20 (KITTI), AdamW
         model.train()
         net = model
-        if world > 1:
+        if dist is not None:
             net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
                                                             gradient_as_bucket_view=True, bucket_cap_mb=64)
         params = [p for p in model.parameters() if p.requires_grad]

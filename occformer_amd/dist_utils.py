@@ -22,8 +22,19 @@ def init(backend, device=None):
     return dist
 
 
+# OCCF_DIST_AT_WORLD_1=1: an initialised process group of ONE rank still issues every collective of the path
+# (reduce_mean, the timing max, SyncBatchNorm's gather / reduce) -- how a 1-GPU box exercises the RCCL call sites
+# (profiles/r05: the N > 1 runs are the driver's)
+_AT_WORLD_1 = os.environ.get("OCCF_DIST_AT_WORLD_1", "0") == "1"
+
+
 def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def collectives_on():
+    """do the path's collectives run?  (more than one rank, or one rank with OCCF_DIST_AT_WORLD_1=1)"""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _AT_WORLD_1)
 
 
 def rank():
@@ -40,7 +51,7 @@ def shard(n_samples, rank_=None, world_=None):
 
 
 def max_over_ranks(value, device="cpu"):
-    if world() == 1:
+    if not collectives_on():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -50,7 +61,7 @@ def max_over_ranks(value, device="cpu"):
 def sum_confusion(hist, device="cpu"):
     """apis/test.py:206-210: all-reduce(SUM) of the lidarseg confusion matrix."""
     t = torch.as_tensor(hist, dtype=torch.int64, device=device)
-    if world() > 1:
+    if collectives_on():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -58,7 +69,7 @@ def sum_confusion(hist, device="cpu"):
 def reduce_mean(t):
     """mmdet.core.reduce_mean (mask2former_nusc_occ.py:408; mask2former_occ.py:425,437): all-reduce(SUM) / world
     of a loss normaliser; identity for a single process."""
-    if world() == 1:
+    if not collectives_on():
         return t
     t = t.clone()
     dist.all_reduce(t.div_(world()), op=dist.ReduceOp.SUM)
@@ -133,7 +144,7 @@ class _SyncMixin:
     def forward(self, x):
         self._check_input_dim(x)
         use_batch = self.training or (self.running_mean is None and self.running_var is None)
-        if not use_batch or world() == 1:
+        if not use_batch or not collectives_on():
             return super().forward(x)
         momentum = 0.0 if self.momentum is None else self.momentum
         track = self.training and self.track_running_stats
@@ -178,4 +189,4 @@ def convert_sync_batchnorm(model, process_group=None):
 
 def is_synced(bn):
     """does this BatchNorm see other ranks' samples (so that one vector per rank still has batch statistics)?"""
-    return isinstance(bn, _SyncMixin) and world() > 1
+    return isinstance(bn, _SyncMixin) and collectives_on()

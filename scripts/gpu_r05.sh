@@ -1,0 +1,51 @@
+#!/bin/bash
+# The GPU visits of round 5, one stage per visit:  bash scripts/gpu_r05.sh <stage>   (results under gpurun_out/, the
+# files worth keeping are copied to profiles/r05/ and indexed in profiles/README.md).  scripts/gpu_final.sh is the
+# end-of-round visit (suite, smoke, bench, rocprof statistics, PMC traffic stamp).
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+O=gpurun_out
+mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+case "${1:-}" in
+a)  # round 5, visit a: the gradient gates on the full gate tape (tiny configs, multistep, smoke at 1e-3), the ungated figure, default bench with forward_from_images, from-images training step + the other backbones, one-rank RCCL run
+( time timeout 900 python -m pytest tests/test_train_step.py tests/test_train_multistep.py tests/test_switches.py tests/test_image_backbone.py -m gpu -q -p no:cacheprovider -s -k "training_step or three_fused or training_switches or dcnv2" ) 2>&1 | grep -v "MIOpen(HIP)" > $O/r05a_pytest_gates.log
+grep -i "gated differently\|whole gradient\|passed\|failed\|error\|^real" $O/r05a_pytest_gates.log | cut -c1-400
+timeout 300 python __graft_entry__.py --smoke 2>&1 | grep -v "MIOpen(HIP)" | tail -4 | tee $O/r05a_smoke.log
+( time timeout 900 python -m pytest tests/test_workloads_gpu.py -m gpu -q -p no:cacheprovider -s -k "training_step and nusc_r50_200" ) 2>&1 | grep -v "MIOpen(HIP)" > $O/r05a_workload_nusc200.log
+grep "training step vs oracle\|passed\|failed\|^real\|Error" $O/r05a_workload_nusc200.log | cut -c1-1200
+( time timeout 900 python bench.py --shape-report $O/r05a_shapes_train.txt ) > $O/r05a_bench_train.json 2> $O/r05a_bench_train.err; echo "bench rc=$?"
+tail -3 $O/r05a_bench_train.err
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r05a_bench_train.json"))
+print("train", round(d["value"], 3), "samples/s", round(d["ms_per_step"], 2), "ms; roofline", round(d["roofline"]["frac"], 4))
+print("check", {k: v for k, v in d.get("check", {}).items() if k != "what"})
+print("forward", round(d["forward"]["value"], 2), d["forward"]["roofline"]["frac"], d["forward"].get("check"))
+print("forward_from_images", d.get("forward_from_images"))
+print("cpu", d["cpu_baseline"])
+for k, v in list(d["kernels"].items())[:30]:
+    print(f"  {k:30s} {v['calls']:4d} {v['total_ms']:8.3f} ms")
+PY
+head -40 $O/r05a_shapes_train.txt
+timeout 600 python bench.py --from-images --steps 10 --warmup 3 > $O/r05a_bench_train_from_images.json 2> $O/r05a_bench_train_from_images.err; echo "rc=$?"; tail -2 $O/r05a_bench_train_from_images.err
+for w in kitti_effb7_128 nusc_r101 kitti_effb7_256lit; do
+  timeout 600 python bench.py --workload $w --mode forward --from-images --steps 20 --warmup 3 > $O/r05a_bench_fwd_from_images_$w.json 2> $O/r05a_bench_fwd_from_images_$w.err; echo "$w rc=$?"; tail -2 $O/r05a_bench_fwd_from_images_$w.err
+done
+python - <<'PY'
+import json
+for f in ("train_from_images", "fwd_from_images_kitti_effb7_128", "fwd_from_images_nusc_r101", "fwd_from_images_kitti_effb7_256lit"):
+    try:
+        d = json.load(open(f"gpurun_out/r05a_bench_{f}.json"))
+        print(f, round(d["value"], 3), "samples/s", round(d["ms_per_step"], 2), "ms", d.get("stages_ms"), "mem", d["peak_memory_GiB"])
+    except Exception as e:
+        print(f, "no json", e)
+PY
+OCCF_DIST_AT_WORLD_1=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --sync-bn > $O/r05a_bench_rccl_world1.json 2> $O/r05a_bench_rccl_world1.err; echo "rccl world-1 rc=$?"
+tail -3 $O/r05a_bench_rccl_world1.err
+python -c "
+import json; d=json.load(open('gpurun_out/r05a_bench_rccl_world1.json')); print('rccl world 1:', round(d['value'],3), 'samples/s', round(d['ms_per_step'],2), 'ms', d['config']['parallelism'])"
+;;
+*) echo "usage: $0 <stage>"; exit 2;;
+esac
