@@ -453,12 +453,23 @@ def dry_run_rank(args, rank, world):
         dist.barrier()
     dt = dist_utils.max_over_ranks(time.perf_counter() - t0)
     if rank == 0:
-        print(json.dumps({"metric": "dry run (mock step on CPU ranks, gloo)", "value": world * args.steps / dt,
+        emit(json.dumps({"metric": "dry run (mock step on CPU ranks, gloo)", "value": world * args.steps / dt,
                           "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
                           "dry_run": True}))
     if dist is not None:
         dist.destroy_process_group()
+
+
+_REAL_STDOUT = None
+
+
+def emit(line):
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        print(line, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (line + "\n").encode())
 
 
 def main():
@@ -490,6 +501,15 @@ def main():
     ap.add_argument("--check", action="store_true", help="also report max abs err vs the oracle output")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    # the contract is ONE line on stdout: everything else this process (or a library under it: RCCL prints a version
+    # banner to stdout when the communicator comes up, r05a) writes to fd 1 goes to stderr; the JSON line is written to
+    # the real stdout at the end
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None and not ("WORLD_SIZE" not in os.environ and args.gpus > 1):
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # not under a launcher: become one (N ranks of this node, one per GPU)
@@ -726,7 +746,7 @@ def main():
                 out["check"] = {"output_voxels_max_abs_err": float((a - b).abs().max()),
                                 "output_points_max_abs_err": None if res_cpu["output_points"] is None else float(
                                     (res_gpu["output_points"].cpu() - res_cpu["output_points"]).abs().max())}
-    print(json.dumps(out))
+    emit(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
     if gate_failure:

@@ -218,7 +218,10 @@ class Conv3d(torch.autograd.Function):
             dw = dw2.view(Cout, *ks, Cin).permute(0, 4, 1, 2, 3)
             if weight.dim() == 4:
                 dw = dw.squeeze(-1)
-            dw = dw.contiguous()
+            # (canonical strides also for size-1 kernel dims: a [Cout, Cin, 1, 1, 1] gradient permuted out of the
+            # tap-major layout "is contiguous" with strides [Cin, 1, Cin, Cin, Cin], which DDP's bucket views refuse --
+            # r05a: "Grad strides do not match bucket view strides", i.e. a copy per such gradient and step)
+            dw = dw.contiguous().reshape(-1).view(weight.shape)
         return dx, dw, db, None, None, None, None, None, None
 
 

@@ -546,6 +546,8 @@ static int occf_pick_ksplit(long M, int N, int K, bool wide, long workspace_floa
   return S < 2 ? 1 : S;
 }
 
+#include "gemm_stream.h"
+
 template <int CONV>
 static int launch_gemm_b(GemmArgsB a, int terms, float* workspace, long workspace_floats, hipStream_t st) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.K % GB_BK != 0) return OCCF_ESHAPE;
@@ -619,6 +621,12 @@ extern "C" int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const 
   if (out_head_dim > 0 && (N % out_head_dim || out_head_dim % 4 || N % 4 || residual || out_head_rows <= 0 ||
                            M % out_head_rows))
     return OCCF_ESHAPE;
+  if (out_head_dim <= 0 && !gn_partial) {
+    // the streaming shapes (M >> N, K <= 256) run on the weight-resident persistent kernel (gemm_stream.h)
+    const int rc = occf_gemm_stream_launch(x, w_hi, w_lo, bias, residual, out, M, N, K, ldx, ldo, ldr, act, terms,
+                                           (hipStream_t)stream);
+    if (rc != OCCF_ESHAPE) return rc;
+  }
   GemmArgsB a = {};
   a.A = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.C = out;
   a.M = (int)M; a.N = N; a.K = K; a.lda = ldx; a.ldc = out_head_dim > 0 ? 4 : ldo; a.ldr = ldr; a.act = act;
