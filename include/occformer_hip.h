@@ -251,6 +251,11 @@ int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w
                          const float* residual, float* out, long M, int N, int K, long ldx, long ldo,
                          long ldr, int act, int terms, float* workspace, long workspace_floats,
                          int out_head_dim, long out_head_rows, float* gn_partial, void* stream);
+/* Linear only: the streaming shapes -- M >= 16 384 rows (OCCF_GEMM_STREAM=n: from n rows; 0: never), K in
+ * {64, 96, ..., 256}, N % 32 == 0, no head-major output / GroupNorm partials -- run on a weight-resident persistent
+ * kernel (csrc/gemm_stream.h: the weight block stays in LDS, rows stream global -> registers -> MFMA -> global).
+ * occf_linear_stream_launches: how many calls took it since the library was loaded (diagnostics / tests). */
+long occf_linear_stream_launches(void);
 int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
                          const float* residual, float* out, int B, int Xi, int Yi, int Zi, int Cin, int Cout,
                          int kX, int kY, int kZ, int stride, int dil, int pad_x, int pad_y, int pad_z,

@@ -612,6 +612,9 @@ extern "C" long occf_gemm_bf16_workspace(long M, int N, int K) {
   return S > 1 ? (long)S * M * N : 0;
 }
 
+static long g_stream_launches = 0;
+extern "C" long occf_linear_stream_launches(void) { return g_stream_launches; }
+
 extern "C" int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
                                     const float* bias, const float* residual, float* out, long M, int N,
                                     int K, long ldx, long ldo, long ldr, int act, int terms, float* workspace,
@@ -625,7 +628,10 @@ extern "C" int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const 
     // the streaming shapes (M >> N, K <= 256) run on the weight-resident persistent kernel (gemm_stream.h)
     const int rc = occf_gemm_stream_launch(x, w_hi, w_lo, bias, residual, out, M, N, K, ldx, ldo, ldr, act, terms,
                                            (hipStream_t)stream);
-    if (rc != OCCF_ESHAPE) return rc;
+    if (rc != OCCF_ESHAPE) {
+      ++g_stream_launches;
+      return rc;
+    }
   }
   GemmArgsB a = {};
   a.A = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.C = out;

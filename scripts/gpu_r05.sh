@@ -47,5 +47,20 @@ tail -3 $O/r05a_bench_rccl_world1.err
 python -c "
 import json; d=json.load(open('gpurun_out/r05a_bench_rccl_world1.json')); print('rccl world 1:', round(d['value'],3), 'samples/s', round(d['ms_per_step'],2), 'ms', d['config']['parallelism'])"
 ;;
+b)  # round 5, visit b: the streaming linear kernel (shape table vs the tile kernel and the floors, its GPU test, end-to-end benches), the precision table
+timeout 600 python scripts/stream_probe.py 2>&1 | grep -v "amdgpu.ids" | tee $O/r05b_stream_probe.txt
+timeout 600 python -m pytest tests/test_gemm_norm_ops.py -m gpu -q -p no:cacheprovider -k "streaming or linear" 2>&1 | tail -3
+for v in 0 1; do
+  OCCF_GEMM_STREAM=$v timeout 400 python bench.py --mode forward --steps 20 --warmup 3 --no-cpu-baseline --shape-report $O/r05b_shapes_fwd_stream$v.txt > $O/r05b_bench_fwd_stream$v.json 2>/dev/null
+  OCCF_GEMM_STREAM=$v timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --shape-report $O/r05b_shapes_train_stream$v.txt > $O/r05b_bench_train_stream$v.json 2>/dev/null
+  python - <<PY
+import json
+f = json.load(open("gpurun_out/r05b_bench_fwd_stream$v.json")); t = json.load(open("gpurun_out/r05b_bench_train_stream$v.json"))
+print("OCCF_GEMM_STREAM=$v forward", round(f["value"], 2), "samples/s", round(f["ms_per_step"], 2), "ms, linear", f["kernels"]["linear"]["total_ms"], "| train", round(t["value"], 3), round(t["ms_per_step"], 2), "ms, linear", t["kernels"]["linear"]["total_ms"], "| train-bench forward", round(t["forward"]["value"], 2))
+PY
+done
+( time timeout 1500 python scripts/precision_probe.py ) 2>&1 | grep -v "amdgpu.ids\|MIOpen(HIP)" > $O/r05b_precision_probe.txt
+tail -12 $O/r05b_precision_probe.txt | cut -c1-400
+;;
 *) echo "usage: $0 <stage>"; exit 2;;
 esac

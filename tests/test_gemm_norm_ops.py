@@ -266,6 +266,47 @@ def test_mlp_fused(be, monkeypatch, C, H, act, ln_mode, M, prec, tol):
     assert err < tol, err
 
 
+@pytest.mark.parametrize("M,K,N,act,bias,res", [(300, 128, 128, 0, True, False), (300, 128, 384, 2, True, True),
+                                               (257, 192, 192, 1, False, True), (97, 224, 192, 0, True, False),
+                                               (300, 256, 256, 0, True, True), (65, 64, 96, 1, True, False),
+                                               (4500, 192, 768, 0, True, False)])
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
+def test_linear_streaming_kernel(be, monkeypatch, M, K, N, act, bias, res, prec, tol):
+    """csrc/gemm_stream.h: the weight-resident persistent linear of the streaming shapes (here forced on from 64 rows
+    and capped at 16 workgroups so that every stream walks several ragged token tiles; N = 384 / 768 split into N blocks
+    that share their rows, K = 224 is the pixel decoder's concatenated input, strided rows = a column block of a wider
+    tensor).  Against float64; and the launch counter proves the kernel -- not the tile kernel -- ran."""
+    monkeypatch.setattr(be.ops, "precision", prec)
+    monkeypatch.setenv("OCCF_GEMM_STREAM", "64")
+    monkeypatch.setenv("OCCF_GEMM_STREAM_WGS", "16")
+    if be.kind == "emu" and M > 1000 and prec == "bf16":
+        pytest.skip("the large case once on the emulation")
+    wide = paramgen.tensor("gs.x", (M, K + 32), 1, 1.2) + 0.2
+    x = wide[:, 16:16 + K]                                         # row stride K + 32
+    w = paramgen.tensor("gs.w", (N, K), 2, K ** -0.5)
+    b = paramgen.tensor("gs.b", (N,), 3, 0.3) if bias else None
+    r = paramgen.tensor("gs.r", (M, N), 4) if res else None
+    ref = F.linear(x.double(), w.double(), None if b is None else b.double())
+    ref = F.gelu(ref) if act == 2 else F.relu(ref) if act == 1 else ref
+    if r is not None:
+        ref = ref + r.double()
+    lib = be.ops.lib
+    n0 = lib.occf_linear_stream_launches()
+    xd = be.to(wide)[:, 16:16 + K]
+    wd = be.to(w)
+    out = be.ops.linear(xd, wd, None if b is None else be.to(b), act, None if r is None else be.to(r),
+                        w_split=be.ops.split_bf16(wd), allow_small=False)
+    assert lib.occf_linear_stream_launches() == n0 + 1, "the streaming kernel did not take this shape"
+    err = float((out.cpu() - ref.float()).abs().max() / ref.abs().max())
+    assert err < tol, err
+    # the tile kernel on the same problem (OCCF_GEMM_STREAM=0): same result to rounding
+    monkeypatch.setenv("OCCF_GEMM_STREAM", "0")
+    out0 = be.ops.linear(xd, wd, None if b is None else be.to(b), act, None if r is None else be.to(r),
+                         w_split=be.ops.split_bf16(wd), allow_small=False)
+    assert lib.occf_linear_stream_launches() == n0 + 1
+    assert float((out0.cpu() - out.cpu()).abs().max() / ref.abs().max()) < 2 * tol
+
+
 def test_linear_head_major_output(be):
     """value projection written directly as [B, heads, Nq, dh] (what msda3d gathers from)"""
     B, Nq, E, H = 2, 150, 96, 8
