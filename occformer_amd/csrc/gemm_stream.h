@@ -41,13 +41,21 @@ struct GemmStreamArgs {
 };
 
 #define GS_NW 8
+template <int V>
+struct gs_int {
+  static constexpr int value = V;
+};
 
 template <int KS, int TERMS>     // K = 16 * KS
 __global__ void __launch_bounds__(GS_NW * 64) gemm_stream_kernel(GemmStreamArgs p) {
   constexpr int K = 16 * KS;
-  constexpr int NT = GS_NW * 64;
   constexpr int IMG = KS * 1024;                   // bytes of one image (hi or lo) of a 32-channel tile
   constexpr int ARR = TERMS == 3 ? 2 : 1;
+  // the NEXT tile's rows travel while this one multiplies (K / 2 more registers: up to K = 192 inside the 256-register
+  // budget of two waves per SIMD; r05b without it: 4.2 TB/s on [680 000, 128] x 128 -- two of a CU's eight waves in their
+  // load phase at a time is 32 KB in flight per CU, i.e. latency-bound)
+  // K = 192 / 224 / 256: the first 8 / 6 / 4 k-steps' worth of the next rows (the rest is fetched at the top of its own iteration)
+  constexpr int PFK = KS <= 10 ? KS : KS == 12 ? 8 : KS == 14 ? 6 : 4;
   OCCF_DYN_SMEM(smem);
   unsigned char* Wimg = (unsigned char*)smem;      // tile j: [hi | lo] at j * ARR * IMG; slot = ks * 64 + row * 2 + k2
   float* bias_s = (float*)(Wimg + (size_t)p.ntb * ARR * IMG);       // [32 * ntb]
@@ -61,59 +69,72 @@ __global__ void __launch_bounds__(GS_NW * 64) gemm_stream_kernel(GemmStreamArgs 
   const int q = x + 8 * (s / p.n_blocks);
   const int n0 = nb * 32 * p.ntb;
 
-  // ---- this block's weight rows -> LDS, fragment order
-  const int slots = p.ntb * KS * 64;
-  for (int arr = 0; arr < ARR; ++arr) {
-    const uint16_t* W = arr ? p.Wl : p.Wh;
-    for (int sl = tid; sl < slots; sl += NT) {
-      const int j = sl / (KS * 64), r = sl - j * (KS * 64);
-      const int ks = r >> 6, row = (r >> 1) & 31, k2 = r & 1;
-      const occf_u4 v = *(const occf_u4*)(W + (long)(n0 + j * 32 + row) * K + ks * 16 + k2 * 8);
-      *(occf_u4*)(Wimg + (size_t)j * ARR * IMG + arr * IMG + r * 16) = v;
+  // ---- this block's weight rows -> LDS in fragment order, as LDS-DMA (global -> LDS without registers): every wave
+  // issues all of its 1 KB pieces back to back and waits once (r05b: a load -> store loop of 18 dependent L2 round
+  // trips per thread, all 256 workgroups on the same 147 KB, cost half of the 52 us of the [91 250, 192] x 192 call)
+  {
+    const uint32_t wbytes = (uint32_t)(32 * p.ntb) * K * 2u;
+    const int pieces = p.ntb * KS;                 // 64-slot (1 KB) pieces per array
+    const int r = lane;                            // slot within the piece: row = (r >> 1) & 31, k2 = r & 1
+    for (int arr = 0; arr < ARR; ++arr) {
+      const occf_bbuf wb = occf_make_bbuf((arr ? p.Wl : p.Wh) + (long)n0 * K, wbytes);
+      for (int pc = wave; pc < pieces; pc += GS_NW) {
+        const int j = pc / KS, ks = pc - j * KS;
+        const uint32_t voff = (uint32_t)(((j * 32 + (r >> 1)) * K + ks * 16 + (r & 1) * 8) * 2);
+        occf_bbuf_load_lds_b128(wb, voff, Wimg + (size_t)j * ARR * IMG + arr * IMG + ks * 1024);
+      }
     }
   }
-  for (int i = tid; i < 32 * p.ntb; i += NT) bias_s[i] = p.bias ? p.bias[n0 + i] : 0.f;
-  __syncthreads();
+  for (int i = tid; i < 32 * p.ntb; i += GS_NW * 64) bias_s[i] = p.bias ? p.bias[n0 + i] : 0.f;
+  __syncthreads();                                 // (waits for this wave's LDS-DMA, then for everybody's)
 
   const long n_wtiles = (p.M + 31) / 32;
-  for (long wt = (long)q * GS_NW + wave; wt < n_wtiles; wt += (long)p.streams * GS_NW) {
+  const long wt_step = (long)p.streams * GS_NW;
+  float4 ra[KS], rb[KS];
+  auto load_rows = [&](long wt, auto first, auto last) __attribute__((always_inline)) {
+    const long tok = wt * 32 + li;
+    const float* xr = p.A + (tok < p.M ? tok : p.M - 1) * p.lda + lk * 8;
+#pragma unroll
+    for (int ks = decltype(first)::value; ks < decltype(last)::value; ++ks) {
+      ra[ks] = *(const float4*)(xr + ks * 16);
+      rb[ks] = *(const float4*)(xr + ks * 16 + 4);
+    }
+  };
+  typedef gs_int<0> k_begin;
+  typedef gs_int<PFK> k_pf;
+  typedef gs_int<KS> k_end;
+  long wt = (long)q * GS_NW + wave;
+  if (PFK > 0 && wt < n_wtiles) load_rows(wt, k_begin(), k_pf());
+  for (; wt < n_wtiles; wt += wt_step) {
+    if (PFK < KS) load_rows(wt, k_pf(), k_end());
     const long tok = wt * 32 + li;
     const bool tok_ok = tok < p.M;
     const long tokc = tok_ok ? tok : p.M - 1;
-    // ---- 32 token rows -> registers (B operand: lane = token li, 8 channels 16 ks + 8 lk ..), split on the fly
+    // ---- 32 token rows (B operand: lane = token li, 8 channels 16 ks + 8 lk ..) split into (hi, lo)
     bf16x8 xh[KS], xl[KS];
-    {
-      const float* xr = p.A + tokc * p.lda + lk * 8;
-      float4 ra[KS], rb[KS];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        ra[ks] = *(const float4*)(xr + ks * 16);
-        rb[ks] = *(const float4*)(xr + ks * 16 + 4);
+    for (int ks = 0; ks < KS; ++ks) {
+      uint32_t h[4], l[4];
+      occf_bf16_split2(ra[ks].x, ra[ks].y, h[0], l[0]);
+      occf_bf16_split2(ra[ks].z, ra[ks].w, h[1], l[1]);
+      occf_bf16_split2(rb[ks].x, rb[ks].y, h[2], l[2]);
+      occf_bf16_split2(rb[ks].z, rb[ks].w, h[3], l[3]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[ks][2 * e] = (short)(h[e] & 0xFFFFu);
+        xh[ks][2 * e + 1] = (short)(h[e] >> 16);
+        xl[ks][2 * e] = (short)(l[e] & 0xFFFFu);
+        xl[ks][2 * e + 1] = (short)(l[e] >> 16);
       }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        uint32_t h[4], l[4];
-        occf_bf16_split2(ra[ks].x, ra[ks].y, h[0], l[0]);
-        occf_bf16_split2(ra[ks].z, ra[ks].w, h[1], l[1]);
-        occf_bf16_split2(rb[ks].x, rb[ks].y, h[2], l[2]);
-        occf_bf16_split2(rb[ks].z, rb[ks].w, h[3], l[3]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xh[ks][2 * e] = (short)(h[e] & 0xFFFFu);
-          xh[ks][2 * e + 1] = (short)(h[e] >> 16);
-          xl[ks][2 * e] = (short)(l[e] & 0xFFFFu);
-          xl[ks][2 * e + 1] = (short)(l[e] >> 16);
-        }
-      }
+    }
+    if (PFK > 0) {       // (the last tile re-reads itself: no branch around loads)
+      OCCF_SCHED_FENCE();
+      load_rows(wt + wt_step < n_wtiles ? wt + wt_step : wt, k_begin(), k_pf());
+      OCCF_SCHED_FENCE();
     }
     float* crow = p.C + tokc * p.ldc + n0 + lk * 4;
     const float* rrow = p.residual ? p.residual + tokc * p.ldr + n0 + lk * 4 : nullptr;
     for (int j = 0; j < p.ntb; ++j) {
-      float4 res[4];
-      if (rrow) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) res[g] = *(const float4*)(rrow + j * 32 + g * 8);
-      }
       const unsigned char* Wt = Wimg + (size_t)j * ARR * IMG + li * 32 + lk * 16;
       f32x16 acc;
 #pragma unroll
@@ -129,6 +150,14 @@ __global__ void __launch_bounds__(GS_NW * 64) gemm_stream_kernel(GemmStreamArgs 
         acc = occf_mfma_bf16_32x32x16(wh, xh[ks], acc);
       }
       // ---- epilogue of this 32-channel tile: registers r = 4 g + e <-> channel 8 g + 4 lk + e of token li
+      // (the residual rows are fetched HERE, not ahead of the MFMAs: 16 registers the prefetched rows need at K = 192;
+      // the SIMD partner covers the latency)
+      float4 res[4];
+      OCCF_SCHED_FENCE();
+      if (rrow) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) res[g] = *(const float4*)(rrow + j * 32 + g * 8);
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 b4 = *(const float4*)(bias_s + j * 32 + g * 8 + lk * 4);

@@ -83,6 +83,7 @@ def main():
             if hasattr(ops, n)}
     rows = []
     for mode, bits in (("bf16x3 (3 products: the default)", None), ("2-term, fp16 piece (11 bits)", 11),
+                       ("2-term fp16 piece in the WEIGHT GRADIENTS only (leaf quantities: nothing propagates)", "wg11"),
                        ("2-term, bf16 piece (8 bits)", 8), ("mixed: bf16x3 convolutions, plain bf16 linears", "mixed"),
                        ("plain bf16 (1 product)", "bf16")):
         for p in gemm_weights(model):
@@ -95,6 +96,9 @@ def main():
                 p.data.copy_(round_bits(exact[id(p)], bits))
             ops.linear_wgrad = lambda dy, x, *a, _f=orig["linear_wgrad"], **k: _f(round_bits(dy, bits), x, *a, **k)
             ops.conv3d_wgrad = lambda dy, x, *a, _f=orig["conv3d_wgrad"], **k: _f(round_bits(dy, bits), x, *a, **k)
+        elif bits == "wg11":
+            ops.linear_wgrad = lambda dy, x, *a, _f=orig["linear_wgrad"], **k: _f(round_bits(dy, 11), x, *a, **k)
+            ops.conv3d_wgrad = lambda dy, x, *a, _f=orig["conv3d_wgrad"], **k: _f(round_bits(dy, 11), x, *a, **k)
         elif bits == "mixed":
             def plain(f):
                 def g(*a, **k):
