@@ -305,6 +305,14 @@ int occf_modulated_deform_im2col(const float* x, const float* offset, const floa
                                  int W, int C, int K, int stride, int pad, int dil, int groups, int deform_groups,
                                  void* stream);
 
+/* Inference epilogue of the 2-D image branch (ResNet Bottleneck / SECONDFPN, outside the north-star path but inside
+ * the reference's from-images forward, occupancyformer.py:59-67): y[p, c] = act(y[p, c] * scale[c] + shift[c]
+ * (+ residual[p, c])) IN PLACE over rows x C channels-last elements -- eval-mode BatchNorm + identity add + ReLU as one
+ * pass over the MIOpen convolution's output.  bf16 != 0: y / residual are bf16 (C % 8 == 0), else fp32 (C % 4 == 0);
+ * scale / shift are fp32 [C]. */
+int occf_scale_shift_act(void* y, const float* scale, const float* shift, const void* residual, long rows, int C,
+                         int relu, int bf16, void* stream);
+
 /* ------------------------------------------------------------------ training-time sampling */
 
 /* point_sample_3d (P/occformer/mask2former/base/mmdet_utils.py:21-47 = F.grid_sample on

@@ -11,6 +11,7 @@ PyTorch-ROCm/MIOpen (outside the hand-written kernel scope
 """
 import collections
 import contextlib
+import os
 import time
 import weakref
 
@@ -108,6 +109,74 @@ class ModulatedDeformConv2dPack(nn.Module):
         return out if dt == torch.float32 else out.to(dt)
 
 
+# ---- inference route of the image branch: convolution (MIOpen) + ONE fused epilogue pass per convolution ------------
+# The reference's modules run conv, BatchNorm, ReLU (and the Bottleneck's identity add) as separate passes over the
+# feature map (7 elementwise passes per Bottleneck); in eval mode without a graph the BatchNorm is an affine map per
+# channel, so the pass after each convolution is csrc/image_epilogue.hip: y = relu(y * scale + shift (+ identity)) in
+# place -- 3 passes per Bottleneck -- and the convolution weights are kept in the branch's dtype / channels_last (under
+# autocast every call re-cast them).  OCCF_IMAGE_FUSE=0 keeps the module-by-module route; training always takes it.
+_IMAGE_FUSE = os.environ.get("OCCF_IMAGE_FUSE", "1") == "1"
+_BN_AFFINE = {}
+_CONV_W = {}
+
+
+def _fused_eval(x, bn):
+    return _IMAGE_FUSE and x.is_cuda and not bn.training and not torch.is_grad_enabled() and x.dim() == 4
+
+
+def _bn_affine(bn):
+    from . import fused
+    key = (fused.param_version(bn.weight, bn.bias), bn.running_mean._version, bn.running_var._version,
+           bn.running_mean.data_ptr())
+    hit = _BN_AFFINE.get(id(bn))
+    if hit is None or hit[0] != key or hit[3]() is not bn:
+        scale = (bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)).contiguous()
+        shift = (bn.bias.detach().float() - bn.running_mean.float() * scale).contiguous()
+        hit = _BN_AFFINE[id(bn)] = (key, scale, shift, weakref.ref(bn))
+    return hit[1], hit[2]
+
+
+def _conv_weight(conv, dtype):
+    from . import fused
+    key = (fused.param_version(conv.weight), dtype)
+    hit = _CONV_W.get(id(conv))
+    if hit is None or hit[0] != key or hit[2]() is not conv:
+        w = conv.weight.detach().to(dtype).contiguous(memory_format=torch.channels_last)
+        hit = _CONV_W[id(conv)] = (key, w, weakref.ref(conv))
+    return hit[1]
+
+
+def conv_bn_act(x, conv, bn, relu=True, residual=None):
+    """relu?(bn(conv(x)) (+ residual)).  Eval mode on the GPU without a graph: MIOpen convolution + one fused epilogue
+    pass (see above); otherwise the reference's module sequence."""
+    if not _fused_eval(x, bn):
+        y = bn(conv(x))
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+    from .ops import get_ops
+    scale, shift = _bn_affine(bn)
+    if isinstance(conv, ModulatedDeformConv2dPack):
+        y = conv(x)                                      # (its own fp32 island; returns the branch's dtype)
+    else:
+        if torch.is_autocast_enabled():
+            x = x.to(torch.get_autocast_gpu_dtype())
+        x = x.contiguous(memory_format=torch.channels_last)
+        w = _conv_weight(conv, x.dtype)
+        with torch.autocast("cuda", enabled=False):
+            if isinstance(conv, nn.ConvTranspose2d):
+                y = F.conv_transpose2d(x, w, None, conv.stride, conv.padding, conv.output_padding, conv.groups,
+                                       conv.dilation)
+            else:
+                y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if conv.bias is not None:
+            shift = shift + conv.bias.detach().float() * scale
+    y = y.contiguous(memory_format=torch.channels_last)
+    if residual is not None:
+        residual = residual.to(y.dtype).contiguous(memory_format=torch.channels_last)
+    return get_ops().scale_shift_act(y, scale, shift, residual, relu)
+
+
 class _Bottleneck(nn.Module):
     expansion = 4
 
@@ -127,10 +196,10 @@ class _Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        y = F.relu(self.bn1(self.conv1(x)))
-        y = F.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        return F.relu(y + (x if self.downsample is None else self.downsample(x)))
+        y = conv_bn_act(x, self.conv1, self.bn1)
+        y = conv_bn_act(y, self.conv2, self.bn2)
+        ident = x if self.downsample is None else conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+        return conv_bn_act(y, self.conv3, self.bn3, residual=ident)
 
 
 @BACKBONES.register_module()
@@ -182,7 +251,7 @@ class ResNet(nn.Module):
         return self
 
     def forward(self, x):
-        x = F.max_pool2d(F.relu(self.bn1(self.conv1(x))), 3, stride=2, padding=1)
+        x = F.max_pool2d(conv_bn_act(x, self.conv1, self.bn1), 3, stride=2, padding=1)
         outs = []
         for i in range(self.num_stages):
             x = getattr(self, f"layer{i + 1}")(x)
@@ -213,7 +282,7 @@ class SECONDFPN(nn.Module):
         self.deblocks = nn.ModuleList(blocks)
 
     def forward(self, x):
-        ups = [blk(x[i]) for i, blk in enumerate(self.deblocks)]
+        ups = [conv_bn_act(x[i], blk[0], blk[1]) for i, blk in enumerate(self.deblocks)]       # blk[2] = nn.ReLU
         return [torch.cat(ups, 1) if len(ups) > 1 else ups[0]]
 
 

@@ -528,6 +528,22 @@ class HipOps:
                    B, X, Y, Z, X2, Y2, Z2, C, self._stream())
         return out
 
+    def scale_shift_act(self, y, scale, shift, residual=None, relu=True):
+        """IN PLACE on a channels_last [N, C, H, W] (or row-major [..., C]) feature map, fp32 or bf16:
+        y = act(y * scale[c] + shift[c] (+ residual)) -- eval BatchNorm + identity add + ReLU of the image branch"""
+        cl = y.dim() == 4 and y.is_contiguous(memory_format=torch.channels_last)
+        C = y.shape[1] if cl else y.shape[-1]
+        if not (cl or y.is_contiguous()) or y.dtype not in (torch.float32, torch.bfloat16):
+            raise OccfError("scale_shift_act: a channels_last / row-major fp32 or bf16 tensor expected")
+        if residual is not None and (residual.shape != y.shape or residual.dtype != y.dtype or residual.stride() != y.stride()):
+            raise OccfError("scale_shift_act: the residual must have the layout of y")
+        if self.strict and not y.is_cuda:
+            raise OccfError("occformer_amd ops need GPU tensors (no CPU path exists)")
+        self._call("occf_scale_shift_act", ctypes.c_void_p(y.data_ptr()), self._ptr(scale, self.f32, C),
+                   self._ptr(shift, self.f32, C), ctypes.c_void_p(residual.data_ptr() if residual is not None else 0),
+                   y.numel() // C, C, int(bool(relu)), int(y.dtype == torch.bfloat16), self._stream())
+        return y
+
     def deform_im2col(self, x_cl, offset, K, stride, pad, dil, groups, deform_groups, mask=None):
         """x_cl [BN, H, W, C], offset [BN, dg*2*K*K, Ho, Wo] (, mask [BN, dg*K*K, Ho, Wo]: DCNv2)
         -> col [BN*Ho*Wo, groups, K*K, C/groups]."""

@@ -62,5 +62,29 @@ done
 ( time timeout 1500 python scripts/precision_probe.py ) 2>&1 | grep -v "amdgpu.ids\|MIOpen(HIP)" > $O/r05b_precision_probe.txt
 tail -12 $O/r05b_precision_probe.txt | cut -c1-400
 ;;
+c)  # round 5, visit c: streaming linear with LDS-DMA staging + next-tile prefetch; fused inference route of the image branch (from-images forward with / without); 2-term fp16 in the weight gradients only
+timeout 600 python scripts/stream_probe.py 2>&1 | grep -v "amdgpu.ids" | tee $O/r05c_stream_probe.txt
+timeout 900 python -m pytest tests/test_gemm_norm_ops.py tests/test_image_backbone.py -m gpu -q -p no:cacheprovider -k "streaming or linear or image or dcn or resnet or scale_shift" 2>&1 | grep -v "MIOpen(HIP)" | tail -8
+for v in 0 1; do
+  OCCF_IMAGE_FUSE=$v timeout 400 python bench.py --mode forward --from-images --steps 20 --warmup 3 > $O/r05c_bench_fwd_from_images_fuse$v.json 2>/dev/null
+  python - <<PY
+import json
+f = json.load(open("gpurun_out/r05c_bench_fwd_from_images_fuse$v.json"))
+print("OCCF_IMAGE_FUSE=$v forward from images", round(f["value"], 2), "samples/s", round(f["ms_per_step"], 2), "ms", f["stages_ms"])
+PY
+done
+timeout 400 python bench.py --workload nusc_r101 --mode forward --from-images --steps 20 --warmup 3 > $O/r05c_bench_fwd_from_images_nusc_r101.json 2>/dev/null
+python -c "
+import json; f=json.load(open('gpurun_out/r05c_bench_fwd_from_images_nusc_r101.json')); print('nusc_r101 from images', round(f['value'],2), round(f['ms_per_step'],2), f['stages_ms'])"
+timeout 400 python bench.py --mode forward --steps 20 --warmup 3 --no-cpu-baseline --shape-report $O/r05c_shapes_fwd.txt > $O/r05c_bench_fwd.json 2>/dev/null
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --shape-report $O/r05c_shapes_train.txt > $O/r05c_bench_train.json 2>/dev/null
+python - <<PY
+import json
+f = json.load(open("gpurun_out/r05c_bench_fwd.json")); t = json.load(open("gpurun_out/r05c_bench_train.json"))
+print("forward", round(f["value"], 2), "samples/s", round(f["ms_per_step"], 2), "ms, linear", f["kernels"]["linear"]["total_ms"], "| train", round(t["value"], 3), round(t["ms_per_step"], 2), "ms, linear", t["kernels"]["linear"]["total_ms"], "| train-bench forward", round(t["forward"]["value"], 2), "from images", round(t["forward_from_images"]["value"], 2))
+PY
+( time timeout 900 python scripts/precision_probe.py wg11 ) 2>&1 | grep -v "amdgpu.ids\|MIOpen(HIP)" > $O/r05c_precision_probe_wg11.txt
+tail -6 $O/r05c_precision_probe_wg11.txt | cut -c1-400
+;;
 *) echo "usage: $0 <stage>"; exit 2;;
 esac

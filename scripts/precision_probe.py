@@ -82,10 +82,13 @@ def main():
     orig = {n: getattr(ops, n) for n in ("linear", "linear_wgrad", "conv3d_wgrad", "mlp_fused", "swin_attention_fused")
             if hasattr(ops, n)}
     rows = []
+    only = set(sys.argv[1:])                 # e.g. "wg11": run a subset (keys: None 11 wg11 8 mixed bf16)
     for mode, bits in (("bf16x3 (3 products: the default)", None), ("2-term, fp16 piece (11 bits)", 11),
                        ("2-term fp16 piece in the WEIGHT GRADIENTS only (leaf quantities: nothing propagates)", "wg11"),
                        ("2-term, bf16 piece (8 bits)", 8), ("mixed: bf16x3 convolutions, plain bf16 linears", "mixed"),
                        ("plain bf16 (1 product)", "bf16")):
+        if only and str(bits) not in only:
+            continue
         for p in gemm_weights(model):
             p.data.copy_(exact[id(p)])
         for n, f in orig.items():

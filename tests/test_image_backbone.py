@@ -249,3 +249,56 @@ def test_image_branch_gpu_vs_cpu(hip):
         model.img_neck.to(memory_format=torch.channels_last)
         out16 = model.image_encoder(img.to(hip.device)).cpu()
         assert float((out16 - ref).abs().max() / ref.abs().max()) < 5e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_res,relu", [(True, True), (False, True), (False, False)])
+def test_scale_shift_act_epilogue(be, dtype, with_res, relu):
+    """csrc/image_epilogue.hip: eval BatchNorm + identity add + ReLU of the image branch as one in-place pass over a
+    channels_last feature map (fp32 and bf16), against the module sequence it replaces"""
+    y = paramgen.tensor("ie.y", (3, 24, 5, 7), 1, 1.5).to(dtype).contiguous(memory_format=torch.channels_last)
+    r = paramgen.tensor("ie.r", (3, 24, 5, 7), 2).to(dtype).contiguous(memory_format=torch.channels_last)
+    scale = 1 + 0.3 * paramgen.tensor("ie.s", (24,), 3)
+    shift = 0.2 * paramgen.tensor("ie.b", (24,), 4)
+    ref = y.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if with_res:
+        ref = ref + r.float()
+    if relu:
+        ref = torch.relu(ref)
+    yd = be.to(y)
+    out = be.ops.scale_shift_act(yd, be.to(scale), be.to(shift), be.to(r) if with_res else None, relu)
+    assert out.data_ptr() == yd.data_ptr() and out.dtype == dtype
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert float((out.float().cpu() - ref).abs().max()) <= tol * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_resnet_fused_inference_route_equals_the_module_route(hip, monkeypatch):
+    """ResNet-50 + SECONDFPN in eval mode on the GPU: the fused route (MIOpen convolution + csrc/image_epilogue.hip, the
+    default) against the module-by-module route (OCCF_IMAGE_FUSE=0), fp32 and the bf16 channels_last mode"""
+    import occformer_amd.detector as D
+    from occformer_amd.registry import MODELS
+    from occformer_amd import configs
+    bb_cfg, neck_cfg = configs.image_branch("nusc_r50_200")
+    torch.manual_seed(0)
+    bb, neck = MODELS.build(bb_cfg).to(hip.device).eval(), MODELS.build(neck_cfg).to(hip.device).eval()
+    for m in list(bb.modules()) + list(neck.modules()):
+        if isinstance(m, torch.nn.BatchNorm2d):              # non-trivial running statistics
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(2, 3, 64, 96, device=hip.device)
+    calls = []
+    orig = hip.ops.scale_shift_act
+    monkeypatch.setattr(hip.ops, "scale_shift_act", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    with torch.no_grad():
+        monkeypatch.setattr(D, "_IMAGE_FUSE", False)
+        ref = neck(bb(x))[0]
+        assert not calls
+        monkeypatch.setattr(D, "_IMAGE_FUSE", True)
+        out = neck(bb(x))[0]
+        assert len(calls) == 53 + 4                          # 53 backbone BatchNorms (stem, 16 x 3, 4 downsample) + 4 deblocks
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out16 = neck(bb(x.contiguous(memory_format=torch.channels_last)))[0]
+    assert out.shape == ref.shape
+    assert float((out - ref).abs().max() / ref.abs().max()) < 1e-4
+    assert float((out16.float() - ref).abs().max() / ref.abs().max()) < 6e-2
