@@ -105,7 +105,7 @@ class ModulatedDeformConv2dPack(nn.Module):
         else:
             out = self._forward_hip(x, offset, mask)
         # (under autocast an fp32 input means the caller's ops produce the autocast dtype: hand that back)
-        dt = torch.get_autocast_gpu_dtype() if autocast and dt == torch.float32 else dt
+        dt = torch.get_autocast_dtype("cuda") if autocast and dt == torch.float32 else dt
         return out if dt == torch.float32 else out.to(dt)
 
 
@@ -160,7 +160,7 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None):
         y = conv(x)                                      # (its own fp32 island; returns the branch's dtype)
     else:
         if torch.is_autocast_enabled():
-            x = x.to(torch.get_autocast_gpu_dtype())
+            x = x.to(torch.get_autocast_dtype("cuda"))
         x = x.contiguous(memory_format=torch.channels_last)
         w = _conv_weight(conv, x.dtype)
         with torch.autocast("cuda", enabled=False):

@@ -86,5 +86,16 @@ PY
 ( time timeout 900 python scripts/precision_probe.py wg11 ) 2>&1 | grep -v "amdgpu.ids\|MIOpen(HIP)" > $O/r05c_precision_probe_wg11.txt
 tail -6 $O/r05c_precision_probe_wg11.txt | cut -c1-400
 ;;
+d)  # round 5, visit d: access-pattern micro-probe (row-per-lane vs coalesced), kernel statistics of the from-images forward with / without the fused image route
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/row_access_probe.hip -o /tmp/rap 2>/dev/null && /tmp/rap | tee $O/r05d_row_access_probe.txt
+cd /tmp && export TMPDIR=/tmp
+for v in 0 1; do
+  OCCF_IMAGE_FUSE=$v timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/r05d_prof_img$v -- python $R/bench.py --mode forward --from-images --steps 10 --warmup 3 > /dev/null 2>&1
+  python $R/scripts/summarize_prof.py $R/$O/r05d_prof_img$v > $R/$O/r05d_fwd_from_images_fuse${v}_kernel_stats.txt 2>&1
+  echo "== OCCF_IMAGE_FUSE=$v"; grep -i "miopen\|conv\|batch_norm\|elementwise\|scale_shift\|nchw\|nhwc\|transpose\|copy\|Cijk\|igemm\|naive" $R/$O/r05d_fwd_from_images_fuse${v}_kernel_stats.txt | head -40 | cut -c1-170
+done
+cd $R
+find $O -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
+;;
 *) echo "usage: $0 <stage>"; exit 2;;
 esac
