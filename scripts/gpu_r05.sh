@@ -97,5 +97,24 @@ done
 cd $R
 find $O -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
 ;;
+e)  # round 5, visit e: streaming linear with whole-line stores (token-row accumulator layout); image epilogue without the 64-bit modulo
+timeout 600 python scripts/stream_probe.py 2>&1 | grep -v "amdgpu.ids" | tee $O/r05e_stream_probe.txt
+timeout 900 python -m pytest tests/test_gemm_norm_ops.py tests/test_image_backbone.py -m gpu -q -p no:cacheprovider -k "streaming or linear or resnet or scale_shift" 2>&1 | grep -v "MIOpen(HIP)" | tail -3
+for v in 0 1; do
+  OCCF_IMAGE_FUSE=$v timeout 400 python bench.py --mode forward --from-images --steps 20 --warmup 3 > $O/r05e_bench_fwd_from_images_fuse$v.json 2>/dev/null
+  python - <<PY
+import json
+f = json.load(open("gpurun_out/r05e_bench_fwd_from_images_fuse$v.json"))
+print("OCCF_IMAGE_FUSE=$v forward from images", round(f["value"], 2), "samples/s", round(f["ms_per_step"], 2), "ms", f["stages_ms"])
+PY
+done
+timeout 400 python bench.py --mode forward --steps 20 --warmup 3 --no-cpu-baseline --shape-report $O/r05e_shapes_fwd.txt > $O/r05e_bench_fwd.json 2>/dev/null
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --shape-report $O/r05e_shapes_train.txt > $O/r05e_bench_train.json 2>/dev/null
+python - <<PY
+import json
+f = json.load(open("gpurun_out/r05e_bench_fwd.json")); t = json.load(open("gpurun_out/r05e_bench_train.json"))
+print("forward", round(f["value"], 2), "samples/s", round(f["ms_per_step"], 2), "ms, linear", f["kernels"]["linear"]["total_ms"], "| train", round(t["value"], 3), round(t["ms_per_step"], 2), "ms, linear", t["kernels"]["linear"]["total_ms"], "| train-bench forward", round(t["forward"]["value"], 2), "from images", round(t["forward_from_images"]["value"], 2))
+PY
+;;
 *) echo "usage: $0 <stage>"; exit 2;;
 esac

@@ -253,13 +253,15 @@ def test_image_branch_gpu_vs_cpu(hip):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("with_res,relu", [(True, True), (False, True), (False, False)])
-def test_scale_shift_act_epilogue(be, dtype, with_res, relu):
+@pytest.mark.parametrize("shape", [(3, 24, 5, 7), (2, 64, 23, 9)])      # (a thread walks the channel groups / stays on one)
+def test_scale_shift_act_epilogue(be, dtype, with_res, relu, shape):
     """csrc/image_epilogue.hip: eval BatchNorm + identity add + ReLU of the image branch as one in-place pass over a
     channels_last feature map (fp32 and bf16), against the module sequence it replaces"""
-    y = paramgen.tensor("ie.y", (3, 24, 5, 7), 1, 1.5).to(dtype).contiguous(memory_format=torch.channels_last)
-    r = paramgen.tensor("ie.r", (3, 24, 5, 7), 2).to(dtype).contiguous(memory_format=torch.channels_last)
-    scale = 1 + 0.3 * paramgen.tensor("ie.s", (24,), 3)
-    shift = 0.2 * paramgen.tensor("ie.b", (24,), 4)
+    C = shape[1]
+    y = paramgen.tensor("ie.y", shape, 1, 1.5).to(dtype).contiguous(memory_format=torch.channels_last)
+    r = paramgen.tensor("ie.r", shape, 2).to(dtype).contiguous(memory_format=torch.channels_last)
+    scale = 1 + 0.3 * paramgen.tensor("ie.s", (C,), 3)
+    shift = 0.2 * paramgen.tensor("ie.b", (C,), 4)
     ref = y.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
     if with_res:
         ref = ref + r.float()
