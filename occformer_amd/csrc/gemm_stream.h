@@ -12,12 +12,12 @@
 // images in MFMA-fragment order, <= 148 KB -- into LDS ONCE and then streams token tiles: each wave owns 32 tokens at
 // a time and works on the TRANSPOSED problem (as mlp_chain.hip)
 //
-//     C[32 tokens x 32 channels] = A[32 x K] . Wtile[32 x K]^T              A operand = token rows (registers), B = W rows (LDS)
+//     Ct[32 channels x 32 tokens] = Wtile[32 x K] . At[K x 32 tokens]        A operand = W rows (LDS), B = At (registers)
 //
-// so the activation rows go global -> registers -> split (hi, lo) without touching LDS (lane = one token row: a load
-// instruction covers 32 rows x 32 bytes, 3 % off the coalesced rate), the result leaves the accumulators as dword stores
-// that cover whole cache lines (lane = channel), and there is no barrier after the staging one: the eight waves drift
-// apart and one wave's row latency / epilogue hides under its SIMD partner's MFMAs.  HBM traffic = the rows once in, once out (N blocks > 1: the blocks of one token range run on the same XCD at
+// so the activation rows go global -> registers -> split (hi, lo) without touching LDS, the result leaves the
+// accumulators as four 16-byte stores per lane (lane = token, 4 consecutive channels), and there is no barrier after
+// the staging one: the eight waves drift apart and one wave's row latency / epilogue hides under its SIMD partner's
+// MFMAs.  HBM traffic = the rows once in, once out (N blocks > 1: the blocks of one token range run on the same XCD at
 // the same time, so the re-reads are L2 hits).
 //
 // The k index of the contraction is free to permute as long as both operands agree; lane (token li, half lk) takes the 8
@@ -107,7 +107,10 @@ __global__ void __launch_bounds__(GS_NW * 64) gemm_stream_kernel(GemmStreamArgs 
   if (PFK > 0 && wt < n_wtiles) load_rows(wt, k_begin(), k_pf());
   for (; wt < n_wtiles; wt += wt_step) {
     if (PFK < KS) load_rows(wt, k_pf(), k_end());
-    // ---- 32 token rows (A operand: lane = token li, 8 channels 16 ks + 8 lk ..) split into (hi, lo)
+    const long tok = wt * 32 + li;
+    const bool tok_ok = tok < p.M;
+    const long tokc = tok_ok ? tok : p.M - 1;
+    // ---- 32 token rows (B operand: lane = token li, 8 channels 16 ks + 8 lk ..) split into (hi, lo)
     bf16x8 xh[KS], xl[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -129,15 +132,8 @@ __global__ void __launch_bounds__(GS_NW * 64) gemm_stream_kernel(GemmStreamArgs 
       load_rows(wt + wt_step < n_wtiles ? wt + wt_step : wt, k_begin(), k_pf());
       OCCF_SCHED_FENCE();
     }
-    // ---- C[32 tokens x 32 channels] per tile j: A operand = the token rows (registers), B operand = W rows (LDS):
-    // lane -> channel n0 + 32 j + li, registers r -> tokens (r & 3) + 8 (r >> 2) + 4 lk.  A store instruction then
-    // writes, for one r, 2 tokens x 128 contiguous bytes -- whole cache lines (r05d scripts/row_access_probe.hip: the
-    // transposed tile's 16-byte-per-row stores cost 15 % of the copy rate, 5.6 -> 4.8 TB/s; row LOADS cost 3 %)
-    // (element offsets are 32-bit: the launcher refuses M * ld >= 2^31; (8 g + e) * ld are wave-uniform scalars)
-    const int left = (int)(p.M - wt * 32 < 32 ? p.M - wt * 32 : 32) - 4 * lk;        // valid rows of this lane half
-    const int ldc = (int)p.ldc, ldr = (int)p.ldr;
-    float* cbase = p.C + (wt * 32 + 4 * lk) * p.ldc + n0 + li;
-    const float* rbase = p.residual ? p.residual + (wt * 32 + 4 * lk) * p.ldr + n0 + li : nullptr;
+    float* crow = p.C + tokc * p.ldc + n0 + lk * 4;
+    const float* rrow = p.residual ? p.residual + tokc * p.ldr + n0 + lk * 4 : nullptr;
     for (int j = 0; j < p.ntb; ++j) {
       const unsigned char* Wt = Wimg + (size_t)j * ARR * IMG + li * 32 + lk * 16;
       f32x16 acc;
@@ -148,26 +144,32 @@ __global__ void __launch_bounds__(GS_NW * 64) gemm_stream_kernel(GemmStreamArgs 
         const bf16x8 wh = *(const bf16x8*)(Wt + ks * 1024);
         if (TERMS == 3) {
           const bf16x8 wl = *(const bf16x8*)(Wt + IMG + ks * 1024);
-          acc = occf_mfma_bf16_32x32x16(xh[ks], wl, acc);
-          acc = occf_mfma_bf16_32x32x16(xl[ks], wh, acc);
+          acc = occf_mfma_bf16_32x32x16(wl, xh[ks], acc);
+          acc = occf_mfma_bf16_32x32x16(wh, xl[ks], acc);
         }
-        acc = occf_mfma_bf16_32x32x16(xh[ks], wh, acc);
+        acc = occf_mfma_bf16_32x32x16(wh, xh[ks], acc);
       }
-      const float bj = bias_s[j * 32 + li];
+      // ---- epilogue of this 32-channel tile: registers r = 4 g + e <-> channel 8 g + 4 lk + e of token li
+      // (the residual rows are fetched HERE, not ahead of the MFMAs: 16 registers the prefetched rows need at K = 192;
+      // the SIMD partner covers the latency)
+      float4 res[4];
       OCCF_SCHED_FENCE();
+      if (rrow) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g) res[g] = *(const float4*)(rrow + j * 32 + g * 8);
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int tr = 8 * g + e;                       // row of this lane half's 4 lk + ... block
-          float v = acc[4 * g + e] + bj;
-          if (p.act == 1) v = fmaxf(v, 0.f);
-          else if (p.act == 2) v = occf_gelu_b(v);
-          if (tr < left) {
-            if (rbase) v += rbase[tr * ldr + j * 32];
-            cbase[tr * ldc + j * 32] = v;
-          }
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = *(const float4*)(bias_s + j * 32 + g * 8 + lk * 4);
+        float4 v = make_float4(acc[4 * g] + b4.x, acc[4 * g + 1] + b4.y, acc[4 * g + 2] + b4.z, acc[4 * g + 3] + b4.w);
+        if (p.act == 1) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        } else if (p.act == 2) {
+          v.x = occf_gelu_b(v.x); v.y = occf_gelu_b(v.y); v.z = occf_gelu_b(v.z); v.w = occf_gelu_b(v.w);
         }
+        if (rrow) { v.x += res[g].x; v.y += res[g].y; v.z += res[g].z; v.w += res[g].w; }
+        if (tok_ok) *(float4*)(crow + j * 32 + g * 8) = v;
+      }
     }
   }
 }
@@ -200,8 +202,7 @@ static int occf_gemm_stream_launch(const float* A, const uint16_t* Wh, const uin
   const long min_rows = occf_gemm_stream_min_rows();
   if (min_rows < 0 || M < min_rows) return OCCF_ESHAPE;
   if (K != 64 && K != 96 && K != 128 && K != 160 && K != 192 && K != 224 && K != 256) return OCCF_ESHAPE;
-  if (lda % 4 != 0 || (terms != 1 && terms != 3)) return OCCF_ESHAPE;
-  if (32 * ldc >= 2147483647L || (residual && 32 * ldr >= 2147483647L)) return OCCF_ESHAPE;
+  if ((lda | ldc) % 4 != 0 || (residual && ldr % 4 != 0) || (terms != 1 && terms != 3)) return OCCF_ESHAPE;
   const int ntb = occf_gemm_stream_ntb(N, K, terms);
   if (ntb == 0) return OCCF_ESHAPE;
   GemmStreamArgs a = {A, Wh, Wl, bias, residual, C, M, N, K, lda, ldc, ldr, act, ntb, N / (32 * ntb), 0};

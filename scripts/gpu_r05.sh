@@ -116,5 +116,8 @@ f = json.load(open("gpurun_out/r05e_bench_fwd.json")); t = json.load(open("gpuru
 print("forward", round(f["value"], 2), "samples/s", round(f["ms_per_step"], 2), "ms, linear", f["kernels"]["linear"]["total_ms"], "| train", round(t["value"], 3), round(t["ms_per_step"], 2), "ms, linear", t["kernels"]["linear"]["total_ms"], "| train-bench forward", round(t["forward"]["value"], 2), "from images", round(t["forward_from_images"]["value"], 2))
 PY
 ;;
+f)  # round 5, visit f: access-pattern probe with the dword whole-line stores and the LDS-transposed float4 stores
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/row_access_probe.hip -o /tmp/rap 2>/dev/null && /tmp/rap | tee $O/r05f_row_access_probe.txt
+;;
 *) echo "usage: $0 <stage>"; exit 2;;
 esac

@@ -7,6 +7,8 @@
 //   mode 2: coalesced loads, ROW stores (lane: row li, floats 32 j + 8 g + 4 lk .. -- the MFMA C layout)
 //   mode 3: ROW loads, ROW stores                        (what gemm_stream does, without the arithmetic)
 //   mode 4: ROW loads with 32 contiguous bytes per lane PAIR per instruction (lk picks the 16-byte half), coalesced stores
+//   mode 5: coalesced loads, DWORD stores that cover whole lines (lane = channel, the token-major MFMA C layout)
+//   mode 6: ROW loads, the C-layout tile transposed through a wave-private LDS region (4.6 KB), float4 whole-line stores
 // build + run on the GPU box:  hipcc --offload-arch=gfx950 -O3 scripts/row_access_probe.hip -o /tmp/rap && /tmp/rap
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -20,7 +22,7 @@ __global__ void __launch_bounds__(512) probe(const float* __restrict__ in, float
   for (long t = (long)blockIdx.x * 8 + wave; t < n_tiles; t += (long)streams * 8) {
     const long row0 = t * 32;
     float4 v[2 * KS];
-    if (MODE == 0 || MODE == 2) {
+    if (MODE == 0 || MODE == 2 || MODE == 5) {
       const float4* src = (const float4*)(in + row0 * K);
 #pragma unroll
       for (int i = 0; i < 2 * KS; ++i) v[i] = src[i * 64 + lane];
@@ -39,7 +41,34 @@ __global__ void __launch_bounds__(512) probe(const float* __restrict__ in, float
         v[2 * ks + 1] = *(const float4*)(xr + ks * 16 + 4);
       }
     }
-    if (MODE == 0 || MODE == 1 || MODE == 4) {
+    if (MODE == 5) {
+      // value v[i] component c -> token (row) 2 * (4 i + c) / ... : any bijection serves; 16 dword stores per 32 channels
+      float* cb = out + row0 * K + (lane & 31);
+      const int lk4 = (lane >> 5) * 4;
+#pragma unroll
+      for (int i = 0; i < 2 * KS; ++i) {
+        const float f[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int r = (i & 3) * 4 + c, j = i >> 2;               // n-tile j, accumulator register r
+          cb[(long)((r & 3) + 8 * (r >> 2) + lk4) * K + j * 32] = f[c];
+        }
+      }
+    } else if (MODE == 6) {
+      __shared__ __attribute__((aligned(16))) float stage[8][32 * 36];
+      float* st = stage[wave];
+#pragma unroll
+      for (int j = 0; j < KS / 2; ++j) {                           // 32-channel tiles
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *(float4*)(st + li * 36 + g * 8 + lk * 4) = v[j * 4 + g];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = i * 8 + (lane >> 3), ch = (lane & 7) * 4;
+          const float4 o = *(const float4*)(st + row * 36 + ch);
+          *(float4*)(out + (row0 + row) * K + j * 32 + ch) = o;
+        }
+      }
+    } else if (MODE == 0 || MODE == 1 || MODE == 4) {
       float4* dst = (float4*)(out + row0 * K);
 #pragma unroll
       for (int i = 0; i < 2 * KS; ++i) dst[i * 64 + lane] = v[i];
@@ -61,7 +90,7 @@ void run(long M) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  for (int mode = 0; mode < 5; ++mode) {
+  for (int mode = 0; mode < 7; ++mode) {
     float best = 1e30f;
     for (int rep = 0; rep < 8; ++rep) {
       const float* a = in + (size_t)(rep % NB) * M * K;
@@ -72,6 +101,8 @@ void run(long M) {
         case 1: hipLaunchKernelGGL((probe<KS, 1>), dim3(256), dim3(512), 0, 0, a, b, M, 256); break;
         case 2: hipLaunchKernelGGL((probe<KS, 2>), dim3(256), dim3(512), 0, 0, a, b, M, 256); break;
         case 3: hipLaunchKernelGGL((probe<KS, 3>), dim3(256), dim3(512), 0, 0, a, b, M, 256); break;
+        case 5: hipLaunchKernelGGL((probe<KS, 5>), dim3(256), dim3(512), 0, 0, a, b, M, 256); break;
+        case 6: hipLaunchKernelGGL((probe<KS, 6>), dim3(256), dim3(512), 0, 0, a, b, M, 256); break;
         default: hipLaunchKernelGGL((probe<KS, 4>), dim3(256), dim3(512), 0, 0, a, b, M, 256); break;
       }
       hipEventRecord(e1);
