@@ -256,6 +256,21 @@ int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w
  * kernel (csrc/gemm_stream.h: the weight block stays in LDS, rows stream global -> registers -> MFMA -> global).
  * occf_linear_stream_launches: how many calls took it since the library was loaded (diagnostics / tests). */
 long occf_linear_stream_launches(void);
+/* The same kernel with the epilogues of the TRAINING graph's Swin block (window_attention.py:300-344: DropPath around
+ * the attention projection and around the FFN; mmcv FFN = Linear, GELU, Linear):
+ *   act = 2 with pre_out != NULL: out = GELU(z), pre_out = z = x W^T + b  (the backward needs z; no separate GELU pass)
+ *   row_scale != NULL: out = residual + row_scale[sample(row)] * (x W^T + b), sample(row) = (row / xy_s) * s_slices +
+ *     row % s_slices  (token rows ((b XY + xy) S + s), xy_s = XY * S: mmcv DropPath, one draw per slice) -- no
+ *     separate DropPath pass
+ *   act = 3: out = (x W^T + b) * GELU'(aux[row, col]) with aux = residual_or_aux (row stride ldr): the data gradient
+ *     through the second FFN linear AND the GELU in one pass.
+ * Returns OCCF_ESHAPE when the shape is outside the kernel's envelope (the caller then runs the unfused sequence). */
+/* 1 when a [M, K] x [N, K]^T linear (contiguous rows, ld % 4 == 0) is inside that kernel's envelope right now */
+int occf_linear_stream_takes(long M, int N, int K);
+int occf_linear_stream_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
+                           const float* residual_or_aux, float* out, float* pre_out, const float* row_scale, long M,
+                           int N, int K, long ldx, long ldo, long ldr, int act, int terms, long xy_s, int s_slices,
+                           void* stream);
 int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
                          const float* residual, float* out, int B, int Xi, int Yi, int Zi, int Cin, int Cout,
                          int kX, int kY, int kZ, int stride, int dil, int pad_x, int pad_y, int pad_z,

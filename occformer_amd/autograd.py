@@ -383,6 +383,89 @@ class DropPathAdd(torch.autograd.Function):
         return dy, get_ops().droppath(None, dy, scale, *ctx.geom), None, None, None
 
 
+# ---- the Swin block's two DropPath branches on the streaming kernel's epilogues (csrc/gemm_stream.h) -----------------
+# window_attention.py:300-344 (SwinBlock.forward): x = x + drop_path(attn(norm1(x))); x = x + drop_path(ffn(norm2(x)))
+# with mmcv's FFN = Linear, GELU, Linear.  As separate nodes (Linear, Act, Linear, DropPathAdd) the branch output, the
+# pre-activation and the activation's gradient each make a round trip through HBM per block ([680 000, 128] at stage 0);
+# here the DropPath scale + identity add ride in the projection's epilogue, the GELU in the first FFN linear's (which
+# also writes the pre-activation the backward needs) and GELU' in the epilogue of the data gradient through the second.
+_SWIN_FUSE = os.environ.get("OCCF_TRAIN_SWIN_FUSE", "1") == "1"
+
+
+def _wgrad(g2, x2, weight, has_bias):
+    dw, db = get_ops().linear_wgrad(g2, x2 if x2.stride(1) == 1 else x2.contiguous(), want_bias=has_bias)
+    return dw.view(weight.shape), db
+
+
+class ProjDropPath(torch.autograd.Function):
+    """out = identity + scale[sample] * (x W^T + b)   (scale None: plain residual add)"""
+
+    @staticmethod
+    def forward(ctx, identity, x, weight, bias, scale, XY, S):
+        ops = get_ops()
+        out = ops.linear_stream(x, fused.split_weight(weight, _w2d), bias.detach(), 0, residual=identity.detach(),
+                                row_scale=scale, XY=XY, S=S)
+        if out is None:
+            raise RuntimeError("ProjDropPath: shape outside the streaming kernel (check stream_fusable first)")
+        ctx.save_for_backward(x, weight, scale)
+        ctx.geom = (XY, S)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, scale = ctx.saved_tensors
+        ops = get_ops()
+        dy = dy.contiguous()
+        db = dy if scale is None else ops.droppath(None, dy, scale, *ctx.geom)
+        dw, dbias = _wgrad(db, x, weight, True)
+        wt, sp = _wt(weight)
+        dx = ops.linear(db, wt, None, w_split=sp)
+        return dy, dx, dw, dbias, None, None, None
+
+
+class SwinFfn(torch.autograd.Function):
+    """out = identity + scale[sample] * (GELU(x W1^T + b1) W2^T + b2)"""
+
+    @staticmethod
+    def forward(ctx, identity, x, w1, b1, w2, b2, scale, XY, S):
+        ops = get_ops()
+        r = ops.linear_stream(x, fused.split_weight(w1, _w2d), b1.detach(), 2, pre_out=True)
+        if r is None:
+            raise RuntimeError("SwinFfn: shape outside the streaming kernel (check stream_fusable first)")
+        f, z = r
+        out = ops.linear_stream(f, fused.split_weight(w2, _w2d), b2.detach(), 0, residual=identity.detach(),
+                                row_scale=scale, XY=XY, S=S)
+        if out is None:
+            raise RuntimeError("SwinFfn: shape outside the streaming kernel (check stream_fusable first)")
+        ctx.save_for_backward(x, z, f, w1, w2, scale)
+        ctx.geom = (XY, S)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, f, w1, w2, scale = ctx.saved_tensors
+        ops = get_ops()
+        dy = dy.contiguous()
+        db = dy if scale is None else ops.droppath(None, dy, scale, *ctx.geom)
+        dw2, db2 = _wgrad(db, f, w2, True)
+        w2t, sp2 = _wt(w2)
+        dz = ops.linear_stream(db, sp2, None, 3, aux=z)             # (db W2) * GELU'(z)
+        if dz is None:
+            dz = ops.act_backward(z, ops.linear(db, w2t, None, w_split=sp2), 2)
+        dw1, db1 = _wgrad(dz, x, w1, True)
+        w1t, sp1 = _wt(w1)
+        dx = ops.linear(dz, w1t, None, w_split=sp1)
+        return dy, dx, dw1, db1, dw2, db2, None, None, None
+
+
+def stream_fusable(M, *dims):
+    """do the Swin block's fused nodes apply?  (bf16 arithmetic, the rows and widths gemm_stream.h takes)"""
+    ops = get_ops()
+    if not _SWIN_FUSE or ops.precision == "f32" or not hasattr(ops, "linear_stream"):
+        return False
+    return all(ops.lib.occf_linear_stream_takes(M, n, k) == 1 for n, k in dims)
+
+
 class TokenBevSlot(torch.autograd.Function):
     """(tok, tok[:, :, :, Z:Z+1]) of the token buffer [B, X, Y, Z + 1, C]: the z-mean slot feeds the BEV ASPP while the
     whole buffer goes on to the soft-gated fusion.  As a plain slice, the slot's gradient came back as a zero-filled

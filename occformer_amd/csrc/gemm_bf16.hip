@@ -615,6 +615,27 @@ extern "C" long occf_gemm_bf16_workspace(long M, int N, int K) {
 static long g_stream_launches = 0;
 extern "C" long occf_linear_stream_launches(void) { return g_stream_launches; }
 
+extern "C" int occf_linear_stream_takes(long M, int N, int K) {
+  if (M < 64 || M >= 2147483647L) return 0;
+  const long min_rows = occf_gemm_stream_min_rows();
+  if (min_rows < 0 || M < min_rows) return 0;
+  if (K != 64 && K != 96 && K != 128 && K != 160 && K != 192 && K != 224 && K != 256) return 0;
+  const int ntb = occf_gemm_stream_ntb(N, K, 3);
+  return ntb > 0 && N / (32 * ntb) <= 32 ? 1 : 0;
+}
+
+// the streaming kernel with its training-graph epilogues (gemm_stream.h): OCCF_ESHAPE = shape outside its envelope
+extern "C" int occf_linear_stream_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo, const float* bias,
+                                      const float* residual_or_aux, float* out, float* pre_out, const float* row_scale,
+                                      long M, int N, int K, long ldx, long ldo, long ldr, int act, int terms, long xy_s,
+                                      int s_slices, void* stream) {
+  if (M >= 2147483647L) return OCCF_ESHAPE;
+  const int rc = occf_gemm_stream_launch(x, w_hi, w_lo, bias, residual_or_aux, out, M, N, K, ldx, ldo, ldr, act, terms,
+                                         (hipStream_t)stream, pre_out, row_scale, xy_s, s_slices);
+  if (rc == 0) ++g_stream_launches;
+  return rc;
+}
+
 extern "C" int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
                                     const float* bias, const float* residual, float* out, long M, int N,
                                     int K, long ldx, long ldo, long ldr, int act, int terms, float* workspace,

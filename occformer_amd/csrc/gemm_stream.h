@@ -34,13 +34,23 @@ struct GemmStreamArgs {
   long M;
   int N, K;
   long lda, ldc, ldr;
-  int act;
+  int act;             // 0 none, 1 ReLU, 2 GELU, 3: multiply by GELU'(aux[row, col]) (aux = `residual`; no residual add)
+  float* pre_out;      // optional: the pre-activation (acc + bias) as a second output [M, N] (row stride ldc)
+  const float* row_scale;   // optional DropPath scale per sample: out = residual + row_scale[sample(row)] * (acc + bias),
+  long xy_s;                // sample(row) = (row / xy_s) * s_slices + row % s_slices  (token rows ((b XY + xy) S + s))
+  int s_slices;
   int ntb;             // 32-channel tiles per workgroup block (N block = 32 * ntb)
   int n_blocks;        // N / (32 * ntb)
   int streams;         // workgroups per N block (each walks the wave tiles q * 8 + wave, + streams * 8, ...)
 };
 
 #define GS_NW 8
+// d/dx of the exact GELU (the formula of bwd_elem.hip's act_bwd_kernel)
+__device__ __forceinline__ float gs_gelu_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
 template <int V>
 struct gs_int {
   static constexpr int value = V;
@@ -133,7 +143,9 @@ __global__ void __launch_bounds__(GS_NW * 64) gemm_stream_kernel(GemmStreamArgs 
       OCCF_SCHED_FENCE();
     }
     float* crow = p.C + tokc * p.ldc + n0 + lk * 4;
+    float* prow = p.pre_out ? p.pre_out + tokc * p.ldc + n0 + lk * 4 : nullptr;
     const float* rrow = p.residual ? p.residual + tokc * p.ldr + n0 + lk * 4 : nullptr;
+    const float rs = p.row_scale ? p.row_scale[(tokc / p.xy_s) * p.s_slices + tokc % p.s_slices] : 1.0f;
     for (int j = 0; j < p.ntb; ++j) {
       const unsigned char* Wt = Wimg + (size_t)j * ARR * IMG + li * 32 + lk * 16;
       f32x16 acc;
@@ -162,12 +174,17 @@ __global__ void __launch_bounds__(GS_NW * 64) gemm_stream_kernel(GemmStreamArgs 
       for (int g = 0; g < 4; ++g) {
         const float4 b4 = *(const float4*)(bias_s + j * 32 + g * 8 + lk * 4);
         float4 v = make_float4(acc[4 * g] + b4.x, acc[4 * g + 1] + b4.y, acc[4 * g + 2] + b4.z, acc[4 * g + 3] + b4.w);
+        if (prow && tok_ok) *(float4*)(prow + j * 32 + g * 8) = v;
         if (p.act == 1) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         } else if (p.act == 2) {
           v.x = occf_gelu_b(v.x); v.y = occf_gelu_b(v.y); v.z = occf_gelu_b(v.z); v.w = occf_gelu_b(v.w);
+        } else if (p.act == 3) {
+          v.x *= gs_gelu_grad(res[g].x); v.y *= gs_gelu_grad(res[g].y);
+          v.z *= gs_gelu_grad(res[g].z); v.w *= gs_gelu_grad(res[g].w);
         }
-        if (rrow) { v.x += res[g].x; v.y += res[g].y; v.z += res[g].z; v.w += res[g].w; }
+        if (p.row_scale) { v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
+        if (rrow && p.act != 3) { v.x += res[g].x; v.y += res[g].y; v.z += res[g].z; v.w += res[g].w; }
         if (tok_ok) *(float4*)(crow + j * 32 + g * 8) = v;
       }
     }
@@ -197,7 +214,8 @@ static inline long occf_gemm_stream_min_rows() {
 // OCCF_ESHAPE: outside this kernel's envelope (the caller then takes the tile kernel)
 static int occf_gemm_stream_launch(const float* A, const uint16_t* Wh, const uint16_t* Wl, const float* bias,
                                    const float* residual, float* C, long M, int N, int K, long lda, long ldc, long ldr,
-                                   int act, int terms, hipStream_t st) {
+                                   int act, int terms, hipStream_t st, float* pre_out = nullptr,
+                                   const float* row_scale = nullptr, long xy_s = 1, int s_slices = 1) {
   if (M < 64) return OCCF_ESHAPE;                       // (the decoder's 100-query linears: no getenv on their path)
   const long min_rows = occf_gemm_stream_min_rows();
   if (min_rows < 0 || M < min_rows) return OCCF_ESHAPE;
@@ -205,7 +223,9 @@ static int occf_gemm_stream_launch(const float* A, const uint16_t* Wh, const uin
   if ((lda | ldc) % 4 != 0 || (residual && ldr % 4 != 0) || (terms != 1 && terms != 3)) return OCCF_ESHAPE;
   const int ntb = occf_gemm_stream_ntb(N, K, terms);
   if (ntb == 0) return OCCF_ESHAPE;
-  GemmStreamArgs a = {A, Wh, Wl, bias, residual, C, M, N, K, lda, ldc, ldr, act, ntb, N / (32 * ntb), 0};
+  if (act < 0 || act > 3 || (act == 3 && !residual) || (row_scale && (xy_s <= 0 || s_slices <= 0))) return OCCF_EINVAL;
+  GemmStreamArgs a = {A, Wh, Wl, bias, residual, C, M, N, K, lda, ldc, ldr, act, pre_out, row_scale, xy_s, s_slices,
+                      ntb, N / (32 * ntb), 0};
   if (a.n_blocks > 32) return OCCF_ESHAPE;
   // one workgroup per CU: 8 XCDs x (32 / n_blocks) streams per N block (OCCF_GEMM_STREAM_WGS caps it: tests walk the
   // tile loop with a handful of workgroups)

@@ -136,18 +136,29 @@ class SwinBlock(nn.Module):
         qkv = A.linear(n1, m.qkv)
         a = A.WindowAttention.apply(qkv, m.qkv.bias, m.relative_position_bias_table, B, X, Y, S, self.heads,
                                     self.attn.shift_size)
+        lin1, lin2 = self.ffn.layers[0][0], self.ffn.layers[1]
+        H = lin1.weight.shape[0]
+        # the large stages run both DropPath branches on the streaming kernel's epilogues (autograd.ProjDropPath /
+        # SwinFfn: no separate DropPath / GELU / GELU' passes); the small ones keep the node-per-op graph
+        fusable = m.proj.bias is not None and lin1.bias is not None and lin2.bias is not None and \
+            A.stream_fusable(t.shape[0], (C, C), (H, C), (C, H))
         sc = self._drop_path(B, S, tok.device)
-        if sc is None:
+        if fusable:
+            t = A.ProjDropPath.apply(t, a, m.proj.weight, m.proj.bias, sc, X * Y, S)
+        elif sc is None:
             t = A.linear(a, m.proj, residual=t)
         else:
             t = A.DropPathAdd.apply(t, A.linear(a, m.proj), sc, X * Y, S)
         t, n2 = A.layernorm_fork(t, self.norm2)
-        f = A.Act.apply(A.linear(n2, self.ffn.layers[0][0]), 2)
         sc = self._drop_path(B, S, tok.device)
-        if sc is None:
-            t = A.linear(f, self.ffn.layers[1], residual=t)
+        if fusable:
+            t = A.SwinFfn.apply(t, n2, lin1.weight, lin1.bias, lin2.weight, lin2.bias, sc, X * Y, S)
         else:
-            t = A.DropPathAdd.apply(t, A.linear(f, self.ffn.layers[1]), sc, X * Y, S)
+            f = A.Act.apply(A.linear(n2, lin1), 2)
+            if sc is None:
+                t = A.linear(f, lin2, residual=t)
+            else:
+                t = A.DropPathAdd.apply(t, A.linear(f, lin2), sc, X * Y, S)
         return t.view(B, X, Y, S, C)
 
 

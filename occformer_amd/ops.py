@@ -368,6 +368,35 @@ class HipOps:
                        out.stride(0), r2.stride(0) if r2 is not None else 0, int(act), self._stream())
         return out.view(*x.shape[:-1], N)
 
+    def linear_stream(self, x, w_split, bias=None, act=0, residual=None, aux=None, pre_out=False, row_scale=None,
+                      XY=1, S=1):
+        """csrc/gemm_stream.h with the training graph's epilogues (occf_linear_stream_fwd): x [M, K] (rows contiguous)
+        -> out [M, N], or (out, pre) with ``pre_out``; ``row_scale`` [samples] with the token-buffer geometry (XY, S);
+        ``act = 3``: out = (x W^T + b) * GELU'(aux).  None when the shape is outside the kernel's envelope (the caller
+        then runs the unfused sequence)."""
+        M, K = x.shape
+        N = w_split[0].shape[0]
+        if x.stride(1) != 1 or w_split[0].numel() != N * K or self.precision == "f32":
+            return None
+        if self.strict and not x.is_cuda:
+            raise OccfError("occformer_amd ops need GPU tensors (no CPU path exists)")
+        side = aux if act == 3 else residual
+        if side is not None and (tuple(side.shape) != (M, N) or side.stride(1) != 1):
+            raise OccfError("linear_stream: residual / aux must be [M, N] with unit column stride")
+        out = torch.empty((M, N), dtype=self.f32, device=x.device)
+        pre = torch.empty((M, N), dtype=self.f32, device=x.device) if pre_out else None
+        rc = self.lib.occf_linear_stream_fwd(
+            ctypes.c_void_p(x.data_ptr()), self._ptr(w_split[0]), self._ptr(w_split[1]), self._ptr(bias, self.f32, N),
+            ctypes.c_void_p(side.data_ptr() if side is not None else 0), self._ptr(out), self._ptr(pre),
+            self._ptr(row_scale, self.f32), M, N, K, x.stride(0), N, side.stride(0) if side is not None else 0, int(act),
+            1 if self.precision == "bf16" else 3, int(XY) * int(S), int(S), self._stream())
+        if rc == -2:
+            return None
+        if rc != 0:
+            raise OccfError(f"occf_linear_stream_fwd failed with code {rc}")
+        self.last_flops = 2 * M * N * K
+        return (out, pre) if pre_out else out
+
     def _halo_fragments(self, w_split, Cin, Cout):
         """the pre-split weight in MFMA-fragment order for the halo kernel (cached ON the split tensor, which is
         itself cached per weight version); None when switched off (OCCF_HALO_FRAG=0) or not packable"""

@@ -119,5 +119,19 @@ PY
 f)  # round 5, visit f: access-pattern probe with the dword whole-line stores and the LDS-transposed float4 stores
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/row_access_probe.hip -o /tmp/rap 2>/dev/null && /tmp/rap | tee $O/r05f_row_access_probe.txt
 ;;
+g)  # round 5, visit g: the Swin block's DropPath branches on the streaming kernel's epilogues (training step with / without), their GPU test, full-size training parity with them
+timeout 600 python -m pytest tests/test_bwd_ops.py tests/test_gemm_norm_ops.py -m gpu -q -p no:cacheprovider -k "swin_block_fused or streaming" 2>&1 | tail -3
+for v in 0 1; do
+  OCCF_TRAIN_SWIN_FUSE=$v timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/r05g_bench_train_swinfuse$v.json 2>/dev/null
+  python - <<PY
+import json
+t = json.load(open("gpurun_out/r05g_bench_train_swinfuse$v.json"))
+k = t["kernels"]
+print("OCCF_TRAIN_SWIN_FUSE=$v train", round(t["value"], 3), "samples/s", round(t["ms_per_step"], 2), "ms | linear", k["linear"]["total_ms"], "linear_stream", k.get("linear_stream", {}).get("total_ms"), "droppath", k["droppath"]["total_ms"], "act_fwd", k.get("act_forward", {}).get("total_ms"), "act_bwd", k["act_backward"]["total_ms"], "mem", t["peak_memory_GiB"])
+PY
+done
+( time timeout 900 python -m pytest tests/test_workloads_gpu.py -m gpu -q -p no:cacheprovider -s -k "training_step and (nusc_r50_200 or kitti_effb7_128)" ) 2>&1 | grep -v "MIOpen(HIP)" > $O/r05g_workloads_train.log
+grep "training step vs oracle\|passed\|failed\|^real\|Error" $O/r05g_workloads_train.log | cut -c1-1300
+;;
 *) echo "usage: $0 <stage>"; exit 2;;
 esac

@@ -515,3 +515,50 @@ def test_depthnet_training_convs_on_the_library_kernels(bound_ops, monkeypatch):
     num = sum(float((g1[k] - g0[k]).norm() ** 2) for k in g0)
     den = sum(float(g0[k].norm() ** 2) for k in g0)
     assert (num / den) ** 0.5 < 2e-3, (num / den) ** 0.5
+
+
+@pytest.mark.parametrize("drop", [0.3, 0.0])
+def test_swin_block_fused_droppath_nodes(bound_ops, monkeypatch, drop):
+    """autograd.ProjDropPath / SwinFfn (DropPath + identity add, GELU + pre-activation, GELU' in the epilogues of the
+    streaming linear, csrc/gemm_stream.h) against the node-per-op graph of the same block (Linear, Act, Linear,
+    DropPathAdd: the graph the oracle comparisons of tests/test_train_step.py pin) on the same DropPath draws -- the
+    SwinBlock of window_attention.py:300-344 in train mode.  Forward, the token gradient and every parameter gradient."""
+    from occformer_amd import autograd as A
+    from occformer_amd import noise
+    from occformer_amd.encoder import SwinBlock
+    from occformer_amd.training import DeviceRNG
+    be = bound_ops
+    monkeypatch.setenv("OCCF_GEMM_STREAM", "64")
+    monkeypatch.setenv("OCCF_GEMM_STREAM_WGS", "16")
+    C, B, X, Y, S = 64, 1, 7, 9, 3
+    blk = SwinBlock(C, C // 32, C, window_size=7, drop_path_rate=drop)
+    blk.load_state_dict(paramgen.fill_state_dict(blk.state_dict(), 21))
+    blk = blk.to(be.device).train()
+    tok = _t("sw_tok", (B, X, Y, S, C), 3)
+    g = _t("sw_g", (B, X, Y, S, C), 4)
+    lib = be.ops.lib
+
+    def run(fuse):
+        monkeypatch.setattr(A, "_SWIN_FUSE", fuse)
+        for p in blk.parameters():
+            p.grad = None
+        x = be.to(tok).requires_grad_()
+        noise.set_rng(DeviceRNG(be.device, 17))
+        try:
+            n0 = lib.occf_linear_stream_launches()
+            y = blk(x)
+            (y * be.to(g)).sum().backward()
+            took = lib.occf_linear_stream_launches() - n0
+        finally:
+            noise.set_rng(None)
+        return y.detach().cpu(), x.grad.cpu(), {k: p.grad.cpu().clone() for k, p in blk.named_parameters()}, took
+
+    y0, dx0, gr0, took0 = run(False)
+    y1, dx1, gr1, took1 = run(True)
+    # fused: projection, FFN in, FFN out forward + the GELU' data gradient = 4 launches the node-per-op graph does not
+    # make through occf_linear_stream_fwd (its own linears go through occf_linear_bf16_fwd, which also streams them)
+    assert took1 >= 4
+    assert _rel(y1, y0) < 1e-5 and _rel(dx1, dx0) < 1e-4
+    for k in gr0:
+        assert _rel(gr1[k], gr0[k]) < 2e-4, k
+    assert float((y0 - tok.detach()).abs().max().item()) > 1e-3     # (the branches are not dropped altogether)
