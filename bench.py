@@ -407,12 +407,58 @@ def forward_from_images(workload, device, image_dtype, steps):
     step()
     m.record_time = False
     stages = {k: round(1e3 * sum(v) / len(v), 3) for k, v in m.time_stats.items() if k}
-    del m
+
+    # the same K frames as a SERVING loop would run them: the image branch of frame t + 1 on a side HIP stream while the
+    # 3-D path of frame t runs on the main stream (two streams, one event per frame; the per-frame latency is the
+    # sequential one above, the throughput is what a stream of frames sees).  Reported NEXT TO the sequential figure,
+    # which is the one the reference's harness measures.
+    if workload == "nusc_r101":
+        # (its DCNv2 layers run on the library's kernels and share the op layer's split-K workspace with the main stream:
+        # not made stream-safe, so no pipelined figure for this workload)
+        del m
+        torch.cuda.empty_cache()
+        return {"metric": "samples/sec forward FROM THE RAW IMAGES", "value": steps / dt, "unit": "samples/s",
+                "steps": steps, "warmup": 3, "ms_per_step": 1e3 * dt / steps,
+                "input": [1, meta["ncams"], 3, *meta["input_size"]], "stages_ms": stages, "pipelined": None}
+    side = torch.cuda.Stream(device=device)
+    main = torch.cuda.current_stream(device)
+
+    def encode_next():
+        side.wait_stream(main)                       # (the frame buffer is resident; keeps allocator reuse ordered)
+        with torch.cuda.stream(side), torch.no_grad():
+            f = m.image_encoder(img_inputs[0])
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return f, ev
+
+    def step_pipelined(feat_ev):
+        f, ev = feat_ev
+        nxt = encode_next()                          # frame t + 1: issued first, runs beside this frame's 3-D path
+        main.wait_event(ev)
+        f.record_stream(main)
+        with torch.no_grad():
+            vox, _, _ = m.extract_feat(None, [f] + list(img_inputs[1:]), metas)
+            m.pts_bbox_head.simple_test(vox, metas, points=points)
+        return nxt
+    fe = encode_next()
+    for _ in range(3):
+        fe = step_pipelined(fe)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fe = step_pipelined(fe)
+    torch.cuda.synchronize()
+    dtp = time.perf_counter() - t0
+    del m, fe
     torch.cuda.empty_cache()
     return {"metric": "samples/sec forward FROM THE RAW IMAGES (img_backbone + img_neck on PyTorch-ROCm / MIOpen, "
                       f"{image_dtype}, inside the timed region -> inference hot path) -- north_star target >= 30",
             "value": steps / dt, "unit": "samples/s", "steps": steps, "warmup": 3, "ms_per_step": 1e3 * dt / steps,
-            "input": [1, meta["ncams"], 3, *meta["input_size"]], "stages_ms": stages}
+            "input": [1, meta["ncams"], 3, *meta["input_size"]], "stages_ms": stages,
+            "pipelined": {"value": steps / dtp, "unit": "samples/s", "ms_per_step": 1e3 * dtp / steps,
+                          "what": "the same frames as a serving loop: image branch of frame t + 1 on a side HIP stream "
+                                  "beside the 3-D path of frame t (throughput; the sequential `value` above is what "
+                                  "tools/analysis_tools/benchmark.py measures)"}}
 
 
 def launch_ranks(n, argv=None):

@@ -368,23 +368,26 @@ extern "C" int occf_layernorm_bwd(const float* x, const float* gamma, const floa
 //   s1[b, grp] = sum_{c in grp} gamma_c A[b, c] / n,  s2 = sum gamma_c Bc[b, c] / n   (n = V * C / G)
 //   dx = rstd * (g * gamma - s1 - xhat * s2);          d_residual = dyt
 // stage 1 (partial sums per row block) / stage 2 (per batch-channel + per group + parameters) / stage 3 (apply).
+// IDX: uint32_t row arithmetic whenever B * V * (C / 4) < 2^31 (see droppath_kernel: the token mode divides per row)
+template <typename IDX>
 __device__ __forceinline__ void gnb_load(const float* __restrict__ x, const float* __restrict__ dy, long b, long V,
-                                         long r, int Z, int C, int c0, int tokens, float4& xv, float4& g) {
-  xv = *(const float4*)(x + (b * V + r) * C + c0);
+                                         IDX r, int Z, int C, int c0, int tokens, float4& xv, float4& g) {
+  xv = *(const float4*)(x + (b * V + (long)r) * C + c0);
   if (tokens) {
-    const long p = r / Z;
-    const int z = (int)(r - p * Z);
+    const IDX p = r / (IDX)Z;
+    const int z = (int)(r - p * (IDX)Z);
     const long Zs = Z + 1;
     const long Vs = (V / Z) * Zs;
-    g = *(const float4*)(dy + (b * Vs + p * Zs + z) * C + c0);
-    const float4 m = *(const float4*)(dy + (b * Vs + p * Zs + Z) * C + c0);
+    g = *(const float4*)(dy + (b * Vs + (long)p * Zs + z) * C + c0);
+    const float4 m = *(const float4*)(dy + (b * Vs + (long)p * Zs + Z) * C + c0);
     const float inv = 1.0f / (float)Z;
     g.x = fmaf(m.x, inv, g.x); g.y = fmaf(m.y, inv, g.y); g.z = fmaf(m.z, inv, g.z); g.w = fmaf(m.w, inv, g.w);
   } else {
-    g = *(const float4*)(dy + (b * V + r) * C + c0);
+    g = *(const float4*)(dy + (b * V + (long)r) * C + c0);
   }
 }
 
+template <typename IDX>
 __global__ void __launch_bounds__(256) gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ dy,
@@ -396,9 +399,9 @@ __global__ void __launch_bounds__(256) gn_bwd_partial_kernel(const float* __rest
   const int tid = threadIdx.x;
   const int cq = tid % Q, rt = tid / Q;
   const int b = blockIdx.y;
-  const long r0 = (long)blockIdx.x * rows_per_block;
-  long r1 = r0 + rows_per_block;
-  if (r1 > V) r1 = V;
+  const IDX r0 = (IDX)blockIdx.x * (IDX)rows_per_block;
+  IDX r1 = r0 + (IDX)rows_per_block;
+  if (r1 > (IDX)V) r1 = (IDX)V;
   float a[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
   if (rt < R) {
     const int cg = C / G, c0 = cq * 4;
@@ -412,9 +415,9 @@ __global__ void __launch_bounds__(256) gn_bwd_partial_kernel(const float* __rest
       bt[e] = beta[c0 + e];
     }
 #pragma unroll 4
-    for (long r = r0 + rt; r < r1; r += R) {
+    for (IDX r = r0 + (IDX)rt; r < r1; r += (IDX)R) {
       float4 xv, g;
-      gnb_load(x, dy, b, V, r, Z, C, c0, tokens, xv, g);
+      gnb_load<IDX>(x, dy, b, V, r, Z, C, c0, tokens, xv, g);
       const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
       const float gg[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
@@ -468,21 +471,24 @@ __global__ void __launch_bounds__(256) gn_bwd_groups_kernel(const float* __restr
   }
 }
 
+template <typename IDX>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dy, const float* __restrict__ gs,
                                                            float* __restrict__ dx, float* __restrict__ dres, int B, long V,
                                                            int Z, int C, int G, int relu, int tokens) {
   const int Q = C / 4;
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long)B * V * Q) return;
-  const int cq = (int)(gid % Q);
-  const long br = gid / Q;
-  const long b = br / V, r = br % V;
+  const IDX gid = (IDX)blockIdx.x * (IDX)blockDim.x + threadIdx.x;
+  if (gid >= (IDX)((long)B * V * Q)) return;
+  const IDX br = gid / (IDX)Q;
+  const int cq = (int)(gid - br * (IDX)Q);
+  const IDX bq = B == 1 ? (IDX)0 : br / (IDX)V;
+  const IDX r = br - bq * (IDX)V;
+  const long b = (long)bq;
   const int c0 = cq * 4, cg = C / G;
   float4 xv, g;
-  gnb_load(x, dy, b, V, r, Z, C, c0, tokens, xv, g);
-  if (dres) *(float4*)(dres + (b * V + r) * C + c0) = g;
+  gnb_load<IDX>(x, dy, b, V, r, Z, C, c0, tokens, xv, g);
+  if (dres) *(float4*)(dres + (b * V + (long)r) * C + c0) = g;
   const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
   const float gg[4] = {g.x, g.y, g.z, g.w};
   float o[4];
@@ -497,7 +503,7 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
     const float ge = (relu && fmaf(xx[e], sc, beta[c0 + e] - s[0] * sc) <= 0.f) ? 0.f : gg[e];
     o[e] = s[1] * (ge * gm - t[0] - xh * t[1]);
   }
-  *(float4*)(dx + (b * V + r) * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
+  *(float4*)(dx + (b * V + (long)r) * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
 #define GNB_ROWS 256
@@ -517,14 +523,23 @@ extern "C" int occf_groupnorm_bwd(const float* x, const float* stats, const floa
   float* partial = workspace;
   float* chan = partial + (long)B * nblk * C * 2;
   float* gs = chan + (long)B * C * 2;
-  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nblk, B), dim3(256), 0, st, x, stats, gamma, beta, dy, partial, V, Z,
-                     C, G, relu, tokens, rows);
+  const bool idx32 = (long)B * V * (C / 4) < 2147483647L - 256 && V + rows < 2147483647L;
+  if (idx32)
+    hipLaunchKernelGGL(gn_bwd_partial_kernel<uint32_t>, dim3(nblk, B), dim3(256), 0, st, x, stats, gamma, beta, dy, partial,
+                       V, Z, C, G, relu, tokens, rows);
+  else
+    hipLaunchKernelGGL(gn_bwd_partial_kernel<long>, dim3(nblk, B), dim3(256), 0, st, x, stats, gamma, beta, dy, partial, V,
+                       Z, C, G, relu, tokens, rows);
   occf_reduce_partials(partial, chan, (long)nblk, 2 * C, (long)C * 2, 1, 0, st, B, (long)nblk * C * 2, (long)C * 2);
   const int tmax = B * G > C ? B * G : C;
   hipLaunchKernelGGL(gn_bwd_groups_kernel, dim3(occf_cdiv(tmax, 256)), dim3(256), 0, st, chan, gamma, gs, dgamma, dbeta,
                      B, C, G, (double)V * (C / G));
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(occf_cdiv((long)B * V * (C / 4), 256)), dim3(256), 0, st, x, stats, gamma,
-                     beta, dy, gs, dx, dresidual, B, V, Z, C, G, relu, tokens);
+  if (idx32)
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<uint32_t>, dim3(occf_cdiv((long)B * V * (C / 4), 256)), dim3(256), 0, st, x,
+                       stats, gamma, beta, dy, gs, dx, dresidual, B, V, Z, C, G, relu, tokens);
+  else
+    hipLaunchKernelGGL(gn_bwd_apply_kernel<long>, dim3(occf_cdiv((long)B * V * (C / 4), 256)), dim3(256), 0, st, x, stats,
+                       gamma, beta, dy, gs, dx, dresidual, B, V, Z, C, G, relu, tokens);
   OCCF_LAUNCH_CHECK();
 }
 
@@ -574,15 +589,19 @@ extern "C" int occf_act_bwd(const float* x, const float* dy, float* dx, long n, 
 // survivors scaled by 1 / keep).  The block's "samples" are the slices of the token buffer: token row
 // ((b*X + x)*Y + y)*S + s belongs to sample b*S + s.  out = identity + branch * scale[sample] (identity may be
 // NULL: out = branch * scale, which is also the backward of the branch).
+// IDX = the integer type of the element / row arithmetic: uint32_t whenever the tensor has < 2^31 float4 pieces (every
+// shape of the path) -- three 64-bit divisions per float4 made this pass VALU-bound (r05: a 64-bit divide is ~100 VALU
+// instructions, the pass moves 48 bytes per thread)
+template <typename IDX>
 __global__ void __launch_bounds__(256) droppath_kernel(const float* __restrict__ identity, const float* __restrict__ branch,
                                                        const float* __restrict__ scale, float* __restrict__ out, long rows,
                                                        int Q, long XY, int S) {
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= rows * Q) return;
-  const long row = gid / Q;
-  const long b = row / (XY * S);
-  const int s = (int)(row % S);
-  const float sc = scale[b * S + s];
+  const IDX gid = (IDX)blockIdx.x * (IDX)blockDim.x + threadIdx.x;
+  if (gid >= (IDX)(rows * Q)) return;
+  const IDX row = gid / (IDX)Q;
+  const IDX b = row / (IDX)(XY * S);
+  const IDX s = row % (IDX)S;
+  const float sc = scale[b * (IDX)S + s];
   const float4 v = ((const float4*)branch)[gid];
   float4 o = make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc);
   if (identity) {
@@ -594,8 +613,13 @@ __global__ void __launch_bounds__(256) droppath_kernel(const float* __restrict__
 extern "C" int occf_droppath(const float* identity, const float* branch, const float* scale, float* out, long rows,
                              int C, long XY, int S, void* stream) {
   if (rows <= 0 || C % 4 != 0 || XY <= 0 || S <= 0 || rows % (XY * S) != 0) return OCCF_EINVAL;
-  hipLaunchKernelGGL(droppath_kernel, dim3(occf_cdiv(rows * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, identity,
-                     branch, scale, out, rows, C / 4, XY, S);
+  const long n4 = rows * (C / 4);
+  if (n4 < 2147483647L - 256)
+    hipLaunchKernelGGL(droppath_kernel<uint32_t>, dim3(occf_cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, identity,
+                       branch, scale, out, rows, C / 4, XY, S);
+  else
+    hipLaunchKernelGGL(droppath_kernel<long>, dim3(occf_cdiv(n4, 256)), dim3(256), 0, (hipStream_t)stream, identity,
+                       branch, scale, out, rows, C / 4, XY, S);
   OCCF_LAUNCH_CHECK();
 }
 

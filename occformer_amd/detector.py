@@ -328,7 +328,10 @@ class OccupancyFormer(nn.Module):
         return t1
 
     def image_encoder(self, img):
-        if self.img_backbone is None:            # caller already supplies neck features [B,N,C,fH,fW]
+        # neck features [B, N, C, fH, fW] instead of images [B, N, 3, H, W]: the caller already ran the image branch
+        # (a detector without one; or a serving loop that runs ``image_encoder`` of the NEXT frame on a side stream
+        # while this frame's 3-D path runs -- bench.py's pipelined from-images record)
+        if self.img_backbone is None or (img.dim() == 5 and img.shape[2] != 3):
             return img
         B, N, C, H, W = img.shape
         x = img.view(B * N, C, H, W)

@@ -133,5 +133,20 @@ done
 ( time timeout 900 python -m pytest tests/test_workloads_gpu.py -m gpu -q -p no:cacheprovider -s -k "training_step and (nusc_r50_200 or kitti_effb7_128)" ) 2>&1 | grep -v "MIOpen(HIP)" > $O/r05g_workloads_train.log
 grep "training step vs oracle\|passed\|failed\|^real\|Error" $O/r05g_workloads_train.log | cut -c1-1300
 ;;
+h)  # round 5, visit h: default bench (pipelined from-images record, 32-bit index arithmetic in droppath / GroupNorm backward), GN / droppath GPU tests
+timeout 600 python -m pytest tests/test_bwd_ops.py -m gpu -q -p no:cacheprovider -k "groupnorm or droppath" 2>&1 | tail -2
+( time timeout 900 python bench.py --shape-report $O/r05h_shapes_train.txt ) > $O/r05h_bench_train.json 2> $O/r05h_bench_train.err; echo "bench rc=$?"
+tail -3 $O/r05h_bench_train.err
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r05h_bench_train.json"))
+print("train", round(d["value"], 3), "samples/s", round(d["ms_per_step"], 2), "ms; roofline", round(d["roofline"]["frac"], 4))
+print("check", {k: v for k, v in d.get("check", {}).items() if k not in ("what", "per_parameter_rel_l2_quantiles", "per_parameter_rel_l2_quantiles_ungated")})
+print("forward", round(d["forward"]["value"], 2), d["forward"]["roofline"]["frac"], d["forward"].get("check"))
+print("forward_from_images", {k: v for k, v in d["forward_from_images"].items() if k != "metric"})
+for k, v in list(d["kernels"].items())[:24]:
+    print(f"  {k:30s} {v['calls']:4d} {v['total_ms']:8.3f} ms")
+PY
+;;
 *) echo "usage: $0 <stage>"; exit 2;;
 esac
