@@ -506,6 +506,56 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const float* __restri
   *(float4*)(dx + (b * V + (long)r) * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
 }
 
+// The same pass with the thread layout of the partial kernel: a workgroup owns `rows_per_block` rows, a thread ONE channel
+// quad of every R-th row -- its 4 x (mean, rstd, s1, s2, gamma, beta) are loaded once instead of once per float4 (the
+// thread-per-float4 form above issues 24 parameter loads for 3 payload accesses), and 4 rows of loads are in flight.
+__global__ void __launch_bounds__(256) gn_bwd_apply_rows_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ dy,
+                                                                const float* __restrict__ gs, float* __restrict__ dx,
+                                                                float* __restrict__ dres, long V, int Z, int C, int G,
+                                                                int relu, int tokens, int rows_per_block) {
+  const int Q = C / 4;
+  const int R = 256 / Q;
+  const int tid = threadIdx.x;
+  const int cq = tid % Q, rt = tid / Q;
+  if (rt >= R) return;
+  const long b = blockIdx.y;
+  const uint32_t r0 = blockIdx.x * (uint32_t)rows_per_block;
+  uint32_t r1 = r0 + (uint32_t)rows_per_block;
+  if (r1 > (uint32_t)V) r1 = (uint32_t)V;
+  const int cg = C / G, c0 = cq * 4;
+  float mean[4], rstd[4], gm[4], sh[4], t0[4], t1[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int grp = (c0 + e) / cg;
+    const float* s = stats + (b * G + grp) * 2;
+    const float* t = gs + (b * G + grp) * 2;
+    mean[e] = s[0];
+    rstd[e] = s[1];
+    gm[e] = gamma[c0 + e];
+    sh[e] = beta[c0 + e] - s[0] * (s[1] * gm[e]);
+    t0[e] = t[0];
+    t1[e] = t[1];
+  }
+#pragma unroll 4
+  for (uint32_t r = r0 + (uint32_t)rt; r < r1; r += (uint32_t)R) {
+    float4 xv, g;
+    gnb_load<uint32_t>(x, dy, b, V, r, Z, C, c0, tokens, xv, g);
+    if (dres) *(float4*)(dres + (b * V + (long)r) * C + c0) = g;
+    const float xx[4] = {xv.x, xv.y, xv.z, xv.w};
+    const float gg[4] = {g.x, g.y, g.z, g.w};
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xx[e] - mean[e]) * rstd[e];
+      const float ge = (relu && fmaf(xx[e], rstd[e] * gm[e], sh[e]) <= 0.f) ? 0.f : gg[e];
+      o[e] = rstd[e] * (ge * gm[e] - t0[e] - xh * t1[e]);
+    }
+    *(float4*)(dx + (b * V + (long)r) * C + c0) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 #define GNB_ROWS 256
 extern "C" long occf_groupnorm_bwd_workspace(int B, long V, int C, int G) {
   return (long)B * occf_cdiv(V, GNB_ROWS) * C * 2 + (long)B * C * 2 + (long)B * G * 2;
@@ -534,7 +584,12 @@ extern "C" int occf_groupnorm_bwd(const float* x, const float* stats, const floa
   const int tmax = B * G > C ? B * G : C;
   hipLaunchKernelGGL(gn_bwd_groups_kernel, dim3(occf_cdiv(tmax, 256)), dim3(256), 0, st, chan, gamma, gs, dgamma, dbeta,
                      B, C, G, (double)V * (C / G));
-  if (idx32)
+  const char* e_rows = getenv("OCCF_GNB_APPLY_ROWS");     // 0: the thread-per-float4 form (read per call: A/B probes)
+  const int rows_form = e_rows ? atoi(e_rows) : 1;
+  if (idx32 && rows_form && C <= 1024 && 256 / (C / 4) >= 1)
+    hipLaunchKernelGGL(gn_bwd_apply_rows_kernel, dim3(nblk, B), dim3(256), 0, st, x, stats, gamma, beta, dy, gs, dx,
+                       dresidual, V, Z, C, G, relu, tokens, rows);
+  else if (idx32)
     hipLaunchKernelGGL(gn_bwd_apply_kernel<uint32_t>, dim3(occf_cdiv((long)B * V * (C / 4), 256)), dim3(256), 0, st, x,
                        stats, gamma, beta, dy, gs, dx, dresidual, B, V, Z, C, G, relu, tokens);
   else

@@ -103,3 +103,47 @@ if "psb" in what:
            lambda: ops.point_sample_3d_backward(dout, pts, (n, 1, X, Y, Z), False, "border"), n=10)
     timeit("torch.cat of ten [V, 16] -> [V, 160]", lambda: torch.cat(small, 1), n=5)
     timeit("zero fill [V, 160]", lambda: big.zero_(), n=5)
+if "gn" in what:
+    # the streaming normalisation / elementwise passes at the full-resolution shapes, with the bytes they actually move
+    def gbs(name, fn, nbytes, n=8):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        print(f"{name:78s} {ms * 1e3:8.1f} us  {nbytes / ms / 1e6:7.0f} GB/s", flush=True)
+    for C, tokens, relu, res in ((128, True, True, False), (192, False, True, False), (192, False, False, True)):
+        B, X, Y, Z, G = 1, 200, 200, 16, 32
+        x = torch.randn(B, X, Y, Z, C, generator=g).cuda()
+        gamma, beta = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+        dy = torch.randn(B, X, Y, Z + 1 if tokens else Z, C, generator=g).cuda()
+        nb = x.numel() * 4
+        st = ops.groupnorm_stats(x, G, 1e-5)
+        gbs(f"groupnorm_stats [{X},{Y},{Z},{C}] (1 pass)", lambda: ops.groupnorm_stats(x, G, 1e-5), nb)
+        r = torch.randn_like(x) if res else None
+        gbs(f"groupnorm_apply relu={relu} tokens={tokens} res={res} ({3 if res else 2} passes)",
+            lambda: ops.groupnorm_apply(x, st, gamma, beta, G, relu, tokens, r), nb * (3 if res else 2))
+        for form in ("0", "1"):
+            os.environ["OCCF_GNB_APPLY_ROWS"] = form
+            gbs(f"groupnorm_backward relu={relu} tokens={tokens} dres={res} (OCCF_GNB_APPLY_ROWS={form}; {6 if res else 5} passes)",
+                lambda: ops.groupnorm_backward(x, st, gamma, beta, dy, G, relu, tokens, want_residual=res),
+                nb * (6 if res else 5))
+    M, C = 680000, 128
+    x = torch.randn(M, C, generator=g).cuda()
+    dy = torch.randn(M, C, generator=g).cuda()
+    w, b = torch.randn(C, generator=g).cuda(), torch.randn(C, generator=g).cuda()
+    gbs("layernorm [680000,128] (2 passes)", lambda: ops.layernorm(x, w, b, 1e-5), M * C * 8)
+    gbs("layernorm_backward [680000,128] (3 passes)", lambda: ops.layernorm_backward(x, w, dy, 1e-5), M * C * 12)
+    sc = torch.rand(17, generator=g).cuda()
+    gbs("droppath identity + branch [680000,128] (3 passes)", lambda: ops.droppath(x, dy, sc, 40000, 17), M * C * 12)
+    gbs("act_backward GELU [680000,128] (3 passes)", lambda: ops.act_backward(x, dy, 2), M * C * 12)
+    tok = torch.randn(1, 200, 200, 17, C, generator=g).cuda()
+    bev = torch.randn(1, 200, 200, C, generator=g).cuda()
+    ident = torch.randn(1, 200, 200, 16, C, generator=g).cuda()
+    cw, cb = torch.randn(C, generator=g).cuda(), torch.randn(1, generator=g).cuda()
+    gbs("dualpath_combine [200,200,16,128] (3 passes)", lambda: ops.dualpath_combine(tok, bev, cw, cb, ident), ident.numel() * 12)

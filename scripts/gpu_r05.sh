@@ -148,5 +148,9 @@ for k, v in list(d["kernels"].items())[:24]:
     print(f"  {k:30s} {v['calls']:4d} {v['total_ms']:8.3f} ms")
 PY
 ;;
+i)  # round 5, visit i: the streaming normalisation / elementwise passes at full resolution with the bytes they move (GroupNorm backward apply: thread-per-float4 vs row-looping form)
+timeout 600 python scripts/bwd_probe.py gn 2>&1 | grep -v "amdgpu.ids" | tee $O/r05i_elementwise_probe.txt
+timeout 600 python -m pytest tests/test_bwd_ops.py -m gpu -q -p no:cacheprovider -k "groupnorm" 2>&1 | tail -2
+;;
 *) echo "usage: $0 <stage>"; exit 2;;
 esac
