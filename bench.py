@@ -160,14 +160,16 @@ def roofline(timed_census, kernels, prec, steps):
         halo = shp[1][1] == 27 * Cin and Cin % 32 == 0 and prec != "f32"
         frag = "true" if get_halo_frag() else "false"
         sch = (1 if os.environ.get("OCCF_HALO_SCHED", "1") != "0" else 0) if get_halo_frag() else 0
-        kname = (f"conv3x3x3_halo_kernel<{2 if Cout % 128 == 0 else 3 if Cout % 192 == 0 else 1}, {terms}, {frag}, {sch}>"
-                 if halo else "gemm_bf16_kernel<CONV>")
+        # (csrc/conv_halo.hip: half-size tiles -- 4 waves, two workgroups per CU -- are the default of the fragment variant)
+        small = get_halo_frag() and os.environ.get("OCCF_HALO_SMALL", "1") != "0"
+        kname = (f"conv3x3x3_halo_kernel<{2 if Cout % 128 == 0 else 3 if Cout % 192 == 0 else 1}, {terms}, {frag}, {sch}, "
+                 f"{2 if small else 4}>" if halo else "gemm_bf16_kernel<CONV>")
         nbytes = 4 * (B * X * Y * Z * (Cin + Cout)) + 4 * Cout * shp[1][1]
         if halo:
             tz = 16 if Z >= 16 else Z
-            ty = 128 // tz
+            ty = (64 if small else 128) // tz
             bn = 128 if Cout % 128 == 0 else 192 if Cout % 192 == 0 else 64
-            grid = B * ((X + 1) // 2) * ((Y + ty - 1) // ty) * (Z // tz) * ((Cout + bn - 1) // bn) * 512
+            grid = B * ((X + 1) // 2) * ((Y + ty - 1) // ty) * (Z // tz) * ((Cout + bn - 1) // bn) * (256 if small else 512)
             traffic, src = pmc_traffic(kname, grid)
     elif name == "conv3d_wgrad":
         B, X, Y, Z, Cout = shp[0]

@@ -88,11 +88,18 @@ typedef uint32_t ch_u2 __attribute__((ext_vector_type(2)));
 // the current k-step (sched_group_barrier), no conditional load in the loop.  The compiler's own order sank the
 // loads to 1-5 MFMAs in front of their first use to save registers (ISA: s_waitcnt lgkmcnt one MFMA after four
 // ds_read_b128, vmcnt four MFMAs after the loads).
-template <int TN, int TERMS, bool FRAG, int SCH = 0>
-__global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
+// WM = waves along M: 4 (workgroup = 8 waves, 256 output voxels, halo tile 115 KB: ONE workgroup per CU) or 2 (round 5:
+// 4 waves, 128 voxels = 2 x-planes x (TY * TZ = 64), halo tile <= 69 KB: TWO workgroups per CU, so that one's chunk
+// boundary -- barrier, a halo round trip to HBM / L2, the split pass, barrier: the whole CU idle with one workgroup --
+// runs under the other's taps; FRAG only)
+template <int TN, int TERMS, bool FRAG, int SCH = 0, int WM = 4>
+__global__ void __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) conv3x3x3_halo_kernel(ConvHaloArgs p) {
+  static_assert(WM == 4 || (WM == 2 && FRAG), "the half-size tile exists for the fragment variant only");
+  constexpr int NT = WM * 128;                        // threads
+  constexpr int PLS = WM == 4 ? 7 : 6;                // log2(TY * TZ): voxels of one x-plane of the tile
   constexpr int BN = 64 * TN;
-  constexpr int NBP = (BN * 4 + 511) / 512;          // 16-B weight pieces per thread per array
-  constexpr int NHI = 13;                             // float4 halo pieces per thread (816 * 8 / 512)
+  constexpr int NBP = (BN * 4 + 511) / 512;          // 16-B weight pieces per thread per array (slab variant)
+  constexpr int NHI = WM == 4 ? 13 : 14;              // float4 halo pieces per thread (816 * 8 / 512; 432 * 8 / 256)
   constexpr bool HPF = TN <= 2;                       // prefetch the next chunk's halo across the taps
   OCCF_DYN_SMEM(smem);
   const int TY = p.TY, TZ = p.TZ;
@@ -130,7 +137,7 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = wm * 64 + i * 32 + (FRAG ? ch_pos(li) : li);
-    const int tx = r >> 7, pp = r & 127;
+    const int tx = r >> PLS, pp = r & ((1 << PLS) - 1);
     hb[i] = (tx * HY + pp / TZ) * HZ + pp % TZ;
   }
   // this thread's halo pieces: clamped element offset (channel 0 of the chunk) + validity bit
@@ -140,7 +147,7 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
   unsigned hok = 0;
 #pragma unroll
   for (int i = 0; i < NHI; ++i) {
-    const int idx = tid + i * 512;
+    const int idx = tid + i * NT;
     const int idc = idx < nhp ? idx : nhp - 1;
     const int h = idc >> 3, kq = idc & 7;
     const int hz = h % HZ, hy = (h / HZ) % HY, hx = h / (HZ * HY);
@@ -186,7 +193,7 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
 #pragma unroll
     for (int ii = 0; ii < HB; ++ii) {
       const int i = i0 + ii;
-      const int idx = tid + i * 512;
+      const int idx = tid + i * NT;
       if (i < NHI && idx < nhp) {
         const bool ok = (hok >> i) & 1u;
         const float4 v = hreg[ii];
@@ -444,8 +451,8 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
       for (int r = 0; r < 16; ++r) {
         const int mrow_ = (r & 3) + 8 * (r >> 2) + 4 * lk;
         const int row = wm * 64 + i * 32 + (FRAG ? ch_pos(mrow_) : mrow_);
-        const int pp = row & 127;
-        const int x = tx0 + (row >> 7), y = ty0 + pp / TZ, z = tz0 + pp % TZ;
+        const int pp = row & ((1 << PLS) - 1);
+        const int x = tx0 + (row >> PLS), y = ty0 + pp / TZ, z = tz0 + pp % TZ;
         mok[r] = n_ok && x < p.X && y < p.Y;
         mrow[r] = ((((long)b * p.X + occf_clampi(x, p.X - 1)) * p.Y + occf_clampi(y, p.Y - 1)) * p.Z + z) * p.Cout;
       }
@@ -470,7 +477,7 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
   }
   if (p.gn_partial) {
     // deterministic workgroup reduction: lanes (lk) -> LDS [wm][channel] -> channel -> group
-    float* red = (float*)smem;                             // [4][BN][2], then [BN][2] at offset 8*BN
+    float* red = (float*)smem;                             // [WM][BN][2]
     __syncthreads();                                        // every wave is out of the tap loop (halo LDS is free)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -485,7 +492,7 @@ __global__ void __launch_bounds__(512) conv3x3x3_halo_kernel(ConvHaloArgs p) {
     if (tid < BN && n0 + tid < p.Cout) {
       float a = 0.f, q = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
+      for (int w = 0; w < WM; ++w) { a += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }
       const long sp = ((long)(tx0 >> 1) * yt + ty0 / TY) * zt + tz0 / TZ;
       float* o = p.gn_partial + ((((long)b * xt * yt * zt) + sp) * p.Cout + n0 + tid) * 2;
       o[0] = a;
@@ -502,10 +509,21 @@ static size_t conv_halo_lds(int TY, int TZ, int TN, int terms, bool frag) {
 
 typedef void (*conv_halo_fn_t)(ConvHaloArgs);
 template <int TN>
-static conv_halo_fn_t conv_halo_fn(bool t3, bool frag, int sch) {
+static conv_halo_fn_t conv_halo_fn(bool t3, bool frag, int sch, bool small) {
+  if (small && sch) return t3 ? conv3x3x3_halo_kernel<TN, 3, true, 1, 2> : conv3x3x3_halo_kernel<TN, 1, true, 1, 2>;
+  if (small) return t3 ? conv3x3x3_halo_kernel<TN, 3, true, 0, 2> : conv3x3x3_halo_kernel<TN, 1, true, 0, 2>;
   if (frag && sch) return t3 ? conv3x3x3_halo_kernel<TN, 3, true, 1> : conv3x3x3_halo_kernel<TN, 1, true, 1>;
   if (frag) return t3 ? conv3x3x3_halo_kernel<TN, 3, true> : conv3x3x3_halo_kernel<TN, 1, true>;
   return t3 ? conv3x3x3_halo_kernel<TN, 3, false> : conv3x3x3_halo_kernel<TN, 1, false>;
+}
+
+// OCCF_HALO_SMALL: 1 (default) = half-size tiles, two workgroups per CU (fragment variant); 0 = 256-voxel tiles.  The
+// choice depends on nothing but this switch and on the fragments being passed: occf_conv3x3x3_halo_gn_blocks answers
+// for the fragment call, and a call WITHOUT fragments that asks for GroupNorm partials under small tiles is refused
+// (OCCF_ESHAPE: the caller's buffer has the small-tile row count).
+static int conv_halo_small() {
+  const char* e = getenv("OCCF_HALO_SMALL");
+  return e ? atoi(e) : 1;
 }
 
 // OCCF_HALO_SCHED: 1 (default) = the explicitly pipelined k-step of the FRAG variant, 0 = the compiler's order
@@ -571,7 +589,6 @@ extern "C" int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, con
   int TZ = Z >= 16 ? 16 : Z;
   if (TZ != 16 && TZ != 8 && TZ != 4) return OCCF_ESHAPE;
   if (Z % TZ != 0) return OCCF_ESHAPE;
-  const int TY = 128 / TZ;
   // N tile: 64*TN channels; pick the widest that does not waste more than a quarter
   int TN;
   if (Cout % 128 == 0) TN = 2;
@@ -579,6 +596,9 @@ extern "C" int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, con
   else if (Cout % 64 == 0) TN = 1;
   else return OCCF_ESHAPE;
   const bool frag = wfrag_hi && (terms == 1 || wfrag_lo);
+  const bool small = frag && conv_halo_small() != 0;
+  if (!frag && gn_partial && conv_halo_small() != 0) return OCCF_ESHAPE;
+  const int TY = (small ? 64 : 128) / TZ;
   const size_t lds = conv_halo_lds(TY, TZ, TN, terms, frag);
   if (lds > 160 * 1024) return OCCF_ESHAPE;
   ConvHaloArgs a = {};
@@ -591,17 +611,18 @@ extern "C" int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, con
   if (blocks >= 2147483647L) return OCCF_ESHAPE;
   const bool t3 = terms == 3, fr = a.Fh != nullptr;
   const int sch = fr ? (conv_halo_sched() ? 1 : 0) : 0;
-  const conv_halo_fn_t fn = TN == 1 ? conv_halo_fn<1>(t3, fr, sch) : TN == 2 ? conv_halo_fn<2>(t3, fr, sch) : conv_halo_fn<3>(t3, fr, sch);
+  const conv_halo_fn_t fn = TN == 1 ? conv_halo_fn<1>(t3, fr, sch, small) : TN == 2 ? conv_halo_fn<2>(t3, fr, sch, small)
+                                                                                   : conv_halo_fn<3>(t3, fr, sch, small);
 #ifndef OCCF_EMU
-  static bool attr_set[4][2][2][2] = {};
-  if (!attr_set[TN][t3][fr][sch]) {
+  static bool attr_set[4][2][2][2][2] = {};
+  if (!attr_set[TN][t3][fr][sch][small]) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set[TN][t3][fr][sch] = true;
+    attr_set[TN][t3][fr][sch][small] = true;
   }
 #endif
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(512), lds, st, a);
+  hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(small ? 256 : 512), lds, st, a);
   return (int)hipGetLastError();
 }
 
@@ -610,6 +631,6 @@ extern "C" int occf_conv3x3x3_halo_fwd(const float* x, const uint16_t* w_hi, con
 extern "C" long occf_conv3x3x3_halo_gn_blocks(int X, int Y, int Z) {
   const int TZ = Z >= 16 ? 16 : Z;
   if ((TZ != 16 && TZ != 8 && TZ != 4) || Z % TZ != 0) return -1;
-  const int TY = 128 / TZ;
+  const int TY = (conv_halo_small() != 0 ? 64 : 128) / TZ;
   return (long)((X + 1) / 2) * ((Y + TY - 1) / TY) * (Z / TZ);
 }

@@ -152,5 +152,17 @@ i)  # round 5, visit i: the streaming normalisation / elementwise passes at full
 timeout 600 python scripts/bwd_probe.py gn 2>&1 | grep -v "amdgpu.ids" | tee $O/r05i_elementwise_probe.txt
 timeout 600 python -m pytest tests/test_bwd_ops.py -m gpu -q -p no:cacheprovider -k "groupnorm" 2>&1 | tail -2
 ;;
+j)  # round 5, visit j: halo conv on half-size tiles (two workgroups per CU) vs the 256-voxel tiles: probe, GPU tests, forward bench
+for v in 0 1; do OCCF_HALO_SMALL=$v timeout 300 python scripts/conv_probe.py 2>/dev/null; done | tee $O/r05j_conv_probe_small.txt
+timeout 900 python -m pytest tests/test_gemm_norm_ops.py tests/test_full_size_gpu.py -m gpu -q -p no:cacheprovider -k "halo or conv or groupnorm_stats" 2>&1 | tail -3
+for v in 0 1; do
+  OCCF_HALO_SMALL=$v timeout 400 python bench.py --mode forward --steps 20 --warmup 3 --check > $O/r05j_bench_fwd_small$v.json 2>/dev/null
+  python - <<PY
+import json
+f = json.load(open("gpurun_out/r05j_bench_fwd_small$v.json"))
+print("OCCF_HALO_SMALL=$v forward", round(f["value"], 2), "samples/s", round(f["ms_per_step"], 2), "ms, conv3d", f["kernels"]["conv3d"]["total_ms"], "roofline", round(f["roofline"]["frac"], 4), f["roofline"]["kernel"][:60], "check", f["check"])
+PY
+done
+;;
 *) echo "usage: $0 <stage>"; exit 2;;
 esac

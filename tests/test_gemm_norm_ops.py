@@ -207,9 +207,12 @@ def test_splitk_small_m_long_k(be, monkeypatch):
 @pytest.mark.parametrize("shape,cin,cout", [((1, 5, 9, 16), 32, 64), ((2, 4, 20, 8), 64, 128), ((1, 3, 34, 4), 32, 192),
                                             ((1, 2, 8, 32), 32, 64)])
 @pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
-@pytest.mark.parametrize("frag", [True, False])      # weights in fragment order from global memory / slabs through LDS
-def test_conv3x3x3_halo(be, monkeypatch, shape, cin, cout, prec, tol, frag):
+# weights in fragment order from global memory, on half-size tiles (two workgroups per CU: the default) and on the
+# 256-voxel tiles; weight slabs through LDS (256-voxel tiles only)
+@pytest.mark.parametrize("frag,small", [(True, "1"), (True, "0"), (False, "1")])
+def test_conv3x3x3_halo(be, monkeypatch, shape, cin, cout, prec, tol, frag, small):
     """LDS-halo conv kernel (odd X, ragged Y tiles, Z = 4/8/16/32) vs fp64 conv3d; with bias/ReLU/residual"""
+    monkeypatch.setenv("OCCF_HALO_SMALL", small)
     monkeypatch.setattr(be.ops, "precision", prec)
     monkeypatch.setattr(be.ops, "use_halo_conv", True)
     monkeypatch.setattr(be.ops, "halo_frag", frag)
@@ -322,10 +325,13 @@ def test_linear_head_major_output(be):
     assert out.shape == ref.shape and torch.allclose(out, ref, atol=2e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("kind", ["halo", "strided", "linear", "linear192"])
+@pytest.mark.parametrize("kind", ["halo", "halo256", "strided", "linear", "linear192"])
 def test_groupnorm_stats_from_conv_epilogue(be, kind, monkeypatch):
     """the GroupNorm statistics emitted by the conv / GEMM epilogues equal groupnorm_stats of the output"""
     ops = be.ops
+    if kind == "halo256":                # the halo kernel's 256-voxel tiles (the default is the half-size tile)
+        monkeypatch.setenv("OCCF_HALO_SMALL", "0")
+        kind = "halo"
     # the epilogue path belongs to launches without K slices (large M); this small case would be sliced
     monkeypatch.setenv("OCCF_GEMM_KSPLIT", "1")
     if ops.precision == "f32":
