@@ -164,5 +164,10 @@ print("OCCF_HALO_SMALL=$v forward", round(f["value"], 2), "samples/s", round(f["
 PY
 done
 ;;
+k)  # round 5, visit k: the full GPU suite + smoke on the current tree
+( time timeout 1700 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=10 ) 2>&1 | grep -v "MIOpen(HIP)" > $O/r05k_pytest_gpu.log
+tail -22 $O/r05k_pytest_gpu.log | cut -c1-300
+timeout 300 python __graft_entry__.py --smoke 2>&1 | grep -v "MIOpen(HIP)" | tail -4 | tee $O/r05k_smoke.log
+;;
 *) echo "usage: $0 <stage>"; exit 2;;
 esac
