@@ -169,5 +169,34 @@ k)  # round 5, visit k: the full GPU suite + smoke on the current tree
 tail -22 $O/r05k_pytest_gpu.log | cut -c1-300
 timeout 300 python __graft_entry__.py --smoke 2>&1 | grep -v "MIOpen(HIP)" | tail -4 | tee $O/r05k_smoke.log
 ;;
+l)  # round 5, visit l: counters of the streaming linear against the tile kernel (SQ wait / issue / MFMA counters, FETCH_SIZE, WRITE_SIZE: separate passes)
+cd /tmp && export TMPDIR=/tmp
+for c in "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+  tag=$(echo $c | cut -c1-8 | tr ' ' '_')
+  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/$O/r05l_pmc_$tag -- python $R/scripts/stream_probe.py quick > /dev/null 2>&1
+done
+cd $R
+python - <<'PY' | tee gpurun_out/r05l_stream_pmc.txt
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for f in glob.glob("gpurun_out/r05l_pmc_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "gemm_stream_kernel" not in k and "gemm_bf16_kernel" not in k: continue
+        key = (k[:48], r.get("Grid_Size"))
+        agg[key][r["Counter_Name"]] += float(r["Counter_Value"]); n[(key, r["Counter_Name"])] += 1
+print("per launch; FETCH_SIZE / WRITE_SIZE in KiB (HBM bytes: FETCH_SIZE x 2 x 1024 -- the gfx950 correction of MI355X_MICROARCH.md, as scripts/summarize_pmc.py -- and WRITE_SIZE x 1024)")
+for key, d in sorted(agg.items()):
+    print(key, {c: round(v / n[(key, c)]) for c, v in sorted(d.items())})
+PY
+find $O -name "*counter_collection.csv" -size +20M -delete 2>/dev/null
+;;
+m)  # round 5, visit m: the tiny gradient gates with 2 048 sampling points, three repetitions; kitti_effb7_128 full-size training parity; smoke
+for i in 1 2 3; do
+  timeout 600 python -m pytest tests/test_train_multistep.py tests/test_train_step.py -m gpu -q -p no:cacheprovider -s -k "three_fused or training_step" 2>&1 | grep -i "whole gradient\|passed\|failed" | cut -c1-160
+done | tee $O/r05m_tiny_gates_x3.log
+timeout 300 python __graft_entry__.py --smoke 2>&1 | grep -v "MIOpen(HIP)" | tail -3 | tee $O/r05m_smoke.log
+timeout 900 python -m pytest tests/test_workloads_gpu.py -m gpu -q -p no:cacheprovider -s -k "training_step and kitti_effb7_128" 2>&1 | grep "training step vs oracle\|passed\|failed" | cut -c1-700 | tee $O/r05m_kitti128.log
+;;
 *) echo "usage: $0 <stage>"; exit 2;;
 esac

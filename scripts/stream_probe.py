@@ -17,7 +17,11 @@ SHAPES = [(680000, 128, 128, 0), (680000, 128, 384, 0), (680000, 128, 128, 2), (
           (640000, 192, 128, 0), (80000, 192, 192, 0), (12500, 512, 512, 0)]
 
 
-def bench(fn, n_buf, iters=24):
+if "quick" in sys.argv:            # (counter passes: three shapes, few iterations)
+    SHAPES = [(680000, 128, 128, 0), (680000, 128, 384, 0), (91250, 192, 768, 1)]
+
+
+def bench(fn, n_buf, iters=6 if "quick" in sys.argv else 24):
     for i in range(3):
         fn(i % n_buf)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

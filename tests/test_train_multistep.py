@@ -90,7 +90,7 @@ def _small():
     cfg["pts_bbox_head"]["transformer_decoder"]["num_layers"] = 3
     cfg["img_bev_encoder_backbone"]["block_numbers"] = [1, 1, 1, 1]
     cfg["img_bev_encoder_neck"]["encoder"]["num_layers"] = 1
-    tc = train_cfg(num_points=64)
+    tc = train_cfg(num_points=2048)        # (see tests/test_train_step._setup: a swapped sampling point weighs 1 / num_points)
     cfg["train_cfg"] = dict(pts=tc)
     cfg["test_cfg"] = None
     meta = dict(meta, pd_layers=1, dec_layers=3, block_numbers=(1, 1, 1, 1))
