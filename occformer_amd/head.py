@@ -228,6 +228,8 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
                 if want_attn and am is None:
                     _, blocked, row_open = ops.mask_pool(dense, target_shape)
                     am = (blocked, row_open)
+        if am is not None:
+            noise.tape_mask(am[0])                  # (comparison tap: a no-op unless a comparison records)
         return cls_pred, LazyMask(dense, mask_embed, mask_feat_tok, vol_shape, mask_feat_split), am
 
     def _project_level_tokens(self, keys, keys_pp):

@@ -72,6 +72,16 @@ def relu_gate(h, heavy=True, gate=None):
     return h
 
 
+def tape_mask(blocked):
+    """the decoder's boolean attention mask of the training graph (mask2former_nusc_occ.py:457-469: pooled mask logits,
+    ``sigmoid < 0.5``): the other discrete decision on fp32 values next to the ReLU gates -- a pooled logit within rounding
+    of zero blocks a key in one implementation and not in the other, and at a coarse level one key is a visible share
+    of a query's attention.  Taped in call order with the heavy gates; a no-op unless a comparison records."""
+    if gates_wanted(True):
+        _gates.append(blocked.detach() != 0)
+    return blocked
+
+
 class RecordedRNG:
     """wraps a noise source and tapes every draw as (kind, CPU tensor) in call order -- the tape a comparison feeds to
     the CPU oracle so that it repeats THIS step's noise (the converse of replaying the oracle's tape on the device; one

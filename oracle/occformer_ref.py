@@ -644,7 +644,7 @@ def _mha(sd, p, q, k, v, heads, mask=None):
     return F.linear(out, sd[p + "out_proj.weight"], sd[p + "out_proj.bias"])
 
 
-def head_predict(sd, p, dec, mask_feat, target_shape, heads, pooling=True):
+def head_predict(sd, p, dec, mask_feat, target_shape, heads, pooling=True, want_attn=True):
     """P/occformer/mask2former/mask2former_nusc_occ.py:426-471 (forward_head).
     dec [B, Q, E]; mask_feat [B, E, X, Y, Z].  Returns cls [B,Q,K+1], mask_pred
     [B,Q,X,Y,Z], pooled logits [B,Q,L] and bool attn mask [B, Q, L] (True = blocked;
@@ -661,7 +661,31 @@ def head_predict(sd, p, dec, mask_feat, target_shape, heads, pooling=True):
     else:
         pooled = F.interpolate(mask_pred, target_shape, mode="trilinear", align_corners=True)
     pooled = pooled.flatten(2)
-    return cls, mask_pred, pooled, pooled.sigmoid() < 0.5
+    return cls, mask_pred, pooled, (_blocked_forced(pooled) if want_attn else None)
+
+
+def _blocked_forced(pooled):
+    """``pooled.sigmoid() < 0.5`` (True = key blocked), or -- inside ``forced_gates`` -- the mask the OTHER implementation
+    used (taped with its heavy ReLU gates, in call order); the elements that differ are counted like flipped gates and
+    their pooled logits must be rounding-close to zero (the caller asserts ``max_rel_z``)."""
+    own = pooled.detach() < 0
+    g = _GATES
+    if g is None:
+        return own
+    assert g.i < len(g.masks), "forced_gates: more attention masks are evaluated than were recorded"
+    m = g.masks[g.i]
+    assert m.shape == own.shape, f"forced_gates: attention mask {g.i} has shape {tuple(own.shape)}, recorded {tuple(m.shape)}"
+    g.i += 1
+    diff = own != m
+    n = int(diff.sum())
+    g.units += own.numel()
+    if n:
+        zd = pooled.detach()
+        a = float(zd[diff].abs().max())
+        g.flipped += n
+        g.max_abs_z = max(g.max_abs_z, a)
+        g.max_rel_z = max(g.max_rel_z, a / max(float(zd.pow(2).mean().sqrt()), 1e-30))
+    return m
 
 
 def mask2former_head(sd, p, feats, heads=6, num_layers=9, num_levels=3, pooling=True,
@@ -695,8 +719,10 @@ def mask2former_head(sd, p, feats, heads=6, num_layers=9, num_levels=3, pooling=
         y = _linear(sd, lp + "ffns.0.layers.1.", _relu_gated(_linear(sd, lp + "ffns.0.layers.0.0.", q)))
         q = F.layer_norm(q + y, (E,), sd[lp + "norms.2.weight"], sd[lp + "norms.2.bias"], 1e-5)
         inter.append((pooled, blocked))
+        # (the mask of the last prediction feeds no attention: it is not formed, as in the product, so that the taped
+        # decisions of a comparison line up)
         cls, mp, pooled, blocked = head_predict(
-            sd, p, q, mask_feat, mem[(i + 1) % num_levels].shape[-3:], heads, pooling)
+            sd, p, q, mask_feat, mem[(i + 1) % num_levels].shape[-3:], heads, pooling, want_attn=i + 1 < num_layers)
         cls_list.append(cls)
         mask_list.append(mp)
     if return_intermediates:
