@@ -147,3 +147,24 @@ if "gn" in what:
     ident = torch.randn(1, 200, 200, 16, C, generator=g).cuda()
     cw, cb = torch.randn(C, generator=g).cuda(), torch.randn(1, generator=g).cuda()
     gbs("dualpath_combine [200,200,16,128] (3 passes)", lambda: ops.dualpath_combine(tok, bev, cw, cb, ident), ident.numel() * 12)
+if "psample" in what:
+    # importance sampling of the head loss at the metric's sizes: S = 10 sets x G = 17 matched masks, 150 528 candidate
+    # points per set, sampled from the channel-major logits [S, G, X, Y, Z] (what runs today) against the same logits
+    # voxel-major [V, 224] (20 columns per set) through the channels-last sampler
+    S, G, P3 = 10, 17, 150528
+    dense = torch.randn(S, G, 200, 200, 16, generator=g).cuda()
+    cand = torch.rand(S, P3, 3, generator=g).cuda()
+    timeit("point_sample_3d dense [10,17,200,200,16] at [10,150528] points", lambda: ops.point_sample_3d(dense, cand, False, "border"))
+    vm = torch.randn(200 * 200 * 16, 224, generator=g).cuda()
+    def vm_sample():
+        return [ops.point_sample_tokens(vm[:, 20 * s:20 * s + 20], (200, 200, 16), cand[s], False, "border") for s in range(S)]
+    timeit("point_sample_tokens x10 on voxel-major [640000, 224] column blocks of 20", vm_sample)
+    feat = torch.randn(640000, 192, generator=g).cuda()
+    w = torch.randn(224, 192, generator=g).cuda() * 0.05
+    sp = ops.split_bf16(w)
+    timeit("linear feat [640000,192] x rows [224,192] -> voxel-major logits", lambda: ops.linear(feat, w, None, w_split=sp))
+    rows = torch.randn(170, 192, generator=g).cuda()
+    fsp = ops.split_bf16(feat)
+    timeit("linear rows [170,192] x feat [640000,192] -> channel-major logits (today)", lambda: ops.linear(rows, feat, None, w_split=fsp, allow_small=False))
+    pts = torch.rand(G, 50176, 3, generator=g).cuda()
+    timeit("point_sample_3d one set's rows [17,1,200,200,16] at their own [17,50176] points", lambda: ops.point_sample_3d(dense[0].unsqueeze(1).contiguous(), pts, False, "border"))

@@ -198,5 +198,8 @@ done | tee $O/r05m_tiny_gates_x3.log
 timeout 300 python __graft_entry__.py --smoke 2>&1 | grep -v "MIOpen(HIP)" | tail -3 | tee $O/r05m_smoke.log
 timeout 900 python -m pytest tests/test_workloads_gpu.py -m gpu -q -p no:cacheprovider -s -k "training_step and kitti_effb7_128" 2>&1 | grep "training step vs oracle\|passed\|failed" | cut -c1-700 | tee $O/r05m_kitti128.log
 ;;
+n)  # round 5, visit n: the head loss's importance sampling, channel-major vs voxel-major logits
+timeout 300 python scripts/bwd_probe.py psample 2>&1 | grep -v "amdgpu.ids" | tee $O/r05n_psample_probe.txt
+;;
 *) echo "usage: $0 <stage>"; exit 2;;
 esac
