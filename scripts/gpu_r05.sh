@@ -201,5 +201,16 @@ timeout 900 python -m pytest tests/test_workloads_gpu.py -m gpu -q -p no:cachepr
 n)  # round 5, visit n: the head loss's importance sampling, channel-major vs voxel-major logits
 timeout 300 python scripts/bwd_probe.py psample 2>&1 | grep -v "amdgpu.ids" | tee $O/r05n_psample_probe.txt
 ;;
+o)  # round 5, visit o: head loss with the voxel-major candidate logits: training bench + full-size parity of two workloads
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/r05o_bench_train.json 2>/dev/null
+python - <<'PY'
+import json
+t = json.load(open("gpurun_out/r05o_bench_train.json"))
+k = t["kernels"]
+print("train", round(t["value"], 3), "samples/s", round(t["ms_per_step"], 2), "ms | point_sample_3d", k["point_sample_3d"], "point_sample_tokens", k.get("point_sample_tokens"), "linear", k["linear"]["total_ms"], "groupnorm_backward", k["groupnorm_backward"]["total_ms"])
+PY
+( time timeout 900 python -m pytest tests/test_workloads_gpu.py tests/test_training.py -m gpu -q -p no:cacheprovider -s -k "(training_step and (nusc_r50_200 or nusc_r101)) or test_training" ) 2>&1 | grep -v "MIOpen(HIP)" > $O/r05o_workloads_train.log
+grep "training step vs oracle\|passed\|failed\|^real\|Error" $O/r05o_workloads_train.log | cut -c1-600
+;;
 *) echo "usage: $0 <stage>"; exit 2;;
 esac
