@@ -586,7 +586,9 @@ extern "C" int occf_groupnorm_bwd(const float* x, const float* stats, const floa
                      B, C, G, (double)V * (C / G));
   const char* e_rows = getenv("OCCF_GNB_APPLY_ROWS");     // 0: the thread-per-float4 form (read per call: A/B probes)
   const int rows_form = e_rows ? atoi(e_rows) : 1;
-  if (idx32 && rows_form && C <= 1024 && 256 / (C / 4) >= 1)
+  // (the row-walking form needs enough 256-row blocks to fill the chip -- r05o: taken for every shape it cost the
+  // mid-size calls, [80 000, 256] and smaller, more than it gave the full-resolution ones)
+  if (idx32 && rows_form && C <= 1024 && 256 / (C / 4) >= 1 && (nblk >= 1024 || rows_form == 2))     // (2: forced, tests)
     hipLaunchKernelGGL(gn_bwd_apply_rows_kernel, dim3(nblk, B), dim3(256), 0, st, x, stats, gamma, beta, dy, gs, dx,
                        dresidual, V, Z, C, G, relu, tokens, rows);
   else if (idx32)

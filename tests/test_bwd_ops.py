@@ -96,7 +96,9 @@ def test_fork_nodes_fuse_the_residual_gradient(be, monkeypatch):
 
 @pytest.mark.parametrize("relu,tokens,res", [(True, True, False), (False, False, False), (True, False, True),
                                              (False, False, True)])
-def test_groupnorm_backward(be, relu, tokens, res):
+@pytest.mark.parametrize("apply_form", ["0", "2"])       # thread-per-float4 / row-walking apply pass (2 = forced at any size)
+def test_groupnorm_backward(be, monkeypatch, relu, tokens, res, apply_form):
+    monkeypatch.setenv("OCCF_GNB_APPLY_ROWS", apply_form)
     B, X, Y, Z, C, G = 2, 5, 6, 4, 64, 8
     x = _t("gn_x", (B, X, Y, Z, C), 3).requires_grad_()
     g = (_t("gn_g", (C,), 4) * 0.2 + 1).requires_grad_()

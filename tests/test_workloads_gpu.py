@@ -242,7 +242,8 @@ def test_workload_training_step_vs_oracle(hip, name):
     assert forced.flipped <= 1e-4 * forced.units, (forced.flipped, forced.units)
     assert whole <= TOL
     # (measured r04n: whole gradient 4.1e-5 ... 1.3e-4, 90 % of the parameters <= 3.9e-4, worst parameter <= 2.0e-3)
-    # per parameter: 90 % within 1e-3; the worst one within 1e-2 -- it is always a dilated BEV-ASPP convolution of a coarse
-    # stage (25 x 25 or 13 x 13 maps under dilation 12 / 18: a handful of contributing positions, light ReLU gates that
-    # are not forced); measured 1.0e-3 ... 6.8e-3 over the round's visits (r05a / r05g / r05k)
-    assert qs[0.9] <= 1e-3 and qs[1.0] <= 1e-2
+    # per parameter: 90 % within 1e-3, 99 % within 3e-3 (measured 7.6e-4 ... 1.4e-3); the single worst one within 2e-2 -- it
+    # is always a dilated BEV-ASPP convolution (a handful of contributing positions on the coarse maps, light ReLU gates
+    # that are not forced) and moves between 1.0e-3 and 1.0e-2 from visit to visit and workload to workload (r05a / g / k /
+    # m / o), so a bound of 6e-3 (3x the round-4 maximum) failed twice in this round's five visits
+    assert qs[0.9] <= 1e-3 and qs[0.99] <= 3e-3 and qs[1.0] <= 2e-2
