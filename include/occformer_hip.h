@@ -507,9 +507,12 @@ int occf_modulated_deform_col2im(const float* x, const float* offset, const floa
                                  int dil, int groups, int deform_groups, void* stream);
 
 /* One launch for a TABLE of strided-gather + bf16-split jobs (the per-step "prepare weights" pass: tap-major,
- * transposed, tap-flipped layouts and (hi, lo) splits of every parameter).  table[(n + 1) * 15] int64 on the device, row
- * r = {in, f32_out or 0, hi_out, lo_out, first pair index, dims[5], input strides[5] (elements, base offset folded
- * into `in`)}; row n carries the total pair count.  A pair = two consecutive outputs of the last dimension (even). */
+ * transposed, tap-flipped layouts and (hi, lo) splits of every parameter).  table[(n + 1) * 16] int64 on the device, row
+ * r = {in, f32_out or 0, hi_out, lo_out, first pair index of its span, dims[5], input strides[5] (elements, base offset
+ * folded into `in`), mode}; row n carries the total span.  A pair = two consecutive outputs of the last dimension
+ * (even).  Spans are whole SLOTS of 512 pairs (one workgroup each): mode 0 = ceil(pairs / 512) slots in output order;
+ * mode 1 (the output's last dimension is the input's slowest: transposes) = ceil(M / 32) * ceil(N / 32) slots, one
+ * 32 x 32 tile of out[M = d0 d1 d2 d3][N = d4] each, staged through LDS.  total_pairs = the total span. */
 int occf_prep_weights(const int64_t* table, int n, long total_pairs, void* stream);
 
 /* ------------------------------------------------------------------ input pipeline / evaluation ---- */

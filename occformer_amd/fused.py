@@ -142,6 +142,7 @@ class _WeightPrep:
             dev = param.device
             e = dict(ref=weakref.ref(param), ptr=param.data_ptr(), shape=tuple(param.shape), ops=ops, kind=kind,
                      dims=dims, strides=strides, base=base, stamp=None,
+                     mode=1 if kind in ("wt", "dg", "flip") else 0,      # transposes go through LDS tiles (prep.hip)
                      f32=None if kind == "split" else torch.empty(oshape, dtype=torch.float32, device=dev),
                      hi=torch.empty(oshape, dtype=torch.int16, device=dev),
                      lo=torch.empty(oshape, dtype=torch.int16, device=dev))
@@ -157,14 +158,23 @@ class _WeightPrep:
                                 "occformer_amd: a prepared weight layout is stale (parameter written behind the cache)")
         return e["f32"], (e["hi"], e["lo"])
 
+    @staticmethod
+    def _span(e):
+        """pairs of the table span of an entry (whole 512-pair slots; csrc/prep.hip): mode 1 = one slot per 32 x 32 tile
+        of the transposed output [M][N], mode 0 = the output pairs in order"""
+        d = e["dims"]
+        if e["mode"] == 1:
+            m = d[0] * d[1] * d[2] * d[3]
+            return ((m + 31) // 32) * ((d[4] + 31) // 32) * 512
+        n = d[0] * d[1] * d[2] * d[3] * d[4]
+        return (n // 2 + 511) // 512 * 512
+
     def _refresh_one(self, ops, e, p):
-        n = 1
-        for d in e["dims"]:
-            n *= d
+        span = self._span(e)
         rows = [[e["ptr"] + 4 * e["base"], 0 if e["f32"] is None else e["f32"].data_ptr(), e["hi"].data_ptr(),
-                 e["lo"].data_ptr(), 0, *e["dims"], *e["strides"]],
-                [0, 0, 0, 0, n // 2] + [1] * 5 + [0] * 5]
-        ops.prep_weights(torch.tensor(rows, dtype=torch.int64).to(p.device), 1, n // 2)
+                 e["lo"].data_ptr(), 0, *e["dims"], *e["strides"], e["mode"]],
+                [0, 0, 0, 0, span] + [1] * 5 + [0] * 5 + [0]]
+        ops.prep_weights(torch.tensor(rows, dtype=torch.int64).to(p.device), 1, span)
         e["stamp"] = (p._version, _EPOCH[0])
         if _CHECK:
             e["sum"] = _checksum(p)
@@ -185,12 +195,9 @@ class _WeightPrep:
             rows, pair0 = [], 0
             for e, p in live:
                 rows.append([e["ptr"] + 4 * e["base"], 0 if e["f32"] is None else e["f32"].data_ptr(),
-                             e["hi"].data_ptr(), e["lo"].data_ptr(), pair0, *e["dims"], *e["strides"]])
-                n = 1
-                for d in e["dims"]:
-                    n *= d
-                pair0 += n // 2
-            rows.append([0, 0, 0, 0, pair0] + [1] * 5 + [0] * 5)
+                             e["hi"].data_ptr(), e["lo"].data_ptr(), pair0, *e["dims"], *e["strides"], e["mode"]])
+                pair0 += self._span(e)
+            rows.append([0, 0, 0, 0, pair0] + [1] * 5 + [0] * 5 + [0])
             # (a pageable upload: only when the set of prepared layouts changes, i.e. during the first one or two steps)
             self.table = torch.tensor(rows, dtype=torch.int64).to(device)
             self.table_for = (ids, str(device))

@@ -37,6 +37,12 @@ cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/prof.log 2>&1 ; echo "rocprof rc=$?" ; tail -2 $O/prof.log
 cd $R
 python scripts/summarize_prof.py $O/prof > $O/kernel_stats.txt 2>&1 ; head -50 $O/kernel_stats.txt
+echo "== rocprof kernel trace (forward)"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fwd -- python $R/bench.py --mode forward --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_fwd.log 2>&1 ; echo "rocprof fwd rc=$?"
+cd $R
+python scripts/summarize_prof.py $O/prof_fwd > $O/fwd_kernel_stats.txt 2>&1 ; head -24 $O/fwd_kernel_stats.txt | cut -c1-150
+find $O/prof_fwd -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
 echo "== rocprof PMC passes (HBM traffic of the training step)"
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
