@@ -160,8 +160,8 @@ def roofline(timed_census, kernels, prec, steps):
         halo = shp[1][1] == 27 * Cin and Cin % 32 == 0 and prec != "f32"
         frag = "true" if get_halo_frag() else "false"
         sch = (1 if os.environ.get("OCCF_HALO_SCHED", "1") != "0" else 0) if get_halo_frag() else 0
-        # (csrc/conv_halo.hip: half-size tiles -- 4 waves, two workgroups per CU -- are the default of the fragment variant)
-        small = get_halo_frag() and os.environ.get("OCCF_HALO_SMALL", "1") != "0"
+        # (csrc/conv_halo.hip: half-size tiles -- 4 waves, two workgroups per CU -- are an opt-in of the fragment variant)
+        small = get_halo_frag() and os.environ.get("OCCF_HALO_SMALL", "0") not in ("0", "")
         kname = (f"conv3x3x3_halo_kernel<{2 if Cout % 128 == 0 else 3 if Cout % 192 == 0 else 1}, {terms}, {frag}, {sch}, "
                  f"{2 if small else 4}>" if halo else "gemm_bf16_kernel<CONV>")
         nbytes = 4 * (B * X * Y * Z * (Cin + Cout)) + 4 * Cout * shp[1][1]

@@ -88,7 +88,7 @@ typedef uint32_t ch_u2 __attribute__((ext_vector_type(2)));
 // the current k-step (sched_group_barrier), no conditional load in the loop.  The compiler's own order sank the
 // loads to 1-5 MFMAs in front of their first use to save registers (ISA: s_waitcnt lgkmcnt one MFMA after four
 // ds_read_b128, vmcnt four MFMAs after the loads).
-// WM = waves along M: 4 (workgroup = 8 waves, 256 output voxels, halo tile 115 KB: ONE workgroup per CU) or 2 (round 5:
+// WM = waves along M: 4 (workgroup = 8 waves, 256 output voxels, halo tile 115 KB: ONE workgroup per CU) or 2 (round 5, opt-in:
 // 4 waves, 128 voxels = 2 x-planes x (TY * TZ = 64), halo tile <= 69 KB: TWO workgroups per CU, so that one's chunk
 // boundary -- barrier, a halo round trip to HBM / L2, the split pass, barrier: the whole CU idle with one workgroup --
 // runs under the other's taps; FRAG only)
@@ -517,13 +517,15 @@ static conv_halo_fn_t conv_halo_fn(bool t3, bool frag, int sch, bool small) {
   return t3 ? conv3x3x3_halo_kernel<TN, 3, false> : conv3x3x3_halo_kernel<TN, 1, false>;
 }
 
-// OCCF_HALO_SMALL: 1 (default) = half-size tiles, two workgroups per CU (fragment variant); 0 = 256-voxel tiles.  The
+// OCCF_HALO_SMALL: 1 = half-size tiles, two workgroups per CU (fragment variant); 0 (default) = 256-voxel tiles.
+// Measured (r05j / r05zz): the same 3.19 ms on the 192-channel launch, +2 ... 4 % on the 128-channel ones, but 2.12 GB of
+// HBM traffic per 192-channel launch instead of 1.72 GB (the halo is 3.4x the tile instead of 2.8x) -- an opt-in.  The
 // choice depends on nothing but this switch and on the fragments being passed: occf_conv3x3x3_halo_gn_blocks answers
 // for the fragment call, and a call WITHOUT fragments that asks for GroupNorm partials under small tiles is refused
 // (OCCF_ESHAPE: the caller's buffer has the small-tile row count).
 static int conv_halo_small() {
   const char* e = getenv("OCCF_HALO_SMALL");
-  return e ? atoi(e) : 1;
+  return e ? atoi(e) : 0;
 }
 
 // OCCF_HALO_SCHED: 1 (default) = the explicitly pipelined k-step of the FRAG variant, 0 = the compiler's order

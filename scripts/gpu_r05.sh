@@ -212,5 +212,20 @@ PY
 ( time timeout 900 python -m pytest tests/test_workloads_gpu.py tests/test_training.py -m gpu -q -p no:cacheprovider -s -k "(training_step and (nusc_r50_200 or nusc_r101)) or test_training" ) 2>&1 | grep -v "MIOpen(HIP)" > $O/r05o_workloads_train.log
 grep "training step vs oracle\|passed\|failed\|^real\|Error" $O/r05o_workloads_train.log | cut -c1-600
 ;;
+q)  # round 5, visit q: FETCH_SIZE / WRITE_SIZE of the roofline kernel (halo conv 192 -> 192 at 200x200x16) on the final kernel sources, from scripts/conv_probe.py (the bench under --pmc outgrew its time limit in r05z: it now also builds and runs the from-images detector)
+Q=$R/$O/r05zz
+mkdir -p $Q
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 170 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $Q/pmc_$c -- python $R/scripts/conv_probe.py 2 > $Q/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
+done
+cd $R
+python scripts/summarize_pmc.py $Q $Q/pmc_traffic.json > $Q/pmc_summary.txt 2>&1; head -8 $Q/pmc_summary.txt | cut -c1-160
+find $Q -name "*counter_collection.csv" -size +20M -delete 2>/dev/null
+timeout 200 python -m pytest tests/test_gemm_norm_ops.py tests/test_workloads_gpu.py -m gpu -q -p no:cacheprovider -k "halo or groupnorm_stats_from or (end_to_end and nusc_r50_200)" 2>&1 | tail -2
+timeout 200 python bench.py --mode forward --steps 20 --warmup 3 --no-cpu-baseline > $Q/bench_fwd.json 2>/dev/null
+python -c "
+import json; f=json.load(open('$Q/bench_fwd.json')); print('forward', round(f['value'],2), 'samples/s', round(f['ms_per_step'],2), 'ms; roofline', round(f['roofline']['frac'],4), 'traffic', f['roofline']['traffic'], f['roofline']['traffic_source'], f['roofline']['kernel'][:52])"
+;;
 *) echo "usage: $0 <stage>"; exit 2;;
 esac

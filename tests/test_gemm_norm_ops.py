@@ -207,8 +207,8 @@ def test_splitk_small_m_long_k(be, monkeypatch):
 @pytest.mark.parametrize("shape,cin,cout", [((1, 5, 9, 16), 32, 64), ((2, 4, 20, 8), 64, 128), ((1, 3, 34, 4), 32, 192),
                                             ((1, 2, 8, 32), 32, 64)])
 @pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
-# weights in fragment order from global memory, on half-size tiles (two workgroups per CU: the default) and on the
-# 256-voxel tiles; weight slabs through LDS (256-voxel tiles only)
+# weights in fragment order from global memory, on half-size tiles (two workgroups per CU: OCCF_HALO_SMALL=1) and on the
+# 256-voxel tiles (the default); weight slabs through LDS (256-voxel tiles only)
 @pytest.mark.parametrize("frag,small", [(True, "1"), (True, "0"), (False, "1")])
 def test_conv3x3x3_halo(be, monkeypatch, shape, cin, cout, prec, tol, frag, small):
     """LDS-halo conv kernel (odd X, ragged Y tiles, Z = 4/8/16/32) vs fp64 conv3d; with bias/ReLU/residual"""
@@ -329,9 +329,11 @@ def test_linear_head_major_output(be):
 def test_groupnorm_stats_from_conv_epilogue(be, kind, monkeypatch):
     """the GroupNorm statistics emitted by the conv / GEMM epilogues equal groupnorm_stats of the output"""
     ops = be.ops
-    if kind == "halo256":                # the halo kernel's 256-voxel tiles (the default is the half-size tile)
+    if kind == "halo256":                # the halo kernel's 256-voxel tiles (the default); "halo": the half-size tiles
         monkeypatch.setenv("OCCF_HALO_SMALL", "0")
         kind = "halo"
+    elif kind == "halo":
+        monkeypatch.setenv("OCCF_HALO_SMALL", "1")
     # the epilogue path belongs to launches without K slices (large M); this small case would be sliced
     monkeypatch.setenv("OCCF_GEMM_KSPLIT", "1")
     if ops.precision == "f32":
