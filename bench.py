@@ -348,9 +348,10 @@ def train_check(model, gl, cpu_losses, cpu_grads, forced, n_draws, ungated):
                                  "bound_on_that": MAX_REL_Z},
                 what="GPU forward_train + backward vs the CPU oracle's train_step: same weights (after the timed "
                      "optimizer steps), same inputs, the GPU step's noise tape replayed by the oracle.  Gated figures: "
-                     "the ReLU gates of the decoder head's MLPs, of DepthNet and of the BEV ASPP's image-level vector "
-                     "taken from the GPU step (units whose pre-activations straddle zero within rounding: counted "
-                     "above; bench.py exits non-zero when one of them is further from zero than the bound).  "
+                     "the ReLU gates of the decoder head's MLPs, of DepthNet and of the BEV ASPP's image-level vector and "
+                     "the decoder's boolean attention masks taken from the GPU step (decisions whose pre-activations / "
+                     "pooled logits straddle zero within rounding: counted above; bench.py exits non-zero when one of "
+                     "them is further from zero than the bound).  "
                      "*_ungated: the oracle on its own gates.  Losses relative to max(1, |loss|), gradients as "
                      "relative L2 of the whole vector / per parameter")
 
