@@ -310,6 +310,47 @@ def test_linear_streaming_kernel(be, monkeypatch, M, K, N, act, bias, res, prec,
     assert float((out0.cpu() - out.cpu()).abs().max() / ref.abs().max()) < 2 * tol
 
 
+@pytest.mark.parametrize("M,K,N", [(300, 128, 128), (170, 192, 384)])
+def test_linear_stream_training_epilogues(be, monkeypatch, M, K, N):
+    """occf_linear_stream_fwd: the three epilogues the Swin block's training graph uses (csrc/gemm_stream.h) against
+    their fp64 formulas -- (a) GELU with the pre-activation as a second output, (b) identity + DropPath scale per token
+    slice x (x W^T + b), (c) (x W^T + b) x GELU'(aux); and None outside the envelope (the caller's unfused fallback)"""
+    monkeypatch.setenv("OCCF_GEMM_STREAM", "64")
+    monkeypatch.setenv("OCCF_GEMM_STREAM_WGS", "16")
+    ops = be.ops
+    if ops.precision == "f32":
+        pytest.skip("the streaming kernel computes in the bf16 split modes")
+    x = paramgen.tensor("se.x", (M, K), 1)
+    w = paramgen.tensor("se.w", (N, K), 2, K ** -0.5)
+    b = paramgen.tensor("se.b", (N,), 3, 0.3)
+    r = paramgen.tensor("se.r", (M, N), 4)
+    xd, wd, bd, rd = be.to(x, w, b, r)
+    sp = ops.split_bf16(wd)
+    z_ref = F.linear(x.double(), w.double(), b.double())
+    # (a)
+    f, z = ops.linear_stream(xd, sp, bd, 2, pre_out=True)
+    assert float((z.cpu() - z_ref.float()).abs().max()) < 3e-5 * float(z_ref.abs().max())
+    assert float((f.cpu() - F.gelu(z_ref).float()).abs().max()) < 3e-5 * float(z_ref.abs().max())
+    # (b) rows ((b XY + xy) S + s) with B = 1: slice s = row % S
+    S = 5 if M % 5 == 0 else 2
+    XY = M // S
+    scale = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25][:S])
+    out = ops.linear_stream(xd, sp, bd, 0, residual=rd, row_scale=be.to(scale), XY=XY, S=S)
+    ref = r.double() + scale.double()[torch.arange(M) % S][:, None] * z_ref
+    assert float((out.cpu() - ref.float()).abs().max()) < 3e-5 * float(ref.abs().max())
+    # (c)
+    aux = paramgen.tensor("se.a", (M, N), 5, 1.5)
+    a64 = aux.double()
+    gelu_grad = 0.5 * (1 + torch.erf(a64 / 2 ** 0.5)) + a64 * torch.exp(-0.5 * a64 * a64) / (2 * torch.pi) ** 0.5
+    out = ops.linear_stream(xd, sp, bd, 3, aux=be.to(aux))
+    ref = z_ref * gelu_grad
+    assert float((out.cpu() - ref.float()).abs().max()) < 3e-5 * float(ref.abs().max())
+    # outside the envelope: K = 320
+    x2 = be.to(paramgen.tensor("se.x2", (M, 320), 6))
+    w2 = be.to(paramgen.tensor("se.w2", (N, 320), 7))
+    assert ops.linear_stream(x2, ops.split_bf16(w2), None, 0) is None
+
+
 def test_linear_head_major_output(be):
     """value projection written directly as [B, heads, Nq, dh] (what msda3d gathers from)"""
     B, Nq, E, H = 2, 150, 96, 8
