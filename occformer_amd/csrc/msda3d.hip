@@ -261,7 +261,11 @@ __global__ void __launch_bounds__(256) msda3d_bwd_kernel(
     const float* __restrict__ value, const float* __restrict__ offs, const float* __restrict__ logits,
     const float* __restrict__ dout, float* __restrict__ dvalue, float* __restrict__ doffs, float* __restrict__ dlogits,
     MsdaLevels lv, int B, int Nq, int H, int Dh, int P, int LPG, long off_ld, long lg_ld, long doff_ld, long dlg_ld,
-    int do_value) {
+    int do_value, float4* __restrict__ rec_w, uint32_t* __restrict__ rec_c) {
+  // rec_w / rec_c (optional): one RECORD per (b, q, h, sample) for the value-gradient tiles below -- softmax weight and
+  // the three trilinear fractions (float4), base cell as 3 x int16 (two words) -- so that the tiles, which visit every
+  // (query, head) once per sampled level AND channel pass (12 times at the 200-grid), do not repeat this pass's softmax
+  // and position arithmetic (~550 VALU instructions per visit against ~1 300 for the 32 corners' atomics)
   // XCD remap as in the forward: a contiguous eighth of the (batch, head, query) space per XCD, i.e. with 8 heads the
   // scatter of one head stays on one L2
   const long gid = (long)occf_xcd_remap(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
@@ -325,6 +329,14 @@ __global__ void __launch_bounds__(256) msda3d_bwd_kernel(
       const float tz = pz - fz, ty = py - fy, tx = px - fx;
       const int iz = (int)fz, iy = (int)fy, ix = (int)fx;
       const float a = w[i] * inv;
+      if (rec_w && live && sub == 0) {
+        const long si = ((long)(b * Nq + q) * H + h) * LP + i;
+        rec_w[si] = make_float4(a, tz, ty, tx);
+        const int cz = iz < -2 ? -2 : (iz > 32000 ? 32000 : iz), cy = iy < -2 ? -2 : (iy > 32000 ? 32000 : iy),
+                  cx = ix < -2 ? -2 : (ix > 32000 ? 32000 : ix);           // (beyond the grid either way: no valid corner)
+        rec_c[2 * si] = ((uint32_t)cz & 0xFFFFu) | ((uint32_t)cy << 16);
+        rec_c[2 * si + 1] = (uint32_t)cx & 0xFFFFu;
+      }
       const long kstride = HM ? Dh : E;
       const float* vbase = HM ? value + (((long)b * H + h) * Nv + lv.start[l]) * Dh + cv
                               : value + ((long)b * Nv + lv.start[l]) * E + h * Dh + cv;
@@ -451,7 +463,8 @@ template <int CPL>
 __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kernel(
     const float* __restrict__ offs, const float* __restrict__ logits, const float* __restrict__ dout,
     float* __restrict__ dvalue, float* __restrict__ scratch, const unsigned* __restrict__ absmax_bits, MsdaLevels lv,
-    MsdaTileCfg tc, int B, int Nq, int H, int Dh, int P, long off_ld, long lg_ld) {
+    MsdaTileCfg tc, int B, int Nq, int H, int Dh, int P, long off_ld, long lg_ld, const float4* __restrict__ rec_w,
+    const uint32_t* __restrict__ rec_c) {
   OCCF_DYN_SMEM(smem_raw);
   unsigned long long* tile = (unsigned long long*)smem_raw;
   const int NT = blockDim.x;
@@ -523,11 +536,13 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
     const float ry = ((float)qy + 0.5f) / (float)lv.Y[lq];
     const float rx = ((float)qx + 0.5f) / (float)lv.X[lq];
     const float* lg = logits + (long)(b * Nq + q) * lg_ld + h * LP;
-    float mx = -3.0e38f;
-    for (int i = 0; i < LP; ++i) mx = fmaxf(mx, lg[i]);
-    float sum = 0.f;
-    for (int i = 0; i < LP; ++i) sum += expf(lg[i] - mx);
-    const float inv = 1.0f / sum;
+    float mx = -3.0e38f, inv = 0.f;
+    if (!rec_w) {
+      for (int i = 0; i < LP; ++i) mx = fmaxf(mx, lg[i]);
+      float sum = 0.f;
+      for (int i = 0; i < LP; ++i) sum += expf(lg[i] - mx);
+      inv = 1.0f / sum;
+    }
     const float* of = offs + (long)(b * Nq + q) * off_ld + h * LP * 3;
     const float* gp = dout + (long)(b * Nq + q) * E + h * Dh + ch0 + sub * CPL;
     float gch[CPL];
@@ -535,16 +550,26 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
     for (int c = 0; c < CPL; ++c) gch[c] = gp[c];
     for (int k = 0; k < P; ++k) {
       const int i = ls * P + k;
-      const float lz = rz + of[i * 3 + 0] / (float)Zs;
-      const float ly = ry + of[i * 3 + 1] / (float)Ys;
-      const float lx = rx + of[i * 3 + 2] / (float)Xs;
-      const float pz = ((2.f * lz - 1.f + 1.f) * (float)Zs - 1.f) * 0.5f;
-      const float py = ((2.f * ly - 1.f + 1.f) * (float)Ys - 1.f) * 0.5f;
-      const float px = ((2.f * lx - 1.f + 1.f) * (float)Xs - 1.f) * 0.5f;
-      const float fz = floorf(pz), fy = floorf(py), fx = floorf(px);
-      const float tz = pz - fz, ty = py - fy, tx = px - fx;
-      const int iz = (int)fz, iy = (int)fy, ix = (int)fx;
-      const float a = expf(lg[i] - mx) * inv;
+      float tz, ty, tx, a;
+      int iz, iy, ix;
+      if (rec_w) {                                      // the gather pass's record of this sample (see msda3d_bwd_kernel)
+        const long si = ((long)(b * Nq + q) * H + h) * LP + i;
+        const float4 rw = rec_w[si];
+        const uint32_t c0 = rec_c[2 * si], c1 = rec_c[2 * si + 1];
+        a = rw.x; tz = rw.y; ty = rw.z; tx = rw.w;
+        iz = (int)(short)(c0 & 0xFFFFu); iy = (int)(short)(c0 >> 16); ix = (int)(short)(c1 & 0xFFFFu);
+      } else {
+        const float lz = rz + of[i * 3 + 0] / (float)Zs;
+        const float ly = ry + of[i * 3 + 1] / (float)Ys;
+        const float lx = rx + of[i * 3 + 2] / (float)Xs;
+        const float pz = ((2.f * lz - 1.f + 1.f) * (float)Zs - 1.f) * 0.5f;
+        const float py = ((2.f * ly - 1.f + 1.f) * (float)Ys - 1.f) * 0.5f;
+        const float px = ((2.f * lx - 1.f + 1.f) * (float)Xs - 1.f) * 0.5f;
+        const float fz = floorf(pz), fy = floorf(py), fx = floorf(px);
+        tz = pz - fz; ty = py - fy; tx = px - fx;
+        iz = (int)fz; iy = (int)fy; ix = (int)fx;
+        a = expf(lg[i] - mx) * inv;
+      }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const int cbx = c >> 2, cby = (c >> 1) & 1, cbz = c & 1;
@@ -671,6 +696,15 @@ static void msda_levels(const int32_t* level_shapes, int num_levels, MsdaLevels&
   total = start;
 }
 
+// OCCF_MSDA_RECORDS=1 (opt-in): the gather pass runs first and leaves per-sample records for the tiles.  Measured
+// r05s at the 200-grid: 2.259 against 2.312 ms per call -- the ~550 VALU instructions a tile visit saves are not what
+// bounds the tiles (nor were more channels per lane, r04m): the same-address LDS atomics of neighbouring queries are.
+static bool msda_records_on() {
+  const char* e = getenv("OCCF_MSDA_RECORDS");
+  return e && atoi(e) != 0;
+}
+static long msda_record_floats(int B, long Nq, int heads) { return msda_records_on() ? (long)B * Nq * heads * 16 * 6 : 0; }
+
 // floats of scratch for occf_msda3d_bwd (the largest level's region slabs; the levels run one after the other)
 extern "C" long occf_msda3d_bwd_workspace(const int32_t* level_shapes, int num_levels, int B, int heads, int head_dim) {
   if (num_levels <= 0 || num_levels > MSDA_MAX_LEVELS || (head_dim != 12 && head_dim != 24)) return 0;
@@ -684,7 +718,9 @@ extern "C" long occf_msda3d_bwd_workspace(const int32_t* level_shapes, int num_l
     const long n = msda_scratch_floats(lv, tc, B, heads);
     need = n > need ? n : need;
   }
-  return need + 4;                                       // + the max|dout| word
+  // + the per-sample records of the gather pass (float4 + two words per (b, q, h, sample); the sample count per head is
+  // not an argument here: the 16 the op admits) + the max|dout| word
+  return need + msda_record_floats(B, total, heads) + 4;
 }
 
 extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets, const float* attn_logits,
@@ -716,15 +752,63 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
     const char* e = getenv("OCCF_MSDA_TILED");
     return e ? atoi(e) : 1;
   }();
-  int do_value = 1;
+  float4* rec_w = nullptr;
+  uint32_t* rec_c = nullptr;
+  MsdaTileCfg cfgs[MSDA_MAX_LEVELS];
+  bool tiles = false;
   if (tiled_env && workspace && (head_dim == 12 || head_dim == 24)) {
-    MsdaTileCfg cfgs[MSDA_MAX_LEVELS];
     bool ok = true;
-    for (int l = 0; l < num_levels; ++l)
-      ok = ok && msda_tile_cfg(lv, l, head_dim, cfgs[l]) &&
-           msda_scratch_floats(lv, cfgs[l], B, heads) + 4 <= workspace_floats;
-    if (ok) {
-      do_value = 0;
+    long smax = 0;
+    for (int l = 0; l < num_levels; ++l) {
+      ok = ok && msda_tile_cfg(lv, l, head_dim, cfgs[l]);
+      if (ok) {
+        const long n = msda_scratch_floats(lv, cfgs[l], B, heads);
+        smax = n > smax ? n : smax;
+      }
+    }
+    tiles = ok && smax + 4 <= workspace_floats;
+    // (the gather pass runs FIRST either way; with OCCF_MSDA_RECORDS=1 it leaves its per-sample records for the tiles)
+    const long rec = msda_record_floats(B, Nq, heads);
+    if (tiles && rec > 0 && smax + rec + 4 <= workspace_floats && smax % 4 == 0) {
+      rec_w = (float4*)(workspace + smax);
+      rec_c = (uint32_t*)(workspace + smax + (long)B * Nq * heads * 16 * 4);
+    }
+  }
+  int lpg = head_dim % 8 == 0 ? 8 : head_dim % 4 == 0 ? 4 : head_dim % 2 == 0 ? 2 : 1;
+  int vec = head_dim / lpg;
+  while (vec > 6 && lpg < 8) { lpg *= 2; vec = head_dim / lpg; }
+  if (head_dim % lpg != 0 || vec > 6) { lpg = 1; vec = head_dim; }
+  // Without the scatter (value gradient taken by the LDS tiles) this pass is a pure gather + dot product like the
+  // forward, and the forward's split serves it best: 12 channels per lane, i.e. the softmax / position / corner-weight
+  // arithmetic of a (query, head) is repeated by 2 lanes instead of 8 (measured r03c; OCCF_MSDA_BWD_VEC12=0 restores
+  // the narrow split, which the atomics of the scatter want: one contiguous head row per corner)
+  static const int vec12_env = [] {
+    const char* e = getenv("OCCF_MSDA_BWD_VEC12");
+    return e ? atoi(e) : 1;
+  }();
+  if (tiles && vec12_env && head_dim % 12 == 0 && (heads * head_dim) % 4 == 0) { vec = 12; lpg = head_dim / 12; }
+  const long total = (long)B * Nq * heads * lpg;
+  const int gather_do_value = tiles ? 0 : 1;
+#define OCCF_MSDB_LAUNCH(V_, HM_)                                                                                   \
+  hipLaunchKernelGGL((msda3d_bwd_kernel<V_, 16, HM_>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,        \
+                     sampling_offsets, attn_logits, dout, dvalue, doffsets, dlogits, lv, B, Nq, heads, head_dim,    \
+                     num_points, lpg, off_ld, lg_ld, doff_ld, dlg_ld, gather_do_value, rec_w, rec_c)
+#define OCCF_MSDB_VEC(HM_)                     \
+  switch (vec) {                               \
+    case 1: OCCF_MSDB_LAUNCH(1, HM_); break;   \
+    case 2: OCCF_MSDB_LAUNCH(2, HM_); break;   \
+    case 3: OCCF_MSDB_LAUNCH(3, HM_); break;   \
+    case 4: OCCF_MSDB_LAUNCH(4, HM_); break;   \
+    case 5: OCCF_MSDB_LAUNCH(5, HM_); break;   \
+    case 6: OCCF_MSDB_LAUNCH(6, HM_); break;   \
+    case 12: OCCF_MSDB_LAUNCH(12, HM_); break; \
+    default: return OCCF_ESHAPE;               \
+  }
+  if (value_head_major) { OCCF_MSDB_VEC(true) } else { OCCF_MSDB_VEC(false) }
+#undef OCCF_MSDB_VEC
+#undef OCCF_MSDB_LAUNCH
+  if (tiles) {
+    {
       unsigned* absmax = (unsigned*)(workspace + workspace_floats - 4);
       hipLaunchKernelGGL(msda_zero_word_kernel, dim3(1), dim3(1), 0, st, absmax);
       hipLaunchKernelGGL(msda_absmax_kernel, dim3(512), dim3(256), 0, st, dout, (long)B * Nq * heads * head_dim, absmax);
@@ -766,47 +850,17 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
         }
         if (tc.cpl == 6)
           hipLaunchKernelGGL(msda3d_bwd_value_tile_kernel<6>, grid, dim3(threads), lds, st, sampling_offsets, attn_logits,
-                             dout, dvalue, workspace, absmax, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
+                             dout, dvalue, workspace, absmax, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld,
+                             (const float4*)rec_w, (const uint32_t*)rec_c);
         else
           hipLaunchKernelGGL(msda3d_bwd_value_tile_kernel<3>, grid, dim3(threads), lds, st, sampling_offsets, attn_logits,
-                             dout, dvalue, workspace, absmax, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld);
-        const long total = (long)B * heads * lv.X[l] * lv.Y[l] * lv.Z[l] * head_dim;
-        hipLaunchKernelGGL(msda3d_bwd_value_gather_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, workspace,
+                             dout, dvalue, workspace, absmax, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld,
+                             (const float4*)rec_w, (const uint32_t*)rec_c);
+        const long cells = (long)B * heads * lv.X[l] * lv.Y[l] * lv.Z[l] * head_dim;
+        hipLaunchKernelGGL(msda3d_bwd_value_gather_kernel, dim3(occf_cdiv(cells, 256)), dim3(256), 0, st, workspace,
                            dvalue, lv, tc, B, heads, head_dim);
       }
     }
   }
-  int lpg = head_dim % 8 == 0 ? 8 : head_dim % 4 == 0 ? 4 : head_dim % 2 == 0 ? 2 : 1;
-  int vec = head_dim / lpg;
-  while (vec > 6 && lpg < 8) { lpg *= 2; vec = head_dim / lpg; }
-  if (head_dim % lpg != 0 || vec > 6) { lpg = 1; vec = head_dim; }
-  // Without the scatter (value gradient taken by the LDS tiles above) this pass is a pure gather + dot product like the
-  // forward, and the forward's split serves it best: 12 channels per lane, i.e. the softmax / position / corner-weight
-  // arithmetic of a (query, head) is repeated by 2 lanes instead of 8 (measured r03c; OCCF_MSDA_BWD_VEC12=0 restores
-  // the narrow split, which the atomics of the scatter want: one contiguous head row per corner)
-  static const int vec12_env = [] {
-    const char* e = getenv("OCCF_MSDA_BWD_VEC12");
-    return e ? atoi(e) : 1;
-  }();
-  if (!do_value && vec12_env && head_dim % 12 == 0 && (heads * head_dim) % 4 == 0) { vec = 12; lpg = head_dim / 12; }
-  const long total = (long)B * Nq * heads * lpg;
-#define OCCF_MSDB_LAUNCH(V_, HM_)                                                                                   \
-  hipLaunchKernelGGL((msda3d_bwd_kernel<V_, 16, HM_>), dim3(occf_cdiv(total, 256)), dim3(256), 0, st, value,        \
-                     sampling_offsets, attn_logits, dout, dvalue, doffsets, dlogits, lv, B, Nq, heads, head_dim,    \
-                     num_points, lpg, off_ld, lg_ld, doff_ld, dlg_ld, do_value)
-#define OCCF_MSDB_VEC(HM_)                     \
-  switch (vec) {                               \
-    case 1: OCCF_MSDB_LAUNCH(1, HM_); break;   \
-    case 2: OCCF_MSDB_LAUNCH(2, HM_); break;   \
-    case 3: OCCF_MSDB_LAUNCH(3, HM_); break;   \
-    case 4: OCCF_MSDB_LAUNCH(4, HM_); break;   \
-    case 5: OCCF_MSDB_LAUNCH(5, HM_); break;   \
-    case 6: OCCF_MSDB_LAUNCH(6, HM_); break;   \
-    case 12: OCCF_MSDB_LAUNCH(12, HM_); break; \
-    default: return OCCF_ESHAPE;               \
-  }
-  if (value_head_major) { OCCF_MSDB_VEC(true) } else { OCCF_MSDB_VEC(false) }
-#undef OCCF_MSDB_VEC
-#undef OCCF_MSDB_LAUNCH
   OCCF_LAUNCH_CHECK();
 }

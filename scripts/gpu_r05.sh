@@ -227,5 +227,9 @@ timeout 200 python bench.py --mode forward --steps 20 --warmup 3 --no-cpu-baseli
 python -c "
 import json; f=json.load(open('$Q/bench_fwd.json')); print('forward', round(f['value'],2), 'samples/s', round(f['ms_per_step'],2), 'ms; roofline', round(f['roofline']['frac'],4), 'traffic', f['roofline']['traffic'], f['roofline']['traffic_source'], f['roofline']['kernel'][:52])"
 ;;
+s)  # round 5, visit s: msda value-gradient tiles with / without the gather pass's per-sample records
+for v in 0 1; do echo -n "OCCF_MSDA_RECORDS=$v: "; OCCF_MSDA_RECORDS=$v timeout 120 python scripts/bwd_probe.py msda 2>/dev/null | tail -1; done | tee $O/r05s_msda_records.txt
+timeout 300 python -m pytest tests/test_bwd_ops.py tests/test_full_size_gpu.py -m gpu -q -p no:cacheprovider -k "msda" 2>&1 | tail -2
+;;
 *) echo "usage: $0 <stage>"; exit 2;;
 esac

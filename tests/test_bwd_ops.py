@@ -352,8 +352,10 @@ def test_masked_attention_backward(be, Q, L, heads, masked):
                                             # levels too large for one LDS tile: the tiled value-gradient path with
                                             # margins, and offsets (scale 2 x 4 cells) that leave the region -> fallback
                                             (24, 2, [(11, 10, 2), (22, 20, 4), (44, 40, 8)])])
-def test_msda3d_backward(be, E, heads, shapes):
+@pytest.mark.parametrize("records", ["1", "0"])      # the tiles read the gather pass's per-sample records / recompute them
+def test_msda3d_backward(be, monkeypatch, E, heads, shapes, records):
     from oracle import occformer_ref as O
+    monkeypatch.setenv("OCCF_MSDA_RECORDS", records)
     B, P = 2, 4
     L = len(shapes)
     Nq = sum(x * y * z for x, y, z in shapes)
