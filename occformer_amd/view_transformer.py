@@ -211,7 +211,13 @@ class _SE(nn.Module):
         self.conv_expand = nn.Conv2d(c, c, 1)
 
     def forward(self, x, x_se):
-        return x * torch.sigmoid(self.conv_expand(_relu(self.conv_reduce(x_se))))
+        # the two 1 x 1 convolutions act on ONE vector per camera ([BN, C, 1, 1]): as linears on [BN, C] -- the same
+        # arithmetic, and the weight gradients come back in the parameters' own strides (as convolutions ATen returned
+        # them channels_last, which DDP's bucket views refuse: a copy per gradient and step, r05v)
+        v = x_se.flatten(1)
+        h = _relu(F.linear(v, self.conv_reduce.weight.flatten(1), self.conv_reduce.bias))
+        g = torch.sigmoid(F.linear(h, self.conv_expand.weight.flatten(1), self.conv_expand.bias))
+        return x * g[:, :, None, None]
 
     def forward_cl(self, x_cl, x_se):
         """x_cl [BN, H, W, 1, C]; x_se [BN, C, 1, 1] (the gate is a per-camera channel vector)"""
