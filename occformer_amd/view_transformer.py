@@ -163,7 +163,8 @@ class _ImageASPP(nn.Module):
 
     def forward(self, x):
         gp = self.global_avg_pool
-        g = gp[1](gp[0](x))
+        # (the 1 x 1 convolution of the pooled [BN, C, 1, 1] vector as a linear: see _SE.forward)
+        g = F.linear(gp[0](x).flatten(1), gp[1].weight.flatten(1), gp[1].bias)[:, :, None, None]
         if self.training and g.numel() == g.shape[1] and not is_synced(gp[2]):
             # one pooled value per channel on this rank (SemanticKITTI: batch 1, one camera): batch statistics do
             # not exist -- the reference gets them from SyncBatchNorm over its 8 ranks (here:
