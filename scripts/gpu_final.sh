@@ -43,13 +43,15 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fwd 
 cd $R
 python scripts/summarize_prof.py $O/prof_fwd > $O/fwd_kernel_stats.txt 2>&1 ; head -24 $O/fwd_kernel_stats.txt | cut -c1-150
 find $O/prof_fwd -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
-echo "== rocprof PMC passes (HBM traffic of the training step)"
+echo "== rocprof PMC passes (HBM traffic of the halo convolutions on these kernel sources: scripts/conv_probe.py)"
+# (round 5: the whole bench under --pmc outgrew any sensible time limit -- it also builds and runs the from-images
+# detector now -- so the counters are collected on the roofline kernel's own probe; scripts/gpu_r05.sh stage q)
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_$c.log 2>&1 ; echo "pmc $c rc=$?"
+  timeout 170 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/scripts/conv_probe.py 2 > $O/pmc_$c.log 2>&1 ; echo "pmc $c rc=$?"
 done
 cd $R
-python scripts/summarize_pmc.py $O $O/pmc_traffic.json > $O/pmc_summary.txt 2>&1 ; head -24 $O/pmc_summary.txt
+python scripts/summarize_pmc.py $O $O/pmc_traffic.json > $O/pmc_summary.txt 2>&1 ; head -8 $O/pmc_summary.txt
 find $O -name "*counter_collection.csv" -size +20M -delete 2>/dev/null
 find $O/prof -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
 du -sh $O
