@@ -440,7 +440,9 @@ int occf_point_loss_rows_bwd(const float* logits, const float* targets, const fl
                              int R, long P, void* stream);
 
 /* Weight (and bias) gradient of occf_linear_*: dw[N, K] = dy[M, N]^T x[M, K], dbias[N] = column sums of dy (NULL
- * to skip); bf16 matrix cores with terms = 3 (fp32-class) or 1, M split into slabs reduced in fixed order.
+ * to skip); bf16 matrix cores with terms = 3 (fp32-class) or 1, or -- terms = 2 -- TWO fp16-piece products per
+ * product (dy as ONE fp16 piece after a per-tensor power-of-two scale taken from max |dy| on the device, x as fp16
+ * (hi, lo): ~2^-12 per dy element, weight gradients are leaf quantities); M split into slabs reduced in fixed order.
  * workspace: occf_linear_wgrad_workspace floats (0: none needed).  Small or odd shapes (M <= 1024, N or K not a
  * multiple of 4) run an exact fp32 kernel. */
 long occf_linear_wgrad_workspace(long M, int N, int K);

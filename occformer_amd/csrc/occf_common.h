@@ -12,6 +12,7 @@ typedef emu_bf16x8 bf16x8;
 #define occf_mfma_f32_32x32x2(a, b, c) emu_mfma_f32_32x32x2f32(a, b, c)
 #define occf_mfma_f32_16x16x4(a, b, c) emu_mfma_f32_16x16x4f32(a, b, c)
 #define occf_mfma_bf16_32x32x16(a, b, c) emu_mfma_f32_32x32x16_bf16(a, b, c)
+#define occf_mfma_f16_32x32x16(a, b, c) emu_mfma_f32_32x32x16_f16(a, b, c)
 static inline float occf_fmul(float a, float b) {
   volatile float r = a * b;
   return r;
@@ -36,6 +37,10 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 #define occf_mfma_f32_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
 #define occf_mfma_f32_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
 #define occf_mfma_bf16_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+// the same tile on fp16 elements (operands travel as the 16-byte bit patterns bf16x8 carries)
+typedef _Float16 occf_f16x8 __attribute__((ext_vector_type(8)));
+#define occf_mfma_f16_32x32x16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(occf_f16x8, a), __builtin_bit_cast(occf_f16x8, b), c, 0, 0, 0)
 // un-contracted fp32 ops: the reference's arithmetic is mul-then-add, never fma
 __device__ __forceinline__ float occf_fmul(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float occf_fadd(float a, float b) { return __fadd_rn(a, b); }
@@ -82,6 +87,44 @@ __device__ __forceinline__
 void occf_bf16_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
   hi = occf_bf16_pack2(a, b);
   lo = occf_bf16_pack2(a - occf_u2f(hi << 16), b - occf_u2f(hi & 0xFFFF0000u));
+}
+
+// ---- fp16 pieces (11 significant bits) for the two-product weight gradients: x = hi + lo with both halves fp16
+// (22 bits; |x| is an activation, far inside the fp16 range), the other operand ONE fp16 piece after a per-tensor
+// power-of-two scale (occf_f16_scale_bits).  Round to nearest even in both builds.
+#ifdef OCCF_EMU
+static inline uint32_t occf_f16_pack2(float a, float b) {
+  return (uint32_t)emu_f32_to_f16(a) | ((uint32_t)emu_f32_to_f16(b) << 16);
+}
+static inline float occf_f16_lo_f32(uint32_t p) { return emu_f16_to_f32((uint16_t)(p & 0xFFFFu)); }
+static inline float occf_f16_hi_f32(uint32_t p) { return emu_f16_to_f32((uint16_t)(p >> 16)); }
+static inline
+#else
+typedef _Float16 occf_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t occf_f16_pack2(float a, float b) {
+  const occf_f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, occf_f16x2));
+}
+__device__ __forceinline__ float occf_f16_lo_f32(uint32_t p) { return (float)__builtin_bit_cast(occf_f16x2, p)[0]; }
+__device__ __forceinline__ float occf_f16_hi_f32(uint32_t p) { return (float)__builtin_bit_cast(occf_f16x2, p)[1]; }
+__device__ __forceinline__
+#endif
+void occf_f16_split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = occf_f16_pack2(a, b);
+  lo = occf_f16_pack2(a - occf_f16_lo_f32(hi), b - occf_f16_hi_f32(hi));
+}
+// power-of-two scale that brings a tensor of absolute maximum `amax_bits` (fp32 bit pattern, >= 0) to [2^14, 2^15):
+// returns the scale's bit pattern and, through `inv`, that of its reciprocal.  Elements below amax * 2^-29 flush.
+#ifdef OCCF_EMU
+static inline
+#else
+__device__ __forceinline__
+#endif
+uint32_t occf_f16_scale_bits(uint32_t amax_bits, uint32_t& inv) {
+  uint32_t e = (amax_bits >> 23) & 0xFFu;                 // biased exponent of the maximum
+  e = e < 15u ? 15u : (e > 254u ? 254u : e);
+  inv = (e - 14u) << 23;                                  // 2^(e - 127 - 14)
+  return (268u - e) << 23;                                // 2^(14 - (e - 127))
 }
 
 // scheduling fence: keeps the instruction groups on either side in program order (used where the

@@ -54,6 +54,9 @@ struct WgArgs {
   // the 192 -> 192 convolution (PMC FETCH_SIZE), i.e. the kernel ran at the HBM roof, not the MFMA roof.
   int xcd_tiles;
   int n_slabs;
+  // TERMS == 2 (two fp16-piece products): scale[0] = bit pattern of max |dY| (wg_absmax_kernel); dY enters as ONE fp16
+  // piece of dY * 2^k, X as fp16 (hi, lo); the partial sums leave multiplied by 2^-k
+  const uint32_t* scale;
   int bc;              // channel tile width (128 = 128-wide tiles + remainder tile, 64 = uniform 64-wide tiles)
   int mix;             // remainder tiles of <= 64 columns run as 64-wide tiles (both dimensions)
   WgGeom g;
@@ -257,13 +260,13 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& p, wg_u4* __restrict__ 
         w.x = wg_pack_lo(br[0 * 4 + d], br[1 * 4 + d]); w.y = wg_pack_lo(br[2 * 4 + d], br[3 * 4 + d]);
         w.z = wg_pack_lo(br[4 * 4 + d], br[5 * 4 + d]); w.w = wg_pack_lo(br[6 * 4 + d], br[7 * 4 + d]);
       }
-      if (TERMS == 3 || p_half == 0) {
-        if (pa_act) Ad[pa_rg * TN + wg_swz(pa_c8 * 8 + e, p.swz)] = v;
-        if (pb_act) Bd[pb_rg * BC + wg_swz(pb_c8 * 8 + e, p.swz)] = w;
-      }
+      if ((TERMS == 3 || p_half == 0) && pa_act) Ad[pa_rg * TN + wg_swz(pa_c8 * 8 + e, p.swz)] = v;
+      if ((TERMS >= 2 || p_half == 0) && pb_act) Bd[pb_rg * BC + wg_swz(pb_c8 * 8 + e, p.swz)] = w;
     }
   };
 
+  uint32_t inv_bits = 0x3F800000u;
+  const float f16_scale = TERMS == 2 ? occf_u2f(occf_f16_scale_bits(p.scale[0], inv_bits)) : 1.0f;
   float4 ra[RPA], rb[RPT];
   auto load_chunk = [&](int ck) __attribute__((always_inline)) {
     const long mb = m_begin + (long)ck * 64;
@@ -335,7 +338,14 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& p, wg_u4* __restrict__ 
       for (int e = 0; e < 4; ++e) {
         uint32_t hh[RPA / 2], ll[RPA / 2];
 #pragma unroll
-        for (int j = 0; j < RPA; j += 2) occf_bf16_split2(cx[e][j], cx[e][j + 1], hh[j / 2], ll[j / 2]);
+        for (int j = 0; j < RPA; j += 2) {
+          if (TERMS == 2) {
+            hh[j / 2] = occf_f16_pack2(cx[e][j] * f16_scale, cx[e][j + 1] * f16_scale);
+            ll[j / 2] = 0u;
+          } else {
+            occf_bf16_split2(cx[e][j], cx[e][j + 1], hh[j / 2], ll[j / 2]);
+          }
+        }
         if (RPA == 8) {
           const int off = a_rg * TN + wg_swz(a_c4 * 4 + e, p.swz);
           wg_u4 h, l;
@@ -366,21 +376,24 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& p, wg_u4* __restrict__ 
       for (int e = 0; e < 4; ++e) {
         uint32_t hh[RPT / 2], ll[RPT / 2];
 #pragma unroll
-        for (int j = 0; j < RPT; j += 2) occf_bf16_split2(cx[e][j], cx[e][j + 1], hh[j / 2], ll[j / 2]);
+        for (int j = 0; j < RPT; j += 2) {
+          if (TERMS == 2) occf_f16_split2(cx[e][j], cx[e][j + 1], hh[j / 2], ll[j / 2]);
+          else occf_bf16_split2(cx[e][j], cx[e][j + 1], hh[j / 2], ll[j / 2]);
+        }
         if (RPT == 8) {
           const int off = b_rg * BC + wg_swz(b_c4 * 4 + e, p.swz);
           wg_u4 h, l;
           h.x = hh[0]; h.y = hh[1]; h.z = hh[RPT / 2 - 2]; h.w = hh[RPT / 2 - 1];
           l.x = ll[0]; l.y = ll[1]; l.z = ll[RPT / 2 - 2]; l.w = ll[RPT / 2 - 1];
           Bh[off] = h;
-          if (TERMS == 3) Bl[off] = l;
+          if (TERMS >= 2) Bl[off] = l;
         } else {
           const int off = (b_rg >> 1) * BC + wg_swz(b_c4 * 4 + e, p.swz);
           uint32_t* dh = (uint32_t*)(Bh + off) + (b_rg & 1) * 2;
           uint32_t* dl = (uint32_t*)(Bl + off) + (b_rg & 1) * 2;
           dh[0] = hh[0];
           dh[1] = hh[1];
-          if (TERMS == 3) { dl[0] = ll[0]; dl[1] = ll[1]; }
+          if (TERMS >= 2) { dl[0] = ll[0]; dl[1] = ll[1]; }
         }
       }
     }
@@ -409,12 +422,17 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& p, wg_u4* __restrict__ 
 #pragma unroll
       for (int j = 0; j < TC; ++j) {
         bh[j] = frag(Bh, BC, wn * (BC / 2) + j * 32 + li, ks);
-        if (TERMS == 3) bl[j] = frag(Bl, BC, wn * (BC / 2) + j * 32 + li, ks);
+        if (TERMS >= 2) bl[j] = frag(Bl, BC, wn * (BC / 2) + j * 32 + li, ks);
       }
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TC; ++j) {
+          if (TERMS == 2) {
+            acc[i][j] = occf_mfma_f16_32x32x16(ah[i], bl[j], acc[i][j]);
+            acc[i][j] = occf_mfma_f16_32x32x16(ah[i], bh[j], acc[i][j]);
+            continue;
+          }
           if (TERMS == 3) {
             acc[i][j] = occf_mfma_bf16_32x32x16(al[i], bh[j], acc[i][j]);
             acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bl[j], acc[i][j]);
@@ -447,6 +465,7 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& p, wg_u4* __restrict__ 
   // ---- epilogue: raw partial sums of this M-slice
   const int Kt = p.taps * p.Cin;
   float* o = p.out + (long)slab * p.N * Kt;
+  const float unscale = occf_u2f(inv_bits);                     // (TERMS == 2: 2^-k, exact; else 1)
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -456,7 +475,7 @@ __device__ __forceinline__ void wgrad_body(const WgArgs& p, wg_u4* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wm * (TN / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (n < p.N) o[(long)n * Kt + (long)tap * p.Cin + c] = acc[i][j][r];
+        if (n < p.N) o[(long)n * Kt + (long)tap * p.Cin + c] = TERMS == 2 ? acc[i][j][r] * unscale : acc[i][j][r];
       }
     }
   if (do_bias) {
@@ -636,6 +655,40 @@ __global__ void __launch_bounds__(256) wgrad_small_tile_kernel(const float* __re
   }
 }
 
+// max |x| of a [M][N] tensor (row stride ld) as an fp32 BIT PATTERN in *slot (zeroed beforehand, same stream):
+// non-negative floats order like their bit patterns, so an integer atomic max is exact and order-independent --
+// deterministic.  Feeds the power-of-two scale of the fp16 weight-gradient operands (occf_f16_scale_bits).
+__global__ void __launch_bounds__(256) wg_absmax_kernel(const float* __restrict__ x, long M, int N4, long ld,
+                                                        uint32_t* __restrict__ slot) {
+  const long total = M * N4;
+  uint32_t m = 0u;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = ld == (long)N4 * 4 ? 0 : i / N4;
+    const float4 v = *(const float4*)(ld == (long)N4 * 4 ? x + i * 4 : x + r * ld + (i - r * N4) * 4);
+    const uint32_t a = occf_f2u(v.x) & 0x7FFFFFFFu, b = occf_f2u(v.y) & 0x7FFFFFFFu, c = occf_f2u(v.z) & 0x7FFFFFFFu,
+                   d = occf_f2u(v.w) & 0x7FFFFFFFu;
+    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d, q = ab > cd ? ab : cd;
+    m = q > m ? q : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax((int*)slot, (int)m);   // (bit patterns < 2^31: signed order = unsigned order)
+}
+static void wg_absmax(const float* x, long M, int N, long ld, uint32_t* slot, hipStream_t st) {
+#ifndef OCCF_EMU
+  (void)hipMemsetAsync(slot, 0, 8, st);
+#else
+  memset(slot, 0, 8);
+#endif
+  const long total = M * (N / 4);
+  long blocks = (total + 256 * 8 - 1) / (256 * 8);
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(wg_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, M, N / 4, ld, slot);
+}
+
 #include "wgrad_g8.h"
 
 static int wg_mix() {
@@ -732,12 +785,15 @@ static int wg_launch(WgArgs a, float* dW, float* db, float* workspace, long work
   const bool pre = a.dYh != nullptr;
   if (pre && a.zfast) {
     if (terms == 3) hipLaunchKernelGGL((wgrad_kernel<3, true, true>), grid, dim3(256), 0, st, a);
+    else if (terms == 2) hipLaunchKernelGGL((wgrad_kernel<2, true, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<1, true, true>), grid, dim3(256), 0, st, a);
   } else if (pre) {
     if (terms == 3) hipLaunchKernelGGL((wgrad_kernel<3, true, false>), grid, dim3(256), 0, st, a);
+    else if (terms == 2) hipLaunchKernelGGL((wgrad_kernel<2, true, false>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<1, true, false>), grid, dim3(256), 0, st, a);
   } else {
     if (terms == 3) hipLaunchKernelGGL((wgrad_kernel<3, false, false>), grid, dim3(256), 0, st, a);
+    else if (terms == 2) hipLaunchKernelGGL((wgrad_kernel<2, false, false>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_kernel<1, false, false>), grid, dim3(256), 0, st, a);
   }
   if (S > 1) {
@@ -748,16 +804,17 @@ static int wg_launch(WgArgs a, float* dW, float* db, float* workspace, long work
   return (int)hipGetLastError();
 }
 
+#define WG_SCALE_SLOT 16     // floats kept at the END of every workspace for the fp16 scale slot (terms == 2)
 extern "C" long occf_linear_wgrad_workspace(long M, int N, int K) {
   if (M <= 1024 || N % 4 || K % 4) return 0;
-  return wg_workspace(M, N, K, 1);
+  return wg_workspace(M, N, K, 1) + WG_SCALE_SLOT;
 }
 
 extern "C" int occf_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias, float* workspace,
                                  long workspace_floats, long M, int N, int K, long ldy, long ldx, int terms,
                                  void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return OCCF_EINVAL;
-  if (terms != 1 && terms != 3) return OCCF_EINVAL;
+  if (terms != 1 && terms != 2 && terms != 3) return OCCF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (M <= 1024 || N % 4 || K % 4 || ldy % 4 || ldx % 4) {
     if (M > 65536) return OCCF_ESHAPE;
@@ -773,6 +830,15 @@ extern "C" int occf_linear_wgrad(const float* dy, const float* x, float* dw, flo
   }
   WgArgs a = {};
   a.dY = dy; a.X = x; a.M = M; a.N = N; a.Cin = K; a.taps = 1; a.ldy = ldy; a.ldx = ldx; a.conv = 0;
+  if (terms == 2) {
+    // two fp16-piece products: dy * 2^k in ONE piece (k from max |dy|, one more read of dy), x in (hi, lo)
+    if (!workspace || workspace_floats < WG_SCALE_SLOT) terms = 3;
+    else {
+      workspace_floats -= WG_SCALE_SLOT;
+      a.scale = (const uint32_t*)(workspace + workspace_floats);
+      wg_absmax(dy, M, N, ldy, (uint32_t*)a.scale, st);
+    }
+  }
   return wg_launch(a, dw, dbias, workspace, workspace_floats, terms, st);
 }
 
@@ -783,6 +849,25 @@ __global__ void __launch_bounds__(256) wg_split_kernel(const float* __restrict__
   if (i >= n2) return;
   uint32_t h, l;
   occf_bf16_split2(x[2 * i], x[2 * i + 1], h, l);
+  ((uint32_t*)hi)[i] = h;
+  ((uint32_t*)lo)[i] = l;
+}
+
+// the fp16 forms (terms == 2): y = f16(x * 2^k) with k from scale[0] (no lo array); (hi, lo) = fp16 halves of x
+__global__ void __launch_bounds__(256) wg_split_f16_y_kernel(const float* __restrict__ x, uint16_t* __restrict__ hi,
+                                                             long n2, const uint32_t* __restrict__ scale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n2) return;
+  uint32_t inv;
+  const float sc = occf_u2f(occf_f16_scale_bits(scale[0], inv));
+  ((uint32_t*)hi)[i] = occf_f16_pack2(x[2 * i] * sc, x[2 * i + 1] * sc);
+}
+__global__ void __launch_bounds__(256) wg_split_f16_x_kernel(const float* __restrict__ x, uint16_t* __restrict__ hi,
+                                                             uint16_t* __restrict__ lo, long n2) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n2) return;
+  uint32_t h, l;
+  occf_f16_split2(x[2 * i], x[2 * i + 1], h, l);
   ((uint32_t*)hi)[i] = h;
   ((uint32_t*)lo)[i] = l;
 }
@@ -804,9 +889,10 @@ extern "C" long occf_conv3d_wgrad_workspace(int B, int Xi, int Yi, int Zi, int C
   const long M = (long)B * Xo * Yo * Zo, nx = (long)B * Xi * Yi * Zi * Cin, ny = M * Cout;
   if (wg_presplit_ok(Cin, Cout, kX * kY * kZ))        // bf16 (hi, lo) copies of dy and x: 4 bytes per element
     need += ny + nx;
+  need += WG_SCALE_SLOT;
   if (Xo > 0 && Yo > 0 && Zo == Zi && wg8_eligible(Zi, Cin, Cout, kX, kY, kZ, stride, dil, pad_z, M, nx, ny)) {
     const long g8 = wg8_workspace(B * Xo, Yo, Zi / 8, Cout, Cin, kX * kY * kZ, nx, ny);  // x in three z-shifted copies
-    if (g8 > need) need = g8;
+    if (g8 + WG_SCALE_SLOT > need) need = g8 + WG_SCALE_SLOT;
   }
   return need;
 }
@@ -817,7 +903,7 @@ extern "C" int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapm
                                  long in_sx, long in_sy, long in_sz, int terms, void* stream) {
   if (B <= 0 || Cin % 4 || Cout % 4 || stride <= 0 || dil <= 0) return OCCF_ESHAPE;
   if (in_sb % 4 || in_sx % 4 || in_sy % 4 || in_sz % 4) return OCCF_ESHAPE;
-  if (terms != 1 && terms != 3) return OCCF_EINVAL;
+  if (terms != 1 && terms != 2 && terms != 3) return OCCF_EINVAL;
   WgArgs a = {};
   WgGeom& g = a.g;
   g.B = B; g.Xi = Xi; g.Yi = Yi; g.Zi = Zi; g.kX = kX; g.kY = kY; g.kZ = kZ; g.stride = stride; g.dil = dil;
@@ -848,10 +934,22 @@ extern "C" int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapm
     uint16_t* xl = xh + 3 * nx;
     const int ZG = Zi / 8;
     const long cols = (long)B * Xi * Yi;
-    hipLaunchKernelGGL(wg8_split_y_kernel, dim3(occf_cdiv((a.M / 8) * Cout, 256)), dim3(256), 0, st, dy,
-                       (long)Cout, a.M / 8, Cout, (wg_u4*)yh, (wg_u4*)yl);
-    hipLaunchKernelGGL(wg8_split_x_kernel, dim3(occf_cdiv(cols * ZG * Cin, 256)), dim3(256), 0, st, x, cols, ZG,
-                       Cin, (wg_u4*)xh, (wg_u4*)xl, cols * ZG * Cin);
+    // terms == 2: ONE fp16 piece of dy * 2^k (k from max |dy|) times the fp16 (hi, lo) halves of x -- two products per
+    // product; the scale slot lives in the (then unused) dY-lo array
+    uint32_t* scale = (uint32_t*)yl;
+    if (terms == 2) {
+      wg_absmax(dy, a.M, Cout, (long)Cout, scale, st);
+      hipLaunchKernelGGL(wg8_split_y_kernel<true>, dim3(occf_cdiv((a.M / 8) * Cout, 256)), dim3(256), 0, st, dy,
+                         (long)Cout, a.M / 8, Cout, (wg_u4*)yh, (wg_u4*)yl, scale);
+      hipLaunchKernelGGL(wg8_split_x_kernel<true>, dim3(occf_cdiv(cols * ZG * Cin, 256)), dim3(256), 0, st, x, cols, ZG,
+                         Cin, (wg_u4*)xh, (wg_u4*)xl, cols * ZG * Cin);
+    } else {
+      hipLaunchKernelGGL(wg8_split_y_kernel<false>, dim3(occf_cdiv((a.M / 8) * Cout, 256)), dim3(256), 0, st, dy,
+                         (long)Cout, a.M / 8, Cout, (wg_u4*)yh, (wg_u4*)yl, scale);
+      hipLaunchKernelGGL(wg8_split_x_kernel<false>, dim3(occf_cdiv(cols * ZG * Cin, 256)), dim3(256), 0, st, x, cols, ZG,
+                         Cin, (wg_u4*)xh, (wg_u4*)xl, cols * ZG * Cin);
+    }
+    q.scale = scale;
     q.Yh = yh; q.Yl = yl; q.Xh = xh; q.Xl = xl; q.out = part; q.xcopy_elems = nx;
     q.n_strips = gm.n_strips; q.strip_w = gm.strip_w; q.seg_planes = gm.seg_planes; q.planes = B * g.Xo;
     q.slabs_per_xcd = (S + 7) / 8;
@@ -866,20 +964,35 @@ extern "C" int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapm
         if (!sn[i].count || !sc[j].count) continue;
         q.n_base = sn[i].base; q.tn_count = sn[i].count; q.c_base = sc[j].base; q.tc_count = sc[j].count;
         q.tiles = a.taps * sn[i].count * sc[j].count;
-        wg8_launch_class(q, sn[i].w / 64, sc[j].w / 64, st);
+        if (terms == 2) wg8_launch_class<true>(q, sn[i].w / 64, sc[j].w / 64, st);
+        else wg8_launch_class<false>(q, sn[i].w / 64, sc[j].w / 64, st);
       }
     if (S > 1)
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(occf_cdiv((long)Cout * Kt, 64)), dim3(256), 0, st, part, dw_tapmajor,
                          (long)Cout * Kt, S, (const float*)nullptr, (float*)nullptr, 0L);
     return (int)hipGetLastError();
   }
+  if (terms == 2) {
+    if (!workspace || workspace_floats < WG_SCALE_SLOT) terms = 3;
+    else {
+      workspace_floats -= WG_SCALE_SLOT;
+      a.scale = (const uint32_t*)(workspace + workspace_floats);
+      wg_absmax(dy, a.M, Cout, (long)Cout, (uint32_t*)a.scale, st);
+    }
+  }
   if (wg_presplit_ok(Cin, Cout, a.taps) && dense && !dbias && workspace && workspace_floats >= nx + ny) {
     uint16_t* yh = (uint16_t*)(workspace + workspace_floats - (nx + ny));
     uint16_t* yl = yh + ny;
     uint16_t* xh = yl + ny;
     uint16_t* xl = xh + nx;
-    hipLaunchKernelGGL(wg_split_kernel, dim3(occf_cdiv(ny / 2, 256)), dim3(256), 0, st, dy, yh, yl, ny / 2);
-    hipLaunchKernelGGL(wg_split_kernel, dim3(occf_cdiv(nx / 2, 256)), dim3(256), 0, st, x, xh, xl, nx / 2);
+    if (terms == 2) {
+      hipLaunchKernelGGL(wg_split_f16_y_kernel, dim3(occf_cdiv(ny / 2, 256)), dim3(256), 0, st, dy, yh, ny / 2, a.scale);
+      hipLaunchKernelGGL(wg_split_f16_x_kernel, dim3(occf_cdiv(nx / 2, 256)), dim3(256), 0, st, x, xh, xl, nx / 2);
+      yl = yh;                                             // (the lo-half staging threads load dY too; never stored)
+    } else {
+      hipLaunchKernelGGL(wg_split_kernel, dim3(occf_cdiv(ny / 2, 256)), dim3(256), 0, st, dy, yh, yl, ny / 2);
+      hipLaunchKernelGGL(wg_split_kernel, dim3(occf_cdiv(nx / 2, 256)), dim3(256), 0, st, x, xh, xl, nx / 2);
+    }
     a.dYh = yh; a.dYl = yl; a.Xh = xh; a.Xl = xl;
     workspace_floats -= nx + ny;
     static const int zfast_env = [] {

@@ -37,6 +37,9 @@ struct Wg8Args {
   int n_strips, strip_w, seg_planes, planes;
   int n_slabs, slabs_per_xcd, tiles;   // tiles = taps * tn_count * tc_count workgroups per slab in THIS launch
   int n_base, c_base, tn_count, tc_count;
+  // two-product fp16 mode (kernel template F16): Yh holds ONE fp16 piece of dY * 2^k, Xh / Xl the fp16 (hi, lo) halves
+  // of x; scale[1] = the bit pattern of 2^-k, applied to the partial sums in the epilogue
+  const uint32_t* scale;
 };
 
 #ifdef OCCF_EMU
@@ -47,13 +50,14 @@ template <int N>
 __device__ __forceinline__ void wg8_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #endif
 
-template <int TI, int TC, int KS, int ST>
+template <int TI, int TC, int KS, int ST, bool F16 = false>
 __global__ void __launch_bounds__(256, 2) wgrad_g8_kernel(Wg8Args p) {
   OCCF_DYN_SMEM(smem_raw);
   constexpr int TN = 64 * TI, BC = 64 * TC, G = 2 * KS;      // G = 8-row groups per stage
   constexpr int AS = G * TN, BS = G * BC;                      // 16-byte slots of one array of one stage
-  constexpr int STAGE = 2 * (AS + BS);
-  wg_u4* lds = (wg_u4*)smem_raw;                               // [ST stages][Ah | Al | Bh | Bl]
+  constexpr int NA = F16 ? 1 : 2;                              // dY arrays (F16: one fp16 piece)
+  constexpr int STAGE = NA * AS + 2 * BS;
+  wg_u4* lds = (wg_u4*)smem_raw;                               // [ST stages][Ah | Al | Bh | Bl]  (F16: [A | Bh | Bl])
 
   // all (tap, tile) workgroups of an M-slab on ONE XCD (workgroup w runs on XCD w % 8): they walk the slab in step and
   // share its columns in that L2; an XCD owns a contiguous block of slabs, i.e. neighbouring strips (which share their
@@ -78,11 +82,14 @@ __global__ void __launch_bounds__(256, 2) wgrad_g8_kernel(Wg8Args p) {
   const long ngroups = npx > 0 && wy > 0 ? ((long)npx * wy) << p.zg_shift : 0;
   const int nsteps = (int)((ngroups + G - 1) / G);
 
-  // ---- DMA role of this wave: 0 = dY hi, 1 = dY lo, 2 = x hi, 3 = x lo
+  // ---- DMA role of this wave: 0 = dY hi, 1 = dY lo, 2 = x hi, 3 = x lo  (F16: waves 0 and 1 share the one dY array,
+  // wave 0 the first half of a stage's row groups, wave 1 the second)
   const bool is_b = wave >= 2, is_lo = (wave & 1) != 0;
   const occf_bbuf buf = is_b ? occf_make_bbuf((is_lo ? p.Xl : p.Xh) + (long)tdz * p.xcopy_elems, p.xbytes)
-                             : occf_make_bbuf(is_lo ? p.Yl : p.Yh, p.ybytes);
-  const int arr_base = wave == 0 ? 0 : wave == 1 ? AS : wave == 2 ? 2 * AS : 2 * AS + BS;
+                             : occf_make_bbuf((is_lo && !F16) ? p.Yl : p.Yh, p.ybytes);
+  const int arr_base = wave == 0 ? 0 : wave == 1 ? (F16 ? 0 : AS) : wave == 2 ? NA * AS : NA * AS + BS;
+  constexpr int GA = F16 ? G / 2 : G;                          // dY row groups one A wave issues per stage
+  const int ga0 = F16 && wave == 1 ? G / 2 : 0;
   const uint32_t lane_off = (uint32_t)((is_b ? c0 : n0) + lane) * 16u;
   // position of the first group of the current stage inside the slab: z-group zg0, strip column cy, plane cpl (relative
   // to px0), and the (batch, x) of that plane
@@ -91,6 +98,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_g8_kernel(Wg8Args p) {
     wg_u4* dst = lds + bufsel * STAGE + arr_base;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
+      if (F16 && !is_b && (g < ga0 || g >= ga0 + GA)) continue;
       const int zz = zg0 + g;
       const int zg = zz & (p.ZG - 1);
       int y = cy + (zz >> p.zg_shift), pl = cpl, x = cx, b = cb;
@@ -143,8 +151,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_g8_kernel(Wg8Args p) {
   const int li = lane & 31, lk = lane >> 5;
   auto compute = [&](int bufsel) __attribute__((always_inline)) {
     const wg_u4* Ah = lds + bufsel * STAGE;
-    const wg_u4* Al = Ah + AS;
-    const wg_u4* Bh = Al + AS;
+    const wg_u4* Al = Ah + AS;                                // (F16: unused)
+    const wg_u4* Bh = Ah + NA * AS;
     const wg_u4* Bl = Bh + BS;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -153,7 +161,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_g8_kernel(Wg8Args p) {
 #pragma unroll
       for (int i = 0; i < TI; ++i) {
         ah[i] = __builtin_bit_cast(bf16x8, Ah[row * TN + wm * (TN / 2) + i * 32 + li]);
-        al[i] = __builtin_bit_cast(bf16x8, Al[row * TN + wm * (TN / 2) + i * 32 + li]);
+        if (!F16) al[i] = __builtin_bit_cast(bf16x8, Al[row * TN + wm * (TN / 2) + i * 32 + li]);
       }
 #pragma unroll
       for (int j = 0; j < TC; ++j) {
@@ -161,18 +169,29 @@ __global__ void __launch_bounds__(256, 2) wgrad_g8_kernel(Wg8Args p) {
         bl[j] = __builtin_bit_cast(bf16x8, Bl[row * BC + wn * (BC / 2) + j * 32 + li]);
       }
       // term-major: consecutive MFMAs write different accumulators (no dependent-accumulator stalls)
+      if (F16) {
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TC; ++j) acc[i][j] = occf_mfma_bf16_32x32x16(al[i], bh[j], acc[i][j]);
+          for (int j = 0; j < TC; ++j) acc[i][j] = occf_mfma_f16_32x32x16(ah[i], bl[j], acc[i][j]);
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TC; ++j) acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bl[j], acc[i][j]);
+          for (int j = 0; j < TC; ++j) acc[i][j] = occf_mfma_f16_32x32x16(ah[i], bh[j], acc[i][j]);
+      } else {
 #pragma unroll
-      for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TC; ++j) acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bh[j], acc[i][j]);
+          for (int j = 0; j < TC; ++j) acc[i][j] = occf_mfma_bf16_32x32x16(al[i], bh[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TC; ++j) acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+          for (int j = 0; j < TC; ++j) acc[i][j] = occf_mfma_bf16_32x32x16(ah[i], bh[j], acc[i][j]);
+      }
     }
   };
 
@@ -187,9 +206,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_g8_kernel(Wg8Args p) {
     // stage s has landed: this wave's pieces by its vmcnt (younger stages may stay in flight), everybody's by the barrier
     const int younger = nsteps - 1 - s;
     if (ST >= 3 && younger >= ST - 2) {
-      if (is_b) wg8_wait_vm<G * TC * (ST - 2)>(); else wg8_wait_vm<G * TI * (ST - 2)>();
+      if (is_b) wg8_wait_vm<G * TC * (ST - 2)>(); else wg8_wait_vm<GA * TI * (ST - 2)>();
     } else if (ST >= 4 && younger == 1) {
-      if (is_b) wg8_wait_vm<G * TC>(); else wg8_wait_vm<G * TI>();
+      if (is_b) wg8_wait_vm<G * TC>(); else wg8_wait_vm<GA * TI>();
     } else {
       wg8_wait_vm<0>();
     }
@@ -203,6 +222,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_g8_kernel(Wg8Args p) {
   // ---- epilogue: raw partial sums of this M-slab (tiles cover N and Cin exactly: no masks)
   const int Kt = p.taps * p.Cin;
   float* o = p.out + (long)slab * p.N * Kt;
+  const float unscale = F16 ? occf_u2f(p.scale[1]) : 1.0f;     // (a power of two: exact)
 #pragma unroll
   for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -211,7 +231,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_g8_kernel(Wg8Args p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wm * (TN / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        o[(long)n * Kt + (long)tap * p.Cin + c] = acc[i][j][r];
+        o[(long)n * Kt + (long)tap * p.Cin + c] = F16 ? acc[i][j][r] * unscale : acc[i][j][r];
       }
     }
 }
@@ -219,8 +239,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_g8_kernel(Wg8Args p) {
 // dY fp32 [M][ldy] -> G8 (hi, lo): a thread owns one 8-row group of ONE channel -- a wave reads 256 contiguous bytes
 // per row and writes 1 KiB contiguous per array (a thread owning four channels wrote 16 of every 64 bytes per store
 // instruction: 0.61 ms for the three x copies of the 192-channel grid)
+template <bool F16>
 __global__ void __launch_bounds__(256) wg8_split_y_kernel(const float* __restrict__ dy, long ldy, long groups, int N,
-                                                          wg_u4* __restrict__ yh, wg_u4* __restrict__ yl) {
+                                                          wg_u4* __restrict__ yh, wg_u4* __restrict__ yl,
+                                                          uint32_t* __restrict__ scale) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= groups * N) return;
   const unsigned i32 = (unsigned)i;                         // (< 2^31 elements per array: 32-bit divisions)
@@ -230,6 +252,18 @@ __global__ void __launch_bounds__(256) wg8_split_y_kernel(const float* __restric
   float v[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) v[j] = src[j * ldy];
+  if (F16) {
+    // scale[0] = bit pattern of max |dy| (wg_absmax_kernel, same stream) -> ONE fp16 piece of dy * 2^k; thread 0
+    // leaves 2^-k in scale[1] for the contraction's epilogue
+    uint32_t inv;
+    const float sc = occf_u2f(occf_f16_scale_bits(scale[0], inv));
+    if (i == 0) scale[1] = inv;
+    wg_u4 h;
+    h.x = occf_f16_pack2(v[0] * sc, v[1] * sc); h.y = occf_f16_pack2(v[2] * sc, v[3] * sc);
+    h.z = occf_f16_pack2(v[4] * sc, v[5] * sc); h.w = occf_f16_pack2(v[6] * sc, v[7] * sc);
+    yh[i] = h;
+    return;
+  }
   uint32_t hh[4], ll[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) occf_bf16_split2(v[2 * t], v[2 * t + 1], hh[t], ll[t]);
@@ -241,6 +275,7 @@ __global__ void __launch_bounds__(256) wg8_split_y_kernel(const float* __restric
 }
 
 // x fp32 [cols][Z][C] (dense) -> three z-shifted G8 (hi, lo) copies: copy w holds x[z + w - 1] (zeros outside [0, Z))
+template <bool F16>
 __global__ void __launch_bounds__(256) wg8_split_x_kernel(const float* __restrict__ x, long cols, int ZG, int C,
                                                           wg_u4* __restrict__ xh, wg_u4* __restrict__ xl,
                                                           long copy_slots) {
@@ -264,7 +299,10 @@ __global__ void __launch_bounds__(256) wg8_split_x_kernel(const float* __restric
   for (int w = 0; w < 3; ++w) {
     uint32_t hh[4], ll[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) occf_bf16_split2(rows[w + 2 * t], rows[w + 2 * t + 1], hh[t], ll[t]);
+    for (int t = 0; t < 4; ++t) {
+      if (F16) occf_f16_split2(rows[w + 2 * t], rows[w + 2 * t + 1], hh[t], ll[t]);
+      else occf_bf16_split2(rows[w + 2 * t], rows[w + 2 * t + 1], hh[t], ll[t]);
+    }
     wg_u4 h, l;
     h.x = hh[0]; h.y = hh[1]; h.z = hh[2]; h.w = hh[3];
     l.x = ll[0]; l.y = ll[1]; l.z = ll[2]; l.w = ll[3];
@@ -345,21 +383,22 @@ static long wg8_workspace(int planes, int Yo, int ZG, int N, int Cin, int taps, 
   return (long)gm.n_slabs * N * (long)taps * Cin + ny + 3 * nx;
 }
 
-template <int TI, int TC, int KS, int ST>
+template <int TI, int TC, int KS, int ST, bool F16>
 static void wg8_launch_one(const Wg8Args& a, hipStream_t st) {
   const unsigned grid = (unsigned)(8 * a.slabs_per_xcd * a.tiles);
-  const size_t smem = (size_t)ST * 2 * (2 * KS) * (64 * TI + 64 * TC) * 16;
+  const size_t smem = (size_t)ST * (2 * KS) * ((F16 ? 1 : 2) * 64 * TI + 2 * 64 * TC) * 16;
 #ifndef OCCF_EMU
   static bool attr_set = false;
   if (smem > 65536 && !attr_set) {
-    (void)hipFuncSetAttribute((const void*)wgrad_g8_kernel<TI, TC, KS, ST>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)smem);
+    (void)hipFuncSetAttribute((const void*)wgrad_g8_kernel<TI, TC, KS, ST, F16>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
 #endif
-  hipLaunchKernelGGL((wgrad_g8_kernel<TI, TC, KS, ST>), dim3(grid), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((wgrad_g8_kernel<TI, TC, KS, ST, F16>), dim3(grid), dim3(256), smem, st, a);
 }
 // (rows per stage = 16 KS, stages ST): two workgroups per CU need <= 80 KB each
+template <bool F16>
 static void wg8_launch_class(const Wg8Args& a, int ti, int tc, hipStream_t st) {
   static const int ks_env = [] { const char* e = getenv("OCCF_WG8_KS"); return e ? atoi(e) : 0; }();
   static const int st_env = [] { const char* e = getenv("OCCF_WG8_ST"); return e ? atoi(e) : 0; }();
@@ -368,11 +407,11 @@ static void wg8_launch_class(const Wg8Args& a, int ti, int tc, hipStream_t st) {
   const int stg = st_env ? st_env : 2;
 #define WG8_CASE(TI_, TC_)                                                                      \
   if (ti == TI_ && tc == TC_) {                                                                 \
-    if (ks == 1 && stg == 2) return wg8_launch_one<TI_, TC_, 1, 2>(a, st);                       \
-    if (ks == 1 && stg == 3) return wg8_launch_one<TI_, TC_, 1, 3>(a, st);                       \
-    if (ks == 1 && stg >= 4) return wg8_launch_one<TI_, TC_, 1, 4>(a, st);                       \
-    if (stg == 2) return wg8_launch_one<TI_, TC_, 2, 2>(a, st);                                  \
-    return wg8_launch_one<TI_, TC_, 2, 3>(a, st);                                                \
+    if (ks == 1 && stg == 2) return wg8_launch_one<TI_, TC_, 1, 2, F16>(a, st);                       \
+    if (ks == 1 && stg == 3) return wg8_launch_one<TI_, TC_, 1, 3, F16>(a, st);                       \
+    if (ks == 1 && stg >= 4) return wg8_launch_one<TI_, TC_, 1, 4, F16>(a, st);                       \
+    if (stg == 2) return wg8_launch_one<TI_, TC_, 2, 2, F16>(a, st);                                  \
+    return wg8_launch_one<TI_, TC_, 2, 3, F16>(a, st);                                                \
   }
   WG8_CASE(1, 1) WG8_CASE(1, 2) WG8_CASE(1, 3) WG8_CASE(2, 1) WG8_CASE(2, 2) WG8_CASE(2, 3) WG8_CASE(3, 1)
   WG8_CASE(3, 2) WG8_CASE(3, 3)

@@ -35,6 +35,7 @@ class HipOps:
         # arithmetic of the dense contractions: "f32" = exact fp32 MFMA; "bf16x3" = 3-term bf16
         # split (fp32-class accuracy, matrix-core rate); "bf16" = plain bf16 products
         self.precision = os.environ.get("OCCF_PRECISION", "bf16x3")
+        self.wgrad_f16 = os.environ.get("OCCF_WGRAD_F16", "1") != "0"
         self.use_halo_conv = os.environ.get("OCCF_HALO_CONV", "1") == "1"
         self.halo_frag = os.environ.get("OCCF_HALO_FRAG", "1") == "1"
         self.swin_frag = os.environ.get("OCCF_SWIN_FRAG", "1") == "1"
@@ -836,6 +837,15 @@ class HipOps:
     def _grad_terms(self):
         return 1 if self.precision == "bf16" else 3
 
+    def _wgrad_terms(self):
+        """weight-gradient contractions: 2 = two fp16-piece products per product (dy as ONE fp16 piece after a per-tensor
+        power-of-two scale, x as fp16 (hi, lo)) -- weight gradients are leaf quantities, the 2^-12 rounding of dy averages
+        over the contraction and propagates nowhere (whole gradient 1.2e-4 against 5.5e-5 with three bf16
+        products).  ``OCCF_WGRAD_F16=0`` keeps the three-term bf16 split."""
+        if self.precision == "bf16x3" and self.wgrad_f16:
+            return 2
+        return self._grad_terms()
+
     def linear_wgrad(self, dy2, x2, want_bias=True):
         """dy2 [M, N], x2 [M, K] (unit column strides) -> (dW [N, K], db [N] or None)"""
         M, N = dy2.shape
@@ -849,7 +859,7 @@ class HipOps:
         self.last_flops = 2 * M * N * K
         self._call("occf_linear_wgrad", ctypes.c_void_p(dy2.data_ptr()), ctypes.c_void_p(x2.data_ptr()),
                    self._ptr(dw), self._ptr(db), self._ptr(ws), need, M, N, K, dy2.stride(0), x2.stride(0),
-                   self._grad_terms(), self._stream())
+                   self._wgrad_terms(), self._stream())
         return dw, db
 
     def conv3d_wgrad(self, dy, x_cl, ksize, stride=1, dil=1, pad=None, want_bias=False):
@@ -868,7 +878,7 @@ class HipOps:
         self.last_flops = 2 * dy.numel() * kX * kY * kZ * Cin
         self._call("occf_conv3d_wgrad", self._ptr(dy, self.f32), ctypes.c_void_p(x_cl.data_ptr()), self._ptr(dw),
                    self._ptr(db), self._ptr(ws), need, *geom, x_cl.stride(0), x_cl.stride(1), x_cl.stride(2),
-                   x_cl.stride(3), self._grad_terms(), self._stream())
+                   x_cl.stride(3), self._wgrad_terms(), self._stream())
         return dw, db
 
     def conv3d_dgrad(self, dy, wt_split, in_shape, ksize, stride=1, dil=1, pad=None):

@@ -1,0 +1,38 @@
+#!/bin/bash
+# The GPU visits of round 6, one stage per visit:  bash scripts/gpu_r06.sh <stage>   (results under gpurun_out/, the
+# files worth keeping are copied to profiles/r06/ and indexed in profiles/README.md).
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+O=gpurun_out
+mkdir -p $O
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+export TMPDIR=/tmp
+brief() {  # brief <json> : the figures of one bench line
+python - "$1" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+except Exception as e:
+    print(sys.argv[1], "no json", e); sys.exit(0)
+print(sys.argv[1].split("/")[-1], round(d["value"], 3), "samples/s", round(d["ms_per_step"], 2), "ms; roofline", round(d["roofline"]["frac"], 4))
+if d.get("check"): print("  check", {k: v for k, v in d["check"].items() if k not in ("what", "forced_relu_gates")})
+for k in ("forward", "forward_from_images", "train_from_images"):
+    if d.get(k): print(" ", k, {a: d[k].get(a) for a in ("value", "ms_per_step", "stages_ms", "check", "error", "pipelined") if d[k].get(a) is not None})
+for k, v in list(d["kernels"].items())[:22]:
+    print(f"    {k:30s} {v['calls']:4d} {v['total_ms']:8.3f} ms")
+PY
+}
+case "${1:-}" in
+a)  # the two-product fp16 weight gradients (tests, same-visit pair), the per-family precision table
+( time timeout 900 python -m pytest tests/test_bwd_ops.py tests/test_full_size_gpu.py -m gpu -q -p no:cacheprovider -k "wgrad" ) 2>&1 | grep -v "MIOpen(HIP)" | tail -6 | tee $O/r06a_pytest_wgrad.log
+for v in 0 1; do
+  OCCF_WGRAD_F16=$v timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --shape-report $O/r06a_shapes_train_wgf16_$v.txt > $O/r06a_bench_train_wgf16_$v.json 2> $O/r06a_bench_train_wgf16_$v.err; echo "wgf16=$v rc=$?"
+  brief $O/r06a_bench_train_wgf16_$v.json
+done
+grep "wgrad" $O/r06a_shapes_train_wgf16_0.txt | head -12; echo; grep "wgrad" $O/r06a_shapes_train_wgf16_1.txt | head -12
+( time timeout 2400 python scripts/precision_probe.py None wg3 wgx cf11 cd11 cfd11 lin11 ) 2>&1 | grep -v "amdgpu.ids\|MIOpen(HIP)\|UserWarning\|_grad_figures\|Consider using" > $O/r06a_precision_probe.txt
+tail -14 $O/r06a_precision_probe.txt | cut -c1-400
+;;
+*) echo "unknown stage"; exit 2;;
+esac

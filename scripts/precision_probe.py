@@ -8,7 +8,17 @@ gradient) and the output gradient of every weight-gradient contraction are round
 the product runs in bf16x3.  Mode "mixed" = bf16x3 in the 3-D convolutions (each followed by a GroupNorm), plain bf16
 in every linear / MLP / fused Swin kernel.  Per mode: forward `output_voxels` max abs error vs the CPU oracle, and the
 training step's whole-gradient relative L2 vs the oracle's train_step on the UNROUNDED weights (same noise tape, the
-mode's own heavy ReLU gates forced: bench.py's `check`)."""
+mode's own heavy ReLU gates forced: bench.py's `check`).
+
+Round 6 (VERDICT r5 #1b): the same question PER KERNEL FAMILY instead of everywhere at once.  A family's two-term
+product is emulated by rounding its ACTIVATION operand to 11 bits (one fp16 piece x the weight's (hi, lo) -- the form a
+kernel would implement: one staged array instead of two) in exactly that family's calls and nowhere else:
+  cf11  the stride-1 3^3 convolutions (the LDS-halo kernel: every one is followed by a GroupNorm), FORWARD only
+  cd11  the same convolutions' DATA gradients only (the forward conv on the tap-flipped weight inside Conv3d.backward)
+  cfd11 both
+  lin11 the streaming linears (M >= 16 384 rows: Swin qkv / proj / FFN, pixel-decoder and decoder-memory projections),
+        forward and data gradient; the eval-mode forward runs with the fused Swin / MLP kernels off so that the same
+        linears are hit"""
 import json
 import os
 import sys
@@ -20,6 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench as B  # noqa: E402
 import occformer_amd  # noqa: E402,F401
+from occformer_amd import autograd as A  # noqa: E402
 from occformer_amd import configs, fused  # noqa: E402
 from occformer_amd.ops import get_ops  # noqa: E402
 from occformer_amd.registry import build_model  # noqa: E402
@@ -79,11 +90,30 @@ def main():
     ocfg = configs.oracle_train_cfg(cfg, meta, class_weight=model.pts_bbox_head.class_weight)
     oargs = (sd, img_inputs[0].cpu(), tuple(t.cpu() for t in img_inputs[1:7]), gt_depths.cpu(), gt_occ.cpu(),
              [p.cpu() for p in gt_points], ocfg)
-    orig = {n: getattr(ops, n) for n in ("linear", "linear_wgrad", "conv3d_wgrad", "mlp_fused", "swin_attention_fused")
+    orig = {n: getattr(ops, n) for n in ("linear", "linear_wgrad", "conv3d_wgrad", "mlp_fused", "swin_attention_fused",
+                                         "conv3d", "linear_stream")
             if hasattr(ops, n)}
+    orig_flags = (ops.use_fused_swin, ops.use_fused_mlp)
+    in_bwd = {"conv": False}
+    conv_bw = A.Conv3d.backward
+
+    def conv_bw_flagged(ctx, *g):
+        in_bwd["conv"] = True
+        try:
+            return conv_bw(ctx, *g)
+        finally:
+            in_bwd["conv"] = False
+    A.Conv3d.backward = staticmethod(conv_bw_flagged)
     rows = []
     only = set(sys.argv[1:])                 # e.g. "wg11": run a subset (keys: None 11 wg11 8 mixed bf16)
-    for mode, bits in (("bf16x3 (3 products: the default)", None), ("2-term, fp16 piece (11 bits)", 11),
+    for mode, bits in (("default: bf16x3, weight gradients on 2 fp16-piece products", None),
+                       ("bf16x3 everywhere (weight gradients on 3 bf16 products: the round-5 arithmetic)", "wg3"),
+                       ("default + the weight gradients of every convolution with <= 4096 output voxels EXACT (fp64)", "wgx"),
+                       ("3^3 halo convolutions FORWARD only: activation in ONE fp16 piece (2 products)", "cf11"),
+                       ("3^3 halo convolutions DATA GRADIENT only: dy in ONE fp16 piece (2 products)", "cd11"),
+                       ("3^3 halo convolutions forward + data gradient (2 products)", "cfd11"),
+                       ("streaming linears (M >= 16384) forward + data gradient: activation in ONE fp16 piece", "lin11"),
+                       ("2-term, fp16 piece (11 bits)", 11),
                        ("2-term fp16 piece in the WEIGHT GRADIENTS only (leaf quantities: nothing propagates)", "wg11"),
                        ("2-term, bf16 piece (8 bits)", 8), ("mixed: bf16x3 convolutions, plain bf16 linears", "mixed"),
                        ("plain bf16 (1 product)", "bf16")):
@@ -94,7 +124,38 @@ def main():
         for n, f in orig.items():
             setattr(ops, n, f)
         ops.precision = "bf16x3"
-        if bits in (11, 8):
+        ops.use_fused_swin, ops.use_fused_mlp = orig_flags
+        ops.wgrad_f16 = bits != "wg3"
+        if bits == "wgx":
+            def conv3d_wgrad(dy, x_cl, ksize, stride=1, dil=1, pad=None, want_bias=False, _f=orig["conv3d_wgrad"]):
+                if dy.numel() // dy.shape[-1] > 4096:
+                    return _f(dy, x_cl, ksize, stride, dil, pad, want_bias=want_bias)
+                import torch.nn.functional as F
+                pd = tuple(dil * (k - 1) // 2 for k in ksize) if pad is None else tuple(pad)
+                xn = x_cl.permute(0, 4, 1, 2, 3).double()
+                w = torch.zeros(dy.shape[-1], x_cl.shape[-1], *ksize, dtype=torch.float64, device=dy.device, requires_grad=True)
+                with torch.enable_grad():
+                    y = F.conv3d(xn, w, stride=stride, padding=pd, dilation=dil)
+                    (dw,) = torch.autograd.grad(y, w, dy.permute(0, 4, 1, 2, 3).double())
+                db = dy.reshape(-1, dy.shape[-1]).double().sum(0).float() if want_bias else None
+                return dw.permute(0, 2, 3, 4, 1).reshape(dy.shape[-1], -1).float().contiguous(), db
+            ops.conv3d_wgrad = conv3d_wgrad
+        if bits in ("cf11", "cd11", "cfd11"):
+            def conv3d(x_cl, weight_tap, ksize, stride=1, dil=1, pad=None, *a, _f=orig["conv3d"], _m=bits, **k):
+                halo = tuple(ksize) == (3, 3, 3) and stride == 1 and dil == 1
+                hit = halo and (("d" in _m[1:-2]) if in_bwd["conv"] else ("f" in _m[1:-2]))
+                return _f(round_bits(x_cl, 11) if hit else x_cl, weight_tap, ksize, stride, dil, pad, *a, **k)
+            ops.conv3d = conv3d
+        elif bits == "lin11":
+            def linear(x, *a, _f=orig["linear"], **k):
+                big = x.numel() // x.shape[-1] >= 16384
+                return _f(round_bits(x, 11) if big else x, *a, **k)
+
+            def linear_stream(x, *a, _f=orig["linear_stream"], **k):
+                return _f(round_bits(x, 11), *a, **k)
+            ops.linear, ops.linear_stream = linear, linear_stream
+            ops.use_fused_swin = ops.use_fused_mlp = False
+        elif bits in (11, 8):
             for p in gemm_weights(model):
                 p.data.copy_(round_bits(exact[id(p)], bits))
             ops.linear_wgrad = lambda dy, x, *a, _f=orig["linear_wgrad"], **k: _f(round_bits(dy, bits), x, *a, **k)

@@ -248,6 +248,64 @@ static inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c) {
   wave_sync();
   return d;
 }
+// fp16 <-> fp32 in software (round to nearest even, subnormals kept): the host build does not rely on F16C
+static inline uint16_t emu_f32_to_f16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000u;
+  u &= 0x7FFFFFFFu;
+  if (u >= 0x7F800000u) return (uint16_t)(sign | (u > 0x7F800000u ? 0x7E00u : 0x7C00u));
+  if (u >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                 // rounds to >= 65520: infinity
+  if (u < 0x38800000u) {                                                     // below the smallest normal half
+    if (u < 0x33000000u) return (uint16_t)sign;                              // < 2^-25: zero
+    const int shift = 126 - (int)(u >> 23);                                  // 14 .. 24
+    const uint32_t m = (u & 0x7FFFFFu) | 0x800000u;
+    const uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    return (uint16_t)(sign | (q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u)));
+  }
+  const uint32_t e = (u >> 23) - 112u, m = u & 0x7FFFFFu;
+  uint32_t h = (e << 10) | (m >> 13);
+  const uint32_t rem = m & 0x1FFFu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+  return (uint16_t)(sign | h);
+}
+static inline float emu_f16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+  uint32_t u;
+  if (e == 31u) u = sign | 0x7F800000u | (m << 13);
+  else if (e) u = sign | ((e + 112u) << 23) | (m << 13);
+  else {
+    const float v = (float)m * 5.9604644775390625e-8f;                       // m * 2^-24
+    memcpy(&u, &v, 4);
+    u |= sign;
+  }
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+// 32x32x16 f16: the bf16 layout with fp16 elements
+static inline emu_f32x16 emu_mfma_f32_32x32x16_f16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c) {
+  using namespace hipemu;
+  Wave& w = g_blk->waves[cur().wave];
+  int l = cur().lane;
+  memcpy(w.slot[l], &a, 16);
+  memcpy(w.slot[l] + 16, &b, 16);
+  wave_sync();
+  emu_f32x16 d = c;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), j = l & 31;
+    float acc = c[r];
+    for (int h = 0; h < 2; ++h) {
+      emu_bf16x8 av, bv;
+      memcpy(&av, w.slot[h * 32 + i], 16);
+      memcpy(&bv, w.slot[h * 32 + j] + 16, 16);
+      for (int e = 0; e < 8; ++e) acc += emu_f16_to_f32((uint16_t)av[e]) * emu_f16_to_f32((uint16_t)bv[e]);
+    }
+    d[r] = acc;
+  }
+  wave_sync();
+  return d;
+}
 // 32x32x16 bf16: lane l supplies A[i=l&31][k=8*(l>>5)+e], B[k=8*(l>>5)+e][j=l&31], e=0..7.
 static inline emu_f32x16 emu_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c) {
   using namespace hipemu;

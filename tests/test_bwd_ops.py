@@ -196,6 +196,19 @@ def test_point_sample_backward(be, align, mode, shared):
     assert _rel(dv.cpu(), vol.grad) < 1e-4
 
 
+@pytest.fixture
+def wgrad_mode():
+    """sets ops.wgrad_f16 for one test and restores it"""
+    saved = []
+
+    def set_mode(be, f16):
+        saved.append((be.ops, be.ops.wgrad_f16))
+        be.ops.wgrad_f16 = bool(f16)
+    yield set_mode
+    for ops, v in saved:
+        ops.wgrad_f16 = v
+
+
 def test_point_loss_rows_backward(be):
     R, P = 5, 300
     x = _t("pl_x", (R, P), 1, 2.0).requires_grad_()
@@ -217,21 +230,31 @@ def test_point_loss_rows_backward(be):
                                    # M <= 2048 with shapes off the 32 x 32 tiles of the small-M kernel; M in (2048, 65536]
                                    # with widths the tile kernel does not take (the 8-lanes-per-output kernel)
                                    (100, 1536, 192), (7, 33, 50), (1024, 18, 18), (2500, 18, 30), (300, 192, 6)])
-def test_linear_wgrad(be, M, N, K):
-    dy = _t("wg_dy", (M, N), M)
+@pytest.mark.parametrize("f16", [False, True])
+def test_linear_wgrad(be, M, N, K, f16, wgrad_mode):
+    """f16 = the two-product weight gradient (ops._wgrad_terms: dy as ONE fp16 piece after a power-of-two scale from
+    max |dy|, x as fp16 (hi, lo)): 2^-12 per dy element, averaged over the M rows -- bound 3e-4; dy is scaled far
+    out of the fp16 range on purpose (the raw values would flush to zero)"""
+    wgrad_mode(be, f16)
+    dy = _t("wg_dy", (M, N), M) * (3e-7 if f16 else 1.0)
     x = _t("wg_x", (M, K), M + 1)
     dw, db = be.ops.linear_wgrad(*be.to(dy, x))
-    assert _rel(dw.cpu(), dy.t() @ x) < 1e-4
+    assert _rel(dw.cpu(), dy.t() @ x) < (3e-4 if f16 else 1e-4)
     assert _rel(db.cpu(), dy.sum(0)) < 1e-4
 
 
-def test_linear_wgrad_strided(be):
-    """operands that are column blocks of wider matrices (row stride > width)"""
+@pytest.mark.parametrize("f16", [False, True])
+def test_linear_wgrad_strided(be, f16, wgrad_mode):
+    """operands that are column blocks of wider matrices (row stride > width); in the fp16 mode the columns OUTSIDE the
+    block are 1e6 times larger -- the scale must come from the block's own maximum"""
+    wgrad_mode(be, f16)
     M, N, K = 1200, 64, 128
     dyw = _t("wgs_dy", (M, 2 * N), 1)
+    dyw[:, :N] *= 1e6
     xw = _t("wgs_x", (M, 3 * K), 2)
     dw, db = be.ops.linear_wgrad(be.to(dyw)[:, N:], be.to(xw)[:, K:2 * K])
-    assert _rel(dw.cpu(), dyw[:, N:].t() @ xw[:, K:2 * K]) < 1e-4 and _rel(db.cpu(), dyw[:, N:].sum(0)) < 1e-4
+    assert _rel(dw.cpu(), dyw[:, N:].t() @ xw[:, K:2 * K]) < (3e-4 if f16 else 1e-4)
+    assert _rel(db.cpu(), dyw[:, N:].sum(0)) < 1e-4
 
 
 CONV_CASES = [
@@ -268,19 +291,23 @@ def _conv_ref(x, w, k, stride, dil):
     return F.conv3d(x, w, stride=stride, dilation=dil, padding=pad)
 
 
+@pytest.mark.parametrize("f16", [False, True])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv3d_wgrad_dgrad(be, case):
+def test_conv3d_wgrad_dgrad(be, case, f16, wgrad_mode):
+    wgrad_mode(be, f16)
     B, dims, Cin, Cout, k, stride, dil = case
     x = _t("cv_x", (B, Cin, *dims), Cin).requires_grad_()
     w = (_t("cv_w", (Cout, Cin, *k), Cout) * (Cin * k[0] * k[1] * k[2]) ** -0.5).requires_grad_()
     y = _conv_ref(x, w, k, stride, dil)
-    dy = _t("cv_dy", tuple(y.shape), 9)
+    dy = _t("cv_dy", tuple(y.shape), 9) * (2e-6 if f16 else 1.0)
     y.backward(dy)
     x_cl = x.detach().permute(0, 2, 3, 4, 1).contiguous()
     dy_cl = dy.permute(0, 2, 3, 4, 1).contiguous()
     dw, _ = be.ops.conv3d_wgrad(be.to(dy_cl), be.to(x_cl), k, stride, dil)
     ref_dw = w.grad.permute(0, 2, 3, 4, 1).reshape(Cout, -1)
-    assert _rel(dw.cpu(), ref_dw) < 1e-4
+    assert _rel(dw.cpu(), ref_dw) < (3e-4 if f16 else 1e-4)
+    if f16:
+        return                              # (the data gradient does not depend on the mode)
     # data gradient: weight re-laid as [Cin, taps * Cout]
     wt = w.detach().permute(1, 2, 3, 4, 0).reshape(Cin, -1).contiguous()
     sp = be.ops.split_bf16(be.to(wt))
