@@ -303,6 +303,21 @@ int occf_conv3x3x3_halo_pack(const uint16_t* w_hi, const uint16_t* w_lo, uint16_
  * occf_conv3x3x3_halo_gn_blocks(X, Y, Z) for the halo kernel (-1: shape not taken). */
 long occf_conv3x3x3_halo_gn_blocks(int X, int Y, int Z);
 
+/* The same convolution as Winograd F(2, 3) along x over the same LDS halo tile (csrc/conv_wino.hip): per output pair
+ * (x0, x0 + 1) four 9-tap contractions of x-transformed planes against x-transformed filters instead of two 27-tap ones
+ * -- 2/3 of the matrix-core products, 3-term bf16 split of the transformed values.  The filter transform happens once
+ * per weight version: occf_conv3x3x3_wino_pack reads the fp32 tap-major weight [Cout, 27*Cin] (tap = (dx*3+dy)*3+dz) and
+ * writes U (hi, lo) in fragment order [Cin/32][4][9][2][Cout/32][64 lanes][8] (occf_conv3x3x3_wino_pack_elems uint16
+ * elements per array; 0 = shape outside the envelope: Cin % 32, Cout % 64, or OCCF_WINO=0).  occf_conv3x3x3_wino_fwd
+ * returns OCCF_ESHAPE (-2) outside its envelope (Z in {4, 8, 16k}); the caller then uses occf_conv3x3x3_halo_fwd.
+ * gn_partial rows per batch element: occf_conv3x3x3_wino_gn_blocks (tiles of one x-pair x 64 (y, z) positions). */
+long occf_conv3x3x3_wino_pack_elems(int Cin, int Cout);
+int occf_conv3x3x3_wino_pack(const float* w_tapmajor, uint16_t* f_hi, uint16_t* f_lo, int Cin, int Cout, void* stream);
+long occf_conv3x3x3_wino_gn_blocks(int X, int Y, int Z);
+int occf_conv3x3x3_wino_fwd(const float* x, const uint16_t* wfrag_hi, const uint16_t* wfrag_lo, const float* bias,
+                            const float* residual, float* out, int B, int X, int Y, int Z, int Cin, int Cout,
+                            long in_sb, long in_sx, long in_sy, long in_sz, int act, float* gn_partial, void* stream);
+
 /* ------------------------------------------------------------------ DepthNet's DCN ------ */
 
 /* Deformable im2col of mmcv-full 1.4.0 `deform_conv2d` (DCNv1; third-party op behind

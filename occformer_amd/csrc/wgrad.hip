@@ -655,11 +655,15 @@ __global__ void __launch_bounds__(256) wgrad_small_tile_kernel(const float* __re
   }
 }
 
-// max |x| of a [M][N] tensor (row stride ld) as an fp32 BIT PATTERN in *slot (zeroed beforehand, same stream):
-// non-negative floats order like their bit patterns, so an integer atomic max is exact and order-independent --
-// deterministic.  Feeds the power-of-two scale of the fp16 weight-gradient operands (occf_f16_scale_bits).
+// max |x| of a [M][N] tensor (row stride ld) as an fp32 BIT PATTERN (non-negative floats order like their bit patterns):
+// <= WG_ABSMAX_BLOCKS workgroups leave one partial maximum each, a one-workgroup second kernel reduces them into
+// slot[0].  No atomics: the first version issued one atomicMax per wave on ONE address -- 8 192 same-line atomics per
+// call serialise at the L2 (r06a: linear_wgrad 11.6 -> 18.8 ms per step).  Feeds the power-of-two scale of the fp16
+// weight-gradient operands (occf_f16_scale_bits).
+#define WG_ABSMAX_BLOCKS 1024
 __global__ void __launch_bounds__(256) wg_absmax_kernel(const float* __restrict__ x, long M, int N4, long ld,
-                                                        uint32_t* __restrict__ slot) {
+                                                        uint32_t* __restrict__ partial) {
+  __shared__ uint32_t wmax[4];
   const long total = M * N4;
   uint32_t m = 0u;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -675,18 +679,37 @@ __global__ void __launch_bounds__(256) wg_absmax_kernel(const float* __restrict_
     const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
     m = t > m ? t : m;
   }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax((int*)slot, (int)m);   // (bit patterns < 2^31: signed order = unsigned order)
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+    partial[blockIdx.x] = a > b ? a : b;
+  }
 }
+__global__ void __launch_bounds__(256) wg_absmax_finish_kernel(const uint32_t* __restrict__ partial, int n,
+                                                               uint32_t* __restrict__ slot) {
+  __shared__ uint32_t wmax[4];
+  uint32_t m = 0u;
+  for (int i = threadIdx.x; i < n; i += 256) m = partial[i] > m ? partial[i] : m;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+    slot[0] = a > b ? a : b;
+  }
+}
+// slot: WG_SCALE_SLOT floats -- [0] the maximum, [1] 2^-k (written by the split pass), [16 ...) the partial maxima
 static void wg_absmax(const float* x, long M, int N, long ld, uint32_t* slot, hipStream_t st) {
-#ifndef OCCF_EMU
-  (void)hipMemsetAsync(slot, 0, 8, st);
-#else
-  memset(slot, 0, 8);
-#endif
   const long total = M * (N / 4);
   long blocks = (total + 256 * 8 - 1) / (256 * 8);
-  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-  hipLaunchKernelGGL(wg_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, M, N / 4, ld, slot);
+  blocks = blocks < 1 ? 1 : (blocks > WG_ABSMAX_BLOCKS ? WG_ABSMAX_BLOCKS : blocks);
+  hipLaunchKernelGGL(wg_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, M, N / 4, ld, slot + 16);
+  hipLaunchKernelGGL(wg_absmax_finish_kernel, dim3(1), dim3(256), 0, st, slot + 16, (int)blocks, slot);
 }
 
 #include "wgrad_g8.h"
@@ -804,7 +827,7 @@ static int wg_launch(WgArgs a, float* dW, float* db, float* workspace, long work
   return (int)hipGetLastError();
 }
 
-#define WG_SCALE_SLOT 16     // floats kept at the END of every workspace for the fp16 scale slot (terms == 2)
+#define WG_SCALE_SLOT (16 + WG_ABSMAX_BLOCKS)   // floats kept at the END of every workspace for the fp16 scale (terms == 2)
 extern "C" long occf_linear_wgrad_workspace(long M, int N, int K) {
   if (M <= 1024 || N % 4 || K % 4) return 0;
   return wg_workspace(M, N, K, 1) + WG_SCALE_SLOT;
@@ -831,7 +854,9 @@ extern "C" int occf_linear_wgrad(const float* dy, const float* x, float* dw, flo
   WgArgs a = {};
   a.dY = dy; a.X = x; a.M = M; a.N = N; a.Cin = K; a.taps = 1; a.ldy = ldy; a.ldx = ldx; a.conv = 0;
   if (terms == 2) {
-    // two fp16-piece products: dy * 2^k in ONE piece (k from max |dy|, one more read of dy), x in (hi, lo)
+    // two fp16-piece products: dy * 2^k in ONE piece (k from max |dy|, one more read of dy), x in (hi, lo).  (The
+    // product's op layer asks for this in the 27-tap convolutions only: a plain linear is bound by its staging, not by
+    // the matrix cores -- r06a: 11.6 ms per step with three bf16 products, no faster with two.)
     if (!workspace || workspace_floats < WG_SCALE_SLOT) terms = 3;
     else {
       workspace_floats -= WG_SCALE_SLOT;
@@ -936,7 +961,7 @@ extern "C" int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapm
     const long cols = (long)B * Xi * Yi;
     // terms == 2: ONE fp16 piece of dy * 2^k (k from max |dy|) times the fp16 (hi, lo) halves of x -- two products per
     // product; the scale slot lives in the (then unused) dY-lo array
-    uint32_t* scale = (uint32_t*)yl;
+    uint32_t* scale = (uint32_t*)yl;                         // (ny * 2 bytes >= WG_SCALE_SLOT floats: M >= 1024, Cout >= 64)
     if (terms == 2) {
       wg_absmax(dy, a.M, Cout, (long)Cout, scale, st);
       hipLaunchKernelGGL(wg8_split_y_kernel<true>, dim3(occf_cdiv((a.M / 8) * Cout, 256)), dim3(256), 0, st, dy,
@@ -973,7 +998,10 @@ extern "C" int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapm
     return (int)hipGetLastError();
   }
   if (terms == 2) {
-    if (!workspace || workspace_floats < WG_SCALE_SLOT) terms = 3;
+    // (only where the operands are pre-split anyway: >= 9 taps re-use each staged row often enough for the matrix
+    // cores to matter)
+    if (!workspace || workspace_floats < WG_SCALE_SLOT + nx + ny || !wg_presplit_ok(Cin, Cout, a.taps) || !dense || dbias)
+      terms = 3;
     else {
       workspace_floats -= WG_SCALE_SLOT;
       a.scale = (const uint32_t*)(workspace + workspace_floats);

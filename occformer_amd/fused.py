@@ -207,8 +207,9 @@ class _WeightPrep:
             e["stamp"] = (p._version, _EPOCH[0])
             if _CHECK:
                 e["sum"] = _checksum(p)
-            if hasattr(e["hi"], "_occf_halo_pack"):          # MFMA-fragment order of the halo kernel: derived from hi / lo
-                del e["hi"]._occf_halo_pack
+            for derived in ("_occf_halo_pack", "_occf_wino_pack"):   # fragment orders of the halo / Winograd kernels:
+                if hasattr(e["hi"], derived):                        # derived from hi / lo / the fp32 layout
+                    delattr(e["hi"], derived)
 
 
 _PREP = _WeightPrep()

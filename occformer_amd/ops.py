@@ -36,8 +36,12 @@ class HipOps:
         # split (fp32-class accuracy, matrix-core rate); "bf16" = plain bf16 products
         self.precision = os.environ.get("OCCF_PRECISION", "bf16x3")
         self.wgrad_f16 = os.environ.get("OCCF_WGRAD_F16", "1") != "0"
+        # (the linears' weight gradients are bound by their operand staging: two products are no faster than three, r06a)
+        self.wgrad_f16_linear = os.environ.get("OCCF_WGRAD_F16_LINEAR", "0") == "1"
         self.use_halo_conv = os.environ.get("OCCF_HALO_CONV", "1") == "1"
         self.halo_frag = os.environ.get("OCCF_HALO_FRAG", "1") == "1"
+        # Winograd F(2, 3) along x for the stride-1 3^3 convolutions (csrc/conv_wino.hip); 0 = the direct halo kernel
+        self.use_wino = os.environ.get("OCCF_WINO", "1") == "1"
         self.swin_frag = os.environ.get("OCCF_SWIN_FRAG", "1") == "1"
         # fused mask contraction + preserve-pooling (the intermediate mask logits are never written)
         self.use_fused_mask_pool = os.environ.get("OCCF_FUSED_MASK_POOL", "1") == "1"
@@ -416,6 +420,26 @@ class HipOps:
             hi._occf_halo_pack = pk
         return pk
 
+    def _wino_fragments(self, weight_tap, w_split, Cin, Cout):
+        """the x-transformed filters U (hi, lo) in MFMA-fragment order for the Winograd kernel (csrc/conv_wino.hip),
+        cached ON the split tensor like the direct kernel's fragments; None when switched off (``use_wino``, OCCF_WINO=0)
+        or outside the envelope"""
+        if not self.use_wino or w_split is None or weight_tap.dtype != self.f32 or not weight_tap.is_contiguous():
+            return None
+        hi = w_split[0]
+        pk = getattr(hi, "_occf_wino_pack", None)
+        if pk is None:
+            n = self.lib.occf_conv3x3x3_wino_pack_elems(Cin, Cout)
+            if n <= 0:
+                return None
+            fh = torch.empty((n,), dtype=hi.dtype, device=hi.device)
+            fl = torch.empty((n,), dtype=hi.dtype, device=hi.device)
+            self._call("occf_conv3x3x3_wino_pack", self._ptr(weight_tap, self.f32), self._ptr(fh), self._ptr(fl), Cin,
+                       Cout, self._stream())
+            pk = (fh, fl)
+            hi._occf_wino_pack = pk
+        return pk
+
     def conv3d(self, x_cl, weight_tap, ksize, stride=1, dil=1, pad=None, bias=None, act=0, residual=None,
                w_split=None, gn=None):
         """x_cl [B, Xi, Yi, Zi, Cin] (any strides with unit channel stride) -> [B, Xo, Yo, Zo, Cout].
@@ -447,6 +471,28 @@ class HipOps:
             halo_args = (ctypes.c_void_p(x_cl.data_ptr()), self._ptr(w_split[0]), self._ptr(w_split[1]),
                          self._ptr(bias), self._ptr(residual), self._ptr(out), B, Xi, Yi, Zi, Cin, Cout,
                          x_cl.stride(0), x_cl.stride(1), x_cl.stride(2), x_cl.stride(3), int(act), terms)
+            # Winograd F(2, 3) along x first (3-term mode only): 2/3 of the matrix-core products
+            wino = self._wino_fragments(weight_tap, w_split, Cin, Cout) if terms == 3 else None
+            if wino is not None:
+                wargs = (ctypes.c_void_p(x_cl.data_ptr()), self._ptr(wino[0]), self._ptr(wino[1]), self._ptr(bias),
+                         self._ptr(residual), self._ptr(out), B, Xi, Yi, Zi, Cin, Cout, x_cl.stride(0), x_cl.stride(1),
+                         x_cl.stride(2), x_cl.stride(3), int(act))
+                rc = -2
+                if want_gn:
+                    nblk = self.lib.occf_conv3x3x3_wino_gn_blocks(Xi, Yi, Zi)
+                    if nblk > 0 and Cout % gn[0] == 0:
+                        part = torch.empty((B * nblk * Cout * 2,), dtype=self.f32, device=x_cl.device)
+                        rc = self.lib.occf_conv3x3x3_wino_fwd(*wargs, self._ptr(part), self._stream())
+                        if rc == 0:
+                            self.last_gn_stats = self._gn_finalize(part, B, nblk, Cout, gn[0],
+                                                                   Xo * Yo * Zo * (Cout // gn[0]), gn[1])
+                            return out
+                if rc == -2:
+                    rc = self.lib.occf_conv3x3x3_wino_fwd(*wargs, ctypes.c_void_p(0), self._stream())
+                if rc == 0:
+                    return out
+                if rc != -2:
+                    raise OccfError(f"occf_conv3x3x3_wino_fwd failed with code {rc}")
             frag = self._halo_fragments(w_split, Cin, Cout)
             frag_args = (self._ptr(frag[0]), self._ptr(frag[1])) if frag else (ctypes.c_void_p(0), ctypes.c_void_p(0))
             rc = -2
@@ -859,7 +905,7 @@ class HipOps:
         self.last_flops = 2 * M * N * K
         self._call("occf_linear_wgrad", ctypes.c_void_p(dy2.data_ptr()), ctypes.c_void_p(x2.data_ptr()),
                    self._ptr(dw), self._ptr(db), self._ptr(ws), need, M, N, K, dy2.stride(0), x2.stride(0),
-                   self._wgrad_terms(), self._stream())
+                   self._wgrad_terms() if self.wgrad_f16_linear else self._grad_terms(), self._stream())
         return dw, db
 
     def conv3d_wgrad(self, dy, x_cl, ksize, stride=1, dil=1, pad=None, want_bias=False):

@@ -34,5 +34,19 @@ grep "wgrad" $O/r06a_shapes_train_wgf16_0.txt | head -12; echo; grep "wgrad" $O/
 ( time timeout 2400 python scripts/precision_probe.py None wg3 wgx cf11 cd11 cfd11 lin11 ) 2>&1 | grep -v "amdgpu.ids\|MIOpen(HIP)\|UserWarning\|_grad_figures\|Consider using" > $O/r06a_precision_probe.txt
 tail -14 $O/r06a_precision_probe.txt | cut -c1-400
 ;;
+b)  # Winograd F(2,3)-along-x halo convolution: tests, probe pair, end-to-end pairs; the probe's forward column (buffers restored)
+( time timeout 900 python -m pytest tests/test_gemm_norm_ops.py tests/test_bwd_ops.py tests/test_full_size_gpu.py -m gpu -q -p no:cacheprovider -k "wino or conv_epilogue or wgrad or conv3d" ) 2>&1 | grep -v "MIOpen(HIP)" | tail -6 | tee $O/r06b_pytest_wino.log
+for v in 0 1; do OCCF_WINO=$v timeout 300 python scripts/conv_probe.py 2>&1 | grep -v "amdgpu.ids"; done | tee $O/r06b_conv_probe_wino.txt
+for v in 0 1; do
+  OCCF_WINO=$v timeout 400 python bench.py --mode forward --check --steps 20 --warmup 3 --shape-report $O/r06b_shapes_fwd_wino$v.txt > $O/r06b_bench_fwd_wino$v.json 2> $O/r06b_bench_fwd_wino$v.err; echo "fwd wino=$v rc=$?"
+  brief $O/r06b_bench_fwd_wino$v.json
+  python -c "
+import json; d=json.load(open('$O/r06b_bench_fwd_wino$v.json')); print('  check', d.get('check'), 'stages', d.get('stages_ms'))"
+  OCCF_WINO=$v timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --shape-report $O/r06b_shapes_train_wino$v.txt > $O/r06b_bench_train_wino$v.json 2> $O/r06b_bench_train_wino$v.err; echo "train wino=$v rc=$?"
+  brief $O/r06b_bench_train_wino$v.json
+done
+( time timeout 1800 python scripts/precision_probe.py None cf11 cd11 lin11 ) 2>&1 | grep -v "amdgpu.ids\|MIOpen(HIP)\|UserWarning\|_grad_figures\|Consider using" > $O/r06b_precision_probe.txt
+tail -8 $O/r06b_precision_probe.txt | cut -c1-400
+;;
 *) echo "unknown stage"; exit 2;;
 esac

@@ -82,6 +82,10 @@ def main():
         torch.nn.utils.clip_grad_norm_(params, 5.0)
         opt.step()
     exact = {id(p): p.detach().clone() for p in gemm_weights(model)}
+    # every buffer too: a train-mode pass moves DepthNet's BatchNorm running statistics, which the NEXT mode's eval
+    # forward would then normalise with -- the forward column of the round-5 table grew by ~1.8e-2 per row for that
+    # reason alone (r06a: 1.8e-2 in a row whose forward arithmetic is the default's), not because of its arithmetic
+    buffers = {n: b.detach().clone() for n, b in model.named_buffers()}
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
     with torch.no_grad():
@@ -121,6 +125,8 @@ def main():
             continue
         for p in gemm_weights(model):
             p.data.copy_(exact[id(p)])
+        for n, b in model.named_buffers():
+            b.data.copy_(buffers[n])
         for n, f in orig.items():
             setattr(ops, n, f)
         ops.precision = "bf16x3"

@@ -202,11 +202,11 @@ def wgrad_mode():
     saved = []
 
     def set_mode(be, f16):
-        saved.append((be.ops, be.ops.wgrad_f16))
-        be.ops.wgrad_f16 = bool(f16)
+        saved.append((be.ops, be.ops.wgrad_f16, be.ops.wgrad_f16_linear))
+        be.ops.wgrad_f16 = be.ops.wgrad_f16_linear = bool(f16)
     yield set_mode
-    for ops, v in saved:
-        ops.wgrad_f16 = v
+    for ops, v, vl in saved:
+        ops.wgrad_f16, ops.wgrad_f16_linear = v, vl
 
 
 def test_point_loss_rows_backward(be):

@@ -215,6 +215,7 @@ def test_conv3x3x3_halo(be, monkeypatch, shape, cin, cout, prec, tol, frag, smal
     monkeypatch.setenv("OCCF_HALO_SMALL", small)
     monkeypatch.setattr(be.ops, "precision", prec)
     monkeypatch.setattr(be.ops, "use_halo_conv", True)
+    monkeypatch.setattr(be.ops, "use_wino", False)          # (the direct kernel; test_conv3x3x3_wino is the default route)
     monkeypatch.setattr(be.ops, "halo_frag", frag)
     B, X, Y, Z = shape
     x = paramgen.tensor("hx", (B, cin, X, Y, Z), 1)
@@ -238,6 +239,48 @@ def test_conv3x3x3_halo(be, monkeypatch, shape, cin, cout, prec, tol, frag, smal
               None, None, ctypes.c_void_p(o2.data_ptr()), B, X, Y, Z, cin, cout, xs.stride(0), xs.stride(1),
               xs.stride(2), xs.stride(3), 0, 3 if prec == "bf16x3" else 1, None, None, None, None)
     assert rc == 0
+
+
+@pytest.mark.parametrize("shape,cin,cout", [((1, 5, 9, 16), 32, 64), ((2, 4, 20, 8), 64, 128), ((1, 3, 34, 4), 32, 192),
+                                            ((1, 2, 8, 32), 32, 64), ((1, 6, 5, 16), 96, 256), ((1, 1, 12, 8), 32, 64)])
+@pytest.mark.parametrize("epilogue", ["plain", "bias_relu_residual", "bias_gelu"])
+def test_conv3x3x3_wino(be, monkeypatch, shape, cin, cout, epilogue):
+    """csrc/conv_wino.hip -- Winograd F(2, 3) along x over the LDS halo tile -- vs fp64 conv3d: odd X (the second output
+    of the last pair masked), X = 1, ragged Y tiles, Z = 4 / 8 / 16 / 32 (two z tiles), two batches, 1 / 3 chunks of
+    input channels (the double-buffered staging), one / two / three 32-column tiles per wave and two N tiles per
+    position tile (256 channels); bias / ReLU / GELU / residual epilogues"""
+    monkeypatch.setattr(be.ops, "precision", "bf16x3")
+    monkeypatch.setattr(be.ops, "use_halo_conv", True)
+    monkeypatch.setattr(be.ops, "use_wino", True)
+    B, X, Y, Z = shape
+    x = paramgen.tensor("wx", (B, cin, X, Y, Z), 1)
+    w = paramgen.tensor("ww", (cout, cin, 3, 3, 3), 2, (cin * 27) ** -0.5)
+    b = paramgen.tensor("wb", (cout,), 3) if epilogue != "plain" else None
+    r = paramgen.tensor("wr", (B, X, Y, Z, cout), 4) if epilogue == "bias_relu_residual" else None
+    y = F.conv3d(x.double(), w.double(), None if b is None else b.double(), padding=1)
+    if epilogue == "bias_relu_residual":
+        y = F.relu(y)
+    elif epilogue == "bias_gelu":
+        y = F.gelu(y)
+    ref = y.permute(0, 2, 3, 4, 1)
+    if r is not None:
+        ref = ref + r.double()
+    ref = ref.float()
+    wt = conv_weight_tapmajor(w)
+    calls = []
+    orig = be.ops.lib.occf_conv3x3x3_wino_fwd
+
+    def counted(*a):
+        rc = orig(*a)
+        calls.append(rc)
+        return rc
+    monkeypatch.setattr(be.ops.lib, "occf_conv3x3x3_wino_fwd", counted)
+    out = be.ops.conv3d(be.to(x.permute(0, 2, 3, 4, 1).contiguous()), be.to(wt), (3, 3, 3),
+                        bias=None if b is None else be.to(b), act={"plain": 0, "bias_relu_residual": 1, "bias_gelu": 2}[epilogue],
+                        residual=None if r is None else be.to(r), w_split=be.ops.split_bf16(be.to(wt))).cpu()
+    assert calls == [0], "the Winograd kernel did not take this shape"
+    err = float((out - ref).abs().max() / ref.abs().max())
+    assert err < 3e-5, err
 
 
 @pytest.mark.parametrize("C,H,act,ln_mode,M", [(128, 128, 2, 1, 150), (192, 768, 1, 2, 70), (256, 256, 2, 1, 64),
@@ -366,11 +409,15 @@ def test_linear_head_major_output(be):
     assert out.shape == ref.shape and torch.allclose(out, ref, atol=2e-4, rtol=1e-4)
 
 
-@pytest.mark.parametrize("kind", ["halo", "halo256", "strided", "linear", "linear192"])
+@pytest.mark.parametrize("kind", ["wino", "halo", "halo256", "strided", "linear", "linear192"])
 def test_groupnorm_stats_from_conv_epilogue(be, kind, monkeypatch):
     """the GroupNorm statistics emitted by the conv / GEMM epilogues equal groupnorm_stats of the output"""
     ops = be.ops
-    if kind == "halo256":                # the halo kernel's 256-voxel tiles (the default); "halo": the half-size tiles
+    monkeypatch.setattr(ops, "use_wino", kind == "wino")
+    if kind == "wino":                   # csrc/conv_wino.hip: tiles of one x-pair x 64 positions (odd X: a masked plane)
+        kind = "halo"
+        monkeypatch.setenv("OCCF_HALO_SMALL", "0")
+    elif kind == "halo256":                # the halo kernel's 256-voxel tiles (the default); "halo": the half-size tiles
         monkeypatch.setenv("OCCF_HALO_SMALL", "0")
         kind = "halo"
     elif kind == "halo":
@@ -395,7 +442,7 @@ def test_groupnorm_stats_from_conv_epilogue(be, kind, monkeypatch):
         y = ops.linear(xd, wd, None, w_split=ops.split_bf16(wd), gn=(G, 1e-5, V))
     else:
         B, cin, cout = 2, 32, 64
-        X, Y, Z = (4, 16, 8) if kind == "halo" else (8, 16, 8)
+        X, Y, Z = (5, 16, 8) if ops.use_wino else (4, 16, 8) if kind == "halo" else (8, 16, 8)
         x = paramgen.tensor("gx", (B, X, Y, Z, cin), 1)
         w = paramgen.tensor("gw", (cout, cin, 3, 3, 3), 2, (cin * 27) ** -0.5)
         wt = conv_weight_tapmajor(w)
