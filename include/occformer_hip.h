@@ -312,11 +312,20 @@ long occf_conv3x3x3_halo_gn_blocks(int X, int Y, int Z);
  * returns OCCF_ESHAPE (-2) outside its envelope (Z in {4, 8, 16k}); the caller then uses occf_conv3x3x3_halo_fwd.
  * gn_partial rows per batch element: occf_conv3x3x3_wino_gn_blocks (tiles of one x-pair x 64 (y, z) positions). */
 long occf_conv3x3x3_wino_pack_elems(int Cin, int Cout);
-int occf_conv3x3x3_wino_pack(const float* w_tapmajor, uint16_t* f_hi, uint16_t* f_lo, int Cin, int Cout, void* stream);
+int occf_conv3x3x3_wino_pack(const float* w_tapmajor, uint16_t* f_hi, uint16_t* f_lo, int Cin, int Cout, int f16,
+                             void* stream);
 long occf_conv3x3x3_wino_gn_blocks(int X, int Y, int Z);
 int occf_conv3x3x3_wino_fwd(const float* x, const uint16_t* wfrag_hi, const uint16_t* wfrag_lo, const float* bias,
                             const float* residual, float* out, int B, int X, int Y, int Z, int Cin, int Cout,
-                            long in_sb, long in_sx, long in_sy, long in_sz, int act, float* gn_partial, void* stream);
+                            long in_sb, long in_sx, long in_sy, long in_sz, int act, float* gn_partial,
+                            const uint32_t* f16_scale, void* stream);
+/* Two-product form of the same kernel (f16_scale != NULL, fragments packed with f16 = 1): x enters as ONE fp16 piece of
+ * (transformed x) * 2^k, k from max |x| (f16_scale = a scale slot filled by occf_absmax_f32 on the same stream), the
+ * filters as fp16 (hi, lo); the output leaves multiplied by 2^-k.  The op layer uses it for the data gradients.
+ * occf_absmax_f32: max |x| of x[rows][cols] (row stride ld, cols % 4 == 0) into slot[0] as an fp32 bit pattern;
+ * slot = occf_absmax_slot_words() uint32 words of device memory; two launches, no atomics. */
+long occf_absmax_slot_words(void);
+int occf_absmax_f32(const float* x, long rows, int cols, long ld, uint32_t* slot, void* stream);
 
 /* ------------------------------------------------------------------ DepthNet's DCN ------ */
 

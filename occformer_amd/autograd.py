@@ -201,8 +201,9 @@ class Conv3d(torch.autograd.Function):
                     return wf, _split(wf)
                 wf, sp = fused.prepared(weight, "flip") or fused._versioned(_FLIP_CACHE, weight, make)
                 dpad = tuple(dil * (k - 1) - p for k, p in zip(ks, pad))
+                # (act_f16: dy may enter as ONE fp16 piece where the Winograd kernel takes the shape -- ops.dgrad_f16)
                 dx = ops.conv3d(g, wf, ks, 1, dil, dpad, None, w_split=sp,
-                                residual=None if dres is None else dres.contiguous())
+                                residual=None if dres is None else dres.contiguous(), act_f16=ops.dgrad_f16)
                 dres = None
             else:
                 def make():

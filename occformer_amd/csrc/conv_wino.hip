@@ -21,8 +21,15 @@
 // per 32-channel chunk and no staging latency on the critical path.  The epilogue exchanges the four M_t through LDS
 // (two rounds of 32 positions), applies the output transform, bias / activation / residual, and emits the GroupNorm
 // partial sums of the outputs.
+//
+// F16 variant (two products per product): the transformed activations as ONE fp16 piece of V_t * 2^k (k from the
+// tensor's absolute maximum, one bit of headroom for the transform's sums), the filters as fp16 (hi, lo).  Used for the
+// DATA GRADIENTS (the forward convolution of dy on the tap-flipped weight): scripts/precision_probe.py measures no
+// change of any gradient figure with dy rounded to 11 bits there (profiles/r06: whole gradient 4.9e-5 vs 5.0e-5), while
+// the same cut in the forward convolutions moves the per-parameter figures to the edge of their bound.
 #include <stdlib.h>
 #include "occf_common.h"
+#include "occf_absmax.h"
 #include "../../include/occformer_hip.h"
 
 struct ConvWinoArgs {
@@ -37,6 +44,7 @@ struct ConvWinoArgs {
   long sb, sx, sy, sz;        // input element strides (channel stride 1)
   int act;
   float* gn_partial;          // optional [B][spatial tiles][Cout][2]
+  const uint32_t* scale;      // F16: scale slot (occf_absmax_f32): [0] = bit pattern of max |x|
 };
 
 typedef uint32_t cw_u2 __attribute__((ext_vector_type(2)));
@@ -50,7 +58,7 @@ __device__ __forceinline__ int cw_pos(int m) {
 }
 __device__ __forceinline__ float cw_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int TN>
+template <int TN, bool F16>
 __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) {
   constexpr int BN = 64 * TN;
   constexpr int HROW = 80;                             // bytes per halo row: 32 bf16 + pad (conflict-free b128 reads)
@@ -59,8 +67,10 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
   const int TY = p.TY, TZ = p.TZ;
   const int HY = TY + 2, HZ = TZ + 2;
   const int NH = 4 * HY * HZ;                          // transformed halo rows
-  const int hl_off = NH * HROW;                        // lo array behind the hi array
-  const int buf_sz = 2 * NH * HROW;                    // one (hi, lo) buffer; two of them
+  const int hl_off = NH * HROW;                        // lo array behind the hi array (F16: no lo array)
+  const int buf_sz = (F16 ? 1 : 2) * NH * HROW;        // one (hi, lo) buffer; two of them
+  uint32_t inv_bits = 0x3F800000u;
+  const float sc = F16 ? occf_u2f(occf_f16_scale_bits(p.scale[0], inv_bits, 1u)) : 1.0f;
   unsigned char* H = (unsigned char*)smem;
 
   const int tid = threadIdx.x;
@@ -138,13 +148,18 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             v[e] = t == 0 ? d[0][e] - d[2][e] : t == 1 ? d[1][e] + d[2][e] : t == 2 ? d[2][e] - d[1][e] : d[1][e] - d[3][e];
-          uint32_t h0, l0, h1, l1;
-          occf_bf16_split2(v[0], v[1], h0, l0);
-          occf_bf16_split2(v[2], v[3], h1, l1);
-          const cw_u2 hi = {h0, h1}, lo = {l0, l1};
           const int off = t * plane_b + urow[j];
-          *(cw_u2*)(Hb + off) = hi;
-          *(cw_u2*)(Hb + hl_off + off) = lo;
+          if (F16) {
+            const cw_u2 hi = {occf_f16_pack2(v[0] * sc, v[1] * sc), occf_f16_pack2(v[2] * sc, v[3] * sc)};
+            *(cw_u2*)(Hb + off) = hi;
+          } else {
+            uint32_t h0, l0, h1, l1;
+            occf_bf16_split2(v[0], v[1], h0, l0);
+            occf_bf16_split2(v[2], v[3], h1, l1);
+            const cw_u2 hi = {h0, h1}, lo = {l0, l1};
+            *(cw_u2*)(Hb + off) = hi;
+            *(cw_u2*)(Hb + hl_off + off) = lo;
+          }
         }
       }
     }
@@ -184,12 +199,25 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
     const unsigned char* ap = H + bufsel * buf_sz + a_base + toff * HROW + s * 32;
     ah[0] = *(const bf16x8*)(ap);
     ah[1] = *(const bf16x8*)(ap + a_i1);
-    al[0] = *(const bf16x8*)(ap + hl_off);
-    al[1] = *(const bf16x8*)(ap + hl_off + a_i1);
+    if (!F16) {
+      al[0] = *(const bf16x8*)(ap + hl_off);
+      al[1] = *(const bf16x8*)(ap + hl_off + a_i1);
+    }
   };
   // term-major: six accumulators between two products into the same one
   auto mma_tm = [&](const bf16x8 (&ah)[2], const bf16x8 (&al)[2], const bf16x8 (&fh)[TN],
                     const bf16x8 (&fl)[TN]) __attribute__((always_inline)) {
+    if (F16) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = occf_mfma_f16_32x32x16(ah[i], fl[j], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = occf_mfma_f16_32x32x16(ah[i], fh[j], acc[i][j]);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -207,9 +235,9 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
 
   bf16x8 f0h[TN], f0l[TN], f1h[TN], f1l[TN];
   bf16x8 a0h[2], a0l[2], a1h[2], a1l[2];
-  constexpr int NA = 4;                                // ds_read_b128 per k-step
+  constexpr int NA = F16 ? 2 : 4;                      // ds_read_b128 per k-step
   constexpr int NF = 2 * TN;                           // global 16-byte loads per k-step
-  constexpr int NM = 6 * TN;                           // MFMAs per k-step
+  constexpr int NM = (F16 ? 4 : 6) * TN;               // MFMAs per k-step
   load_f(0, 0, 0, f0h, f0l);
 #pragma unroll
   for (int j = 0; j < NUT; ++j) {
@@ -257,6 +285,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
   // outputs of x-parity t & 1, MFMA rows 16 (t >> 1) .. + 16, its 32 TN columns
   float* E = (float*)smem;                             // [4 t][32 rows][BN]
   const int xp = wt & 1, rh = wt >> 1;
+  const float unscale = occf_u2f(inv_bits);            // (F16: 2^-k, exact; else 1)
   float gs[TN], gq[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.f;
@@ -286,6 +315,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
         const float e0 = E[(0 * 32 + m) * BN + col], e1 = E[(1 * 32 + m) * BN + col], e2 = E[(2 * 32 + m) * BN + col],
                     e3 = E[(3 * 32 + m) * BN + col];
         float v = xp == 0 ? (e0 + e1) + e2 : (e1 - e2) - e3;
+        if (F16) v *= unscale;
         if (p.bias) v += p.bias[n];
         if (p.act == 1) v = fmaxf(v, 0.f);
         else if (p.act == 2) v = cw_gelu(v);
@@ -327,6 +357,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
 // w fp32 [Cout][27 * Cin] (tap-major rows, tap = (dx * 3 + dy) * 3 + dz) -> U (hi, lo) in fragment order
 // [chunk][t][tap9 = dy * 3 + dz][k-step][Cout / 32][lane = lk * 32 + li][8]: element e of lane (lk, li) =
 // U_t[jg * 32 + li][tap9][chunk * 32 + (s * 2 + lk) * 8 + e].  thread = one 16-byte group of each array
+template <bool F16>
 __global__ void __launch_bounds__(256) conv_wino_pack_kernel(const float* __restrict__ w, uint16_t* __restrict__ fh,
                                                              uint16_t* __restrict__ fl, int Cin, int Cout) {
   const int ngrp = Cout >> 5, n_chunks = Cin >> 5;
@@ -357,7 +388,10 @@ __global__ void __launch_bounds__(256) conv_wino_pack_kernel(const float* __rest
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   uint32_t hh[4], ll[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) occf_bf16_split2(u[2 * q], u[2 * q + 1], hh[q], ll[q]);
+  for (int q = 0; q < 4; ++q) {
+    if (F16) occf_f16_split2(u[2 * q], u[2 * q + 1], hh[q], ll[q]);
+    else occf_bf16_split2(u[2 * q], u[2 * q + 1], hh[q], ll[q]);
+  }
   u4 h, l;
   h.x = hh[0]; h.y = hh[1]; h.z = hh[2]; h.w = hh[3];
   l.x = ll[0]; l.y = ll[1]; l.z = ll[2]; l.w = ll[3];
@@ -385,11 +419,24 @@ extern "C" long occf_conv3x3x3_wino_pack_elems(int Cin, int Cout) {
 }
 
 extern "C" int occf_conv3x3x3_wino_pack(const float* w_tapmajor, uint16_t* f_hi, uint16_t* f_lo, int Cin, int Cout,
-                                        void* stream) {
+                                        int f16, void* stream) {
   if (occf_conv3x3x3_wino_pack_elems(Cin, Cout) == 0 || !w_tapmajor || !f_hi || !f_lo) return OCCF_ESHAPE;
   const long groups = 36L * Cin * Cout / 8;
-  hipLaunchKernelGGL(conv_wino_pack_kernel, dim3(occf_cdiv(groups, 256)), dim3(256), 0, (hipStream_t)stream, w_tapmajor,
-                     f_hi, f_lo, Cin, Cout);
+  if (f16)
+    hipLaunchKernelGGL(conv_wino_pack_kernel<true>, dim3(occf_cdiv(groups, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w_tapmajor, f_hi, f_lo, Cin, Cout);
+  else
+    hipLaunchKernelGGL(conv_wino_pack_kernel<false>, dim3(occf_cdiv(groups, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w_tapmajor, f_hi, f_lo, Cin, Cout);
+  OCCF_LAUNCH_CHECK();
+}
+
+/* max |x| of x[rows][cols] (row stride ld, cols % 4 == 0, 16-byte aligned rows) into a scale slot of
+ * occf_absmax_slot_words() uint32 words: slot[0] = the maximum's fp32 bit pattern.  Two launches, no atomics. */
+extern "C" long occf_absmax_slot_words() { return OCCF_ABSMAX_SLOT; }
+extern "C" int occf_absmax_f32(const float* x, long rows, int cols, long ld, uint32_t* slot, void* stream) {
+  if (!x || !slot || rows <= 0 || cols <= 0 || cols % 4 || ld % 4) return OCCF_ESHAPE;
+  wg_absmax(x, rows, cols, ld, slot, (hipStream_t)stream);
   OCCF_LAUNCH_CHECK();
 }
 
@@ -411,7 +458,7 @@ extern "C" long occf_conv3x3x3_wino_gn_blocks(int X, int Y, int Z) {
 extern "C" int occf_conv3x3x3_wino_fwd(const float* x, const uint16_t* wfrag_hi, const uint16_t* wfrag_lo,
                                        const float* bias, const float* residual, float* out, int B, int X, int Y,
                                        int Z, int Cin, int Cout, long in_sb, long in_sx, long in_sy, long in_sz,
-                                       int act, float* gn_partial, void* stream) {
+                                       int act, float* gn_partial, const uint32_t* f16_scale, void* stream) {
   if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || Cin <= 0 || Cin % 32 != 0 || Cout <= 0) return OCCF_ESHAPE;
   if (!conv_wino_enabled() || !wfrag_hi || !wfrag_lo) return OCCF_ESHAPE;
   if (in_sb % 4 || in_sx % 4 || in_sy % 4 || in_sz % 4) return OCCF_ESHAPE;
@@ -431,16 +478,21 @@ extern "C" int occf_conv3x3x3_wino_fwd(const float* x, const uint16_t* wfrag_hi,
   a.tz_shift = TZ == 16 ? 4 : TZ == 8 ? 3 : 2;
   a.sb = in_sb; a.sx = in_sx; a.sy = in_sy; a.sz = in_sz; a.act = act;
   a.gn_partial = gn_partial;
+  a.scale = f16_scale;
   const long blocks = (long)B * ((X + 1) / 2) * ((Y + TY - 1) / TY) * (Z / TZ) * (Cout / (64 * TN));
   if (blocks >= 2147483647L) return OCCF_ESHAPE;
   typedef void (*fn_t)(ConvWinoArgs);
-  const fn_t fn = TN == 1 ? conv3x3x3_wino_kernel<1> : TN == 2 ? conv3x3x3_wino_kernel<2> : conv3x3x3_wino_kernel<3>;
+  const bool f16 = f16_scale != nullptr;
+  const fn_t fn = f16 ? (TN == 1 ? conv3x3x3_wino_kernel<1, true> : TN == 2 ? conv3x3x3_wino_kernel<2, true>
+                                                                            : conv3x3x3_wino_kernel<3, true>)
+                      : (TN == 1 ? conv3x3x3_wino_kernel<1, false> : TN == 2 ? conv3x3x3_wino_kernel<2, false>
+                                                                             : conv3x3x3_wino_kernel<3, false>);
 #ifndef OCCF_EMU
-  static bool attr_set[4] = {};
-  if (!attr_set[TN]) {
+  static bool attr_set[4][2] = {};
+  if (!attr_set[TN][f16]) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set[TN] = true;
+    attr_set[TN][f16] = true;
   }
 #endif
   hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(512), lds, (hipStream_t)stream, a);

@@ -645,8 +645,10 @@ extern "C" int occf_linear_bf16_fwd(const float* x, const uint16_t* w_hi, const 
   if (out_head_dim > 0 && (N % out_head_dim || out_head_dim % 4 || N % 4 || residual || out_head_rows <= 0 ||
                            M % out_head_rows))
     return OCCF_ESHAPE;
-  if (out_head_dim <= 0 && !gn_partial) {
-    // the streaming shapes (M >> N, K <= 256) run on the weight-resident persistent kernel (gemm_stream.h)
+  if (out_head_dim <= 0 && !gn_partial && act >= 0 && act <= 2) {
+    // the streaming shapes (M >> N, K <= 256) run on the weight-resident persistent kernel (gemm_stream.h); act = 3
+    // (x GELU'(aux)) belongs to occf_linear_stream_fwd alone: the tile kernel below reads any other code as
+    // identity + residual, so the generic entry point must not change meaning with M
     const int rc = occf_gemm_stream_launch(x, w_hi, w_lo, bias, residual, out, M, N, K, ldx, ldo, ldr, act, terms,
                                            (hipStream_t)stream);
     if (rc != OCCF_ESHAPE) {

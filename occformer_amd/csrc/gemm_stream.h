@@ -224,6 +224,8 @@ static int occf_gemm_stream_launch(const float* A, const uint16_t* Wh, const uin
   const int ntb = occf_gemm_stream_ntb(N, K, terms);
   if (ntb == 0) return OCCF_ESHAPE;
   if (act < 0 || act > 3 || (act == 3 && !residual) || (row_scale && (xy_s <= 0 || s_slices <= 0))) return OCCF_EINVAL;
+  // (row_scale[(row / xy_s) * s_slices + row % s_slices]: whole samples only, or the last rows read past the vector)
+  if (row_scale && M % xy_s != 0) return OCCF_EINVAL;
   GemmStreamArgs a = {A, Wh, Wl, bias, residual, C, M, N, K, lda, ldc, ldr, act, pre_out, row_scale, xy_s, s_slices,
                       ntb, N / (32 * ntb), 0};
   if (a.n_blocks > 32) return OCCF_ESHAPE;

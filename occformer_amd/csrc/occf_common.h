@@ -120,11 +120,13 @@ static inline
 #else
 __device__ __forceinline__
 #endif
-uint32_t occf_f16_scale_bits(uint32_t amax_bits, uint32_t& inv) {
+uint32_t occf_f16_scale_bits(uint32_t amax_bits, uint32_t& inv, uint32_t headroom = 0u) {
+  // ``headroom`` bits below that: a consumer that ADDS two scaled values before rounding to fp16 (the Winograd input
+  // transform) asks for 1 -> maximum in [2^13, 2^14), sums below 2^15
   uint32_t e = (amax_bits >> 23) & 0xFFu;                 // biased exponent of the maximum
-  e = e < 15u ? 15u : (e > 254u ? 254u : e);
-  inv = (e - 14u) << 23;                                  // 2^(e - 127 - 14)
-  return (268u - e) << 23;                                // 2^(14 - (e - 127))
+  e = e < 15u ? 15u : (e > 250u ? 250u : e);
+  inv = (e - 14u + headroom) << 23;                       // 2^(e - 127 - 14 + headroom)
+  return (268u - headroom - e) << 23;                     // 2^(14 - headroom - (e - 127))
 }
 
 // scheduling fence: keeps the instruction groups on either side in program order (used where the

@@ -207,7 +207,7 @@ class _WeightPrep:
             e["stamp"] = (p._version, _EPOCH[0])
             if _CHECK:
                 e["sum"] = _checksum(p)
-            for derived in ("_occf_halo_pack", "_occf_wino_pack"):   # fragment orders of the halo / Winograd kernels:
+            for derived in ("_occf_halo_pack", "_occf_wino_pack", "_occf_wino_pack_f16"):   # fragment orders of the halo / Winograd kernels:
                 if hasattr(e["hi"], derived):                        # derived from hi / lo / the fp32 layout
                     delattr(e["hi"], derived)
 

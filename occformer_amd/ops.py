@@ -42,6 +42,8 @@ class HipOps:
         self.halo_frag = os.environ.get("OCCF_HALO_FRAG", "1") == "1"
         # Winograd F(2, 3) along x for the stride-1 3^3 convolutions (csrc/conv_wino.hip); 0 = the direct halo kernel
         self.use_wino = os.environ.get("OCCF_WINO", "1") == "1"
+        # the data gradients of those convolutions on two fp16-piece products (dy in ONE piece; OCCF_DGRAD_F16=0: three)
+        self.dgrad_f16 = os.environ.get("OCCF_DGRAD_F16", "1") == "1"
         self.swin_frag = os.environ.get("OCCF_SWIN_FRAG", "1") == "1"
         # fused mask contraction + preserve-pooling (the intermediate mask logits are never written)
         self.use_fused_mask_pool = os.environ.get("OCCF_FUSED_MASK_POOL", "1") == "1"
@@ -420,14 +422,15 @@ class HipOps:
             hi._occf_halo_pack = pk
         return pk
 
-    def _wino_fragments(self, weight_tap, w_split, Cin, Cout):
+    def _wino_fragments(self, weight_tap, w_split, Cin, Cout, f16=False):
         """the x-transformed filters U (hi, lo) in MFMA-fragment order for the Winograd kernel (csrc/conv_wino.hip),
         cached ON the split tensor like the direct kernel's fragments; None when switched off (``use_wino``, OCCF_WINO=0)
-        or outside the envelope"""
+        or outside the envelope.  ``f16``: fp16 (hi, lo) halves for the two-product form"""
         if not self.use_wino or w_split is None or weight_tap.dtype != self.f32 or not weight_tap.is_contiguous():
             return None
         hi = w_split[0]
-        pk = getattr(hi, "_occf_wino_pack", None)
+        attr = "_occf_wino_pack_f16" if f16 else "_occf_wino_pack"
+        pk = getattr(hi, attr, None)
         if pk is None:
             n = self.lib.occf_conv3x3x3_wino_pack_elems(Cin, Cout)
             if n <= 0:
@@ -435,15 +438,25 @@ class HipOps:
             fh = torch.empty((n,), dtype=hi.dtype, device=hi.device)
             fl = torch.empty((n,), dtype=hi.dtype, device=hi.device)
             self._call("occf_conv3x3x3_wino_pack", self._ptr(weight_tap, self.f32), self._ptr(fh), self._ptr(fl), Cin,
-                       Cout, self._stream())
+                       Cout, int(f16), self._stream())
             pk = (fh, fl)
-            hi._occf_wino_pack = pk
+            setattr(hi, attr, pk)
         return pk
 
+    def absmax_slot(self, x2):
+        """scale slot of a contiguous [rows, cols] tensor for the two-product fp16 kernels: slot[0] = the bit pattern of
+        max |x| (csrc/occf_absmax.h: two launches, no atomics, no host synchronisation)"""
+        slot = torch.empty((self.lib.occf_absmax_slot_words(),), dtype=self.i32, device=x2.device)
+        self._call("occf_absmax_f32", self._ptr(x2, self.f32), x2.shape[0], x2.shape[1], x2.stride(0), self._ptr(slot),
+                   self._stream())
+        return slot
+
     def conv3d(self, x_cl, weight_tap, ksize, stride=1, dil=1, pad=None, bias=None, act=0, residual=None,
-               w_split=None, gn=None):
+               w_split=None, gn=None, act_f16=False):
         """x_cl [B, Xi, Yi, Zi, Cin] (any strides with unit channel stride) -> [B, Xo, Yo, Zo, Cout].
-        ``gn = (groups, eps)``: GroupNorm statistics of the output -> ``self.last_gn_stats`` (see linear)."""
+        ``gn = (groups, eps)``: GroupNorm statistics of the output -> ``self.last_gn_stats`` (see linear).
+        ``act_f16``: the caller allows x_cl to enter as ONE fp16 piece (two products per product, csrc/conv_wino.hip's
+        F16 variant) -- the data gradients of the stride-1 3^3 convolutions; ignored where no such kernel applies."""
         self.last_gn_stats = None
         B, Xi, Yi, Zi, Cin = x_cl.shape
         assert x_cl.stride(4) == 1
@@ -472,23 +485,28 @@ class HipOps:
                          self._ptr(bias), self._ptr(residual), self._ptr(out), B, Xi, Yi, Zi, Cin, Cout,
                          x_cl.stride(0), x_cl.stride(1), x_cl.stride(2), x_cl.stride(3), int(act), terms)
             # Winograd F(2, 3) along x first (3-term mode only): 2/3 of the matrix-core products
-            wino = self._wino_fragments(weight_tap, w_split, Cin, Cout) if terms == 3 else None
+            f16 = bool(act_f16) and terms == 3 and x_cl.is_contiguous()
+            wino = self._wino_fragments(weight_tap, w_split, Cin, Cout, f16) if terms == 3 else None
             if wino is not None:
                 wargs = (ctypes.c_void_p(x_cl.data_ptr()), self._ptr(wino[0]), self._ptr(wino[1]), self._ptr(bias),
                          self._ptr(residual), self._ptr(out), B, Xi, Yi, Zi, Cin, Cout, x_cl.stride(0), x_cl.stride(1),
                          x_cl.stride(2), x_cl.stride(3), int(act))
+                # (slot_t stays referenced until the launches below are queued: a buffer allocated in between -- the
+                # GroupNorm partials, which the same kernel WRITES -- must not land on its memory)
+                slot_t = self.absmax_slot(x_cl.view(-1, Cin)) if f16 else None
+                slot = self._ptr(slot_t) if f16 else ctypes.c_void_p(0)
                 rc = -2
                 if want_gn:
                     nblk = self.lib.occf_conv3x3x3_wino_gn_blocks(Xi, Yi, Zi)
                     if nblk > 0 and Cout % gn[0] == 0:
                         part = torch.empty((B * nblk * Cout * 2,), dtype=self.f32, device=x_cl.device)
-                        rc = self.lib.occf_conv3x3x3_wino_fwd(*wargs, self._ptr(part), self._stream())
+                        rc = self.lib.occf_conv3x3x3_wino_fwd(*wargs, self._ptr(part), slot, self._stream())
                         if rc == 0:
                             self.last_gn_stats = self._gn_finalize(part, B, nblk, Cout, gn[0],
                                                                    Xo * Yo * Zo * (Cout // gn[0]), gn[1])
                             return out
                 if rc == -2:
-                    rc = self.lib.occf_conv3x3x3_wino_fwd(*wargs, ctypes.c_void_p(0), self._stream())
+                    rc = self.lib.occf_conv3x3x3_wino_fwd(*wargs, ctypes.c_void_p(0), slot, self._stream())
                 if rc == 0:
                     return out
                 if rc != -2:

@@ -48,5 +48,17 @@ done
 ( time timeout 1800 python scripts/precision_probe.py None cf11 cd11 lin11 ) 2>&1 | grep -v "amdgpu.ids\|MIOpen(HIP)\|UserWarning\|_grad_figures\|Consider using" > $O/r06b_precision_probe.txt
 tail -8 $O/r06b_precision_probe.txt | cut -c1-400
 ;;
+c)  # data gradients on the two-product Winograd kernel: tests, same-visit pair, the default bench with its check, the training-parity gates
+( time timeout 900 python -m pytest tests/test_gemm_norm_ops.py tests/test_bwd_ops.py -m gpu -q -p no:cacheprovider -k "wino or wgrad" ) 2>&1 | grep -v "MIOpen(HIP)" | tail -4 | tee $O/r06c_pytest_wino_f16.log
+for v in 0 1; do
+  OCCF_DGRAD_F16=$v timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --shape-report $O/r06c_shapes_train_dgf16_$v.txt > $O/r06c_bench_train_dgf16_$v.json 2> $O/r06c_bench_train_dgf16_$v.err; echo "train dgrad_f16=$v rc=$?"
+  brief $O/r06c_bench_train_dgf16_$v.json
+done
+( time timeout 1500 python -m pytest tests/test_train_step.py tests/test_train_multistep.py -m gpu -q -p no:cacheprovider -s -k "training_step or three_fused" ) 2>&1 | grep -v "MIOpen(HIP)" > $O/r06c_pytest_gates.log
+grep -i "gated differently\|whole gradient\|passed\|failed\|error\|^real" $O/r06c_pytest_gates.log | cut -c1-400
+( time timeout 900 python bench.py --shape-report $O/r06c_shapes_train.txt ) > $O/r06c_bench_train.json 2> $O/r06c_bench_train.err; echo "bench rc=$?"
+tail -3 $O/r06c_bench_train.err
+brief $O/r06c_bench_train.json
+;;
 *) echo "unknown stage"; exit 2;;
 esac
