@@ -404,10 +404,13 @@ class ProjDropPath(torch.autograd.Function):
     @staticmethod
     def forward(ctx, identity, x, weight, bias, scale, XY, S):
         ops = get_ops()
-        out = ops.linear_stream(x, fused.split_weight(weight, _w2d), bias.detach(), 0, residual=identity.detach(),
-                                row_scale=scale, XY=XY, S=S)
+        sp = fused.split_weight(weight, _w2d)
+        out = ops.linear_stream(x, sp, bias.detach(), 0, residual=identity.detach(), row_scale=scale, XY=XY, S=S)
         if out is None:
-            raise RuntimeError("ProjDropPath: shape outside the streaming kernel (check stream_fusable first)")
+            # outside the streaming kernel's envelope after all (stream_fusable asks for the default arithmetic; the
+            # envelope switches are re-read per call): the unfused sequence, same result
+            y = ops.linear(x, weight.detach(), bias.detach(), w_split=sp)
+            out = identity.detach() + y if scale is None else ops.droppath(identity.detach(), y, scale, XY, S)
         ctx.save_for_backward(x, weight, scale)
         ctx.geom = (XY, S)
         return out
@@ -430,14 +433,16 @@ class SwinFfn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, identity, x, w1, b1, w2, b2, scale, XY, S):
         ops = get_ops()
-        r = ops.linear_stream(x, fused.split_weight(w1, _w2d), b1.detach(), 2, pre_out=True)
-        if r is None:
-            raise RuntimeError("SwinFfn: shape outside the streaming kernel (check stream_fusable first)")
+        sp1, sp2 = fused.split_weight(w1, _w2d), fused.split_weight(w2, _w2d)
+        r = ops.linear_stream(x, sp1, b1.detach(), 2, pre_out=True)
+        if r is None:                                   # (the unfused sequence: see ProjDropPath)
+            z = ops.linear(x, w1.detach(), b1.detach(), w_split=sp1)
+            r = (ops.act_forward(z, 2), z)
         f, z = r
-        out = ops.linear_stream(f, fused.split_weight(w2, _w2d), b2.detach(), 0, residual=identity.detach(),
-                                row_scale=scale, XY=XY, S=S)
+        out = ops.linear_stream(f, sp2, b2.detach(), 0, residual=identity.detach(), row_scale=scale, XY=XY, S=S)
         if out is None:
-            raise RuntimeError("SwinFfn: shape outside the streaming kernel (check stream_fusable first)")
+            y = ops.linear(f, w2.detach(), b2.detach(), w_split=sp2)
+            out = identity.detach() + y if scale is None else ops.droppath(identity.detach(), y, scale, XY, S)
         ctx.save_for_backward(x, z, f, w1, w2, scale)
         ctx.geom = (XY, S)
         return out

@@ -331,7 +331,9 @@ class OccupancyFormer(nn.Module):
         # neck features [B, N, C, fH, fW] instead of images [B, N, 3, H, W]: the caller already ran the image branch
         # (a detector without one; or a serving loop that runs ``image_encoder`` of the NEXT frame on a side stream
         # while this frame's 3-D path runs -- bench.py's pipelined from-images record)
-        if self.img_backbone is None or (img.dim() == 5 and img.shape[2] != 3):
+        # The signal is explicit (a channel count != 3 would also skip the backbone for 1- or 4-channel
+        # images and push a 3-channel feature map through it): this method marks what it returns.
+        if self.img_backbone is None or getattr(img, "_occf_neck_features", False):
             return img
         B, N, C, H, W = img.shape
         x = img.view(B * N, C, H, W)
@@ -350,7 +352,9 @@ class OccupancyFormer(nn.Module):
                 x = self.img_neck(x)
                 if isinstance(x, (list, tuple)):
                     x = x[0]
-        return x.view(B, N, *x.shape[1:])
+        x = x.view(B, N, *x.shape[1:])
+        x._occf_neck_features = True
+        return x
 
     def bev_encoder(self, x):
         t = self._tick("", 0.0) if self.record_time else 0.0

@@ -390,6 +390,9 @@ class HipOps:
         side = aux if act == 3 else residual
         if side is not None and (tuple(side.shape) != (M, N) or side.stride(1) != 1):
             raise OccfError("linear_stream: residual / aux must be [M, N] with unit column stride")
+        if row_scale is not None and (M % (int(XY) * int(S)) or row_scale.numel() != M // int(XY)):
+            raise OccfError(f"linear_stream: row_scale needs one entry per (sample, slice): {M} rows, XY = {XY}, S = {S}, "
+                            f"{row_scale.numel()} entries")
         out = torch.empty((M, N), dtype=self.f32, device=x.device)
         pre = torch.empty((M, N), dtype=self.f32, device=x.device) if pre_out else None
         rc = self.lib.occf_linear_stream_fwd(

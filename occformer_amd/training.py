@@ -184,7 +184,12 @@ def _candidate_logits_voxel_major(ops, rows_e, feat, S, G, vol_shape, cand_zyx, 
     reads per point and set (2.18 ms at the 200-grid, r05n); here the same contraction is written VOXEL-major --
     [V, S x Gp] with Gp = G rounded up to 4 columns, one streaming linear over the mask features -- so that a candidate
     reads 8 contiguous Gp-float rows (0.37 ms for the ten sets + the linear).  None when the geometry does not fit (the
-    caller then samples the channel-major volume)."""
+    caller then samples the channel-major volume).
+
+    The ranking logits come from a contraction of their own (freshly split, zero-padded rows), not from ``dense``: in
+    the default three-term arithmetic both carry ~2^-16 per product and rank alike (tests/test_training.py compares this
+    helper with ``point_sample_3d(dense)``); in the one-term ``bf16`` mode their roundings differ and a near-tie in
+    |logit| may be ranked the other way -- a swapped candidate weighs 1 / num_points of one mask loss."""
     if ops.precision == "f32" or G == 0 or feat.dim() != 2 or feat.stride(1) != 1:
         return None
     Gp = (G + 3) // 4 * 4

@@ -386,6 +386,17 @@ def test_linear_stream_training_epilogues(be, monkeypatch, M, K, N):
     out = ops.linear_stream(xd, sp, bd, 0, residual=rd, row_scale=be.to(scale), XY=XY, S=S)
     ref = r.double() + scale.double()[torch.arange(M) % S][:, None] * z_ref
     assert float((out.cpu() - ref.float()).abs().max()) < 3e-5 * float(ref.abs().max())
+    # (b') two samples: sample index (row / (XY S)) * S + row % S, a scale vector of B * S entries; and a
+    # row count that is not whole samples is refused instead of reading past the vector
+    if M % (2 * S) == 0:
+        XY2 = M // (2 * S)
+        scale2 = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25, 2.0, 0.0, 0.5, 1.0, 0.25][:2 * S])
+        out = ops.linear_stream(xd, sp, bd, 0, residual=rd, row_scale=be.to(scale2), XY=XY2, S=S)
+        rows = torch.arange(M)
+        ref = r.double() + scale2.double()[(rows // (XY2 * S)) * S + rows % S][:, None] * z_ref
+        assert float((out.cpu() - ref.float()).abs().max()) < 3e-5 * float(ref.abs().max())
+    with pytest.raises(Exception):
+        ops.linear_stream(xd, sp, bd, 0, residual=rd, row_scale=be.to(scale), XY=XY + 1, S=S)
     # (c)
     aux = paramgen.tensor("se.a", (M, N), 5, 1.5)
     a64 = aux.double()

@@ -274,3 +274,29 @@ def test_device_confusion_matrix_and_miou_match_numpy():
     assert np.array_equal(hist.numpy(), ref_hist)
     ref = np.nanmean(TR.per_class_iu(ref_hist))
     assert abs(float(TR.mean_iou_device(hist)) - ref) < 1e-12
+
+
+@pytest.mark.parametrize("S,G,dims", [(3, 5, (6, 5, 4)), (10, 6, (5, 4, 8)), (2, 17, (4, 4, 4)), (10, 7, (3, 4, 2))])
+def test_candidate_logits_voxel_major(be, S, G, dims):
+    """training._candidate_logits_voxel_major (the importance sampling's ranking logits contracted voxel-major and read
+    through the channels-last sampler) against the path it replaces -- point_sample_3d of the channel-major logits
+    [S, G, X, Y, Z] (mmdet_utils.py:91-246 via mask2former_nusc_occ.py:253-262): G % 4 != 0 (padded columns), S * Gp
+    beyond one 64-column block, and S * Gp > 256 where the helper declines (the caller keeps the dense path)."""
+    from occformer_amd.training import _candidate_logits_voxel_major
+    E, P3 = 32, 50
+    X, Y, Z = dims
+    V = X * Y * Z
+    rows_e = paramgen.tensor("cl_rows", (S * G, E), 1)
+    feat = paramgen.tensor("cl_feat", (V, E), 2)
+    cand = paramgen.uniform("cl_cand", (S, P3, 3), 3)                     # (x, y, z) in [0, 1]
+    dense = (rows_e @ feat.t()).view(S, G, X, Y, Z)
+    ops = be.ops
+    got = _candidate_logits_voxel_major(ops, be.to(rows_e), be.to(feat), S, G, (X, Y, Z), be.to(cand.flip(-1).contiguous()),
+                                        "zeros")
+    Gp = (G + 3) // 4 * 4
+    if S * Gp > 256:
+        assert got is None
+        return
+    assert got is not None and tuple(got.shape) == (S, G, P3)
+    ref = ops.point_sample_3d(be.to(dense), be.to(cand.flip(-1).contiguous()), False, "zeros")
+    assert float((got.cpu() - ref.cpu()).abs().max()) <= 2e-4 * float(ref.abs().max())
