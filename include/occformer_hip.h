@@ -327,6 +327,38 @@ int occf_conv3x3x3_wino_fwd(const float* x, const uint16_t* wfrag_hi, const uint
 long occf_absmax_slot_words(void);
 int occf_absmax_f32(const float* x, long rows, int cols, long ld, uint32_t* slot, void* stream);
 
+/* ------------------------------------------------------------------ decoder rows (inference) ------ */
+
+/* The occupancy decoder's per-query work between its attention kernels as two kernels per layer
+ * (DetrTransformerDecoderLayer ('cross_attn','norm','self_attn','norm','ffn','norm') + forward_head's per-query half,
+ * P/occformer/mask2former/mask2former_nusc_occ.py:426-456, 640-667; csrc/decoder_rows.hip).  rows = B * Q query rows of
+ * E channels; qpos [Q, E] is added per sample (row % Q).  Every weight matrix W [N, K] enters as a PAIR of fragment
+ * arrays {hi, lo} (a host array of two device pointers) made by occf_decoder_rows_pack (bf16 split, order
+ * [ceil(N/16)][K/32][64 lanes][8]; occf_decoder_rows_pack_elems uint16 elements per array, 0: K % 32 != 0).
+ *   K1: q1 = LN(attn_out Wo^T + bo + q_in); [qs | ks] = (q1 + qpos) [Wq; Wk]^T + b_qk; vs = q1 Wv^T + b_v
+ *   K2 (mode 1): q2 = LN1(attn_out Wo^T + bo + q_in); q3 = LN2(relu(q2 W1^T + b1) W2^T + b2 + q2);
+ *       d = LNpost(q3); cls = d Wc^T + bc [rows, n_cls]; mask_embed = W_me2 relu(W_me1 relu(W_me0 d)) (+ biases);
+ *       qx = (q3 + qpos) Wqnext^T + b_qnext (f_qnext NULL: skipped).  mode 0: q_in IS q3 (the set before layer 0).
+ * E % 32 == 0, H % 32 == 0, LDS: 16 rows of all activations (160 KB at E = 192, H = 1536); else OCCF_ESHAPE. */
+long occf_decoder_rows_pack_elems(int N, int K);
+int occf_decoder_rows_pack(const float* w, long ld, int N, int K, uint16_t* f_hi, uint16_t* f_lo, void* stream);
+int occf_decoder_rows_k1(const float* attn_out, const float* q_in, const float* qpos, int rows, int E, int Q,
+                         const uint16_t* const* f_out, const float* b_out, const float* ln_gamma,
+                         const float* ln_beta, float ln_eps, const uint16_t* const* f_qk, const float* b_qk,
+                         const uint16_t* const* f_v, const float* b_v, float* q1, float* qs, float* ks,
+                         float* vs, void* stream);
+int occf_decoder_rows_k2(int mode, const float* attn_out, const float* q_in, const float* qpos, int rows,
+                         int E, int H, int Q, const uint16_t* const* f_out, const float* b_out,
+                         const float* ln1_gamma, const float* ln1_beta, float ln1_eps,
+                         const uint16_t* const* f_ffn1, const float* b_ffn1, const uint16_t* const* f_ffn2,
+                         const float* b_ffn2, const float* ln2_gamma, const float* ln2_beta, float ln2_eps,
+                         const float* post_gamma, const float* post_beta, float post_eps,
+                         const uint16_t* const* f_cls, const float* b_cls, int n_cls,
+                         const uint16_t* const* f_me0, const float* b_me0, const uint16_t* const* f_me1,
+                         const float* b_me1, const uint16_t* const* f_me2, const float* b_me2,
+                         const uint16_t* const* f_qnext, const float* b_qnext, float* q3, float* cls,
+                         float* mask_embed, float* qx, void* stream);
+
 /* ------------------------------------------------------------------ DepthNet's DCN ------ */
 
 /* Deformable im2col of mmcv-full 1.4.0 `deform_conv2d` (DCNv1; third-party op behind

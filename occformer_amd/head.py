@@ -182,6 +182,15 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
         cls_pred = fused.linear(d, self.cls_embed)
         me = self.mask_embed
         mask_embed = fused.linear(fused.linear(fused.linear(d, me[0], act=1), me[2], act=1), me[4])
+        return self._head_from_embed(cls_pred, mask_embed, mask_feat_tok, vol_shape, target_shape, mask_feat_split,
+                                     want_mask, want_attn)
+
+    def _head_from_embed(self, cls_pred, mask_embed, mask_feat_tok, vol_shape, target_shape, mask_feat_split, want_mask,
+                         want_attn):
+        """forward_head from the class logits / mask embeddings on (inference): the mask contraction and the
+        preserve-pooling attention mask"""
+        ops = get_ops()
+        d = mask_embed
         B, Q = mask_embed.shape[:2]
         if not want_mask and want_attn and mask_feat_split is not None and Q <= 128 and ops.use_fused_mask_pool:
             fusedp = ops.mask_gemm_pool(mask_embed, mask_feat_split, vol_shape, target_shape)
@@ -273,6 +282,98 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
             out.append((k, v))
         return out
 
+    def _decoder_rows_pack(self):
+        """every weight of the decoder's per-query chain in the fragment order csrc/decoder_rows.hip reads (per weight
+        version; inference only), or None when the kernels do not apply (arithmetic mode, switch, widths)"""
+        ops = get_ops()
+        dec = self.transformer_decoder
+        E = self.decoder_embed_dims
+        if not ops.use_decoder_rows or ops.precision != "bf16x3" or E % 32 or self.training:
+            return None
+        params = list(dec.parameters()) + list(self.cls_embed.parameters()) + list(self.mask_embed.parameters())
+        ver = fused.param_version(*params) + (id(ops),)
+        cache = getattr(self, "_rows_pack", None)
+        if cache is not None and cache[0] == ver:
+            return cache[1]
+        with torch.no_grad():
+            def lin(w, b):
+                f = ops.decoder_rows_pack(w.detach().float().contiguous())
+                return None if f is None else (f, None if b is None else b.detach().float().contiguous())
+
+            def ln(n):
+                return (n.weight.detach(), n.bias.detach(), n.eps)
+            layers = []
+            for l in dec.layers:
+                xa, sa = l.attentions[0].attn, l.attentions[1].attn
+                f1, f2 = l.ffns[0].layers[0][0], l.ffns[0].layers[1]
+                if l.ffns[0].act != "relu":
+                    layers = None
+                    break
+                layers.append(dict(
+                    xq=lin(xa.in_proj_weight[:E], xa.in_proj_bias[:E]), out0=lin(xa.out_proj.weight, xa.out_proj.bias),
+                    ln0=ln(l.norms[0]), qk=lin(sa.in_proj_weight[:2 * E], sa.in_proj_bias[:2 * E]),
+                    v=lin(sa.in_proj_weight[2 * E:], sa.in_proj_bias[2 * E:]),
+                    out1=lin(sa.out_proj.weight, sa.out_proj.bias), ln1=ln(l.norms[1]),
+                    ffn1=lin(f1.weight, f1.bias), ffn2=lin(f2.weight, f2.bias), ln2=ln(l.norms[2]), H=f1.weight.shape[0]))
+            me = self.mask_embed
+            head = dict(post=ln(dec.post_norm), cls=lin(self.cls_embed.weight, self.cls_embed.bias),
+                        n_cls=self.cls_embed.weight.shape[0], me0=lin(me[0].weight, me[0].bias),
+                        me1=lin(me[2].weight, me[2].bias), me2=lin(me[4].weight, me[4].bias))
+        ok = layers is not None and all(v is not None for l in layers for v in l.values()) and \
+            all(v is not None for v in head.values()) and me[4].weight.shape[0] == E and \
+            all(l["H"] % 32 == 0 and (4 * E * 4 + 2 * (E + 8) * 2 + 2 * (l["H"] + 8) * 2) * 16 <= 160 * 1024 for l in layers)
+        pack = (layers, head) if ok else None
+        self._rows_pack = (ver, pack)
+        return pack
+
+    def _cross_kv(self, layer, key, key_with_pos):
+        """this layer's projected cross-attention keys / values (when the stacked per-level projection does not apply)"""
+        ops = get_ops()
+        a = layer.attentions[0].attn
+        E = self.decoder_embed_dims
+        w, b = a.in_proj_weight.detach(), a.in_proj_bias.detach()
+        sp = fused.split_weight(a.in_proj_weight)
+        part = (lambda lo, hi: None) if sp is None else (lambda lo, hi: (sp[0][lo:hi], sp[1][lo:hi]))
+        k = ops.linear(key_with_pos, w[E:2 * E], b[E:2 * E], w_split=part(E, 2 * E))
+        v = ops.linear(key, w[2 * E:], b[2 * E:], w_split=part(2 * E, 3 * E))
+        return k, v
+
+    def _forward_rows(self, pack, q, qpos, keys, keys_pp, kv_all, mask_tok, vol_shape, shapes, mf_split, last_only):
+        """the decoder loop of ``forward`` (inference) on csrc/decoder_rows.hip: per layer cross-attention -> K1 ->
+        self-attention -> K2 -> mask contraction + pooling; the same values as the launch-per-op loop"""
+        ops = get_ops()
+        layers_pk, head = pack
+        nl = self.num_transformer_feat_level
+        layers = self.transformer_decoder.layers
+        n_layers = len(layers)
+        q = q.contiguous()
+        qpos = qpos[0].contiguous()                                   # [Q, E]
+        cls_list, mask_list = [], []
+        _, cls, me, qx = ops.decoder_rows_k2(None, q, qpos, None, head, layers_pk[0]["xq"])
+        cls, mp, am = self._head_from_embed(cls, me, mask_tok, vol_shape, shapes[0], mf_split, not last_only, True)
+        if not last_only:
+            cls_list.append(cls)
+            mask_list.append(mp)
+        for i, layer in enumerate(layers):
+            lv = i % nl
+            if kv_all is not None:
+                j = i // nl
+                k, v = kv_all[lv][0][:, j], kv_all[lv][1][:, j]
+            else:
+                k, v = self._cross_kv(layer, keys[lv], keys_pp[lv])
+            o = ops.masked_attention(qx, k, v, self.num_heads, am[0], am[1])
+            q1, qs, ks, vs = ops.decoder_rows_k1(o, q, qpos, layers_pk[i])
+            o2 = ops.masked_attention(qs, ks, vs, self.num_heads, None, None)
+            last = i == n_layers - 1
+            q, cls, me, qx = ops.decoder_rows_k2(o2, q1, qpos, layers_pk[i], head,
+                                                 None if last else layers_pk[i + 1]["xq"], want_q=not last)
+            cls, mp, am = self._head_from_embed(cls, me, mask_tok, vol_shape, shapes[(i + 1) % nl], mf_split,
+                                                last or not last_only, not last)
+            if last or not last_only:
+                cls_list.append(cls)
+                mask_list.append(mp)
+        return cls_list, mask_list
+
     # -- mask2former_nusc_occ.py:589-689
     def forward(self, voxel_feats, img_metas=None, last_only=False, **kwargs):
         """Reference contract: (list[10] cls, list[10] mask_pred).  ``last_only=True`` (what
@@ -301,6 +402,10 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
             mask_tok = mask_tok.contiguous()
         n_layers = len(self.transformer_decoder.layers)
         cls_list, mask_list = [], []
+        rows_pack = None if self.training else self._decoder_rows_pack()
+        if rows_pack is not None:
+            return self._forward_rows(rows_pack, q, qpos, keys, keys_pp, self._project_level_tokens(keys, keys_pp),
+                                      mask_tok, vol_shape, shapes, mf_split, last_only)
         cls, mp, am = self.forward_head(q, mask_tok, vol_shape, shapes[0], mf_split, want_mask=not last_only)
         if not last_only:
             cls_list.append(cls)

@@ -44,6 +44,8 @@ class HipOps:
         self.use_wino = os.environ.get("OCCF_WINO", "1") == "1"
         # the data gradients of those convolutions on two fp16-piece products (dy in ONE piece; OCCF_DGRAD_F16=0: three)
         self.dgrad_f16 = os.environ.get("OCCF_DGRAD_F16", "1") == "1"
+        # the decoder's per-query chain as two kernels per layer in inference (csrc/decoder_rows.hip); 0 = one launch per op
+        self.use_decoder_rows = os.environ.get("OCCF_DECODER_ROWS", "1") == "1"
         self.swin_frag = os.environ.get("OCCF_SWIN_FRAG", "1") == "1"
         # fused mask contraction + preserve-pooling (the intermediate mask logits are never written)
         self.use_fused_mask_pool = os.environ.get("OCCF_FUSED_MASK_POOL", "1") == "1"
@@ -254,6 +256,58 @@ class HipOps:
                    self._ptr(row_open, self.i32, B * Q),
                    self._ptr(out), self._ptr(ws), need, B, Q, L, E, heads, self._stream())
         return out
+
+    # ---- the decoder's per-query chain as two kernels per layer (csrc/decoder_rows.hip, inference)
+    def decoder_rows_pack(self, w):
+        """weight [N, K] fp32 -> the (hi, lo) fragment pair csrc/decoder_rows.hip reads, or None (K % 32 != 0)"""
+        N, K = w.shape
+        n = self.lib.occf_decoder_rows_pack_elems(N, K)
+        if n <= 0 or w.stride(1) != 1:
+            return None
+        fh = torch.empty((n,), dtype=torch.int16, device=w.device)
+        fl = torch.empty((n,), dtype=torch.int16, device=w.device)
+        self._call("occf_decoder_rows_pack", self._ptr(w, self.f32), w.stride(0), N, K, self._ptr(fh), self._ptr(fl),
+                   self._stream())
+        return fh, fl
+
+    @staticmethod
+    def _pair(f):
+        return None if f is None else (ctypes.c_void_p * 2)(f[0].data_ptr(), f[1].data_ptr())
+
+    def decoder_rows_k1(self, attn_out, q_in, qpos, pk):
+        """pk: dict of (fragment pair, bias) per linear + LayerNorm triples (head.py: _decoder_rows_pack)
+        -> (q1, qs, ks, vs), each [B, Q, E]"""
+        B, Q, E = q_in.shape
+        outs = [torch.empty((B, Q, E), dtype=self.f32, device=q_in.device) for _ in range(4)]
+        g, bt, eps = pk["ln0"]
+        self._call("occf_decoder_rows_k1", self._ptr(attn_out, self.f32, B * Q * E), self._ptr(q_in, self.f32, B * Q * E),
+                   self._ptr(qpos, self.f32, Q * E), B * Q, E, Q, self._pair(pk["out0"][0]), self._ptr(pk["out0"][1]),
+                   self._ptr(g), self._ptr(bt), float(eps), self._pair(pk["qk"][0]), self._ptr(pk["qk"][1]),
+                   self._pair(pk["v"][0]), self._ptr(pk["v"][1]), *(self._ptr(o) for o in outs), self._stream())
+        return tuple(outs)
+
+    def decoder_rows_k2(self, attn_out, q_in, qpos, pk, head, nxt, want_q=True):
+        """``pk`` None: head only (q_in = the queries).  head: post_norm / cls / mask_embed pack; nxt: the NEXT layer's
+        cross-attention query projection (pair, bias) or None.  -> (q3 or None, cls [B, Q, n_cls], mask_embed, qx or None)"""
+        B, Q, E = q_in.shape
+        dev = q_in.device
+        n_cls = head["n_cls"]
+        q3 = torch.empty((B, Q, E), dtype=self.f32, device=dev) if (pk is not None and want_q) else None
+        cls = torch.empty((B, Q, n_cls), dtype=self.f32, device=dev)
+        me = torch.empty((B, Q, E), dtype=self.f32, device=dev)
+        qx = torch.empty((B, Q, E), dtype=self.f32, device=dev) if nxt is not None else None
+        z = ctypes.c_void_p(0)
+        lin = lambda e: (self._pair(e[0]), self._ptr(e[1])) if e is not None else (z, z)
+        ln = lambda e: (self._ptr(e[0]), self._ptr(e[1]), float(e[2])) if e is not None else (z, z, 0.0)
+        H = pk["H"] if pk is not None else 32
+        self._call("occf_decoder_rows_k2", 1 if pk is not None else 0,
+                   self._ptr(attn_out, self.f32, B * Q * E) if pk is not None else z, self._ptr(q_in, self.f32, B * Q * E),
+                   self._ptr(qpos, self.f32, Q * E), B * Q, E, H, Q,
+                   *lin(pk["out1"] if pk else None), *ln(pk["ln1"] if pk else None),
+                   *lin(pk["ffn1"] if pk else None), *lin(pk["ffn2"] if pk else None), *ln(pk["ln2"] if pk else None),
+                   *ln(head["post"]), *lin(head["cls"]), n_cls, *lin(head["me0"]), *lin(head["me1"]), *lin(head["me2"]),
+                   *lin(nxt), self._ptr(q3), self._ptr(cls), self._ptr(me), self._ptr(qx), self._stream())
+        return q3, cls, me, qx
 
     def upsample_classify(self, mask_pred, cls, occ_size):
         B, Q, X, Y, Z = mask_pred.shape

@@ -60,5 +60,22 @@ grep -i "gated differently\|whole gradient\|passed\|failed\|error\|^real" $O/r06
 tail -3 $O/r06c_bench_train.err
 brief $O/r06c_bench_train.json
 ;;
+d)  # decoder rows kernels: tests, forward pair, forward kernel statistics
+( time timeout 900 python -m pytest tests/test_attn_ops.py tests/test_switches.py tests/test_modules_golden.py -m gpu -q -p no:cacheprovider -k "decoder_rows or every_switch or head" ) 2>&1 | grep -v "MIOpen(HIP)" | tail -4 | tee $O/r06d_pytest_decoder_rows.log
+for v in 0 1; do
+  OCCF_DECODER_ROWS=$v timeout 400 python bench.py --mode forward --check --steps 30 --warmup 3 --no-cpu-baseline > $O/r06d_bench_fwd_rows$v.json 2> $O/r06d_bench_fwd_rows$v.err; echo "fwd rows=$v rc=$?"
+  brief $O/r06d_bench_fwd_rows$v.json
+  python -c "
+import json; d=json.load(open('$O/r06d_bench_fwd_rows$v.json')); print('  stages', d.get('stages_ms'))"
+  OCCF_DECODER_ROWS=$v timeout 400 python bench.py --mode forward --from-images --steps 30 --warmup 3 > $O/r06d_bench_fwd_from_images_rows$v.json 2> $O/r06d_bench_fwd_from_images_rows$v.err; echo "fwd from images rows=$v rc=$?"
+  python -c "
+import json; d=json.load(open('$O/r06d_bench_fwd_from_images_rows$v.json')); print('  from images', round(d['value'],2), 'samples/s', round(d['ms_per_step'],2), 'ms', d.get('stages_ms'))"
+done
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/r06d_prof_fwd -- python $R/bench.py --mode forward --steps 10 --warmup 2 --no-cpu-baseline > $R/$O/r06d_prof_fwd.log 2>&1 ; echo "rocprof fwd rc=$?"
+cd $R
+python scripts/summarize_prof.py $O/r06d_prof_fwd > $O/r06d_fwd_kernel_stats.txt 2>&1 ; head -40 $O/r06d_fwd_kernel_stats.txt | cut -c1-150
+find $O/r06d_prof_fwd -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
+;;
 *) echo "unknown stage"; exit 2;;
 esac

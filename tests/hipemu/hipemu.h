@@ -248,6 +248,29 @@ static inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c) {
   wave_sync();
   return d;
 }
+// 16x16x32 bf16: lane l supplies A[i=l&15][k=8*(l>>4)+e], B[k=8*(l>>4)+e][j=l&15], e=0..7; D reg r: row=4*(l>>4)+r, col=l&15.
+static inline emu_f32x4 emu_mfma_f32_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c) {
+  using namespace hipemu;
+  Wave& w = g_blk->waves[cur().wave];
+  int l = cur().lane;
+  memcpy(w.slot[l], &a, 16);
+  memcpy(w.slot[l] + 16, &b, 16);
+  wave_sync();
+  emu_f32x4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    int i = 4 * (l >> 4) + r, j = l & 15;
+    float acc = c[r];
+    for (int g = 0; g < 4; ++g) {
+      emu_bf16x8 av, bv;
+      memcpy(&av, w.slot[g * 16 + i], 16);
+      memcpy(&bv, w.slot[g * 16 + j] + 16, 16);
+      for (int e = 0; e < 8; ++e) acc += emu_bf16_to_f32(av[e]) * emu_bf16_to_f32(bv[e]);
+    }
+    d[r] = acc;
+  }
+  wave_sync();
+  return d;
+}
 // fp16 <-> fp32 in software (round to nearest even, subnormals kept): the host build does not rely on F16C
 static inline uint16_t emu_f32_to_f16(float f) {
   uint32_t u;

@@ -202,3 +202,60 @@ def test_swin_attention_fused(be, monkeypatch, X, Y, S, shift, B, packed):
     assert out is not None
     out = out.cpu().view(B, X, Y, S, C).permute(0, 3, 1, 2, 4).reshape(B * S, X * Y, C)
     assert torch.allclose(out, ref, atol=2e-4, rtol=2e-4), float((out - ref).abs().max())
+
+
+@pytest.mark.parametrize("B,Q,E,H,n_cls", [(1, 100, 192, 1536, 18), (2, 37, 64, 96, 21)])
+def test_decoder_rows_kernels(be, B, Q, E, H, n_cls):
+    """csrc/decoder_rows.hip: the decoder layer's per-query chain as two kernels (K1 after the cross-attention, K2 after
+    the self-attention, K2 in head-only mode for the prediction set in front of layer 0) against the same chain in
+    fp64 torch -- mmcv's DetrTransformerDecoderLayer order ('cross_attn','norm','self_attn','norm','ffn','norm') with
+    the positional term added to q and k only, and forward_head's post_norm / cls_embed / mask_embed
+    (mask2former_nusc_occ.py:426-456, 640-667).  Rows that do not fill the last 16-row workgroup; two samples (qpos per
+    sample); a class count that is not a multiple of 16."""
+    import torch.nn.functional as F
+    ops = be.ops
+    t = lambda n, shp, sc=1.0: paramgen.tensor("dr." + n, shp, 1, sc)
+    lin = lambda n, N, K: (t(n + ".w", (N, K), K ** -0.5), t(n + ".b", (N,), 0.2))
+    ln = lambda n: (1 + t(n + ".g", (E,), 0.2), t(n + ".bt", (E,), 0.2), 1e-5)
+    W = {n: lin(n, *nk) for n, nk in dict(out0=(E, E), qk=(2 * E, E), v=(E, E), out1=(E, E), ffn1=(H, E), ffn2=(E, H),
+                                           cls=(n_cls, E), me0=(E, E), me1=(E, E), me2=(E, E), xq=(E, E)).items()}
+    N = {n: ln(n) for n in ("ln0", "ln1", "ln2", "post")}
+    o, q, o2 = t("o", (B, Q, E)), t("q", (B, Q, E)), t("o2", (B, Q, E))
+    qpos = t("qpos", (Q, E))
+    d64 = lambda x: x.double()
+    L = lambda x, n: F.linear(x, d64(W[n][0]), d64(W[n][1]))
+    LN = lambda x, n: F.layer_norm(x, (E,), d64(N[n][0]), d64(N[n][1]), N[n][2])
+    pk = lambda n: (ops.decoder_rows_pack(be.to(W[n][0])), be.to(W[n][1]))
+    nd = lambda n: (be.to(N[n][0]), be.to(N[n][1]), N[n][2])
+    layer = dict(out0=pk("out0"), ln0=nd("ln0"), qk=pk("qk"), v=pk("v"), out1=pk("out1"), ln1=nd("ln1"), ffn1=pk("ffn1"),
+                 ffn2=pk("ffn2"), ln2=nd("ln2"), H=H)
+    head = dict(post=nd("post"), cls=pk("cls"), n_cls=n_cls, me0=pk("me0"), me1=pk("me1"), me2=pk("me2"))
+    od, qd, o2d, qposd = be.to(o, q, o2, qpos)
+    # K1
+    q1r = LN(L(d64(o), "out0") + d64(q), "ln0")
+    qkr = L(q1r + d64(qpos), "qk")
+    q1, qs, ks, vs = ops.decoder_rows_k1(od, qd, qposd, layer)
+    tol = lambda ref: 3e-5 * float(ref.abs().max())
+    assert float((q1.cpu() - q1r).abs().max()) < tol(q1r)
+    assert float((qs.cpu() - qkr[..., :E]).abs().max()) < tol(qkr) and float((ks.cpu() - qkr[..., E:]).abs().max()) < tol(qkr)
+    vr = L(q1r, "v")
+    assert float((vs.cpu() - vr).abs().max()) < tol(vr)
+    # K2, whole chain (on the kernel's own q1 as the residual operand)
+    q1x = d64(q1.cpu())
+    q2r = LN(L(d64(o2), "out1") + q1x, "ln1")
+    q3r = LN(L(F.relu(L(q2r, "ffn1")), "ffn2") + q2r, "ln2")
+    dr = LN(q3r, "post")
+    clsr = L(dr, "cls")
+    mer = L(F.relu(L(F.relu(L(dr, "me0")), "me1")), "me2")
+    qxr = L(q3r + d64(qpos), "xq")
+    q3, cls, me, qx = ops.decoder_rows_k2(o2d, q1, qposd, layer, head, pk("xq"))
+    for got, ref in ((q3, q3r), (cls, clsr), (me, mer), (qx, qxr)):
+        assert tuple(got.shape) == tuple(ref.shape)
+        assert float((got.cpu() - ref).abs().max()) < tol(ref)
+    # K2, head only, no next layer
+    none, cls0, me0, qx0 = ops.decoder_rows_k2(None, qd, qposd, None, head, None)
+    d0 = LN(d64(q), "post")
+    assert none is None and qx0 is None
+    assert float((cls0.cpu() - L(d0, "cls")).abs().max()) < tol(clsr)
+    me0r = L(F.relu(L(F.relu(L(d0, "me0")), "me1")), "me2")
+    assert float((me0.cpu() - me0r).abs().max()) < tol(me0r)

@@ -18,6 +18,8 @@ SWITCHES = [
     {"precision": "f32"},                      # OCCF_PRECISION=f32
     {"halo_frag": False},                      # OCCF_HALO_FRAG=0: weight slabs through LDS instead of global fragments
     {"swin_frag": False},                      # OCCF_SWIN_FRAG=0: row-major weights in the fused Swin kernel
+    {"use_wino": False},                       # OCCF_WINO=0: the direct 27-tap halo kernel instead of Winograd F(2, 3)
+    {"use_decoder_rows": False},               # OCCF_DECODER_ROWS=0: the decoder's per-query chain as one launch per op
 ]
 
 
@@ -48,7 +50,8 @@ def test_every_switch_gives_the_same_forward(be, monkeypatch):
     saved = {k: getattr(be.ops, k) for s in SWITCHES for k in s}
     # (the host emulation is ~100x slower than the chip: the CPU run covers the three paths with their own kernels,
     # the GPU run all of them)
-    todo = SWITCHES if be.kind == "hip" else [SWITCHES[0], SWITCHES[1], SWITCHES[2], SWITCHES[5], SWITCHES[6]]
+    todo = SWITCHES if be.kind == "hip" else [SWITCHES[0], SWITCHES[1], SWITCHES[2], SWITCHES[5], SWITCHES[6],
+                                              SWITCHES[8], SWITCHES[9]]
     try:
         ref = None
         for sw in todo:
