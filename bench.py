@@ -68,8 +68,9 @@ class KernelCensus:
                 tensors = [t for t in list(a) + list(kw.values()) + list(outs) if torch.is_tensor(t)]
                 nbytes = sum(t.numel() * t.element_size() for t in {t.data_ptr(): t for t in tensors}.values())
                 self.records.setdefault(_name, []).append((e0, e1, nbytes, self.ops.last_flops))
-                if _name in ("linear", "conv3d", "conv3d_wgrad", "conv3d_dgrad"):
-                    shp = (tuple(a[0].shape), tuple(a[1].shape) if torch.is_tensor(a[1]) else tuple(a[2]))
+                if _name in ("linear", "conv3d", "conv3d_wgrad", "conv3d_dgrad", "linear_wgrad", "linear_stream"):
+                    second = a[1][0] if isinstance(a[1], (tuple, list)) and torch.is_tensor(a[1][0]) else a[1]
+                    shp = (tuple(a[0].shape), tuple(second.shape) if torch.is_tensor(second) else tuple(a[2]))
                     self.shapes.setdefault((_name, shp), []).append((e0, e1, self.ops.last_flops))
                 return out
 

@@ -326,6 +326,20 @@ int occf_conv3x3x3_wino_fwd(const float* x, const uint16_t* wfrag_hi, const uint
  * slot = occf_absmax_slot_words() uint32 words of device memory; two launches, no atomics. */
 long occf_absmax_slot_words(void);
 int occf_absmax_f32(const float* x, long rows, int cols, long ld, uint32_t* slot, void* stream);
+int occf_absmax_flat(const float* x, long n, uint32_t* slot, void* stream);   /* any length / alignment */
+
+/* Reproducible scatter sums (the op layer's ``deterministic`` mode, OCCF_DETERMINISTIC=1): the scatter kernels of the
+ * backward with their float atomics replaced by 64-bit FIXED-POINT integer atomics -- the same contributions add up to the
+ * same bits in any arrival order.  acc = a ZERO-FILLED int64 buffer shaped like the float result, slot = a scale slot
+ * holding the maximum of the scattered tensor (occf_absmax_*: contributions are that tensor times weights <= 1, scaled
+ * to < 2^30); occf_fx_to_f32 turns the sums back into floats (precision 2^-30 of that maximum). */
+int occf_point_sample_3d_bwd_fx(const float* dout, const float* pts, long long* acc, const uint32_t* slot, int N, int C,
+                                int X, int Y, int Z, long P, int shared_pts, int align_corners, int border_padding,
+                                long voxel_major_ld, void* stream);
+int occf_deform_col2im_fx(const float* x, const float* offset, const float* mask, const float* dcol, long long* acc,
+                          float* doffset, float* dmask, const uint32_t* slot, int BN, int H, int W, int C, int K,
+                          int stride, int pad, int dil, int groups, int deform_groups, void* stream);
+int occf_fx_to_f32(const long long* acc, float* out, long n, const uint32_t* slot, void* stream);
 
 /* ------------------------------------------------------------------ decoder rows (inference) ------ */
 

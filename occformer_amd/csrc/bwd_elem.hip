@@ -869,11 +869,16 @@ extern "C" int occf_upsample_add_bwd(const float* dout, float* dcoarse, int B, i
 // ======================================================================================= point sampling backward
 // d_vol[n, c, corner] += w_corner * dout[n, c, p]  (F.grid_sample's backward w.r.t. the input; the points carry
 // no gradient in the reference: they come from no_grad sampling).  d_vol must be zero-filled by the caller.
+// FX: dvol is a zero-filled int64 buffer of the same shape, the contributions enter in fixed point (occf_scatter_add):
+// the sums do not depend on the arrival order
+template <bool FX>
 __global__ void __launch_bounds__(256) point_sample_3d_bwd_kernel(const float* __restrict__ dout,
-                                                                  const float* __restrict__ pts, float* __restrict__ dvol,
+                                                                  const float* __restrict__ pts, void* __restrict__ dvol,
                                                                   int N, int C, int X, int Y, int Z, long P, int shared_pts,
                                                                   int align_corners, int border, long voxel_major_ld,
-                                                                  int cgroups) {
+                                                                  int cgroups, const uint32_t* __restrict__ slot) {
+  float fx_inv = 1.f;
+  const float fx_scale = FX ? occf_fx_scale(slot[0], fx_inv) : 1.f;
   // thread = (n, channel group, point), like the forward
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)N * cgroups * P) return;
@@ -902,7 +907,7 @@ __global__ void __launch_bounds__(256) point_sample_3d_bwd_kernel(const float* _
   // consumes as a row-major [voxels, rows] operand); otherwise [N, C, V]
   const long vstride = voxel_major_ld > 0 ? voxel_major_ld : 1;
   for (int c = cg; c < C; c += cgroups) {
-    float* v = voxel_major_ld > 0 ? dvol + ((long)n * C + c) : dvol + ((long)n * C + c) * V;
+    const long v0 = voxel_major_ld > 0 ? ((long)n * C + c) : ((long)n * C + c) * V;
     const float g = dout[((long)n * C + c) * P + pi];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -911,7 +916,7 @@ __global__ void __launch_bounds__(256) point_sample_3d_bwd_kernel(const float* _
       if (!ok) continue;
       const int zz = bz ? i1[0] : i0[0], yy = by ? i1[1] : i0[1], xx = bx ? i1[2] : i0[2];
       const float w = (bz ? t[0] : 1.f - t[0]) * (by ? t[1] : 1.f - t[1]) * (bx ? t[2] : 1.f - t[2]);
-      if (w != 0.f) atomicAdd(v + (((long)xx * Y + yy) * Z + zz) * vstride, w * g);
+      if (w != 0.f) occf_scatter_add<FX>(dvol, v0 + (((long)xx * Y + yy) * Z + zz) * vstride, w * g, fx_scale);
     }
   }
 }
@@ -922,9 +927,38 @@ extern "C" int occf_point_sample_3d_bwd(const float* dout, const float* pts, flo
   if (voxel_major_ld != 0 && voxel_major_ld < (long)N * C) return OCCF_EINVAL;
   if (P == 0) return 0;
   const int cgroups = occf_sample_cgroups(N, C, P);
-  hipLaunchKernelGGL(point_sample_3d_bwd_kernel, dim3(occf_cdiv((long)N * cgroups * P, 256)), dim3(256), 0,
-                     (hipStream_t)stream, dout, pts, dvol, N, C, X, Y, Z, P, shared_pts, align_corners, border_padding,
-                     voxel_major_ld, cgroups);
+  hipLaunchKernelGGL(point_sample_3d_bwd_kernel<false>, dim3(occf_cdiv((long)N * cgroups * P, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dout, pts, (void*)dvol, N, C, X, Y, Z, P, shared_pts, align_corners,
+                     border_padding, voxel_major_ld, cgroups, (const uint32_t*)nullptr);
+  OCCF_LAUNCH_CHECK();
+}
+
+// the same scatter in 64-bit fixed point (reproducible): acc = zero-filled int64 buffer shaped like dvol; slot = scale
+// slot holding max |dout| (occf_absmax_f32 / occf_absmax_flat on the same stream); occf_fx_to_f32 converts afterwards
+extern "C" int occf_point_sample_3d_bwd_fx(const float* dout, const float* pts, long long* acc, const uint32_t* slot,
+                                           int N, int C, int X, int Y, int Z, long P, int shared_pts, int align_corners,
+                                           int border_padding, long voxel_major_ld, void* stream) {
+  if (N <= 0 || C <= 0 || X <= 0 || Y <= 0 || Z <= 0 || P < 0 || !acc || !slot) return OCCF_EINVAL;
+  if (voxel_major_ld != 0 && voxel_major_ld < (long)N * C) return OCCF_EINVAL;
+  if (P == 0) return 0;
+  const int cgroups = occf_sample_cgroups(N, C, P);
+  hipLaunchKernelGGL(point_sample_3d_bwd_kernel<true>, dim3(occf_cdiv((long)N * cgroups * P, 256)), dim3(256), 0,
+                     (hipStream_t)stream, dout, pts, (void*)acc, N, C, X, Y, Z, P, shared_pts, align_corners,
+                     border_padding, voxel_major_ld, cgroups, slot);
+  OCCF_LAUNCH_CHECK();
+}
+
+__global__ void __launch_bounds__(256) fx_to_f32_kernel(const long long* __restrict__ acc, float* __restrict__ out, long n,
+                                                        const uint32_t* __restrict__ slot) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float inv;
+  (void)occf_fx_scale(slot[0], inv);
+  out[i] = (float)((double)acc[i] * (double)inv);
+}
+extern "C" int occf_fx_to_f32(const long long* acc, float* out, long n, const uint32_t* slot, void* stream) {
+  if (n <= 0 || !acc || !out || !slot) return OCCF_EINVAL;
+  hipLaunchKernelGGL(fx_to_f32_kernel, dim3(occf_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, acc, out, n, slot);
   OCCF_LAUNCH_CHECK();
 }
 

@@ -440,6 +440,12 @@ extern "C" int occf_absmax_f32(const float* x, long rows, int cols, long ld, uin
   OCCF_LAUNCH_CHECK();
 }
 
+extern "C" int occf_absmax_flat(const float* x, long n, uint32_t* slot, void* stream) {
+  if (!x || !slot || n <= 0) return OCCF_ESHAPE;
+  wg_absmax_flat(x, n, slot, (hipStream_t)stream);
+  OCCF_LAUNCH_CHECK();
+}
+
 static int conv_wino_tz(int Z) {
   const int TZ = Z >= 16 ? 16 : Z;
   if ((TZ != 16 && TZ != 8 && TZ != 4) || Z % TZ != 0) return 0;

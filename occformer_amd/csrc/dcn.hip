@@ -99,10 +99,15 @@ extern "C" int occf_modulated_deform_im2col(const float* x, const float* offset,
 // `mask` != NULL (DCNv2, mmcv `modulated_deformable_col2im` + `_coord`): the forward sample was scaled by the modulation
 // mk = mask[bn, dg*K*K + t, ho, wo], so dx and doffset carry the factor mk and dmask[bn, dg*K*K + t, ho, wo] =
 // <dcol, unscaled sample> (every element written).
+// FX: dx is a zero-filled int64 buffer, the scatter runs in fixed point (occf_scatter_add: reproducible sums)
+template <bool FX>
 __global__ void __launch_bounds__(256) deform_col2im_kernel(
     const float* __restrict__ x, const float* __restrict__ offset, const float* __restrict__ mask,
-    const float* __restrict__ dcol, float* __restrict__ dx, float* __restrict__ doffset, float* __restrict__ dmask,
-    int BN, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad, int dil, int groups, int dgroups) {
+    const float* __restrict__ dcol, void* __restrict__ dx, float* __restrict__ doffset, float* __restrict__ dmask,
+    int BN, int H, int W, int C, int Ho, int Wo, int K, int stride, int pad, int dil, int groups, int dgroups,
+    const uint32_t* __restrict__ slot) {
+  float fx_inv = 1.f;
+  const float fx_scale = FX ? occf_fx_scale(slot[0], fx_inv) : 1.f;
   const int KK = K * K;
   const int lane = threadIdx.x & 63;
   const long wid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -135,7 +140,7 @@ __global__ void __launch_bounds__(256) deform_col2im_kernel(
       const int g = c / cpg, cg = c - g * cpg;
       const float4 gc = *(const float4*)(dcol + (pix * groups + g) * KK * cpg + (long)t * cpg + cg);
       const float* xb = x + (long)bn * H * W * C + c;
-      float* db = dx + (long)bn * H * W * C + c;
+      const long db = (long)bn * H * W * C + c;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int yy = y0 + (k >> 1), xx = x0 + (k & 1);
@@ -146,12 +151,12 @@ __global__ void __launch_bounds__(256) deform_col2im_kernel(
         gy = fmaf(((k >> 1) ? 1.f : -1.f) * wx, dot, gy);
         gx = fmaf(((k & 1) ? 1.f : -1.f) * wy, dot, gx);
         gm = fmaf(wy * wx, dot, gm);
-        float* d = db + ((long)yy * W + xx) * C;
+        const long d = db + ((long)yy * W + xx) * C;
         const float wgt = wy * wx * mk;
-        atomicAdd(d + 0, wgt * gc.x);
-        atomicAdd(d + 1, wgt * gc.y);
-        atomicAdd(d + 2, wgt * gc.z);
-        atomicAdd(d + 3, wgt * gc.w);
+        occf_scatter_add<FX>(dx, d + 0, wgt * gc.x, fx_scale);
+        occf_scatter_add<FX>(dx, d + 1, wgt * gc.y, fx_scale);
+        occf_scatter_add<FX>(dx, d + 2, wgt * gc.z, fx_scale);
+        occf_scatter_add<FX>(dx, d + 3, wgt * gc.w, fx_scale);
       }
     }
   }
@@ -176,9 +181,9 @@ extern "C" int occf_deform_col2im(const float* x, const float* offset, const flo
   const int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1;
   const int Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
   const long waves = (long)BN * Ho * Wo * K * K * deform_groups;
-  hipLaunchKernelGGL(deform_col2im_kernel, dim3(occf_cdiv(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                     offset, (const float*)nullptr, dcol, dx, doffset, (float*)nullptr, BN, H, W, C, Ho, Wo, K, stride,
-                     pad, dil, groups, deform_groups);
+  hipLaunchKernelGGL(deform_col2im_kernel<false>, dim3(occf_cdiv(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     offset, (const float*)nullptr, dcol, (void*)dx, doffset, (float*)nullptr, BN, H, W, C, Ho, Wo, K,
+                     stride, pad, dil, groups, deform_groups, (const uint32_t*)nullptr);
   OCCF_LAUNCH_CHECK();
 }
 
@@ -191,8 +196,27 @@ extern "C" int occf_modulated_deform_col2im(const float* x, const float* offset,
   const int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1;
   const int Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
   const long waves = (long)BN * Ho * Wo * K * K * deform_groups;
-  hipLaunchKernelGGL(deform_col2im_kernel, dim3(occf_cdiv(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                     offset, mask, dcol, dx, doffset, dmask, BN, H, W, C, Ho, Wo, K, stride, pad, dil, groups,
-                     deform_groups);
+  hipLaunchKernelGGL(deform_col2im_kernel<false>, dim3(occf_cdiv(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     offset, mask, dcol, (void*)dx, doffset, dmask, BN, H, W, C, Ho, Wo, K, stride, pad, dil, groups,
+                     deform_groups, (const uint32_t*)nullptr);
+  OCCF_LAUNCH_CHECK();
+}
+
+// both col2im forms with the data-gradient scatter in 64-bit fixed point (reproducible): acc = zero-filled int64 buffer
+// shaped like dx, slot = scale slot holding max |dcol|; mask / dmask NULL = DCNv1.  occf_fx_to_f32 converts afterwards.
+extern "C" int occf_deform_col2im_fx(const float* x, const float* offset, const float* mask, const float* dcol,
+                                     long long* acc, float* doffset, float* dmask, const uint32_t* slot, int BN, int H,
+                                     int W, int C, int K, int stride, int pad, int dil, int groups, int deform_groups,
+                                     void* stream) {
+  if (BN <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || groups <= 0 || deform_groups <= 0 || !acc || !slot)
+    return OCCF_EINVAL;
+  if ((mask == nullptr) != (dmask == nullptr)) return OCCF_EINVAL;
+  if (C % groups || C % deform_groups || (C / groups) % 4 || (C / deform_groups) % 4) return OCCF_ESHAPE;
+  const int Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  const int Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  const long waves = (long)BN * Ho * Wo * K * K * deform_groups;
+  hipLaunchKernelGGL(deform_col2im_kernel<true>, dim3(occf_cdiv(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     offset, mask, dcol, (void*)acc, doffset, dmask, BN, H, W, C, Ho, Wo, K, stride, pad, dil, groups,
+                     deform_groups, slot);
   OCCF_LAUNCH_CHECK();
 }

@@ -27,6 +27,7 @@
 
 #define DR_ROWS 16
 #define DR_THREADS 512
+#define DR_RING 6          // k-steps of weight fragments in flight per wave (48 VGPRs)
 
 struct DrLinear {
   const uint16_t* fh;      // fragments [Npad / 16][K / 32][64 lanes][8]
@@ -110,18 +111,40 @@ __device__ __forceinline__ void dr_gemm(const DrSmem& s, const unsigned char* ih
   for (int nt = wave; nt < ntiles; nt += DR_THREADS / 64) {
     const uint16_t* ah = L.fh + ((long)nt * ksteps * 64 + lane) * 8;
     const uint16_t* al = L.fl + ((long)nt * ksteps * 64 + lane) * 8;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    bf16x8 wh = *(const bf16x8*)ah, wl = *(const bf16x8*)al;
-    for (int ks = 0; ks < ksteps; ++ks) {
-      const int kn = ks + 1 < ksteps ? ks + 1 : ks;              // (next k-step's weights in flight; clamped)
-      const bf16x8 nh = *(const bf16x8*)(ah + (long)kn * 512), nl = *(const bf16x8*)(al + (long)kn * 512);
-      const bf16x8 xh = *(const bf16x8*)(bh + ks * 64), xl = *(const bf16x8*)(bl + ks * 64);
-      acc = dr_mfma_16x16x32(wl, xh, acc);
-      acc = dr_mfma_16x16x32(wh, xl, acc);
-      acc = dr_mfma_16x16x32(wh, xh, acc);
-      wh = nh;
-      wl = nl;
+    // a ring of DR_RING k-steps of weight fragments in flight (K = 192: the whole tile at once): with one k-step ahead
+    // a wave paid a full L2 round trip per 3 MFMAs -- 131 us per K2 launch (r06d), latency, not bandwidth
+    bf16x8 rh[DR_RING], rl[DR_RING];
+#pragma unroll
+    for (int i = 0; i < DR_RING; ++i) {
+      const int kk = i < ksteps ? i : ksteps - 1;
+      rh[i] = *(const bf16x8*)(ah + (long)kk * 512);
+      rl[i] = *(const bf16x8*)(al + (long)kk * 512);
     }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};     // (even / odd k-steps: two dependency chains)
+    for (int ks0 = 0; ks0 < ksteps; ks0 += DR_RING) {
+#pragma unroll
+      for (int i = 0; i < DR_RING; ++i) {
+        const int ks = ks0 + i;
+        if (ks < ksteps) {
+          const bf16x8 xh = *(const bf16x8*)(bh + ks * 64), xl = *(const bf16x8*)(bl + ks * 64);
+          if (i & 1) {
+            acc1 = dr_mfma_16x16x32(rl[i], xh, acc1);
+            acc1 = dr_mfma_16x16x32(rh[i], xl, acc1);
+            acc1 = dr_mfma_16x16x32(rh[i], xh, acc1);
+          } else {
+            acc0 = dr_mfma_16x16x32(rl[i], xh, acc0);
+            acc0 = dr_mfma_16x16x32(rh[i], xl, acc0);
+            acc0 = dr_mfma_16x16x32(rh[i], xh, acc0);
+          }
+          const int kn = ks + DR_RING < ksteps ? ks + DR_RING : ksteps - 1;     // refill the slot (clamped: unconditional load)
+          rh[i] = *(const bf16x8*)(ah + (long)kn * 512);
+          rl[i] = *(const bf16x8*)(al + (long)kn * 512);
+        }
+      }
+    }
+    f32x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = acc0[r] + acc1[r];
     const int n = nt * 16 + g * 4;                                // this lane: features n .. n + 3 of query row j
     float v[4];
 #pragma unroll

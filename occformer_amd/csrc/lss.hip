@@ -266,49 +266,68 @@ extern "C" int occf_lift_splat_fwd(const float* depth, const float* feat, const 
   OCCF_LAUNCH_CHECK();
 }
 
-// Backward of the fused lift+splat (training): one wave per point.
+// Backward of the fused lift+splat (training): one wave per PIXEL (bn, hw), which walks the D depth bins of its ray
+// in order -- the D points of a pixel are the only contributions to that pixel's feature gradient, so it accumulates in
+// registers in a fixed order (no atomics, no memset, bit-reproducible; round 6: the first version was one wave per
+// point with float atomicAdd into d_feat, one of the five non-deterministic sums of the training step).
 //   d_depth[p]          = sum_c g[vox(p), c] * feat[bn, hw, c]
-//   d_feat[bn, hw, c]  += depth[p] * g[vox(p), c]        (atomic: D points share a pixel)
+//   d_feat[bn, hw, c]   = sum_d depth[p(d)] * g[vox(p(d)), c]
 __global__ void __launch_bounds__(256) lift_splat_bwd_kernel(
     const float* __restrict__ out_grad, const float* __restrict__ depth,
     const float* __restrict__ feat, const int32_t* __restrict__ vox, float* __restrict__ d_depth,
-    float* __restrict__ d_feat, long n_pts, int D, int HW, int C) {
+    float* __restrict__ d_feat, long n_pix, int D, int HW, int C) {
   const int lane = threadIdx.x & 63;
-  const long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (p >= n_pts) return;
-  const int v = vox[p];
-  float dd = 0.f;
-  if (v >= 0) {
-    const int DHW = D * HW;
-    const int bn = (int)(p / DHW);
-    const int hw = (int)((p - (long)bn * DHW) % HW);
-    const float dp = depth[p];
-    const float* g = out_grad + (long)v * C;
-    const float* fr = feat + ((long)bn * HW + hw) * C;
-    float* df = d_feat + ((long)bn * HW + hw) * C;
-    for (int c = lane; c < C; c += 64) {
-      const float gv = g[c];
-      dd += gv * fr[c];
-      atomicAdd(df + c, dp * gv);
+  const long px = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (px >= n_pix) return;
+  const int bn = (int)(px / HW), hw = (int)(px - (long)bn * HW);
+  const float* fr = feat + px * C;
+  float* df = d_feat + px * C;
+  for (int c0 = 0; c0 < C; c0 += 256) {                      // 4 channels per lane and pass (C = 128: one pass)
+    float f[4], acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + lane + 64 * e;
+      f[e] = c < C ? fr[c] : 0.f;
+      acc[e] = 0.f;
+    }
+    for (int d = 0; d < D; ++d) {
+      const long p = ((long)bn * D + d) * HW + hw;
+      const int v = vox[p];                                   // (wave-uniform)
+      float dd = 0.f;
+      if (v >= 0) {
+        const float dp = depth[p];
+        const float* g = out_grad + (long)v * C;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = c0 + lane + 64 * e;
+          const float gv = c < C ? g[c] : 0.f;
+          dd += gv * f[e];
+          acc[e] += dp * gv;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) dd += __shfl_xor(dd, o);
+      if (lane == 0) {
+        if (c0 == 0) d_depth[p] = dd;
+        else d_depth[p] += dd;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + lane + 64 * e;
+      if (c < C) df[c] = acc[e];
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) dd += __shfl_xor(dd, o);
-  if (lane == 0) d_depth[p] = dd;
 }
 
 extern "C" int occf_lift_splat_bwd(const float* out_grad, const float* depth, const float* feat,
                                    const int32_t* vox, float* d_depth, float* d_feat, long n_pts,
                                    int BN, int D, int HW, int C, void* stream) {
   if (n_pts <= 0 || BN <= 0 || D <= 0 || HW <= 0 || C <= 0) return OCCF_EINVAL;
+  if (n_pts != (long)BN * D * HW) return OCCF_EINVAL;       // (vox / depth cover every frustum point)
   hipStream_t st = (hipStream_t)stream;
-#ifndef OCCF_EMU
-  hipError_t e = hipMemsetAsync(d_feat, 0, sizeof(float) * (size_t)BN * HW * C, st);
-  if (e != hipSuccess) return (int)e;
-#else
-  memset(d_feat, 0, sizeof(float) * (size_t)BN * HW * C);
-#endif
-  hipLaunchKernelGGL(lift_splat_bwd_kernel, dim3(occf_cdiv(n_pts * 64, 256)), dim3(256), 0, st,
-                     out_grad, depth, feat, vox, d_depth, d_feat, n_pts, D, HW, C);
+  const long n_pix = (long)BN * HW;
+  hipLaunchKernelGGL(lift_splat_bwd_kernel, dim3(occf_cdiv(n_pix * 64, 256)), dim3(256), 0, st,
+                     out_grad, depth, feat, vox, d_depth, d_feat, n_pix, D, HW, C);
   OCCF_LAUNCH_CHECK();
 }

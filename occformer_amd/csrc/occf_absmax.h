@@ -61,4 +61,32 @@ static inline void wg_absmax(const float* x, long M, int N, long ld, uint32_t* s
 }
 
 
+// the same for a flat array of n floats (any alignment / length): scalar loads
+static __global__ void __launch_bounds__(256) wg_absmax_flat_kernel(const float* __restrict__ x, long n,
+                                                                    uint32_t* __restrict__ partial) {
+  __shared__ uint32_t wmax[4];
+  uint32_t m = 0u;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const uint32_t a = occf_f2u(x[i]) & 0x7FFFFFFFu;
+    m = a > m ? a : m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t t = (uint32_t)__shfl_xor((int)m, o);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+    partial[blockIdx.x] = a > b ? a : b;
+  }
+}
+static inline void wg_absmax_flat(const float* x, long n, uint32_t* slot, hipStream_t st) {
+  long blocks = (n + 256 * 16 - 1) / (256 * 16);
+  blocks = blocks < 1 ? 1 : (blocks > WG_ABSMAX_BLOCKS ? WG_ABSMAX_BLOCKS : blocks);
+  hipLaunchKernelGGL(wg_absmax_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, slot + 16);
+  hipLaunchKernelGGL(wg_absmax_finish_kernel, dim3(1), dim3(256), 0, st, slot + 16, (int)blocks, slot);
+}
+
 #define OCCF_ABSMAX_SLOT (16 + WG_ABSMAX_BLOCKS)   // uint32 words of a scale slot: [0] max bits, [1] 2^-k, [16 ...) partials

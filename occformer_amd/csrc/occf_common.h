@@ -129,6 +129,33 @@ uint32_t occf_f16_scale_bits(uint32_t amax_bits, uint32_t& inv, uint32_t headroo
   return (268u - headroom - e) << 23;                     // 2^(14 - headroom - (e - 127))
 }
 
+// ---- reproducible scatter sums (ops.deterministic / OCCF_DETERMINISTIC=1): a float atomicAdd makes the result depend on
+// the order the contributions arrive in; the same contributions as 64-bit FIXED POINT add up to the same bits in any
+// order.  scale = 2^(29 - exponent of max |v|) from a scale slot (occf_absmax_f32): |contribution| < 2^30 converts with
+// one rounding + one int32 conversion (the generic float -> int64 conversion is ~25 VALU instructions), sign-extended
+// into the 64-bit accumulator; precision 2^-30 of the tensor's maximum.  occf_fx_to_f32 turns the sums back.
+#ifdef OCCF_EMU
+static inline
+#else
+__device__ __forceinline__
+#endif
+float occf_fx_scale(uint32_t amax_bits, float& inv) {
+  uint32_t e = (amax_bits >> 23) & 0xFFu;
+  e = e < 31u ? 31u : (e > 254u ? 254u : e);
+  inv = occf_u2f((e - 29u) << 23);                       // 2^(e - 127 - 29)
+  return occf_u2f((283u - e) << 23);                     // 2^(29 - (e - 127))
+}
+template <bool FX>
+#ifdef OCCF_EMU
+static inline
+#else
+__device__ __forceinline__
+#endif
+void occf_scatter_add(void* base, long idx, float v, float fx_scale) {
+  if (FX) atomicAdd((unsigned long long*)base + idx, (unsigned long long)(long long)(int)rintf(v * fx_scale));
+  else atomicAdd((float*)base + idx, v);
+}
+
 // scheduling fence: keeps the instruction groups on either side in program order (used where the
 // compiler's register-minimising order would serialise LDS latency and dependent MFMAs)
 #ifdef OCCF_EMU

@@ -46,6 +46,9 @@ class HipOps:
         self.dgrad_f16 = os.environ.get("OCCF_DGRAD_F16", "1") == "1"
         # the decoder's per-query chain as two kernels per layer in inference (csrc/decoder_rows.hip); 0 = one launch per op
         self.use_decoder_rows = os.environ.get("OCCF_DECODER_ROWS", "1") == "1"
+        # OCCF_DETERMINISTIC=1: every scatter sum of the backward in a fixed order or in integer fixed point (two runs of
+        # a seeded step give the same bits; tests/test_train_step.py::test_training_step_is_reproducible)
+        self.deterministic = os.environ.get("OCCF_DETERMINISTIC", "0") == "1"
         self.swin_frag = os.environ.get("OCCF_SWIN_FRAG", "1") == "1"
         # fused mask contraction + preserve-pooling (the intermediate mask logits are never written)
         self.use_fused_mask_pool = os.environ.get("OCCF_FUSED_MASK_POOL", "1") == "1"
@@ -764,7 +767,9 @@ class HipOps:
         self._call("occf_sample_wor_fwd", self._ptr(weights, self.f32), self._ptr(uniforms, self.f32),
                    self._ptr(out), self._ptr(ws), R, V, int(k), int(weights.shape[0] == 1 and R > 1),
                    int(exponential), self._stream())
-        return out
+        # (the compaction hands out slots in arrival order: the SET is reproducible, the order is not -- sorted in the
+        # reproducible mode so that everything summed over these indices adds up in the same order)
+        return out.sort(dim=1).values if self.deterministic else out
 
     def topk_smallest_abs(self, values, k):
         """values [R, V] -> int64 indices [R, k] of the k smallest |values| per row (unordered)."""
@@ -773,7 +778,7 @@ class HipOps:
         out = torch.empty((R, k), dtype=torch.int64, device=values.device)
         self._call("occf_topk_smallest_abs_fwd", self._ptr(values, self.f32), self._ptr(out), self._ptr(ws), R, V,
                    int(k), self._stream())
-        return out
+        return out.sort(dim=1).values if self.deterministic else out
 
     def point_loss_rows(self, logits, targets):
         """logits/targets [R, P] -> [R, 4] = sums of {BCE, sigmoid*t, sigmoid, t}."""
@@ -933,6 +938,25 @@ class HipOps:
         P = pts.shape[1]
         shared = pts.shape[0] == 1 and N > 1
         shape = (X * Y * Z, int(voxel_major_cols)) if voxel_major_cols else tuple(vol_shape)
+        if self.deterministic and P > 0:
+            # reproducible sums: the scatter in 64-bit fixed point into a buffer of this call's own columns, then floats
+            ld = N * C if voxel_major_cols else 0
+            acc = torch.zeros((X * Y * Z, ld) if ld else tuple(vol_shape), dtype=torch.int64, device=dout.device)
+            slot = torch.empty((self.lib.occf_absmax_slot_words(),), dtype=self.i32, device=dout.device)
+            self._call("occf_absmax_flat", self._ptr(dout, self.f32), dout.numel(), self._ptr(slot), self._stream())
+            self._call("occf_point_sample_3d_bwd_fx", self._ptr(dout, self.f32), self._ptr(pts, self.f32), self._ptr(acc),
+                       self._ptr(slot), N, C, X, Y, Z, P, int(shared), int(align_corners), int(padding_mode == "border"),
+                       ld, self._stream())
+            part = torch.empty(acc.shape, dtype=self.f32, device=dout.device)
+            self._call("occf_fx_to_f32", self._ptr(acc), self._ptr(part), acc.numel(), self._ptr(slot), self._stream())
+            if not voxel_major_cols:
+                return part
+            if out is None:
+                out = torch.zeros(shape, dtype=self.f32, device=dout.device)
+            elif tuple(out.shape) != shape or col0 < 0 or col0 + N * C > voxel_major_cols:
+                raise OccfError("point_sample_3d_backward: out must be the voxel-major [X*Y*Z, ld] buffer")
+            out[:, col0:col0 + N * C] = part
+            return out
         if out is not None:
             if not voxel_major_cols or tuple(out.shape) != shape or col0 < 0 or col0 + N * C > voxel_major_cols:
                 raise OccfError("point_sample_3d_backward: out must be the voxel-major [X*Y*Z, ld] buffer")
@@ -1072,8 +1096,20 @@ class HipOps:
     def deform_col2im(self, x_cl, offset, dcol, K, stride, pad, dil, groups, deform_groups, mask=None):
         """backward of deform_im2col -> (dx [BN, H, W, C], doffset like offset[, dmask like mask: DCNv2])"""
         BN, H, W, C = x_cl.shape
-        dx = torch.zeros_like(x_cl)
         doff = torch.empty_like(offset)
+        if self.deterministic:
+            acc = torch.zeros(x_cl.shape, dtype=torch.int64, device=x_cl.device)
+            slot = torch.empty((self.lib.occf_absmax_slot_words(),), dtype=self.i32, device=x_cl.device)
+            self._call("occf_absmax_flat", self._ptr(dcol, self.f32), dcol.numel(), self._ptr(slot), self._stream())
+            dmask = torch.empty_like(mask) if mask is not None else None
+            self._call("occf_deform_col2im_fx", self._ptr(x_cl, self.f32), self._ptr(offset, self.f32),
+                       self._ptr(mask, self.f32) if mask is not None else ctypes.c_void_p(0), self._ptr(dcol, self.f32),
+                       self._ptr(acc), self._ptr(doff), self._ptr(dmask), self._ptr(slot), BN, H, W, C, K, stride, pad,
+                       dil, groups, deform_groups, self._stream())
+            dx = torch.empty_like(x_cl)
+            self._call("occf_fx_to_f32", self._ptr(acc), self._ptr(dx), acc.numel(), self._ptr(slot), self._stream())
+            return (dx, doff, dmask) if mask is not None else (dx, doff)
+        dx = torch.zeros_like(x_cl)
         if mask is not None:
             dmask = torch.empty_like(mask)
             self._call("occf_modulated_deform_col2im", self._ptr(x_cl, self.f32), self._ptr(offset, self.f32),

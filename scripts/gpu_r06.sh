@@ -77,5 +77,19 @@ cd $R
 python scripts/summarize_prof.py $O/r06d_prof_fwd > $O/r06d_fwd_kernel_stats.txt 2>&1 ; head -40 $O/r06d_fwd_kernel_stats.txt | cut -c1-150
 find $O/r06d_prof_fwd -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
 ;;
+e)  # decoder rows with the fragment ring; reproducibility of the training step; linear_wgrad shapes
+( time timeout 900 python -m pytest tests/test_attn_ops.py tests/test_bwd_ops.py tests/test_lss_ops.py tests/test_image_backbone.py -m gpu -q -p no:cacheprovider -k "decoder_rows or point_sample or lift_splat or deform or dcn" ) 2>&1 | grep -v "MIOpen(HIP)" | tail -4 | tee $O/r06e_pytest.log
+for v in 0 1; do
+  OCCF_DECODER_ROWS=$v timeout 400 python bench.py --mode forward --check --steps 30 --warmup 3 --no-cpu-baseline > $O/r06e_bench_fwd_rows$v.json 2> $O/r06e_bench_fwd_rows$v.err; echo "fwd rows=$v rc=$?"
+  python -c "
+import json; d=json.load(open('$O/r06e_bench_fwd_rows$v.json')); print('  fwd', round(d['value'],2), 'samples/s', round(d['ms_per_step'],2), 'ms', d.get('stages_ms'), {k: (v['calls'], v['total_ms']) for k, v in d['kernels'].items() if 'decoder' in k or k in ('linear', 'layernorm')})"
+done
+( time timeout 600 python -m pytest tests/test_train_step.py -m gpu -q -p no:cacheprovider -s -k "reproducible" ) 2>&1 | grep -v "MIOpen(HIP)" | grep "reproducibility\|passed\|failed\|Error" | cut -c1-1500 | tee $O/r06e_reproducible.log
+OCCF_DETERMINISTIC=1 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/r06e_bench_train_det.json 2> $O/r06e_bench_train_det.err; echo "train det rc=$?"
+brief $O/r06e_bench_train_det.json | head -3
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --shape-report $O/r06e_shapes_train.txt > $O/r06e_bench_train.json 2> $O/r06e_bench_train.err; echo "train rc=$?"
+brief $O/r06e_bench_train.json | head -3
+grep "linear_wgrad" $O/r06e_shapes_train.txt | head -24
+;;
 *) echo "unknown stage"; exit 2;;
 esac

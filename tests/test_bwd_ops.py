@@ -181,8 +181,11 @@ def test_upsample_add_backward(be, shape, shape2):
     assert _rel(dc.cpu(), coarse.grad.permute(0, 2, 3, 4, 1)) < 1e-5
 
 
+@pytest.mark.parametrize("det", [False, True])
 @pytest.mark.parametrize("align,mode,shared", [(False, "border", False), (True, "zeros", False), (False, "zeros", True)])
-def test_point_sample_backward(be, align, mode, shared):
+def test_point_sample_backward(be, align, mode, shared, det, monkeypatch):
+    """det: the reproducible form (ops.deterministic: the scatter in 64-bit fixed point scaled by max |dout|, then floats)"""
+    monkeypatch.setattr(be.ops, "deterministic", det)
     N, C, X, Y, Z, P = 3, 2, 6, 5, 4, 200
     vol = _t("ps_v", (N, C, X, Y, Z), 1).requires_grad_()
     pts = paramgen.uniform("ps_p", (1 if shared else N, P, 3), 2) * 1.2 - 0.1
@@ -194,6 +197,14 @@ def test_point_sample_backward(be, align, mode, shared):
     assert _rel(fwd.cpu(), out.detach()) < 1e-5
     dv = be.ops.point_sample_3d_backward(be.to(dout), be.to(pts.contiguous()), (N, C, X, Y, Z), align, mode)
     assert _rel(dv.cpu(), vol.grad) < 1e-4
+    # the voxel-major form [V, ld] the mask-logit contraction consumes, into columns col0 .. of a shared buffer
+    ld, col0 = N * C + 5, 3
+    shared_buf = torch.zeros((X * Y * Z, ld), device=be.device)
+    got = be.ops.point_sample_3d_backward(be.to(dout * 1e-7), be.to(pts.contiguous()), (N, C, X, Y, Z), align, mode,
+                                          voxel_major_cols=ld, out=shared_buf, col0=col0)
+    ref = vol.grad.reshape(N * C, -1).t() * 1e-7
+    assert _rel(got[:, col0:col0 + N * C].cpu(), ref) < 1e-4
+    assert float(got[:, :col0].abs().max()) == 0.0 and float(got[:, col0 + N * C:].abs().max()) == 0.0
 
 
 @pytest.fixture
@@ -421,9 +432,11 @@ def test_msda3d_backward_keeps_a_diverged_step_visible(be):
         assert not bool(torch.isfinite(dv).all()), bad
 
 
+@pytest.mark.parametrize("det", [False, True])
 @pytest.mark.parametrize("groups,dg", [(4, 1), (2, 2)])
-def test_deform_col2im(be, groups, dg):
+def test_deform_col2im(be, groups, dg, det, monkeypatch):
     from oracle import occformer_ref as O
+    monkeypatch.setattr(be.ops, "deterministic", det)     # (det: the data-gradient scatter in 64-bit fixed point)
     BN, C, H, W, K = 2, 32, 6, 7, 3
     x = _t("dc2_x", (BN, C, H, W), 1).requires_grad_()
     off = (_t("dc2_off", (BN, dg * 2 * K * K, H, W), 2) * 1.5).requires_grad_()
