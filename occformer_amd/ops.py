@@ -281,13 +281,31 @@ class HipOps:
         """pk: dict of (fragment pair, bias) per linear + LayerNorm triples (head.py: _decoder_rows_pack)
         -> (q1, qs, ks, vs), each [B, Q, E]"""
         B, Q, E = q_in.shape
-        outs = [torch.empty((B, Q, E), dtype=self.f32, device=q_in.device) for _ in range(4)]
-        g, bt, eps = pk["ln0"]
-        self._call("occf_decoder_rows_k1", self._ptr(attn_out, self.f32, B * Q * E), self._ptr(q_in, self.f32, B * Q * E),
-                   self._ptr(qpos, self.f32, Q * E), B * Q, E, Q, self._pair(pk["out0"][0]), self._ptr(pk["out0"][1]),
-                   self._ptr(g), self._ptr(bt), float(eps), self._pair(pk["qk"][0]), self._ptr(pk["qk"][1]),
-                   self._pair(pk["v"][0]), self._ptr(pk["v"][1]), *(self._ptr(o) for o in outs), self._stream())
-        return tuple(outs)
+        out = torch.empty((4, B, Q, E), dtype=self.f32, device=q_in.device)
+        if self.strict and not (attn_out.is_cuda and attn_out.is_contiguous() and q_in.is_contiguous()):
+            raise OccfError("decoder_rows_k1: contiguous GPU tensors expected")
+        # the static arguments (weights, biases, norms) as ctypes objects built ONCE per weight pack: with ~20 / ~45
+        # arguments per call the per-call conversions cost more host time than the launches they replace (r06d)
+        args = pk.get("_k1_args")
+        if args is None:
+            g, bt, eps = pk["ln0"]
+            args = [None, None, self._ptr(qpos, self.f32, Q * E), 0, E, Q, self._pair(pk["out0"][0]),
+                    self._ptr(pk["out0"][1]), self._ptr(g), self._ptr(bt), ctypes.c_float(float(eps)),
+                    self._pair(pk["qk"][0]), self._ptr(pk["qk"][1]), self._pair(pk["v"][0]), self._ptr(pk["v"][1]),
+                    None, None, None, None, None]
+            pk["_k1_args"] = args
+            pk["_k1_qpos"] = qpos.data_ptr()
+        if pk["_k1_qpos"] != qpos.data_ptr():
+            args[2] = self._ptr(qpos, self.f32, Q * E)
+            pk["_k1_qpos"] = qpos.data_ptr()
+        p0, step = out.data_ptr(), B * Q * E * 4
+        args[0], args[1], args[3] = attn_out.data_ptr(), q_in.data_ptr(), B * Q
+        args[15], args[16], args[17], args[18] = p0, p0 + step, p0 + 2 * step, p0 + 3 * step
+        args[19] = self._stream()
+        rc = self.lib.occf_decoder_rows_k1(*args)
+        if rc != 0:
+            raise OccfError(f"occf_decoder_rows_k1 failed with code {rc}")
+        return out[0], out[1], out[2], out[3]
 
     def decoder_rows_k2(self, attn_out, q_in, qpos, pk, head, nxt, want_q=True):
         """``pk`` None: head only (q_in = the queries).  head: post_norm / cls / mask_embed pack; nxt: the NEXT layer's
@@ -295,21 +313,36 @@ class HipOps:
         B, Q, E = q_in.shape
         dev = q_in.device
         n_cls = head["n_cls"]
+        if self.strict and not (q_in.is_cuda and q_in.is_contiguous() and (attn_out is None or attn_out.is_contiguous())):
+            raise OccfError("decoder_rows_k2: contiguous GPU tensors expected")
         q3 = torch.empty((B, Q, E), dtype=self.f32, device=dev) if (pk is not None and want_q) else None
         cls = torch.empty((B, Q, n_cls), dtype=self.f32, device=dev)
         me = torch.empty((B, Q, E), dtype=self.f32, device=dev)
         qx = torch.empty((B, Q, E), dtype=self.f32, device=dev) if nxt is not None else None
-        z = ctypes.c_void_p(0)
-        lin = lambda e: (self._pair(e[0]), self._ptr(e[1])) if e is not None else (z, z)
-        ln = lambda e: (self._ptr(e[0]), self._ptr(e[1]), float(e[2])) if e is not None else (z, z, 0.0)
-        H = pk["H"] if pk is not None else 32
-        self._call("occf_decoder_rows_k2", 1 if pk is not None else 0,
-                   self._ptr(attn_out, self.f32, B * Q * E) if pk is not None else z, self._ptr(q_in, self.f32, B * Q * E),
-                   self._ptr(qpos, self.f32, Q * E), B * Q, E, H, Q,
-                   *lin(pk["out1"] if pk else None), *ln(pk["ln1"] if pk else None),
-                   *lin(pk["ffn1"] if pk else None), *lin(pk["ffn2"] if pk else None), *ln(pk["ln2"] if pk else None),
-                   *ln(head["post"]), *lin(head["cls"]), n_cls, *lin(head["me0"]), *lin(head["me1"]), *lin(head["me2"]),
-                   *lin(nxt), self._ptr(q3), self._ptr(cls), self._ptr(me), self._ptr(qx), self._stream())
+        holder = pk if pk is not None else head
+        key = ("_k2_args", id(head), id(nxt), qpos.data_ptr())
+        args = holder.get(key)
+        if args is None:
+            z = ctypes.c_void_p(0)
+            lin = lambda e: [self._pair(e[0]), self._ptr(e[1])] if e is not None else [z, z]
+            ln = lambda e: [self._ptr(e[0]), self._ptr(e[1]), ctypes.c_float(float(e[2]))] if e is not None else [z, z, ctypes.c_float(0.0)]
+            H = pk["H"] if pk is not None else 32
+            args = [1 if pk is not None else 0, None, None, self._ptr(qpos, self.f32, Q * E), 0, E, H, Q,
+                    *lin(pk["out1"] if pk else None), *ln(pk["ln1"] if pk else None),
+                    *lin(pk["ffn1"] if pk else None), *lin(pk["ffn2"] if pk else None), *ln(pk["ln2"] if pk else None),
+                    *ln(head["post"]), *lin(head["cls"]), n_cls, *lin(head["me0"]), *lin(head["me1"]), *lin(head["me2"]),
+                    *lin(nxt), None, None, None, None, None]
+            holder[key] = args
+        n = len(args)
+        args[1] = attn_out.data_ptr() if pk is not None else None
+        args[2], args[4] = q_in.data_ptr(), B * Q
+        args[n - 5] = q3.data_ptr() if q3 is not None else None
+        args[n - 4], args[n - 3] = cls.data_ptr(), me.data_ptr()
+        args[n - 2] = qx.data_ptr() if qx is not None else None
+        args[n - 1] = self._stream()
+        rc = self.lib.occf_decoder_rows_k2(*args)
+        if rc != 0:
+            raise OccfError(f"occf_decoder_rows_k2 failed with code {rc}")
         return q3, cls, me, qx
 
     def upsample_classify(self, mask_pred, cls, occ_size):

@@ -91,5 +91,19 @@ timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --shape-repo
 brief $O/r06e_bench_train.json | head -3
 grep "linear_wgrad" $O/r06e_shapes_train.txt | head -24
 ;;
+f)  # decoder rows on one XCD with cached launch arguments: host issue time vs GPU time, forward pairs; reproducibility
+for v in 0 1; do OCCF_DECODER_ROWS=$v timeout 300 python scripts/issue_probe.py 2>&1 | grep "per forward"; done | tee $O/r06f_issue_probe.txt
+for v in 0 1; do
+  OCCF_DECODER_ROWS=$v timeout 400 python bench.py --mode forward --check --steps 30 --warmup 3 --no-cpu-baseline > $O/r06f_bench_fwd_rows$v.json 2> $O/r06f_bench_fwd_rows$v.err; echo "fwd rows=$v rc=$?"
+  python -c "
+import json; d=json.load(open('$O/r06f_bench_fwd_rows$v.json')); print('  fwd', round(d['value'],2), 'samples/s', round(d['ms_per_step'],2), 'ms', d.get('check'), d.get('stages_ms'), {k: (v['calls'], v['total_ms']) for k, v in d['kernels'].items() if 'decoder' in k or k in ('linear', 'layernorm')})"
+  OCCF_DECODER_ROWS=$v timeout 400 python bench.py --mode forward --from-images --steps 30 --warmup 3 > $O/r06f_bench_fwd_from_images_rows$v.json 2> $O/r06f_bench_fwd_from_images_rows$v.err
+  python -c "
+import json; d=json.load(open('$O/r06f_bench_fwd_from_images_rows$v.json')); print('  from images', round(d['value'],2), 'samples/s', round(d['ms_per_step'],2), 'ms', d.get('stages_ms'))"
+done
+( time timeout 600 python -m pytest tests/test_train_step.py tests/test_attn_ops.py -m gpu -q -p no:cacheprovider -s -k "reproducible or decoder_rows" ) 2>&1 | grep -v "MIOpen(HIP)" | grep "reproducibility\|passed\|failed\|Error" | cut -c1-1500 | tee $O/r06f_reproducible.log
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --shape-report $O/r06f_shapes_train.txt > $O/r06f_bench_train.json 2> $O/r06f_bench_train.err; echo "train rc=$?"
+brief $O/r06f_bench_train.json | head -12
+;;
 *) echo "unknown stage"; exit 2;;
 esac

@@ -148,10 +148,16 @@ def test_training_step_is_reproducible():
     from occformer_amd.training import DeviceRNG
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    from occformer_amd import view_transformer
     ops = get_ops()
     d = torch.device("cuda:0")
     cfg, meta, tc, model, sd, cams, x, gt_occ, pts, gd = _setup()
     model = model.to(d).train()
+    # (DepthNet's training convolutions run on the library's kernels from 4 096 rows up and on MIOpen below: in this tiny
+    # configuration MIOpen's weight gradients -- float atomics -- were the only four gradients of 584 that differed
+    # between two runs, at 1e-7, r06e; the switch sends them through the library as at full size)
+    monkey = view_transformer._DEPTHNET_LIB
+    view_transformer._DEPTHNET_LIB = "1"
     metas = [dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])] * x.shape[0]
     img_inputs = [t.to(d) for t in (x, *cams)] + [gd.to(d)]
     saved = ops.deterministic
@@ -170,6 +176,7 @@ def test_training_step_is_reproducible():
                          {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
     finally:
         ops.deterministic = saved
+        view_transformer._DEPTHNET_LIB = monkey
         noise.set_rng(None)
     (l0, g0), (l1, g1) = runs
     bad_l = [k for k in l0 if not torch.equal(l0[k], l1[k])]
