@@ -71,7 +71,10 @@ class KernelCensus:
                 if _name in ("linear", "conv3d", "conv3d_wgrad", "conv3d_dgrad", "linear_wgrad", "linear_stream"):
                     second = a[1][0] if isinstance(a[1], (tuple, list)) and torch.is_tensor(a[1][0]) else a[1]
                     shp = (tuple(a[0].shape), tuple(second.shape) if torch.is_tensor(second) else tuple(a[2]))
-                    self.shapes.setdefault((_name, shp), []).append((e0, e1, self.ops.last_flops))
+                    # (the data gradients of the stride-1 3^3 convolutions ask for the two-product kernel: their own row)
+                    tag = _name + ("[dy in one fp16 piece]" if _name == "conv3d" and kw.get("act_f16") and
+                                   getattr(self.ops, "use_wino", False) else "")
+                    self.shapes.setdefault((tag, shp), []).append((e0, e1, self.ops.last_flops))
                 return out
 
             setattr(self.ops, name, wrapped)
@@ -134,49 +137,60 @@ def pmc_traffic(kernel_substr, grid_size, pick="calls"):
         return None, None
     # pick = "bytes": the launch shape that moves the most (the dominant launch of a kernel used at many shapes)
     r = max(best, key=(lambda r: r["fetch_bytes"] + r["write_bytes"]) if pick == "bytes" else (lambda r: r["calls"]))
+    _PMC_EXTRA.clear()
+    _PMC_EXTRA.update({k: r[k] for k in ("mfma_busy_frac", "clock_ghz", "wait_inst_any_frac", "valu_per_mfma") if k in r})
     return r["fetch_bytes"] + r["write_bytes"], os.path.basename(files[-1])
 
 
-def roofline(timed_census, kernels, prec, steps):
-    """The dominant kernel = the (op, shape) with the largest total time among the convolution launches (forward,
-    data gradient, weight gradient) of the timed region (HIP events on the launching stream); priced on ALGORITHMIC
-    flops against the dense MFMA peak."""
-    torch.cuda.synchronize()
-    best = None
-    for (name, shp), recs in timed_census.shapes.items():
-        ms = [r[0].elapsed_time(r[1]) for r in recs]
-        if best is None or sum(ms) > best[0]:
-            best = (sum(ms), name, shp, ms, recs[0][2])
-    if best is None:
-        return None
-    tot, name, shp, ms, flops = best
-    avg_ms = tot / len(ms)
+_PMC_EXTRA = {}          # SQ / GRBM counters of the kernel pmc_traffic() last returned (scripts/summarize_pmc.py)
+
+
+def _conv_entry(name, shp, ms, flops, prec):
+    """one (op, shape) row of the convolution family: kernel name, algorithmic rate, matrix-core products per
+    algorithmic product, PMC traffic of that kernel on these sources (or None)"""
+    from occformer_amd.ops import get_ops
+    ops = get_ops()
+    avg_ms = sum(ms) / len(ms)
     achieved = flops / (avg_ms * 1e-3) / 1e12
-    peak = F32_MFMA_PEAK_TF if prec == "f32" else BF16_MFMA_PEAK_TF
     terms = 3 if prec == "bf16x3" else 1
-    traffic, src, nbytes = None, None, None
-    if name == "conv3d":
+    traffic, src, nbytes, extra = None, None, None, {}
+    products = float({"f32": 1, "bf16x3": 3, "bf16": 1}[prec])
+    base = name.split("[")[0]
+    if base == "conv3d":
         B, X, Y, Z, Cin = shp[0]
         Cout = shp[1][0]
         halo = shp[1][1] == 27 * Cin and Cin % 32 == 0 and prec != "f32"
-        frag = "true" if get_halo_frag() else "false"
-        sch = (1 if os.environ.get("OCCF_HALO_SCHED", "1") != "0" else 0) if get_halo_frag() else 0
-        # (csrc/conv_halo.hip: half-size tiles -- 4 waves, two workgroups per CU -- are an opt-in of the fragment variant)
-        small = get_halo_frag() and os.environ.get("OCCF_HALO_SMALL", "0") not in ("0", "")
-        kname = (f"conv3x3x3_halo_kernel<{2 if Cout % 128 == 0 else 3 if Cout % 192 == 0 else 1}, {terms}, {frag}, {sch}, "
-                 f"{2 if small else 4}>" if halo else "gemm_bf16_kernel<CONV>")
+        tz = 16 if Z >= 16 else Z
+        wino = halo and prec == "bf16x3" and getattr(ops, "use_wino", False) and Cout % 64 == 0 and tz in (4, 8, 16) and \
+            Z % tz == 0 and os.environ.get("OCCF_WINO", "1") != "0"
+        tn = 2 if Cout % 128 == 0 else 3 if Cout % 192 == 0 else 1
         nbytes = 4 * (B * X * Y * Z * (Cin + Cout)) + 4 * Cout * shp[1][1]
-        if halo:
-            tz = 16 if Z >= 16 else Z
+        if wino:
+            # csrc/conv_wino.hip: Winograd F(2, 3) along x -- 18 instead of 27 multiply-adds per output voxel
+            f16 = name != base
+            kname = f"conv3x3x3_wino_kernel<{tn}, {'true' if f16 else 'false'}>"
+            products = (2 if f16 else 3) * 2.0 / 3.0
+            grid = B * ((X + 1) // 2) * ((Y + 64 // tz - 1) // (64 // tz)) * (Z // tz) * (Cout // (64 * tn)) * 512
+            traffic, src = pmc_traffic(kname, grid)
+            extra = dict(_PMC_EXTRA) if traffic is not None else {}
+        elif halo:
+            frag = "true" if get_halo_frag() else "false"
+            sch = (1 if os.environ.get("OCCF_HALO_SCHED", "1") != "0" else 0) if get_halo_frag() else 0
+            small = get_halo_frag() and os.environ.get("OCCF_HALO_SMALL", "0") not in ("0", "")
+            kname = f"conv3x3x3_halo_kernel<{tn}, {terms}, {frag}, {sch}, {2 if small else 4}>"
             ty = (64 if small else 128) // tz
-            bn = 128 if Cout % 128 == 0 else 192 if Cout % 192 == 0 else 64
+            bn = 64 * tn
             grid = B * ((X + 1) // 2) * ((Y + ty - 1) // ty) * (Z // tz) * ((Cout + bn - 1) // bn) * (256 if small else 512)
             traffic, src = pmc_traffic(kname, grid)
-    elif name == "conv3d_wgrad":
+            extra = dict(_PMC_EXTRA) if traffic is not None else {}
+        else:
+            kname = "gemm_bf16_kernel<CONV>"
+    elif base == "conv3d_wgrad":
         B, X, Y, Z, Cout = shp[0]
         Cin = shp[1][-1]
         presplit = taps_hint(shp, flops) >= 9 and Cin % 8 == 0 and Cout % 8 == 0
-        kname = f"wgrad_kernel<{128 if (Cin % 128 == 0 or Cin > 128) else 64}, {terms}, {'true' if presplit else 'false'}>"
+        f16 = prec == "bf16x3" and getattr(ops, "wgrad_f16", False) and presplit
+        kname = f"wgrad_kernel<{2 if f16 else terms}, {'true' if presplit else 'false'}, ...>"
         taps = flops // max(2 * B * X * Y * Z * Cout * Cin, 1)
         same_grid = list(shp[1][:4]) == [B, X, Y, Z]
         if taps == 27 and same_grid and Z in (8, 16, 32, 64) and Cin % 64 == 0 and Cout % 64 == 0 and terms == 3 \
@@ -184,16 +198,52 @@ def roofline(timed_census, kernels, prec, steps):
             # csrc/wgrad_g8.h: tiles of 192 / 128 / 64 channels, LDS-DMA staging (the largest tile class of the launch)
             tile = lambda c: 3 if c % 192 == 0 or (c % 128 == 64 and c >= 192) else 2 if c % 128 == 0 else 1
             ti, tc = tile(Cout), tile(Cin)
-            kname = f"wgrad_g8_kernel<{ti}, {tc}, {1 if ti + tc >= 5 else 2}, 2>"
+            kname = f"wgrad_g8_kernel<{ti}, {tc}, {1 if ti + tc >= 5 else 2}, 2, {'true' if f16 else 'false'}>"
+        if f16:
+            products = 2.0
         nbytes = 4 * (B * X * Y * Z * Cout) + 4 * int(torch.tensor(shp[1]).prod()) + 4 * Cout * taps * Cin
-        traffic, src = pmc_traffic(kname, None, pick="bytes")
+        traffic, src = pmc_traffic(kname.split(", ...")[0], None, pick="bytes")
+        extra = dict(_PMC_EXTRA) if traffic is not None else {}
     else:
         kname = "gemm_bf16_kernel<CONV, transposed loader>"
-    return {"bound": "mfma", "kernel": f"{kname}  [{name} {list(shp[0])} {list(shp[1])}]", "achieved": achieved,
-            "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": src,
-            "mfma_products_per_algorithmic_product": {"f32": 1, "bf16x3": 3, "bf16": 1}[prec],
-            "avg_kernel_ms": avg_ms, "algorithmic_flops_per_launch": flops, "launches_timed": len(ms),
-            "launches_per_step": len(ms) // max(steps, 1), "algorithmic_bytes_per_launch": nbytes}
+    return dict(kernel=f"{kname}  [{name} {list(shp[0])} {list(shp[1])}]", avg_kernel_ms=avg_ms, achieved=achieved,
+                launches_timed=len(ms), total_ms=sum(ms), algorithmic_flops_per_launch=flops,
+                mfma_products_per_algorithmic_product=round(products, 3), traffic=traffic, traffic_source=src,
+                algorithmic_bytes_per_launch=nbytes, **extra)
+
+
+def roofline(timed_census, kernels, prec, steps):
+    """The dominant kernel = the (op, shape) with the largest total time among the convolution launches (forward,
+    data gradient, weight gradient) of the timed region (HIP events on the launching stream); priced on ALGORITHMIC
+    flops against the dense MFMA peak.  ``family``: the other large rows of the same census, each with the matrix-core
+    products it spends per algorithmic product (3-term split x Winograd's 2/3; two fp16-piece products in the data and
+    weight gradients) -- the executed-MFMA utilisation of a row is ``frac`` x that number."""
+    torch.cuda.synchronize()
+    peak = F32_MFMA_PEAK_TF if prec == "f32" else BF16_MFMA_PEAK_TF
+    rows = []
+    for (name, shp), recs in timed_census.shapes.items():
+        if not name.startswith("conv3d"):
+            continue
+        ms = [r[0].elapsed_time(r[1]) for r in recs]
+        rows.append((sum(ms), name, shp, ms, recs[0][2]))
+    if not rows:
+        return None
+    rows.sort(key=lambda r: -r[0])
+    fam = []
+    for tot, name, shp, ms, flops in rows[:6]:
+        e = _conv_entry(name, shp, ms, flops, prec)
+        e["frac"] = e["achieved"] / peak
+        e["launches_per_step"] = len(ms) // max(steps, 1)
+        fam.append(e)
+    top = fam[0]
+    out = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"], "peak": peak, "unit": "TFLOP/s",
+           "frac": top["frac"], "traffic": top["traffic"], "traffic_source": top["traffic_source"]}
+    out.update({k: v for k, v in top.items() if k not in out and k != "total_ms"})
+    out["family"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items()
+                      if k in ("kernel", "avg_kernel_ms", "achieved", "frac", "launches_per_step",
+                               "mfma_products_per_algorithmic_product", "traffic", "mfma_busy_frac", "clock_ghz")}
+                     for e in fam]
+    return out
 
 
 def get_halo_frag():

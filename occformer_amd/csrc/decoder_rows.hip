@@ -105,70 +105,92 @@ __device__ __forceinline__ void dr_operand(const DrSmem& s, const float* x, cons
   }
 }
 // out[q][n] = act(sum_k W[n][k] x[q][k] + bias[n]) (+ res[q][n]) for the 16 rows of the operand image (ih, il); out row
-// stride ldo.  out == NULL: the result goes to the hidden-layer operand image (xh, xl) as bf16 (hi, lo) instead
+// stride ldo.  out == NULL: the result goes to the hidden-layer operand image (xh, xl) as bf16 (hi, lo) instead.
+// A wave's work is the FLAT sequence of (tile, k-step) pairs of its tiles (tile = wave, wave + 8, ...): a ring of DR_RING
+// weight fragments stays in flight ACROSS tile boundaries, so a wave stalls on memory once per GEMM, not once per tile
+// (with a per-tile ring every tile start paid a full round trip: 110 us per K2 launch, r06e / r06f).
 __device__ __forceinline__ void dr_gemm(const DrSmem& s, const unsigned char* ih, const unsigned char* il,
                                         const DrLinear& L, int act, float* out, int ldo, const float* res, int ldr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NW = DR_THREADS / 64;
   const int j = lane & 15, g = lane >> 4;
   const int KP = L.K + 8, ksteps = L.K >> 5, ntiles = (L.N + 15) >> 4;
   const unsigned char* bh = ih + ((long)j * KP + g * 8) * 2;
   const unsigned char* bl = il + ((long)j * KP + g * 8) * 2;
-  for (int nt = wave; nt < ntiles; nt += DR_THREADS / 64) {
-    const uint16_t* ah = L.fh + ((long)nt * ksteps * 64 + lane) * 8;
-    const uint16_t* al = L.fl + ((long)nt * ksteps * 64 + lane) * 8;
-    // a ring of DR_RING k-steps of weight fragments in flight (K = 192: the whole tile at once): with one k-step ahead
-    // a wave paid a full L2 round trip per 3 MFMAs -- 131 us per K2 launch (r06d), latency, not bandwidth
-    bf16x8 rh[DR_RING], rl[DR_RING];
+  const int my_tiles = wave < ntiles ? (ntiles - wave + NW - 1) / NW : 0;
+  const int total = my_tiles * ksteps;                      // flat (tile, k-step) items of this wave
+  if (total == 0) return;
+  // fragment address of flat item f (clamped to the last one: every refill is an unconditional load)
+  auto frag = [&](const uint16_t* base, int f) __attribute__((always_inline)) -> bf16x8 {
+    const int fc = f < total ? f : total - 1;
+    const int t = fc / ksteps, ks = fc - t * ksteps;
+    return *(const bf16x8*)(base + ((long)((wave + t * NW) * ksteps + ks) * 64 + lane) * 8);
+  };
+  bf16x8 rh[DR_RING], rl[DR_RING];
+#pragma unroll
+  for (int i = 0; i < DR_RING; ++i) {
+    rh[i] = frag(L.fh, i);
+    rl[i] = frag(L.fl, i);
+  }
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};     // (alternating k-steps: two dependency chains)
+  int t = 0, ks = 0;
+  for (int f0 = 0; f0 < total; f0 += DR_RING) {
 #pragma unroll
     for (int i = 0; i < DR_RING; ++i) {
-      const int kk = i < ksteps ? i : ksteps - 1;
-      rh[i] = *(const bf16x8*)(ah + (long)kk * 512);
-      rl[i] = *(const bf16x8*)(al + (long)kk * 512);
-    }
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};     // (even / odd k-steps: two dependency chains)
-    for (int ks0 = 0; ks0 < ksteps; ks0 += DR_RING) {
+      const int f = f0 + i;
+      if (f < total) {
+        const bf16x8 xh = *(const bf16x8*)(bh + ks * 64), xl = *(const bf16x8*)(bl + ks * 64);
+        if (i & 1) {
+          acc1 = dr_mfma_16x16x32(rl[i], xh, acc1);
+          acc1 = dr_mfma_16x16x32(rh[i], xl, acc1);
+          acc1 = dr_mfma_16x16x32(rh[i], xh, acc1);
+        } else {
+          acc0 = dr_mfma_16x16x32(rl[i], xh, acc0);
+          acc0 = dr_mfma_16x16x32(rh[i], xl, acc0);
+          acc0 = dr_mfma_16x16x32(rh[i], xh, acc0);
+        }
+        rh[i] = frag(L.fh, f + DR_RING);
+        rl[i] = frag(L.fl, f + DR_RING);
+        if (++ks == ksteps) {
+          // ---- tile finished: this lane holds features n .. n + 3 of query row j
+          const int n = (wave + t * NW) * 16 + g * 4;
+          float v[4];
 #pragma unroll
-      for (int i = 0; i < DR_RING; ++i) {
-        const int ks = ks0 + i;
-        if (ks < ksteps) {
-          const bf16x8 xh = *(const bf16x8*)(bh + ks * 64), xl = *(const bf16x8*)(bl + ks * 64);
-          if (i & 1) {
-            acc1 = dr_mfma_16x16x32(rl[i], xh, acc1);
-            acc1 = dr_mfma_16x16x32(rh[i], xl, acc1);
-            acc1 = dr_mfma_16x16x32(rh[i], xh, acc1);
-          } else {
-            acc0 = dr_mfma_16x16x32(rl[i], xh, acc0);
-            acc0 = dr_mfma_16x16x32(rh[i], xl, acc0);
-            acc0 = dr_mfma_16x16x32(rh[i], xh, acc0);
+          for (int r = 0; r < 4; ++r) {
+            v[r] = (acc0[r] + acc1[r]) + ((L.bias && n + r < L.N) ? L.bias[n + r] : 0.f);
+            if (act == 1) v[r] = fmaxf(v[r], 0.f);
+            if (res) v[r] += res[j * ldr + n + r];
+            acc0[r] = 0.f;
+            acc1[r] = 0.f;
           }
-          const int kn = ks + DR_RING < ksteps ? ks + DR_RING : ksteps - 1;     // refill the slot (clamped: unconditional load)
-          rh[i] = *(const bf16x8*)(ah + (long)kn * 512);
-          rl[i] = *(const bf16x8*)(al + (long)kn * 512);
+          if (out) {
+            *(float4*)(out + j * ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint32_t h0, l0, h1, l1;
+            occf_bf16_split2(v[0], v[1], h0, l0);
+            occf_bf16_split2(v[2], v[3], h1, l1);
+            const dr_u2 hi = {h0, h1}, lo = {l0, l1};
+            *(dr_u2*)(s.xh + ((long)j * (L.N + 8) + n) * 2) = hi;
+            *(dr_u2*)(s.xl + ((long)j * (L.N + 8) + n) * 2) = lo;
+          }
+          ks = 0;
+          ++t;
         }
       }
     }
-    f32x4 acc;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = acc0[r] + acc1[r];
-    const int n = nt * 16 + g * 4;                                // this lane: features n .. n + 3 of query row j
-    float v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      v[r] = acc[r] + ((L.bias && n + r < L.N) ? L.bias[n + r] : 0.f);
-      if (act == 1) v[r] = fmaxf(v[r], 0.f);
-      if (res) v[r] += res[j * ldr + n + r];
-    }
-    if (out) {
-      *(float4*)(out + j * ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-      uint32_t h0, l0, h1, l1;
-      occf_bf16_split2(v[0], v[1], h0, l0);
-      occf_bf16_split2(v[2], v[3], h1, l1);
-      const dr_u2 hi = {h0, h1}, lo = {l0, l1};
-      *(dr_u2*)(s.xh + ((long)j * (L.N + 8) + n) * 2) = hi;
-      *(dr_u2*)(s.xl + ((long)j * (L.N + 8) + n) * 2) = lo;
-    }
   }
+}
+// every weight of the launch into this XCD's L2 before the chain starts (one touch per 128-byte line, spread over the
+// launch's workgroups): the GEMMs then see L2-hit latency on their first fragments instead of a miss per stage
+__device__ __forceinline__ uint32_t dr_touch(const DrLinear& L, int part, int parts) {
+  uint32_t x = 0u;
+  if (!L.fh) return x;
+  const long lines = (long)((L.N + 15) >> 4) * (L.K >> 5) * 1024 / 128;     // 128-byte lines per array
+  for (long i = (long)part * DR_THREADS + threadIdx.x; i < lines; i += (long)parts * DR_THREADS) {
+    x ^= *(const volatile uint32_t*)((const char*)L.fh + i * 128);
+    x ^= *(const volatile uint32_t*)((const char*)L.fl + i * 128);
+  }
+  return x;
 }
 // LayerNorm of the 16 rows in place (32 lanes per row, two-pass statistics in fp32 as ATen: mean, then centred squares)
 __device__ __forceinline__ void dr_layernorm(float* x, int E, const DrNorm& n) {
@@ -210,6 +232,11 @@ __global__ void __launch_bounds__(DR_THREADS) decoder_rows_k1_kernel(DrArgs p) {
   if (blockIdx.x % DR_XCD_SPREAD) return;
   const DrSmem s = dr_smem(smem, p.E, 0);
   const int row0 = (blockIdx.x / DR_XCD_SPREAD) * DR_ROWS, E = p.E;
+  {
+    const int part = blockIdx.x / DR_XCD_SPREAD, parts = gridDim.x / DR_XCD_SPREAD;
+    const uint32_t x = dr_touch(p.out_proj, part, parts) ^ dr_touch(p.qk, part, parts) ^ dr_touch(p.v, part, parts);
+    if (x == 0x9E3779B9u && p.rows < 0) p.out_q[0] = 0.f;       // (never true: keeps the touches)
+  }
   dr_load(s.a, p.in_o, row0, p.rows, E, 0);
   dr_load(s.b, p.in_q, row0, p.rows, E, 0);
   __syncthreads();
@@ -239,6 +266,13 @@ __global__ void __launch_bounds__(DR_THREADS) decoder_rows_k2_kernel(DrArgs p) {
   if (blockIdx.x % DR_XCD_SPREAD) return;
   const DrSmem s = dr_smem(smem, p.E, p.H);
   const int row0 = (blockIdx.x / DR_XCD_SPREAD) * DR_ROWS, E = p.E, H = p.H;
+  {
+    const int part = blockIdx.x / DR_XCD_SPREAD, parts = gridDim.x / DR_XCD_SPREAD;
+    uint32_t x = dr_touch(p.cls, part, parts) ^ dr_touch(p.me0, part, parts) ^ dr_touch(p.me1, part, parts) ^
+                 dr_touch(p.me2, part, parts) ^ dr_touch(p.qnext, part, parts);
+    if (p.mode) x ^= dr_touch(p.out_proj, part, parts) ^ dr_touch(p.ffn1, part, parts) ^ dr_touch(p.ffn2, part, parts);
+    if (x == 0x9E3779B9u && p.rows < 0) p.out_a[0] = 0.f;       // (never true: keeps the touches)
+  }
   if (p.mode) {
     dr_load(s.a, p.in_o, row0, p.rows, E, 0);
     dr_load(s.b, p.in_q, row0, p.rows, E, 0);

@@ -105,5 +105,35 @@ done
 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --shape-report $O/r06f_shapes_train.txt > $O/r06f_bench_train.json 2> $O/r06f_bench_train.err; echo "train rc=$?"
 brief $O/r06f_bench_train.json | head -12
 ;;
+g)  # decoder rows with the flat weight ring + L2 touch: forward pairs and per-kernel statistics of both launch structures
+timeout 300 python -m pytest tests/test_attn_ops.py -m gpu -q -p no:cacheprovider -k "decoder_rows" 2>&1 | tail -2
+for v in 0 1; do
+  OCCF_DECODER_ROWS=$v timeout 400 python bench.py --mode forward --check --steps 30 --warmup 3 --no-cpu-baseline > $O/r06g_bench_fwd_rows$v.json 2> $O/r06g_bench_fwd_rows$v.err; echo "fwd rows=$v rc=$?"
+  python -c "
+import json; d=json.load(open('$O/r06g_bench_fwd_rows$v.json')); print('  fwd', round(d['value'],2), 'samples/s', round(d['ms_per_step'],2), 'ms', d.get('check'), d.get('stages_ms'), {k: (v['calls'], v['total_ms']) for k, v in d['kernels'].items() if 'decoder' in k or k in ('linear', 'layernorm')})"
+done
+cd /tmp
+for v in 0 1; do
+  OCCF_DECODER_ROWS=$v timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/r06g_prof_fwd_rows$v -- python $R/bench.py --mode forward --steps 10 --warmup 2 --no-cpu-baseline > $R/$O/r06g_prof_fwd_rows$v.log 2>&1 ; echo "rocprof fwd rows=$v rc=$?"
+  ( cd $R; python scripts/summarize_prof.py $O/r06g_prof_fwd_rows$v > $O/r06g_fwd_kernel_stats_rows$v.txt 2>&1 )
+  find $R/$O/r06g_prof_fwd_rows$v -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
+done
+cd $R
+python - <<'PY'
+import re
+def load(p):
+    d = {}
+    for line in open(p):
+        m = re.match(r"(.{1,92}?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", line.rstrip())
+        if m:
+            d[m.group(1).strip()] = (int(m.group(2)), float(m.group(3)))
+    return d
+a, b = load("gpurun_out/r06g_fwd_kernel_stats_rows0.txt"), load("gpurun_out/r06g_fwd_kernel_stats_rows1.txt")
+print("total ms (13 forwards incl. warmup... same count both):", round(sum(v[1] for v in a.values()), 2), round(sum(v[1] for v in b.values()), 2))
+diff = sorted(((b.get(k, (0, 0))[1] - a.get(k, (0, 0))[1], k, a.get(k, (0, 0)), b.get(k, (0, 0))) for k in set(a) | set(b)), key=lambda t: -abs(t[0]))
+for dlt, k, x, y in diff[:14]:
+    print(f"{dlt:+9.3f} ms  {k[:70]:70s} rows0 {x}  rows1 {y}")
+PY
+;;
 *) echo "unknown stage"; exit 2;;
 esac
