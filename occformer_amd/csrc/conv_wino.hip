@@ -286,9 +286,13 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
   float* E = (float*)smem;                             // [4 t][32 rows][BN]
   const int xp = wt & 1, rh = wt >> 1;
   const float unscale = occf_u2f(inv_bits);            // (F16: 2^-k, exact; else 1)
-  float gs[TN], gq[TN];
+  float gs[TN], gq[TN], bj[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) gs[j] = gq[j] = 0.f;
+  for (int j = 0; j < TN; ++j) {
+    gs[j] = gq[j] = 0.f;
+    // (this lane's TN bias values once: a load per (row, column tile) inside the loops below is waited for on the spot)
+    bj[j] = p.bias ? p.bias[n0 + wn * (BN / 2) + j * 32 + li] : 0.f;
+  }
   __syncthreads();                                     // every wave is out of the tap loop (halo LDS is free)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -301,6 +305,18 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
       }
     __syncthreads();
     const int x = tx0 + xp;
+    // the residual operand of this round: 8 x TN loads in ONE batch (clamped addresses, unconditional inside the branch)
+    float rv[8][TN];
+    if (p.residual) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int pos = i * 32 + cw_pos(16 * rh + 2 * q + lk);
+        const int y = ty0 + (pos >> p.tz_shift), z = tz0 + (pos & (TZ - 1));
+        const long vrow = ((((long)b * p.X + occf_clampi(x, p.X - 1)) * p.Y + occf_clampi(y, p.Y - 1)) * p.Z + z) * p.Cout;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) rv[q][j] = p.residual[vrow + n0 + wn * (BN / 2) + j * 32 + li];
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int m = 16 * rh + 2 * q + lk;
@@ -316,11 +332,11 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
                     e3 = E[(3 * 32 + m) * BN + col];
         float v = xp == 0 ? (e0 + e1) + e2 : (e1 - e2) - e3;
         if (F16) v *= unscale;
-        if (p.bias) v += p.bias[n];
+        v += bj[j];
         if (p.act == 1) v = fmaxf(v, 0.f);
         else if (p.act == 2) v = cw_gelu(v);
         if (v_ok) {
-          if (p.residual) v += p.residual[vrow + n];
+          if (p.residual) v += rv[q][j];
           p.out[vrow + n] = v;
           gs[j] += v;
           gq[j] = fmaf(v, v, gq[j]);

@@ -39,6 +39,7 @@ struct DrLinear {
   const uint16_t* fl;
   const float* bias;       // [N] or NULL
   int N, K;                // N = real outputs; tiles cover ceil(N / 16) * 16 (the pack pads with zero rows)
+  int boff;                // float offset of this linear's bias copy in the LDS bias area (padded to 16 N)
 };
 struct DrNorm {
   const float* gamma;
@@ -51,6 +52,7 @@ struct DrArgs {
   const float* in_q;       // residual operand [rows, E]
   const float* qpos;       // [Q, E]
   int mode;                // K2: 1 = whole chain, 0 = head only (in_q is q3)
+  int nbias;               // floats of the LDS bias area
   DrLinear out_proj, qk, v;                       // K1
   DrLinear ffn1, ffn2, cls, me0, me1, me2, qnext; // K2 (qnext.fh == NULL: no next layer)
   DrNorm ln_a, ln_b, ln_post;                     // K1: ln_a = norm0;  K2: ln_a = norm1, ln_b = norm2
@@ -65,7 +67,8 @@ typedef uint32_t dr_u2 __attribute__((ext_vector_type(2)));
 struct DrSmem {
   float* a;                // [16][E]
   float* b;                // [16][E]
-  float* h;                // [16][2E]
+  float* h;                // [16][HC]  (K1: HC = 2E for [Qs | Ks];  K2: HC = 32 ceil(n_cls / 32) for the class logits)
+  float* bias;             // every bias of the launch (zeros where a linear has none): the GEMM epilogues read LDS only
   unsigned char* oh;       // operand image of an [16][E] activation, hi: [16][E + 8] bf16
   unsigned char* ol;
   unsigned char* xh;       // operand image of the FFN's hidden activation [16][H + 8] (K2 only): written by the first FFN
@@ -109,12 +112,13 @@ __device__ __forceinline__ void dr_operand(const DrSmem& s, const float* x, cons
 // A wave's work is the FLAT sequence of (tile, k-step) pairs of its tiles (tile = wave, wave + 8, ...): a ring of DR_RING
 // weight fragments stays in flight ACROSS tile boundaries, so a wave stalls on memory once per GEMM, not once per tile
 // (with a per-tile ring every tile start paid a full round trip: 110 us per K2 launch, r06e / r06f).
-__device__ __forceinline__ void dr_gemm(const DrSmem& s, const unsigned char* ih, const unsigned char* il,
-                                        const DrLinear& L, int act, float* out, int ldo, const float* res, int ldr) {
+template <int R>
+__device__ __forceinline__ void dr_gemm_r(const DrSmem& s, const unsigned char* ih, const unsigned char* il,
+                                          const DrLinear& L, int act, float* out, int ldo, const float* res, int ldr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int NW = DR_THREADS / 64;
   const int j = lane & 15, g = lane >> 4;
-  const int KP = L.K + 8, ksteps = L.K >> 5, ntiles = (L.N + 15) >> 4;
+  const int KP = L.K + 8, ksteps = L.K >> 5, ntiles = (L.N + 15) >> 4;      // (ksteps % R == 0: the caller picks R)
   const unsigned char* bh = ih + ((long)j * KP + g * 8) * 2;
   const unsigned char* bl = il + ((long)j * KP + g * 8) * 2;
   const int my_tiles = wave < ntiles ? (ntiles - wave + NW - 1) / NW : 0;
@@ -126,20 +130,25 @@ __device__ __forceinline__ void dr_gemm(const DrSmem& s, const unsigned char* ih
     const int t = fc / ksteps, ks = fc - t * ksteps;
     return *(const bf16x8*)(base + ((long)((wave + t * NW) * ksteps + ks) * 64 + lane) * 8);
   };
-  bf16x8 rh[DR_RING], rl[DR_RING];
+  bf16x8 rh[R], rl[R];
 #pragma unroll
-  for (int i = 0; i < DR_RING; ++i) {
+  for (int i = 0; i < R; ++i) {
     rh[i] = frag(L.fh, i);
     rl[i] = frag(L.fl, i);
+    OCCF_SCHED_FENCE();      // (slot order = issue order: the wait at the loop header is the one both entries need)
   }
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};     // (alternating k-steps: two dependency chains)
-  int t = 0, ks = 0;
-  for (int f0 = 0; f0 < total; f0 += DR_RING) {
+  // The ring cycle (R k-steps) is STRAIGHT-LINE code: no branch, every refill unconditional (clamped).  With a branch in
+  // the cycle (a tile boundary test per k-step) the compiler's wait-count pass gave up on the loop-carried ring and
+  // waited vmcnt(0) at the top of every cycle -- the newest refill's full latency once per R k-steps: 103 us per K2
+  // launch whatever the ring depth or the cache level the weights came from (r06e ... r06g).  A tile is a whole number of
+  // cycles; its epilogue (between cycles) touches LDS only: the biases were staged there at kernel start.
+  int f = 0;
+  for (int t = 0; t < my_tiles; ++t) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // (alternating k-steps: two dependency chains)
+    for (int ks0 = 0; ks0 < ksteps; ks0 += R) {
 #pragma unroll
-    for (int i = 0; i < DR_RING; ++i) {
-      const int f = f0 + i;
-      if (f < total) {
-        const bf16x8 xh = *(const bf16x8*)(bh + ks * 64), xl = *(const bf16x8*)(bl + ks * 64);
+      for (int i = 0; i < R; ++i) {
+        const bf16x8 xh = *(const bf16x8*)(bh + (ks0 + i) * 64), xl = *(const bf16x8*)(bl + (ks0 + i) * 64);
         if (i & 1) {
           acc1 = dr_mfma_16x16x32(rl[i], xh, acc1);
           acc1 = dr_mfma_16x16x32(rh[i], xl, acc1);
@@ -149,36 +158,49 @@ __device__ __forceinline__ void dr_gemm(const DrSmem& s, const unsigned char* ih
           acc0 = dr_mfma_16x16x32(rh[i], xl, acc0);
           acc0 = dr_mfma_16x16x32(rh[i], xh, acc0);
         }
-        rh[i] = frag(L.fh, f + DR_RING);
-        rl[i] = frag(L.fl, f + DR_RING);
-        if (++ks == ksteps) {
-          // ---- tile finished: this lane holds features n .. n + 3 of query row j
-          const int n = (wave + t * NW) * 16 + g * 4;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = (acc0[r] + acc1[r]) + ((L.bias && n + r < L.N) ? L.bias[n + r] : 0.f);
-            if (act == 1) v[r] = fmaxf(v[r], 0.f);
-            if (res) v[r] += res[j * ldr + n + r];
-            acc0[r] = 0.f;
-            acc1[r] = 0.f;
-          }
-          if (out) {
-            *(float4*)(out + j * ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            uint32_t h0, l0, h1, l1;
-            occf_bf16_split2(v[0], v[1], h0, l0);
-            occf_bf16_split2(v[2], v[3], h1, l1);
-            const dr_u2 hi = {h0, h1}, lo = {l0, l1};
-            *(dr_u2*)(s.xh + ((long)j * (L.N + 8) + n) * 2) = hi;
-            *(dr_u2*)(s.xl + ((long)j * (L.N + 8) + n) * 2) = lo;
-          }
-          ks = 0;
-          ++t;
-        }
+        rh[i] = frag(L.fh, f + i + R);
+        rl[i] = frag(L.fl, f + i + R);
+        // (pin the refill behind its slot's MFMAs: left alone the scheduler sank all 2 R loads to the end of the cycle
+        // and the loop waited vmcnt(0) at its top -- the ring was never in flight)
+        OCCF_SCHED_FENCE();
       }
+      f += R;
+    }
+    // ---- tile finished: this lane holds features n .. n + 3 of query row j
+    const int n = (wave + t * NW) * 16 + g * 4;
+    const float4 bv = *(const float4*)(s.bias + L.boff + n);
+    float v[4] = {(acc0[0] + acc1[0]) + bv.x, (acc0[1] + acc1[1]) + bv.y, (acc0[2] + acc1[2]) + bv.z,
+                  (acc0[3] + acc1[3]) + bv.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (act == 1) v[r] = fmaxf(v[r], 0.f);
+      if (res) v[r] += res[j * ldr + n + r];
+    }
+    if (out) {
+      *(float4*)(out + j * ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      uint32_t h0, l0, h1, l1;
+      occf_bf16_split2(v[0], v[1], h0, l0);
+      occf_bf16_split2(v[2], v[3], h1, l1);
+      const dr_u2 hi = {h0, h1}, lo = {l0, l1};
+      *(dr_u2*)(s.xh + ((long)j * (L.N + 8) + n) * 2) = hi;
+      *(dr_u2*)(s.xl + ((long)j * (L.N + 8) + n) * 2) = lo;
     }
   }
+}
+__device__ __forceinline__ void dr_gemm(const DrSmem& s, const unsigned char* ih, const unsigned char* il,
+                                        const DrLinear& L, int act, float* out, int ldo, const float* res, int ldr) {
+  const int ksteps = L.K >> 5;
+  if (ksteps % DR_RING == 0) dr_gemm_r<DR_RING>(s, ih, il, L, act, out, ldo, res, ldr);       // (192, 1536, ...)
+  else if (ksteps % 3 == 0) dr_gemm_r<3>(s, ih, il, L, act, out, ldo, res, ldr);
+  else if (ksteps % 2 == 0) dr_gemm_r<2>(s, ih, il, L, act, out, ldo, res, ldr);
+  else dr_gemm_r<1>(s, ih, il, L, act, out, ldo, res, ldr);
+}
+// the bias of a linear (zeros when it has none, and in the padding up to 16 ceil(N / 16)) -> the LDS bias area
+__device__ __forceinline__ void dr_stage_bias(const DrSmem& s, const DrLinear& L) {
+  if (!L.fh) return;
+  const int np = ((L.N + 15) >> 4) << 4;
+  for (int i = threadIdx.x; i < np; i += DR_THREADS) s.bias[L.boff + i] = (L.bias && i < L.N) ? L.bias[i] : 0.f;
 }
 // every weight of the launch into this XCD's L2 before the chain starts (one touch per 128-byte line, spread over the
 // launch's workgroups): the GEMMs then see L2-hit latency on their first fragments instead of a miss per stage
@@ -211,27 +233,33 @@ __device__ __forceinline__ void dr_layernorm(float* x, int E, const DrNorm& n) {
   for (int c = l; c < E; c += 32) x[r * E + c] = (x[r * E + c] - mean) * rstd * n.gamma[c] + n.beta[c];
 }
 
-__device__ __forceinline__ DrSmem dr_smem(char* smem, int E, int H) {
+// HC = columns of the h buffer, NB = floats of the bias area; H = 0: no hidden-layer image (K1)
+__device__ __forceinline__ DrSmem dr_smem(char* smem, int E, int H, int HC, int NB) {
   DrSmem s;
   s.a = (float*)smem;
   s.b = s.a + DR_ROWS * E;
   s.h = s.b + DR_ROWS * E;
-  s.oh = (unsigned char*)(s.h + DR_ROWS * 2 * E);
+  s.bias = s.h + DR_ROWS * HC;
+  s.oh = (unsigned char*)(s.bias + NB);
   s.ol = s.oh + (size_t)DR_ROWS * (E + 8) * 2;
   s.xh = s.ol + (size_t)DR_ROWS * (E + 8) * 2;
   s.xl = s.xh + (size_t)DR_ROWS * (H + 8) * 2;
   return s;
 }
-// (H = 0: K1, no hidden-layer image)
-static size_t dr_smem_bytes(int E, int H) {
-  return (size_t)DR_ROWS * 4 * E * 4 + (size_t)2 * DR_ROWS * (E + 8) * 2 + (H ? (size_t)2 * DR_ROWS * (H + 8) * 2 : 0);
+static size_t dr_smem_bytes(int E, int H, int HC, int NB) {
+  return (size_t)DR_ROWS * (2 * E + HC) * 4 + (size_t)NB * 4 + (size_t)2 * DR_ROWS * (E + 8) * 2 +
+         (H ? (size_t)2 * DR_ROWS * (H + 8) * 2 : 0);
 }
+static int dr_pad16(int n) { return (n + 15) / 16 * 16; }
 
 __global__ void __launch_bounds__(DR_THREADS) decoder_rows_k1_kernel(DrArgs p) {
   OCCF_DYN_SMEM(smem);
   if (blockIdx.x % DR_XCD_SPREAD) return;
-  const DrSmem s = dr_smem(smem, p.E, 0);
+  const DrSmem s = dr_smem(smem, p.E, 0, 2 * p.E, p.nbias);
   const int row0 = (blockIdx.x / DR_XCD_SPREAD) * DR_ROWS, E = p.E;
+  dr_stage_bias(s, p.out_proj);
+  dr_stage_bias(s, p.qk);
+  dr_stage_bias(s, p.v);
   {
     const int part = blockIdx.x / DR_XCD_SPREAD, parts = gridDim.x / DR_XCD_SPREAD;
     const uint32_t x = dr_touch(p.out_proj, part, parts) ^ dr_touch(p.qk, part, parts) ^ dr_touch(p.v, part, parts);
@@ -264,8 +292,17 @@ __global__ void __launch_bounds__(DR_THREADS) decoder_rows_k1_kernel(DrArgs p) {
 __global__ void __launch_bounds__(DR_THREADS) decoder_rows_k2_kernel(DrArgs p) {
   OCCF_DYN_SMEM(smem);
   if (blockIdx.x % DR_XCD_SPREAD) return;
-  const DrSmem s = dr_smem(smem, p.E, p.H);
+  const int HC = 32 * ((p.cls.N + 31) / 32);
+  const DrSmem s = dr_smem(smem, p.E, p.H, HC, p.nbias);
   const int row0 = (blockIdx.x / DR_XCD_SPREAD) * DR_ROWS, E = p.E, H = p.H;
+  dr_stage_bias(s, p.out_proj);
+  dr_stage_bias(s, p.ffn1);
+  dr_stage_bias(s, p.ffn2);
+  dr_stage_bias(s, p.cls);
+  dr_stage_bias(s, p.me0);
+  dr_stage_bias(s, p.me1);
+  dr_stage_bias(s, p.me2);
+  dr_stage_bias(s, p.qnext);
   {
     const int part = blockIdx.x / DR_XCD_SPREAD, parts = gridDim.x / DR_XCD_SPREAD;
     uint32_t x = dr_touch(p.cls, part, parts) ^ dr_touch(p.me0, part, parts) ^ dr_touch(p.me1, part, parts) ^
@@ -309,10 +346,10 @@ __global__ void __launch_bounds__(DR_THREADS) decoder_rows_k2_kernel(DrArgs p) {
   __syncthreads();
   dr_operand(s, s.b, nullptr, E);
   __syncthreads();
-  dr_gemm(s, s.oh, s.ol, p.cls, 0, s.h, 32 * ((p.cls.N + 31) / 32), nullptr, 0);
+  dr_gemm(s, s.oh, s.ol, p.cls, 0, s.h, HC, nullptr, 0);
   dr_gemm(s, s.oh, s.ol, p.me0, 1, s.a, E, nullptr, 0);
   __syncthreads();
-  dr_store(p.out_a, s.h, 32 * ((p.cls.N + 31) / 32), 0, row0, p.rows, p.cls.N);
+  dr_store(p.out_a, s.h, HC, 0, row0, p.rows, p.cls.N);
   dr_operand(s, s.a, nullptr, E);
   __syncthreads();
   dr_gemm(s, s.oh, s.ol, p.me1, 1, s.b, E, nullptr, 0);
@@ -364,11 +401,12 @@ extern "C" int occf_decoder_rows_pack(const float* w, long ld, int N, int K, uin
 
 static int dr_check(int rows, int E, int H, int Q) {
   if (rows <= 0 || Q <= 0 || rows % Q || E <= 0 || E % 32 || H <= 0 || H % 32) return OCCF_ESHAPE;
-  if (dr_smem_bytes(E, H) > 160 * 1024) return OCCF_ESHAPE;
   return 0;
 }
-static DrLinear dr_lin(const uint16_t* const* f, const float* bias, int N, int K) {
-  DrLinear L = {f ? f[0] : nullptr, f ? f[1] : nullptr, bias, N, K};
+// (boff: running offset into the bias area, advanced by 16 ceil(N / 16) for every linear that exists)
+static DrLinear dr_lin(const uint16_t* const* f, const float* bias, int N, int K, int& boff) {
+  DrLinear L = {f ? f[0] : nullptr, f ? f[1] : nullptr, bias, N, K, boff};
+  if (f) boff += dr_pad16(N);
   return L;
 }
 
@@ -382,10 +420,13 @@ extern "C" int occf_decoder_rows_k1(const float* attn_out, const float* q_in, co
   if (rc) return rc;
   DrArgs a = {};
   a.rows = rows; a.E = E; a.H = 0; a.Q = Q; a.in_o = attn_out; a.in_q = q_in; a.qpos = qpos;
-  a.out_proj = dr_lin(f_out, b_out, E, E); a.qk = dr_lin(f_qk, b_qk, 2 * E, E); a.v = dr_lin(f_v, b_v, E, E);
+  int nb = 0;
+  a.out_proj = dr_lin(f_out, b_out, E, E, nb); a.qk = dr_lin(f_qk, b_qk, 2 * E, E, nb); a.v = dr_lin(f_v, b_v, E, E, nb);
+  a.nbias = nb;
   a.ln_a = DrNorm{ln_gamma, ln_beta, ln_eps};
   a.out_q = q1; a.out_a = qs; a.out_b = ks; a.out_c = vs;
-  const size_t lds = dr_smem_bytes(E, 0);
+  const size_t lds = dr_smem_bytes(E, 0, 2 * E, nb);
+  if (lds > 160 * 1024) return OCCF_ESHAPE;
 #ifndef OCCF_EMU
   static bool attr = false;
   if (!attr) {
@@ -417,15 +458,18 @@ extern "C" int occf_decoder_rows_k2(int mode, const float* attn_out, const float
   if (n_cls <= 0 || n_cls > 2 * E) return OCCF_ESHAPE;
   DrArgs a = {};
   a.rows = rows; a.E = E; a.H = H; a.Q = Q; a.in_o = attn_out; a.in_q = q_in; a.qpos = qpos; a.mode = mode;
-  a.out_proj = dr_lin(f_out, b_out, E, E);
-  a.ffn1 = dr_lin(f_ffn1, b_ffn1, H, E); a.ffn2 = dr_lin(f_ffn2, b_ffn2, E, H);
-  a.cls = dr_lin(f_cls, b_cls, n_cls, E);
-  a.me0 = dr_lin(f_me0, b_me0, E, E); a.me1 = dr_lin(f_me1, b_me1, E, E); a.me2 = dr_lin(f_me2, b_me2, E, E);
-  a.qnext = dr_lin(f_qnext, b_qnext, E, E);
+  int nb = 0;
+  a.out_proj = dr_lin(mode ? f_out : nullptr, b_out, E, E, nb);
+  a.ffn1 = dr_lin(mode ? f_ffn1 : nullptr, b_ffn1, H, E, nb); a.ffn2 = dr_lin(mode ? f_ffn2 : nullptr, b_ffn2, E, H, nb);
+  a.cls = dr_lin(f_cls, b_cls, n_cls, E, nb);
+  a.me0 = dr_lin(f_me0, b_me0, E, E, nb); a.me1 = dr_lin(f_me1, b_me1, E, E, nb); a.me2 = dr_lin(f_me2, b_me2, E, E, nb);
+  a.qnext = dr_lin(f_qnext, b_qnext, E, E, nb);
+  a.nbias = nb;
   a.ln_a = DrNorm{ln1_gamma, ln1_beta, ln1_eps}; a.ln_b = DrNorm{ln2_gamma, ln2_beta, ln2_eps};
   a.ln_post = DrNorm{post_gamma, post_beta, post_eps};
   a.out_q = q3; a.out_a = cls; a.out_b = mask_embed; a.out_c = qx;
-  const size_t lds = dr_smem_bytes(E, H);
+  const size_t lds = dr_smem_bytes(E, H, 32 * ((n_cls + 31) / 32), nb);
+  if (lds > 160 * 1024) return OCCF_ESHAPE;
 #ifndef OCCF_EMU
   static bool attr = false;
   if (!attr) {

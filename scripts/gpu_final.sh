@@ -43,15 +43,23 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fwd 
 cd $R
 python scripts/summarize_prof.py $O/prof_fwd > $O/fwd_kernel_stats.txt 2>&1 ; head -24 $O/fwd_kernel_stats.txt | cut -c1-150
 find $O/prof_fwd -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
-echo "== rocprof PMC passes (HBM traffic of the halo convolutions on these kernel sources: scripts/conv_probe.py)"
-# (round 5: the whole bench under --pmc outgrew any sensible time limit -- it also builds and runs the from-images
-# detector now -- so the counters are collected on the roofline kernel's own probe; scripts/gpu_r05.sh stage q)
+echo "== rocprof PMC passes on the convolution family's own probe (scripts/conv_family_probe.py: forward / data gradient / weight gradient at 192 and 128 channels)"
+# (round 5: the whole bench under --pmc outgrew any sensible time limit, so the counters are collected on the roofline
+# kernels' own probe; round 6: + the SQ / GRBM sets the roofline argument leans on -- matrix-pipe busy, sustained clock)
 cd /tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 170 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python $R/scripts/conv_probe.py 2 > $O/pmc_$c.log 2>&1 ; echo "pmc $c rc=$?"
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$i -- python $R/scripts/conv_family_probe.py 2 > $O/pmc_$i.log 2>&1 ; echo "pmc pass $i ($set) rc=$?"
 done
 cd $R
 python scripts/summarize_pmc.py $O $O/pmc_traffic.json > $O/pmc_summary.txt 2>&1 ; head -8 $O/pmc_summary.txt
 find $O -name "*counter_collection.csv" -size +20M -delete 2>/dev/null
 find $O/prof -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
+echo "== one rank on RCCL: kernel trace of a DDP step (are the bucket all-reduces under the backward?)"
+cd /tmp
+OCCF_DIST_AT_WORLD_1=1 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof_rccl -- python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 $R/bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline > $O/prof_rccl.log 2>&1 ; echo "rccl trace rc=$?"
+cd $R
+python scripts/rccl_overlap.py $O/prof_rccl > $O/rccl_overlap.txt 2>&1 ; tail -12 $O/rccl_overlap.txt | cut -c1-220
+find $O/prof_rccl -name "*kernel_trace.csv" -size +20M -delete 2>/dev/null
 du -sh $O

@@ -105,7 +105,7 @@ done
 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --shape-report $O/r06f_shapes_train.txt > $O/r06f_bench_train.json 2> $O/r06f_bench_train.err; echo "train rc=$?"
 brief $O/r06f_bench_train.json | head -12
 ;;
-g)  # decoder rows with the flat weight ring + L2 touch: forward pairs and per-kernel statistics of both launch structures
+g)  # (also run as visit h with the branch-free ring cycle) decoder rows with the flat weight ring + L2 touch: forward pairs and per-kernel statistics of both launch structures
 timeout 300 python -m pytest tests/test_attn_ops.py -m gpu -q -p no:cacheprovider -k "decoder_rows" 2>&1 | tail -2
 for v in 0 1; do
   OCCF_DECODER_ROWS=$v timeout 400 python bench.py --mode forward --check --steps 30 --warmup 3 --no-cpu-baseline > $O/r06g_bench_fwd_rows$v.json 2> $O/r06g_bench_fwd_rows$v.err; echo "fwd rows=$v rc=$?"
