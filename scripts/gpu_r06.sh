@@ -135,5 +135,24 @@ for dlt, k, x, y in diff[:14]:
     print(f"{dlt:+9.3f} ms  {k[:70]:70s} rows0 {x}  rows1 {y}")
 PY
 ;;
+j)  # reproducibility gate, counters of the msda value-gradient tiles, the conv family's counters through the new summarizer, the default bench with its check
+( time timeout 600 python -m pytest tests/test_train_step.py -m gpu -q -p no:cacheprovider -s -k "reproducible" ) 2>&1 | grep -v "MIOpen(HIP)" | grep "reproducibility\|passed\|failed\|Error" | cut -c1-1200 | tee $O/r06j_reproducible.log
+bash scripts/pmc_probe.sh r06j_msda_pmc msda3d_bwd python $R/scripts/bwd_probe.py msda > $O/r06j_msda_pmc.log 2>&1; tail -60 $O/r06j_msda_pmc.log | grep -v "^pmc pass" | cut -c1-160
+P=$R/$O/r06j_conv_pmc; mkdir -p $P; cd /tmp
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout 240 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $P/pmc_$i -- python $R/scripts/conv_family_probe.py 2 > $P/pmc_$i.log 2>&1 ; echo "pmc pass $i ($set) rc=$?"
+done
+cd $R
+python scripts/summarize_pmc.py $P $P/pmc_traffic.json > $O/r06j_conv_pmc_summary.txt 2>&1 ; head -14 $O/r06j_conv_pmc_summary.txt | cut -c1-190
+cp $P/pmc_traffic.json $O/r06j_pmc_traffic.json
+find $P -name "*.csv" -size +2M -delete 2>/dev/null
+( time timeout 900 python bench.py --shape-report $O/r06j_shapes_train.txt ) > $O/r06j_bench_train.json 2> $O/r06j_bench_train.err; echo "bench rc=$?"
+tail -3 $O/r06j_bench_train.err
+brief $O/r06j_bench_train.json | head -16
+python -c "
+import json; d=json.load(open('$O/r06j_bench_train.json')); print(json.dumps(d['roofline'], indent=0)[:3000])"
+;;
 *) echo "unknown stage"; exit 2;;
 esac
