@@ -300,7 +300,7 @@ def cpu_baseline_train(model, cfg, meta, img_inputs, targets, tape, gates):
     if replay.i != len(tape):
         raise RuntimeError("the oracle consumed a different number of noise draws than the GPU step")
     replay = _Replay(tape, torch.device("cpu"))
-    forced = O.forced_gates(gates)
+    forced = O.forced_gates(gates, level="heavy+bev")
     losses, grads = T.train_step(*oargs, rng=replay, gates=forced)
     if replay.i != len(tape) or forced.i != len(gates):
         raise RuntimeError("the oracle consumed a different number of noise draws / heavy ReLUs than the GPU step")
@@ -348,7 +348,7 @@ def train_check_gpu_step(model, net_kwargs, device):
     from occformer_amd.training import DeviceRNG
     rec = noise.RecordedRNG(DeviceRNG(device, 1234))
     noise.set_rng(rec)
-    gates = noise.record_gates(True)
+    gates = noise.record_gates("heavy+bev")
     try:
         for p in model.parameters():
             p.grad = None

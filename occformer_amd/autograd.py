@@ -272,10 +272,12 @@ class GroupNorm(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, dres, None
 
 
-def group_norm(x_cl, gn, relu=False, tokens=False, residual=None, stats=None):
+def group_norm(x_cl, gn, relu=False, tokens=False, residual=None, stats=None, gate_class=False):
+    """``gate_class``: how the comparison tap classifies this map's ReLU units (noise.gates_wanted: False = light,
+    "bev" = a BEV-ASPP map)"""
     y = GroupNorm.apply(x_cl, gn.weight, gn.bias, gn.num_groups, gn.eps, relu, tokens, residual, stats)
-    if relu and noise.gates_wanted(False):
-        noise.relu_gate(y, False, lambda: _gn_relu_gate(x_cl, gn, y, tokens, residual, stats))
+    if relu and noise.gates_wanted(gate_class):
+        noise.relu_gate(y, gate_class, lambda: _gn_relu_gate(x_cl, gn, y, tokens, residual, stats))
     return y
 
 
@@ -292,16 +294,16 @@ def _gn_relu_gate(x_cl, gn, y, tokens, residual, stats):
     return (y.detach() > 0).movedim(-1, 1)
 
 
-def conv_gn(x_cl, conv_mod, gn, relu=False, tokens=False, residual=None):
+def conv_gn(x_cl, conv_mod, gn, relu=False, tokens=False, residual=None, gate_class=False):
     """conv -> GroupNorm (-> ReLU / token buffer / + residual); the statistics come from the convolution's epilogue
     where the launch has one (as in the inference path, fused.conv_gn) instead of a separate pass over its output"""
     ks, stride, dil, pad = _conv_geometry(conv_mod)
     if (ks == (1, 1, 1) and stride == 1 and x_cl.is_contiguous()) or not _GN_EPILOGUE:
-        return group_norm(conv(x_cl, conv_mod), gn, relu, tokens, residual)
+        return group_norm(conv(x_cl, conv_mod), gn, relu, tokens, residual, gate_class=gate_class)
     ops = get_ops()
     y = Conv3d.apply(x_cl, conv_mod.weight, conv_mod.bias, ks, stride, dil, pad, False, (gn.num_groups, gn.eps))
     stats, ops.last_gn_stats = ops.last_gn_stats, None
-    return group_norm(y, gn, relu, tokens, residual, stats)
+    return group_norm(y, gn, relu, tokens, residual, stats, gate_class=gate_class)
 
 
 class LayerNorm(torch.autograd.Function):

@@ -73,6 +73,7 @@ struct DrSmem {
   unsigned char* ol;
   unsigned char* xh;       // operand image of the FFN's hidden activation [16][H + 8] (K2 only): written by the first FFN
   unsigned char* xl;       // GEMM's epilogue -- the fp32 hidden layer (98 KB at H = 1536) never exists
+  char* dump;              // 1 KB per wave that nothing reads: where the L2 touches' LDS-DMA lands (dr_touch)
 };
 
 // rows [row0, row0 + 16) of a global [rows][E] matrix -> LDS (zeros beyond the last row); with ``mod`` > 0 the source row
@@ -247,12 +248,13 @@ __device__ __forceinline__ DrSmem dr_smem(char* smem, int E, int H, int HC, int 
   s.bias = s.h + DR_ROWS * HC;
   s.oh = (unsigned char*)(s.bias + NB);
   s.ol = s.oh + (size_t)DR_ROWS * (E + 8) * 2;
-  s.xh = s.ol + (size_t)DR_ROWS * (E + 8) * 2;
+  s.dump = (char*)(s.ol + (size_t)DR_ROWS * (E + 8) * 2);
+  s.xh = (unsigned char*)s.dump + (DR_THREADS / 64) * 1024;
   s.xl = s.xh + (size_t)DR_ROWS * (H + 8) * 2;
   return s;
 }
 static size_t dr_smem_bytes(int E, int H, int HC, int NB) {
-  return (size_t)DR_ROWS * (2 * E + HC) * 4 + (size_t)NB * 4 + (size_t)2 * DR_ROWS * (E + 8) * 2 +
+  return (size_t)DR_ROWS * (2 * E + HC) * 4 + (size_t)NB * 4 + (size_t)2 * DR_ROWS * (E + 8) * 2 + (DR_THREADS / 64) * 1024 +
          (H ? (size_t)2 * DR_ROWS * (H + 8) * 2 : 0);
 }
 static int dr_pad16(int n) { return (n + 15) / 16 * 16; }
@@ -267,7 +269,7 @@ __global__ void __launch_bounds__(DR_THREADS) decoder_rows_k1_kernel(DrArgs p) {
   dr_stage_bias(s, p.v);
   {
     const int part = blockIdx.x / DR_XCD_SPREAD, parts = gridDim.x / DR_XCD_SPREAD;
-    char* dump = (char*)s.h;                                     // (first written by the [Qs | Ks] GEMM, barriers later)
+    char* dump = s.dump;
     dr_touch(p.out_proj, part, parts, dump);
     dr_touch(p.qk, part, parts, dump);
     dr_touch(p.v, part, parts, dump);
@@ -312,7 +314,7 @@ __global__ void __launch_bounds__(DR_THREADS) decoder_rows_k2_kernel(DrArgs p) {
   dr_stage_bias(s, p.qnext);
   {
     const int part = blockIdx.x / DR_XCD_SPREAD, parts = gridDim.x / DR_XCD_SPREAD;
-    char* dump = (char*)s.xh;                                    // (the hidden-layer image: first written by the FFN, barriers later)
+    char* dump = s.dump;
     if (p.mode) {
       dr_touch(p.out_proj, part, parts, dump);
       dr_touch(p.ffn1, part, parts, dump);

@@ -172,7 +172,7 @@ class _AtrousGN(nn.Module):
 
     def forward(self, x_cl):
         if self.training:
-            return A.conv_gn(x_cl, self.atrous_conv, self.bn, relu=True)
+            return A.conv_gn(x_cl, self.atrous_conv, self.bn, relu=True, gate_class="bev")
         return fused.conv_gn(x_cl, self.atrous_conv, self.bn, relu=True)
 
 
@@ -202,7 +202,7 @@ class _ASPP(nn.Module):
         g = g.view(B, 1, 1, 1, C).expand(B, X, Y, 1, C)
         y = torch.cat((*branches, g), -1)
         if self.training:
-            y = A.conv_gn(y, self.conv1, self.bn1, relu=True)
+            y = A.conv_gn(y, self.conv1, self.bn1, relu=True, gate_class="bev")
             mask = noise.dropout_mask((B, C, X, Y), self.dropout.p, x_cl.device)     # aspp.py:103,122
             if mask is not None:
                 y = y * mask.permute(0, 2, 3, 1).unsqueeze(3)
@@ -229,9 +229,10 @@ class BottleNeckASPP(nn.Module):
     def forward(self, x_cl):
         """x_cl [B, X, Y, 1, C] (any row stride) -> contiguous [B, X, Y, 1, C]."""
         if self.training:
-            y = A.conv_gn(x_cl, self.input_conv[0], self.input_conv[1], relu=True)
+            # (gate_class "bev": the comparison tap's class of the BEV ASPP's maps -- a no-op unless a comparison records)
+            y = A.conv_gn(x_cl, self.input_conv[0], self.input_conv[1], relu=True, gate_class="bev")
             y = self.aspp(y)
-            return A.conv_gn(y, self.output_conv[0], self.output_conv[1], relu=True, residual=x_cl)
+            return A.conv_gn(y, self.output_conv[0], self.output_conv[1], relu=True, residual=x_cl, gate_class="bev")
         y = fused.conv_gn(x_cl, self.input_conv[0], self.input_conv[1], relu=True)
         y = self.aspp(y)
         return fused.conv_gn(y, self.output_conv[0], self.output_conv[1], relu=True, residual=x_cl.contiguous())

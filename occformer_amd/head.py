@@ -321,7 +321,7 @@ class _Mask2FormerOccBase(OccHeadTrainingMixin, nn.Module):
                         me1=lin(me[2].weight, me[2].bias), me2=lin(me[4].weight, me[4].bias))
         ok = layers is not None and all(v is not None for l in layers for v in l.values()) and \
             all(v is not None for v in head.values()) and me[4].weight.shape[0] == E and \
-            all(l["H"] % 32 == 0 and (4 * E * 4 + 2 * (E + 8) * 2 + 2 * (l["H"] + 8) * 2) * 16 <= 160 * 1024 for l in layers)
+            all(l["H"] % 32 == 0 and (2 * E * 4 + 2 * (E + 8) * 2 + 2 * (l["H"] + 8) * 2) * 16 + 24 * 1024 <= 160 * 1024 for l in layers)
         pack = (layers, head) if ok else None
         self._rows_pack = (ver, pack)
         return pack

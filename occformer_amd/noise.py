@@ -52,15 +52,20 @@ _level = None
 
 
 def record_gates(on=True):
-    """start (``True`` / "heavy" or "all" -> the list that fills up, in call order) or stop (``False``) recording"""
+    """start (``True`` / "heavy", "heavy+bev" or "all" -> the list that fills up, in call order) or stop (``False``)
+    recording.  "heavy+bev" = the heavy units plus the BEV ASPP's GroupNorm + ReLU maps (class "bev": small maps on the
+    coarse stages, where one unit is a visible share of the convolution's gradient -- oracle.occformer_ref.forced_gates)"""
     global _gates, _level
     _gates = [] if on else None
-    _level = None if not on else ("all" if on == "all" else "heavy")
+    _level = None if not on else (on if on in ("all", "heavy+bev") else "heavy")
     return _gates
 
 
 def gates_wanted(heavy):
-    return _gates is not None and (heavy or _level == "all")
+    """``heavy``: True (heavy unit), "bev" (a BEV-ASPP map) or False (any other ReLU of the path)"""
+    if _gates is None:
+        return False
+    return heavy is True or _level == "all" or (heavy == "bev" and _level == "heavy+bev")
 
 
 def relu_gate(h, heavy=True, gate=None):

@@ -182,10 +182,17 @@ class forced_gates:
 
     ``level="all"``: EVERY ReLU of the path takes its gate from the tape (the encoder's / pixel decoder's
     GroupNorm + ReLU maps and the pixel decoder's FFNs as well) -- for the tiny configurations, where one unit of a
-    10^4-unit map weighs 1e-3 of the whole gradient."""
+    10^4-unit map weighs 1e-3 of the whole gradient.
+
+    ``level="heavy+bev"`` (round 6: the full-size comparisons): the heavy units plus the GroupNorm + ReLU maps of the
+    BEV ASPP (aspp.py:107-122, 166-172; class "bev").  On the coarse stages those maps have 625 ... 2 500 positions, so ONE
+    unit decided differently is 1.6e-3 ... 4e-4 of the gradient of the convolution behind it -- the per-parameter tail of
+    every full-size comparison was "a dilated BEV-ASPP convolution of a coarse stage" (1e-3 ... 1e-2 from visit to visit,
+    untouched by exact weight-gradient arithmetic: scripts/precision_probe.py ``wgx``).  ~40 M more taped units at the
+    metric's grid; the same legitimacy rule (rounding-close pre-activations, a vanishing fraction) applies to them."""
 
     def __init__(self, masks, level="heavy"):
-        assert level in ("heavy", "all")
+        assert level in ("heavy", "heavy+bev", "all")
         self.masks = [m.detach().cpu().bool() for m in masks]
         self.level = level
         self.i = 0
@@ -207,10 +214,11 @@ class forced_gates:
 
 
 def _relu_gated(z, heavy=True):
-    """ReLU: F.relu, or -- inside ``forced_gates``, for the heavy units (decoder head MLPs, DepthNet, the ASPP's
-    image-level vector: few units, each feeding whole feature maps) or for every unit at level "all" -- the forced gate"""
+    """ReLU: F.relu, or -- inside ``forced_gates``, for the heavy units (``heavy`` True: decoder head MLPs, DepthNet, the
+    ASPP's image-level vector: few units, each feeding whole feature maps), for the BEV ASPP's maps (``heavy`` "bev") at
+    level "heavy+bev", or for every unit (``heavy`` False too) at level "all" -- the forced gate"""
     g = _GATES
-    if g is None or not (heavy or g.level == "all"):
+    if g is None or not (heavy is True or g.level == "all" or (heavy == "bev" and g.level == "heavy+bev")):
         return F.relu(z)
     assert g.i < len(g.masks), "forced_gates: more ReLUs are evaluated than gate masks were recorded"
     m = g.masks[g.i]
@@ -465,19 +473,19 @@ def bottleneck_aspp(sd, p, x, groups=32):
     ch = C // 4
     g_in = groups
     g_aspp = ch // 2 if ch <= groups else groups
-    y = _relu_gated(_gn(sd, p + "input_conv.1.", _conv2d(sd, p + "input_conv.0.", x), g_in), False)
+    y = _relu_gated(_gn(sd, p + "input_conv.1.", _conv2d(sd, p + "input_conv.0.", x), g_in), "bev")
     a = p + "aspp."
     outs = []
     for i, dil in enumerate((1, 6, 12, 18), 1):
         q = f"{a}aspp{i}."
         z = _conv2d(sd, q + "atrous_conv.", y, padding=0 if i == 1 else dil, dilation=dil)
-        outs.append(_relu_gated(_gn(sd, q + "bn.", z, g_aspp), False))
+        outs.append(_relu_gated(_gn(sd, q + "bn.", z, g_aspp), "bev"))
     g = y.mean((2, 3), keepdim=True)
     g = _relu_gated(_gn(sd, a + "global_avg_pool.2.", _conv2d(sd, a + "global_avg_pool.1.", g), g_aspp))
     outs.append(g.expand(-1, -1, *y.shape[2:]))
-    z = _relu_gated(_gn(sd, a + "bn1.", _conv2d(sd, a + "conv1.", torch.cat(outs, 1)), g_aspp), False)
+    z = _relu_gated(_gn(sd, a + "bn1.", _conv2d(sd, a + "conv1.", torch.cat(outs, 1)), g_aspp), "bev")
     y = y + _dropout(z, _TRAIN["aspp_drop"] if _TRAIN else 0.0)
-    y = _relu_gated(_gn(sd, p + "output_conv.1.", _conv2d(sd, p + "output_conv.0.", y), groups), False)
+    y = _relu_gated(_gn(sd, p + "output_conv.1.", _conv2d(sd, p + "output_conv.0.", y), groups), "bev")
     return x + y
 
 

@@ -154,5 +154,12 @@ brief $O/r06j_bench_train.json | head -16
 python -c "
 import json; d=json.load(open('$O/r06j_bench_train.json')); print(json.dumps(d['roofline'], indent=0)[:3000])"
 ;;
+k)  # the BEV ASPP's maps on the gate tape (level heavy+bev): full-size training parity + the default bench's check
+( time timeout 1200 python -m pytest tests/test_workloads_gpu.py -m gpu -q -p no:cacheprovider -s -k "training_step and (nusc_r50_200 or kitti_effb7_128)" ) 2>&1 | grep -v "MIOpen(HIP)" > $O/r06k_workloads_train.log
+grep "training step vs oracle\|passed\|failed\|^real\|Error" $O/r06k_workloads_train.log | cut -c1-1500
+( time timeout 900 python bench.py --shape-report $O/r06k_shapes_train.txt ) > $O/r06k_bench_train.json 2> $O/r06k_bench_train.err; echo "bench rc=$?"
+tail -3 $O/r06k_bench_train.err
+brief $O/r06k_bench_train.json | head -8
+;;
 *) echo "unknown stage"; exit 2;;
 esac

@@ -192,7 +192,7 @@ def main():
         e_pts = float((res["output_points"].cpu() - ref_fwd["output_points"]).abs().max())
         model.train()
         gl, tape, gates = B.train_check_gpu_step(model, kw, dev)
-        forced = O.forced_gates(gates)
+        forced = O.forced_gates(gates, level="heavy+bev")
         t0 = time.perf_counter()
         cl, cg = T.train_step(*oargs, rng=B._Replay(tape, torch.device("cpu")), gates=forced)
         worst, whole, quant, n = B._grad_figures(model, gl, {k: float(v) for k, v in cl.items()}, cg)

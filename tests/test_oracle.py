@@ -102,6 +102,19 @@ def test_forced_gates_mechanism():
     assert torch.equal(gy2, other.float())
     assert float((y2 - torch.relu(z)).abs().max()) <= 3.1e-7      # the forward moves by the flipped pre-activations only
     assert O._GATES is None and torch.equal(O._relu_gated(z), torch.relu(z))      # outside the context: plain ReLU
+    # the three classes against the three levels: heavy units are forced at every level, the BEV ASPP's maps ("bev") from
+    # "heavy+bev" on, every other ReLU (False) at "all" only -- and the product's tap (noise.gates_wanted) agrees
+    from occformer_amd import noise
+    for level, taken in (("heavy", (True,)), ("heavy+bev", (True, "bev")), ("all", (True, "bev", False))):
+        for cls in (True, "bev", False):
+            with O.forced_gates([other], level=level) as g:
+                O._relu_gated(z, cls)
+            assert g.i == (1 if cls in taken else 0), (level, cls)
+            noise.record_gates(level)
+            try:
+                assert noise.gates_wanted(cls) == (cls in taken), (level, cls)
+            finally:
+                noise.record_gates(False)
 
 
 def test_synthetic_rig_has_no_noise_amplifying_camera_columns():

@@ -161,7 +161,7 @@ def test_workload_training_step_vs_oracle(hip, name):
         opt.zero_grad(set_to_none=True)
         rec = noise.RecordedRNG(DeviceRNG(d, seed))
         noise.set_rng(rec)
-        gates = noise.record_gates(True)
+        gates = noise.record_gates("heavy+bev")
         try:
             losses = model(return_loss=True, **kw)
             sum(v for k, v in losses.items() if "loss" in k).backward()
@@ -183,7 +183,7 @@ def test_workload_training_step_vs_oracle(hip, name):
         oargs = (sd, img_inputs[0].cpu(), tuple(t.cpu() for t in img_inputs[1:7]), gt_depths.cpu(), gt_occ.cpu(),
                  None if gt_points is None else [p.cpu() for p in gt_points], ocfg)
         losses, tape, gates = product_step(tape_seed)
-        forced = O.forced_gates(gates)
+        forced = O.forced_gates(gates, level="heavy+bev")
         cpu_replay = ReplayRNG(tape, torch.device("cpu"))
         t0 = time.perf_counter()
         ref_losses, ref_grads = T.train_step(*oargs, rng=cpu_replay, gates=forced)
