@@ -367,7 +367,11 @@ MAX_REL_Z = 5e-4        # a forced gate may differ from the oracle's own only wh
 
 # per-parameter bounds of a FULL-SIZE training-step comparison, shared by this file's `check` and
 # tests/test_workloads_gpu.py (one filter, one set of bounds: VERDICT r5 weak #1)
-PER_PARAMETER_BOUNDS = {"90%": 1e-3, "99%": 3e-3, "100%": 2e-2}
+# (round 6: the worst parameter back at 6e-3 -- it had been loosened to 2e-2 in round 5 for "a dilated BEV-ASPP convolution
+# of a coarse stage" that moved between 1e-3 and 1e-2 from visit to visit; that tail was ReLU units of the BEV ASPP's small
+# maps decided differently within rounding, and with those maps on the gate tape (level "heavy+bev") the worst parameter
+# measures 3.3e-4 ... 1.1e-3: profiles/r06/r06k_*)
+PER_PARAMETER_BOUNDS = {"90%": 1e-3, "99%": 3e-3, "100%": 6e-3}
 WHOLE_GRADIENT_BOUND = 1e-3
 
 

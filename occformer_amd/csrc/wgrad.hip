@@ -617,27 +617,41 @@ __global__ void __launch_bounds__(256) wgrad_small_kernel(const float* __restric
 
 // the same for M <= 2048 as a 32 x 32 register-tiled contraction staged through LDS: the kernel above re-reads dY and X
 // once per OUTPUT (8 lanes walking M with strided loads: 28 us per call for the decoder's 100-row linears, ~120 calls
-// per training step); here a workgroup reads its 32 columns of each operand once
+// per training step); here a workgroup reads its 32 columns of each operand once.  MC = rows staged per pass: 32, or
+// -- M <= 128, the decoder's 100-query linears -- 128: ALL rows in one pass, i.e. every load of the call in flight at
+// once and ONE barrier instead of a load round trip + two barriers per 32 rows (17 us per call, 2 ms per training
+// step in 120 launches, profiles/r05/r05z_train_kernel_stats.txt).
+template <int MC>
 __global__ void __launch_bounds__(256) wgrad_small_tile_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                                float* __restrict__ dW, float* __restrict__ db, long M,
                                                                int N, int K, long ldy, long ldx) {
-  __shared__ float ys[32][33], xs[32][33];
+  __shared__ float ys[MC][33], xs[MC][33];
   const int ktiles = (K + 31) / 32;
   const int n0 = (int)(blockIdx.x / ktiles) * 32, k0 = (int)(blockIdx.x % ktiles) * 32;
   const int tid = threadIdx.x, n = tid >> 3, kq = (tid & 7) * 4;
   const int lr = tid >> 5, lc = tid & 31;                       // loader: rows lr, lr + 8, .. of column lc
   float acc[4] = {0.f, 0.f, 0.f, 0.f}, bsum = 0.f;
   const bool do_b = db != nullptr && k0 == 0 && (tid & 7) == 0;
-  for (long m0 = 0; m0 < M; m0 += 32) {
+  for (long m0 = 0; m0 < M; m0 += MC) {
+    // (clamped addresses, masked values: the loads of a pass are one batch)
+    float yv[MC / 8], xv[MC / 8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < MC / 8; ++j) {
       const long m = m0 + lr + 8 * j;
-      ys[lr + 8 * j][lc] = (m < M && n0 + lc < N) ? dY[m * ldy + n0 + lc] : 0.f;
-      xs[lr + 8 * j][lc] = (m < M && k0 + lc < K) ? X[m * ldx + k0 + lc] : 0.f;
+      const long mc = m < M ? m : M - 1;
+      yv[j] = dY[mc * ldy + (n0 + lc < N ? n0 + lc : N - 1)];
+      xv[j] = X[mc * ldx + (k0 + lc < K ? k0 + lc : K - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < MC / 8; ++j) {
+      const long m = m0 + lr + 8 * j;
+      ys[lr + 8 * j][lc] = (m < M && n0 + lc < N) ? yv[j] : 0.f;
+      xs[lr + 8 * j][lc] = (m < M && k0 + lc < K) ? xv[j] : 0.f;
     }
     __syncthreads();
+    const int rows = M - m0 < MC ? (int)(M - m0) : MC;          // (zero rows beyond M add nothing; skipped)
 #pragma unroll 8
-    for (int r = 0; r < 32; ++r) {
+    for (int r = 0; r < rows; ++r) {
       const float a = ys[r][n];
       acc[0] = fmaf(a, xs[r][kq + 0], acc[0]);
       acc[1] = fmaf(a, xs[r][kq + 1], acc[1]);
@@ -645,7 +659,7 @@ __global__ void __launch_bounds__(256) wgrad_small_tile_kernel(const float* __re
       acc[3] = fmaf(a, xs[r][kq + 3], acc[3]);
       if (do_b) bsum += a;
     }
-    __syncthreads();
+    if (m0 + MC < M) __syncthreads();
   }
   if (n0 + n < N) {
 #pragma unroll
@@ -787,8 +801,12 @@ extern "C" int occf_linear_wgrad(const float* dy, const float* x, float* dw, flo
   if (M <= 1024 || N % 4 || K % 4 || ldy % 4 || ldx % 4) {
     if (M > 65536) return OCCF_ESHAPE;
     if (M <= 2048) {
-      hipLaunchKernelGGL(wgrad_small_tile_kernel, dim3((unsigned)(((N + 31) / 32) * ((K + 31) / 32))), dim3(256), 0, st,
-                         dy, x, dw, dbias, M, N, K, ldy, ldx);
+      if (M <= 128)
+        hipLaunchKernelGGL(wgrad_small_tile_kernel<128>, dim3((unsigned)(((N + 31) / 32) * ((K + 31) / 32))), dim3(256), 0,
+                           st, dy, x, dw, dbias, M, N, K, ldy, ldx);
+      else
+        hipLaunchKernelGGL(wgrad_small_tile_kernel<32>, dim3((unsigned)(((N + 31) / 32) * ((K + 31) / 32))), dim3(256), 0,
+                           st, dy, x, dw, dbias, M, N, K, ldy, ldx);
       return (int)hipGetLastError();
     }
     const long total = ((long)N * K > N ? (long)N * K : N) * 8;

@@ -161,5 +161,11 @@ grep "training step vs oracle\|passed\|failed\|^real\|Error" $O/r06k_workloads_t
 tail -3 $O/r06k_bench_train.err
 brief $O/r06k_bench_train.json | head -8
 ;;
+l)  # the whole GPU suite on the current tree + the one-pass small-M weight gradient
+( time timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider ) > $O/r06l_pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -v "MIOpen(HIP)" $O/r06l_pytest_gpu.log | tail -12 | cut -c1-300
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --shape-report $O/r06l_shapes_train.txt > $O/r06l_bench_train.json 2> $O/r06l_bench_train.err; echo "train rc=$?"
+brief $O/r06l_bench_train.json | head -30
+grep "linear_wgrad x(100" $O/r06l_shapes_train.txt
+;;
 *) echo "unknown stage"; exit 2;;
 esac
