@@ -441,7 +441,20 @@ struct MsdaTileCfg {
   int CH, passes, lpg;                      // channels per pass, passes per head, lanes per query (CH = cpl * lpg)
   int cpl;                                  // channels per lane: 3 or 6
   int stride;                               // 1: strided walk over the queries (conflict spreading), 0: linear
+  int pad;                                  // extra 64-bit slots per cell in LDS (see msda_tile_pad)
 };
+
+// LDS cell stride = CH + pad 64-bit slots.  Unpadded (CH = 12: 24 dwords) two cells 8 apart share their banks
+// (24 * 8 = 3 * 64), and on a level with Zs = 8 that is every pair of NEIGHBOURING (x, y) columns: queries adjacent in y
+// hit the same banks in the same wave instruction -- PMC r06j: SQ_LDS_BANK_CONFLICT = 56 % of the kernel's LDS cycles.
+// One slot of padding (26 dwords per cell) sends cells c .. c + 31 to 32 different bank pairs.  OCCF_MSDA_PAD=0: off.
+static int msda_tile_pad() {
+  static const int v = [] {
+    const char* e = getenv("OCCF_MSDA_PAD");
+    return e ? atoi(e) : 1;
+  }();
+  return v > 0 ? 1 : 0;
+}
 
 __device__ __forceinline__ int msda_cdiv_pos(long num, long den) { return num <= 0 ? 0 : (int)((num + den - 1) / den); }
 
@@ -484,9 +497,9 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
   const int tx0 = tx_ * tc.T, ty0 = ty_ * tc.T;
   const int rx0 = tx0 - tc.M, ry0 = ty0 - tc.M;
   const int RX = tc.T + 2 * tc.M, RY = RX;
-  const int CH = tc.CH, ch0 = pass * CH;
+  const int CH = tc.CH, ch0 = pass * CH, CHP = tc.CH + tc.pad;
   const long ncell = (long)RX * RY * Zs;
-  for (long i = threadIdx.x; i < ncell * CH; i += NT) tile[i] = 0ull;
+  for (long i = threadIdx.x; i < ncell * CHP; i += NT) tile[i] = 0ull;
   __syncthreads();
 
   // query boxes per query level: cell(q) = floor((2q + 1) * Xs / (2 * Xq)) in [tx0, tx0 + T)
@@ -578,7 +591,7 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
         const float cw = a * (cbx ? tx : 1.f - tx) * (cby ? ty : 1.f - ty) * (cbz ? tz : 1.f - tz);
         const int lx_ = xx - rx0, ly_ = yy - ry0;
         if ((unsigned)lx_ < (unsigned)RX && (unsigned)ly_ < (unsigned)RY) {
-          unsigned long long* t = tile + ((lx_ * RY + ly_) * Zs + zz) * CH + sub * CPL;
+          unsigned long long* t = tile + ((lx_ * RY + ly_) * Zs + zz) * CHP + sub * CPL;
           const float cs = cw * fx_scale;
 #pragma unroll
           for (int c = 0; c < CPL; ++c) atomicAdd(t + c, msda_fx(cs * gch[c]));
@@ -594,7 +607,10 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
   // hand the region over: plain coalesced stores into this workgroup's slab of the scratch buffer; the gather
   // kernel below sums, for every cell, the (at most 9) regions that cover it -- no atomics, fixed order
   float* slab = scratch + (((long)b * H + h) * gridDim.x + blockIdx.x) * (ncell * CH);
-  for (long i = threadIdx.x; i < ncell * CH; i += NT) slab[i] = (float)((double)(long long)tile[i] * (double)fx_inv);
+  for (long i = threadIdx.x; i < ncell * CH; i += NT) {
+    const long cell = i / CH;
+    slab[i] = (float)((double)(long long)tile[cell * CHP + (i - cell * CH)] * (double)fx_inv);
+  }
 }
 
 // dvalue[cell, h*Dh + ch] += sum over the regions that contain the cell (tiles: <= 3 per axis; whole-level mode: the
@@ -646,6 +662,7 @@ static bool msda_tile_cfg(const MsdaLevels& lv, int ls, int Dh, MsdaTileCfg& tc)
   const int X = lv.X[ls], Y = lv.Y[ls], Z = lv.Z[ls];
   tc.ls = ls;
   tc.M = 5;
+  tc.pad = msda_tile_pad();
   // channels per pass: 12 (4 lanes per query) if a tile of at least 4 x 4 columns fits, else 6
   for (int lpg = Dh >= 12 ? 4 : Dh / 3; lpg >= 2; lpg >>= 1) {
     if (Dh % (3 * lpg)) continue;
@@ -658,7 +675,8 @@ static bool msda_tile_cfg(const MsdaLevels& lv, int ls, int Dh, MsdaTileCfg& tc)
     // (12 per lane measured slower again: 2.38 vs 2.28 ms per call, profiles/r04/r04m_msda_cpl.txt)
     tc.cpl = (cpl_env >= 6 && tc.CH % 6 == 0) ? 6 : 3;
     tc.lpg = tc.CH / tc.cpl;
-    if ((long)X * Y * Z * tc.CH * 8 <= budget) {        // the whole level as one tile, its queries split over groups
+    const int CHP = tc.CH + tc.pad;                       // (the LDS footprint counts the padded cells)
+    if ((long)X * Y * Z * CHP * 8 <= budget) {          // the whole level as one tile, its queries split over groups
       tc.T = X > Y ? X : Y;
       tc.M = 0;
       tc.tiles_x = tc.tiles_y = 1;
@@ -666,8 +684,8 @@ static bool msda_tile_cfg(const MsdaLevels& lv, int ls, int Dh, MsdaTileCfg& tc)
       return true;
     }
     int T = 16;
-    while (T > 2 && (long)(T + 2 * tc.M) * (T + 2 * tc.M) * Z * tc.CH * 8 > budget) --T;
-    if ((long)(T + 2 * tc.M) * (T + 2 * tc.M) * Z * tc.CH * 8 > budget || (T < 4 && lpg > 2)) continue;
+    while (T > 2 && (long)(T + 2 * tc.M) * (T + 2 * tc.M) * Z * CHP * 8 > budget) --T;
+    if ((long)(T + 2 * tc.M) * (T + 2 * tc.M) * Z * CHP * 8 > budget || (T < 4 && lpg > 2)) continue;
     tc.groups = 1;
     tc.T = T;
     tc.tiles_x = (X + T - 1) / T;
@@ -824,7 +842,7 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
       for (int l = 0; l < num_levels; ++l) {
         MsdaTileCfg tc = cfgs[l];
         tc.stride = strided;
-        const size_t lds = (size_t)(tc.T + 2 * tc.M) * (tc.T + 2 * tc.M) * lv.Z[l] * tc.CH * 8;
+        const size_t lds = (size_t)(tc.T + 2 * tc.M) * (tc.T + 2 * tc.M) * lv.Z[l] * (tc.CH + tc.pad) * 8;
 #ifndef OCCF_EMU
         static size_t lds_max[2] = {0, 0};
         const int ci = tc.cpl == 6 ? 1 : 0;

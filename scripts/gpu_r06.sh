@@ -161,7 +161,8 @@ grep "training step vs oracle\|passed\|failed\|^real\|Error" $O/r06k_workloads_t
 tail -3 $O/r06k_bench_train.err
 brief $O/r06k_bench_train.json | head -8
 ;;
-l)  # the whole GPU suite on the current tree + the one-pass small-M weight gradient
+l)  # the whole GPU suite on the current tree + the one-pass small-M weight gradient + the msda tile padding pair
+for v in 0 1; do OCCF_MSDA_PAD=$v timeout 300 python scripts/bwd_probe.py msda 2>&1 | grep "msda3d_backward" | sed "s/^/OCCF_MSDA_PAD=$v: /"; done | tee $O/r06l_msda_pad.txt
 ( time timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider ) > $O/r06l_pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -v "MIOpen(HIP)" $O/r06l_pytest_gpu.log | tail -12 | cut -c1-300
 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --shape-report $O/r06l_shapes_train.txt > $O/r06l_bench_train.json 2> $O/r06l_bench_train.err; echo "train rc=$?"
 brief $O/r06l_bench_train.json | head -30
