@@ -45,6 +45,7 @@ struct ConvWinoArgs {
   int act;
   float* gn_partial;          // optional [B][spatial tiles][Cout][2]
   const uint32_t* scale;      // F16: scale slot (occf_absmax_f32): [0] = bit pattern of max |x|
+  int stagger;                // 1: the two waves of a SIMD stage the next chunk at different taps (OCCF_WINO_STAGGER)
 };
 
 typedef uint32_t cw_u2 __attribute__((ext_vector_type(2)));
@@ -244,6 +245,11 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
     load_halo(0, j);
     store_halo(0, j);
   }
+#ifdef OCCF_EMU
+  const int stage_tap = (p.stagger && (wave >> 2)) ? 5 : 3;
+#else
+  const int stage_tap = __builtin_amdgcn_readfirstlane((p.stagger && (wave >> 2)) ? 5 : 3);
+#endif
   for (int cc = 0; cc < n_chunks; ++cc) {
     const int bufsel = cc & 1;
     __syncthreads();                                   // chunk cc's planes are complete; chunk cc - 1's taps are done
@@ -253,12 +259,15 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
       // the next chunk's planes go into the OTHER buffer (last read in chunk cc - 1: before the barrier), one staging
-      // unit at taps 3 and 6, each three taps after its loads were issued
-      if (tap == 3 && more) {
+      // unit at a time, each at least two taps after its loads were issued.  The two waves that share a SIMD (w and
+      // w + 4) stage at DIFFERENT taps (3 / 6 and 5 / 8): the barrier at the chunk boundary keeps all eight waves in
+      // step, so with one schedule both waves of a SIMD left the matrix pipe idle for the same ~1 300 cycles of
+      // transform + split + LDS stores, twice per chunk
+      if (tap == stage_tap && more) {
         store_halo(bufsel ^ 1, 0);
         load_halo((cc + 1) * 32, 1);
       }
-      if (tap == 6 && more) store_halo(bufsel ^ 1, 1);
+      if (tap == stage_tap + 3 && more) store_halo(bufsel ^ 1, 1);
       const int toff = tap_off(tap);
       const int tnx = tap_off(tap < 8 ? tap + 1 : 0);  // (tap 8: a harmless read, replaced after the barrier)
       const int ncc = tap < 8 ? cc : cc + 1, ntap = tap < 8 ? tap + 1 : 0;
@@ -501,6 +510,10 @@ extern "C" int occf_conv3x3x3_wino_fwd(const float* x, const uint16_t* wfrag_hi,
   a.sb = in_sb; a.sx = in_sx; a.sy = in_sy; a.sz = in_sz; a.act = act;
   a.gn_partial = gn_partial;
   a.scale = f16_scale;
+  {
+    const char* e = getenv("OCCF_WINO_STAGGER");
+    a.stagger = e ? (atoi(e) != 0) : 1;
+  }
   const long blocks = (long)B * ((X + 1) / 2) * ((Y + TY - 1) / TY) * (Z / TZ) * (Cout / (64 * TN));
   if (blocks >= 2147483647L) return OCCF_ESHAPE;
   typedef void (*fn_t)(ConvWinoArgs);

@@ -658,11 +658,14 @@ __global__ void __launch_bounds__(256) msda3d_bwd_value_gather_kernel(const floa
 static bool msda_tile_cfg(const MsdaLevels& lv, int ls, int Dh, MsdaTileCfg& tc) {
   // bytes of LDS per workgroup (8 bytes per element).  Larger tiles are slower: 140 KB 2.51 ms, 156 KB 2.72 ms per call
   // against 2.50 (profiles/r04/r04k_msda_lds_sweep.txt) -- fewer, longer workgroups on the same LDS atomic rate
-  const long budget = 124 * 1024;
   const int X = lv.X[ls], Y = lv.Y[ls], Z = lv.Z[ls];
   tc.ls = ls;
   tc.M = 5;
   tc.pad = msda_tile_pad();
+  // (the budget grows with the padding so that the tile GEOMETRY stays what the sweep chose: the first padded version
+  // kept 124 KB, which turned the coarsest level from one whole-level tile with 32 query groups into four tiles and
+  // cost 2.39 -> 3.41 ms per call, r06l)
+  const long budget = 124L * 1024 * (12 + tc.pad) / 12;
   // channels per pass: 12 (4 lanes per query) if a tile of at least 4 x 4 columns fits, else 6
   for (int lpg = Dh >= 12 ? 4 : Dh / 3; lpg >= 2; lpg >>= 1) {
     if (Dh % (3 * lpg)) continue;

@@ -168,5 +168,14 @@ timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --shape-repo
 brief $O/r06l_bench_train.json | head -30
 grep "linear_wgrad x(100" $O/r06l_shapes_train.txt
 ;;
+m)  # msda tile padding with the scaled LDS budget; staggered staging taps of the Winograd kernel
+for v in 0 1; do OCCF_MSDA_PAD=$v timeout 300 python scripts/bwd_probe.py msda 2>&1 | grep "msda3d_backward" | sed "s/^/OCCF_MSDA_PAD=$v: /"; done | tee $O/r06m_msda_pad.txt
+for v in 0 1; do OCCF_WINO_STAGGER=$v timeout 300 python scripts/conv_probe.py 2>&1 | grep -v "amdgpu.ids"; done | tee $O/r06m_conv_probe_stagger.txt
+timeout 600 python -m pytest tests/test_gemm_norm_ops.py tests/test_bwd_ops.py -m gpu -q -p no:cacheprovider -k "wino or msda" 2>&1 | tail -2
+for v in 0 1; do
+  OCCF_WINO_STAGGER=$v timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/r06m_bench_train_stagger$v.json 2> $O/r06m_bench_train_stagger$v.err; echo "train stagger=$v rc=$?"
+  brief $O/r06m_bench_train_stagger$v.json | head -9
+done
+;;
 *) echo "unknown stage"; exit 2;;
 esac
