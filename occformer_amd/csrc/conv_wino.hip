@@ -45,7 +45,6 @@ struct ConvWinoArgs {
   int act;
   float* gn_partial;          // optional [B][spatial tiles][Cout][2]
   const uint32_t* scale;      // F16: scale slot (occf_absmax_f32): [0] = bit pattern of max |x|
-  int stagger;                // 1: the two waves of a SIMD stage the next chunk at different taps (OCCF_WINO_STAGGER)
 };
 
 typedef uint32_t cw_u2 __attribute__((ext_vector_type(2)));
@@ -234,61 +233,86 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
   };
   auto tap_off = [&](int tap) __attribute__((always_inline)) -> int { return (tap / 3) * HZ + tap % 3; };
 
-  bf16x8 f0h[TN], f0l[TN], f1h[TN], f1l[TN];
+  // B (weight) fragments: a ring of BD k-steps -- BD - 1 k-steps ahead of their MFMAs.  One k-step ahead (the direct
+  // kernel's pipeline) is 12 / 18 MFMAs = 384 / 576 cycles of this wave plus as many of its SIMD partner: ~0.4 us at
+  // 128 channels, about the L2 round trip under load -- PMC r06j: matrix pipe 50 % busy at 128 channels, 57 % at 192,
+  // i.e. the SHORTER k-step waits more.  Two ahead doubles the distance for 8 TN more registers.
+  constexpr int BD = TN <= 2 ? 3 : 2;
+  bf16x8 fh[BD][TN], fl[BD][TN];
   bf16x8 a0h[2], a0l[2], a1h[2], a1l[2];
   constexpr int NA = F16 ? 2 : 4;                      // ds_read_b128 per k-step
   constexpr int NF = 2 * TN;                           // global 16-byte loads per k-step
   constexpr int NM = (F16 ? 4 : 6) * TN;               // MFMAs per k-step
-  load_f(0, 0, 0, f0h, f0l);
+  int b_cc = 0, b_tap = 0, b_s = 0;                    // stream position of the NEXT fragment set to load
+  auto load_next_b = [&](bf16x8 (&h)[TN], bf16x8 (&l)[TN]) __attribute__((always_inline)) {
+    load_f(b_cc, b_tap, b_s, h, l);
+    if (++b_s == 2) {
+      b_s = 0;
+      if (++b_tap == 9) { b_tap = 0; ++b_cc; }
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < BD - 1; ++i) load_next_b(fh[i], fl[i]);
 #pragma unroll
   for (int j = 0; j < NUT; ++j) {
     load_halo(0, j);
     store_halo(0, j);
   }
-#ifdef OCCF_EMU
-  const int stage_tap = (p.stagger && (wave >> 2)) ? 5 : 3;
-#else
-  const int stage_tap = __builtin_amdgcn_readfirstlane((p.stagger && (wave >> 2)) ? 5 : 3);
-#endif
+  // one k-step: the NEXT k-step's A fragments (LDS) and the fragment set BD - 1 k-steps ahead (global) issued at the head
+  // of this k-step's MFMAs, one per MFMA (explicit issue pipeline: conv_halo.hip)
+#define CW_STEP(ACH, ACL, ANH, ANL, NEXT_TOFF, NEXT_S, BCUR, BLOAD)                                   \
+  do {                                                                                                \
+    OCCF_SCHED_FENCE();                                                                               \
+    load_a(bufsel, NEXT_TOFF, NEXT_S, ANH, ANL);                                                      \
+    load_next_b(fh[BLOAD], fl[BLOAD]);                                                                \
+    mma_tm(ACH, ACL, fh[BCUR], fl[BCUR]);                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) { OCCF_SCHED_GROUP(0x008, 1); OCCF_SCHED_GROUP(0x100, 1); } \
+    _Pragma("unroll") for (int i_ = 0; i_ < NF; ++i_) { OCCF_SCHED_GROUP(0x008, 1); OCCF_SCHED_GROUP(0x020, 1); } \
+    OCCF_SCHED_GROUP(0x008, (NM > NA + NF ? NM - NA - NF : 0));                                       \
+    OCCF_SCHED_FENCE();                                                                               \
+  } while (0)
   for (int cc = 0; cc < n_chunks; ++cc) {
     const int bufsel = cc & 1;
     __syncthreads();                                   // chunk cc's planes are complete; chunk cc - 1's taps are done
     const bool more = cc + 1 < n_chunks;
     if (more) load_halo((cc + 1) * 32, 0);             // lands under the first taps
     load_a(bufsel, 0, 0, a0h, a0l);
+    if constexpr (BD == 3) {
+      // three taps (six k-steps) per iteration: the ring slots are static
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      // the next chunk's planes go into the OTHER buffer (last read in chunk cc - 1: before the barrier), one staging
-      // unit at a time, each at least two taps after its loads were issued.  The two waves that share a SIMD (w and
-      // w + 4) stage at DIFFERENT taps (3 / 6 and 5 / 8): the barrier at the chunk boundary keeps all eight waves in
-      // step, so with one schedule both waves of a SIMD left the matrix pipe idle for the same ~1 300 cycles of
-      // transform + split + LDS stores, twice per chunk
-      if (tap == stage_tap && more) {
-        store_halo(bufsel ^ 1, 0);
-        load_halo((cc + 1) * 32, 1);
+      for (int t0 = 0; t0 < 9; t0 += 3) {
+        // the next chunk's planes go into the OTHER buffer (last read in chunk cc - 1: before the barrier), one staging
+        // unit at taps 3 and 6, each three taps after its loads were issued
+        if (t0 == 3 && more) {
+          store_halo(bufsel ^ 1, 0);
+          load_halo((cc + 1) * 32, 1);
+        }
+        if (t0 == 6 && more) store_halo(bufsel ^ 1, 1);
+        const int o0 = tap_off(t0), o1 = tap_off(t0 + 1), o2 = tap_off(t0 + 2);
+        const int o3 = tap_off(t0 + 3 < 9 ? t0 + 3 : 0);  // (after tap 8: a harmless read, replaced after the barrier)
+        CW_STEP(a0h, a0l, a1h, a1l, o0, 1, 0, 2);
+        CW_STEP(a1h, a1l, a0h, a0l, o1, 0, 1, 0);
+        CW_STEP(a0h, a0l, a1h, a1l, o1, 1, 2, 1);
+        CW_STEP(a1h, a1l, a0h, a0l, o2, 0, 0, 2);
+        CW_STEP(a0h, a0l, a1h, a1l, o2, 1, 1, 0);
+        CW_STEP(a1h, a1l, a0h, a0l, o3, 0, 2, 1);
       }
-      if (tap == stage_tap + 3 && more) store_halo(bufsel ^ 1, 1);
-      const int toff = tap_off(tap);
-      const int tnx = tap_off(tap < 8 ? tap + 1 : 0);  // (tap 8: a harmless read, replaced after the barrier)
-      const int ncc = tap < 8 ? cc : cc + 1, ntap = tap < 8 ? tap + 1 : 0;
-      OCCF_SCHED_FENCE();
-      load_a(bufsel, toff, 1, a1h, a1l);
-      load_f(cc, tap, 1, f1h, f1l);
-      mma_tm(a0h, a0l, f0h, f0l);
-      load_a(bufsel, tnx, 0, a0h, a0l);
-      load_f(ncc, ntap, 0, f0h, f0l);
-      mma_tm(a1h, a1l, f1h, f1l);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) { OCCF_SCHED_GROUP(0x008, 1); OCCF_SCHED_GROUP(0x100, 1); }
-#pragma unroll
-        for (int i = 0; i < NF; ++i) { OCCF_SCHED_GROUP(0x008, 1); OCCF_SCHED_GROUP(0x020, 1); }
-        OCCF_SCHED_GROUP(0x008, (NM > NA + NF ? NM - NA - NF : 0));
+    } else {
+#pragma unroll 1
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap == 3 && more) {
+          store_halo(bufsel ^ 1, 0);
+          load_halo((cc + 1) * 32, 1);
+        }
+        if (tap == 6 && more) store_halo(bufsel ^ 1, 1);
+        const int toff = tap_off(tap);
+        const int tnx = tap_off(tap < 8 ? tap + 1 : 0);  // (tap 8: a harmless read, replaced after the barrier)
+        CW_STEP(a0h, a0l, a1h, a1l, toff, 1, 0, 1);
+        CW_STEP(a1h, a1l, a0h, a0l, tnx, 0, 1, 0);
       }
-      OCCF_SCHED_FENCE();
     }
   }
+#undef CW_STEP
 
   // ---- epilogue: the four M_t of a position meet in LDS, two rounds of 32 positions; wave (t, wn) then owns the
   // outputs of x-parity t & 1, MFMA rows 16 (t >> 1) .. + 16, its 32 TN columns
@@ -510,10 +534,6 @@ extern "C" int occf_conv3x3x3_wino_fwd(const float* x, const uint16_t* wfrag_hi,
   a.sb = in_sb; a.sx = in_sx; a.sy = in_sy; a.sz = in_sz; a.act = act;
   a.gn_partial = gn_partial;
   a.scale = f16_scale;
-  {
-    const char* e = getenv("OCCF_WINO_STAGGER");
-    a.stagger = e ? (atoi(e) != 0) : 1;
-  }
   const long blocks = (long)B * ((X + 1) / 2) * ((Y + TY - 1) / TY) * (Z / TZ) * (Cout / (64 * TN));
   if (blocks >= 2147483647L) return OCCF_ESHAPE;
   typedef void (*fn_t)(ConvWinoArgs);

@@ -177,5 +177,11 @@ for v in 0 1; do
   brief $O/r06m_bench_train_stagger$v.json | head -9
 done
 ;;
+n)  # Winograd kernel with the weight fragments two k-steps ahead (128-channel variant); msda padding off again
+timeout 300 python scripts/conv_probe.py 2>&1 | grep -v "amdgpu.ids" | tee $O/r06n_conv_probe_bd3.txt
+timeout 600 python -m pytest tests/test_gemm_norm_ops.py -m gpu -q -p no:cacheprovider -k "wino or conv_epilogue" 2>&1 | tail -2
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/r06n_bench_train.json 2> $O/r06n_bench_train.err; echo "train rc=$?"
+brief $O/r06n_bench_train.json | head -12
+;;
 *) echo "unknown stage"; exit 2;;
 esac
