@@ -235,9 +235,10 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
 
   // B (weight) fragments: a ring of BD k-steps -- BD - 1 k-steps ahead of their MFMAs.  One k-step ahead (the direct
   // kernel's pipeline) is 12 / 18 MFMAs = 384 / 576 cycles of this wave plus as many of its SIMD partner: ~0.4 us at
-  // 128 channels, about the L2 round trip under load -- PMC r06j: matrix pipe 50 % busy at 128 channels, 57 % at 192,
-  // i.e. the SHORTER k-step waits more.  Two ahead doubles the distance for 8 TN more registers.
-  constexpr int BD = TN <= 2 ? 3 : 2;
+  // 128 channels.  BD = 3 (two k-steps ahead, 8 TN more registers; the ISA then waits vmcnt(7) / (5) with 8 loads in
+  // flight) was measured at 128 channels: 1.223 vs 1.210 ms (r06n vs r06m) -- the distance of the weight fragments is
+  // not what idles the matrix pipe either.  The three-deep form stays compiled behind this constant.
+  constexpr int BD = 2;
   bf16x8 fh[BD][TN], fl[BD][TN];
   bf16x8 a0h[2], a0l[2], a1h[2], a1l[2];
   constexpr int NA = F16 ? 2 : 4;                      // ds_read_b128 per k-step
