@@ -230,15 +230,23 @@ def roofline(timed_census, kernels, prec, steps):
         return None
     rows.sort(key=lambda r: -r[0])
     fam = []
-    for tot, name, shp, ms, flops in rows[:6]:
+    for tot, name, shp, ms, flops in rows[:8]:
         e = _conv_entry(name, shp, ms, flops, prec)
         e["frac"] = e["achieved"] / peak
         e["launches_per_step"] = len(ms) // max(steps, 1)
         fam.append(e)
-    top = fam[0]
+    # the dominant KERNEL = the kernel name with the largest total time over all its launch shapes (among the rows above);
+    # the record quotes its heaviest shape
+    per_kernel = {}
+    for e in fam:
+        k = e["kernel"].split("  [")[0]
+        per_kernel[k] = per_kernel.get(k, 0.0) + e["total_ms"]
+    dom = max(per_kernel, key=per_kernel.get)
+    top = max((e for e in fam if e["kernel"].split("  [")[0] == dom), key=lambda e: e["total_ms"])
     out = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["achieved"], "peak": peak, "unit": "TFLOP/s",
            "frac": top["frac"], "traffic": top["traffic"], "traffic_source": top["traffic_source"]}
     out.update({k: v for k, v in top.items() if k not in out and k != "total_ms"})
+    out["kernel_total_ms_in_timed_region"] = round(per_kernel[dom], 3)
     out["family"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in e.items()
                       if k in ("kernel", "avg_kernel_ms", "achieved", "frac", "launches_per_step",
                                "mfma_products_per_algorithmic_product", "traffic", "mfma_busy_frac", "clock_ghz")}

@@ -183,5 +183,14 @@ timeout 600 python -m pytest tests/test_gemm_norm_ops.py -m gpu -q -p no:cachepr
 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/r06n_bench_train.json 2> $O/r06n_bench_train.err; echo "train rc=$?"
 brief $O/r06n_bench_train.json | head -12
 ;;
+o)  # DepthNet's 3x3 convolution on the generic kernel: split-K / tile-width sweep
+timeout 120 python scripts/depthnet_conv_probe.py 2>&1 | grep "conv 3x3" | tee $O/r06o_depthnet_conv_probe.txt
+for k in 1 2 3 4 5 6 8; do OCCF_GEMM_KSPLIT=$k timeout 120 python scripts/depthnet_conv_probe.py 2>&1 | grep "conv 3x3"; done | tee -a $O/r06o_depthnet_conv_probe.txt
+for k in 1 2 3 4; do OCCF_GEMM_BN=64 OCCF_GEMM_KSPLIT=$k timeout 120 python scripts/depthnet_conv_probe.py 2>&1 | grep "conv 3x3"; done | tee -a $O/r06o_depthnet_conv_probe.txt
+;;
+p)  # DDP bucket timeline on one rank (nccl); DepthNet conv sweep
+OCCF_DIST_AT_WORLD_1=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29543 scripts/ddp_bucket_timeline.py 2>&1 | grep -v "MIOpen\|amdgpu.ids\|Warning\|warn" | tail -14 | tee $O/r06p_ddp_bucket_timeline.txt
+bash scripts/gpu_r06.sh o
+;;
 *) echo "unknown stage"; exit 2;;
 esac
