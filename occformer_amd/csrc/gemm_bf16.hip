@@ -143,6 +143,28 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
   const long m0 = (long)(wg / n_tiles) * GB_BM;
   const int n0 = (wg % n_tiles) * BN;
 
+  // CONV == 2: the class-major decode of the tile's 128 rows ONCE (one row per thread of the first two waves) into LDS:
+  // the dY-grid voxel (x / s, y / s, z / s), the batch (-1: padding row of the class) and the dx row the epilogue
+  // stores to.  occf_cls_row is ~450 VALU instructions (a 64-bit and eight 32-bit run-time divisions): per staged row
+  // and per epilogue row of every thread it cost more than the tile's MFMAs (r06q: 1x1x1 / stride-2 data gradient
+  // 0.43 ms for 0.33 GB of stores).
+  __shared__ int cr_x[CONV == 2 ? GB_BM : 1], cr_y[CONV == 2 ? GB_BM : 1], cr_z[CONV == 2 ? GB_BM : 1],
+      cr_b[CONV == 2 ? GB_BM : 1], cr_row[CONV == 2 ? GB_BM : 1];
+  __shared__ int cr_cls;
+  if (CONV == 2) {
+    if (tid < GB_BM) {
+      long b;
+      int xo, yo, zo, cc;
+      const long m = m0 + tid;
+      const bool ok = occf_cls_row(p.g, m < p.M ? m : 0, b, xo, yo, zo, cc) && m < p.M;
+      const int s = p.g.stride;
+      cr_x[tid] = xo / s; cr_y[tid] = yo / s; cr_z[tid] = zo / s;
+      cr_b[tid] = ok ? (int)b : -1;
+      cr_row[tid] = ok ? (int)(((b * p.g.Xo + xo) * p.g.Yo + yo) * p.g.Zo + zo) : -1;
+      if (tid == 0) cr_cls = cc;
+    }
+    __syncthreads();
+  }
   // A staging: 4 float4 per thread; 8 consecutive lanes cover one 128-B row segment
   long a_base[4];
   int a_x[4], a_y[4], a_z[4], a_m[4], a_kq[4];
@@ -154,20 +176,25 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
     a_kq[i] = idx & 7;
     const long m = m0 + a_m[i];
     a_ok[i] = m < p.M;
-    if (CONV) {
+    if (CONV == 2) {
+      // class-major rows: the dY voxel of (row, tap) is (x / s, y / s, z / s) + the tap's offset of this tile's
+      // class (tapoff below) -- no division per (row, k-tile)
+      const int bb = cr_b[a_m[i]];
+      a_ok[i] = bb >= 0;
+      a_base[i] = (long)(bb >= 0 ? bb : 0) * p.g.sb;
+      a_x[i] = cr_x[a_m[i]]; a_y[i] = cr_y[a_m[i]]; a_z[i] = cr_z[a_m[i]];
+    } else if (CONV) {
       const long mm = a_ok[i] ? m : 0;
       int zo = (int)(mm % p.g.Zo);
       int yo = (int)((mm / p.g.Zo) % p.g.Yo);
       int xo = (int)((mm / ((long)p.g.Zo * p.g.Yo)) % p.g.Xo);
       long b = mm / ((long)p.g.Zo * p.g.Yo * p.g.Xo);
-      if (CONV == 2) {
-        int cls_unused;
-        a_ok[i] = occf_cls_row(p.g, mm, b, xo, yo, zo, cls_unused) && a_ok[i];
-      }
       a_base[i] = b * p.g.sb;
-      a_x[i] = p.g.transposed ? xo + p.g.pad_x : xo * p.g.stride - p.g.pad_x;
-      a_y[i] = p.g.transposed ? yo + p.g.pad_y : yo * p.g.stride - p.g.pad_y;
-      a_z[i] = p.g.transposed ? zo + p.g.pad_z : zo * p.g.stride - p.g.pad_z;
+      {
+        a_x[i] = p.g.transposed ? xo + p.g.pad_x : xo * p.g.stride - p.g.pad_x;
+        a_y[i] = p.g.transposed ? yo + p.g.pad_y : yo * p.g.stride - p.g.pad_y;
+        a_z[i] = p.g.transposed ? zo + p.g.pad_z : zo * p.g.stride - p.g.pad_z;
+      }
     } else {
       a_base[i] = (a_ok[i] ? m : 0) * p.lda;
       a_x[i] = a_y[i] = a_z[i] = 0;
@@ -190,11 +217,14 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
   occf_u4 rbh[PF][NB], rbl[PF][NB];
   // CONV == 2: the taps this tile's parity class can reach (all taps if the tile straddles two classes)
   __shared__ int tapmap[CONV == 2 ? 64 : 1];
+  // ... and, per reachable tap, the offset of the dY voxel it reads from (x / s, y / s, z / s): (class + pad - tap * dil) / s
+  // per axis, an exact division, packed as three biased 10-bit fields.  (The generic transposed loader divides and
+  // takes remainders by the run-time stride per row and k-tile: ~1 300 VALU instructions per thread against 24 MFMAs
+  // per wave -- the stride-2 data gradients ran at a third of their forward convolutions' rate, r06y.)
+  __shared__ int tapoff[CONV == 2 ? 64 : 1];
   __shared__ int tapcount;
   if (CONV == 2) {
-    long b0;
-    int x0, y0, z0, c0;
-    occf_cls_row(p.g, m0, b0, x0, y0, z0, c0);            // per_pad % 128 == 0: one class per tile
+    const int c0 = cr_cls;                                // per_pad % 128 == 0: one class per tile
     const int ntaps = p.g.kX * p.g.kY * p.g.kZ;
     if (tid < 64) {
       bool ok = tid < ntaps;
@@ -206,7 +236,15 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
         ok = ((vx % s) + s) % s == 0 && ((vy % s) + s) % s == 0 && ((vz % s) + s) % s == 0;
       }
       const unsigned long long mk = __ballot(ok);
-      if (ok) tapmap[__popcll(mk & ((1ull << tid) - 1))] = tid;
+      if (ok) {
+        const int s = p.g.stride;
+        const int dz = tid % p.g.kZ, dy = (tid / p.g.kZ) % p.g.kY, dx = tid / (p.g.kZ * p.g.kY);
+        const int ox = (c0 / (s * s) + p.g.pad_x - dx * p.g.dil) / s, oy = ((c0 / s) % s + p.g.pad_y - dy * p.g.dil) / s,
+                  oz = (c0 % s + p.g.pad_z - dz * p.g.dil) / s;
+        const int at = __popcll(mk & ((1ull << tid) - 1));
+        tapmap[at] = tid;
+        tapoff[at] = (ox + 512) | ((oy + 512) << 10) | ((oz + 512) << 20);
+      }
       if (tid == 0) tapcount = __popcll(mk);
     }
     __syncthreads();
@@ -220,7 +258,10 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
     if (CONV) {
       int tap = k0 / p.g.Cin;                       // Cin % 32 == 0: block-uniform tap
       const int c0 = k0 - tap * p.g.Cin;
+      int ox = 0, oy = 0, oz = 0;
       if (CONV == 2) {
+        const int po = tapoff[tap];
+        ox = (po & 1023) - 512; oy = ((po >> 10) & 1023) - 512; oz = ((po >> 20) & 1023) - 512;
         tap = tapmap[tap];
         k0 = tap * p.g.Cin + c0;
       }
@@ -229,7 +270,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
       for (int i = 0; i < 4; ++i) {
         int xi = a_x[i] + dx * p.g.dil, yi = a_y[i] + dy * p.g.dil, zi = a_z[i] + dz * p.g.dil;
         bool ok = a_ok[i];
-        if (p.g.transposed) {
+        if (CONV == 2) {
+          xi = a_x[i] + ox; yi = a_y[i] + oy; zi = a_z[i] + oz;
+        } else if (p.g.transposed) {
           xi = a_x[i] - dx * p.g.dil; yi = a_y[i] - dy * p.g.dil; zi = a_z[i] - dz * p.g.dil;
           const int s = p.g.stride;
           ok = ok && xi >= 0 && yi >= 0 && zi >= 0 && xi % s == 0 && yi % s == 0 && zi % s == 0;
@@ -422,10 +465,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
               const int hh = n / p.hm_dh;
               *(float4*)(e_out + ((bb * (p.N / p.hm_dh) + hh) * p.hm_rows + q) * p.hm_dh + (n - hh * p.hm_dh)) = v;
             } else if (CONV == 2 && !part) {
-              long bb;
-              int xo, yo, zo, cc;
-              if (occf_cls_row(p.g, m, bb, xo, yo, zo, cc))
-                *(float4*)(e_out + (((bb * p.g.Xo + xo) * p.g.Yo + yo) * p.g.Zo + zo) * e_ldc + n) = v;
+              const int orow = cr_row[h * 64 + row];
+              if (orow >= 0) *(float4*)(e_out + (long)orow * e_ldc + n) = v;
             } else {
               *(float4*)(e_out + m * e_ldc + n) = v;
             }
@@ -447,10 +488,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
           if (e_res) v += e_res[m * p.ldr + nn + e];
           long mo = m;
           if (CONV == 2 && !part) {
-            long bb;
-            int xo, yo, zo, cc;
-            if (!occf_cls_row(p.g, m, bb, xo, yo, zo, cc)) continue;
-            mo = ((bb * p.g.Xo + xo) * p.g.Yo + yo) * p.g.Zo + zo;
+            if (cr_row[h * 64 + row] < 0) continue;
+            mo = cr_row[h * 64 + row];
           }
           e_out[mo * e_ldc + nn + e] = v;
         }
@@ -501,16 +540,25 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 // the same for the class-major data gradient: slab rows are class-major (with padding rows), out rows are voxels
 __global__ void __launch_bounds__(256) splitk_reduce_cls_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                                 long M, int N, int S, long ldc, ConvGeomB g) {
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= M * N) return;
-  const long m = gid / N;
-  const int n = (int)(gid % N);
-  long bb;
-  int xo, yo, zo, cc;
-  if (!occf_cls_row(g, m, bb, xo, yo, zo, cc)) return;
-  float v = 0.f;
-  for (int s = 0; s < S; ++s) v += slab[(long)s * M * N + gid];
-  out[(((bb * g.Xo + xo) * g.Yo + yo) * g.Zo + zo) * ldc + n] = v;
+  // 16 rows per workgroup, each decoded once (occf_cls_row: ~450 VALU instructions) instead of once per element
+  __shared__ long orow[16];
+  const long m0 = (long)blockIdx.x * 16;
+  if (threadIdx.x < 16) {
+    const long m = m0 + threadIdx.x;
+    long bb;
+    int xo, yo, zo, cc;
+    const bool ok = m < M && occf_cls_row(g, m < M ? m : 0, bb, xo, yo, zo, cc);
+    orow[threadIdx.x] = ok ? ((bb * g.Xo + xo) * g.Yo + yo) * g.Zo + zo : -1;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 16 * N; idx += 256) {
+    const int r = idx / N, n = idx - r * N;
+    if (orow[r] < 0) continue;
+    const long gid = (m0 + r) * N + n;
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += slab[(long)s * M * N + gid];
+    out[orow[r] * ldc + n] = v;
+  }
 }
 
 static int occf_pick_ksplit(long M, int N, int K, bool wide, long workspace_floats) {
@@ -571,6 +619,13 @@ static int launch_gemm_b(GemmArgsB a, int terms, float* workspace, long workspac
     return e ? atoi(e) : 3;
   }();
   const bool deep = pf_env >= 2;
+  static const bool dgrad_pf2 = [] {
+    // class-major data gradient: two k-tiles of loads in flight (182 + 64 registers: still two workgroups per CU; the
+    // generic convolution loader at 128-wide tiles needs 209 + 64 for that and stays at one): 1.386 -> 1.247 ms on the
+    // 256 -> 128 stride-2 gradient at the 200-grid (r06r).  OCCF_DGRAD_PF=1: one
+    const char* e = getenv("OCCF_DGRAD_PF");
+    return e ? atoi(e) == 2 : true;
+  }();
   // prefetch depth per variant: as deep as the 256-register budget of two waves per SIMD allows
   // (accumulators live in AGPRs: 64 for BN = 128, 32 for BN = 64)
 #define OCCF_GB_LAUNCH(BN_, T_)                                                                              \
@@ -580,6 +635,8 @@ static int launch_gemm_b(GemmArgsB a, int terms, float* workspace, long workspac
     if (sp) {                                                                                                \
       if (deep) hipLaunchKernelGGL((gemm_bf16_kernel<BN_, T_, CONV, true, PF_SP>), grid, dim3(256), 0, st, a); \
       else hipLaunchKernelGGL((gemm_bf16_kernel<BN_, T_, CONV, true, 1>), grid, dim3(256), 0, st, a);       \
+    } else if (CONV == 2 && dgrad_pf2) {                                                                     \
+      hipLaunchKernelGGL((gemm_bf16_kernel<BN_, T_, CONV, false, 2>), grid, dim3(256), 0, st, a);             \
     } else {                                                                                                 \
       if (deep) hipLaunchKernelGGL((gemm_bf16_kernel<BN_, T_, CONV, false, PF_NS>), grid, dim3(256), 0, st, a); \
       else hipLaunchKernelGGL((gemm_bf16_kernel<BN_, T_, CONV, false, 1>), grid, dim3(256), 0, st, a);      \
@@ -594,9 +651,8 @@ static int launch_gemm_b(GemmArgsB a, int terms, float* workspace, long workspac
   }
 #undef OCCF_GB_LAUNCH
   if (a.ksplit > 1 && CONV == 2) {
-    const long total = (long)a.M * a.N;
-    hipLaunchKernelGGL(splitk_reduce_cls_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, a.slab, a.C, (long)a.M,
-                       a.N, a.ksplit, a.ldc, a.g);
+    hipLaunchKernelGGL(splitk_reduce_cls_kernel, dim3(occf_cdiv((long)a.M, 16)), dim3(256), 0, st, a.slab, a.C,
+                       (long)a.M, a.N, a.ksplit, a.ldc, a.g);
   } else if (a.ksplit > 1) {
     const long total = (long)a.M * a.N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(occf_cdiv(total, 256)), dim3(256), 0, st, a.slab, a.bias,

@@ -1070,7 +1070,9 @@ class HipOps:
         dx = torch.empty(tuple(in_shape), dtype=self.f32, device=dy.device)
         K = kX * kY * kZ * Cout
         ws, nws = self._splitk_workspace(B * Xi * Yi * Zi, Cin, K, dy.device)
-        self.last_flops = 2 * B * Xi * Yi * Zi * Cin * K
+        # (the multiply-adds of the forward convolution: every (output voxel, tap, channel pair) once -- NOT input voxels x
+        # taps, which counts the structural zeros of a strided convolution's gradient)
+        self.last_flops = 2 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * Cin * K
         self._call("occf_conv3d_bf16_dgrad", self._ptr(dy, self.f32), self._ptr(wt_split[0]), self._ptr(wt_split[1]),
                    self._ptr(dx), B, Xi, Yi, Zi, Cin, Cout, kX, kY, kZ, int(stride), int(dil), pad[0], pad[1], pad[2],
                    self._grad_terms(), self._ptr(ws), nws, self._stream())

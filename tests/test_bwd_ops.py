@@ -326,6 +326,25 @@ def test_conv3d_wgrad_dgrad(be, case, f16, wgrad_mode):
     assert _rel(dx.cpu(), x.grad.permute(0, 2, 3, 4, 1)) < 1e-4
 
 
+@pytest.mark.parametrize("case", [(2, (8, 8, 4), 64, 32, (3, 3, 3), 2, 1), (1, (16, 16, 8), 32, 64, (3, 3, 3), 2, 1),
+                                  (1, (8, 6, 4), 64, 128, (1, 1, 1), 2, 1)])
+def test_strided_dgrad_split_k(be, case, monkeypatch):
+    """the class-major data gradient with its K loop cut in two slices (forced: the cost model only splits at sizes the
+    emulator cannot afford): the per-tile row table, the tap offsets and the 16-rows-per-workgroup slab reduction"""
+    monkeypatch.setenv("OCCF_GEMM_KSPLIT", "2")
+    B, dims, Cin, Cout, k, stride, dil = case
+    x = _t("cv_x", (B, Cin, *dims), Cin).requires_grad_()
+    w = _t("cv_w", (Cout, Cin, *k), Cout) * (Cin * k[0] * k[1] * k[2]) ** -0.5
+    y = _conv_ref(x, w, k, stride, dil)
+    dy = _t("cv_dy", tuple(y.shape), 9)
+    y.backward(dy)
+    dy_cl = dy.permute(0, 2, 3, 4, 1).contiguous()
+    wt = w.permute(1, 2, 3, 4, 0).reshape(Cin, -1).contiguous()
+    sp = be.ops.split_bf16(be.to(wt))
+    dx = be.ops.conv3d_dgrad(be.to(dy_cl), sp, (B, *dims, Cin), k, stride, dil)
+    assert _rel(dx.cpu(), x.grad.permute(0, 2, 3, 4, 1)) < 1e-4
+
+
 @pytest.mark.parametrize("X,Y,S,heads,shift,B", [(14, 14, 3, 1, 0, 1), (10, 9, 2, 2, 3, 2), (7, 16, 1, 4, 3, 1),
                                                  (5, 5, 2, 3, 0, 1)])
 def test_window_attention_backward(be, X, Y, S, heads, shift, B):
