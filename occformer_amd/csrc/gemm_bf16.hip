@@ -42,6 +42,10 @@ struct ConvGeomB {
   // 27 taps on average for a 3^3 / stride-2 convolution instead of all of them with 7/8 zero-filled
   int cls;
   int per_pad;         // rows reserved per class: its (Xo/s)(Yo/s)(Zo/s) voxels rounded up to whole 128-row tiles
+  // bytes spanned by the tensor read (< 2 GiB): the loader reads it through a bounded buffer resource -- byte offset
+  // = row offset + the k-tile's tap offset (one 32-bit add), padding taps / rows select an out-of-range offset and the
+  // hardware returns zeros (no clamped coordinates, no 64-bit address arithmetic, no value masks)
+  uint32_t a_bytes;
 };
 struct GemmArgsB {
   const float* A;
@@ -168,7 +172,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
   // A staging: 4 float4 per thread; 8 consecutive lanes cover one 128-B row segment
   long a_base[4];
   int a_x[4], a_y[4], a_z[4], a_m[4], a_kq[4];
+  int a_off[4];        // CONV: byte offset of (row, tap offset 0, this thread's 16-byte column group) inside the tensor
   bool a_ok[4];
+  const occf_bbuf abuf = occf_make_bbuf(p.A, CONV ? p.g.a_bytes : 0u);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = tid + i * 256;
@@ -184,11 +190,15 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
       a_base[i] = (long)(bb >= 0 ? bb : 0) * p.g.sb;
       a_x[i] = cr_x[a_m[i]]; a_y[i] = cr_y[a_m[i]]; a_z[i] = cr_z[a_m[i]];
     } else if (CONV) {
-      const long mm = a_ok[i] ? m : 0;
-      int zo = (int)(mm % p.g.Zo);
-      int yo = (int)((mm / p.g.Zo) % p.g.Yo);
-      int xo = (int)((mm / ((long)p.g.Zo * p.g.Yo)) % p.g.Xo);
-      long b = mm / ((long)p.g.Zo * p.g.Yo * p.g.Xo);
+      // (M < 2^31: 32-bit divisions -- a 64-bit one is ~4x the instructions, five per row)
+      const unsigned mm = a_ok[i] ? (unsigned)m : 0u;
+      const unsigned q1 = mm / (unsigned)p.g.Zo;
+      const int zo = (int)(mm - q1 * (unsigned)p.g.Zo);
+      const unsigned q2 = q1 / (unsigned)p.g.Yo;
+      const int yo = (int)(q1 - q2 * (unsigned)p.g.Yo);
+      const unsigned q3 = q2 / (unsigned)p.g.Xo;
+      const int xo = (int)(q2 - q3 * (unsigned)p.g.Xo);
+      const long b = (long)q3;
       a_base[i] = b * p.g.sb;
       {
         a_x[i] = p.g.transposed ? xo + p.g.pad_x : xo * p.g.stride - p.g.pad_x;
@@ -199,6 +209,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
       a_base[i] = (a_ok[i] ? m : 0) * p.lda;
       a_x[i] = a_y[i] = a_z[i] = 0;
     }
+    // (two's complement: a border row's negative coordinates wrap; the sum with an in-range tap's offset is exact)
+    a_off[i] = CONV ? (int)((a_base[i] + a_x[i] * p.g.sx + a_y[i] * p.g.sy + a_z[i] * p.g.sz) * 4) + a_kq[i] * 16 : 0;
   }
   long b_base[NB];
   int b_n[NB], b_slot[NB];
@@ -266,27 +278,39 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgsB p) {
         k0 = tap * p.g.Cin + c0;
       }
       const int dz = tap % p.g.kZ, dy = (tap / p.g.kZ) % p.g.kY, dx = tap / (p.g.kZ * p.g.kY);
+      uint32_t voff[4];
+      if (CONV == 2 || !p.g.transposed || p.g.stride == 1) {
+        // the tap moves every row by the same (uniform) number of voxels
+        const int ddx = CONV == 2 ? ox : p.g.transposed ? -dx * p.g.dil : dx * p.g.dil;
+        const int ddy = CONV == 2 ? oy : p.g.transposed ? -dy * p.g.dil : dy * p.g.dil;
+        const int ddz = CONV == 2 ? oz : p.g.transposed ? -dz * p.g.dil : dz * p.g.dil;
+        const int toff = (int)((ddx * p.g.sx + ddy * p.g.sy + ddz * p.g.sz + c0) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool ok = a_ok[i] && (unsigned)(a_x[i] + ddx) < (unsigned)p.g.Xi &&
+                          (unsigned)(a_y[i] + ddy) < (unsigned)p.g.Yi && (unsigned)(a_z[i] + ddz) < (unsigned)p.g.Zi;
+          voff[i] = ok ? (uint32_t)(a_off[i] + toff) : OCCF_BUF_OOB;
+        }
+      } else {
+        // strided data gradient outside the class-major envelope: divisions per row
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int xi = a_x[i] - dx * p.g.dil, yi = a_y[i] - dy * p.g.dil, zi = a_z[i] - dz * p.g.dil;
+          const int s = p.g.stride;
+          bool ok = a_ok[i] && xi >= 0 && yi >= 0 && zi >= 0 && xi % s == 0 && yi % s == 0 && zi % s == 0;
+          xi = xi >= 0 ? xi / s : -1; yi = yi >= 0 ? yi / s : -1; zi = zi >= 0 ? zi / s : -1;
+          ok = ok && xi < p.g.Xi && yi < p.g.Yi && zi < p.g.Zi;
+          voff[i] = ok ? (uint32_t)((a_base[i] + xi * p.g.sx + yi * p.g.sy + zi * p.g.sz + c0) * 4 + a_kq[i] * 16)
+                       : OCCF_BUF_OOB;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        int xi = a_x[i] + dx * p.g.dil, yi = a_y[i] + dy * p.g.dil, zi = a_z[i] + dz * p.g.dil;
-        bool ok = a_ok[i];
-        if (CONV == 2) {
-          xi = a_x[i] + ox; yi = a_y[i] + oy; zi = a_z[i] + oz;
-        } else if (p.g.transposed) {
-          xi = a_x[i] - dx * p.g.dil; yi = a_y[i] - dy * p.g.dil; zi = a_z[i] - dz * p.g.dil;
-          const int s = p.g.stride;
-          ok = ok && xi >= 0 && yi >= 0 && zi >= 0 && xi % s == 0 && yi % s == 0 && zi % s == 0;
-          xi = xi >= 0 ? xi / s : -1; yi = yi >= 0 ? yi / s : -1; zi = zi >= 0 ? zi / s : -1;
-        }
-        ok = ok && xi >= 0 && xi < p.g.Xi && yi >= 0 && yi < p.g.Yi && zi >= 0 && zi < p.g.Zi;
-        const int xc = occf_clampi(xi, p.g.Xi - 1), yc = occf_clampi(yi, p.g.Yi - 1),
-                  zc = occf_clampi(zi, p.g.Zi - 1);
-        const float4 v = *(const float4*)(p.A + a_base[i] + xc * p.g.sx + yc * p.g.sy + zc * p.g.sz + c0 +
-                                          a_kq[i] * 4);
-        ra[d][i].x = ok ? v.x : 0.f;
-        ra[d][i].y = ok ? v.y : 0.f;
-        ra[d][i].z = ok ? v.z : 0.f;
-        ra[d][i].w = ok ? v.w : 0.f;
+        const occf_u32x4 v = occf_bbuf_load_b128(abuf, voff[i]);
+        ra[d][i].x = occf_u2f(v.x);
+        ra[d][i].y = occf_u2f(v.y);
+        ra[d][i].z = occf_u2f(v.z);
+        ra[d][i].w = occf_u2f(v.w);
       }
     } else {
       // rows >= M read row 0: their products land in accumulator rows the epilogue never stores
@@ -738,6 +762,10 @@ extern "C" int occf_conv3d_bf16_fwd(const float* x, const uint16_t* w_hi, const 
   g.sb = in_sb; g.sx = in_sx; g.sy = in_sy; g.sz = in_sz;
   const long M = (long)B * g.Xo * g.Yo * g.Zo;
   if (g.Xo <= 0 || g.Yo <= 0 || g.Zo <= 0 || M >= 2147483647L) return OCCF_ESHAPE;
+  // the input (possibly a strided view) is read through a bounded buffer: its extent in bytes, < 2 GiB
+  const long ext = ((long)(B - 1) * in_sb + (long)(Xi - 1) * in_sx + (long)(Yi - 1) * in_sy + (long)(Zi - 1) * in_sz + Cin) * 4;
+  if (in_sb < 0 || in_sx < 0 || in_sy < 0 || in_sz < 0 || ext >= 2147483647L) return OCCF_ESHAPE;
+  g.a_bytes = (uint32_t)ext;
   a.A = x; a.Wh = w_hi; a.Wl = w_lo; a.bias = bias; a.residual = residual; a.C = out;
   a.M = (int)M; a.N = Cout; a.K = kX * kY * kZ * Cin; a.lda = 0; a.ldc = Cout; a.ldr = Cout; a.act = act;
   a.gn_partial = gn_partial;
@@ -765,7 +793,8 @@ extern "C" int occf_conv3d_bf16_dgrad(const float* dy, const uint16_t* wt_hi, co
   g.Cin = Cout;
   g.sz = Cout; g.sy = (long)Zo * Cout; g.sx = (long)Yo * Zo * Cout; g.sb = (long)Xo * Yo * Zo * Cout;
   const long M = (long)B * Xi * Yi * Zi;
-  if (M >= 2147483647L) return OCCF_ESHAPE;
+  if (M >= 2147483647L || (long)B * g.sb * 4 >= 2147483647L) return OCCF_ESHAPE;   // (dY is read through a bounded buffer)
+  g.a_bytes = (uint32_t)((long)B * g.sb * 4);
   a.A = dy; a.Wh = wt_hi; a.Wl = wt_lo; a.C = dx;
   a.M = (int)M; a.N = Cin; a.K = kX * kY * kZ * Cout; a.lda = 0; a.ldc = Cin; a.ldr = Cin; a.act = 0;
   static const int cls_env = [] {

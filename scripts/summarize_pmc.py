@@ -63,14 +63,23 @@ for key in val:
     if mf and va:
         row["valu_per_mfma"] = va / mf
         row["mfma_per_launch"] = mf
+    if gui and va:
+        # a wave64 VALU instruction occupies its SIMD's vector pipe for 4 cycles (MFMAs are counted in SQ_INSTS_VALU too:
+        # they issue in one pass and run on the matrix pipe, so they are taken out first)
+        row["valu_busy_frac"] = (va - (mf or 0.0)) * 4.0 / 1024.0 / (gui / 8.0)
     rows.append(row)
-rows.sort(key=lambda r: -(r["fetch_bytes"] + r["write_bytes"]) * r["calls"])
-print(f"{'kernel':72s} {'grid':>9s} {'calls':>5s} {'fetch_x2 MB':>12s} {'write MB':>9s} {'mfma busy':>9s} {'GHz':>5s} {'wait':>5s} {'valu/mfma':>9s}")
+BY_TIME = "--by-time" in sys.argv
+if BY_TIME:
+    sys.argv.remove("--by-time")
+    rows.sort(key=lambda r: -r.get("duration_us_under_pmc", 0.0) * r["calls"])
+else:
+    rows.sort(key=lambda r: -(r["fetch_bytes"] + r["write_bytes"]) * r["calls"])
+print(f"{'kernel':72s} {'grid':>9s} {'calls':>5s} {'fetch_x2 MB':>12s} {'write MB':>9s} {'mfma busy':>9s} {'GHz':>5s} {'wait':>5s} {'valu/mfma':>9s} {'valu busy':>9s} {'us':>8s}")
 fmt = lambda v, f: (f % v) if v is not None else "-"
-for r in rows[:40]:
+for r in rows[:(120 if BY_TIME else 40)]:
     print(f"{r['kernel'][:72]:72s} {r['grid']:9d} {r['calls']:5d} {r['fetch_bytes'] / 1e6:12.2f} {r['write_bytes'] / 1e6:9.2f} "
           f"{fmt(r.get('mfma_busy_frac'), '%.3f'):>9s} {fmt(r.get('clock_ghz'), '%.2f'):>5s} {fmt(r.get('wait_inst_any_frac'), '%.2f'):>5s} "
-          f"{fmt(r.get('valu_per_mfma'), '%.2f'):>9s}")
+          f"{fmt(r.get('valu_per_mfma'), '%.2f'):>9s} {fmt(r.get('valu_busy_frac'), '%.3f'):>9s} {fmt(r.get('duration_us_under_pmc'), '%.1f'):>8s}")
 if len(sys.argv) > 2:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from occformer_amd.csrc.build import _digest
