@@ -603,7 +603,10 @@ static int occf_pick_ksplit(long M, int N, int K, bool wide, long workspace_floa
     const double slab_us = (double)M * N * 8.0 / 5.0e6;  // per slice, at ~5 TB/s (mostly L2/MALL resident)
     double best = 1e30;
     S = 1;
-    const int smax = nk / 4 < 16 ? nk / 4 : 16;
+    // at most 16 slices -- or, for a handful of tiles with a long K (the matching costs' [200, 50 176] x [17, 50 176]:
+    // two tiles, 1 568 k-tiles: 32 workgroups at 16 slices, 70 us for 44 MB), as many as fill the CUs once with pairs
+    const int cap = tiles * 16 >= 512 ? 16 : (int)(512 / tiles < 128 ? 512 / tiles : 128);
+    const int smax = nk / 4 < cap ? nk / 4 : cap;
     for (int c = 1; c <= smax; ++c) {
       const long turns = (tiles * c + 255) / 256;
       const double eff = turns == 1 ? 1.6 : (double)turns;

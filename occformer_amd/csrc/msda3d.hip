@@ -657,6 +657,52 @@ __global__ void __launch_bounds__(256) msda3d_bwd_value_gather_kernel(const floa
   dvalue[((long)b * Nv + lv.start[ls] + cell) * ((long)H * Dh) + h * Dh + ch] += s;
 }
 
+// the same, four channels per thread and 32-bit index arithmetic: blockIdx.y = (b, h), thread = (cell, channel quad).
+// The scalar kernel above decodes (b, h, cell, channel) from one 64-bit index -- six 64-bit and eight 32-bit run-time
+// divisions per output ELEMENT: its vector pipe was 89 % busy (PMC r06t), 200 us per call for 0.2 GB of traffic.
+// Needs Dh % 4 == 0 and tc.CH % 4 == 0 (a quad never straddles a pass).
+__global__ void __launch_bounds__(256) msda3d_bwd_value_gather4_kernel(const float* __restrict__ scratch,
+                                                                       float* __restrict__ dvalue, MsdaLevels lv,
+                                                                       MsdaTileCfg tc, int B, int H, int Dh) {
+  const int ls = tc.ls;
+  const int Xs = lv.X[ls], Ys = lv.Y[ls], Zs = lv.Z[ls];
+  const unsigned cells = (unsigned)(Xs * Ys * Zs), q4 = (unsigned)Dh >> 2;
+  const unsigned g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= cells * q4) return;
+  const unsigned cell = g / q4;
+  const int ch = (int)(g - cell * q4) * 4;
+  const int h = (int)(blockIdx.y % (unsigned)H), b = (int)(blockIdx.y / (unsigned)H);
+  const unsigned cxy = cell / (unsigned)Zs;
+  const int z = (int)(cell - cxy * (unsigned)Zs);
+  const int x = (int)(cxy / (unsigned)Ys), y = (int)(cxy - (unsigned)x * (unsigned)Ys);
+  const int pass = ch / tc.CH, chl = ch - pass * tc.CH;
+  const int RX = tc.T + 2 * tc.M, RY = RX;
+  const long region = (long)RX * RY * Zs * tc.CH;
+  const long nblk = (long)tc.tiles_x * tc.tiles_y * tc.groups * tc.passes;
+  const float* base = scratch + ((long)b * H + h) * nblk * region;
+  int tx_lo = (x - tc.M - tc.T + 1), ty_lo = (y - tc.M - tc.T + 1);
+  tx_lo = tx_lo <= 0 ? 0 : (tx_lo + tc.T - 1) / tc.T;
+  ty_lo = ty_lo <= 0 ? 0 : (ty_lo + tc.T - 1) / tc.T;
+  int tx_hi = (x + tc.M) / tc.T, ty_hi = (y + tc.M) / tc.T;
+  tx_hi = tx_hi > tc.tiles_x - 1 ? tc.tiles_x - 1 : tx_hi;
+  ty_hi = ty_hi > tc.tiles_y - 1 ? tc.tiles_y - 1 : ty_hi;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int tx = tx_lo; tx <= tx_hi; ++tx)
+    for (int ty = ty_lo; ty <= ty_hi; ++ty) {
+      const long local = (((long)(x - (tx * tc.T - tc.M)) * RY + (y - (ty * tc.T - tc.M))) * Zs + z) * tc.CH + chl;
+      for (int gq = 0; gq < tc.groups; ++gq) {
+        const long blk = (((long)tx * tc.tiles_y + ty) * tc.groups + gq) * tc.passes + pass;
+        const float4 v = *(const float4*)(base + blk * region + local);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+  const long Nv = lv.start[lv.n - 1] + (long)lv.X[lv.n - 1] * lv.Y[lv.n - 1] * lv.Z[lv.n - 1];
+  float4* d = (float4*)(dvalue + ((long)b * Nv + lv.start[ls] + cell) * ((long)H * Dh) + h * Dh + ch);
+  float4 o = *d;
+  o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+  *d = o;
+}
+
 static bool msda_tile_cfg(const MsdaLevels& lv, int ls, int Dh, MsdaTileCfg& tc) {
   // bytes of LDS per workgroup (8 bytes per element).  Larger tiles are slower: 140 KB 2.51 ms, 156 KB 2.72 ms per call
   // against 2.50 (profiles/r04/r04k_msda_lds_sweep.txt) -- fewer, longer workgroups on the same LDS atomic rate
@@ -880,8 +926,14 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
                              dout, dvalue, workspace, absmax, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld,
                              (const float4*)rec_w, (const uint32_t*)rec_c);
         const long cells = (long)B * heads * lv.X[l] * lv.Y[l] * lv.Z[l] * head_dim;
-        hipLaunchKernelGGL(msda3d_bwd_value_gather_kernel, dim3(occf_cdiv(cells, 256)), dim3(256), 0, st, workspace,
-                           dvalue, lv, tc, B, heads, head_dim);
+        const long per_bh = (long)lv.X[l] * lv.Y[l] * lv.Z[l] * (head_dim / 4);
+        if (head_dim % 4 == 0 && tc.CH % 4 == 0 && per_bh < 2147483647L && (long)B * heads < 65536 &&
+            ((size_t)workspace & 15) == 0 && ((size_t)dvalue & 15) == 0)
+          hipLaunchKernelGGL(msda3d_bwd_value_gather4_kernel, dim3((unsigned)occf_cdiv(per_bh, 256), (unsigned)(B * heads)),
+                             dim3(256), 0, st, workspace, dvalue, lv, tc, B, heads, head_dim);
+        else
+          hipLaunchKernelGGL(msda3d_bwd_value_gather_kernel, dim3(occf_cdiv(cells, 256)), dim3(256), 0, st, workspace,
+                             dvalue, lv, tc, B, heads, head_dim);
       }
     }
   }
