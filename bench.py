@@ -198,8 +198,12 @@ def _conv_entry(name, shp, ms, flops, prec):
             # csrc/wgrad_g8.h: tiles of 192 / 128 / 64 channels, LDS-DMA staging (the largest tile class of the launch)
             tile = lambda c: 3 if c % 192 == 0 or (c % 128 == 64 and c >= 192) else 2 if c % 128 == 0 else 1
             ti, tc = tile(Cout), tile(Cin)
-            kname = f"wgrad_g8_kernel<{ti}, {tc}, {1 if ti + tc >= 5 else 2}, 2, {'true' if f16 else 'false'}>"
-        if f16:
+            x1 = f16 and getattr(ops, "wgrad_f16_single", False)
+            kname = (f"wgrad_g8_kernel<{ti}, {tc}, 2, 2, true, true>" if x1 else
+                     f"wgrad_g8_kernel<{ti}, {tc}, {1 if ti + tc >= 5 else 2}, 2, {'true' if f16 else 'false'}, false>")
+            if x1:
+                products = 1.0           # dy and x each ONE fp16 piece (csrc/wgrad_g8.h X1; precision_probe.py wg1c)
+        if f16 and products != 1.0:
             products = 2.0
         nbytes = 4 * (B * X * Y * Z * Cout) + 4 * int(torch.tensor(shp[1]).prod()) + 4 * Cout * taps * Cin
         traffic, src = pmc_traffic(kname.split(", ...")[0], None, pick="bytes")

@@ -520,7 +520,9 @@ int occf_linear_wgrad(const float* dy, const float* x, float* dw, float* dbias, 
                       long workspace_floats, long M, int N, int K, long ldy, long ldx, int terms, void* stream);
 
 /* Weight gradient of occf_conv3d_*_fwd in the tap-major layout dw[Cout, kX*kY*kZ*Cin]; x addressed by strides as in
- * the forward, dy[B*Xo*Yo*Zo, Cout] contiguous. */
+ * the forward, dy[B*Xo*Yo*Zo, Cout] contiguous.  terms as occf_linear_wgrad, plus terms = 4: ONE product per product
+ * -- dy (scaled) and x each as one fp16 piece -- on the G8 kernel's shapes (stride 1, 3^3, Z % 8 == 0, channels % 64
+ * == 0, dense x); every other shape computes terms = 2. */
 long occf_conv3d_wgrad_workspace(int B, int Xi, int Yi, int Zi, int Cin, int Cout, int kX, int kY, int kZ, int stride,
                                  int dil, int pad_x, int pad_y, int pad_z);
 int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapmajor, float* dbias, float* workspace,

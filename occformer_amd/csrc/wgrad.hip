@@ -891,7 +891,10 @@ extern "C" int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapm
                                  long in_sx, long in_sy, long in_sz, int terms, void* stream) {
   if (B <= 0 || Cin % 4 || Cout % 4 || stride <= 0 || dil <= 0) return OCCF_ESHAPE;
   if (in_sb % 4 || in_sx % 4 || in_sy % 4 || in_sz % 4) return OCCF_ESHAPE;
-  if (terms != 1 && terms != 2 && terms != 3) return OCCF_EINVAL;
+  if (terms != 1 && terms != 2 && terms != 3 && terms != 4) return OCCF_EINVAL;
+  // terms == 4: ONE product -- dy and x each in one fp16 piece -- where the G8 kernel applies; elsewhere it means 2
+  const bool x1 = terms == 4;
+  if (x1) terms = 2;
   WgArgs a = {};
   WgGeom& g = a.g;
   g.B = B; g.Xi = Xi; g.Yi = Yi; g.Zi = Zi; g.kX = kX; g.kY = kY; g.kZ = kZ; g.stride = stride; g.dil = dil;
@@ -929,8 +932,12 @@ extern "C" int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapm
       wg_absmax(dy, a.M, Cout, (long)Cout, scale, st);
       hipLaunchKernelGGL(wg8_split_y_kernel<true>, dim3(occf_cdiv((a.M / 8) * Cout, 256)), dim3(256), 0, st, dy,
                          (long)Cout, a.M / 8, Cout, (wg_u4*)yh, (wg_u4*)yl, scale);
-      hipLaunchKernelGGL(wg8_split_x_kernel<true>, dim3(occf_cdiv(cols * ZG * Cin, 256)), dim3(256), 0, st, x, cols, ZG,
-                         Cin, (wg_u4*)xh, (wg_u4*)xl, cols * ZG * Cin);
+      if (x1)
+        hipLaunchKernelGGL((wg8_split_x_kernel<true, true>), dim3(occf_cdiv(cols * ZG * Cin, 256)), dim3(256), 0, st, x,
+                           cols, ZG, Cin, (wg_u4*)xh, (wg_u4*)xl, cols * ZG * Cin);
+      else
+        hipLaunchKernelGGL(wg8_split_x_kernel<true>, dim3(occf_cdiv(cols * ZG * Cin, 256)), dim3(256), 0, st, x, cols, ZG,
+                           Cin, (wg_u4*)xh, (wg_u4*)xl, cols * ZG * Cin);
     } else {
       hipLaunchKernelGGL(wg8_split_y_kernel<false>, dim3(occf_cdiv((a.M / 8) * Cout, 256)), dim3(256), 0, st, dy,
                          (long)Cout, a.M / 8, Cout, (wg_u4*)yh, (wg_u4*)yl, scale);
@@ -952,7 +959,8 @@ extern "C" int occf_conv3d_wgrad(const float* dy, const float* x, float* dw_tapm
         if (!sn[i].count || !sc[j].count) continue;
         q.n_base = sn[i].base; q.tn_count = sn[i].count; q.c_base = sc[j].base; q.tc_count = sc[j].count;
         q.tiles = a.taps * sn[i].count * sc[j].count;
-        if (terms == 2) wg8_launch_class<true>(q, sn[i].w / 64, sc[j].w / 64, st);
+        if (terms == 2 && x1) wg8_launch_class_x1(q, sn[i].w / 64, sc[j].w / 64, st);
+        else if (terms == 2) wg8_launch_class<true>(q, sn[i].w / 64, sc[j].w / 64, st);
         else wg8_launch_class<false>(q, sn[i].w / 64, sc[j].w / 64, st);
       }
     if (S > 1)

@@ -38,6 +38,9 @@ class HipOps:
         self.wgrad_f16 = os.environ.get("OCCF_WGRAD_F16", "1") != "0"
         # (the linears' weight gradients are bound by their operand staging: two products are no faster than three, r06a)
         self.wgrad_f16_linear = os.environ.get("OCCF_WGRAD_F16_LINEAR", "0") == "1"
+        # the convolutions' weight gradients on ONE product (dy and x each one fp16 piece) where the G8 kernel applies:
+        # scripts/precision_probe.py wg1c -- whole gradient 4.5e-5 -> 5.0e-5, worst parameter 4.4e-4 -> 5.9e-4
+        self.wgrad_f16_single = os.environ.get("OCCF_WGRAD_F16_SINGLE", "1") != "0"
         self.use_halo_conv = os.environ.get("OCCF_HALO_CONV", "1") == "1"
         self.halo_frag = os.environ.get("OCCF_HALO_FRAG", "1") == "1"
         # Winograd F(2, 3) along x for the stride-1 3^3 convolutions (csrc/conv_wino.hip); 0 = the direct halo kernel
@@ -1056,7 +1059,8 @@ class HipOps:
         self.last_flops = 2 * dy.numel() * kX * kY * kZ * Cin
         self._call("occf_conv3d_wgrad", self._ptr(dy, self.f32), ctypes.c_void_p(x_cl.data_ptr()), self._ptr(dw),
                    self._ptr(db), self._ptr(ws), need, *geom, x_cl.stride(0), x_cl.stride(1), x_cl.stride(2),
-                   x_cl.stride(3), self._wgrad_terms(), self._stream())
+                   x_cl.stride(3), 4 if (self._wgrad_terms() == 2 and self.wgrad_f16_single) else self._wgrad_terms(),
+                   self._stream())
         return dw, db
 
     def conv3d_dgrad(self, dy, wt_split, in_shape, ksize, stride=1, dil=1, pad=None):

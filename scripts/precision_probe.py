@@ -16,6 +16,7 @@ kernel would implement: one staged array instead of two) in exactly that family'
   cf11  the stride-1 3^3 convolutions (the LDS-halo kernel: every one is followed by a GroupNorm), FORWARD only
   cd11  the same convolutions' DATA gradients only (the forward conv on the tap-flipped weight inside Conv3d.backward)
   cfd11 both
+  wg1c  the convolutions' WEIGHT gradients on one product: dy in one fp16 piece (as shipped) AND x in one fp16 piece
   lin11 the streaming linears (M >= 16 384 rows: Swin qkv / proj / FFN, pixel-decoder and decoder-memory projections),
         forward and data gradient; the eval-mode forward runs with the fused Swin / MLP kernels off so that the same
         linears are hit"""
@@ -113,6 +114,7 @@ def main():
     for mode, bits in (("default: bf16x3, weight gradients on 2 fp16-piece products", None),
                        ("bf16x3 everywhere (weight gradients on 3 bf16 products: the round-5 arithmetic)", "wg3"),
                        ("default + the weight gradients of every convolution with <= 4096 output voxels EXACT (fp64)", "wgx"),
+                       ("default + the CONVOLUTIONS' weight gradients on ONE product: dy and x each in one fp16 piece", "wg1c"),
                        ("3^3 halo convolutions FORWARD only: activation in ONE fp16 piece (2 products)", "cf11"),
                        ("3^3 halo convolutions DATA GRADIENT only: dy in ONE fp16 piece (2 products)", "cd11"),
                        ("3^3 halo convolutions forward + data gradient (2 products)", "cfd11"),
@@ -166,6 +168,9 @@ def main():
                 p.data.copy_(round_bits(exact[id(p)], bits))
             ops.linear_wgrad = lambda dy, x, *a, _f=orig["linear_wgrad"], **k: _f(round_bits(dy, bits), x, *a, **k)
             ops.conv3d_wgrad = lambda dy, x, *a, _f=orig["conv3d_wgrad"], **k: _f(round_bits(dy, bits), x, *a, **k)
+        elif bits == "wg1c":
+            # (x rounded to 11 bits: its fp16 lo half is zero, so the shipped two-product kernel computes the one product)
+            ops.conv3d_wgrad = lambda dy, x, *a, _f=orig["conv3d_wgrad"], **k: _f(dy, round_bits(x, 11), *a, **k)
         elif bits == "wg11":
             ops.linear_wgrad = lambda dy, x, *a, _f=orig["linear_wgrad"], **k: _f(round_bits(dy, 11), x, *a, **k)
             ops.conv3d_wgrad = lambda dy, x, *a, _f=orig["conv3d_wgrad"], **k: _f(round_bits(dy, 11), x, *a, **k)

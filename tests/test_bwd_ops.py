@@ -213,11 +213,12 @@ def wgrad_mode():
     saved = []
 
     def set_mode(be, f16):
-        saved.append((be.ops, be.ops.wgrad_f16, be.ops.wgrad_f16_linear))
+        saved.append((be.ops, be.ops.wgrad_f16, be.ops.wgrad_f16_linear, be.ops.wgrad_f16_single))
         be.ops.wgrad_f16 = be.ops.wgrad_f16_linear = bool(f16)
+        be.ops.wgrad_f16_single = f16 == "x1"       # the convolutions' one-product form (G8 shapes)
     yield set_mode
-    for ops, v, vl in saved:
-        ops.wgrad_f16, ops.wgrad_f16_linear = v, vl
+    for ops, v, vl, vs in saved:
+        ops.wgrad_f16, ops.wgrad_f16_linear, ops.wgrad_f16_single = v, vl, vs
 
 
 def test_point_loss_rows_backward(be):
@@ -302,11 +303,16 @@ def _conv_ref(x, w, k, stride, dil):
     return F.conv3d(x, w, stride=stride, dilation=dil, padding=pad)
 
 
-@pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("f16", [False, True, "x1"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv3d_wgrad_dgrad(be, case, f16, wgrad_mode):
+    """f16 = True: dy in one fp16 piece x the fp16 (hi, lo) halves of x; "x1": ONE product -- x too in one fp16 piece --
+    on the G8 kernel's shapes (the other shapes compute the two-product form: skipped here)"""
     wgrad_mode(be, f16)
     B, dims, Cin, Cout, k, stride, dil = case
+    if f16 == "x1" and not (stride == 1 and dil == 1 and k == (3, 3, 3) and dims[2] % 8 == 0 and Cin % 64 == 0 and
+                            Cout % 64 == 0 and B * dims[0] * dims[1] * dims[2] >= 1024):
+        pytest.skip("not a G8 shape")
     x = _t("cv_x", (B, Cin, *dims), Cin).requires_grad_()
     w = (_t("cv_w", (Cout, Cin, *k), Cout) * (Cin * k[0] * k[1] * k[2]) ** -0.5).requires_grad_()
     y = _conv_ref(x, w, k, stride, dil)
@@ -316,7 +322,13 @@ def test_conv3d_wgrad_dgrad(be, case, f16, wgrad_mode):
     dy_cl = dy.permute(0, 2, 3, 4, 1).contiguous()
     dw, _ = be.ops.conv3d_wgrad(be.to(dy_cl), be.to(x_cl), k, stride, dil)
     ref_dw = w.grad.permute(0, 2, 3, 4, 1).reshape(Cout, -1)
-    assert _rel(dw.cpu(), ref_dw) < (3e-4 if f16 else 1e-4)
+    assert _rel(dw.cpu(), ref_dw) < (6e-4 if f16 == "x1" else 3e-4 if f16 else 1e-4)
+    if f16 == "x1":
+        # ... and it IS the one-product arithmetic: the two-product kernel on x rounded to one fp16 piece agrees to
+        # accumulation-order noise
+        be.ops.wgrad_f16_single = False
+        dw2, _ = be.ops.conv3d_wgrad(be.to(dy_cl), be.to(x_cl.half().float()), k, stride, dil)
+        assert _rel(dw.cpu(), dw2.cpu()) < 2e-6
     if f16:
         return                              # (the data gradient does not depend on the mode)
     # data gradient: weight re-laid as [Cin, taps * Cout]

@@ -26,7 +26,7 @@ def test_conv3d_stage0(hip):
     assert _rel(out.permute(0, 4, 1, 2, 3), ref) < 1e-4
 
 
-@pytest.mark.parametrize("f16", [False, True])
+@pytest.mark.parametrize("f16", [False, True, "x1"])
 @pytest.mark.parametrize("C,dims", [(192, (200, 200, 16)), (128, (200, 200, 16)), (256, (100, 100, 8))])
 def test_conv3d_wgrad_full_size_taps(hip, C, dims, f16):
     """the weight gradient of the full-resolution 3^3 convolutions (csrc/wgrad_g8.h: LDS-DMA pipeline over ~2 500
@@ -37,12 +37,14 @@ def test_conv3d_wgrad_full_size_taps(hip, C, dims, f16):
     X, Y, Z = dims
     x = torch.randn(1, X, Y, Z, C, generator=g).to(dev)
     dy = torch.randn(1, X, Y, Z, C, generator=g).to(dev) * (1e-6 if f16 else 1.0)
-    saved = hip.ops.wgrad_f16
-    hip.ops.wgrad_f16 = f16           # two fp16-piece products (dy in one piece after its power-of-two scale): 6e-4
+    saved = hip.ops.wgrad_f16, hip.ops.wgrad_f16_single
+    # True: two fp16-piece products (dy in one piece after its power-of-two scale): 6e-4; "x1": ONE product (x in one
+    # fp16 piece too -- the default of the training step): 8e-4
+    hip.ops.wgrad_f16, hip.ops.wgrad_f16_single = bool(f16), f16 == "x1"
     try:
-        _wgrad_full_size_check(hip, C, X, Y, Z, x, dy, 6e-4 if f16 else 2e-4)
+        _wgrad_full_size_check(hip, C, X, Y, Z, x, dy, 8e-4 if f16 == "x1" else 6e-4 if f16 else 2e-4)
     finally:
-        hip.ops.wgrad_f16 = saved
+        hip.ops.wgrad_f16, hip.ops.wgrad_f16_single = saved
 
 
 def _wgrad_full_size_check(hip, C, X, Y, Z, x, dy, bound):
