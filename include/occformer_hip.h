@@ -319,6 +319,8 @@ int occf_conv3x3x3_wino_fwd(const float* x, const uint16_t* wfrag_hi, const uint
                             const float* residual, float* out, int B, int X, int Y, int Z, int Cin, int Cout,
                             long in_sb, long in_sx, long in_sy, long in_sz, int act, float* gn_partial,
                             const uint32_t* f16_scale, void* stream);
+/* (wfrag_lo == NULL together with f16_scale != NULL selects the ONE-product form of the two-product kernel below: the
+ * transformed filters too as one fp16 piece -- the hi fragments alone.) */
 /* Two-product form of the same kernel (f16_scale != NULL, fragments packed with f16 = 1): x enters as ONE fp16 piece of
  * (transformed x) * 2^k, k from max |x| (f16_scale = a scale slot filled by occf_absmax_f32 on the same stream), the
  * filters as fp16 (hi, lo); the output leaves multiplied by 2^-k.  The op layer uses it for the data gradients.

@@ -27,6 +27,11 @@
 // DATA GRADIENTS (the forward convolution of dy on the tap-flipped weight): scripts/precision_probe.py measures no
 // change of any gradient figure with dy rounded to 11 bits there (profiles/r06: whole gradient 4.9e-5 vs 5.0e-5), while
 // the same cut in the forward convolutions moves the per-parameter figures to the edge of their bound.
+//
+// W1 variant of it (ONE product per product): the filters too as ONE fp16 piece (the hi half of the same packed
+// fragments; the lo array is not read): half the MFMAs and half the weight-fragment loads of the F16 variant.
+// precision_probe.py `cd1` (profiles/r06/r06x_precision_cd1.txt): whole gradient 5.0e-5 -> 5.2e-5, 90 % of the
+// parameters 1.3e-4 -> 2.0e-4, worst 5.9e-4 -> 6.9e-4 against bounds of 1e-3 / 1e-3 / 6e-3.
 #include <stdlib.h>
 #include "occf_common.h"
 #include "occf_absmax.h"
@@ -58,8 +63,9 @@ __device__ __forceinline__ int cw_pos(int m) {
 }
 __device__ __forceinline__ float cw_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int TN, bool F16>
+template <int TN, bool F16, bool W1 = false>
 __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) {
+  static_assert(F16 || !W1, "the one-piece filter belongs to the fp16 variant");
   constexpr int BN = 64 * TN;
   constexpr int HROW = 80;                             // bytes per halo row: 32 bf16 + pad (conflict-free b128 reads)
   constexpr int NUT = 2;                               // staging units per thread (<= 1024 units: HY * HZ * 8)
@@ -190,7 +196,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       fh[j] = *(const bf16x8*)(p.Fh + o + j * 512 + lane8);
-      fl[j] = *(const bf16x8*)(p.Fl + o + j * 512 + lane8);
+      if (!W1) fl[j] = *(const bf16x8*)(p.Fl + o + j * 512 + lane8);
     }
   };
   const int a_base = hb[0] * HROW + lk * 16;
@@ -208,10 +214,12 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
   auto mma_tm = [&](const bf16x8 (&ah)[2], const bf16x8 (&al)[2], const bf16x8 (&fh)[TN],
                     const bf16x8 (&fl)[TN]) __attribute__((always_inline)) {
     if (F16) {
+      if (!W1) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = occf_mfma_f16_32x32x16(ah[i], fl[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) acc[i][j] = occf_mfma_f16_32x32x16(ah[i], fl[j], acc[i][j]);
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -242,8 +250,8 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
   bf16x8 fh[BD][TN], fl[BD][TN];
   bf16x8 a0h[2], a0l[2], a1h[2], a1l[2];
   constexpr int NA = F16 ? 2 : 4;                      // ds_read_b128 per k-step
-  constexpr int NF = 2 * TN;                           // global 16-byte loads per k-step
-  constexpr int NM = (F16 ? 4 : 6) * TN;               // MFMAs per k-step
+  constexpr int NF = (W1 ? 1 : 2) * TN;                // global 16-byte loads per k-step
+  constexpr int NM = (W1 ? 2 : F16 ? 4 : 6) * TN;      // MFMAs per k-step
   int b_cc = 0, b_tap = 0, b_s = 0;                    // stream position of the NEXT fragment set to load
   auto load_next_b = [&](bf16x8 (&h)[TN], bf16x8 (&l)[TN]) __attribute__((always_inline)) {
     load_f(b_cc, b_tap, b_s, h, l);
@@ -268,7 +276,7 @@ __global__ void __launch_bounds__(512, 1) conv3x3x3_wino_kernel(ConvWinoArgs p) 
     load_next_b(fh[BLOAD], fl[BLOAD]);                                                                \
     mma_tm(ACH, ACL, fh[BCUR], fl[BCUR]);                                                             \
     _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) { OCCF_SCHED_GROUP(0x008, 1); OCCF_SCHED_GROUP(0x100, 1); } \
-    _Pragma("unroll") for (int i_ = 0; i_ < NF; ++i_) { OCCF_SCHED_GROUP(0x008, 1); OCCF_SCHED_GROUP(0x020, 1); } \
+    _Pragma("unroll") for (int i_ = 0; i_ < NF; ++i_) { OCCF_SCHED_GROUP(0x008, (NM >= NA + NF ? 1 : 0)); OCCF_SCHED_GROUP(0x020, 1); } \
     OCCF_SCHED_GROUP(0x008, (NM > NA + NF ? NM - NA - NF : 0));                                       \
     OCCF_SCHED_FENCE();                                                                               \
   } while (0)
@@ -516,7 +524,8 @@ extern "C" int occf_conv3x3x3_wino_fwd(const float* x, const uint16_t* wfrag_hi,
                                        int Z, int Cin, int Cout, long in_sb, long in_sx, long in_sy, long in_sz,
                                        int act, float* gn_partial, const uint32_t* f16_scale, void* stream) {
   if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0 || Cin <= 0 || Cin % 32 != 0 || Cout <= 0) return OCCF_ESHAPE;
-  if (!conv_wino_enabled() || !wfrag_hi || !wfrag_lo) return OCCF_ESHAPE;
+  // (f16_scale given and wfrag_lo NULL: the one-product W1 variant)
+  if (!conv_wino_enabled() || !wfrag_hi || (!wfrag_lo && !f16_scale)) return OCCF_ESHAPE;
   if (in_sb % 4 || in_sx % 4 || in_sy % 4 || in_sz % 4) return OCCF_ESHAPE;
   if ((long)X * in_sx >= 2147483647L || (long)Y * in_sy >= 2147483647L) return OCCF_ESHAPE;  // int halo offsets
   const int TZ = conv_wino_tz(Z);
@@ -538,13 +547,15 @@ extern "C" int occf_conv3x3x3_wino_fwd(const float* x, const uint16_t* wfrag_hi,
   const long blocks = (long)B * ((X + 1) / 2) * ((Y + TY - 1) / TY) * (Z / TZ) * (Cout / (64 * TN));
   if (blocks >= 2147483647L) return OCCF_ESHAPE;
   typedef void (*fn_t)(ConvWinoArgs);
-  const bool f16 = f16_scale != nullptr;
-  const fn_t fn = f16 ? (TN == 1 ? conv3x3x3_wino_kernel<1, true> : TN == 2 ? conv3x3x3_wino_kernel<2, true>
-                                                                            : conv3x3x3_wino_kernel<3, true>)
-                      : (TN == 1 ? conv3x3x3_wino_kernel<1, false> : TN == 2 ? conv3x3x3_wino_kernel<2, false>
-                                                                             : conv3x3x3_wino_kernel<3, false>);
+  const int f16 = f16_scale == nullptr ? 0 : wfrag_lo ? 1 : 2;
+  const fn_t fn = f16 == 2 ? (TN == 1 ? conv3x3x3_wino_kernel<1, true, true> : TN == 2 ? conv3x3x3_wino_kernel<2, true, true>
+                                                                                       : conv3x3x3_wino_kernel<3, true, true>)
+                  : f16 ? (TN == 1 ? conv3x3x3_wino_kernel<1, true> : TN == 2 ? conv3x3x3_wino_kernel<2, true>
+                                                                              : conv3x3x3_wino_kernel<3, true>)
+                        : (TN == 1 ? conv3x3x3_wino_kernel<1, false> : TN == 2 ? conv3x3x3_wino_kernel<2, false>
+                                                                               : conv3x3x3_wino_kernel<3, false>);
 #ifndef OCCF_EMU
-  static bool attr_set[4][2] = {};
+  static bool attr_set[4][3] = {};
   if (!attr_set[TN][f16]) {
     hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;

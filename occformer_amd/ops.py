@@ -47,6 +47,9 @@ class HipOps:
         self.use_wino = os.environ.get("OCCF_WINO", "1") == "1"
         # the data gradients of those convolutions on two fp16-piece products (dy in ONE piece; OCCF_DGRAD_F16=0: three)
         self.dgrad_f16 = os.environ.get("OCCF_DGRAD_F16", "1") == "1"
+        # ... and on ONE product: the transformed filters too as one fp16 piece (csrc/conv_wino.hip W1;
+        # scripts/precision_probe.py cd1: whole gradient 5.0e-5 -> 5.2e-5, worst parameter 5.9e-4 -> 6.9e-4)
+        self.dgrad_f16_single = os.environ.get("OCCF_DGRAD_F16_SINGLE", "1") == "1"
         # the decoder's per-query chain as two kernels per layer in inference (csrc/decoder_rows.hip); 0 = one launch per op
         self.use_decoder_rows = os.environ.get("OCCF_DECODER_ROWS", "1") == "1"
         # OCCF_DETERMINISTIC=1: every scatter sum of the backward in a fixed order or in integer fixed point (two runs of
@@ -584,7 +587,9 @@ class HipOps:
             f16 = bool(act_f16) and terms == 3 and x_cl.is_contiguous()
             wino = self._wino_fragments(weight_tap, w_split, Cin, Cout, f16) if terms == 3 else None
             if wino is not None:
-                wargs = (ctypes.c_void_p(x_cl.data_ptr()), self._ptr(wino[0]), self._ptr(wino[1]), self._ptr(bias),
+                # (one-product form: the lo fragments are not passed)
+                w_lo = ctypes.c_void_p(0) if (f16 and self.dgrad_f16_single) else self._ptr(wino[1])
+                wargs = (ctypes.c_void_p(x_cl.data_ptr()), self._ptr(wino[0]), w_lo, self._ptr(bias),
                          self._ptr(residual), self._ptr(out), B, Xi, Yi, Zi, Cin, Cout, x_cl.stride(0), x_cl.stride(1),
                          x_cl.stride(2), x_cl.stride(3), int(act))
                 # (slot_t stays referenced until the launches below are queued: a buffer allocated in between -- the

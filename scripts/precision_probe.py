@@ -118,6 +118,7 @@ def main():
                        ("3^3 halo convolutions FORWARD only: activation in ONE fp16 piece (2 products)", "cf11"),
                        ("3^3 halo convolutions DATA GRADIENT only: dy in ONE fp16 piece (2 products)", "cd11"),
                        ("3^3 halo convolutions forward + data gradient (2 products)", "cfd11"),
+                       ("3^3 halo convolutions DATA GRADIENT on ONE product: dy in one fp16 piece AND the weights rounded to 11 bits", "cd1"),
                        ("streaming linears (M >= 16384) forward + data gradient: activation in ONE fp16 piece", "lin11"),
                        ("2-term, fp16 piece (11 bits)", 11),
                        ("2-term fp16 piece in the WEIGHT GRADIENTS only (leaf quantities: nothing propagates)", "wg11"),
@@ -153,6 +154,14 @@ def main():
                 halo = tuple(ksize) == (3, 3, 3) and stride == 1 and dil == 1
                 hit = halo and (("d" in _m[1:-2]) if in_bwd["conv"] else ("f" in _m[1:-2]))
                 return _f(round_bits(x_cl, 11) if hit else x_cl, weight_tap, ksize, stride, dil, pad, *a, **k)
+            ops.conv3d = conv3d
+        elif bits == "cd1":
+            def conv3d(x_cl, weight_tap, ksize, stride=1, dil=1, pad=None, *a, _f=orig["conv3d"], **k):
+                hit = tuple(ksize) == (3, 3, 3) and stride == 1 and dil == 1 and in_bwd["conv"]
+                if hit:
+                    weight_tap = round_bits(weight_tap, 11)
+                    k["w_split"] = ops.split_bf16(weight_tap)
+                return _f(x_cl, weight_tap, ksize, stride, dil, pad, *a, **k)
             ops.conv3d = conv3d
         elif bits == "lin11":
             def linear(x, *a, _f=orig["linear"], **k):
