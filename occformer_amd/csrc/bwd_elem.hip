@@ -557,8 +557,20 @@ __global__ void __launch_bounds__(256) gn_bwd_apply_rows_kernel(const float* __r
 }
 
 #define GNB_ROWS 256
+// rows per workgroup of the partial-sum pass: 256 at the full-resolution volumes, fewer where 256-row blocks would
+// leave the chip empty -- a [1 250, 1 024] GroupNorm was 5 workgroups of 256 SERIAL row steps per thread (56 us), a
+// [10 000, 512] one 40 workgroups: the 80 calls of a training step averaged 47 us (r06v kernel statistics), most of it
+// latency.  Aim at ~1 000 workgroups, at least four row steps per thread.
+static int gnb_rows(int B, long V, int C) {
+  const int R = 256 / (C / 4) > 0 ? 256 / (C / 4) : 1;         // rows a workgroup covers per step
+  long rows = occf_cdiv(V * B, 1024L);
+  rows = occf_cdiv(rows, (long)R) * R;
+  if (rows < 4L * R) rows = 4L * R;
+  return (int)(rows > GNB_ROWS ? GNB_ROWS : rows);
+}
 extern "C" long occf_groupnorm_bwd_workspace(int B, long V, int C, int G) {
-  return (long)B * occf_cdiv(V, GNB_ROWS) * C * 2 + (long)B * C * 2 + (long)B * G * 2;
+  if (C <= 0 || C % 4) return 0;
+  return (long)B * occf_cdiv(V, (long)gnb_rows(B, V, C)) * C * 2 + (long)B * C * 2 + (long)B * G * 2;
 }
 
 extern "C" int occf_groupnorm_bwd(const float* x, const float* stats, const float* gamma, const float* beta,
@@ -568,8 +580,9 @@ extern "C" int occf_groupnorm_bwd(const float* x, const float* stats, const floa
   if (B <= 0 || P <= 0 || Z <= 0 || C % 4 != 0 || C > 1024 || G <= 0 || C % G != 0) return OCCF_ESHAPE;
   hipStream_t st = (hipStream_t)stream;
   const long V = P * Z;
-  const int rows = GNB_ROWS;
-  const int nblk = occf_cdiv(V, rows);
+  const int rows = gnb_rows(B, V, C);
+  const int nblk = (int)occf_cdiv(V, (long)rows);
+  const int nblk256 = (int)occf_cdiv(V, (long)GNB_ROWS);        // (the row-walking apply pass keeps 256-row blocks)
   float* partial = workspace;
   float* chan = partial + (long)B * nblk * C * 2;
   float* gs = chan + (long)B * C * 2;
@@ -588,9 +601,9 @@ extern "C" int occf_groupnorm_bwd(const float* x, const float* stats, const floa
   const int rows_form = e_rows ? atoi(e_rows) : 1;
   // (the row-walking form needs enough 256-row blocks to fill the chip -- r05o: taken for every shape it cost the
   // mid-size calls, [80 000, 256] and smaller, more than it gave the full-resolution ones)
-  if (idx32 && rows_form && C <= 1024 && 256 / (C / 4) >= 1 && (nblk >= 1024 || rows_form == 2))     // (2: forced, tests)
-    hipLaunchKernelGGL(gn_bwd_apply_rows_kernel, dim3(nblk, B), dim3(256), 0, st, x, stats, gamma, beta, dy, gs, dx,
-                       dresidual, V, Z, C, G, relu, tokens, rows);
+  if (idx32 && rows_form && C <= 1024 && 256 / (C / 4) >= 1 && (nblk256 >= 1024 || rows_form == 2))  // (2: forced, tests)
+    hipLaunchKernelGGL(gn_bwd_apply_rows_kernel, dim3(nblk256, B), dim3(256), 0, st, x, stats, gamma, beta, dy, gs, dx,
+                       dresidual, V, Z, C, G, relu, tokens, GNB_ROWS);
   else if (idx32)
     hipLaunchKernelGGL(gn_bwd_apply_kernel<uint32_t>, dim3(occf_cdiv((long)B * V * (C / 4), 256)), dim3(256), 0, st, x,
                        stats, gamma, beta, dy, gs, dx, dresidual, B, V, Z, C, G, relu, tokens);
