@@ -75,6 +75,11 @@ def build(name):
 def main():
     a = [v for v in sys.argv[1:] if not v.startswith("--")]
     n = int(a[0]) if a else 20
+    only = [v[7:].split(",") for v in sys.argv[1:] if v.startswith("--only=")]
+    if only:
+        for k in list(VARIANTS):
+            if k not in only[0]:
+                del VARIANTS[k]
     if "--build-only" in sys.argv:
         for v in VARIANTS:
             print(v, build(v))

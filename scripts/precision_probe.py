@@ -111,7 +111,7 @@ def main():
     A.Conv3d.backward = staticmethod(conv_bw_flagged)
     rows = []
     only = set(sys.argv[1:])                 # e.g. "wg11": run a subset (keys: None 11 wg11 8 mixed bf16)
-    for mode, bits in (("default: bf16x3, weight gradients on 2 fp16-piece products", None),
+    for mode, bits in (("default: bf16x3; the 3^3 convolutions' weight gradients (G8 shapes) and stride-1 data gradients on ONE fp16-piece product", None),
                        ("bf16x3 everywhere (weight gradients on 3 bf16 products: the round-5 arithmetic)", "wg3"),
                        ("default + the weight gradients of every convolution with <= 4096 output voxels EXACT (fp64)", "wgx"),
                        ("default + the CONVOLUTIONS' weight gradients on ONE product: dy and x each in one fp16 piece", "wg1c"),

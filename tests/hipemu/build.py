@@ -37,6 +37,17 @@ def build(force=False):
     stamp = os.path.join(OUT, "digest.txt")
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == h.hexdigest():
         return LIB
+    # one builder at a time: the pytest-xdist workers of a CPU run all arrive here with a stale library (they used to
+    # compile into the same object files at once, and one of them linked a half-written one)
+    import fcntl
+    with open(os.path.join(OUT, "build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == h.hexdigest():
+            return LIB
+        return _build_locked(srcs, h.hexdigest(), stamp)
+
+
+def _build_locked(srcs, digest, stamp):
     objs = []
     procs = []
     for s in srcs:
@@ -53,7 +64,7 @@ def build(force=False):
     o = os.path.join(OUT, "hipemu.o")
     subprocess.check_call([CXX, "-O2", "-std=c++17", "-fPIC", "-c", os.path.join(HERE, "hipemu.cpp"), "-o", o])
     subprocess.check_call([CXX, "-shared", "-o", LIB, *objs, o])
-    open(stamp, "w").write(h.hexdigest())
+    open(stamp, "w").write(digest)
     return LIB
 
 
