@@ -56,7 +56,11 @@ struct gs_int {
   static constexpr int value = V;
 };
 
-template <int KS, int TERMS>     // K = 16 * KS
+// PLAIN: bias only (act 0, no residual / aux, no second output, no row scale) -- the epilogue of most launches of a
+// training step, without the general form's ~10 wave-uniform branches per 4-channel group (40 per 32-channel tile of
+// 36 MFMAs; scripts/gemm_stream_ablation_probe.py: the kernel with every load and store removed ran 2.5x over its
+// MFMA time)
+template <int KS, int TERMS, bool PLAIN = false>     // K = 16 * KS
 __global__ void __launch_bounds__(GS_NW * 64) gemm_stream_kernel(GemmStreamArgs p) {
   constexpr int K = 16 * KS;
   constexpr int IMG = KS * 1024;                   // bytes of one image (hi or lo) of a 32-channel tile
@@ -164,6 +168,15 @@ __global__ void __launch_bounds__(GS_NW * 64) gemm_stream_kernel(GemmStreamArgs 
       // ---- epilogue of this 32-channel tile: registers r = 4 g + e <-> channel 8 g + 4 lk + e of token li
       // (the residual rows are fetched HERE, not ahead of the MFMAs: 16 registers the prefetched rows need at K = 192;
       // the SIMD partner covers the latency)
+      if (PLAIN) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = *(const float4*)(bias_s + j * 32 + g * 8 + lk * 4);
+          const float4 v = make_float4(acc[4 * g] + b4.x, acc[4 * g + 1] + b4.y, acc[4 * g + 2] + b4.z, acc[4 * g + 3] + b4.w);
+          if (tok_ok) *(float4*)(crow + j * 32 + g * 8) = v;
+        }
+        continue;
+      }
       float4 res[4];
       OCCF_SCHED_FENCE();
       if (rrow) {
@@ -242,19 +255,21 @@ static int occf_gemm_stream_launch(const float* A, const uint16_t* Wh, const uin
   const size_t lds = (size_t)ntb * (terms == 3 ? 2 : 1) * (K / 16) * 1024 + (size_t)ntb * 128;
   typedef void (*fn_t)(GemmStreamArgs);
   fn_t fn = nullptr;
+  const bool plain = act == 0 && !residual && !pre_out && !row_scale;
 #define GS_PICK(KS_)                                                                                     \
-  case KS_: fn = terms == 3 ? (fn_t)gemm_stream_kernel<KS_, 3> : (fn_t)gemm_stream_kernel<KS_, 1>; break
+  case KS_: fn = terms == 3 ? (plain ? (fn_t)gemm_stream_kernel<KS_, 3, true> : (fn_t)gemm_stream_kernel<KS_, 3>) \
+                            : (fn_t)gemm_stream_kernel<KS_, 1>; break
   switch (K / 16) {
     GS_PICK(4); GS_PICK(6); GS_PICK(8); GS_PICK(10); GS_PICK(12); GS_PICK(14); GS_PICK(16);
     default: return OCCF_ESHAPE;
   }
 #undef GS_PICK
 #ifndef OCCF_EMU
-  static bool done[17][2] = {};
-  if (!done[K / 16][terms == 3]) {
+  static bool done[17][3] = {};
+  if (!done[K / 16][terms == 3 ? (plain ? 2 : 1) : 0]) {
     hipError_t err = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err != hipSuccess) return (int)err;
-    done[K / 16][terms == 3] = true;
+    done[K / 16][terms == 3 ? (plain ? 2 : 1) : 0] = true;
   }
 #endif
   hipLaunchKernelGGL(fn, dim3(grid), dim3(GS_NW * 64), lds, st, a);

@@ -35,7 +35,7 @@ def edit(src, what):
         rep("    if (PFK < KS) load_rows(wt, k_pf(), k_end());", "    if (PFK < KS && wt < GS_NW * 100000L) { if (wt == (long)q * GS_NW + wave) load_rows(wt, k_pf(), k_end()); }")
         rep("      load_rows(wt + wt_step < n_wtiles ? wt + wt_step : wt, k_begin(), k_pf());", "      if (p.act == 77) load_rows(wt, k_begin(), k_pf());")
     if "no_store" in what:
-        rep("        if (tok_ok) *(float4*)(crow + j * 32 + g * 8) = v;", "        if (tok_ok && (p.act == 77 || v.x == 12345.678f)) *(float4*)(crow + j * 32 + g * 8) = v;")
+        src = src.replace("if (tok_ok) *(float4*)(crow + j * 32 + g * 8) = v;", "if (tok_ok && (p.act == 77 || v.x == 12345.678f)) *(float4*)(crow + j * 32 + g * 8) = v;")
     if "lds_const" in what:
         rep("        const bf16x8 wh = *(const bf16x8*)(Wt + ks * 1024);", "        const bf16x8 wh = *(const bf16x8*)(Wt + (ks & 1) * 1024);")
         rep("          const bf16x8 wl = *(const bf16x8*)(Wt + IMG + ks * 1024);", "          const bf16x8 wl = *(const bf16x8*)(Wt + IMG + (ks & 1) * 1024);")

@@ -85,6 +85,24 @@ def test_conv3d_strided_input_view(be):
     assert torch.allclose(out.permute(0, 4, 1, 2, 3), ref, **TOL)
 
 
+@pytest.mark.parametrize("stride,dil,B", [(2, 1, 1), (1, 2, 2), (2, 1, 2)])
+def test_conv3d_generic_loader_on_a_view(be, monkeypatch, stride, dil, B):
+    """the implicit-GEMM kernel's bounded-buffer loader (csrc/gemm_bf16.hip CONV = 1: byte offset = row offset + tap offset,
+    padding taps = an out-of-range offset) on an input that is a strided view -- the Z height slices AND a channel block of
+    a wider token buffer, two batches: the buffer's extent comes from the strides, border rows start at negative offsets"""
+    monkeypatch.setattr(be.ops, "precision", "bf16x3")
+    X, Y, Z, C = 14, 10, 4, 32                       # (>= 64 output rows at stride 2: the matrix-core path)
+    tok = paramgen.tensor("tokg", (B, X, Y, Z + 1, C + 32), 9)
+    w = paramgen.tensor("cwg", (64, C, 3, 3, 3), 9, (27 * C) ** -0.5)
+    view = tok[:, :, :, :Z, 32:]
+    ref = F.conv3d(view.permute(0, 4, 1, 2, 3).double(), w.double(), stride=stride, padding=dil, dilation=dil).float()
+    wt = conv_weight_tapmajor(w)
+    out = be.ops.conv3d(be.to(tok)[:, :, :, :Z, 32:], be.to(wt), (3, 3, 3), stride, dil,
+                        w_split=be.ops.split_bf16(be.to(wt))).cpu()
+    err = float((out.permute(0, 4, 1, 2, 3) - ref).abs().max() / ref.abs().max())
+    assert err < 3e-5, err
+
+
 @pytest.mark.parametrize("C,G,shape", [(32, 8, (2, 5, 4, 3)), (192, 32, (1, 6, 6, 2)), (48, 8, (1, 40, 30, 2))])
 def test_groupnorm(be, C, G, shape):
     B, X, Y, Z = shape
