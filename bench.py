@@ -168,8 +168,9 @@ def _conv_entry(name, shp, ms, flops, prec):
         if wino:
             # csrc/conv_wino.hip: Winograd F(2, 3) along x -- 18 instead of 27 multiply-adds per output voxel
             f16 = name != base
-            kname = f"conv3x3x3_wino_kernel<{tn}, {'true' if f16 else 'false'}>"
-            products = (2 if f16 else 3) * 2.0 / 3.0
+            w1 = f16 and getattr(ops, "dgrad_f16_single", False)       # the filters too as one fp16 piece: ONE product
+            kname = f"conv3x3x3_wino_kernel<{tn}, {'true' if f16 else 'false'}, {'true' if w1 else 'false'}>"
+            products = (1 if w1 else 2 if f16 else 3) * 2.0 / 3.0
             grid = B * ((X + 1) // 2) * ((Y + 64 // tz - 1) // (64 // tz)) * (Z // tz) * (Cout // (64 * tn)) * 512
             traffic, src = pmc_traffic(kname, grid)
             extra = dict(_PMC_EXTRA) if traffic is not None else {}

@@ -473,8 +473,14 @@ __device__ __forceinline__ unsigned long long msda_fx(float x) {
 // CPL = channels per lane.  Every lane of a query repeats the query's softmax, the four sample positions and the 32
 // corner weights (~1 000 VALU instructions against 32 CPL LDS atomics): 6 channels per lane instead of 3 halve the
 // lanes that repeat them.
+// PL ("pass loop"): the channel passes of a head run INSIDE the workgroup (zero -> scatter -> flush per pass) instead of
+// as separate workgroups, and the sample records of a thread's FIRST query -- softmax weight, fractions and corner of its
+// P <= 4 points: everything that does not depend on the channel -- are kept in registers across the passes.  The
+// ablation (scripts/msda_bwd_ablation_probe.py, r06af) put the per-query loop at 42 % of the backward and its LDS
+// atomics at 2 %: ~1 700 VALU instructions per lane and pass for 192 atomics, repeated in each of the 4 passes of a
+// level-0 head.  A thread's later queries (workgroups with more queries than slots) are recomputed per pass as before.
 #define MSDA_TILE_THREADS 1024
-template <int CPL>
+template <int CPL, bool PL = false>
 __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kernel(
     const float* __restrict__ offs, const float* __restrict__ logits, const float* __restrict__ dout,
     float* __restrict__ dvalue, float* __restrict__ scratch, const unsigned* __restrict__ absmax_bits, MsdaLevels lv,
@@ -490,8 +496,9 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
   const int ls = tc.ls;
   const int Xs = lv.X[ls], Ys = lv.Y[ls], Zs = lv.Z[ls];
   int bx = blockIdx.x;
-  const int pass = bx % tc.passes;
-  bx /= tc.passes;
+  const int pass0 = PL ? 0 : bx % tc.passes;
+  if (!PL) bx /= tc.passes;
+  const int npass = PL ? tc.passes : 1;
   const int grp = bx % tc.groups;
   bx /= tc.groups;
   const int ty_ = bx % tc.tiles_y, tx_ = bx / tc.tiles_y;
@@ -499,10 +506,8 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
   const int tx0 = tx_ * tc.T, ty0 = ty_ * tc.T;
   const int rx0 = tx0 - tc.M, ry0 = ty0 - tc.M;
   const int RX = tc.T + 2 * tc.M, RY = RX;
-  const int CH = tc.CH, ch0 = pass * CH, CHP = tc.CH + tc.pad;
+  const int CH = tc.CH, CHP = tc.CH + tc.pad;
   const long ncell = (long)RX * RY * Zs;
-  for (long i = threadIdx.x; i < ncell * CHP; i += NT) tile[i] = 0ull;
-  __syncthreads();
 
   // query boxes per query level: cell(q) = floor((2q + 1) * Xs / (2 * Xq)) in [tx0, tx0 + T)
   int qx_lo[MSDA_MAX_LEVELS], qy_lo[MSDA_MAX_LEVELS], nqx[MSDA_MAX_LEVELS], nqy[MSDA_MAX_LEVELS], cum[MSDA_MAX_LEVELS + 1];
@@ -536,8 +541,24 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
   const int n_q = it_end > it_begin ? it_end - it_begin : 0;
   unsigned stride = 1u;                                     // coprime with n_q; j * stride stays below 2^32
   if (tc.stride > 0 && n_q > 1 && n_q < 1000000) stride = (unsigned)(((n_q % 4099) ? 4099 : 4111) % n_q);
+  // (PL) records of this thread's first query
+  int r_q = 0, r_c0[4] = {0, 0, 0, 0}, r_c1[4] = {0, 0, 0, 0};
+  float r_a[4] = {0.f, 0.f, 0.f, 0.f}, r_tz[4] = {0.f, 0.f, 0.f, 0.f}, r_ty[4] = {0.f, 0.f, 0.f, 0.f},
+        r_tx[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int ps = 0; ps < npass; ++ps) {
+  const int pass = pass0 + ps;
+  const int ch0 = pass * CH;
+  if (ps > 0) __syncthreads();                              // the previous pass's flush has read the tile
+  for (long i = threadIdx.x; i < ncell * CHP; i += NT) tile[i] = 0ull;
+  __syncthreads();
   float* dvb = dvalue + ((long)b * Nv + lv.start[ls]) * E + h * Dh + ch0 + sub * CPL;
   for (int u = slot; u < n_q; u += slots) {
+    const bool cached = PL && ps > 0 && u == slot;
+    const bool keep = PL && ps == 0 && u == slot;
+    int q = r_q;
+    float rz = 0.f, ry = 0.f, rx = 0.f, mx = -3.0e38f, inv = 0.f;
+    const float* lg = logits;
+    if (!cached) {
     const int it = it_begin + (int)(((unsigned)u * stride) % (unsigned)n_q);
     int lq = 0;
     while (lq + 1 < L && it >= cum[lq + 1]) ++lq;
@@ -546,28 +567,32 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
     const int qz = r % Zq;
     r /= Zq;
     const int qy = qy_lo[lq] + r % nqy[lq], qx = qx_lo[lq] + r / nqy[lq];
-    const int q = lv.start[lq] + (qx * lv.Y[lq] + qy) * Zq + qz;
-    const float rz = ((float)qz + 0.5f) / (float)Zq;
-    const float ry = ((float)qy + 0.5f) / (float)lv.Y[lq];
-    const float rx = ((float)qx + 0.5f) / (float)lv.X[lq];
-    const float* lg = logits + (long)(b * Nq + q) * lg_ld + h * LP;
-    float mx = -3.0e38f, inv = 0.f;
+    q = lv.start[lq] + (qx * lv.Y[lq] + qy) * Zq + qz;
+    rz = ((float)qz + 0.5f) / (float)Zq;
+    ry = ((float)qy + 0.5f) / (float)lv.Y[lq];
+    rx = ((float)qx + 0.5f) / (float)lv.X[lq];
+    lg = logits + (long)(b * Nq + q) * lg_ld + h * LP;
+    if (keep) r_q = q;
     if (!rec_w) {
       for (int i = 0; i < LP; ++i) mx = fmaxf(mx, lg[i]);
       float sum = 0.f;
       for (int i = 0; i < LP; ++i) sum += expf(lg[i] - mx);
       inv = 1.0f / sum;
     }
+    }
     const float* of = offs + (long)(b * Nq + q) * off_ld + h * LP * 3;
     const float* gp = dout + (long)(b * Nq + q) * E + h * Dh + ch0 + sub * CPL;
     float gch[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) gch[c] = gp[c];
-    for (int k = 0; k < P; ++k) {
+    auto point = [&](const int k) __attribute__((always_inline)) {
       const int i = ls * P + k;
       float tz, ty, tx, a;
       int iz, iy, ix;
-      if (rec_w) {                                      // the gather pass's record of this sample (see msda3d_bwd_kernel)
+      if (cached) {
+        a = r_a[k & 3]; tz = r_tz[k & 3]; ty = r_ty[k & 3]; tx = r_tx[k & 3];
+        iz = (int)(short)(r_c0[k & 3] & 0xFFFF); iy = (int)(short)((unsigned)r_c0[k & 3] >> 16); ix = r_c1[k & 3];
+      } else if (rec_w) {                                      // the gather pass's record of this sample (see msda3d_bwd_kernel)
         const long si = ((long)(b * Nq + q) * H + h) * LP + i;
         const float4 rw = rec_w[si];
         const uint32_t c0 = rec_c[2 * si], c1 = rec_c[2 * si + 1];
@@ -584,6 +609,13 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
         tz = pz - fz; ty = py - fy; tx = px - fx;
         iz = (int)fz; iy = (int)fy; ix = (int)fx;
         a = expf(lg[i] - mx) * inv;
+      }
+      if (keep) {
+        // (corner indices beyond +-32 767 cells cannot reach the grid: saturate them out of range)
+        const int sz = iz < -32768 ? -32768 : iz > 32767 ? 32767 : iz, sy = iy < -32768 ? -32768 : iy > 32767 ? 32767 : iy;
+        r_a[k & 3] = a; r_tz[k & 3] = tz; r_ty[k & 3] = ty; r_tx[k & 3] = tx;
+        r_c0[k & 3] = (int)(((unsigned)sz & 0xFFFFu) | ((unsigned)sy << 16));
+        r_c1[k & 3] = ix;
       }
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
@@ -603,15 +635,23 @@ __global__ void __launch_bounds__(MSDA_TILE_THREADS) msda3d_bwd_value_tile_kerne
           for (int c = 0; c < CPL; ++c) atomicAdd(d + c, cw * gch[c]);
         }
       }
+    };
+    if constexpr (PL) {                                  // (k is a constant in every copy: the records stay in registers)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (k < P) point(k);
+    } else {
+      for (int k = 0; k < P; ++k) point(k);
     }
   }
   __syncthreads();
   // hand the region over: plain coalesced stores into this workgroup's slab of the scratch buffer; the gather
   // kernel below sums, for every cell, the (at most 9) regions that cover it -- no atomics, fixed order
-  float* slab = scratch + (((long)b * H + h) * gridDim.x + blockIdx.x) * (ncell * CH);
+  float* slab = scratch + (((long)b * H + h) * ((long)gridDim.x * npass) + (long)blockIdx.x * npass + ps) * (ncell * CH);
   for (long i = threadIdx.x; i < ncell * CH; i += NT) {
     const long cell = i / CH;
     slab[i] = (float)((double)(long long)tile[cell * CHP + (i - cell * CH)] * (double)fx_inv);
+  }
   }
 }
 
@@ -894,16 +934,26 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
         MsdaTileCfg tc = cfgs[l];
         tc.stride = strided;
         const size_t lds = (size_t)(tc.T + 2 * tc.M) * (tc.T + 2 * tc.M) * lv.Z[l] * (tc.CH + tc.pad) * 8;
+        // the channel passes inside the workgroup (kernel template PL) where a head takes several and the points' records
+        // fit the four register slots; OCCF_MSDA_PASSLOOP=0: one workgroup per pass
+        static const int pl_env = [] {
+          const char* e = getenv("OCCF_MSDA_PASSLOOP");
+          return e ? atoi(e) : 1;
+        }();
+        const bool pl = pl_env && tc.passes > 1 && num_points <= 4;
 #ifndef OCCF_EMU
-        static size_t lds_max[2] = {0, 0};
-        const int ci = tc.cpl == 6 ? 1 : 0;
+        static size_t lds_max[4] = {0, 0, 0, 0};
+        const int ci = (tc.cpl == 6 ? 1 : 0) + (pl ? 2 : 0);
         if (lds > lds_max[ci]) {
-          const void* fn = ci == 1 ? (const void*)msda3d_bwd_value_tile_kernel<6> : (const void*)msda3d_bwd_value_tile_kernel<3>;
+          const void* fn = ci == 3   ? (const void*)msda3d_bwd_value_tile_kernel<6, true>
+                           : ci == 2 ? (const void*)msda3d_bwd_value_tile_kernel<3, true>
+                           : ci == 1 ? (const void*)msda3d_bwd_value_tile_kernel<6>
+                                     : (const void*)msda3d_bwd_value_tile_kernel<3>;
           hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
           lds_max[ci] = lds;
         }
 #endif
-        const dim3 grid((unsigned)(tc.tiles_x * tc.tiles_y * tc.groups * tc.passes), heads, B);
+        const dim3 grid((unsigned)(tc.tiles_x * tc.tiles_y * tc.groups * (pl ? 1 : tc.passes)), heads, B);
         // threads: as many as the tile's queries fill evenly (level-0 tiles hold ~600 queries x lpg lanes)
         int threads = tile_threads;
         if (tc.groups == 1) {
@@ -917,7 +967,15 @@ extern "C" int occf_msda3d_bwd(const float* value, const float* sampling_offsets
           const long t = occf_cdiv(occf_cdiv(lanes, rounds), 64) * 64;
           threads = (int)(t < 64 ? 64 : (t > tile_threads ? tile_threads : t));
         }
-        if (tc.cpl == 6)
+        if (pl && tc.cpl == 6)
+          hipLaunchKernelGGL((msda3d_bwd_value_tile_kernel<6, true>), grid, dim3(threads), lds, st, sampling_offsets,
+                             attn_logits, dout, dvalue, workspace, absmax, lv, tc, B, Nq, heads, head_dim, num_points, off_ld,
+                             lg_ld, (const float4*)rec_w, (const uint32_t*)rec_c);
+        else if (pl)
+          hipLaunchKernelGGL((msda3d_bwd_value_tile_kernel<3, true>), grid, dim3(threads), lds, st, sampling_offsets,
+                             attn_logits, dout, dvalue, workspace, absmax, lv, tc, B, Nq, heads, head_dim, num_points, off_ld,
+                             lg_ld, (const float4*)rec_w, (const uint32_t*)rec_c);
+        else if (tc.cpl == 6)
           hipLaunchKernelGGL(msda3d_bwd_value_tile_kernel<6>, grid, dim3(threads), lds, st, sampling_offsets, attn_logits,
                              dout, dvalue, workspace, absmax, lv, tc, B, Nq, heads, head_dim, num_points, off_ld, lg_ld,
                              (const float4*)rec_w, (const uint32_t*)rec_c);

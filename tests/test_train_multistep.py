@@ -116,8 +116,36 @@ def oracle_step(cfg, meta, tc, sd, cams, x, gt_occ, pts, gd, rng, **kw):
 
 
 def test_three_fused_adamw_steps_then_oracle(bound):
+    """On the GPU the three optimizer steps run REPRODUCIBLY (``ops.deterministic`` + the switches of
+    test_training_step_is_reproducible): with float-atomic scatter sums in their backward the weights the 4th step
+    starts from differed in their low bits from run to run, and one such problem instance in ~20 sits next to a discrete
+    decision of the matcher / samplers the tape does not cover -- whole gradient 4.8e-3 instead of the usual 4e-5 ... 4e-4
+    (profiles/r06/r06ag_multistep_*.txt: the same rate with the round's arithmetic cuts switched off).  A fixed instance
+    gives a fixed verdict."""
     be = bound
     d = be.device
+    det = _Deterministic(be) if torch.device(d).type == "cuda" else None
+    try:
+        _three_steps_then_oracle(be, d)
+    finally:
+        if det is not None:
+            det.restore()
+
+
+class _Deterministic:
+    def __init__(self, be):
+        from occformer_amd import view_transformer
+        self.vt, self.ops = view_transformer, be.ops
+        self.saved = (view_transformer._DEPTHNET_LIB, torch.backends.cudnn.deterministic, be.ops.deterministic)
+        view_transformer._DEPTHNET_LIB = "1"
+        torch.backends.cudnn.deterministic = True
+        be.ops.deterministic = True
+
+    def restore(self):
+        self.vt._DEPTHNET_LIB, torch.backends.cudnn.deterministic, self.ops.deterministic = self.saved
+
+
+def _three_steps_then_oracle(be, d):
     cfg, meta, tc = _small()
     model = build_model(cfg)
     model.load_state_dict(paramgen.fill_state_dict(model.state_dict(), 77))
