@@ -177,7 +177,9 @@ __global__ void __launch_bounds__(GS_NW * 64) gemm_stream_kernel(GemmStreamArgs 
         }
         continue;
       }
-      float4 res[4];
+      // the general epilogue, one wave-uniform branch per STAGE of a 32-channel tile (not per 4-channel group: the
+      // branches, not the arithmetic, were what the bias-only variant above saved)
+      float4 res[4], v[4];
       OCCF_SCHED_FENCE();
       if (rrow) {
 #pragma unroll
@@ -186,19 +188,38 @@ __global__ void __launch_bounds__(GS_NW * 64) gemm_stream_kernel(GemmStreamArgs 
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 b4 = *(const float4*)(bias_s + j * 32 + g * 8 + lk * 4);
-        float4 v = make_float4(acc[4 * g] + b4.x, acc[4 * g + 1] + b4.y, acc[4 * g + 2] + b4.z, acc[4 * g + 3] + b4.w);
-        if (prow && tok_ok) *(float4*)(prow + j * 32 + g * 8) = v;
-        if (p.act == 1) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        } else if (p.act == 2) {
-          v.x = occf_gelu_b(v.x); v.y = occf_gelu_b(v.y); v.z = occf_gelu_b(v.z); v.w = occf_gelu_b(v.w);
-        } else if (p.act == 3) {
-          v.x *= gs_gelu_grad(res[g].x); v.y *= gs_gelu_grad(res[g].y);
-          v.z *= gs_gelu_grad(res[g].z); v.w *= gs_gelu_grad(res[g].w);
+        v[g] = make_float4(acc[4 * g] + b4.x, acc[4 * g + 1] + b4.y, acc[4 * g + 2] + b4.z, acc[4 * g + 3] + b4.w);
+      }
+      if (prow && tok_ok) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *(float4*)(prow + j * 32 + g * 8) = v[g];
+      }
+      if (p.act == 1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          v[g] = make_float4(fmaxf(v[g].x, 0.f), fmaxf(v[g].y, 0.f), fmaxf(v[g].z, 0.f), fmaxf(v[g].w, 0.f));
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          v[g] = make_float4(occf_gelu_b(v[g].x), occf_gelu_b(v[g].y), occf_gelu_b(v[g].z), occf_gelu_b(v[g].w));
+      } else if (p.act == 3) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          v[g].x *= gs_gelu_grad(res[g].x); v[g].y *= gs_gelu_grad(res[g].y);
+          v[g].z *= gs_gelu_grad(res[g].z); v[g].w *= gs_gelu_grad(res[g].w);
         }
-        if (p.row_scale) { v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
-        if (rrow && p.act != 3) { v.x += res[g].x; v.y += res[g].y; v.z += res[g].z; v.w += res[g].w; }
-        if (tok_ok) *(float4*)(crow + j * 32 + g * 8) = v;
+      }
+      if (p.row_scale) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { v[g].x *= rs; v[g].y *= rs; v[g].z *= rs; v[g].w *= rs; }
+      }
+      if (rrow && p.act != 3) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { v[g].x += res[g].x; v[g].y += res[g].y; v[g].z += res[g].z; v[g].w += res[g].w; }
+      }
+      if (tok_ok) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *(float4*)(crow + j * 32 + g * 8) = v[g];
       }
     }
   }
