@@ -89,6 +89,12 @@ def test_training_switches_give_the_same_step(be, monkeypatch, switch):
     kw = dict(img_metas=[dict(occ_size=meta["occ_size"], pc_range=meta["pc_range"])],
               img_inputs=[t[:1].to(d) for t in (x, *cams)] + [gd[:1].to(d)], gt_occ=gt_occ[:1].to(d),
               points_occ=[pts[0].to(d)])
+    if torch.device(d).type == "cuda":
+        # both steps REPRODUCIBLE (fixed-point scatter sums, deterministic library algorithms): with float atomics in the
+        # backward the pair's difference moved from run to run -- 1e-3 ... 4e-3 against the 3e-3 below, one failure in four
+        # visits of round 6 (r06fin2) -- so the verdict was a coin with a small head.  Now it is one fixed number.
+        monkeypatch.setattr(be.ops, "deterministic", True)
+        monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)
 
     def step():
         for p in model.parameters():
@@ -115,4 +121,5 @@ def test_training_switches_give_the_same_step(be, monkeypatch, switch):
     num = sum(float((g[k] - v).norm() ** 2) for k, v in ref_g.items())
     den = sum(float(v.norm() ** 2) for v in ref_g.values())
     # (the library's kernels and ATen sum in different orders; a flipped ReLU gate of this tiny model weighs ~1e-3)
+    print(f"{switch}: whole gradient of the pair, relative L2 {(num / den) ** 0.5:.3e}")
     assert (num / den) ** 0.5 < 3e-3, (switch, (num / den) ** 0.5)
