@@ -157,6 +157,23 @@ def test_upsample_add(be, lo, hi):
     assert torch.allclose(out.permute(0, 4, 1, 2, 3), ref, **TOL)
 
 
+def test_linear_few_tiles_long_k(be, monkeypatch):
+    """two output tiles, 256 k-tiles (the matching costs' [200, 50 176] x [17, 50 176] in small): the split-K cost model may
+    take up to 128 slices when a handful of tiles would otherwise leave the chip empty (csrc/gemm_bf16.hip
+    occf_pick_ksplit); the slab workspace the host sizes must match what the launch picks, and the fixed-order slab
+    reduction must still give the fp32-class result"""
+    monkeypatch.setattr(be.ops, "precision", "bf16x3")
+    M, N, K = 200, 17, 8192
+    assert be.ops.lib.occf_gemm_bf16_workspace(M, N, K) > 16 * M * N, "more than 16 slices expected for this shape"
+    x = paramgen.tensor("fx", (M, K), 1)
+    w = paramgen.tensor("fw", (N, K), 2, K ** -0.5)
+    b = paramgen.tensor("fb", (N,), 3)
+    ref = F.linear(x.double(), w.double(), b.double()).float()
+    wd = be.to(w)
+    out = be.ops.linear(be.to(x), wd, be.to(b), w_split=be.ops.split_bf16(wd)).cpu()
+    assert float((out - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
 # ---------------------------------------------------------------- split-bf16 matrix-core path
 @pytest.mark.parametrize("M,N,K,act", [(300, 96, 64, 0), (130, 256, 96, 2), (100, 1000, 192, 0), (257, 192, 32, 1)])
 @pytest.mark.parametrize("prec,tol", [("bf16x3", 2e-5), ("bf16", 2e-2)])
