@@ -204,6 +204,12 @@ def _conv_entry(name, shp, ms, flops, prec):
                      f"wgrad_g8_kernel<{ti}, {tc}, {1 if ti + tc >= 5 else 2}, 2, {'true' if f16 else 'false'}, false>")
             if x1:
                 products = 1.0           # dy and x each ONE fp16 piece (csrc/wgrad_g8.h X1; precision_probe.py wg1c)
+        if (taps == 9 and same_grid and Z == 1 and X in (8, 16, 32, 64) and Cin % 64 == 0 and Cout % 64 == 0 and f16
+                and getattr(ops, "wgrad_2d_as_g8", False) and getattr(ops, "wgrad_f16_single", False)):
+            # ops.conv3d_wgrad: a 2-D 3x3 weight gradient with a power-of-two first extent runs as a [1, Y, X] volume on G8
+            tile = lambda c: 3 if c % 192 == 0 or (c % 128 == 64 and c >= 192) else 2 if c % 128 == 0 else 1
+            kname = f"wgrad_g8_kernel<{tile(Cout)}, {tile(Cin)}, 2, 2, true, true> (+ two transposes)"
+            products = 1.0
         if f16 and products != 1.0:
             products = 2.0
         nbytes = 4 * (B * X * Y * Z * Cout) + 4 * int(torch.tensor(shp[1]).prod()) + 4 * Cout * taps * Cin

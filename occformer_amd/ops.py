@@ -50,6 +50,8 @@ class HipOps:
         # ... and on ONE product: the transformed filters too as one fp16 piece (csrc/conv_wino.hip W1;
         # scripts/precision_probe.py cd1: whole gradient 5.0e-5 -> 5.2e-5, worst parameter 5.9e-4 -> 6.9e-4)
         self.dgrad_f16_single = os.environ.get("OCCF_DGRAD_F16_SINGLE", "1") == "1"
+        # 2-D 3x3 weight gradients with a first extent of 8 / 16 / 32 / 64 as [1, Y, X] volumes on the G8 kernel
+        self.wgrad_2d_as_g8 = os.environ.get("OCCF_WGRAD_2D_G8", "1") != "0"
         # the decoder's per-query chain as two kernels per layer in inference (csrc/decoder_rows.hip); 0 = one launch per op
         self.use_decoder_rows = os.environ.get("OCCF_DECODER_ROWS", "1") == "1"
         # OCCF_DETERMINISTIC=1: every scatter sum of the backward in a fixed order or in integer fixed point (two runs of
@@ -1056,6 +1058,27 @@ class HipOps:
         kX, kY, kZ = ksize
         if pad is None:
             pad = tuple(dil * (k - 1) // 2 for k in ksize)
+        if (self.wgrad_2d_as_g8 and Zi == 1 and (kX, kY, kZ) == (3, 3, 1) and stride == 1 and dil == 1
+                and tuple(pad) == (1, 1, 0) and Xi in (8, 16, 32, 64) and Cin % 64 == 0 and Cout % 64 == 0
+                and B * Xi * Yi >= 1024 and self._wgrad_terms() == 2 and dy.shape[1:4] == x_cl.shape[1:4]):
+            # a 2-D 3x3 convolution whose FIRST spatial extent is 8 / 16 / 32 / 64 (DepthNet's 16 x 44 feature maps): with
+            # that axis moved innermost it is a [1, Y, X] volume with a (1, 3, 3) window -- the G8 kernel's shape (groups
+            # of 8 consecutive rows along the innermost axis; csrc/wgrad_g8.h) instead of the register-transposing kernel
+            # (VALU-bound: 0.18 ms per call against ~0.05 for two 8 MB transposes + the G8 launch).  Taps come back as
+            # (dy, dx) and are swapped to (dx, dy).
+            xp = x_cl.permute(0, 3, 2, 1, 4).contiguous()
+            dp = dy.permute(0, 3, 2, 1, 4).contiguous()
+            flops = 2 * dy.numel() * 9 * Cin
+            dwp, _ = self._conv3d_wgrad(dp, xp, (1, 3, 3), 1, 1, (0, 1, 1), False)
+            self.last_flops = flops
+            db = dy.reshape(-1, Cout).sum(0) if want_bias else None
+            return dwp.view(Cout, 3, 3, Cin).transpose(1, 2).reshape(Cout, 9 * Cin), db
+        return self._conv3d_wgrad(dy, x_cl, ksize, stride, dil, pad, want_bias)
+
+    def _conv3d_wgrad(self, dy, x_cl, ksize, stride, dil, pad, want_bias):
+        B, Xi, Yi, Zi, Cin = x_cl.shape
+        Cout = dy.shape[-1]
+        kX, kY, kZ = ksize
         dw = torch.empty((Cout, kX * kY * kZ * Cin), dtype=self.f32, device=dy.device)
         db = torch.empty((Cout,), dtype=self.f32, device=dy.device) if want_bias else None
         geom = (B, Xi, Yi, Zi, Cin, Cout, kX, kY, kZ, int(stride), int(dil), pad[0], pad[1], pad[2])

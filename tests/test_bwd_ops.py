@@ -338,6 +338,41 @@ def test_conv3d_wgrad_dgrad(be, case, f16, wgrad_mode):
     assert _rel(dx.cpu(), x.grad.permute(0, 2, 3, 4, 1)) < 1e-4
 
 
+@pytest.mark.parametrize("on", [True, False])
+def test_conv2d_wgrad_on_the_g8_kernel(be, on, wgrad_mode):
+    """DepthNet's shape in small: a 3x3 convolution over [B, 16, 44] maps (Z = 1) -- with the 16-extent moved innermost
+    the G8 weight-gradient kernel takes it as a [1, 44, 16] volume with a (1, 3, 3) window (ops.wgrad_2d_as_g8); the taps
+    must come back in (dx, dy) order.  Off: the register-transposing kernel on the same inputs."""
+    wgrad_mode(be, True)
+    saved = be.ops.wgrad_2d_as_g8
+    be.ops.wgrad_2d_as_g8 = on
+    try:
+        B, H, W, Cin, Cout = 2, 16, 44, 64, 128
+        x = _t("c2_x", (B, Cin, H, W, 1), 3).requires_grad_()
+        w = (_t("c2_w", (Cout, Cin, 3, 3, 1), 4) * (9 * Cin) ** -0.5).requires_grad_()
+        y = F.conv3d(x, w, padding=(1, 1, 0))
+        dy = _t("c2_dy", tuple(y.shape), 5) * 3e-6
+        y.backward(dy)
+        calls = []
+        orig = be.ops._conv3d_wgrad
+
+        def spy(dy_, x_, k, *a, **kw):
+            calls.append(tuple(k))
+            return orig(dy_, x_, k, *a, **kw)
+        be.ops._conv3d_wgrad = spy
+        try:
+            dw, db = be.ops.conv3d_wgrad(be.to(dy.permute(0, 2, 3, 4, 1).contiguous()), be.to(x.detach().permute(0, 2, 3, 4, 1).contiguous()),
+                                         (3, 3, 1), 1, 1, want_bias=True)
+        finally:
+            be.ops._conv3d_wgrad = orig
+        assert calls == [(1, 3, 3) if on else (3, 3, 1)], calls
+        ref = w.grad.permute(0, 2, 3, 4, 1).reshape(Cout, -1)
+        assert _rel(dw.cpu(), ref) < 6e-4
+        assert _rel(db.cpu(), dy.sum((0, 2, 3, 4))) < 1e-5
+    finally:
+        be.ops.wgrad_2d_as_g8 = saved
+
+
 @pytest.mark.parametrize("case", [(2, (8, 8, 4), 64, 32, (3, 3, 3), 2, 1), (1, (16, 16, 8), 32, 64, (3, 3, 3), 2, 1),
                                   (1, (8, 6, 4), 64, 128, (1, 1, 1), 2, 1)])
 def test_strided_dgrad_split_k(be, case, monkeypatch):
